@@ -1,0 +1,140 @@
+/*
+ * ptref.h -- public interface of the CPU ORACLE ("ptref").
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library. The product path (pathtrace-rs_amd/) never includes,
+ * links or calls anything in oracle/.
+ *
+ * ptref is a plain-C restatement of the reference's (bitshifter/pathtrace-rs
+ * 0.1.2) hot path: Scene::update -> ray_trace -> Hitable::ray_hit ->
+ * Material::scatter, plus the host-side scene construction needed to feed it
+ * (Storage::new / presets / Params::new_scene / Camera::new). Every function
+ * in ptref.c cites the reference file:line it follows.
+ *
+ * PARITY STATUS: "parity unpinned" against the Rust binary. The reference
+ * ships no tests, no golden vectors and cannot be built here (no Rust
+ * toolchain, no vendored crates). The oracle is pinned only to
+ *   (1) the public xoshiro256+ / SplitMix64 known-answer vectors, and
+ *   (2) the survey-side derived fixtures in tests/golden/ (SURVEY.md 8c).
+ * Un-vendored third-party arithmetic (rand 0.8.5, rand_xoshiro 0.6.0,
+ * glam 0.20.5) is restated from the crates' published algorithms; the
+ * assumptions are listed at the top of ptref.c.
+ */
+#ifndef PTREF_H
+#define PTREF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ora_scene ora_scene;
+
+/* ---- scene construction (offline.rs:16-24) ------------------------------
+ * rng = Params::new_rng (seed 0) -> Storage::new(rng) -> presets::from_name
+ * -> Params::new_scene (List, or BVH when use_bvh). Returns NULL when the
+ * preset name is unknown (presets.rs:36). */
+ora_scene *ora_scene_from_preset(const char *name, uint32_t width,
+                                 uint32_t height, int use_bvh);
+void ora_scene_free(ora_scene *s);
+
+/* ---- Scene::update (scene.rs:73-121) ------------------------------------
+ * buffer: width*height*3 floats, row 0 = bottom row, read AND written
+ * (frame blend). Returns the ray count. nthreads<=0 -> all online cores. */
+uint64_t ora_scene_update(const ora_scene *s, uint32_t width, uint32_t height,
+                          uint32_t samples, uint32_t max_depth,
+                          uint32_t frame_num, float *buffer, int nthreads);
+
+/* Same, restricted to pixel indices [pix_begin, pix_end) of the full frame
+ * (buffer is still the full-frame buffer; other pixels are untouched). Lets
+ * tests and the bounded cpu_baseline sample check full-size configs. */
+uint64_t ora_scene_update_range(const ora_scene *s, uint32_t width,
+                                uint32_t height, uint32_t samples,
+                                uint32_t max_depth, uint32_t frame_num,
+                                float *buffer, uint64_t pix_begin,
+                                uint64_t pix_end, int nthreads);
+
+/* Same, for an explicit list of pixel indices. */
+uint64_t ora_scene_update_pixels(const ora_scene *s, uint32_t width,
+                                 uint32_t height, uint32_t samples,
+                                 uint32_t max_depth, uint32_t frame_num,
+                                 float *buffer, const uint32_t *pixels,
+                                 uint64_t n_pixels, int nthreads);
+
+/* ---- flat export of the built scene (for cross-checks / feeding the
+ *      product through its C ABI in tests) -------------------------------- */
+uint32_t ora_scene_num_spheres(const ora_scene *s);
+uint32_t ora_scene_num_materials(const ora_scene *s);
+uint32_t ora_scene_num_textures(const ora_scene *s);
+uint32_t ora_scene_num_bvh_nodes(const ora_scene *s);
+int32_t ora_scene_bvh_root(const ora_scene *s);   /* -1 when list mode */
+int ora_scene_has_perlin_texture(const ora_scene *s);
+uint64_t ora_scene_build_draws(const ora_scene *s); /* scene-build RNG ledger */
+/* spheres: n*4 floats (cx,cy,cz,radius) in list order; material: n ids */
+void ora_scene_export_spheres(const ora_scene *s, float *xyzr,
+                              uint32_t *material_id);
+/* materials: n rows of 6 floats: kind, a0,a1,a2, param(fuzz|ref_idx), texture_id(-1 none)
+ * kinds: 0 lambertian 1 metal 2 dielectric 3 diffuse_light */
+void ora_scene_export_materials(const ora_scene *s, float *rows6);
+/* textures: n rows of 7 floats: kind, c0,c1,c2, odd_id, even_id, scale
+ * kinds: 0 constant 1 checker 2 noise */
+void ora_scene_export_textures(const ora_scene *s, float *rows7);
+/* perlin: randvec 256*3 floats, perm_x/y/z 256 u32 each */
+void ora_scene_export_perlin(const ora_scene *s, float *randvec,
+                             uint32_t *perm_x, uint32_t *perm_y,
+                             uint32_t *perm_z);
+/* bvh nodes: n rows of 8: min3,max3 as floats then lhs,rhs as int32 bit
+ * patterns (child >= 0: node index; child < 0: ~sphere_index) */
+void ora_scene_export_bvh(const ora_scene *s, float *minmax6, int32_t *lhs_rhs2);
+/* camera: 24 floats in camera.rs:8-19 field order */
+void ora_scene_export_camera(const ora_scene *s, float *cam24);
+/* sky: returns has_sky; rgb filled when set */
+int ora_scene_export_sky(const ora_scene *s, float *rgb3);
+
+/* ---- unit-level probes for known-answer tests --------------------------- */
+void ora_splitmix64(uint64_t seed, uint64_t *out, int n);
+void ora_xoshiro_seed_from_u64(uint64_t seed, uint64_t state[4]);
+uint64_t ora_xoshiro_next_u64(uint64_t state[4]);
+float ora_xoshiro_gen_f32(uint64_t state[4]);
+int32_t ora_xoshiro_gen_range_i32(uint64_t state[4], int32_t low, int32_t high);
+uint64_t ora_pixel_seed(uint32_t x, uint32_t y, uint32_t frame_num);
+void ora_sinf_cosf(float x, float *s, float *c);
+/* Sphere::ray_hit: returns 1 on hit; out9 = point3, normal3, t, u, v */
+int ora_sphere_ray_hit(const float centre_radius[4], const float origin[3],
+                       const float direction[3], float t_min, float t_max,
+                       float out9[9]);
+int ora_aabb_ray_hit(const float min3[3], const float max3[3],
+                     const float origin[3], const float direction[3],
+                     float t_min, float t_max);
+float ora_schlick(float cosine, float ref_idx);
+void ora_random_unit_vector(uint64_t state[4], float out3[3]);
+void ora_random_in_unit_sphere(uint64_t state[4], float out3[3]);
+void ora_random_in_unit_disk(uint64_t state[4], float out3[3]);
+/* Camera::get_ray: out7 = origin3, direction3, time */
+void ora_camera_get_ray(const float cam24[24], float s, float t,
+                        uint64_t state[4], float out7[7]);
+void ora_camera_new(const float lookfrom[3], const float lookat[3],
+                    const float vup[3], float vfov, float aspect,
+                    float aperture, float focus_dist, float time0, float time1,
+                    float cam24[24]);
+float ora_perlin_noise(const ora_scene *s, const float p[3]);
+float ora_perlin_turb(const ora_scene *s, const float p[3]);
+/* Texture::value for texture id */
+void ora_texture_value(const ora_scene *s, uint32_t texture_id,
+                       const float p[3], float rgb[3]);
+/* Scene::ray_trace on one explicit ray; returns colour, adds to *ray_count */
+void ora_ray_trace(const ora_scene *s, const float origin[3],
+                   const float direction[3], float time, uint32_t max_depth,
+                   uint64_t state[4], float rgb[3], uint64_t *ray_count);
+/* math.rs:36-48 */
+void ora_linear_to_srgb(const float rgb[3], uint8_t out[3]);
+/* offline.rs:43-51: full frame -> top-down RGB8 */
+void ora_frame_to_srgb8(const float *buffer, uint32_t width, uint32_t height,
+                        uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
