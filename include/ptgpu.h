@@ -1,0 +1,182 @@
+/*
+ * ptgpu.h -- C ABI of the MI355X-native path-tracing hot path (libptgpu.so).
+ *
+ * This is the drop-in boundary for ONE path of bitshifter/pathtrace-rs 0.1.2:
+ *     Scene::update(&self, &Params, &Camera, frame_num, &mut [(f32,f32,f32)]) -> usize
+ *                                                     (reference src/scene.rs:73-121)
+ * and everything it calls (ray_trace scene.rs:49-71, Hitable::ray_hit
+ * collision/hitable.rs:39-65, Material::scatter material.rs:138-159,
+ * Texture::value texture.rs:74-91, Camera::get_ray camera.rs:56-68).
+ *
+ * The reference has no FFI / plugin layer; a Rust host would bind these entry
+ * points with `extern "C"` inside Scene::new / Scene::update (binding shown in
+ * INTEGRATION.md). Plain pointers and sizes only; no C++ or torch types.
+ * All functions return PT_OK (0) or a PT_ERR_* code and never throw or abort;
+ * pt_last_error() returns a thread-local message for the last failure.
+ *
+ * Threading: thread-compatible. One in-flight render per pt_scene handle
+ * (same contract as Scene::update(&self) being called from one thread,
+ * offline.rs:29 / glium_window.rs:102). Distinct handles may be used from
+ * distinct threads.
+ */
+#ifndef PTGPU_H
+#define PTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_ERR_INVALID_ARG 1  /* NULL pointer, zero size, bad index in the scene description */
+#define PT_ERR_HIP 2          /* a HIP runtime call failed (message carries hipGetErrorString) */
+#define PT_ERR_NO_DEVICE 3    /* no gfx950 device / HIP runtime unavailable */
+#define PT_ERR_UNSUPPORTED 4  /* e.g. use_bvh requested on a scene created without BVH nodes */
+
+/* params.rs:11-18 `Params` (bools widened to u32) */
+typedef struct pt_params {
+    uint32_t width;
+    uint32_t height;
+    uint32_t samples;
+    uint32_t max_depth;
+    uint32_t random_seed; /* != 0: per-pixel seeds derive from pt_scene_set_seed_base (no parity claim) */
+    uint32_t use_bvh;     /* != 0: BVHNode::ray_hit traversal (bvh.rs:37-62); 0: HitableList scan (hitable_list.rs:40-56) */
+} pt_params;
+
+/* camera.rs:8-19 `Camera`: 24 floats in declaration order */
+typedef struct pt_camera {
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3];
+    float v[3];
+    float w[3];
+    float time0;
+    float time1;
+    float lens_radius;
+} pt_camera;
+
+/* collision/sphere.rs:8-11 `Sphere` (radius is signed: presets.rs:265 uses -0.45) */
+typedef struct pt_sphere {
+    float cx, cy, cz, radius;
+} pt_sphere;
+
+/* material.rs:13-19 `Material` (Isotropic is out of scope: only cornell_smoke uses it) */
+enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3 };
+typedef struct pt_material {
+    uint32_t kind;
+    float albedo[3]; /* Metal albedo */
+    float param;     /* Metal fuzz | Dielectric ref_idx */
+    int32_t texture; /* Lambertian albedo / DiffuseLight emit texture index, else -1 */
+} pt_material;
+
+/* texture.rs:40-55 `Texture` (Image is out of scope: needs media/earthmap.jpg) */
+enum { PT_TEX_CONSTANT = 0, PT_TEX_CHECKER = 1, PT_TEX_NOISE = 2 };
+typedef struct pt_texture {
+    uint32_t kind;
+    float color[3]; /* Constant */
+    int32_t odd;    /* Checker: texture indices (may nest) */
+    int32_t even;
+    float scale;    /* Noise */
+} pt_texture;
+
+/* perlin.rs:7-12 `Perlin` */
+typedef struct pt_perlin {
+    float randvec[256][3];
+    uint32_t perm_x[256];
+    uint32_t perm_y[256];
+    uint32_t perm_z[256];
+} pt_perlin;
+
+/* collision/bvh.rs:24-28 `BVHNode`, flattened: child >= 0 is a node index,
+ * child < 0 is ~sphere_index (a Hitable::Sphere leaf). */
+typedef struct pt_bvh_node {
+    float min[3];
+    float max[3];
+    int32_t lhs;
+    int32_t rhs;
+} pt_bvh_node;
+
+/* The Scene (scene.rs:18-22) as flat PODs: `world` (List order = sphere
+ * order; optional BVH over the same spheres) + `sky`. */
+typedef struct pt_scene_desc {
+    uint32_t n_spheres;
+    const pt_sphere *spheres;        /* n_spheres, in HitableList order */
+    const uint32_t *sphere_material; /* n_spheres material indices */
+    uint32_t n_materials;
+    const pt_material *materials;
+    uint32_t n_textures;
+    const pt_texture *textures;
+    const pt_perlin *perlin;         /* NULL unless a Noise texture exists */
+    uint32_t n_bvh_nodes;            /* 0: list only */
+    const pt_bvh_node *bvh_nodes;
+    int32_t bvh_root;                /* node index of the root, -1 when no BVH */
+    uint32_t has_sky;                /* scene.rs:20 Option<Vec3> */
+    float sky[3];
+} pt_scene_desc;
+
+typedef struct pt_scene pt_scene;
+
+/* Number of visible HIP devices. */
+int pt_device_count(int *count_out);
+
+/* Scene::new (scene.rs:25-31): validates and uploads the scene to `device`
+ * (HBM-resident SoA). The description is copied; the caller
+ * may free it afterwards. */
+int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene **scene_out);
+void pt_scene_destroy(pt_scene *scene);
+
+/* Scene::update (scene.rs:73-121) with a HOST pixel buffer, exactly the
+ * reference's contract: rgb_inout is width*height*3 floats (row 0 = bottom
+ * row, offline.rs:44), READ (frame blend scene.rs:114-116) and written;
+ * *ray_count_out receives the number of ray_trace invocations. Synchronous. */
+int pt_render(pt_scene *scene, const pt_params *params, const pt_camera *camera,
+              uint32_t frame_num, float *rgb_inout, uint64_t *ray_count_out);
+
+/* Same with a DEVICE-resident buffer on `hip_stream` (hipStream_t, NULL =
+ * default stream); asynchronous. d_ray_count (device, 8 bytes) is overwritten
+ * with this call's ray count. The accumulation buffer stays in HBM across
+ * frames (progressive mode, glium_window.rs:94-133). */
+int pt_render_device(pt_scene *scene, const pt_params *params, const pt_camera *camera,
+                     uint32_t frame_num, float *d_rgb_inout, uint64_t *d_ray_count,
+                     void *hip_stream);
+
+/* Multi-GPU shard of Scene::update: renders only the rows y of the frame with
+ * y % shard_count == shard_index into a COMPACT device buffer of
+ * pt_shard_rows() * width * 3 floats (local row j <-> frame row
+ * j*shard_count + shard_index). Seeds depend only on (x, y, frame)
+ * (scene.rs:99-101), so the union of shards is bit-identical to the full
+ * frame. No data-path collective happens here; the caller gathers. */
+int pt_render_shard_device(pt_scene *scene, const pt_params *params, const pt_camera *camera,
+                           uint32_t frame_num, uint32_t shard_index, uint32_t shard_count,
+                           float *d_rgb_shard_inout, uint64_t *d_ray_count, void *hip_stream);
+uint32_t pt_shard_rows(uint32_t height, uint32_t shard_index, uint32_t shard_count);
+
+/* Base seed used when params->random_seed != 0 (scene.rs:96-97 uses
+ * rand::random(), i.e. non-reproducible by design). */
+int pt_scene_set_seed_base(pt_scene *scene, uint64_t seed_base);
+
+/* Duration in ms of the trace kernel of the most recent render on this
+ * handle, measured with HIP events on the launch stream (synchronises on the
+ * stop event). Also the launch geometry, for roofline bookkeeping. */
+int pt_last_kernel_ms(pt_scene *scene, float *ms_out);
+int pt_last_launch_info(pt_scene *scene, uint32_t *grid_out, uint32_t *block_out,
+                        uint32_t *lds_bytes_out);
+
+/* Tuning knobs (0 = library default): waves resident per CU for the
+ * persistent grid, and kernel variant ("kernel variants"). */
+int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
+
+/* Thread-local message describing the last error returned on this thread. */
+const char *pt_last_error(void);
+
+/* Library / kernel identification string, e.g. "ptgpu 0.1 gfx950". */
+const char *pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTGPU_H */

@@ -1,0 +1,205 @@
+// pt_device.h -- device-side arithmetic of the path-tracing hot path (gfx950).
+//
+// Every function states the reference file:line whose arithmetic it must
+// reproduce. The rule for this file: anything that feeds CONTROL FLOW (hit /
+// miss, t, normal, scatter direction, Schlick probability, RNG draws) is written
+// with the reference's exact operation order, separate mul and add (the TU is
+// compiled with -ffp-contract=off; Rust never fuses), IEEE division and sqrt
+// (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt), no fast-math.
+// Colour-only values (texture colours, attenuation folding) follow the same
+// order as well, so list/BVH scenes without libm calls are bit-exact.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ptdev {
+
+constexpr float kMaxT = 3.40282346638528859812e+38f;  // scene.rs:15 f32::MAX
+constexpr float kMinT = 0.001f;                       // scene.rs:16
+constexpr float kPi = 3.14159274101257324f;           // f32::consts::PI
+
+struct f3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 add3(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 mul3(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ f3 scale3(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 divs3(f3 a, float s) { return f3{a.x / s, a.y / s, a.z / s}; }
+__device__ __forceinline__ f3 neg3(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+// glam Vec3::dot: (x*x' + y*y') + z*z'
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ float length3(f3 a) { return sqrtf(dot3(a, a)); }
+// glam 0.20 scalar Vec3::normalize: v * (1.0 / length)
+__device__ __forceinline__ f3 normalize3(f3 a) { return scale3(a, 1.0f / length3(a)); }
+
+// ---- RNG: rand_xoshiro 0.6 Xoshiro256Plus seeded through SplitMix64 -------
+// call sites: scene.rs:96-102 (per-pixel seed), every rng.gen::<f32>()
+struct Rng {
+    uint64_t s0, s1, s2, s3;
+};
+
+__device__ __forceinline__ uint64_t splitmix64_next(uint64_t &x) {
+    x += 0x9e3779b97f4a7c15ULL;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ void rng_seed_from_u64(Rng &r, uint64_t seed) {
+    uint64_t x = seed;
+    r.s0 = splitmix64_next(x);
+    r.s1 = splitmix64_next(x);
+    r.s2 = splitmix64_next(x);
+    r.s3 = splitmix64_next(x);
+}
+
+__device__ __forceinline__ uint64_t rng_next_u64(Rng &r) {
+    const uint64_t result = r.s0 + r.s3;
+    const uint64_t t = r.s1 << 17;
+    r.s2 ^= r.s0;
+    r.s3 ^= r.s1;
+    r.s1 ^= r.s2;
+    r.s0 ^= r.s3;
+    r.s2 ^= t;
+    r.s3 = (r.s3 << 45) | (r.s3 >> 19);
+    return result;
+}
+
+// rand 0.8 Standard f32: (next_u32 >> 8) * 2^-24, next_u32 = next_u64 >> 32
+__device__ __forceinline__ float rng_f32(Rng &r) {
+    const uint32_t v = (uint32_t)(rng_next_u64(r) >> 40);
+    return (1.0f / 16777216.0f) * (float)v;
+}
+
+// ---- simd.rs:107-208 sinf_cosf (Cephes polynomial, lane 0 of the SSE2 code)
+__device__ __forceinline__ void sinf_cosf_ref(float xin, float &sin_out, float &cos_out) {
+    uint32_t sign_bit_sin = __float_as_uint(xin) & 0x80000000u;
+    float x = __uint_as_float(__float_as_uint(xin) & 0x7fffffffu);
+    float y = x * 1.27323954473516f;  // simd.rs:128
+    int emm2 = (int)y;                // cvttps: truncate
+    emm2 = (emm2 + 1) & ~1;           // simd.rs:134-135
+    y = (float)emm2;
+    int emm4 = emm2;
+    const uint32_t swap_sign_bit_sin = ((uint32_t)(emm2 & 4)) << 29;
+    const uint32_t poly_mask = ((emm2 & 2) == 0) ? 0xffffffffu : 0u;
+    float xmm1 = y * -0.78515625f;  // simd.rs:152-160
+    float xmm2 = y * -2.4187564849853515625e-4f;
+    float xmm3 = y * -3.77489497744594108e-8f;
+    x = x + xmm1;
+    x = x + xmm2;
+    x = x + xmm3;
+    emm4 = emm4 - 2;
+    const uint32_t sign_bit_cos = ((~(uint32_t)emm4) & 4u) << 29;
+    sign_bit_sin ^= swap_sign_bit_sin;
+    const float z = x * x;
+    y = 2.443315711809948E-005f;  // simd.rs:170-181
+    y = y * z;
+    y = y + -1.388731625493765E-003f;
+    y = y * z;
+    y = y + 4.166664568298827E-002f;
+    y = y * z;
+    y = y * z;
+    const float tmp = z * 0.5f;
+    y = y - tmp;
+    y = y + 1.0f;
+    float y2 = -1.9515295891E-4f;  // simd.rs:184-191
+    y2 = y2 * z;
+    y2 = y2 + 8.3321608736E-3f;
+    y2 = y2 * z;
+    y2 = y2 + -1.6666654611E-1f;
+    y2 = y2 * z;
+    y2 = y2 * x;
+    y2 = y2 + x;
+    const float ysin2 = __uint_as_float(poly_mask & __float_as_uint(y2));  // simd.rs:194-201
+    const float ysin1 = __uint_as_float(~poly_mask & __float_as_uint(y));
+    y2 = y2 - ysin2;
+    y = y - ysin1;
+    const float s = ysin1 + ysin2;
+    const float c = y + y2;
+    sin_out = __uint_as_float(__float_as_uint(s) ^ sign_bit_sin);
+    cos_out = __uint_as_float(__float_as_uint(c) ^ sign_bit_cos);
+}
+
+// ---- math.rs:6-34 sampling -------------------------------------------------
+// math.rs:6-13 (runs even when lens_radius == 0; 2 draws per iteration)
+__device__ __forceinline__ void random_in_unit_disk(Rng &rng, float &px, float &py) {
+    for (;;) {
+        const float a = rng_f32(rng);
+        const float b = rng_f32(rng);
+        const float x = a * 2.0f - 1.0f;
+        const float y = b * 2.0f - 1.0f;
+        // p.dot(p) with z = 0*2 - 0 = 0: (x*x + y*y) + 0*0
+        if (((x * x + y * y) + 0.0f) < 1.0f) {
+            px = x;
+            py = y;
+            return;
+        }
+    }
+}
+
+// math.rs:15-26
+__device__ __forceinline__ f3 random_in_unit_sphere(Rng &rng) {
+    for (;;) {
+        const float a = 2.0f * rng_f32(rng) - 1.0f;
+        const float b = 2.0f * rng_f32(rng) - 1.0f;
+        const float c = 2.0f * rng_f32(rng) - 1.0f;
+        const f3 p = mk3(a, b, c);
+        if (dot3(p, p) < 1.0f) return p;
+    }
+}
+
+// math.rs:28-34
+__device__ __forceinline__ f3 random_unit_vector(Rng &rng) {
+    const float z = rng_f32(rng) * 2.0f - 1.0f;
+    const float a = rng_f32(rng) * 2.0f * kPi;
+    const float r = sqrtf(1.0f - z * z);
+    float sina, cosa;
+    sinf_cosf_ref(a, sina, cosa);
+    return mk3(r * cosa, r * sina, z);
+}
+
+// math.rs:61-63
+__device__ __forceinline__ f3 reflect3(f3 v, f3 n) { return sub3(v, scale3(n, 2.0f * dot3(v, n))); }
+
+// math.rs:65-73
+__device__ __forceinline__ bool refract3(f3 v, f3 n, float ni_over_nt, f3 &out) {
+    const float dt = dot3(v, n);
+    const float discriminant = 1.0f - (ni_over_nt * ni_over_nt) * (1.0f - (dt * dt));
+    if (discriminant > 0.0f) {
+        out = sub3(scale3(sub3(v, scale3(n, dt)), ni_over_nt), scale3(n, sqrtf(discriminant)));
+        return true;
+    }
+    return false;
+}
+
+// math.rs:76-80. powf(x, 5.0) is the one control-affecting libm call
+// (material.rs:108-109). glibc's powf is not correctly rounded (<= 0.82 ULP)
+// and even differs between its own FMA / non-FMA ifunc variants, so it cannot
+// be matched bit-for-bit; we evaluate x^5 in binary64 (relative error < 2^-51)
+// and round once, i.e. the correctly rounded result except for astronomically
+// rare double-rounding ties. tests/test_gpu_parity.py measures the mismatch
+// rate against the host powf.
+__device__ __forceinline__ float pow5_ref(float x) {
+    const double xd = (double)x;
+    const double x2 = xd * xd;
+    return (float)(x2 * x2 * xd);
+}
+
+__device__ __forceinline__ float schlick_ref(float cosine, float ref_idx) {
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * pow5_ref(1.0f - cosine);
+}
+
+// Rust `f32 as usize` (saturating, NaN -> 0) followed by `& 255`
+__device__ __forceinline__ uint32_t floor_as_usize_low8(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 18446744073709551616.0f) return 255u;
+    return (uint32_t)((unsigned long long)f) & 255u;
+}
+
+}  // namespace ptdev

@@ -1,0 +1,442 @@
+// pt_kernel.h -- persistent-threads path-tracing kernel for gfx950 (MI355X).
+//
+// One pixel per lane; every lane owns its pixel's xoshiro256+ stream
+// (scene.rs:96-102) and walks samples and bounces iteratively. When a path
+// terminates the lane regenerates the next camera ray in place; when the
+// pixel's samples are exhausted the lane pulls the next pixel from a global
+// work counter (one wave-aggregated atomic per refill). The sphere scan is
+// wave-uniform: all 64 lanes test their own ray against the same sphere,
+// whose centre/r^2 are broadcast from LDS.
+#pragma once
+#include "pt_device.h"
+#include "ptgpu.h"
+
+namespace ptdev {
+
+constexpr int kBlock = 256;      // 4 waves: one per SIMD of a CU
+constexpr int kBvhStack = 32;    // per-lane traversal stack entries (LDS)
+
+struct DMat {  // 32 B
+    uint32_t kind;
+    float a0, a1, a2;
+    float param;
+    int32_t tex;
+    float pad0, pad1;
+};
+struct DTex {  // 32 B
+    uint32_t kind;
+    float c0, c1, c2;
+    int32_t odd, even;
+    float scale;
+    float pad;
+};
+struct DNode {  // 32 B, collision/bvh.rs:24-28 flattened
+    float minx, miny, minz, maxx, maxy, maxz;
+    int32_t lhs, rhs;
+};
+
+struct DCamera {  // camera.rs:8-19
+    f3 origin, lower_left_corner, horizontal, vertical, u, v, w;
+    float time0, time1, lens_radius;
+};
+
+struct KArgs {
+    // scene (HBM resident)
+    const float4 *spheres;       // cx, cy, cz, radius
+    const float4 *spheres_r2;    // cx, cy, cz, radius*radius (sphere.rs:36), scan layout
+    const uint32_t *sphere_mat;  // material index per sphere
+    const DMat *mats;
+    const DTex *texs;
+    const float4 *perlin_vec;    // 256 gradients (xyz, pad)
+    const uint32_t *perlin_perm; // 768 entries: perm_x | perm_y | perm_z
+    const DNode *nodes;
+    uint32_t n_spheres;
+    int32_t bvh_root;
+    uint32_t has_sky;
+    f3 sky;
+    uint32_t has_noise;
+    // frame
+    DCamera cam;
+    uint32_t width, height, samples, max_depth, frame_num;
+    float inv_nx, inv_ny, inv_ns, mix_prev, mix_new;  // scene.rs:82-87 (computed on the host in f32)
+    uint32_t random_seed;
+    uint64_t seed_base;
+    // sharding: rows y with y % shard_count == shard_index, compact buffer
+    uint32_t shard_index, shard_count, local_rows;
+    uint32_t tiles_x, n_items;  // 8x8 tiles over (width x local_rows); n_items = tiles * 64
+    // outputs / work queue
+    float *rgb;
+    unsigned long long *ray_count;
+    uint32_t *work_counter;
+    float *gstack;  // global path-stack fallback when max_depth*3*kBlock*4 exceeds the LDS budget
+    uint32_t stack_in_lds;
+    uint32_t lds_sphere_bytes;  // offsets of the dynamic LDS carve
+};
+
+// ---- perlin.rs:54-111 -------------------------------------------------------
+struct PerlinLds {
+    const float4 *vec;       // 256 x float4
+    const uint32_t *perm;    // 768
+};
+
+__device__ __noinline__ float perlin_noise(const PerlinLds &pn, f3 p) {
+    const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const uint32_t i = floor_as_usize_low8(fx), j = floor_as_usize_low8(fy), k = floor_as_usize_low8(fz);
+    const float uu = u * u * (3.0f - 2.0f * u);
+    const float vv = v * v * (3.0f - 2.0f * v);
+    const float ww = w * w * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; ++di) {
+        const float ii = (float)di;
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+            const float jj = (float)dj;
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                const float kk = (float)dk;
+                const uint32_t idx = pn.perm[(i + di) & 255] ^ pn.perm[256 + ((j + dj) & 255)] ^
+                                     pn.perm[512 + ((k + dk) & 255)];
+                const float4 g = pn.vec[idx];
+                const f3 weight = mk3(u - ii, v - jj, w - kk);
+                accum += (ii * uu + (1.0f - ii) * (1.0f - uu)) * (jj * vv + (1.0f - jj) * (1.0f - vv)) *
+                         (kk * ww + (1.0f - kk) * (1.0f - ww)) * dot3(mk3(g.x, g.y, g.z), weight);
+            }
+        }
+    }
+    return accum;
+}
+
+// perlin.rs:76-87
+__device__ __forceinline__ float perlin_turb(const PerlinLds &pn, f3 p) {
+    float accum = 0.0f;
+    f3 temp_p = p;
+    float weight = 1.0f;
+    for (int d = 0; d < 7; ++d) {
+        accum += weight * perlin_noise(pn, temp_p);
+        weight *= 0.5f;
+        temp_p = scale3(temp_p, 2.0f);
+    }
+    return fabsf(accum);
+}
+
+// texture.rs:74-91 (Constant / Checker / Noise; Checker may nest)
+__device__ __noinline__ f3 texture_value(const DTex *texs, const PerlinLds &pn, int32_t tex, f3 p) {
+    DTex t = texs[tex];
+    while (t.kind == PT_TEX_CHECKER) {
+        const f3 s = mk3(10.0f * p.x, 10.0f * p.y, 10.0f * p.z);
+        const float sines = sinf(s.x) * sinf(s.y) * sinf(s.z);
+        t = texs[(sines < 0.0f) ? t.odd : t.even];
+    }
+    if (t.kind == PT_TEX_NOISE) {
+        const float v = 1.0f + sinf(t.scale * p.z + 10.0f * perlin_turb(pn, p));
+        return mk3(0.5f * v, 0.5f * v, 0.5f * v);  // vec3(1,1,1) * 0.5 * (1 + sin(..))
+    }
+    return mk3(t.c0, t.c1, t.c2);
+}
+
+// ---- sphere.rs:29-66 exact slow path for one sphere ---------------------------
+// Returns true and narrows `closest` when the sphere is hit in (kMinT, closest).
+__device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float &closest) {
+    const float sq = sqrtf(disc);
+    float t = (-b - sq) / a;
+    if (t < closest && t > kMinT) {
+        closest = t;
+        return true;
+    }
+    t = (-b + sq) / a;
+    if (t < closest && t > kMinT) {
+        closest = t;
+        return true;
+    }
+    return false;
+}
+
+// hitable_list.rs:40-56 over sphere.rs:29-66: wave-uniform scan, sphere data
+// broadcast from LDS (s_sph[k] = cx, cy, cz, r*r).
+__device__ __forceinline__ int intersect_list(const float4 *s_sph, int n, f3 o, f3 d, float a, float &t_out) {
+    float closest = kMaxT;
+    int idx = -1;
+    for (int k = 0; k < n; ++k) {
+        const float4 c = s_sph[k];
+        const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
+        const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
+        const float disc = b * b - a * cc;
+        if (disc > 0.0f) {
+            if (sphere_roots(a, b, disc, closest)) idx = k;
+        }
+    }
+    t_out = closest;
+    return idx;
+}
+
+// aabb.rs:46-58 with the SSE min/max NaN rule (second operand on NaN)
+__device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ bool aabb_hit(const DNode &n, f3 o, f3 rcp, float tmin, float tmax) {
+    const float mnx = (n.minx - o.x) * rcp.x, mny = (n.miny - o.y) * rcp.y, mnz = (n.minz - o.z) * rcp.z;
+    const float mxx = (n.maxx - o.x) * rcp.x, mxy = (n.maxy - o.y) * rcp.y, mxz = (n.maxz - o.z) * rcp.z;
+    const float t0x = sse_min(mnx, mxx), t0y = sse_min(mny, mxy), t0z = sse_min(mnz, mxz);
+    const float t1x = sse_max(mnx, mxx), t1y = sse_max(mny, mxy), t1z = sse_max(mnz, mxz);
+    const float lox = sse_max(t0x, tmin), loy = sse_max(t0y, tmin), loz = sse_max(t0z, tmin);
+    const float hix = sse_min(t1x, tmax), hiy = sse_min(t1y, tmax), hiz = sse_min(t1z, tmax);
+    return (hix > lox) && (hiy > loy) && (hiz > loz);
+}
+
+// bvh.rs:37-62: both children are visited with the ORIGINAL t_max and the
+// smaller t wins, rhs on ties. Iterative DFS (lhs before rhs) with an explicit
+// per-lane stack in LDS; a candidate replaces the best when t <= best, which is
+// the same winner as the recursion's pairwise (lhs.t < rhs.t ? lhs : rhs).
+__device__ __forceinline__ int intersect_bvh(const KArgs &A, uint32_t *s_stack /* [kBvhStack][kBlock] */, f3 o, f3 d,
+                                             float a, bool active, float &t_out) {
+    const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // ray.rs:14
+    const int tid = threadIdx.x;
+    int sp = 0;
+    float best = kMaxT;
+    int idx = -1;
+    bool have = false;
+    if (active) s_stack[(sp++) * kBlock + tid] = (uint32_t)A.bvh_root;
+    while (sp > 0) {
+        const int32_t ref = (int32_t)s_stack[(--sp) * kBlock + tid];
+        if (ref >= 0) {
+            const DNode n = A.nodes[ref];
+            if (aabb_hit(n, o, rcp, kMinT, kMaxT)) {
+                if (sp + 2 <= kBvhStack) {
+                    s_stack[(sp++) * kBlock + tid] = (uint32_t)n.rhs;
+                    s_stack[(sp++) * kBlock + tid] = (uint32_t)n.lhs;
+                }
+            }
+        } else {
+            const int k = ~ref;
+            const float4 c = A.spheres[k];
+            const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
+            const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+            const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
+            const float disc = b * b - a * cc;
+            if (disc > 0.0f) {
+                float t = kMaxT;
+                if (sphere_roots(a, b, disc, t)) {
+                    if (!have || t <= best) {
+                        best = t;
+                        idx = k;
+                        have = true;
+                    }
+                }
+            }
+        }
+    }
+    t_out = best;
+    return idx;
+}
+
+// SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
+// (staged once per workgroup); otherwise from HBM/L2 through wave-uniform loads.
+template <bool BVH, bool SPH_LDS>
+__global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS carve (all offsets multiples of 16)
+    float4 *s_sph = reinterpret_cast<float4 *>(smem);  // list mode: n_spheres x (cx,cy,cz,r^2)
+    unsigned char *p = smem + A.lds_sphere_bytes;
+    float4 *s_pvec = reinterpret_cast<float4 *>(p);     // perlin gradients (4 KB) when has_noise
+    uint32_t *s_perm = reinterpret_cast<uint32_t *>(p + (A.has_noise ? 4096 : 0));
+    p += A.has_noise ? (4096 + 3072) : 0;
+    uint32_t *s_bvh = reinterpret_cast<uint32_t *>(p);
+    p += BVH ? (kBvhStack * kBlock * 4) : 0;
+    float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][kBlock] attenuation stack
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+
+    if (!BVH && SPH_LDS) {
+        for (uint32_t k = tid; k < A.n_spheres; k += kBlock) s_sph[k] = A.spheres_r2[k];
+    }
+    if (A.has_noise) {
+        for (int k = tid; k < 256; k += kBlock) s_pvec[k] = A.perlin_vec[k];
+        for (int k = tid; k < 768; k += kBlock) s_perm[k] = A.perlin_perm[k];
+    }
+    __syncthreads();
+
+    PerlinLds pn{s_pvec, s_perm};
+    float *path = A.stack_in_lds ? (s_path + tid)
+                                 : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * kBlock + tid);
+
+    bool have = false, exhausted = false, need_cam = true;
+    uint32_t px = 0, py = 0, boff = 0, sample = 0, depth = 0, nrays = 0;
+    Rng rng{0, 0, 0, 0};
+    f3 col = mk3(0.f, 0.f, 0.f), o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
+
+    for (;;) {
+        // ---- refill: one wave-aggregated atomic for all lanes that need a pixel
+        if (!have && !exhausted) {
+            const unsigned long long m = __ballot(1);
+            const int leader = __ffsll((long long)m) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(A.work_counter, (uint32_t)__popcll(m));
+            base = __shfl(base, leader);
+            const uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (item >= A.n_items) {
+                exhausted = true;
+            } else {
+                const uint32_t tile = item >> 6, in = item & 63u;
+                const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
+                const uint32_t ly = (tile / A.tiles_x) * 8u + (in >> 3);
+                if (x < A.width && ly < A.local_rows) {
+                    have = true;
+                    px = x;
+                    py = ly * A.shard_count + A.shard_index;
+                    boff = (ly * A.width + x) * 3u;
+                    sample = 0;
+                    need_cam = true;
+                    col = mk3(0.f, 0.f, 0.f);
+                    // scene.rs:96-102
+                    uint64_t seed = ((uint64_t)px * 1973ull + (uint64_t)py * 9277ull + (uint64_t)A.frame_num * 26699ull) | 1ull;
+                    if (A.random_seed) {
+                        uint64_t h = A.seed_base ^ (seed * 0x9e3779b97f4a7c15ULL);
+                        seed = splitmix64_next(h);
+                    }
+                    rng_seed_from_u64(rng, seed);
+                }
+            }
+        }
+        if (__ballot(have) == 0ull) {
+            if (__ballot(!exhausted) == 0ull) break;
+            continue;
+        }
+
+        // ---- camera.rs:56-68 + scene.rs:107-108: start the next sample
+        if (have && need_cam) {
+            const float u = ((float)px + rng_f32(rng)) * A.inv_nx;
+            const float v = ((float)py + rng_f32(rng)) * A.inv_ny;
+            float dx, dy;
+            random_in_unit_disk(rng, dx, dy);
+            const float rdx = A.cam.lens_radius * dx, rdy = A.cam.lens_radius * dy;
+            const f3 offset = add3(scale3(A.cam.u, rdx), scale3(A.cam.v, rdy));
+            (void)rng_f32(rng);  // camera.rs:59 time draw (spheres ignore ray.time)
+            const f3 dir = sub3(sub3(add3(add3(A.cam.lower_left_corner, scale3(A.cam.horizontal, u)),
+                                          scale3(A.cam.vertical, v)),
+                                     A.cam.origin),
+                                offset);
+            o = add3(A.cam.origin, offset);
+            d = normalize3(dir);
+            depth = 0;
+            need_cam = false;
+        }
+
+        // ---- hitable.rs:39-65: closest hit (inactive lanes carry a null ray)
+        const f3 ro = have ? o : mk3(0.f, 0.f, 0.f);
+        const f3 rd = have ? d : mk3(0.f, 0.f, 0.f);
+        const float a = dot3(rd, rd);  // sphere.rs:34
+        float t_hit;
+        int idx;
+        if (BVH)
+            idx = intersect_bvh(A, s_bvh, ro, rd, a, have, t_hit);
+        else
+            idx = intersect_list(SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, (int)A.n_spheres, ro, rd, a, t_hit);
+
+        // ---- scene.rs:49-71 one level of ray_trace
+        if (have) {
+            nrays += 1;
+            bool terminal = true;
+            f3 V;
+            if (idx < 0) {
+                // scene.rs:40-47
+                if (A.has_sky) {
+                    V = A.sky;
+                } else {
+                    const float t = 0.5f * (d.y + 1.0f);
+                    const float w1 = 1.0f - t;
+                    V = mk3(w1 + (t * 0.5f) * 0.3f, w1 + (t * 0.7f) * 0.3f, w1 + (t * 1.0f) * 0.3f);
+                }
+            } else {
+                const float4 sp = A.spheres[idx];
+                const f3 centre = mk3(sp.x, sp.y, sp.z);
+                const f3 point = add3(o, scale3(d, t_hit));            // ray.rs:24-26
+                const f3 normal = divs3(sub3(point, centre), sp.w);    // sphere.rs:42
+                const DMat m = A.mats[A.sphere_mat[idx]];
+                f3 emitted = mk3(0.f, 0.f, 0.f);                        // material.rs:161-167
+                if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = texture_value(A.texs, pn, m.tex, point);
+                bool scattered = false;
+                f3 att = mk3(1.f, 1.f, 1.f), nd = d;
+                if (depth < A.max_depth) {
+                    if (m.kind == PT_MAT_LAMBERTIAN) {  // material.rs:52-67
+                        const f3 target = add3(add3(point, normal), random_unit_vector(rng));
+                        att = texture_value(A.texs, pn, m.tex, point);
+                        nd = normalize3(sub3(target, point));
+                        scattered = true;
+                    } else if (m.kind == PT_MAT_METAL) {  // material.rs:69-89
+                        const f3 reflected = reflect3(d, normal);
+                        if (dot3(reflected, normal) > 0.0f) {
+                            att = mk3(m.a0, m.a1, m.a2);
+                            const f3 rs = random_in_unit_sphere(rng);
+                            nd = normalize3(add3(reflected, scale3(rs, m.param)));
+                            scattered = true;
+                        }
+                    } else if (m.kind == PT_MAT_DIELECTRIC) {  // material.rs:91-124
+                        const float ref_idx = m.param;
+                        const float rdotn = dot3(d, normal);
+                        f3 outward_normal;
+                        float ni_over_nt, cosine;
+                        if (rdotn > 0.0f) {
+                            cosine = rdotn / length3(d);
+                            cosine = sqrtf(1.0f - ref_idx * ref_idx * (1.0f - cosine * cosine));
+                            outward_normal = neg3(normal);
+                            ni_over_nt = ref_idx;
+                        } else {
+                            cosine = -rdotn / length3(d);
+                            outward_normal = normal;
+                            ni_over_nt = 1.0f / ref_idx;
+                        }
+                        f3 refracted;
+                        bool use_refract = false;
+                        if (refract3(d, outward_normal, ni_over_nt, refracted)) {
+                            const float reflect_prob = schlick_ref(cosine, ref_idx);
+                            if (rng_f32(rng) > reflect_prob) use_refract = true;
+                        }
+                        nd = use_refract ? normalize3(refracted) : normalize3(reflect3(d, normal));
+                        scattered = true;
+                    }
+                }
+                if (scattered) {
+                    path[(depth * 3 + 0) * kBlock] = att.x;
+                    path[(depth * 3 + 1) * kBlock] = att.y;
+                    path[(depth * 3 + 2) * kBlock] = att.z;
+                    depth += 1;
+                    o = point;
+                    d = nd;
+                    terminal = false;
+                } else {
+                    V = emitted;
+                }
+            }
+            if (terminal) {
+                // scene.rs:62-64 unwound: emitted(=0) + attenuation * deeper, innermost first
+                for (int k = (int)depth - 1; k >= 0; --k) {
+                    V.x = 0.0f + path[(k * 3 + 0) * kBlock] * V.x;
+                    V.y = 0.0f + path[(k * 3 + 1) * kBlock] * V.y;
+                    V.z = 0.0f + path[(k * 3 + 2) * kBlock] * V.z;
+                }
+                col = add3(col, V);  // scene.rs:110
+                sample += 1;
+                need_cam = true;
+                if (sample == A.samples) {
+                    // scene.rs:113-116
+                    col = scale3(col, A.inv_ns);
+                    float *out = A.rgb + boff;
+                    out[0] = out[0] * A.mix_prev + col.x * A.mix_new;
+                    out[1] = out[1] * A.mix_prev + col.y * A.mix_new;
+                    out[2] = out[2] * A.mix_prev + col.z * A.mix_new;
+                    have = false;
+                }
+            }
+        }
+    }
+
+    // scene.rs:118 ray_count: wave reduce, one atomic per wave
+    unsigned long long total = nrays;
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
+    if (lane == 0) atomicAdd(A.ray_count, total);
+}
+
+}  // namespace ptdev

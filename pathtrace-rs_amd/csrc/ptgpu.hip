@@ -1,0 +1,469 @@
+// ptgpu.hip -- C-ABI implementation (include/ptgpu.h) over the gfx950 kernels.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// (-ffp-contract=off is REQUIRED: the reference never fuses mul+add, and every
+// control-affecting value must round exactly like the CPU path.)
+#include "ptgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "pt_kernel.h"
+
+using namespace ptdev;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(PT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr uint32_t kLdsBudget = 160u * 1024u;       // LDS per CU on gfx950
+constexpr uint32_t kLdsPerBlockMax = 96u * 1024u;   // leave room for >= 1 co-resident block's statics
+
+}  // namespace
+
+struct pt_scene {
+    int device = 0;
+    int num_cus = 0;
+    uint32_t n_spheres = 0, n_materials = 0, n_textures = 0, n_nodes = 0;
+    int32_t bvh_root = -1;
+    uint32_t bvh_depth = 0;
+    uint32_t has_sky = 0;
+    float sky[3] = {0, 0, 0};
+    uint32_t has_noise = 0;
+    // device memory
+    float4 *d_spheres = nullptr, *d_spheres_r2 = nullptr;
+    uint32_t *d_sphere_mat = nullptr;
+    DMat *d_mats = nullptr;
+    DTex *d_texs = nullptr;
+    float4 *d_perlin_vec = nullptr;
+    uint32_t *d_perlin_perm = nullptr;
+    DNode *d_nodes = nullptr;
+    uint32_t *d_work_counter = nullptr;       // 1 u32
+    unsigned long long *d_ray_count = nullptr; // internal counter for pt_render
+    float *d_frame = nullptr;                 // internal frame buffer for pt_render (host-buffer entry point)
+    size_t d_frame_floats = 0;
+    float *d_gstack = nullptr;
+    size_t d_gstack_floats = 0;
+    uint64_t seed_base = 0x243f6a8885a308d3ull;
+    // tuning
+    uint32_t blocks_per_cu = 0, variant = 0;
+    // last launch
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_valid = false;
+    uint32_t last_grid = 0, last_block = 0, last_lds = 0;
+};
+
+extern "C" const char *pt_last_error(void) { return g_err; }
+extern "C" const char *pt_version(void) { return "ptgpu 0.1 gfx950"; }
+
+extern "C" int pt_device_count(int *count_out) {
+    if (!count_out) return fail(PT_ERR_INVALID_ARG, "count_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count_out = 0;
+        return fail(PT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count_out = n;
+    return PT_OK;
+}
+
+extern "C" uint32_t pt_shard_rows(uint32_t height, uint32_t shard_index, uint32_t shard_count) {
+    if (shard_count == 0 || shard_index >= shard_count || height <= shard_index) return 0;
+    return (height - shard_index + shard_count - 1) / shard_count;
+}
+
+namespace {
+
+// Depth of the supplied BVH (also validates child indices and acyclicity by
+// bounding the walk); returns 0 on a malformed tree.
+uint32_t bvh_depth_checked(const pt_bvh_node *nodes, uint32_t n_nodes, uint32_t n_spheres, int32_t root) {
+    struct Item { int32_t node; uint32_t depth; };
+    std::vector<Item> st;
+    st.push_back({root, 1});
+    uint32_t maxd = 0;
+    size_t visited = 0;
+    while (!st.empty()) {
+        Item it = st.back();
+        st.pop_back();
+        if (it.node < 0 || (uint32_t)it.node >= n_nodes) return 0;
+        if (++visited > (size_t)n_nodes * 2 + 2) return 0;  // a DAG/cycle would blow past this
+        if (it.depth > maxd) maxd = it.depth;
+        const int32_t ch[2] = {nodes[it.node].lhs, nodes[it.node].rhs};
+        for (int c = 0; c < 2; ++c) {
+            if (ch[c] >= 0) {
+                st.push_back({ch[c], it.depth + 1});
+            } else if ((uint32_t)(~ch[c]) >= n_spheres) {
+                return 0;
+            }
+        }
+    }
+    return maxd;
+}
+
+template <typename T>
+int upload(T **dst, const void *src, size_t count) {
+    HIP_TRY(hipMalloc((void **)dst, count * sizeof(T) > 0 ? count * sizeof(T) : sizeof(T)));
+    if (count) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene **scene_out) {
+    if (!desc || !scene_out) return fail(PT_ERR_INVALID_ARG, "desc/scene_out is NULL");
+    *scene_out = nullptr;
+    if (desc->n_spheres == 0 || !desc->spheres || !desc->sphere_material)
+        return fail(PT_ERR_INVALID_ARG, "scene has no spheres");
+    if (desc->n_materials == 0 || !desc->materials) return fail(PT_ERR_INVALID_ARG, "scene has no materials");
+    if (desc->n_textures && !desc->textures) return fail(PT_ERR_INVALID_ARG, "textures is NULL");
+    if (desc->n_spheres > 0x7fffffffu) return fail(PT_ERR_INVALID_ARG, "too many spheres");
+    bool has_noise = false;
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const pt_texture &t = desc->textures[i];
+        if (t.kind > PT_TEX_NOISE) return fail(PT_ERR_INVALID_ARG, "texture %u: unknown kind %u", i, t.kind);
+        if (t.kind == PT_TEX_CHECKER) {
+            // arena order (storage.rs:45-48): sub-textures are allocated before the checker that
+            // references them; requiring odd/even < i also guarantees termination on device.
+            if (t.odd < 0 || t.even < 0 || (uint32_t)t.odd >= i || (uint32_t)t.even >= i)
+                return fail(PT_ERR_INVALID_ARG, "texture %u: checker children must be earlier textures", i);
+        }
+        if (t.kind == PT_TEX_NOISE) has_noise = true;
+    }
+    if (has_noise && !desc->perlin) return fail(PT_ERR_INVALID_ARG, "noise texture without perlin tables");
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        const pt_material &m = desc->materials[i];
+        if (m.kind > PT_MAT_DIFFUSE_LIGHT) return fail(PT_ERR_INVALID_ARG, "material %u: unknown kind %u", i, m.kind);
+        if (m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_DIFFUSE_LIGHT) {
+            if (m.texture < 0 || (uint32_t)m.texture >= desc->n_textures)
+                return fail(PT_ERR_INVALID_ARG, "material %u: texture index %d out of range", i, m.texture);
+        }
+    }
+    for (uint32_t i = 0; i < desc->n_spheres; ++i)
+        if (desc->sphere_material[i] >= desc->n_materials)
+            return fail(PT_ERR_INVALID_ARG, "sphere %u: material index out of range", i);
+    uint32_t bvh_depth = 0;
+    if (desc->n_bvh_nodes) {
+        if (!desc->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "bvh_nodes is NULL");
+        bvh_depth = bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_spheres, desc->bvh_root);
+        if (bvh_depth == 0) return fail(PT_ERR_INVALID_ARG, "malformed BVH (bad child index or cycle)");
+        if (bvh_depth + 1 > (uint32_t)kBvhStack)
+            return fail(PT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack (%d)", bvh_depth, kBvhStack - 1);
+    }
+    if (desc->perlin)
+        for (int i = 0; i < 256; ++i)
+            if (desc->perlin->perm_x[i] > 255 || desc->perlin->perm_y[i] > 255 || desc->perlin->perm_z[i] > 255)
+                return fail(PT_ERR_INVALID_ARG, "perlin permutation entry > 255");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+
+    pt_scene *s = new (std::nothrow) pt_scene();
+    if (!s) return fail(PT_ERR_INVALID_ARG, "out of host memory");
+    s->device = device;
+    s->num_cus = prop.multiProcessorCount;
+    s->n_spheres = desc->n_spheres;
+    s->n_materials = desc->n_materials;
+    s->n_textures = desc->n_textures;
+    s->n_nodes = desc->n_bvh_nodes;
+    s->bvh_root = desc->n_bvh_nodes ? desc->bvh_root : -1;
+    s->bvh_depth = bvh_depth;
+    s->has_sky = desc->has_sky ? 1u : 0u;
+    memcpy(s->sky, desc->sky, sizeof s->sky);
+    s->has_noise = has_noise ? 1u : 0u;
+
+    // flatten to the device layouts
+    std::vector<float4> sph(desc->n_spheres), sph_r2(desc->n_spheres);
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+        const pt_sphere &p = desc->spheres[i];
+        sph[i] = make_float4(p.cx, p.cy, p.cz, p.radius);
+        const volatile float r2 = p.radius * p.radius;  // sphere.rs:36, one f32 rounding
+        sph_r2[i] = make_float4(p.cx, p.cy, p.cz, r2);
+    }
+    std::vector<DMat> mats(desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        const pt_material &m = desc->materials[i];
+        mats[i] = DMat{m.kind, m.albedo[0], m.albedo[1], m.albedo[2], m.param, m.texture, 0.f, 0.f};
+    }
+    std::vector<DTex> texs(desc->n_textures ? desc->n_textures : 1);
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const pt_texture &t = desc->textures[i];
+        texs[i] = DTex{t.kind, t.color[0], t.color[1], t.color[2], t.odd, t.even, t.scale, 0.f};
+    }
+    std::vector<DNode> nodes(desc->n_bvh_nodes);
+    for (uint32_t i = 0; i < desc->n_bvh_nodes; ++i) {
+        const pt_bvh_node &n = desc->bvh_nodes[i];
+        nodes[i] = DNode{n.min[0], n.min[1], n.min[2], n.max[0], n.max[1], n.max[2], n.lhs, n.rhs};
+    }
+    std::vector<float4> pvec(256, make_float4(0, 0, 0, 0));
+    std::vector<uint32_t> pperm(768, 0);
+    if (desc->perlin) {
+        for (int i = 0; i < 256; ++i) {
+            pvec[i] = make_float4(desc->perlin->randvec[i][0], desc->perlin->randvec[i][1], desc->perlin->randvec[i][2], 0.f);
+            pperm[i] = desc->perlin->perm_x[i];
+            pperm[256 + i] = desc->perlin->perm_y[i];
+            pperm[512 + i] = desc->perlin->perm_z[i];
+        }
+    }
+    int rc = PT_OK;
+    if ((rc = upload(&s->d_spheres, sph.data(), sph.size())) || (rc = upload(&s->d_spheres_r2, sph_r2.data(), sph_r2.size())) ||
+        (rc = upload(&s->d_sphere_mat, desc->sphere_material, desc->n_spheres)) ||
+        (rc = upload(&s->d_mats, mats.data(), mats.size())) || (rc = upload(&s->d_texs, texs.data(), texs.size())) ||
+        (rc = upload(&s->d_perlin_vec, pvec.data(), pvec.size())) || (rc = upload(&s->d_perlin_perm, pperm.data(), pperm.size())) ||
+        (rc = upload(&s->d_nodes, nodes.data(), nodes.size()))) {
+        pt_scene_destroy(s);
+        return rc;
+    }
+    if (hipMalloc((void **)&s->d_work_counter, 64) != hipSuccess || hipMalloc((void **)&s->d_ray_count, 64) != hipSuccess ||
+        hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess) {
+        pt_scene_destroy(s);
+        return fail(PT_ERR_HIP, "allocating work counters / events failed");
+    }
+    if (const char *e = getenv("PTGPU_BLOCKS_PER_CU")) s->blocks_per_cu = (uint32_t)atoi(e);
+    if (const char *e = getenv("PTGPU_VARIANT")) s->variant = (uint32_t)atoi(e);
+    *scene_out = s;
+    return PT_OK;
+}
+
+extern "C" void pt_scene_destroy(pt_scene *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipFree(s->d_spheres);
+    (void)hipFree(s->d_spheres_r2);
+    (void)hipFree(s->d_sphere_mat);
+    (void)hipFree(s->d_mats);
+    (void)hipFree(s->d_texs);
+    (void)hipFree(s->d_perlin_vec);
+    (void)hipFree(s->d_perlin_perm);
+    (void)hipFree(s->d_nodes);
+    (void)hipFree(s->d_work_counter);
+    (void)hipFree(s->d_ray_count);
+    (void)hipFree(s->d_frame);
+    (void)hipFree(s->d_gstack);
+    if (s->ev_start) (void)hipEventDestroy(s->ev_start);
+    if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
+    delete s;
+}
+
+extern "C" int pt_scene_set_seed_base(pt_scene *s, uint64_t seed_base) {
+    if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
+    s->seed_base = seed_base;
+    return PT_OK;
+}
+
+extern "C" int pt_scene_set_tuning(pt_scene *s, uint32_t blocks_per_cu, uint32_t variant) {
+    if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
+    s->blocks_per_cu = blocks_per_cu;
+    s->variant = variant;
+    return PT_OK;
+}
+
+namespace {
+
+f3 to3(const float *p) { return f3{p[0], p[1], p[2]}; }
+
+int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t frame_num, uint32_t shard_index,
+           uint32_t shard_count, float *d_rgb, uint64_t *d_ray_count, hipStream_t stream) {
+    if (!s || !params || !cam || !d_rgb || !d_ray_count) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (params->width == 0 || params->height == 0 || params->samples == 0)
+        return fail(PT_ERR_INVALID_ARG, "width/height/samples must be non-zero");
+    if ((uint64_t)params->width * params->height > 0x3fffffffull) return fail(PT_ERR_INVALID_ARG, "frame too large");
+    if (shard_count == 0 || shard_index >= shard_count) return fail(PT_ERR_INVALID_ARG, "bad shard %u/%u", shard_index, shard_count);
+    const bool bvh = params->use_bvh != 0;
+    if (bvh && s->bvh_root < 0) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the scene was created without BVH nodes");
+    HIP_TRY(hipSetDevice(s->device));
+
+    KArgs A;
+    memset(&A, 0, sizeof A);
+    A.spheres = s->d_spheres;
+    A.spheres_r2 = s->d_spheres_r2;
+    A.sphere_mat = s->d_sphere_mat;
+    A.mats = s->d_mats;
+    A.texs = s->d_texs;
+    A.perlin_vec = s->d_perlin_vec;
+    A.perlin_perm = s->d_perlin_perm;
+    A.nodes = s->d_nodes;
+    A.n_spheres = s->n_spheres;
+    A.bvh_root = s->bvh_root;
+    A.has_sky = s->has_sky;
+    A.sky = to3(s->sky);
+    A.has_noise = s->has_noise;
+    A.cam.origin = to3(cam->origin);
+    A.cam.lower_left_corner = to3(cam->lower_left_corner);
+    A.cam.horizontal = to3(cam->horizontal);
+    A.cam.vertical = to3(cam->vertical);
+    A.cam.u = to3(cam->u);
+    A.cam.v = to3(cam->v);
+    A.cam.w = to3(cam->w);
+    A.cam.time0 = cam->time0;
+    A.cam.time1 = cam->time1;
+    A.cam.lens_radius = cam->lens_radius;
+    A.width = params->width;
+    A.height = params->height;
+    A.samples = params->samples;
+    A.max_depth = params->max_depth;
+    A.frame_num = frame_num;
+    // scene.rs:82-87, evaluated in f32 exactly like the reference
+    {
+        const volatile float one = 1.0f;
+        A.inv_nx = one / (float)params->width;
+        A.inv_ny = one / (float)params->height;
+        A.inv_ns = one / (float)params->samples;
+        const volatile float mp = (float)frame_num / (float)(frame_num + 1u);
+        A.mix_prev = mp;
+        A.mix_new = one - mp;
+    }
+    A.random_seed = params->random_seed;
+    A.seed_base = s->seed_base;
+    A.shard_index = shard_index;
+    A.shard_count = shard_count;
+    A.local_rows = pt_shard_rows(params->height, shard_index, shard_count);
+    A.tiles_x = (params->width + 7u) / 8u;
+    const uint32_t tiles_y = (A.local_rows + 7u) / 8u;
+    A.n_items = A.tiles_x * tiles_y * 64u;
+    A.rgb = d_rgb;
+    A.ray_count = reinterpret_cast<unsigned long long *>(d_ray_count);
+    A.work_counter = s->d_work_counter;
+
+    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
+    if (A.n_items == 0) return PT_OK;
+
+    // ---- LDS carve -----------------------------------------------------------
+    uint32_t sph_bytes = 0;
+    bool sph_lds = false;
+    if (!bvh) {
+        sph_bytes = ((s->n_spheres * 16u) + 15u) & ~15u;
+        sph_lds = (s->variant != 1u) && sph_bytes <= 64u * 1024u;
+        if (!sph_lds) sph_bytes = 0;
+    }
+    uint32_t lds = sph_bytes;
+    if (s->has_noise) lds += 4096u + 3072u;
+    if (bvh) lds += (uint32_t)kBvhStack * kBlock * 4u;
+    const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
+    A.stack_in_lds = (lds + path_bytes <= kLdsPerBlockMax) ? 1u : 0u;
+    if (A.stack_in_lds) lds += (uint32_t)path_bytes;
+    A.lds_sphere_bytes = sph_bytes;
+
+    // ---- persistent grid: CUs x resident blocks --------------------------------
+    uint32_t bpc = s->blocks_per_cu;
+    if (bpc == 0) bpc = bvh ? 2u : 2u;
+    const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
+    if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
+    if (bpc > 8u) bpc = 8u;
+    uint32_t grid = (uint32_t)s->num_cus * bpc;
+    const uint32_t need = (A.n_items + kBlock - 1) / kBlock;
+    if (grid > need) grid = need;
+    if (grid == 0) grid = 1;
+
+    if (!A.stack_in_lds) {
+        const size_t need_floats = (size_t)grid * params->max_depth * 3ull * kBlock;
+        if (need_floats > s->d_gstack_floats) {
+            (void)hipFree(s->d_gstack);
+            s->d_gstack = nullptr;
+            s->d_gstack_floats = 0;
+            HIP_TRY(hipMalloc((void **)&s->d_gstack, need_floats * sizeof(float)));
+            s->d_gstack_floats = need_floats;
+        }
+        A.gstack = s->d_gstack;
+    }
+
+    void (*kern)(const KArgs) = nullptr;
+    if (bvh)
+        kern = pt_trace_kernel<true, false>;
+    else if (sph_lds)
+        kern = pt_trace_kernel<false, true>;
+    else
+        kern = pt_trace_kernel<false, false>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+
+    HIP_TRY(hipEventRecord(s->ev_start, stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev_stop, stream));
+    s->ev_valid = true;
+    s->last_grid = grid;
+    s->last_block = kBlock;
+    s->last_lds = lds;
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" int pt_render_device(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t frame_num,
+                                float *d_rgb_inout, uint64_t *d_ray_count, void *hip_stream) {
+    return launch(s, params, cam, frame_num, 0, 1, d_rgb_inout, d_ray_count, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int pt_render_shard_device(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t frame_num,
+                                      uint32_t shard_index, uint32_t shard_count, float *d_rgb_shard_inout,
+                                      uint64_t *d_ray_count, void *hip_stream) {
+    return launch(s, params, cam, frame_num, shard_index, shard_count, d_rgb_shard_inout, d_ray_count,
+                  reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+extern "C" int pt_render(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t frame_num, float *rgb_inout,
+                         uint64_t *ray_count_out) {
+    if (!s || !params || !cam || !rgb_inout || !ray_count_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (params->width == 0 || params->height == 0 || params->samples == 0)
+        return fail(PT_ERR_INVALID_ARG, "width/height/samples must be non-zero");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t floats = (size_t)params->width * params->height * 3u;
+    if (floats > s->d_frame_floats) {
+        (void)hipFree(s->d_frame);
+        s->d_frame = nullptr;
+        s->d_frame_floats = 0;
+        HIP_TRY(hipMalloc((void **)&s->d_frame, floats * sizeof(float)));
+        s->d_frame_floats = floats;
+    }
+    // the buffer is read (frame blend, scene.rs:114-116) and written
+    HIP_TRY(hipMemcpy(s->d_frame, rgb_inout, floats * sizeof(float), hipMemcpyHostToDevice));
+    int rc = launch(s, params, cam, frame_num, 0, 1, s->d_frame, reinterpret_cast<uint64_t *>(s->d_ray_count), nullptr);
+    if (rc != PT_OK) return rc;
+    HIP_TRY(hipMemcpy(rgb_inout, s->d_frame, floats * sizeof(float), hipMemcpyDeviceToHost));
+    unsigned long long rc64 = 0;
+    HIP_TRY(hipMemcpy(&rc64, s->d_ray_count, sizeof rc64, hipMemcpyDeviceToHost));
+    *ray_count_out = rc64;
+    return PT_OK;
+}
+
+extern "C" int pt_last_kernel_ms(pt_scene *s, float *ms_out) {
+    if (!s || !ms_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (!s->ev_valid) return fail(PT_ERR_INVALID_ARG, "no render has been launched on this scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms_out, s->ev_start, s->ev_stop));
+    return PT_OK;
+}
+
+extern "C" int pt_last_launch_info(pt_scene *s, uint32_t *grid_out, uint32_t *block_out, uint32_t *lds_bytes_out) {
+    if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
+    if (grid_out) *grid_out = s->last_grid;
+    if (block_out) *block_out = s->last_block;
+    if (lds_bytes_out) *lds_bytes_out = s->last_lds;
+    return PT_OK;
+}

@@ -1,0 +1,248 @@
+"""ctypes binding of libptgpu.so (include/ptgpu.h) -- plumbing only.
+
+The product is the HIP library; this module only marshals PODs. It fails
+loudly when the shared library is missing: there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_build", "libptgpu.so")
+
+PT_OK = 0
+PT_ERR_INVALID_ARG = 1
+PT_ERR_HIP = 2
+PT_ERR_NO_DEVICE = 3
+PT_ERR_UNSUPPORTED = 4
+
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
+TEX_CONSTANT, TEX_CHECKER, TEX_NOISE = 0, 1, 2
+
+
+class PtParams(C.Structure):  # params.rs:11-18
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32),
+                ("max_depth", C.c_uint32), ("random_seed", C.c_uint32), ("use_bvh", C.c_uint32)]
+
+
+class PtCamera(C.Structure):  # camera.rs:8-19
+    _fields_ = [("origin", C.c_float * 3), ("lower_left_corner", C.c_float * 3),
+                ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+                ("time0", C.c_float), ("time1", C.c_float), ("lens_radius", C.c_float)]
+
+    @classmethod
+    def from_floats(cls, f24):
+        f = np.ascontiguousarray(f24, dtype=np.float32)
+        assert f.size == 24
+        cam = cls()
+        C.memmove(C.addressof(cam), f.ctypes.data, 96)
+        return cam
+
+
+class PtSphere(C.Structure):
+    _fields_ = [("cx", C.c_float), ("cy", C.c_float), ("cz", C.c_float), ("radius", C.c_float)]
+
+
+class PtMaterial(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("albedo", C.c_float * 3), ("param", C.c_float), ("texture", C.c_int32)]
+
+
+class PtTexture(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("color", C.c_float * 3), ("odd", C.c_int32), ("even", C.c_int32),
+                ("scale", C.c_float)]
+
+
+class PtPerlin(C.Structure):
+    _fields_ = [("randvec", (C.c_float * 3) * 256), ("perm_x", C.c_uint32 * 256),
+                ("perm_y", C.c_uint32 * 256), ("perm_z", C.c_uint32 * 256)]
+
+
+class PtBvhNode(C.Structure):
+    _fields_ = [("min", C.c_float * 3), ("max", C.c_float * 3), ("lhs", C.c_int32), ("rhs", C.c_int32)]
+
+
+class PtSceneDesc(C.Structure):
+    _fields_ = [("n_spheres", C.c_uint32), ("spheres", C.POINTER(PtSphere)),
+                ("sphere_material", C.POINTER(C.c_uint32)),
+                ("n_materials", C.c_uint32), ("materials", C.POINTER(PtMaterial)),
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(PtTexture)),
+                ("perlin", C.POINTER(PtPerlin)),
+                ("n_bvh_nodes", C.c_uint32), ("bvh_nodes", C.POINTER(PtBvhNode)), ("bvh_root", C.c_int32),
+                ("has_sky", C.c_uint32), ("sky", C.c_float * 3)]
+
+
+EXPORTS = [
+    "pt_device_count", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
+    "pt_render_shard_device", "pt_shard_rows", "pt_scene_set_seed_base", "pt_last_kernel_ms",
+    "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version",
+]
+
+_lib = None
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("ptgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load libptgpu.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.pt_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.pt_scene_create.argtypes = [C.POINTER(PtSceneDesc), C.c_int, C.POINTER(vp)]
+        L.pt_scene_destroy.argtypes = [vp]
+        L.pt_scene_destroy.restype = None
+        L.pt_render.argtypes = [vp, C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, vp, C.POINTER(C.c_uint64)]
+        L.pt_render_device.argtypes = [vp, C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, vp, vp, vp]
+        L.pt_render_shard_device.argtypes = [vp, C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, C.c_uint32,
+                                             C.c_uint32, vp, vp, vp]
+        L.pt_shard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.pt_shard_rows.restype = C.c_uint32
+        L.pt_scene_set_seed_base.argtypes = [vp, C.c_uint64]
+        L.pt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.pt_last_launch_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.pt_scene_set_tuning.argtypes = [vp, C.c_uint32, C.c_uint32]
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != PT_OK:
+        raise PtError(rc, lib().pt_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().pt_device_count(C.byref(n))
+    return n.value if rc == PT_OK else 0
+
+
+class SceneDesc:
+    """Owns the numpy/ctypes storage behind a pt_scene_desc."""
+
+    def __init__(self, spheres, sphere_material, materials, textures, perlin=None, bvh_nodes=None, bvh_root=-1,
+                 sky=None):
+        self.spheres = np.ascontiguousarray(spheres, dtype=np.float32).reshape(-1, 4)
+        self.sphere_material = np.ascontiguousarray(sphere_material, dtype=np.uint32)
+        self.materials = (PtMaterial * max(1, len(materials)))()
+        for i, (kind, albedo, param, tex) in enumerate(materials):
+            m = self.materials[i]
+            m.kind, m.param, m.texture = int(kind), float(param), int(tex)
+            m.albedo[:] = [float(a) for a in albedo]
+        self.n_materials = len(materials)
+        self.textures = (PtTexture * max(1, len(textures)))()
+        for i, (kind, color, odd, even, scale) in enumerate(textures):
+            t = self.textures[i]
+            t.kind, t.odd, t.even, t.scale = int(kind), int(odd), int(even), float(scale)
+            t.color[:] = [float(c) for c in color]
+        self.n_textures = len(textures)
+        self.perlin = None
+        if perlin is not None:
+            randvec, px, py, pz = perlin
+            self.perlin = PtPerlin()
+            rv = np.ascontiguousarray(randvec, dtype=np.float32).reshape(256, 3)
+            C.memmove(C.addressof(self.perlin.randvec), rv.ctypes.data, 256 * 12)
+            for name, arr in (("perm_x", px), ("perm_y", py), ("perm_z", pz)):
+                a = np.ascontiguousarray(arr, dtype=np.uint32)
+                C.memmove(C.addressof(getattr(self.perlin, name)), a.ctypes.data, 1024)
+        self.bvh_nodes = None
+        self.n_bvh_nodes = 0
+        if bvh_nodes is not None and len(bvh_nodes[0]):
+            minmax, lr = bvh_nodes
+            minmax = np.ascontiguousarray(minmax, dtype=np.float32).reshape(-1, 6)
+            lr = np.ascontiguousarray(lr, dtype=np.int32).reshape(-1, 2)
+            self.n_bvh_nodes = len(minmax)
+            self.bvh_nodes = (PtBvhNode * self.n_bvh_nodes)()
+            packed = np.zeros((self.n_bvh_nodes, 8), dtype=np.float32)
+            packed[:, :6] = minmax
+            packed[:, 6:] = lr.view(np.float32)
+            C.memmove(C.addressof(self.bvh_nodes), packed.ctypes.data, self.n_bvh_nodes * 32)
+        self.bvh_root = int(bvh_root)
+        self.sky = sky
+
+    def struct(self):
+        d = PtSceneDesc()
+        d.n_spheres = len(self.spheres)
+        d.spheres = C.cast(self.spheres.ctypes.data, C.POINTER(PtSphere))
+        d.sphere_material = C.cast(self.sphere_material.ctypes.data, C.POINTER(C.c_uint32))
+        d.n_materials = self.n_materials
+        d.materials = C.cast(self.materials, C.POINTER(PtMaterial))
+        d.n_textures = self.n_textures
+        d.textures = C.cast(self.textures, C.POINTER(PtTexture))
+        d.perlin = C.pointer(self.perlin) if self.perlin is not None else None
+        d.n_bvh_nodes = self.n_bvh_nodes
+        d.bvh_nodes = C.cast(self.bvh_nodes, C.POINTER(PtBvhNode)) if self.bvh_nodes is not None else None
+        d.bvh_root = self.bvh_root if self.n_bvh_nodes else -1
+        d.has_sky = 1 if self.sky is not None else 0
+        if self.sky is not None:
+            d.sky[:] = [float(c) for c in self.sky]
+        return d
+
+
+class Scene:
+    """pt_scene handle (Scene::new, scene.rs:25-31)."""
+
+    def __init__(self, desc, device=0):
+        self._h = C.c_void_p()
+        self._desc = desc  # keep storage alive during create
+        d = desc.struct()
+        _check(lib().pt_scene_create(C.byref(d), device, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().pt_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_tuning(self, blocks_per_cu=0, variant=0):
+        _check(lib().pt_scene_set_tuning(self._h, blocks_per_cu, variant))
+
+    def set_seed_base(self, seed):
+        _check(lib().pt_scene_set_seed_base(self._h, seed))
+
+    def update(self, params, camera, frame_num, buffer):
+        """Scene::update (scene.rs:73-121) on a host numpy buffer [H, W, 3] float32 (in/out)."""
+        assert buffer.dtype == np.float32 and buffer.flags["C_CONTIGUOUS"]
+        assert buffer.size == params.width * params.height * 3
+        rc = C.c_uint64(0)
+        _check(lib().pt_render(self._h, C.byref(params), C.byref(camera), frame_num, buffer.ctypes.data, C.byref(rc)))
+        return rc.value
+
+    def update_device(self, params, camera, frame_num, d_rgb_ptr, d_ray_count_ptr, stream=0):
+        _check(lib().pt_render_device(self._h, C.byref(params), C.byref(camera), frame_num, d_rgb_ptr,
+                                      d_ray_count_ptr, stream))
+
+    def update_shard_device(self, params, camera, frame_num, shard_index, shard_count, d_rgb_ptr, d_ray_count_ptr,
+                            stream=0):
+        _check(lib().pt_render_shard_device(self._h, C.byref(params), C.byref(camera), frame_num, shard_index,
+                                            shard_count, d_rgb_ptr, d_ray_count_ptr, stream))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _check(lib().pt_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def last_launch_info(self):
+        g, b, l = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _check(lib().pt_last_launch_info(self._h, C.byref(g), C.byref(b), C.byref(l)))
+        return g.value, b.value, l.value
+
+
+def shard_rows(height, shard_index, shard_count):
+    return lib().pt_shard_rows(height, shard_index, shard_count)

@@ -1,0 +1,37 @@
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_ptgpu():
+    """The product package directory is `pathtrace-rs_amd` (not an importable identifier)."""
+    name = "pathtrace_rs_amd_ptgpu"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "pathtrace-rs_amd", "ptgpu.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.fixture(scope="session")
+def ptgpu():
+    return load_ptgpu()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_binding
+    oracle_binding.lib()
+    return oracle_binding

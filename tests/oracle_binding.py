@@ -1,0 +1,172 @@
+"""ctypes binding of the CPU oracle (oracle/ptref.h). TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg;
+never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "_build", "libptref.so")
+
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "_build/libptref.so"], stdout=subprocess.DEVNULL)
+    return LIB
+
+
+def build_native(out_dir=None):
+    """-O3 -march=native build for the cpu_baseline leg; compiled on the box that runs it."""
+    out_dir = out_dir or os.path.join(ORACLE_DIR, "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libptref_native_%s.so" % os.uname().nodename.replace("/", "_"))
+    src = os.path.join(ORACLE_DIR, "ptref.c")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-std=c11", "-D_GNU_SOURCE", "-fPIC", "-ffp-contract=off",
+                               "-fno-fast-math", "-fexcess-precision=standard", "-shared", "-o", out, src, "-lm",
+                               "-lpthread"])
+    return out
+
+
+def _bind(L):
+    vp, u32, u64, i32, f32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_float
+    L.ora_scene_from_preset.restype = vp
+    L.ora_scene_from_preset.argtypes = [C.c_char_p, u32, u32, C.c_int]
+    L.ora_scene_free.argtypes = [vp]
+    L.ora_scene_free.restype = None
+    L.ora_scene_update.restype = u64
+    L.ora_scene_update.argtypes = [vp, u32, u32, u32, u32, u32, vp, C.c_int]
+    L.ora_scene_update_range.restype = u64
+    L.ora_scene_update_range.argtypes = [vp, u32, u32, u32, u32, u32, vp, u64, u64, C.c_int]
+    L.ora_scene_update_pixels.restype = u64
+    L.ora_scene_update_pixels.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp, u64, C.c_int]
+    for n in ("num_spheres", "num_materials", "num_textures", "num_bvh_nodes"):
+        f = getattr(L, "ora_scene_" + n)
+        f.restype, f.argtypes = u32, [vp]
+    L.ora_scene_bvh_root.restype, L.ora_scene_bvh_root.argtypes = i32, [vp]
+    L.ora_scene_has_perlin_texture.restype, L.ora_scene_has_perlin_texture.argtypes = C.c_int, [vp]
+    L.ora_scene_build_draws.restype, L.ora_scene_build_draws.argtypes = u64, [vp]
+    L.ora_scene_export_spheres.argtypes = [vp, vp, vp]
+    L.ora_scene_export_materials.argtypes = [vp, vp]
+    L.ora_scene_export_textures.argtypes = [vp, vp]
+    L.ora_scene_export_perlin.argtypes = [vp, vp, vp, vp, vp]
+    L.ora_scene_export_bvh.argtypes = [vp, vp, vp]
+    L.ora_scene_export_camera.argtypes = [vp, vp]
+    L.ora_scene_export_sky.restype, L.ora_scene_export_sky.argtypes = C.c_int, [vp, vp]
+    L.ora_splitmix64.argtypes = [u64, vp, C.c_int]
+    L.ora_xoshiro_seed_from_u64.argtypes = [u64, vp]
+    L.ora_xoshiro_next_u64.restype, L.ora_xoshiro_next_u64.argtypes = u64, [vp]
+    L.ora_xoshiro_gen_f32.restype, L.ora_xoshiro_gen_f32.argtypes = f32, [vp]
+    L.ora_xoshiro_gen_range_i32.restype, L.ora_xoshiro_gen_range_i32.argtypes = i32, [vp, i32, i32]
+    L.ora_pixel_seed.restype, L.ora_pixel_seed.argtypes = u64, [u32, u32, u32]
+    L.ora_sinf_cosf.argtypes = [f32, vp, vp]
+    L.ora_sphere_ray_hit.restype, L.ora_sphere_ray_hit.argtypes = C.c_int, [vp, vp, vp, f32, f32, vp]
+    L.ora_aabb_ray_hit.restype, L.ora_aabb_ray_hit.argtypes = C.c_int, [vp, vp, vp, vp, f32, f32]
+    L.ora_schlick.restype, L.ora_schlick.argtypes = f32, [f32, f32]
+    for n in ("random_unit_vector", "random_in_unit_sphere", "random_in_unit_disk"):
+        getattr(L, "ora_" + n).argtypes = [vp, vp]
+    L.ora_camera_get_ray.argtypes = [vp, f32, f32, vp, vp]
+    L.ora_camera_new.argtypes = [vp, vp, vp, f32, f32, f32, f32, f32, f32, vp]
+    L.ora_perlin_noise.restype, L.ora_perlin_noise.argtypes = f32, [vp, vp]
+    L.ora_perlin_turb.restype, L.ora_perlin_turb.argtypes = f32, [vp, vp]
+    L.ora_texture_value.argtypes = [vp, u32, vp, vp]
+    L.ora_ray_trace.argtypes = [vp, vp, vp, f32, u32, vp, vp, vp]
+    L.ora_linear_to_srgb.argtypes = [vp, vp]
+    L.ora_frame_to_srgb8.argtypes = [vp, u32, u32, vp]
+    return L
+
+
+def lib(path=None):
+    global _lib
+    if path is not None:
+        return _bind(C.CDLL(path))
+    if _lib is None:
+        _lib = _bind(C.CDLL(build()))
+    return _lib
+
+
+class OracleScene:
+    """offline.rs:16-24: seed-0 rng -> Storage::new -> preset -> new_scene."""
+
+    def __init__(self, preset, width, height, use_bvh=False, library=None):
+        self.L = library or lib()
+        self.h = self.L.ora_scene_from_preset(preset.encode(), width, height, 1 if use_bvh else 0)
+        if not self.h:
+            raise KeyError("unrecognised preset %r" % preset)
+        self.preset, self.width, self.height, self.use_bvh = preset, width, height, bool(use_bvh)
+
+    def close(self):
+        if self.h:
+            self.L.ora_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # Scene::update
+    def update(self, samples, max_depth=10, frame_num=0, buffer=None, nthreads=0, pix_range=None, pixels=None):
+        W, H = self.width, self.height
+        if buffer is None:
+            buffer = np.zeros((H, W, 3), dtype=np.float32)
+        assert buffer.dtype == np.float32 and buffer.flags["C_CONTIGUOUS"] and buffer.size == W * H * 3
+        if pixels is not None:
+            px = np.ascontiguousarray(pixels, dtype=np.uint32)
+            rc = self.L.ora_scene_update_pixels(self.h, W, H, samples, max_depth, frame_num, buffer.ctypes.data,
+                                                px.ctypes.data, len(px), nthreads)
+        elif pix_range is not None:
+            rc = self.L.ora_scene_update_range(self.h, W, H, samples, max_depth, frame_num, buffer.ctypes.data,
+                                               pix_range[0], pix_range[1], nthreads)
+        else:
+            rc = self.L.ora_scene_update(self.h, W, H, samples, max_depth, frame_num, buffer.ctypes.data, nthreads)
+        return buffer, rc
+
+    # flat export ---------------------------------------------------------
+    def export(self):
+        L, h = self.L, self.h
+        n = L.ora_scene_num_spheres(h)
+        xyzr = np.zeros((n, 4), np.float32)
+        mid = np.zeros(n, np.uint32)
+        L.ora_scene_export_spheres(h, xyzr.ctypes.data, mid.ctypes.data)
+        nm = L.ora_scene_num_materials(h)
+        mats = np.zeros((nm, 6), np.float32)
+        L.ora_scene_export_materials(h, mats.ctypes.data)
+        nt = L.ora_scene_num_textures(h)
+        texs = np.zeros((max(nt, 1), 7), np.float32)
+        L.ora_scene_export_textures(h, texs.ctypes.data)
+        texs = texs[:nt]
+        rv = np.zeros((256, 3), np.float32)
+        px, py, pz = (np.zeros(256, np.uint32) for _ in range(3))
+        L.ora_scene_export_perlin(h, rv.ctypes.data, px.ctypes.data, py.ctypes.data, pz.ctypes.data)
+        nn = L.ora_scene_num_bvh_nodes(h)
+        minmax = np.zeros((max(nn, 1), 6), np.float32)
+        lr = np.zeros((max(nn, 1), 2), np.int32)
+        if nn:
+            L.ora_scene_export_bvh(h, minmax.ctypes.data, lr.ctypes.data)
+        cam = np.zeros(24, np.float32)
+        L.ora_scene_export_camera(h, cam.ctypes.data)
+        sky = np.zeros(3, np.float32)
+        has_sky = L.ora_scene_export_sky(h, sky.ctypes.data)
+        return dict(spheres=xyzr, sphere_material=mid, materials=mats, textures=texs, perlin=(rv, px, py, pz),
+                    has_perlin=bool(L.ora_scene_has_perlin_texture(h)), bvh_minmax=minmax[:nn], bvh_children=lr[:nn],
+                    bvh_root=L.ora_scene_bvh_root(h), camera=cam, sky=(sky if has_sky else None),
+                    build_draws=L.ora_scene_build_draws(h))
+
+
+def to_ptgpu_desc(ptgpu, ex):
+    """Turn an oracle export into the product's pt_scene_desc (tests feed the SAME scene to both)."""
+    materials = [(int(r[0]), r[1:4], r[4], int(r[5])) for r in ex["materials"]]
+    textures = [(int(r[0]), r[1:4], int(r[4]), int(r[5]), r[6]) for r in ex["textures"]]
+    bvh = (ex["bvh_minmax"], ex["bvh_children"]) if len(ex["bvh_minmax"]) else None
+    return ptgpu.SceneDesc(ex["spheres"], ex["sphere_material"], materials, textures,
+                           perlin=ex["perlin"] if ex["has_perlin"] else None, bvh_nodes=bvh,
+                           bvh_root=ex["bvh_root"], sky=ex["sky"])
