@@ -1,0 +1,277 @@
+// scene.cpp -- Params, Camera, Perlin, Storage, BVH build and the Scene handle.
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+#include "host.hpp"
+
+namespace pt {
+
+// ---- params.rs:21-27 -------------------------------------------------------
+Xoshiro256Plus Params::new_rng() const {
+    if (random_seed) {
+        // rand::random(): OS entropy in the reference; not reproducible by design
+        uint64_t seed = 0x9e3779b97f4a7c15ULL;
+        if (FILE *f = fopen("/dev/urandom", "rb")) {
+            if (fread(&seed, sizeof seed, 1, f) != 1) seed ^= reinterpret_cast<uintptr_t>(&seed);
+            fclose(f);
+        }
+        return Xoshiro256Plus::seed_from_u64(seed);
+    }
+    return Xoshiro256Plus::seed_from_u64(0);
+}
+
+pt_params Params::c_params() const {
+    return pt_params{width, height, samples, max_depth, random_seed ? 1u : 0u, use_bvh ? 1u : 0u};
+}
+
+// ---- camera.rs:22-54 -------------------------------------------------------
+static void put(float dst[3], Vec3 v) {
+    dst[0] = v.x;
+    dst[1] = v.y;
+    dst[2] = v.z;
+}
+
+Camera Camera::create(Vec3 lookfrom, Vec3 lookat, Vec3 vup, float vfov, float aspect, float aperture,
+                      float focus_dist, float time0, float time1) {
+    constexpr float kPi = 3.14159274101257324f;
+    const float theta = vfov * kPi / 180.0f;
+    const float half_height = std::tan(theta * 0.5f);
+    const float half_width = aspect * half_height;
+    const Vec3 w = normalize(lookfrom - lookat);
+    const Vec3 u = normalize(cross(vup, w));
+    const Vec3 v = cross(w, u);
+    Camera c{};
+    put(c.pod.origin, lookfrom);
+    put(c.pod.lower_left_corner,
+        lookfrom - half_width * focus_dist * u - half_height * focus_dist * v - focus_dist * w);
+    put(c.pod.horizontal, 2.0f * half_width * focus_dist * u);
+    put(c.pod.vertical, 2.0f * half_height * focus_dist * v);
+    put(c.pod.u, u);
+    put(c.pod.v, v);
+    put(c.pod.w, w);
+    c.pod.time0 = time0;
+    c.pod.time1 = time1;
+    c.pod.lens_radius = aperture * 0.5f;
+    return c;
+}
+
+// ---- perlin.rs:15-51 -------------------------------------------------------
+static void generate_perm(Xoshiro256Plus &rng, uint32_t *perm) {
+    for (uint32_t i = 0; i < 256; ++i) perm[i] = i;
+    for (int i = 255; i >= 0; --i) {  // perlin.rs:27-32
+        const size_t target = static_cast<size_t>(std::floor(rng.gen_f32() * static_cast<float>(i + 1)));
+        std::swap(perm[i], perm[target]);
+    }
+}
+
+Perlin::Perlin(Xoshiro256Plus &rng) {
+    for (auto &v : randvec) {  // perlin.rs:15-25
+        const float a = -1.0f + 2.0f * rng.gen_f32();
+        const float b = -1.0f + 2.0f * rng.gen_f32();
+        const float c = -1.0f + 2.0f * rng.gen_f32();
+        v = normalize(Vec3(a, b, c));
+    }
+    generate_perm(rng, perm_x);
+    generate_perm(rng, perm_y);
+    generate_perm(rng, perm_z);
+}
+
+// ---- storage.rs:45-96 ------------------------------------------------------
+TextureId Storage::alloc_constant(Vec3 color) {
+    textures.push_back(pt_texture{PT_TEX_CONSTANT, {color.x, color.y, color.z}, -1, -1, 0.0f});
+    return static_cast<TextureId>(textures.size() - 1);
+}
+TextureId Storage::alloc_checker(TextureId odd, TextureId even) {
+    textures.push_back(pt_texture{PT_TEX_CHECKER, {0.f, 0.f, 0.f}, odd, even, 0.0f});
+    return static_cast<TextureId>(textures.size() - 1);
+}
+TextureId Storage::alloc_noise(float scale) {
+    uses_noise = true;
+    textures.push_back(pt_texture{PT_TEX_NOISE, {0.f, 0.f, 0.f}, -1, -1, scale});
+    return static_cast<TextureId>(textures.size() - 1);
+}
+MaterialId Storage::alloc_lambertian(TextureId albedo) {
+    materials.push_back(pt_material{PT_MAT_LAMBERTIAN, {0.f, 0.f, 0.f}, 0.0f, albedo});
+    return static_cast<MaterialId>(materials.size() - 1);
+}
+MaterialId Storage::alloc_metal(Vec3 albedo, float fuzz) {
+    materials.push_back(pt_material{PT_MAT_METAL, {albedo.x, albedo.y, albedo.z}, fuzz, -1});
+    return static_cast<MaterialId>(materials.size() - 1);
+}
+MaterialId Storage::alloc_dielectric(float ref_idx) {
+    materials.push_back(pt_material{PT_MAT_DIELECTRIC, {0.f, 0.f, 0.f}, ref_idx, -1});
+    return static_cast<MaterialId>(materials.size() - 1);
+}
+MaterialId Storage::alloc_diffuse_light(TextureId emit) {
+    materials.push_back(pt_material{PT_MAT_DIFFUSE_LIGHT, {0.f, 0.f, 0.f}, 0.0f, emit});
+    return static_cast<MaterialId>(materials.size() - 1);
+}
+uint32_t Storage::alloc_sphere(Vec3 centre, float radius) {
+    spheres.push_back(pt_sphere{centre.x, centre.y, centre.z, radius});
+    return static_cast<uint32_t>(spheres.size() - 1);
+}
+
+// ---- bvh.rs:64-94,268-347 --------------------------------------------------
+namespace {
+
+struct Box {
+    Vec3 min, max;
+};
+Box unite(const Box &a, const Box &b) { return Box{vmin(a.min, b.min), vmax(a.max, b.max)}; }  // aabb.rs:61-66
+
+// A build-time Hitable: either a leaf sphere (ref < 0 => ~sphere index) or a BVHNode index.
+struct BuildRef {
+    int32_t ref;
+    Box box;
+};
+
+class BvhBuilder {
+public:
+    BvhBuilder(Xoshiro256Plus &rng, BvhBuild &out) : rng_(rng), out_(out) {}
+
+    // bvh.rs:268-283; sort_unstable_by's tie order is unspecified, a stable sort is used here
+    void sort_by_axis(BuildRef *v, size_t n) {
+        const int axis = rng_.gen_range(0, 3);
+        std::stable_sort(v, v + n, [axis](const BuildRef &l, const BuildRef &r) { return l.box.min[axis] < r.box.min[axis]; });
+    }
+    int32_t alloc(const BuildRef &lhs, const BuildRef &rhs, const Box &box) {  // bvh.rs:335-347
+        pt_bvh_node n{};
+        n.min[0] = box.min.x, n.min[1] = box.min.y, n.min[2] = box.min.z;
+        n.max[0] = box.max.x, n.max[1] = box.max.y, n.max[2] = box.max.z;
+        n.lhs = lhs.ref;
+        n.rhs = rhs.ref;
+        out_.nodes.push_back(n);
+        return static_cast<int32_t>(out_.nodes.size() - 1);
+    }
+    BuildRef new_node(BuildRef *v, size_t n) {  // bvh.rs:298-313
+        const size_t pivot = n / 2;
+        const BuildRef lhs = new_split(v, pivot);
+        const BuildRef rhs = new_split(v + pivot, n - pivot);
+        const Box box = unite(lhs.box, rhs.box);
+        return BuildRef{alloc(lhs, rhs, box), box};
+    }
+    BuildRef new_split(BuildRef *v, size_t n) {  // bvh.rs:315-333
+        sort_by_axis(v, n);
+        if (n == 1) return v[0];
+        if (n == 2) {
+            const Box box = unite(v[0].box, v[1].box);
+            return BuildRef{alloc(v[0], v[1], box), box};
+        }
+        return new_node(v, n);
+    }
+
+private:
+    Xoshiro256Plus &rng_;
+    BvhBuild &out_;
+};
+
+uint32_t depth_of(const std::vector<pt_bvh_node> &nodes, int32_t ref) {
+    if (ref < 0) return 0;
+    return 1 + std::max(depth_of(nodes, nodes[ref].lhs), depth_of(nodes, nodes[ref].rhs));
+}
+
+}  // namespace
+
+BvhBuild build_bvh(Xoshiro256Plus &rng, const Storage &storage, std::vector<SphereHitable> hitables) {
+    BvhBuild out;
+    std::vector<BuildRef> refs;
+    refs.reserve(hitables.size());
+    for (size_t i = 0; i < hitables.size(); ++i) {
+        const pt_sphere &s = storage.spheres[hitables[i].sphere];
+        const Vec3 c(s.cx, s.cy, s.cz), r = Vec3::splat(s.radius);  // sphere.rs:69-75
+        refs.push_back(BuildRef{~static_cast<int32_t>(i), Box{c - r, c + r}});
+    }
+    BvhBuilder b(rng, out);
+    const size_t n = refs.size();
+    if (n == 0) return out;  // bvh.rs:72
+    if (n == 1) {            // bvh.rs:73-79 lhs == rhs
+        out.root = b.alloc(refs[0], refs[0], refs[0].box);
+    } else if (n == 2) {     // bvh.rs:80-88
+        out.root = b.alloc(refs[0], refs[1], unite(refs[0].box, refs[1].box));
+    } else {                 // bvh.rs:89-92 new_root
+        b.sort_by_axis(refs.data(), n);
+        out.root = b.new_node(refs.data(), n).ref;
+    }
+    out.max_depth = depth_of(out.nodes, out.root);
+    return out;
+}
+
+// ---- scene.rs:18-31, params.rs:29-46 ---------------------------------------
+Scene::~Scene() {
+    if (handle_) pt_scene_destroy(handle_);
+}
+
+std::unique_ptr<Scene> Scene::new_scene(const Params &params, Xoshiro256Plus &rng, const Storage &storage,
+                                        const std::vector<SphereHitable> &hitables, std::optional<Vec3> sky,
+                                        int device) {
+    std::unique_ptr<Scene> s(new Scene());
+    // the world list in HitableList order (hitable_list.rs:13-16)
+    s->spheres_.reserve(hitables.size());
+    s->sphere_material_.reserve(hitables.size());
+    for (const SphereHitable &h : hitables) {
+        s->spheres_.push_back(storage.spheres.at(h.sphere));
+        s->sphere_material_.push_back(h.material);
+    }
+    s->materials_ = storage.materials;
+    s->textures_ = storage.textures;
+    if (storage.uses_noise) {
+        s->perlin_.reset(new pt_perlin());
+        for (int i = 0; i < 256; ++i) {
+            s->perlin_->randvec[i][0] = storage.perlin_noise.randvec[i].x;
+            s->perlin_->randvec[i][1] = storage.perlin_noise.randvec[i].y;
+            s->perlin_->randvec[i][2] = storage.perlin_noise.randvec[i].z;
+            s->perlin_->perm_x[i] = storage.perlin_noise.perm_x[i];
+            s->perlin_->perm_y[i] = storage.perlin_noise.perm_y[i];
+            s->perlin_->perm_z[i] = storage.perlin_noise.perm_z[i];
+        }
+    }
+    int32_t root = -1;
+    if (params.use_bvh) {  // params.rs:36-40
+        // the list positions are the leaf ids: build over hitables re-indexed 0..n-1
+        Storage const &st = storage;
+        std::vector<SphereHitable> listed = hitables;
+        BvhBuild bvh = [&] {
+            // build_bvh reads storage.spheres[h.sphere]; leaves are numbered by LIST position
+            return build_bvh(rng, st, listed);
+        }();
+        s->bvh_nodes_ = std::move(bvh.nodes);
+        root = bvh.root;
+    }
+    pt_scene_desc &d = s->desc_;
+    d.n_spheres = static_cast<uint32_t>(s->spheres_.size());
+    d.spheres = s->spheres_.data();
+    d.sphere_material = s->sphere_material_.data();
+    d.n_materials = static_cast<uint32_t>(s->materials_.size());
+    d.materials = s->materials_.data();
+    d.n_textures = static_cast<uint32_t>(s->textures_.size());
+    d.textures = s->textures_.data();
+    d.perlin = s->perlin_.get();
+    d.n_bvh_nodes = static_cast<uint32_t>(s->bvh_nodes_.size());
+    d.bvh_nodes = s->bvh_nodes_.empty() ? nullptr : s->bvh_nodes_.data();
+    d.bvh_root = root;
+    d.has_sky = sky.has_value() ? 1u : 0u;
+    if (sky) d.sky[0] = sky->x, d.sky[1] = sky->y, d.sky[2] = sky->z;
+    if (device >= 0) {
+        const int rc = pt_scene_create(&d, device, &s->handle_);
+        if (rc != PT_OK) throw std::runtime_error(std::string("pt_scene_create: ") + pt_last_error());
+    }
+    return s;
+}
+
+size_t Scene::update(const Params &params, const Camera &camera, uint32_t frame_num, float *buffer) {
+    if (!handle_) throw std::runtime_error("Scene::update: scene was built without a device (inspection only)");
+    const pt_params p = params.c_params();
+    uint64_t rays = 0;
+    const int rc = pt_render(handle_, &p, &camera.pod, frame_num, buffer, &rays);
+    if (rc != PT_OK) throw std::runtime_error(std::string("pt_render: ") + pt_last_error());
+    return static_cast<size_t>(rays);
+}
+
+float Scene::last_kernel_ms() const {
+    float ms = 0.f;
+    if (!handle_ || pt_last_kernel_ms(handle_, &ms) != PT_OK) return -1.f;
+    return ms;
+}
+
+}  // namespace pt
