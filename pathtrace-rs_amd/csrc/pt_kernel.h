@@ -43,7 +43,7 @@ struct DCamera {  // camera.rs:8-19
 struct KArgs {
     // scene (HBM resident)
     const float4 *spheres;       // cx, cy, cz, radius
-    const float4 *spheres_r2;    // cx, cy, cz, radius*radius (sphere.rs:36), scan layout
+    const float4 *spheres_r2;    // cx, cy, cz, radius*radius (sphere.rs:36), scan layout, padded to n_spheres_pad
     const uint32_t *sphere_mat;  // material index per sphere
     const DMat *mats;
     const DTex *texs;
@@ -51,6 +51,7 @@ struct KArgs {
     const uint32_t *perlin_perm; // 768 entries: perm_x | perm_y | perm_z
     const DNode *nodes;
     uint32_t n_spheres;
+    uint32_t n_spheres_pad;      // multiple of kScanUnroll; padding entries can never be hit
     int32_t bvh_root;
     uint32_t has_sky;
     f3 sky;
@@ -153,21 +154,78 @@ __device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float
     return false;
 }
 
-// hitable_list.rs:40-56 over sphere.rs:29-66: wave-uniform scan, sphere data
-// broadcast from LDS (s_sph[k] = cx, cy, cz, r*r).
-__device__ __forceinline__ int intersect_list(const float4 *s_sph, int n, f3 o, f3 d, float a, float &t_out) {
-    float closest = kMaxT;
-    int idx = -1;
-    for (int k = 0; k < n; ++k) {
-        const float4 c = s_sph[k];
-        const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
-        const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
-        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
-        const float disc = b * b - a * cc;
-        if (disc > 0.0f) {
+// hitable_list.rs:40-56 over sphere.rs:29-66, restructured for the GPU in two phases that
+// together perform exactly the reference's sequence of accepted hits:
+//
+//  phase 1 (wave-uniform, branch-free): for every sphere k compute the reference's
+//     discriminant with the reference's operation order (sphere.rs:33-37). Lanes whose
+//     discriminant is > 0 append k to a per-lane candidate queue in LDS (unconditional
+//     ds_write to slot `cnt`, then cnt += pass). Spheres with discriminant <= 0 do
+//     nothing in the reference either (sphere.rs:38), so skipping them is exact.
+//  phase 2 (per-lane, short): replay the queued spheres IN INDEX ORDER through the exact
+//     root / t_min / closest_so_far logic (sphere.rs:38-64, hitable_list.rs:48-54).
+//
+// The sphere table is read 8 entries at a time (kScanUnroll) so the loads of a group are
+// in flight before its arithmetic starts; the table is padded to a multiple of 8 with
+// (3e38, 3e38, 3e38, 0) entries whose discriminant is NaN or -inf.
+constexpr int kScanUnroll = 8;
+constexpr int kQueueCap = 16;  // per-lane candidate slots (u16), drained when a lane exceeds kQueueCap - kScanUnroll
+
+__device__ __forceinline__ void drain_candidates(const float4 *sph, const uint16_t *q, uint32_t &cnt, f3 o, f3 d,
+                                                 float a, float &closest, int &idx) {
+    for (uint32_t j = 0; __any(j < cnt); ++j) {
+        if (j < cnt) {
+            const int k = q[j * kBlock];
+            const float4 c = sph[k];
+            const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
+            const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+            const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
+            const float disc = b * b - a * cc;
             if (sphere_roots(a, b, disc, closest)) idx = k;
         }
     }
+    cnt = 0;
+}
+
+// sph: (cx, cy, cz, r*r) table with n_pad (multiple of kScanUnroll) entries, in LDS or HBM;
+// q: this lane's column of the [kQueueCap+1][kBlock] u16 queue in LDS.
+// The per-sphere pass/fail is kept as a wave lane mask (v_cmp -> SGPR pair); lanes touch their
+// queue only inside the (rare) groups where some lane passed.
+__device__ __forceinline__ int intersect_list(const float4 *sph, int n_pad, uint16_t *q, f3 o, f3 d, float a,
+                                              float &t_out) {
+    float closest = kMaxT;
+    int idx = -1;
+    uint32_t cnt = 0;
+    for (int k0 = 0; k0 < n_pad; k0 += kScanUnroll) {
+        float4 c[kScanUnroll];
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) c[u] = sph[k0 + u];
+        float disc[kScanUnroll];
+#pragma unroll
+        for (int u = 0; u < kScanUnroll; ++u) {
+            const float ocx = o.x - c[u].x, ocy = o.y - c[u].y, ocz = o.z - c[u].z;
+            const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+            const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c[u].w;
+            disc[u] = b * b - a * cc;
+        }
+        // one compare per group: max over the group's discriminants (v_max3; NaNs are ignored by
+        // maxNum exactly as `NaN > 0` is false)
+        float m = __builtin_fmaxf(__builtin_fmaxf(disc[0], disc[1]), disc[2]);
+#pragma unroll
+        for (int u = 3; u + 1 < kScanUnroll; u += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, disc[u]), disc[u + 1]);
+        if ((kScanUnroll & 1) == 0) m = __builtin_fmaxf(m, disc[kScanUnroll - 1]);
+        if (__any(m > 0.0f)) {
+#pragma unroll
+            for (int u = 0; u < kScanUnroll; ++u) {
+                if (disc[u] > 0.0f) {
+                    q[cnt * kBlock] = (uint16_t)(k0 + u);
+                    cnt += 1;
+                }
+            }
+            if (__any(cnt > (uint32_t)(kQueueCap - kScanUnroll))) drain_candidates(sph, q, cnt, o, d, a, closest, idx);
+        }
+    }
+    drain_candidates(sph, q, cnt, o, d, a, closest, idx);
     t_out = closest;
     return idx;
 }
@@ -244,13 +302,15 @@ __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
     p += A.has_noise ? (4096 + 3072) : 0;
     uint32_t *s_bvh = reinterpret_cast<uint32_t *>(p);
     p += BVH ? (kBvhStack * kBlock * 4) : 0;
+    uint16_t *s_queue = reinterpret_cast<uint16_t *>(p);  // list mode: [kQueueCap+1][kBlock] u16
+    p += BVH ? 0 : ((kQueueCap + 1) * kBlock * 2 + 15) / 16 * 16;
     float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][kBlock] attenuation stack
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
     if (!BVH && SPH_LDS) {
-        for (uint32_t k = tid; k < A.n_spheres; k += kBlock) s_sph[k] = A.spheres_r2[k];
+        for (uint32_t k = tid; k < A.n_spheres_pad; k += kBlock) s_sph[k] = A.spheres_r2[k];
     }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += kBlock) s_pvec[k] = A.perlin_vec[k];
@@ -333,7 +393,8 @@ __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
         if (BVH)
             idx = intersect_bvh(A, s_bvh, ro, rd, a, have, t_hit);
         else
-            idx = intersect_list(SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, (int)A.n_spheres, ro, rd, a, t_hit);
+            idx = intersect_list(SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, (int)A.n_spheres_pad, s_queue + tid, ro, rd,
+                                 a, t_hit);
 
         // ---- scene.rs:49-71 one level of ray_trace
         if (have) {

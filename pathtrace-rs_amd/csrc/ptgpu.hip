@@ -197,7 +197,8 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
     s->has_noise = has_noise ? 1u : 0u;
 
     // flatten to the device layouts
-    std::vector<float4> sph(desc->n_spheres), sph_r2(desc->n_spheres);
+    const uint32_t n_pad = (desc->n_spheres + kScanUnroll - 1) / kScanUnroll * kScanUnroll;
+    std::vector<float4> sph(desc->n_spheres), sph_r2(n_pad, make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f));
     for (uint32_t i = 0; i < desc->n_spheres; ++i) {
         const pt_sphere &p = desc->spheres[i];
         sph[i] = make_float4(p.cx, p.cy, p.cz, p.radius);
@@ -308,6 +309,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.perlin_perm = s->d_perlin_perm;
     A.nodes = s->d_nodes;
     A.n_spheres = s->n_spheres;
+    A.n_spheres_pad = (s->n_spheres + kScanUnroll - 1) / kScanUnroll * kScanUnroll;
     A.bvh_root = s->bvh_root;
     A.has_sky = s->has_sky;
     A.sky = to3(s->sky);
@@ -357,13 +359,14 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     uint32_t sph_bytes = 0;
     bool sph_lds = false;
     if (!bvh) {
-        sph_bytes = ((s->n_spheres * 16u) + 15u) & ~15u;
+        sph_bytes = A.n_spheres_pad * 16u;
         sph_lds = (s->variant != 1u) && sph_bytes <= 64u * 1024u;
         if (!sph_lds) sph_bytes = 0;
     }
     uint32_t lds = sph_bytes;
     if (s->has_noise) lds += 4096u + 3072u;
     if (bvh) lds += (uint32_t)kBvhStack * kBlock * 4u;
+    if (!bvh) lds += ((kQueueCap + 1) * kBlock * 2u + 15u) / 16u * 16u;
     const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
     A.stack_in_lds = (lds + path_bytes <= kLdsPerBlockMax) ? 1u : 0u;
     if (A.stack_in_lds) lds += (uint32_t)path_bytes;
@@ -371,7 +374,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
 
     // ---- persistent grid: CUs x resident blocks --------------------------------
     uint32_t bpc = s->blocks_per_cu;
-    if (bpc == 0) bpc = bvh ? 2u : 2u;
+    if (bpc == 0) bpc = bvh ? 2u : 3u;
     const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
     if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
     if (bpc > 8u) bpc = 8u;
