@@ -105,6 +105,7 @@ def main():
 
     ptgpu = _load("pathtrace_rs_amd_ptgpu", "pathtrace-rs_amd/ptgpu.py")
     pthost = _load("pathtrace_rs_amd_pthost", "pathtrace-rs_amd/pthost.py")
+    sharding = _load("pathtrace_rs_amd_sharding", "pathtrace-rs_amd/sharding.py")
 
     # scene + camera built by the C++ host (presets.rs / camera.rs mirror), uploaded via the C ABI
     hs = pthost.HostScene(args.preset, W, H, samples=S, use_bvh=args.bvh, device=local_rank)
@@ -114,8 +115,7 @@ def main():
     cam = hs.camera
 
     stream = torch.cuda.current_stream()
-    rows = ptgpu.shard_rows(H, rank % N, N) if N > 1 else H
-    max_rows = (H + N - 1) // N
+    max_rows = sharding.padded_rows(H, N)
     shard = torch.zeros((max_rows, W, 3), dtype=torch.float32, device=dev)
     ray_count = torch.zeros(1, dtype=torch.int64, device=dev)
     gathered = torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev) if N > 1 else None
@@ -131,10 +131,8 @@ def main():
         else:
             scene.update_shard_device(params, cam, 0, rank, N, shard.data_ptr(), ray_count.data_ptr(),
                                       stream.cuda_stream)
-            dist.all_gather_into_tensor(gathered, shard)          # RCCL over xGMI: 1 collective / frame
-            dist.all_reduce(ray_count)                            # scene.rs:118-120
-            # de-interleave: frame row y = j*N + r  <-  gathered[r, j]
-            frame = gathered.permute(1, 0, 2, 3).reshape(max_rows * N, W, 3)[:H]
+            # RCCL over xGMI: ONE all_gather per frame (+ 8-byte all_reduce, scene.rs:118-120), de-interleave
+            frame = sharding.gather_frame(dist, shard, gathered, ray_count, H)
         return frame
 
     def fence():

@@ -170,6 +170,15 @@ int pt_last_launch_info(pt_scene *scene, uint32_t *grid_out, uint32_t *block_out
  * persistent grid, and kernel variant ("kernel variants"). */
 int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
 
+/* Device self-test probes (diagnostics for the parity tests; not part of the reference's
+ * interface): evaluate one device primitive on n host inputs.
+ *   PT_PROBE_POW5    out[i] = device x^5 used by schlick (math.rs:79 powf(x, 5.0))
+ *   PT_PROBE_SIN/COS out[i] = sinf_cosf(in[i]) (simd.rs:107-208)
+ *   PT_PROBE_RNG     in[i] reinterpreted as a u32 seed s; out[i] = the (i%16+1)-th gen::<f32>() of
+ *                    Xoshiro256Plus::seed_from_u64(s) */
+enum { PT_PROBE_POW5 = 0, PT_PROBE_SIN = 1, PT_PROBE_COS = 2, PT_PROBE_RNG = 3 };
+int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n);
+
 /* Thread-local message describing the last error returned on this thread. */
 const char *pt_last_error(void);
 

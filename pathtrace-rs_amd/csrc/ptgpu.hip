@@ -470,3 +470,49 @@ extern "C" int pt_last_launch_info(pt_scene *s, uint32_t *grid_out, uint32_t *bl
     if (lds_bytes_out) *lds_bytes_out = s->last_lds;
     return PT_OK;
 }
+
+// ---- device self-test probes ---------------------------------------------------
+namespace {
+__global__ void probe_kernel(uint32_t probe, const float *in, float *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    float r = 0.f, s, c;
+    switch (probe) {
+    case PT_PROBE_POW5: r = pow5_ref(x); break;
+    case PT_PROBE_SIN: sinf_cosf_ref(x, s, c); r = s; break;
+    case PT_PROBE_COS: sinf_cosf_ref(x, s, c); r = c; break;
+    default: {
+        Rng rng;
+        rng_seed_from_u64(rng, (uint64_t)__float_as_uint(x));
+        for (size_t k = 0; k <= (i & 15); ++k) r = rng_f32(rng);
+    }
+    }
+    out[i] = r;
+}
+}  // namespace
+
+extern "C" int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n) {
+    if (!in || !out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (probe > PT_PROBE_RNG) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
+    if (n == 0) return PT_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
+    HIP_TRY(hipSetDevice(device));
+    float *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_in, n * sizeof(float)));
+    if (hipMalloc((void **)&d_out, n * sizeof(float)) != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(PT_ERR_HIP, "hipMalloc failed");
+    }
+    hipError_t e = hipMemcpy(d_in, in, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, probe, d_in, d_out, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(PT_ERR_HIP, "probe failed: %s", hipGetErrorString(e));
+    return PT_OK;
+}

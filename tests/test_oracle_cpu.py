@@ -1,0 +1,293 @@
+"""CPU suite: the oracle (oracle/ptref.c) against the external pins and the committed golden fixtures.
+
+The reference ships no tests or golden vectors, so the pins are: the public
+xoshiro256+/SplitMix64 vectors, the survey-derived fixtures of SURVEY.md 8c, hand-derived
+known answers for the geometric primitives, and oracle-rendered frames guarding against drift.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+KAT = json.load(open(os.path.join(GOLDEN, "rng_kat.json")))
+
+
+def _state(vals):
+    import ctypes
+    return (ctypes.c_uint64 * 4)(*vals)
+
+
+def test_xoshiro_public_vector(oracle):
+    L = oracle.lib()
+    st = _state([1, 2, 3, 4])
+    got = [L.ora_xoshiro_next_u64(st) for _ in range(10)]
+    assert got == KAT["xoshiro256plus_state_1_2_3_4_next_u64"]
+
+
+def test_splitmix64_seed0(oracle):
+    import ctypes
+    L = oracle.lib()
+    out = (ctypes.c_uint64 * 4)()
+    L.ora_splitmix64(0, out, 4)
+    assert ["%016x" % v for v in out] == KAT["splitmix64_seed0"]
+
+
+def test_seed_from_u64_streams(oracle):
+    L = oracle.lib()
+    st = _state([0, 0, 0, 0])
+    L.ora_xoshiro_seed_from_u64(0, st)
+    got = [float(np.float32(L.ora_xoshiro_gen_f32(st))) for _ in range(6)]
+    assert got == KAT["seed_from_u64_0_first_f32"]
+    L.ora_xoshiro_seed_from_u64(1, st)
+    assert ["%016x" % v for v in st] == KAT["seed_from_u64_1_state"]
+    got = [float(np.float32(L.ora_xoshiro_gen_f32(st))) for _ in range(6)]
+    assert got == KAT["seed_from_u64_1_first_f32"]
+
+
+def test_gen_f32_is_24_bits_in_unit_interval(oracle):
+    L = oracle.lib()
+    st = _state([0, 0, 0, 0])
+    L.ora_xoshiro_seed_from_u64(12345, st)
+    v = np.array([L.ora_xoshiro_gen_f32(st) for _ in range(4000)], np.float32)
+    assert v.min() >= 0.0 and v.max() < 1.0
+    assert np.all(v * 16777216.0 == np.floor(v * 16777216.0))  # multiples of 2^-24
+
+
+def test_pixel_seeds(oracle):
+    L = oracle.lib()
+    for key, want in KAT["pixel_seeds_frame0"].items():
+        x, y = map(int, key.split(","))
+        assert L.ora_pixel_seed(x, y, 0) == want
+    assert L.ora_pixel_seed(2, 0, 0) == (2 * 1973) | 1  # even sums get the low bit forced
+    assert L.ora_pixel_seed(0, 0, 3) == (3 * 26699) | 1
+
+
+def test_gen_range_0_3(oracle):
+    L = oracle.lib()
+    st = _state([0, 0, 0, 0])
+    L.ora_xoshiro_seed_from_u64(7, st)
+    v = np.array([L.ora_xoshiro_gen_range_i32(st, 0, 3) for _ in range(6000)])
+    assert set(np.unique(v)) == {0, 1, 2}
+    assert np.all(np.bincount(v) > 1800)
+
+
+def test_random_spheres_build_ledger(oracle):
+    led = KAT["random_spheres_ledger"]
+    sc = oracle.OracleScene("random_spheres", 1200, 800)
+    ex = sc.export()
+    assert ex["build_draws"] == led["total_draws"]
+    assert len(ex["spheres"]) == led["spheres"]
+    kinds = ex["materials"][ex["sphere_material"][1:485], 0]
+    assert (kinds == 0).sum() == led["lambertian"]
+    assert (kinds == 1).sum() == led["metal"]
+    assert (kinds == 2).sum() == led["dielectric"]
+    np.testing.assert_allclose(ex["spheres"][1, :3], led["first_small_centre"], rtol=0, atol=1e-6)
+    tex = int(ex["materials"][ex["sphere_material"][1], 5])
+    np.testing.assert_allclose(ex["textures"][tex, 1:4], led["first_small_albedo"], rtol=0, atol=1e-8)
+    # ground: checker(constant, constant) r = 1000; tail: dielectric / lambertian / metal r = 1
+    assert ex["spheres"][0].tolist() == [0.0, -1000.0, 0.0, 1000.0]
+    assert ex["textures"][int(ex["materials"][0, 5]), 0] == 1
+    assert ex["materials"][ex["sphere_material"][485:], 0].tolist() == [2.0, 0.0, 1.0]
+    # Storage::new consumes 1536 draws before any preset (perlin.rs:15-51)
+    assert oracle.OracleScene("small", 200, 100).export()["build_draws"] == 1536
+
+
+def test_unknown_preset_returns_none(oracle):
+    with pytest.raises(KeyError):
+        oracle.OracleScene("cornell", 64, 64)
+
+
+def test_sinf_cosf_accuracy_and_quadrants(oracle):
+    import ctypes
+    L = oracle.lib()
+    s, c = ctypes.c_float(), ctypes.c_float()
+    xs = np.linspace(0, 2 * np.pi, 4001, dtype=np.float32)
+    err = 0.0
+    for x in xs:
+        L.ora_sinf_cosf(float(x), ctypes.byref(s), ctypes.byref(c))
+        err = max(err, abs(s.value - np.sin(np.float64(x))), abs(c.value - np.cos(np.float64(x))))
+    assert err < 3e-7
+    L.ora_sinf_cosf(0.0, ctypes.byref(s), ctypes.byref(c))
+    assert (s.value, c.value) == (0.0, 1.0)
+    L.ora_sinf_cosf(-1.0, ctypes.byref(s), ctypes.byref(c))  # sine is odd, cosine even
+    s1, c1 = ctypes.c_float(), ctypes.c_float()
+    L.ora_sinf_cosf(1.0, ctypes.byref(s1), ctypes.byref(c1))
+    assert s.value == -s1.value and c.value == c1.value
+
+
+def _hit(L, sphere, o, d, tmin=0.001, tmax=3.4028234663852886e38):
+    out = np.zeros(9, np.float32)
+    s_, o_, d_ = (np.asarray(v, np.float32) for v in (sphere, o, d))  # keep the temporaries alive across the call
+    ok = L.ora_sphere_ray_hit(s_.ctypes.data, o_.ctypes.data, d_.ctypes.data, tmin, tmax, out.ctypes.data)
+    return ok, out
+
+
+def test_sphere_ray_hit_known_answers(oracle):
+    L = oracle.lib()
+    # head-on: unit sphere at z = -5, ray down -z: near root 4, normal towards the ray
+    ok, h = _hit(L, [0, 0, -5, 1], [0, 0, 0], [0, 0, -1])
+    assert ok and h[6] == 4.0 and h[:3].tolist() == [0, 0, -4] and h[3:6].tolist() == [0, 0, 1]
+    # origin inside the sphere: near root is negative -> far root (sphere.rs:53-64)
+    ok, h = _hit(L, [0, 0, 0, 2], [0, 0, 0], [1, 0, 0])
+    assert ok and h[6] == 2.0 and h[3:6].tolist() == [1, 0, 0]
+    # negative radius flips the normal (presets.rs:265 hollow glass)
+    ok, h = _hit(L, [0, 0, -5, -1], [0, 0, 0], [0, 0, -1])
+    assert ok and h[6] == 4.0 and h[3:6].tolist() == [0, 0, -1]
+    # t_max narrowing is strict: a hit at exactly t_max is rejected, so the earlier list entry wins ties
+    ok, _ = _hit(L, [0, 0, -5, 1], [0, 0, 0], [0, 0, -1], tmax=4.0)
+    assert not ok
+    ok, _ = _hit(L, [0, 0, -5, 1], [0, 0, 0], [0, 0, -1], tmax=4.0000005)
+    assert ok
+    # miss, tangent (discriminant == 0 is a miss: sphere.rs:38 uses > 0) and behind
+    assert not _hit(L, [0, 3, -5, 1], [0, 0, 0], [0, 0, -1])[0]
+    assert not _hit(L, [0, 1, -5, 1], [0, 0, 0], [0, 0, -1])[0]
+    assert not _hit(L, [0, 0, 5, 1], [0, 0, 0], [0, 0, -1])[0]
+    # unnormalised direction: t scales by 1/|d| because a = d.d divides (sphere.rs:40)
+    ok, h = _hit(L, [0, 0, -5, 1], [0, 0, 0], [0, 0, -2])
+    assert ok and h[6] == 2.0
+
+
+def test_aabb_slab_and_nan_rule(oracle):
+    L = oracle.lib()
+    def hit(mn, mx, o, d):
+        arrs = [np.asarray(v, np.float32) for v in (mn, mx, o, d)]
+        return L.ora_aabb_ray_hit(*[x.ctypes.data for x in arrs], 0.001, 3.4028234663852886e38)
+    assert hit([-1, -1, -6], [1, 1, -4], [0, 0, 0], [0, 0, -1])
+    assert not hit([-1, -1, -6], [1, 1, -4], [0, 3, 0], [0, 0, -1])
+    assert not hit([-1, -1, 4], [1, 1, 6], [0, 0, 0], [0, 0, -1])          # behind
+    # origin exactly on a slab plane with a zero direction component: (min - o) * inf = 0 * inf = NaN.
+    # _mm_min_ps/_mm_max_ps return the SECOND operand on NaN (aabb.rs:51-54): t0 = max_delta = +inf,
+    # t1 = max_delta = +inf -> tmax(=f32::MAX) > tmin(=+inf) is false -> miss.
+    assert not hit([0, -1, -6], [1, 1, -4], [0, 0, 0], [0, 0, -1])
+
+
+def test_schlick_and_refraction_edge(oracle):
+    L = oracle.lib()
+    r0 = ((1 - 1.5) / (1 + 1.5)) ** 2
+    assert abs(L.ora_schlick(1.0, 1.5) - r0) < 1e-7          # normal incidence
+    assert abs(L.ora_schlick(0.0, 1.5) - 1.0) < 1e-7         # grazing
+    assert np.isnan(L.ora_schlick(float("nan"), 1.5))        # NaN cosine -> NaN -> `draw > NaN` is false
+
+
+def test_sampling_draw_counts(oracle):
+    L = oracle.lib()
+    out = np.zeros(3, np.float32)
+    st = _state([0, 0, 0, 0])
+    L.ora_xoshiro_seed_from_u64(99, st)
+    ref = _state(list(st))
+    L.ora_random_unit_vector(st, out.ctypes.data)             # exactly 2 draws (math.rs:29-30)
+    for _ in range(2):
+        L.ora_xoshiro_next_u64(ref)
+    assert list(st) == list(ref)
+    assert abs(float(np.dot(out.astype(np.float64), out.astype(np.float64))) - 1.0) < 1e-6
+    for fn, per in ((L.ora_random_in_unit_sphere, 3), (L.ora_random_in_unit_disk, 2)):
+        L.ora_xoshiro_seed_from_u64(5, st)
+        ref = _state(list(st))
+        fn(st, out.ctypes.data)
+        assert float(np.dot(out, out)) < 1.0
+        n = 0
+        while list(ref) != list(st) and n < 200:
+            L.ora_xoshiro_next_u64(ref)
+            n += 1
+        assert n > 0 and n % per == 0                            # rejection loop: whole iterations only
+
+
+def test_camera_get_ray_draws_even_without_aperture(oracle):
+    L = oracle.lib()
+    cam = np.zeros(24, np.float32)
+    lf, la, up = (np.asarray(v, np.float32) for v in ([13, 2, 3], [0, 0, 0], [0, 1, 0]))
+    L.ora_camera_new(lf.ctypes.data, la.ctypes.data, up.ctypes.data, 20.0, 1.5, 0.0, 10.0, 0.0, 0.0, cam.ctypes.data)
+    assert cam[23] == 0.0 and cam[0:3].tolist() == [13, 2, 3]
+    st = _state([0, 0, 0, 0])
+    L.ora_xoshiro_seed_from_u64(3, st)
+    before = list(st)
+    out = np.zeros(7, np.float32)
+    L.ora_camera_get_ray(cam.ctypes.data, 0.5, 0.5, st, out.ctypes.data)
+    assert list(st) != before                                     # disk loop + time draw still consume (math.rs:6-13)
+    assert out[0:3].tolist() == [13, 2, 3]                        # zero aperture -> origin unchanged
+    d = out[3:6].astype(np.float64)
+    want = -np.array([13, 2, 3.0]) / np.linalg.norm([13, 2, 3.0])
+    np.testing.assert_allclose(d, want, atol=2e-6)               # centre ray looks at the origin
+
+
+def test_perlin_saturating_cast_and_range(oracle):
+    sc = oracle.OracleScene("two_perlin_spheres", 64, 64)
+    L = oracle.lib()
+    # negative coordinates: `floor(x) as usize` saturates to 0, so cells x in [-1,0) and [-2,-1) share gradients
+    p1, p2 = np.asarray([-0.25, 0.5, 0.5], np.float32), np.asarray([-1.25, 0.5, 0.5], np.float32)
+    n1 = L.ora_perlin_noise(sc.h, p1.ctypes.data)
+    n2 = L.ora_perlin_noise(sc.h, p2.ctypes.data)
+    assert n1 == n2
+    pts = np.random.default_rng(0).uniform(-20, 20, size=(500, 3)).astype(np.float32)
+    vals = np.array([L.ora_perlin_noise(sc.h, p.ctypes.data) for p in pts])
+    assert np.all(np.abs(vals) <= 1.0) and vals.std() > 0.05
+    turb = np.array([L.ora_perlin_turb(sc.h, p.ctypes.data) for p in pts])
+    assert np.all(turb >= 0.0)
+
+
+def test_checker_texture_selects_by_sine_sign(oracle):
+    sc = oracle.OracleScene("random_spheres", 120, 80)
+    L = oracle.lib()
+    rgb = np.zeros(3, np.float32)
+    for p in ([0.1, 0.1, 0.1], [0.1, 0.1, -0.1], [3.3, -2.2, 0.7]):
+        pa = np.asarray(p, np.float32)
+        L.ora_texture_value(sc.h, 2, pa.ctypes.data, rgb.ctypes.data)
+        s = np.prod(np.sin(10.0 * np.asarray(p, np.float64)))
+        want = [0.2, 0.3, 0.1] if s < 0 else [0.9, 0.9, 0.9]
+        np.testing.assert_allclose(rgb, want, atol=1e-7)
+
+
+def test_linear_to_srgb(oracle):
+    L = oracle.lib()
+    out = np.zeros(3, np.uint8)
+    v1, v2 = np.asarray([0.0, 1.0, 0.5], np.float32), np.asarray([-1.0, 30.0, float("nan")], np.float32)
+    L.ora_linear_to_srgb(v1.ctypes.data, out.ctypes.data)
+    assert out.tolist() == [0, 255, int((1.055 * 0.5 ** 0.41666666 - 0.055) * 255.99)]
+    L.ora_linear_to_srgb(v2.ctypes.data, out.ctypes.data)
+    assert out.tolist() == [0, 255, 0]
+
+
+def test_list_and_bvh_agree(oracle):
+    for preset, W, H, S in (("small", 80, 40, 4), ("random_spheres", 60, 40, 2), ("aras", 64, 36, 2)):
+        a, ra = oracle.OracleScene(preset, W, H, use_bvh=False).update(S)
+        b, rb = oracle.OracleScene(preset, W, H, use_bvh=True).update(S)
+        assert ra == rb and np.array_equal(a, b)
+
+
+def test_thread_count_does_not_change_results(oracle):
+    sc = oracle.OracleScene("small", 64, 32)
+    a, ra = sc.update(4, nthreads=1)
+    b, rb = sc.update(4, nthreads=5)
+    assert ra == rb and np.array_equal(a, b)
+
+
+def test_frame_accumulation_blend(oracle):
+    sc = oracle.OracleScene("small", 48, 24)
+    f0, _ = sc.update(2, frame_num=0)
+    f1_alone, _ = sc.update(2, frame_num=1, buffer=np.zeros_like(f0))
+    acc, _ = sc.update(2, frame_num=1, buffer=f0.copy())
+    # scene.rs:86-87,114-116: mix_prev = 1/2 at frame 1
+    np.testing.assert_array_equal(acc, f0 * np.float32(0.5) + (f1_alone / np.float32(0.5)) * np.float32(0.5))
+    assert not np.array_equal(f0, f1_alone)                       # frame_num enters the seed
+
+
+def test_max_depth_zero_counts_only_primary_rays(oracle):
+    sc = oracle.OracleScene("small", 40, 20)
+    _, rays = sc.update(3, max_depth=0)
+    assert rays == 40 * 20 * 3
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))))
+def test_oracle_reproduces_golden(oracle, path):
+    g = np.load(path)
+    W, H, S = int(g["width"]), int(g["height"]), int(g["samples"])
+    if W * H * S > 3_000_000 and len(g["pixels"]) * S > 300_000:
+        pytest.skip("large crop: regenerated by make_golden.py, checked on the GPU box against HIP")
+    sc = oracle.OracleScene(str(g["preset"]), W, H, use_bvh=bool(g["use_bvh"]))
+    buf = np.zeros((H, W, 3), np.float32)
+    _, rays = sc.update(S, int(g["depth"]), 0, buffer=buf, pixels=g["pixels"])
+    assert rays == int(g["ray_count"])
+    assert np.array_equal(buf.reshape(-1, 3)[g["pixels"]], g["rgb"])
