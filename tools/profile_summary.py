@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/prof_<tag>/ (tools/profile.sh) into profiles/<tag>_*.{txt,json}."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join("gpurun_out", "prof_" + tag)
+os.makedirs("profiles", exist_ok=True)
+lines = []
+
+
+def find(pattern):
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    return hits[0] if hits else None
+
+
+# 1. kernel stats
+ks = find("stats/**/*kernel_stats.csv")
+kt = find("stats/**/*kernel_trace.csv")
+lines.append("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
+avg_ms = None
+if ks:
+    for r in csv.DictReader(open(ks)):
+        lines.append("%-70s calls %s total_ns %s avg_ns %s pct %s" % (r["Name"][:70], r["Calls"], r["TotalDurationNs"],
+                                                                    r["AverageNs"], r["Percentage"]))
+        if "pt_trace_kernel" in r["Name"]:
+            avg_ms = float(r["AverageNs"]) / 1e6
+if kt:
+    durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt))
+            if "pt_trace_kernel" in r["Kernel_Name"]]
+    lines.append("pt_trace_kernel dispatch durations (ms): " + ", ".join("%.3f" % d for d in durs))
+    rows = [r for r in csv.DictReader(open(kt)) if "pt_trace_kernel" in r["Kernel_Name"]]
+    if rows:
+        r = rows[-1]
+        lines.append("launch: grid %s wg %s LDS %s VGPR %s accVGPR %s SGPR %s scratch %s" % (
+            r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("LDS_Block_Size"), r.get("VGPR_Count"),
+            r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("Scratch_Size")))
+
+# 2. PMC passes (sum over dispatches of the trace kernel, then per launch)
+pmc = {}
+for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
+    f = find(d + "/**/*counter_collection.csv")
+    if not f:
+        continue
+    agg, disp = collections.defaultdict(float), set()
+    for r in csv.DictReader(open(f)):
+        if "pt_trace_kernel" in r["Kernel_Name"]:
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+            disp.add(r["Dispatch_Id"])
+    n = max(1, len(disp))
+    for k, v in agg.items():
+        pmc[k] = v / n
+lines.append("")
+lines.append("# PMC counters, per launch of pt_trace_kernel (separate --pmc passes)")
+for k in sorted(pmc):
+    lines.append("%-32s %.6g" % (k, pmc[k]))
+out = {"tag": tag, "kernel_avg_ms": avg_ms, "pmc_per_launch": pmc}
+if "FETCH_SIZE" in pmc or "WRITE_SIZE" in pmc:
+    # MI355X_MICROARCH.md "HBM": counters are in KiB; FETCH_SIZE under-reports wide coalesced reads by 2x on
+    # gfx950, so the read side is doubled before it is compared with byte counts. WRITE_SIZE is uncalibrated.
+    fetch = pmc.get("FETCH_SIZE", 0.0) * 1024 * 2
+    write = pmc.get("WRITE_SIZE", 0.0) * 1024
+    out["hbm_bytes_per_launch"] = fetch + write
+    out["hbm_read_bytes_corrected"] = fetch
+    out["hbm_write_bytes"] = write
+    lines.append("HBM traffic per launch: read %.3f MB (FETCH_SIZE KiB x 1024 x 2 gfx950 correction), write %.3f MB"
+                 % (fetch / 1e6, write / 1e6))
+bl = os.path.join(src, "bench_line.json")
+if os.path.exists(bl) and os.path.getsize(bl):
+    out["bench_line_under_profiler"] = json.load(open(bl))
+    lines.append("")
+    lines.append("# bench.py line under the profiler: value %.1f %s, kernel_ms %.3f" % (
+        out["bench_line_under_profiler"]["value"], out["bench_line_under_profiler"]["unit"],
+        out["bench_line_under_profiler"]["roofline"]["kernel_ms"]))
+open(os.path.join("profiles", tag + "_rocprof_summary.txt"), "w").write("\n".join(lines) + "\n")
+json.dump(out, open(os.path.join("profiles", tag + "_pmc_traffic.json"), "w"), indent=1)
+print("\n".join(lines))
