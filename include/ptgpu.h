@@ -166,9 +166,15 @@ int pt_last_kernel_ms(pt_scene *scene, float *ms_out);
 int pt_last_launch_info(pt_scene *scene, uint32_t *grid_out, uint32_t *block_out,
                         uint32_t *lds_bytes_out);
 
-/* Tuning knobs (0 = library default): waves resident per CU for the
- * persistent grid, and kernel variant ("kernel variants"). */
+/* Tuning knobs (0 = library default): workgroups resident per CU for the persistent grid, and a
+ * kernel-variant bit mask (DESIGN.md "kernel variants"): 1 = scan table from HBM/L2 instead of LDS,
+ * 2 = attenuation stack in HBM, 4 = disable the MFMA prefilter (exact VALU scan), 8 = verify mode. */
 int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
+
+/* Verify-mode counters of the MFMA prefilter (variant bit 8): out4 = { exact-positive pairs the
+ * prefilter failed to flag (must be 0), queued candidates, queue-overflow fallbacks, exact-positive
+ * pairs }. Synchronises the device. */
+int pt_scene_debug_counters(pt_scene *scene, uint64_t out4[4], int reset);
 
 /* Device self-test probes (diagnostics for the parity tests; not part of the reference's
  * interface): evaluate one device primitive on n host inputs.

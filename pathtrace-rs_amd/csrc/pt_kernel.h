@@ -35,6 +35,8 @@ struct DNode {  // 32 B, collision/bvh.rs:24-28 flattened
     int32_t lhs, rhs;
 };
 
+struct DWideNode;
+
 struct DCamera {  // camera.rs:8-19
     f3 origin, lower_left_corner, horizontal, vertical, u, v, w;
     float time0, time1, lens_radius;
@@ -49,9 +51,21 @@ struct KArgs {
     const DTex *texs;
     const float4 *perlin_vec;    // 256 gradients (xyz, pad)
     const uint32_t *perlin_perm; // 768 entries: perm_x | perm_y | perm_z
-    const DNode *nodes;
+    const DWideNode *wnodes;  // caller's BVH re-laid out: children's AABBs inside the parent
+    const uint32_t *leaf_rank;       // DFS (lhs before rhs) order of each sphere's leaf, for equal-t ties
+    float root_min[3], root_max[3];
     uint32_t n_spheres;
     uint32_t n_spheres_pad;      // multiple of kScanUnroll; padding entries can never be hit
+    // MFMA discriminant prefilter (list mode, see "MFMA prefilter" below); n_tiles == 0 disables it
+    const uint4 *afrag;          // [n_tiles][2 chunks][64 lanes] x 8 f16: sphere-feature A fragments
+    const uint16_t *tile_sphere; // [n_tiles*32] sphere index of each fragment row, 0xffff = padding
+    const uint32_t *large;       // spheres outside the prefilter's range: tested exactly for every ray
+    uint32_t n_tiles, n_large;
+    float c0[3];                 // feature-space origin (f32-exact), radius bound of the prefiltered set
+    float rs2;                   // Rs^2, Rs >= max(|c - c0| + |r|) over prefiltered spheres
+    float m0, gamma;             // margin = a * (m0 + gamma * (|o - c0|^2 + Rs^2))
+    uint32_t verify;             // debug: count exact-positive pairs the prefilter did not flag
+    unsigned long long *debug;   // [4] misses, candidates, overflow fallbacks, exact positives
     int32_t bvh_root;
     uint32_t has_sky;
     f3 sky;
@@ -230,6 +244,204 @@ __device__ __forceinline__ int intersect_list(const float4 *sph, int n_pad, uint
     return idx;
 }
 
+// ---- MFMA prefilter ------------------------------------------------------------------------
+// The line-sphere discriminant of sphere.rs:33-37 is invariant under moving the ray origin along
+// the ray, and it is a bilinear form in lifted features:
+//     disc = (o'.d - c.d)^2 - a (|o'|^2 - 2 c.o' + |c|^2 - r^2)  =  S(c, r) . R(o', d) + (o'.d)^2 - a |o'|^2
+//     S = [cx^2 cy^2 cz^2 cx*cy cx*cz cy*cz cx cy cz |c|^2-r^2]
+//     R = [dx^2 dy^2 dz^2 2dxdy 2dxdz 2dydz  2a*o'x-2(o'.d)dx  2a*o'y-2(o'.d)dy  2a*o'z-2(o'.d)dz  -a]
+// with c, o' relative to a fixed centre c0 and o' = the point of the ray's line closest to c0 (so all
+// magnitudes stay ~ scene radius). S.R for 32 spheres x 32 rays is ONE pair of
+// v_mfma_f32_32x32x16_f16 (K = 32 slots: Sh*Rh, Sh*Rl, Sl*Rh with hi/lo-split f16 operands, ~22-bit
+// inputs, f32 accumulation). A pair is a CANDIDATE when S.R > a|o'|^2 - (o'.d)^2 - margin; the margin
+// bounds every rounding difference between this evaluation and the reference's f32 discriminant
+// (DESIGN.md "MFMA prefilter: error budget"), so every sphere whose reference discriminant is > 0
+// is a candidate. Candidates are then run through the exact reference arithmetic (phase 2); the
+// prefilter never decides a hit, it only discards certain misses.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+struct RayFeat {
+    half8 b0[2], b1[2];  // B fragments for ray-half 0 / 1, chunk 0 / 1
+    float thr0, thr1;    // candidate thresholds of the ray this lane serves in half 0 / 1
+};
+
+__device__ __forceinline__ half8 shfl_xor32(half8 v) {
+    union { half8 h; int i[4]; } u, r;
+    u.h = v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.i[k] = __shfl_xor(u.i[k], 32);
+    return r.h;
+}
+
+__device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d, float a, bool active, int lane) {
+    // origin relative to c0, moved along the ray to the point closest to c0 (any point of the line
+    // is valid; rounding here only needs to be covered by the margin)
+    const f3 ot = mk3(o.x - A.c0[0], o.y - A.c0[1], o.z - A.c0[2]);
+    const float od0 = __builtin_fmaf(ot.z, d.z, __builtin_fmaf(ot.y, d.y, ot.x * d.x));
+    const float s = active ? (-od0 / a) : 0.0f;
+    const f3 op = mk3(__builtin_fmaf(s, d.x, ot.x), __builtin_fmaf(s, d.y, ot.y), __builtin_fmaf(s, d.z, ot.z));
+    const float od = __builtin_fmaf(op.z, d.z, __builtin_fmaf(op.y, d.y, op.x * d.x));
+    const float oo = __builtin_fmaf(op.z, op.z, __builtin_fmaf(op.y, op.y, op.x * op.x));
+    const float ot2 = __builtin_fmaf(ot.z, ot.z, __builtin_fmaf(ot.y, ot.y, ot.x * ot.x));
+    float R[10];
+    R[0] = d.x * d.x; R[1] = d.y * d.y; R[2] = d.z * d.z;
+    R[3] = 2.0f * d.x * d.y; R[4] = 2.0f * d.x * d.z; R[5] = 2.0f * d.y * d.z;
+    const float a2 = 2.0f * a, od2 = 2.0f * od;
+    R[6] = __builtin_fmaf(a2, op.x, -od2 * d.x);
+    R[7] = __builtin_fmaf(a2, op.y, -od2 * d.y);
+    R[8] = __builtin_fmaf(a2, op.z, -od2 * d.z);
+    R[9] = -a;
+    const float margin = a * __builtin_fmaf(A.gamma, ot2 + A.rs2, A.m0);
+    // a ray whose line passes farther than sqrt(oo) > Rs (+ margin) from c0 still gets the generic test
+    float thr = __builtin_fmaf(a, oo, -(od * od)) - margin;
+    if (!active || !(thr == thr)) thr = active ? -3.0e38f : 3.0e38f;  // NaN -> everything is a candidate
+    _Float16 slot[32];
+#pragma unroll
+    for (int f = 0; f < 10; ++f) {
+        const _Float16 h = (_Float16)R[f];
+        const _Float16 l = (_Float16)(R[f] - (float)h);
+        slot[f] = h;        // x Sh
+        slot[10 + f] = l;   // x Sh
+        slot[20 + f] = h;   // x Sl
+    }
+    slot[30] = (_Float16)0.0f;
+    slot[31] = (_Float16)0.0f;
+    half8 own[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) own[c][h][e] = slot[c * 16 + h * 8 + e];
+    const bool lo = lane < 32;
+    RayFeat f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const half8 mine = lo ? own[c][0] : own[c][1];   // own ray, this lane's k-half
+        const half8 give = lo ? own[c][1] : own[c][0];   // what lane^32 needs of my ray
+        const half8 other = shfl_xor32(give);            // partner ray, this lane's k-half
+        f.b0[c] = lo ? mine : other;                     // MFMA over rays 0..31
+        f.b1[c] = lo ? other : mine;                     // MFMA over rays 32..63
+    }
+    const float thr_p = __shfl_xor(thr, 32);
+    f.thr0 = lo ? thr : thr_p;
+    f.thr1 = lo ? thr_p : thr;
+    return f;
+}
+
+__device__ __forceinline__ float max16(const float16v &v) {
+    float m = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]);
+#pragma unroll
+    for (int r = 3; r + 1 < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, v[r]), v[r + 1]);
+    return __builtin_fmaxf(m, v[15]);
+}
+
+// Append sphere `sph` to the candidate queue of block-local ray `ray_tid` (any lane of the wave
+// may serve any ray of the wave, hence the LDS atomic).
+__device__ __forceinline__ void push_candidate(uint32_t *qcnt, uint16_t *queue, int ray_tid, uint32_t sph) {
+    const uint32_t slot = atomicAdd(&qcnt[ray_tid], 1u);
+    if (slot < (uint32_t)kQueueCap) queue[slot * kBlock + ray_tid] = (uint16_t)sph;
+}
+
+// exact reference test of one sphere, order independent: candidate t as sphere.rs:38-64 would
+// return it for t_max = f32::MAX, winner = lexicographic (t, index) minimum == the sequential
+// closest_so_far scan of hitable_list.rs:40-56 (DESIGN.md "order-independent closest hit")
+__device__ __forceinline__ void exact_candidate(const float4 c, int k, f3 o, f3 d, float a, float &best, int &idx) {
+    const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
+    const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+    const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
+    const float disc = b * b - a * cc;
+    if (disc > 0.0f) {
+        float t = kMaxT;
+        if (sphere_roots(a, b, disc, t)) {
+            if (t < best || (t == best && k < idx) || idx < 0) {
+                best = t;
+                idx = k;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *sph, const uint4 *s_afrag,
+                                                   const uint16_t *s_tile_sphere, uint32_t *qcnt, uint16_t *queue,
+                                                   f3 o, f3 d, float a, bool active, float &t_out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave_base = tid & ~63;
+    const RayFeat rf = make_ray_features(A, o, d, a, active, lane);
+    const int row_off = 4 * (lane >> 5);
+    const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (uint32_t T = 0; T < A.n_tiles; ++T) {
+        union { uint4 u; half8 h; } a0, a1;
+        a0.u = s_afrag[(T * 2 + 0) * 64 + lane];
+        a1.u = s_afrag[(T * 2 + 1) * 64 + lane];
+        float16v acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, rf.b0[0], zero, 0, 0, 0);
+        float16v acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, rf.b1[0], zero, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, rf.b0[1], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, rf.b1[1], acc1, 0, 0, 0);
+        const bool any0 = max16(acc0) > rf.thr0, any1 = max16(acc1) > rf.thr1;
+        if (__any(any0 || any1)) {
+            const uint16_t *ts = s_tile_sphere + T * 32 + row_off;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2);
+                if (acc0[r] > rf.thr0) push_candidate(qcnt, queue, wave_base + (lane & 31), ts[row]);
+                if (acc1[r] > rf.thr1) push_candidate(qcnt, queue, wave_base + 32 + (lane & 31), ts[row]);
+            }
+        }
+    }
+    // ---- phase 2: exact arithmetic on the candidates of this lane's own ray ----
+    float best = kMaxT;
+    int idx = -1;
+    const uint32_t cnt = qcnt[tid];
+    qcnt[tid] = 0;
+    for (uint32_t j = 0; j < A.n_large; ++j) {  // wave-uniform: spheres outside the prefilter's range
+        const int k = (int)A.large[j];
+        if (active) exact_candidate(sph[k], k, o, d, a, best, idx);
+    }
+    const bool overflow = cnt > (uint32_t)kQueueCap;
+    if (__any(overflow || (A.verify && active))) {
+        if (overflow || A.verify) {
+            // queue overflow (ray far outside the prefilter's accuracy range) or verify mode: brute force
+            float vbest = kMaxT;
+            int vidx = -1;
+            for (int k = 0; k < (int)A.n_spheres; ++k) {
+                const float4 c = sph[k];
+                exact_candidate(c, k, o, d, a, vbest, vidx);
+                if (A.verify && active) {
+                    const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
+                    const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+                    const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
+                    if (b * b - a * cc > 0.0f) {
+                        bool found = overflow;
+                        for (uint32_t j = 0; j < A.n_large && !found; ++j) found = ((int)A.large[j] == k);
+                        for (uint32_t j = 0; j < cnt && j < (uint32_t)kQueueCap && !found; ++j) found = (queue[j * kBlock + tid] == k);
+                        atomicAdd(&A.debug[3], 1ull);
+                        if (!found) atomicAdd(&A.debug[0], 1ull);
+                    }
+                }
+            }
+            if (A.verify && active) {
+                atomicAdd(&A.debug[1], (unsigned long long)cnt);
+                if (overflow) atomicAdd(&A.debug[2], 1ull);
+            }
+            if (overflow) {
+                best = vbest;
+                idx = vidx;
+            }
+        }
+    }
+    if (!overflow) {
+        for (uint32_t j = 0; __any(j < cnt); ++j) {
+            if (j < cnt) {
+                const int k = queue[j * kBlock + tid];
+                exact_candidate(sph[k], k, o, d, a, best, idx);
+            }
+        }
+    }
+    t_out = best;
+    return idx;
+}
+
 // aabb.rs:46-58 with the SSE min/max NaN rule (second operand on NaN)
 __device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
@@ -243,10 +455,61 @@ __device__ __forceinline__ bool aabb_hit(const DNode &n, f3 o, f3 rcp, float tmi
     return (hix > lox) && (hiy > loy) && (hiz > loz);
 }
 
-// bvh.rs:37-62: both children are visited with the ORIGINAL t_max and the
-// smaller t wins, rhs on ties. Iterative DFS (lhs before rhs) with an explicit
-// per-lane stack in LDS; a candidate replaces the best when t <= best, which is
-// the same winner as the recursion's pairwise (lhs.t < rhs.t ? lhs : rhs).
+// bvh.rs:37-62 over the CALLER's tree, restructured for the GPU without changing its result.
+//
+// Reference semantics: a leaf sphere is tested (with t_max = f32::MAX) iff every ancestor node's
+// AABB passes aabb.rs:46-58 with (t_min, f32::MAX); among the hits the smallest t wins and equal t
+// resolves to the leaf that comes LAST in lhs-before-rhs DFS order (`lhs.t < rhs.t ? lhs : rhs`).
+//
+// Here: each device node carries the AABBs of its two children (one 64-byte fetch tests both), the
+// children are visited near-first, and a subtree is skipped when its slab entry distance exceeds the
+// best hit so far by a safety slack. Skipping such a subtree cannot change the winner: every sphere
+// inside has t >= entry distance (up to rounding, covered by the slack), and the
+// subtree's AABB test itself is the reference's, evaluated with the reference's arithmetic. Equal-t
+// ties are resolved by the precomputed DFS rank of the leaf instead of by visiting order.
+struct DWideNode {  // 64 B
+    float lmin[3], lmax[3];  // AABB of lhs when lhs is an inner node
+    float rmin[3], rmax[3];  // AABB of rhs when rhs is an inner node
+    int32_t lhs, rhs;        // >= 0 inner node, < 0 ~sphere
+    uint32_t pad0, pad1;
+};
+
+// aabb.rs:46-58 (exact), also returning the entry distance max(t0x, t0y, t0z, t_min) for ordering
+__device__ __forceinline__ bool aabb_hit_enter(const float mn[3], const float mx[3], f3 o, f3 rcp, float &t_enter) {
+    const float mnx = (mn[0] - o.x) * rcp.x, mny = (mn[1] - o.y) * rcp.y, mnz = (mn[2] - o.z) * rcp.z;
+    const float mxx = (mx[0] - o.x) * rcp.x, mxy = (mx[1] - o.y) * rcp.y, mxz = (mx[2] - o.z) * rcp.z;
+    const float t0x = sse_min(mnx, mxx), t0y = sse_min(mny, mxy), t0z = sse_min(mnz, mxz);
+    const float t1x = sse_max(mnx, mxx), t1y = sse_max(mny, mxy), t1z = sse_max(mnz, mxz);
+    const float lox = sse_max(t0x, kMinT), loy = sse_max(t0y, kMinT), loz = sse_max(t0z, kMinT);
+    const float hix = sse_min(t1x, kMaxT), hiy = sse_min(t1y, kMaxT), hiz = sse_min(t1z, kMaxT);
+    t_enter = fmaxf(fmaxf(lox, loy), loz);
+    return (hix > lox) && (hiy > loy) && (hiz > loz);
+}
+
+// relative / absolute slack of the distance cull (DESIGN.md "BVH culling slack")
+constexpr float kCullRel = 1.02f;
+constexpr float kCullAbs = 0.02f;
+
+__device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, f3 o, f3 d, float a, float &best, int &idx,
+                                         uint32_t &best_rank) {
+    const float4 c = A.spheres[k];
+    const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
+    const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+    const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
+    const float disc = b * b - a * cc;
+    if (disc > 0.0f) {
+        float t = kMaxT;  // hitable.rs:47 passes the ORIGINAL t_max to every leaf
+        if (sphere_roots(a, b, disc, t)) {
+            const uint32_t rank = A.leaf_rank[k];
+            if (idx < 0 || t < best || (t == best && rank > best_rank)) {
+                best = t;
+                idx = k;
+                best_rank = rank;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ int intersect_bvh(const KArgs &A, uint32_t *s_stack /* [kBvhStack][kBlock] */, f3 o, f3 d,
                                              float a, bool active, float &t_out) {
     const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // ray.rs:14
@@ -254,35 +517,30 @@ __device__ __forceinline__ int intersect_bvh(const KArgs &A, uint32_t *s_stack /
     int sp = 0;
     float best = kMaxT;
     int idx = -1;
-    bool have = false;
-    if (active) s_stack[(sp++) * kBlock + tid] = (uint32_t)A.bvh_root;
+    uint32_t best_rank = 0;
+    float te;
+    if (active && aabb_hit_enter(A.root_min, A.root_max, o, rcp, te)) s_stack[(sp++) * kBlock + tid] = (uint32_t)A.bvh_root;
     while (sp > 0) {
         const int32_t ref = (int32_t)s_stack[(--sp) * kBlock + tid];
-        if (ref >= 0) {
-            const DNode n = A.nodes[ref];
-            if (aabb_hit(n, o, rcp, kMinT, kMaxT)) {
-                if (sp + 2 <= kBvhStack) {
-                    s_stack[(sp++) * kBlock + tid] = (uint32_t)n.rhs;
-                    s_stack[(sp++) * kBlock + tid] = (uint32_t)n.lhs;
-                }
-            }
-        } else {
-            const int k = ~ref;
-            const float4 c = A.spheres[k];
-            const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
-            const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
-            const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
-            const float disc = b * b - a * cc;
-            if (disc > 0.0f) {
-                float t = kMaxT;
-                if (sphere_roots(a, b, disc, t)) {
-                    if (!have || t <= best) {
-                        best = t;
-                        idx = k;
-                        have = true;
-                    }
-                }
-            }
+        const DWideNode n = A.wnodes[ref];
+        // leaves first: they can only shrink `best` before the inner children are considered
+        if (n.lhs < 0) bvh_leaf(A, ~n.lhs, o, d, a, best, idx, best_rank);
+        if (n.rhs < 0) bvh_leaf(A, ~n.rhs, o, d, a, best, idx, best_rank);
+        float tl = 0.f, tr = 0.f;
+        bool hl = false, hr = false;
+        if (n.lhs >= 0) hl = aabb_hit_enter(n.lmin, n.lmax, o, rcp, tl);
+        if (n.rhs >= 0) hr = aabb_hit_enter(n.rmin, n.rmax, o, rcp, tr);
+        const float limit = (idx >= 0) ? (best * kCullRel + kCullAbs) : kMaxT;
+        hl = hl && !(tl > limit);
+        hr = hr && !(tr > limit);
+        if (hl && hr) {
+            const bool l_near = tl <= tr;
+            s_stack[(sp++) * kBlock + tid] = (uint32_t)(l_near ? n.rhs : n.lhs);
+            s_stack[(sp++) * kBlock + tid] = (uint32_t)(l_near ? n.lhs : n.rhs);
+        } else if (hl) {
+            s_stack[(sp++) * kBlock + tid] = (uint32_t)n.lhs;
+        } else if (hr) {
+            s_stack[(sp++) * kBlock + tid] = (uint32_t)n.rhs;
         }
     }
     t_out = best;
@@ -291,7 +549,7 @@ __device__ __forceinline__ int intersect_bvh(const KArgs &A, uint32_t *s_stack /
 
 // SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
 // (staged once per workgroup); otherwise from HBM/L2 through wave-uniform loads.
-template <bool BVH, bool SPH_LDS>
+template <bool BVH, bool SPH_LDS, bool MFMA>
 __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
@@ -304,6 +562,12 @@ __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
     p += BVH ? (kBvhStack * kBlock * 4) : 0;
     uint16_t *s_queue = reinterpret_cast<uint16_t *>(p);  // list mode: [kQueueCap+1][kBlock] u16
     p += BVH ? 0 : ((kQueueCap + 1) * kBlock * 2 + 15) / 16 * 16;
+    uint4 *s_afrag = reinterpret_cast<uint4 *>(p);        // MFMA: [n_tiles][2][64] x 16 B
+    p += MFMA ? A.n_tiles * 2048u : 0u;
+    uint16_t *s_tile_sphere = reinterpret_cast<uint16_t *>(p);
+    p += MFMA ? ((A.n_tiles * 64u + 15u) & ~15u) : 0u;
+    uint32_t *s_qcnt = reinterpret_cast<uint32_t *>(p);
+    p += MFMA ? kBlock * 4 : 0;
     float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][kBlock] attenuation stack
 
     const int tid = threadIdx.x;
@@ -311,6 +575,11 @@ __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
 
     if (!BVH && SPH_LDS) {
         for (uint32_t k = tid; k < A.n_spheres_pad; k += kBlock) s_sph[k] = A.spheres_r2[k];
+    }
+    if (MFMA) {
+        for (uint32_t k = tid; k < A.n_tiles * 128u; k += kBlock) s_afrag[k] = A.afrag[k];
+        for (uint32_t k = tid; k < A.n_tiles * 32u; k += kBlock) s_tile_sphere[k] = A.tile_sphere[k];
+        s_qcnt[tid] = 0;
     }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += kBlock) s_pvec[k] = A.perlin_vec[k];
@@ -392,6 +661,9 @@ __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
         int idx;
         if (BVH)
             idx = intersect_bvh(A, s_bvh, ro, rd, a, have, t_hit);
+        else if (MFMA)
+            idx = intersect_list_mfma(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_qcnt,
+                                      s_queue, ro, rd, a, have, t_hit);
         else
             idx = intersect_list(SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, (int)A.n_spheres_pad, s_queue + tid, ro, rd,
                                  a, t_hit);

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -57,7 +58,17 @@ struct pt_scene {
     DTex *d_texs = nullptr;
     float4 *d_perlin_vec = nullptr;
     uint32_t *d_perlin_perm = nullptr;
-    DNode *d_nodes = nullptr;
+    DWideNode *d_wnodes = nullptr;
+    uint32_t *d_leaf_rank = nullptr;
+    float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    // MFMA prefilter data (n_tiles == 0: prefilter not applicable to this scene)
+    uint4 *d_afrag = nullptr;
+    uint16_t *d_tile_sphere = nullptr;
+    uint32_t *d_large = nullptr;
+    uint32_t n_tiles = 0, n_large = 0;
+    float c0[3] = {0, 0, 0};
+    float rs2 = 0.f, m0 = 0.f, gamma = 0.f;
+    unsigned long long *d_debug = nullptr;    // 4 u64 counters (verify mode)
     uint32_t *d_work_counter = nullptr;       // 1 u32
     unsigned long long *d_ray_count = nullptr; // internal counter for pt_render
     float *d_frame = nullptr;                 // internal frame buffer for pt_render (host-buffer entry point)
@@ -126,6 +137,97 @@ int upload(T **dst, const void *src, size_t count) {
     HIP_TRY(hipMalloc((void **)dst, count * sizeof(T) > 0 ? count * sizeof(T) : sizeof(T)));
     if (count) HIP_TRY(hipMemcpy(*dst, src, count * sizeof(T), hipMemcpyHostToDevice));
     return PT_OK;
+}
+
+}  // namespace
+
+
+namespace {
+
+// ---- MFMA prefilter preparation (DESIGN.md "MFMA prefilter") ------------------------------------
+// Spheres whose centre/radius stay within the f16 feature range relative to the set's centroid are
+// packed 32 per tile into A fragments of v_mfma_f32_32x32x16_f16; the rest ("large", e.g. the
+// r = 1000 ground sphere) are tested exactly for every ray. Features are computed in binary64 from
+// the exact f32 inputs and split into hi/lo f16.
+constexpr double kFeatRange = 48.0;   // |c - c0| + |r| bound for prefiltered spheres (features <= 2304 < 65504)
+constexpr double kRadiusMax = 8.0;
+constexpr uint32_t kMaxLarge = 8;
+
+struct MfmaPrep {
+    std::vector<uint16_t> afrag;  // f16 bit patterns, [tile][chunk][lane][8]
+    std::vector<uint16_t> tile_sphere;
+    std::vector<uint32_t> large;
+    float c0[3] = {0, 0, 0};
+    double rs = 0.0;
+    uint32_t n_tiles = 0;
+};
+
+uint16_t f16_bits(_Float16 h) {
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+bool prepare_mfma(const pt_scene_desc *desc, MfmaPrep &out) {
+    const uint32_t n = desc->n_spheres;
+    if (n > 0xfff0u) return false;
+    // centroid of the moderate-radius spheres, rounded to f32 (c0 must be exactly what the device subtracts)
+    double cx = 0, cy = 0, cz = 0;
+    uint32_t m = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const pt_sphere &p = desc->spheres[i];
+        if (std::fabs((double)p.radius) <= kRadiusMax && std::isfinite(p.cx + p.cy + p.cz + p.radius)) {
+            cx += p.cx, cy += p.cy, cz += p.cz, ++m;
+        }
+    }
+    if (m == 0) return false;
+    out.c0[0] = (float)(cx / m), out.c0[1] = (float)(cy / m), out.c0[2] = (float)(cz / m);
+    std::vector<uint32_t> small;
+    for (uint32_t i = 0; i < n; ++i) {
+        const pt_sphere &p = desc->spheres[i];
+        const double dx = (double)p.cx - out.c0[0], dy = (double)p.cy - out.c0[1], dz = (double)p.cz - out.c0[2];
+        const double reach = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)p.radius);
+        if (std::isfinite(reach) && std::fabs((double)p.radius) <= kRadiusMax && reach <= kFeatRange) {
+            small.push_back(i);
+            if (reach > out.rs) out.rs = reach;
+        } else {
+            out.large.push_back(i);
+        }
+    }
+    if (out.large.size() > kMaxLarge || small.size() < 32) return false;
+    out.n_tiles = (uint32_t)((small.size() + 31) / 32);
+    out.tile_sphere.assign((size_t)out.n_tiles * 32, 0xffffu);
+    out.afrag.assign((size_t)out.n_tiles * 2 * 64 * 8, 0);
+    for (uint32_t T = 0; T < out.n_tiles; ++T) {
+        for (uint32_t row = 0; row < 32; ++row) {
+            const size_t j = (size_t)T * 32 + row;
+            double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 60000.0};  // padding: S.R = -a * 60000, never a candidate
+            if (j < small.size()) {
+                const pt_sphere &p = desc->spheres[small[j]];
+                out.tile_sphere[j] = (uint16_t)small[j];
+                const double x = (double)p.cx - out.c0[0], y = (double)p.cy - out.c0[1], z = (double)p.cz - out.c0[2];
+                const volatile float r2f = p.radius * p.radius;  // sphere.rs:36 (the reference squares in f32)
+                S[0] = x * x, S[1] = y * y, S[2] = z * z, S[3] = x * y, S[4] = x * z, S[5] = y * z;
+                S[6] = x, S[7] = y, S[8] = z, S[9] = x * x + y * y + z * z - (double)r2f;
+            }
+            _Float16 slot[32];
+            for (int f = 0; f < 10; ++f) {
+                const _Float16 h = (_Float16)S[f];
+                const _Float16 l = (_Float16)(S[f] - (double)h);
+                slot[f] = h;        // x Rh
+                slot[10 + f] = h;   // x Rl
+                slot[20 + f] = l;   // x Rh
+            }
+            slot[30] = (_Float16)0.0, slot[31] = (_Float16)0.0;
+            for (int c = 0; c < 2; ++c)
+                for (int half = 0; half < 2; ++half) {
+                    const uint32_t lane = row + 32 * half;
+                    for (int e = 0; e < 8; ++e)
+                        out.afrag[(((size_t)T * 2 + c) * 64 + lane) * 8 + e] = f16_bits(slot[c * 16 + half * 8 + e]);
+                }
+        }
+    }
+    return true;
 }
 
 }  // namespace
@@ -215,10 +317,36 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
         const pt_texture &t = desc->textures[i];
         texs[i] = DTex{t.kind, t.color[0], t.color[1], t.color[2], t.odd, t.even, t.scale, 0.f};
     }
-    std::vector<DNode> nodes(desc->n_bvh_nodes);
+    // Re-lay the caller's BVH out for traversal: every node carries its children's AABBs (the same
+    // float values the reference tests, just stored one level up), plus the DFS rank of every leaf.
+    std::vector<DWideNode> wnodes(desc->n_bvh_nodes);
+    std::vector<uint32_t> leaf_rank(desc->n_spheres, 0);
     for (uint32_t i = 0; i < desc->n_bvh_nodes; ++i) {
         const pt_bvh_node &n = desc->bvh_nodes[i];
-        nodes[i] = DNode{n.min[0], n.min[1], n.min[2], n.max[0], n.max[1], n.max[2], n.lhs, n.rhs};
+        DWideNode w;
+        memset(&w, 0, sizeof w);
+        w.lhs = n.lhs;
+        w.rhs = n.rhs;
+        if (n.lhs >= 0) memcpy(w.lmin, desc->bvh_nodes[n.lhs].min, 12), memcpy(w.lmax, desc->bvh_nodes[n.lhs].max, 12);
+        if (n.rhs >= 0) memcpy(w.rmin, desc->bvh_nodes[n.rhs].min, 12), memcpy(w.rmax, desc->bvh_nodes[n.rhs].max, 12);
+        wnodes[i] = w;
+    }
+    if (desc->n_bvh_nodes) {
+        memcpy(s->root_min, desc->bvh_nodes[desc->bvh_root].min, 12);
+        memcpy(s->root_max, desc->bvh_nodes[desc->bvh_root].max, 12);
+        // lhs-before-rhs DFS; a sphere referenced by several leaves keeps its LAST rank (bvh.rs:73-79 lhs == rhs)
+        std::vector<int32_t> st{desc->bvh_root};
+        uint32_t rank = 0;
+        while (!st.empty()) {
+            const int32_t ref = st.back();
+            st.pop_back();
+            if (ref < 0) {
+                leaf_rank[~ref] = rank++;
+            } else {
+                st.push_back(desc->bvh_nodes[ref].rhs);
+                st.push_back(desc->bvh_nodes[ref].lhs);
+            }
+        }
     }
     std::vector<float4> pvec(256, make_float4(0, 0, 0, 0));
     std::vector<uint32_t> pperm(768, 0);
@@ -235,9 +363,31 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
         (rc = upload(&s->d_sphere_mat, desc->sphere_material, desc->n_spheres)) ||
         (rc = upload(&s->d_mats, mats.data(), mats.size())) || (rc = upload(&s->d_texs, texs.data(), texs.size())) ||
         (rc = upload(&s->d_perlin_vec, pvec.data(), pvec.size())) || (rc = upload(&s->d_perlin_perm, pperm.data(), pperm.size())) ||
-        (rc = upload(&s->d_nodes, nodes.data(), nodes.size()))) {
+        (rc = upload(&s->d_wnodes, wnodes.data(), wnodes.size())) || (rc = upload(&s->d_leaf_rank, leaf_rank.data(), leaf_rank.size()))) {
         pt_scene_destroy(s);
         return rc;
+    }
+    {
+        MfmaPrep prep;
+        if (prepare_mfma(desc, prep)) {
+            if ((rc = upload(&s->d_afrag, prep.afrag.data(), prep.afrag.size() / 8)) ||
+                (rc = upload(&s->d_tile_sphere, prep.tile_sphere.data(), prep.tile_sphere.size())) ||
+                (rc = upload(&s->d_large, prep.large.data(), prep.large.size()))) {
+                pt_scene_destroy(s);
+                return rc;
+            }
+            s->n_tiles = prep.n_tiles;
+            s->n_large = (uint32_t)prep.large.size();
+            memcpy(s->c0, prep.c0, sizeof s->c0);
+            s->rs2 = (float)(prep.rs * prep.rs * 1.0001);
+            // margin = a * (m0 + gamma * (|o - c0|^2 + Rs^2)); see DESIGN.md for the derivation
+            s->m0 = (float)(1.0e-5 * prep.rs * prep.rs + 1.0e-4);
+            s->gamma = 8.0e-6f;
+        }
+    }
+    if (hipMalloc((void **)&s->d_debug, 64) != hipSuccess || hipMemset(s->d_debug, 0, 64) != hipSuccess) {
+        pt_scene_destroy(s);
+        return fail(PT_ERR_HIP, "allocating debug counters failed");
     }
     if (hipMalloc((void **)&s->d_work_counter, 64) != hipSuccess || hipMalloc((void **)&s->d_ray_count, 64) != hipSuccess ||
         hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess) {
@@ -260,7 +410,12 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_texs);
     (void)hipFree(s->d_perlin_vec);
     (void)hipFree(s->d_perlin_perm);
-    (void)hipFree(s->d_nodes);
+    (void)hipFree(s->d_wnodes);
+    (void)hipFree(s->d_leaf_rank);
+    (void)hipFree(s->d_afrag);
+    (void)hipFree(s->d_tile_sphere);
+    (void)hipFree(s->d_large);
+    (void)hipFree(s->d_debug);
     (void)hipFree(s->d_work_counter);
     (void)hipFree(s->d_ray_count);
     (void)hipFree(s->d_frame);
@@ -307,7 +462,10 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.texs = s->d_texs;
     A.perlin_vec = s->d_perlin_vec;
     A.perlin_perm = s->d_perlin_perm;
-    A.nodes = s->d_nodes;
+    A.wnodes = s->d_wnodes;
+    A.leaf_rank = s->d_leaf_rank;
+    memcpy(A.root_min, s->root_min, 12);
+    memcpy(A.root_max, s->root_max, 12);
     A.n_spheres = s->n_spheres;
     A.n_spheres_pad = (s->n_spheres + kScanUnroll - 1) / kScanUnroll * kScanUnroll;
     A.bvh_root = s->bvh_root;
@@ -360,21 +518,34 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     bool sph_lds = false;
     if (!bvh) {
         sph_bytes = A.n_spheres_pad * 16u;
-        sph_lds = (s->variant != 1u) && sph_bytes <= 64u * 1024u;
+        sph_lds = (s->variant & 1u) == 0 && sph_bytes <= 64u * 1024u;
         if (!sph_lds) sph_bytes = 0;
     }
+    const bool mfma = !bvh && sph_lds && s->n_tiles > 0 && (s->variant & 4u) == 0;
+    A.afrag = s->d_afrag;
+    A.tile_sphere = s->d_tile_sphere;
+    A.large = s->d_large;
+    A.n_tiles = mfma ? s->n_tiles : 0u;
+    A.n_large = s->n_large;
+    memcpy(A.c0, s->c0, sizeof A.c0);
+    A.rs2 = s->rs2;
+    A.m0 = s->m0;
+    A.gamma = s->gamma;
+    A.verify = (s->variant & 8u) ? 1u : 0u;
+    A.debug = s->d_debug;
     uint32_t lds = sph_bytes;
     if (s->has_noise) lds += 4096u + 3072u;
     if (bvh) lds += (uint32_t)kBvhStack * kBlock * 4u;
     if (!bvh) lds += ((kQueueCap + 1) * kBlock * 2u + 15u) / 16u * 16u;
+    if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + kBlock * 4u;
     const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
-    A.stack_in_lds = (lds + path_bytes <= kLdsPerBlockMax) ? 1u : 0u;
+    A.stack_in_lds = (!bvh && (s->variant & 2u) == 0 && lds + path_bytes <= kLdsPerBlockMax) ? 1u : 0u;
     if (A.stack_in_lds) lds += (uint32_t)path_bytes;
     A.lds_sphere_bytes = sph_bytes;
 
     // ---- persistent grid: CUs x resident blocks --------------------------------
     uint32_t bpc = s->blocks_per_cu;
-    if (bpc == 0) bpc = bvh ? 2u : 3u;
+    if (bpc == 0) bpc = bvh ? 4u : (mfma ? 2u : 3u);
     const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
     if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
     if (bpc > 8u) bpc = 8u;
@@ -397,11 +568,13 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
 
     void (*kern)(const KArgs) = nullptr;
     if (bvh)
-        kern = pt_trace_kernel<true, false>;
+        kern = pt_trace_kernel<true, false, false>;
+    else if (mfma)
+        kern = pt_trace_kernel<false, true, true>;
     else if (sph_lds)
-        kern = pt_trace_kernel<false, true>;
+        kern = pt_trace_kernel<false, true, false>;
     else
-        kern = pt_trace_kernel<false, false>;
+        kern = pt_trace_kernel<false, false, false>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
     HIP_TRY(hipEventRecord(s->ev_start, stream));
@@ -514,5 +687,14 @@ extern "C" int pt_selftest_probe(int device, uint32_t probe, const float *in, fl
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(PT_ERR_HIP, "probe failed: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
+extern "C" int pt_scene_debug_counters(pt_scene *s, uint64_t out4[4], int reset) {
+    if (!s || !out4) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out4, s->d_debug, 32, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(s->d_debug, 0, 32));
     return PT_OK;
 }

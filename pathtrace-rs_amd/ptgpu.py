@@ -76,7 +76,7 @@ class PtSceneDesc(C.Structure):
 EXPORTS = [
     "pt_device_count", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_render_shard_device", "pt_shard_rows", "pt_scene_set_seed_base", "pt_last_kernel_ms",
-    "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe",
+    "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters",
 ]
 
 _lib = None
@@ -112,6 +112,7 @@ def lib():
         L.pt_last_launch_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.pt_scene_set_tuning.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.pt_selftest_probe.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_size_t]
+        L.pt_scene_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.pt_last_error.restype = C.c_char_p
         L.pt_version.restype = C.c_char_p
         _lib = L
@@ -233,6 +234,11 @@ class Scene:
                             stream=0):
         _check(lib().pt_render_shard_device(self._h, C.byref(params), C.byref(camera), frame_num, shard_index,
                                             shard_count, d_rgb_ptr, d_ray_count_ptr, stream))
+
+    def debug_counters(self, reset=True):
+        out = (C.c_uint64 * 4)()
+        _check(lib().pt_scene_debug_counters(self._h, out, 1 if reset else 0))
+        return dict(misses=out[0], candidates=out[1], overflows=out[2], exact_positives=out[3])
 
     def last_kernel_ms(self):
         ms = C.c_float(0)
