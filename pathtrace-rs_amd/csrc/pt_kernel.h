@@ -299,7 +299,13 @@ __device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d,
     _Float16 slot[32];
 #pragma unroll
     for (int f = 0; f < 10; ++f) {
-        const _Float16 h = (_Float16)R[f];
+        // hi/lo split: the residual MUST be taken against the very f16 value that is stored. hipcc was
+        // observed to round the two uses of (_Float16)R[f] differently at exact ties (RNE for the stored
+        // half, RTZ inside the folded residual), which loses one f16 ulp; the opaque register copy pins
+        // one conversion result for both uses.
+        unsigned int hbits = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)R[f]);
+        asm volatile("" : "+v"(hbits));
+        const _Float16 h = __builtin_bit_cast(_Float16, (unsigned short)hbits);
         const _Float16 l = (_Float16)(R[f] - (float)h);
         slot[f] = h;        // x Sh
         slot[10 + f] = l;   // x Sh
@@ -363,6 +369,7 @@ __device__ __forceinline__ void exact_candidate(const float4 c, int k, f3 o, f3 
     }
 }
 
+template <bool VERIFY>
 __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *sph, const uint4 *s_afrag,
                                                    const uint16_t *s_tile_sphere, uint32_t *qcnt, uint16_t *queue,
                                                    f3 o, f3 d, float a, bool active, float &t_out) {
@@ -399,15 +406,15 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
         if (active) exact_candidate(sph[k], k, o, d, a, best, idx);
     }
     const bool overflow = cnt > (uint32_t)kQueueCap;
-    if (__any(overflow || (A.verify && active))) {
-        if (overflow || A.verify) {
+    if (__any(overflow || (VERIFY && active))) {
+        if (overflow || VERIFY) {
             // queue overflow (ray far outside the prefilter's accuracy range) or verify mode: brute force
             float vbest = kMaxT;
             int vidx = -1;
             for (int k = 0; k < (int)A.n_spheres; ++k) {
                 const float4 c = sph[k];
                 exact_candidate(c, k, o, d, a, vbest, vidx);
-                if (A.verify && active) {
+                if (VERIFY && active) {
                     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
                     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
                     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
@@ -416,11 +423,18 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                         for (uint32_t j = 0; j < A.n_large && !found; ++j) found = ((int)A.large[j] == k);
                         for (uint32_t j = 0; j < cnt && j < (uint32_t)kQueueCap && !found; ++j) found = (queue[j * kBlock + tid] == k);
                         atomicAdd(&A.debug[3], 1ull);
-                        if (!found) atomicAdd(&A.debug[0], 1ull);
+                        if (!found) {
+                            if (atomicAdd(&A.debug[0], 1ull) == 0ull) {  // record the first miss for offline analysis
+                                float *dbg = reinterpret_cast<float *>(A.debug + 4);
+                                dbg[0] = o.x, dbg[1] = o.y, dbg[2] = o.z, dbg[3] = d.x, dbg[4] = d.y, dbg[5] = d.z;
+                                dbg[6] = (float)k, dbg[7] = b * b - a * cc, dbg[8] = (lane < 32) ? rf.thr0 : rf.thr1;
+                                dbg[9] = a, dbg[10] = (float)cnt;
+                            }
+                        }
                     }
                 }
             }
-            if (A.verify && active) {
+            if (VERIFY && active) {
                 atomicAdd(&A.debug[1], (unsigned long long)cnt);
                 if (overflow) atomicAdd(&A.debug[2], 1ull);
             }
@@ -549,7 +563,7 @@ __device__ __forceinline__ int intersect_bvh(const KArgs &A, uint32_t *s_stack /
 
 // SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
 // (staged once per workgroup); otherwise from HBM/L2 through wave-uniform loads.
-template <bool BVH, bool SPH_LDS, bool MFMA>
+template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY>
 __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
@@ -662,7 +676,7 @@ __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
         if (BVH)
             idx = intersect_bvh(A, s_bvh, ro, rd, a, have, t_hit);
         else if (MFMA)
-            idx = intersect_list_mfma(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_qcnt,
+            idx = intersect_list_mfma<VERIFY>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_qcnt,
                                       s_queue, ro, rd, a, have, t_hit);
         else
             idx = intersect_list(SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, (int)A.n_spheres_pad, s_queue + tid, ro, rd,

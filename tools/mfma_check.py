@@ -8,7 +8,7 @@ def _load(name, rel):
     sys.modules[name] = m; spec.loader.exec_module(m); return m
 ptgpu = _load("pathtrace_rs_amd_ptgpu", "pathtrace-rs_amd/ptgpu.py")
 pthost = _load("pathtrace_rs_amd_pthost", "pathtrace-rs_amd/pthost.py")
-for preset, W, H, S in (("random_spheres", 300, 200, 4), ("aras", 320, 180, 4), ("small", 200, 100, 4)):
+for preset, W, H, S in (("random_spheres", 120, 80, 4), ("random_spheres", 600, 400, 8), ("aras", 320, 180, 8), ("small", 200, 100, 4)):
     hs = pthost.HostScene(preset, W, H, samples=S, device=0)
     sc = hs.device_scene()
     p = ptgpu.PtParams(W, H, S, 10, 0, 0)
@@ -25,3 +25,8 @@ for preset, W, H, S in (("random_spheres", 300, 200, 4), ("aras", 320, 180, 4), 
         print()
     same = all(np.array_equal(outs[4][0], outs[v][0]) and outs[4][1] == outs[v][1] for v in (0, 8))
     print(preset, "MFMA == exact scan:", same)
+    for v in (0, 8):
+        d = (outs[4][0] != outs[v][0]).any(axis=2)
+        if d.any():
+            ys, xs = np.nonzero(d)
+            print("  variant", v, "differs at", list(zip(xs[:5].tolist(), ys[:5].tolist())), "count", d.sum(), "rays", outs[v][1], "vs", outs[4][1])
