@@ -13,7 +13,13 @@
 
 namespace ptdev {
 
-constexpr int kBlock = 256;      // 4 waves: one per SIMD of a CU
+#ifndef PT_BLOCK
+#define PT_BLOCK 256
+#endif
+#ifndef PT_MINWAVES
+#define PT_MINWAVES 2
+#endif
+constexpr int kBlock = PT_BLOCK;  // threads per workgroup (the main loop never synchronises across waves)
 constexpr int kBvhStack = 32;    // per-lane traversal stack entries (LDS)
 
 struct DMat {  // 32 B
@@ -183,7 +189,7 @@ __device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float
 // in flight before its arithmetic starts; the table is padded to a multiple of 8 with
 // (3e38, 3e38, 3e38, 0) entries whose discriminant is NaN or -inf.
 constexpr int kScanUnroll = 8;
-constexpr int kQueueCap = 16;  // per-lane candidate slots (u16), drained when a lane exceeds kQueueCap - kScanUnroll
+constexpr int kQueueCap = 20;  // per-lane candidate slots (u16), drained when a lane exceeds kQueueCap - kScanUnroll
 
 __device__ __forceinline__ void drain_candidates(const float4 *sph, const uint16_t *q, uint32_t &cnt, f3 o, f3 d,
                                                  float a, float &closest, int &idx) {
@@ -262,8 +268,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 struct RayFeat {
-    half8 b0[2], b1[2];  // B fragments for ray-half 0 / 1, chunk 0 / 1
-    float thr0, thr1;    // candidate thresholds of the ray this lane serves in half 0 / 1
+    half8 b0[2], b1[2];  // B fragments for ray-half 0 / 1, chunk 0 / 1 (slots 30/31 carry the threshold)
 };
 
 __device__ __forceinline__ half8 shfl_xor32(half8 v) {
@@ -294,25 +299,34 @@ __device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d,
     R[9] = -a;
     const float margin = a * __builtin_fmaf(A.gamma, ot2 + A.rs2, A.m0);
     // a ray whose line passes farther than sqrt(oo) > Rs (+ margin) from c0 still gets the generic test
+    // candidate <=> S.R > thr. The tile GEMM evaluates thr - S.R directly (sphere fragments hold -S, and
+    // slots 30/31 hold 1 x thr_hi, 1 x thr_lo), so a candidate is simply a NEGATIVE accumulator.
     float thr = __builtin_fmaf(a, oo, -(od * od)) - margin;
-    if (!active || !(thr == thr)) thr = active ? -3.0e38f : 3.0e38f;  // NaN -> everything is a candidate
+    thr -= 1.0e-6f * __builtin_fabsf(thr);                         // covers the hi/lo f16 representation of thr
+    if (!(thr == thr)) thr = -60000.0f;                            // NaN -> everything is a candidate
+    thr = __builtin_fminf(__builtin_fmaxf(thr, -60000.0f), 60000.0f);  // |S.R| < 60000 always (features <= 2304)
+    if (!active) thr = 60000.0f;
     _Float16 slot[32];
 #pragma unroll
-    for (int f = 0; f < 10; ++f) {
+    for (int f = 0; f < 11; ++f) {
+        const float v = (f < 10) ? R[f] : thr;
         // hi/lo split: the residual MUST be taken against the very f16 value that is stored. hipcc was
-        // observed to round the two uses of (_Float16)R[f] differently at exact ties (RNE for the stored
+        // observed to round the two uses of (_Float16)v differently at exact ties (RNE for the stored
         // half, RTZ inside the folded residual), which loses one f16 ulp; the opaque register copy pins
         // one conversion result for both uses.
-        unsigned int hbits = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)R[f]);
+        unsigned int hbits = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)v);
         asm volatile("" : "+v"(hbits));
         const _Float16 h = __builtin_bit_cast(_Float16, (unsigned short)hbits);
-        const _Float16 l = (_Float16)(R[f] - (float)h);
-        slot[f] = h;        // x Sh
-        slot[10 + f] = l;   // x Sh
-        slot[20 + f] = h;   // x Sl
+        const _Float16 l = (_Float16)(v - (float)h);
+        if (f < 10) {
+            slot[f] = h;        // x (-Sh)
+            slot[10 + f] = l;   // x (-Sh)
+            slot[20 + f] = h;   // x (-Sl)
+        } else {
+            slot[30] = h;       // x 1
+            slot[31] = l;       // x 1
+        }
     }
-    slot[30] = (_Float16)0.0f;
-    slot[31] = (_Float16)0.0f;
     half8 own[2][2];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -330,9 +344,6 @@ __device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d,
         f.b0[c] = lo ? mine : other;                     // MFMA over rays 0..31
         f.b1[c] = lo ? other : mine;                     // MFMA over rays 32..63
     }
-    const float thr_p = __shfl_xor(thr, 32);
-    f.thr0 = lo ? thr : thr_p;
-    f.thr1 = lo ? thr_p : thr;
     return f;
 }
 
@@ -343,12 +354,10 @@ __device__ __forceinline__ float max16(const float16v &v) {
     return __builtin_fmaxf(m, v[15]);
 }
 
-// Append sphere `sph` to the candidate queue of block-local ray `ray_tid` (any lane of the wave
-// may serve any ray of the wave, hence the LDS atomic).
-__device__ __forceinline__ void push_candidate(uint32_t *qcnt, uint16_t *queue, int ray_tid, uint32_t sph) {
-    const uint32_t slot = atomicAdd(&qcnt[ray_tid], 1u);
-    if (slot < (uint32_t)kQueueCap) queue[slot * kBlock + ray_tid] = (uint16_t)sph;
-}
+// Candidate queues without atomics: a lane appends the pairs IT found to its own two sub-queues (one per
+// ray half it serves); ray rho's candidates are then the sub-queues [rho >> 5] of lanes (rho & 31) and
+// (rho & 31) + 32, i.e. of the owner lane and of lane ^ 32. Entries are fragment slots (tile*32 + row).
+constexpr int kSubCap = kQueueCap / 2;
 
 // exact reference test of one sphere, order independent: candidate t as sphere.rs:38-64 would
 // return it for t_max = f32::MAX, winner = lexicographic (t, index) minimum == the sequential
@@ -371,41 +380,64 @@ __device__ __forceinline__ void exact_candidate(const float4 c, int k, f3 o, f3 
 
 template <bool VERIFY>
 __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *sph, const uint4 *s_afrag,
-                                                   const uint16_t *s_tile_sphere, uint32_t *qcnt, uint16_t *queue,
+                                                   const uint16_t *s_tile_sphere, uint16_t *queue,
                                                    f3 o, f3 d, float a, bool active, float &t_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave_base = tid & ~63;
     const RayFeat rf = make_ray_features(A, o, d, a, active, lane);
     const int row_off = 4 * (lane >> 5);
     const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t cnt0 = 0, cnt1 = 0;  // candidates this lane found for the ray it serves in half 0 / half 1
+    union Frag { uint4 u; half8 h; };
+    Frag a0, a1, n0, n1;
+    a0.u = s_afrag[lane];
+    a1.u = s_afrag[64 + lane];
     for (uint32_t T = 0; T < A.n_tiles; ++T) {
-        union { uint4 u; half8 h; } a0, a1;
-        a0.u = s_afrag[(T * 2 + 0) * 64 + lane];
-        a1.u = s_afrag[(T * 2 + 1) * 64 + lane];
+        const uint32_t Tn = (T + 1 < A.n_tiles) ? T + 1 : T;   // prefetch the next tile's fragments
+        n0.u = s_afrag[(Tn * 2 + 0) * 64 + lane];
+        n1.u = s_afrag[(Tn * 2 + 1) * 64 + lane];
         float16v acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, rf.b0[0], zero, 0, 0, 0);
         float16v acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, rf.b1[0], zero, 0, 0, 0);
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, rf.b0[1], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, rf.b1[1], acc1, 0, 0, 0);
-        const bool any0 = max16(acc0) > rf.thr0, any1 = max16(acc1) > rf.thr1;
-        if (__any(any0 || any1)) {
-            const uint16_t *ts = s_tile_sphere + T * 32 + row_off;
+        a0 = n0;
+        a1 = n1;
+        // sign bits of the 2 x 16 accumulators -> one 32-bit mask per lane (v_alignbit shifts a sign in);
+        // register r of set s ends up at bit 16*s + 15 - r
+        uint32_t m0 = 0, m1 = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2);
-                if (acc0[r] > rf.thr0) push_candidate(qcnt, queue, wave_base + (lane & 31), ts[row]);
-                if (acc1[r] > rf.thr1) push_candidate(qcnt, queue, wave_base + 32 + (lane & 31), ts[row]);
+        for (int r = 0; r < 16; ++r) {
+            m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(acc0[r]), 31);
+            m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(acc1[r]), 31);
+        }
+        uint32_t m = m0 | (m1 << 16);
+        const uint32_t slot_base = T * 32 + row_off;
+        while (__any(m != 0u)) {
+            if (m != 0u) {
+                const uint32_t bit = 31u - (uint32_t)__builtin_clz(m);
+                m &= ~(1u << bit);
+                const uint32_t set = bit >> 4, r = 15u - (bit & 15u);
+                const uint32_t slot = slot_base + (r & 3u) + 8u * (r >> 2);
+                const uint32_t c = set ? cnt1 : cnt0;
+                if (c < (uint32_t)kSubCap) queue[(set * kSubCap + c) * kBlock + tid] = (uint16_t)slot;
+                cnt0 += set ^ 1u;
+                cnt1 += set;
             }
         }
     }
     // ---- phase 2: exact arithmetic on the candidates of this lane's own ray ----
     float best = kMaxT;
     int idx = -1;
-    const uint32_t cnt = qcnt[tid];
-    qcnt[tid] = 0;
+    const bool lo = lane < 32;
+    const uint32_t cnt_own = lo ? cnt0 : cnt1;                                  // my ray, found by me
+    const uint32_t cnt_par = (uint32_t)__shfl_xor((int)(lo ? cnt1 : cnt0), 32);   // my ray, found by lane ^ 32
+    const uint16_t *q_own = queue + (lo ? 0 : kSubCap) * kBlock + tid;
+    const uint16_t *q_par = queue + (lo ? 0 : kSubCap) * kBlock + (tid ^ 32);
+    const uint32_t cnt = cnt_own + cnt_par;
     for (uint32_t j = 0; j < A.n_large; ++j) {  // wave-uniform: spheres outside the prefilter's range
         const int k = (int)A.large[j];
         if (active) exact_candidate(sph[k], k, o, d, a, best, idx);
     }
-    const bool overflow = cnt > (uint32_t)kQueueCap;
+    const bool overflow = cnt_own > (uint32_t)kSubCap || cnt_par > (uint32_t)kSubCap;
     if (__any(overflow || (VERIFY && active))) {
         if (overflow || VERIFY) {
             // queue overflow (ray far outside the prefilter's accuracy range) or verify mode: brute force
@@ -421,13 +453,14 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                     if (b * b - a * cc > 0.0f) {
                         bool found = overflow;
                         for (uint32_t j = 0; j < A.n_large && !found; ++j) found = ((int)A.large[j] == k);
-                        for (uint32_t j = 0; j < cnt && j < (uint32_t)kQueueCap && !found; ++j) found = (queue[j * kBlock + tid] == k);
+                        for (uint32_t j = 0; j < cnt_own && j < (uint32_t)kSubCap && !found; ++j) found = (s_tile_sphere[q_own[j * kBlock]] == k);
+                        for (uint32_t j = 0; j < cnt_par && j < (uint32_t)kSubCap && !found; ++j) found = (s_tile_sphere[q_par[j * kBlock]] == k);
                         atomicAdd(&A.debug[3], 1ull);
                         if (!found) {
                             if (atomicAdd(&A.debug[0], 1ull) == 0ull) {  // record the first miss for offline analysis
                                 float *dbg = reinterpret_cast<float *>(A.debug + 4);
                                 dbg[0] = o.x, dbg[1] = o.y, dbg[2] = o.z, dbg[3] = d.x, dbg[4] = d.y, dbg[5] = d.z;
-                                dbg[6] = (float)k, dbg[7] = b * b - a * cc, dbg[8] = (lane < 32) ? rf.thr0 : rf.thr1;
+                                dbg[6] = (float)k, dbg[7] = b * b - a * cc, dbg[8] = 0.f;
                                 dbg[9] = a, dbg[10] = (float)cnt;
                             }
                         }
@@ -447,7 +480,8 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     if (!overflow) {
         for (uint32_t j = 0; __any(j < cnt); ++j) {
             if (j < cnt) {
-                const int k = queue[j * kBlock + tid];
+                const uint32_t slot = (j < cnt_own) ? q_own[j * kBlock] : q_par[(j - cnt_own) * kBlock];
+                const int k = s_tile_sphere[slot];
                 exact_candidate(sph[k], k, o, d, a, best, idx);
             }
         }
@@ -564,7 +598,7 @@ __device__ __forceinline__ int intersect_bvh(const KArgs &A, uint32_t *s_stack /
 // SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
 // (staged once per workgroup); otherwise from HBM/L2 through wave-uniform loads.
 template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY>
-__global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
+__global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
     float4 *s_sph = reinterpret_cast<float4 *>(smem);  // list mode: n_spheres x (cx,cy,cz,r^2)
@@ -580,8 +614,7 @@ __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
     p += MFMA ? A.n_tiles * 2048u : 0u;
     uint16_t *s_tile_sphere = reinterpret_cast<uint16_t *>(p);
     p += MFMA ? ((A.n_tiles * 64u + 15u) & ~15u) : 0u;
-    uint32_t *s_qcnt = reinterpret_cast<uint32_t *>(p);
-    p += MFMA ? kBlock * 4 : 0;
+
     float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][kBlock] attenuation stack
 
     const int tid = threadIdx.x;
@@ -593,7 +626,6 @@ __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
     if (MFMA) {
         for (uint32_t k = tid; k < A.n_tiles * 128u; k += kBlock) s_afrag[k] = A.afrag[k];
         for (uint32_t k = tid; k < A.n_tiles * 32u; k += kBlock) s_tile_sphere[k] = A.tile_sphere[k];
-        s_qcnt[tid] = 0;
     }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += kBlock) s_pvec[k] = A.perlin_vec[k];
@@ -676,7 +708,7 @@ __global__ __launch_bounds__(kBlock, 2) void pt_trace_kernel(const KArgs A) {
         if (BVH)
             idx = intersect_bvh(A, s_bvh, ro, rd, a, have, t_hit);
         else if (MFMA)
-            idx = intersect_list_mfma<VERIFY>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_qcnt,
+            idx = intersect_list_mfma<VERIFY>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere,
                                       s_queue, ro, rd, a, have, t_hit);
         else
             idx = intersect_list(SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, (int)A.n_spheres_pad, s_queue + tid, ro, rd,

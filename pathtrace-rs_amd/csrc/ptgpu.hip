@@ -201,7 +201,7 @@ bool prepare_mfma(const pt_scene_desc *desc, MfmaPrep &out) {
     for (uint32_t T = 0; T < out.n_tiles; ++T) {
         for (uint32_t row = 0; row < 32; ++row) {
             const size_t j = (size_t)T * 32 + row;
-            double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 60000.0};  // padding: S.R = -a * 60000, never a candidate
+            double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 60000.0};  // padding: S.R = -a * 60000 < thr, never a candidate
             if (j < small.size()) {
                 const pt_sphere &p = desc->spheres[small[j]];
                 out.tile_sphere[j] = (uint16_t)small[j];
@@ -211,14 +211,14 @@ bool prepare_mfma(const pt_scene_desc *desc, MfmaPrep &out) {
                 S[6] = x, S[7] = y, S[8] = z, S[9] = x * x + y * y + z * z - (double)r2f;
             }
             _Float16 slot[32];
-            for (int f = 0; f < 10; ++f) {
-                const _Float16 h = (_Float16)S[f];
-                const _Float16 l = (_Float16)(S[f] - (double)h);
+            for (int f = 0; f < 10; ++f) {  // fragments hold -S: the GEMM yields thr - S.R (negative = candidate)
+                const _Float16 h = (_Float16)(-S[f]);
+                const _Float16 l = (_Float16)(-S[f] - (double)h);
                 slot[f] = h;        // x Rh
                 slot[10 + f] = h;   // x Rl
                 slot[20 + f] = l;   // x Rh
             }
-            slot[30] = (_Float16)0.0, slot[31] = (_Float16)0.0;
+            slot[30] = (_Float16)1.0, slot[31] = (_Float16)1.0;  // x thr_hi, x thr_lo
             for (int c = 0; c < 2; ++c)
                 for (int half = 0; half < 2; ++half) {
                     const uint32_t lane = row + 32 * half;
@@ -531,13 +531,13 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.rs2 = s->rs2;
     A.m0 = s->m0;
     A.gamma = s->gamma;
-    A.verify = (s->variant & 8u) ? 1u : 0u;
+    A.verify = ((s->variant & 8u) ? 1u : 0u) | ((s->variant & 16u) ? 2u : 0u);  // bit 16: timing experiment, no stack
     A.debug = s->d_debug;
     uint32_t lds = sph_bytes;
     if (s->has_noise) lds += 4096u + 3072u;
     if (bvh) lds += (uint32_t)kBvhStack * kBlock * 4u;
     if (!bvh) lds += ((kQueueCap + 1) * kBlock * 2u + 15u) / 16u * 16u;
-    if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + kBlock * 4u;
+    if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u);
     const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
     // the MFMA variant keeps the attenuation stack in HBM: its LDS goes to the A fragments, and 3 resident
     // workgroups per CU beat 1 with an LDS stack (measured 7.5 vs 3.0 Grays/s)
@@ -571,7 +571,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     void (*kern)(const KArgs) = nullptr;
     if (bvh)
         kern = pt_trace_kernel<true, false, false, false>;
-    else if (mfma && A.verify)
+    else if (mfma && (A.verify & 1u))
         kern = pt_trace_kernel<false, true, true, true>;
     else if (mfma)
         kern = pt_trace_kernel<false, true, true, false>;
