@@ -89,6 +89,7 @@ struct KArgs {
     float *rgb;
     unsigned long long *ray_count;
     uint32_t *work_counter;
+    const uint32_t *tile_order;  // optional permutation of the 8x8 work tiles (expensive tiles first)
     float *gstack;  // global path-stack fallback when max_depth*3*kBlock*4 exceeds the LDS budget
     uint32_t stack_in_lds;
     uint32_t lds_sphere_bytes;  // offsets of the dynamic LDS carve
@@ -654,7 +655,8 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             if (item >= A.n_items) {
                 exhausted = true;
             } else {
-                const uint32_t tile = item >> 6, in = item & 63u;
+                const uint32_t in = item & 63u;
+                const uint32_t tile = A.tile_order ? A.tile_order[item >> 6] : (item >> 6);
                 const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
                 const uint32_t ly = (tile / A.tiles_x) * 8u + (in >> 3);
                 if (x < A.width && ly < A.local_rows) {
@@ -816,6 +818,55 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
     unsigned long long total = nrays;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
     if (lane == 0) atomicAdd(A.ray_count, total);
+}
+
+// ---- work ordering ------------------------------------------------------------------------------
+// The frame ends when the slowest lane finishes its last pixel, and a pixel's samples are inherently
+// serial (one RNG stream, scene.rs:96-111). Handing out the expensive tiles FIRST keeps that tail
+// short. The cost class of a tile is a heuristic (first hit of the tile's centre ray: glass > metal >
+// diffuse > sky); it only changes the ORDER in which pixels are rendered, never a pixel's value.
+__global__ void pt_tile_class_kernel(const KArgs A, uint32_t n_work_tiles, uint32_t *tile_class, uint32_t *class_count) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_work_tiles) return;
+    uint32_t x = (t % A.tiles_x) * 8u + 4u, ly = (t / A.tiles_x) * 8u + 4u;
+    if (x >= A.width) x = A.width - 1u;
+    if (ly >= A.local_rows) ly = A.local_rows - 1u;
+    const float u = ((float)x + 0.5f) * A.inv_nx, v = ((float)(ly * A.shard_count + A.shard_index) + 0.5f) * A.inv_ny;
+    const f3 o = A.cam.origin;
+    const f3 d = sub3(add3(add3(A.cam.lower_left_corner, scale3(A.cam.horizontal, u)), scale3(A.cam.vertical, v)), o);
+    const float a = dot3(d, d);
+    float best = kMaxT;
+    int idx = -1;
+    for (uint32_t k = 0; k < A.n_spheres; ++k) {
+        const float4 c = A.spheres_r2[k];
+        const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
+        const float b = ocx * d.x + ocy * d.y + ocz * d.z;
+        const float disc = b * b - a * (ocx * ocx + ocy * ocy + ocz * ocz - c.w);
+        if (disc > 0.0f) {
+            const float t0 = (-b - sqrtf(disc)) / a;
+            if (t0 > kMinT && t0 < best) best = t0, idx = (int)k;
+        }
+    }
+    uint32_t cls = 0;  // 0 sky / light, 1 diffuse, 2 metal, 3 glass (most bounces)
+    if (idx >= 0) {
+        const uint32_t kind = A.mats[A.sphere_mat[idx]].kind;
+        cls = kind == PT_MAT_DIELECTRIC ? 3u : (kind == PT_MAT_METAL ? 2u : (kind == PT_MAT_LAMBERTIAN ? 1u : 0u));
+    }
+    tile_class[t] = cls;
+    atomicAdd(&class_count[cls], 1u);
+}
+
+__global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile_class, const uint32_t *class_count,
+                                     uint32_t *tile_order) {
+    __shared__ uint32_t cursor[4];
+    if (threadIdx.x == 0) {  // most expensive class first
+        cursor[3] = 0;
+        cursor[2] = class_count[3];
+        cursor[1] = class_count[3] + class_count[2];
+        cursor[0] = class_count[3] + class_count[2] + class_count[1];
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) tile_order[atomicAdd(&cursor[tile_class[t]], 1u)] = t;
 }
 
 }  // namespace ptdev

@@ -69,6 +69,8 @@ struct pt_scene {
     float c0[3] = {0, 0, 0};
     float rs2 = 0.f, m0 = 0.f, gamma = 0.f;
     unsigned long long *d_debug = nullptr;    // 4 u64 counters (verify mode)
+    uint32_t *d_tile_buf = nullptr;           // [8 counters | n tile classes | n tile order]
+    size_t d_tile_cap = 0;
     uint32_t *d_work_counter = nullptr;       // 1 u32
     unsigned long long *d_ray_count = nullptr; // internal counter for pt_render
     float *d_frame = nullptr;                 // internal frame buffer for pt_render (host-buffer entry point)
@@ -416,6 +418,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_tile_sphere);
     (void)hipFree(s->d_large);
     (void)hipFree(s->d_debug);
+    (void)hipFree(s->d_tile_buf);
     (void)hipFree(s->d_work_counter);
     (void)hipFree(s->d_ray_count);
     (void)hipFree(s->d_frame);
@@ -566,6 +569,25 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
             s->d_gstack_floats = need_floats;
         }
         A.gstack = s->d_gstack;
+    }
+
+    // ---- heavy-first work order (list mode, small scenes; variant bit 32 disables it) ----------------
+    A.tile_order = nullptr;
+    const uint32_t n_work_tiles = A.n_items / 64u;
+    if (!bvh && s->n_spheres <= 4096u && n_work_tiles >= 64u && (s->variant & 32u) == 0) {
+        if (n_work_tiles > s->d_tile_cap) {
+            (void)hipFree(s->d_tile_buf);
+            s->d_tile_buf = nullptr;
+            s->d_tile_cap = 0;
+            HIP_TRY(hipMalloc((void **)&s->d_tile_buf, (8 + 2 * (size_t)n_work_tiles) * sizeof(uint32_t)));
+            s->d_tile_cap = n_work_tiles;
+        }
+        uint32_t *counts = s->d_tile_buf, *cls = s->d_tile_buf + 8, *order = cls + s->d_tile_cap;
+        HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(pt_tile_class_kernel, dim3((n_work_tiles + 255) / 256), dim3(256), 0, stream, A, n_work_tiles, cls, counts);
+        hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cls, counts, order);
+        HIP_TRY(hipGetLastError());
+        A.tile_order = order;
     }
 
     void (*kern)(const KArgs) = nullptr;
