@@ -143,13 +143,29 @@ __device__ __forceinline__ float perlin_turb(const PerlinLds &pn, f3 p) {
     return fabsf(accum);
 }
 
+// texture.rs:78-85: `sin(s.x) * sin(s.y) * sin(s.z) < 0.0`. Only the SIGN of the product is used, and
+// sign(sin x) = sign(x) * (-1)^floor(|x| / pi) for every finite x != 0 (libm's sinf is accurate to
+// < 1 ulp and |sin x| of an f32 x is never small enough to round to zero, so its sign is the exact
+// sign; the f64 quotient has ~1000x more resolution than the closest an f32 gets to a multiple of pi
+// at scene scale). A zero factor makes the product +-0, which is not < 0. Three f64 multiplies
+// replace three full-range sinf evaluations; huge or non-finite arguments take the sinf path.
+__device__ __forceinline__ bool checker_is_odd(float sx, float sy, float sz) {
+    const float ax = __builtin_fabsf(sx), ay = __builtin_fabsf(sy), az = __builtin_fabsf(sz);
+    if (!(ax < 1.0e6f && ay < 1.0e6f && az < 1.0e6f)) return sinf(sx) * sinf(sy) * sinf(sz) < 0.0f;
+    if (sx == 0.0f || sy == 0.0f || sz == 0.0f) return false;
+    constexpr double kInvPi = 0.31830988618379067154;
+    const int kx = (int)((double)ax * kInvPi), ky = (int)((double)ay * kInvPi), kz = (int)((double)az * kInvPi);
+    const int neg = (kx ^ ky ^ kz) & 1;
+    const int sgn = (int)((__float_as_uint(sx) ^ __float_as_uint(sy) ^ __float_as_uint(sz)) >> 31);
+    return (neg ^ sgn) != 0;
+}
+
 // texture.rs:74-91 (Constant / Checker / Noise; Checker may nest)
 __device__ __noinline__ f3 texture_value(const DTex *texs, const PerlinLds &pn, int32_t tex, f3 p) {
     DTex t = texs[tex];
     while (t.kind == PT_TEX_CHECKER) {
         const f3 s = mk3(10.0f * p.x, 10.0f * p.y, 10.0f * p.z);
-        const float sines = sinf(s.x) * sinf(s.y) * sinf(s.z);
-        t = texs[(sines < 0.0f) ? t.odd : t.even];
+        t = texs[checker_is_odd(s.x, s.y, s.z) ? t.odd : t.even];
     }
     if (t.kind == PT_TEX_NOISE) {
         const float v = 1.0f + sinf(t.scale * p.z + 10.0f * perlin_turb(pn, p));
