@@ -60,6 +60,11 @@ struct KArgs {
     const DWideNode *wnodes;  // caller's BVH re-laid out: children's AABBs inside the parent
     const uint32_t *leaf_rank;       // DFS (lhs before rhs) order of each sphere's leaf, for equal-t ties
     float root_min[3], root_max[3];
+    uint32_t n_nodes, nodes_in_lds, bvh_stack_entries;
+    // BVH mode acceleration structure built by pt_scene_create (the caller's tree only defines the RESULT)
+    const float4 *gate;          // [2*n_spheres] AABB (min, max) of each sphere's parent node in the caller's tree
+    const uint32_t *bvh_large;   // spheres kept out of the internal tree (huge radius): tested for every ray
+    uint32_t n_bvh_large;
     uint32_t n_spheres;
     uint32_t n_spheres_pad;      // multiple of kScanUnroll; padding entries can never be hit
     // MFMA discriminant prefilter (list mode, see "MFMA prefilter" below); n_tiles == 0 disables it
@@ -536,7 +541,7 @@ struct DWideNode {  // 64 B
     float lmin[3], lmax[3];  // AABB of lhs when lhs is an inner node
     float rmin[3], rmax[3];  // AABB of rhs when rhs is an inner node
     int32_t lhs, rhs;        // >= 0 inner node, < 0 ~sphere
-    uint32_t pad0, pad1;
+    uint32_t pad0, pad1;     // internal tree: smallest |radius| below lhs / rhs (float bits)
 };
 
 // aabb.rs:46-58 (exact), also returning the entry distance max(t0x, t0y, t0z, t_min) for ordering
@@ -555,7 +560,11 @@ __device__ __forceinline__ bool aabb_hit_enter(const float mn[3], const float mx
 constexpr float kCullRel = 1.02f;
 constexpr float kCullAbs = 0.02f;
 
-__device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, f3 o, f3 d, float a, float &best, int &idx,
+// One leaf of the reference tree: hitable.rs:47 passes the ORIGINAL t_max to the sphere, and the sphere only
+// counts if every ancestor AABB passed aabb.rs:46-58. Ancestor boxes nest (each is the union of its
+// children, aabb.rs:61-66, and the slab arithmetic is monotone in the box), so testing the sphere's PARENT
+// box with the reference's exact arithmetic decides all of them.
+__device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, f3 o, f3 d, f3 rcp, float a, float &best, int &idx,
                                          uint32_t &best_rank) {
     const float4 c = A.spheres[k];
     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
@@ -563,53 +572,101 @@ __device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, f3 o, f3 d, floa
     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
     const float disc = b * b - a * cc;
     if (disc > 0.0f) {
-        float t = kMaxT;  // hitable.rs:47 passes the ORIGINAL t_max to every leaf
+        float t = kMaxT;
         if (sphere_roots(a, b, disc, t)) {
             const uint32_t rank = A.leaf_rank[k];
             if (idx < 0 || t < best || (t == best && rank > best_rank)) {
-                best = t;
-                idx = k;
-                best_rank = rank;
+                const float4 gmn = A.gate[2 * k], gmx = A.gate[2 * k + 1];
+                const float mn[3] = {gmn.x, gmn.y, gmn.z}, mx[3] = {gmx.x, gmx.y, gmx.z};
+                float te;
+                if (aabb_hit_enter(mn, mx, o, rcp, te)) {
+                    best = t;
+                    idx = k;
+                    best_rank = rank;
+                }
             }
         }
     }
 }
 
-__device__ __forceinline__ int intersect_bvh(const KArgs &A, uint32_t *s_stack /* [kBvhStack][kBlock] */, f3 o, f3 d,
-                                             float a, bool active, float &t_out) {
+// Conservative slab test of an INTERNAL-tree box: never rejects a box that contains a sphere whose
+// reference discriminant can be positive. The reference's f32 discriminant differs from the exact one by
+// <= ~1.3e-6 * a * (|o-c|^2 + r^2), i.e. a sphere behaves as if its radius were larger by at most
+// ~0.65e-6 * (|o-c|^2 + r^2) / r; the box is padded by >= 4x that bound (r_min = smallest radius below the
+// node) plus an absolute epsilon. NaNs (0 * inf) count as a hit.
+__device__ __forceinline__ bool accel_box_hit(const float mn[3], const float mx[3], float rmin, f3 o, f3 rcp, float limit,
+                                              float &t_enter) {
+    const float cx = 0.5f * (mn[0] + mx[0]) - o.x, cy = 0.5f * (mn[1] + mx[1]) - o.y, cz = 0.5f * (mn[2] + mx[2]) - o.z;
+    const float hx = mx[0] - mn[0], hy = mx[1] - mn[1], hz = mx[2] - mn[2];
+    const float reach2 = 2.0f * ((cx * cx + cy * cy + cz * cz) + 0.25f * (hx * hx + hy * hy + hz * hz));
+    const float pad = 3.0e-6f * reach2 / rmin + 1.0e-4f;
+    const float ax = (mn[0] - pad - o.x) * rcp.x, bx = (mx[0] + pad - o.x) * rcp.x;
+    const float ay = (mn[1] - pad - o.y) * rcp.y, by = (mx[1] + pad - o.y) * rcp.y;
+    const float az = (mn[2] - pad - o.z) * rcp.z, bz = (mx[2] + pad - o.z) * rcp.z;
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    t_enter = tn;
+    return !(tf < tn) && !(tn > limit);
+}
+
+// Resumable per-lane traversal state. A ray-iteration in BVH mode is NOT lockstep: lanes whose traversal
+// has finished are shaded (and given their next ray) as soon as enough of them are waiting, while the
+// long-tail lanes simply keep their stack and continue in the next round -- otherwise every wave would
+// run as long as its slowest ray (measured: 19 % lane utilisation with lockstep iterations).
+struct BvhTrav {
+    int sp;
+    float best;
+    int idx;
+    uint32_t rank;
+    bool active;
+};
+constexpr int kReadyMin = 32;  // shade as soon as this many lanes of the wave have a finished traversal
+
+__device__ __forceinline__ void bvh_start(const KArgs &A, uint32_t *s_stack, f3 o, f3 d, float a, BvhTrav &st) {
     const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // ray.rs:14
+    st.sp = 0;
+    st.best = kMaxT;
+    st.idx = -1;
+    st.rank = 0;
+    st.active = true;
+    for (uint32_t j = 0; j < A.n_bvh_large; ++j) bvh_leaf(A, (int)A.bvh_large[j], o, d, rcp, a, st.best, st.idx, st.rank);
+    if (A.bvh_root >= 0) s_stack[(st.sp++) * kBlock + threadIdx.x] = (uint32_t)A.bvh_root;
+}
+
+template <bool NODES_LDS>
+__device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const DWideNode *nodes, f3 o, f3 d, float a,
+                                        bool have, BvhTrav &st) {
+    const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int tid = threadIdx.x;
-    int sp = 0;
-    float best = kMaxT;
-    int idx = -1;
-    uint32_t best_rank = 0;
-    float te;
-    if (active && aabb_hit_enter(A.root_min, A.root_max, o, rcp, te)) s_stack[(sp++) * kBlock + tid] = (uint32_t)A.bvh_root;
-    while (sp > 0) {
-        const int32_t ref = (int32_t)s_stack[(--sp) * kBlock + tid];
-        const DWideNode n = A.wnodes[ref];
-        // leaves first: they can only shrink `best` before the inner children are considered
-        if (n.lhs < 0) bvh_leaf(A, ~n.lhs, o, d, a, best, idx, best_rank);
-        if (n.rhs < 0) bvh_leaf(A, ~n.rhs, o, d, a, best, idx, best_rank);
-        float tl = 0.f, tr = 0.f;
-        bool hl = false, hr = false;
-        if (n.lhs >= 0) hl = aabb_hit_enter(n.lmin, n.lmax, o, rcp, tl);
-        if (n.rhs >= 0) hr = aabb_hit_enter(n.rmin, n.rmax, o, rcp, tr);
-        const float limit = (idx >= 0) ? (best * kCullRel + kCullAbs) : kMaxT;
-        hl = hl && !(tl > limit);
-        hr = hr && !(tr > limit);
-        if (hl && hr) {
-            const bool l_near = tl <= tr;
-            s_stack[(sp++) * kBlock + tid] = (uint32_t)(l_near ? n.rhs : n.lhs);
-            s_stack[(sp++) * kBlock + tid] = (uint32_t)(l_near ? n.lhs : n.rhs);
-        } else if (hl) {
-            s_stack[(sp++) * kBlock + tid] = (uint32_t)n.lhs;
-        } else if (hr) {
-            s_stack[(sp++) * kBlock + tid] = (uint32_t)n.rhs;
+    for (;;) {
+        if (st.active) {
+            if (st.sp == 0) {
+                st.active = false;
+            } else {
+                const int32_t ref = (int32_t)s_stack[(--st.sp) * kBlock + tid];
+                const DWideNode n = nodes[ref];
+                // leaves first: they can only shrink `best` before the inner children are considered
+                if (n.lhs < 0) bvh_leaf(A, ~n.lhs, o, d, rcp, a, st.best, st.idx, st.rank);
+                if (n.rhs < 0) bvh_leaf(A, ~n.rhs, o, d, rcp, a, st.best, st.idx, st.rank);
+                const float limit = (st.idx >= 0) ? (st.best * kCullRel + kCullAbs) : kMaxT;
+                float tl = 0.f, tr = 0.f;
+                bool hl = false, hr = false;
+                if (n.lhs >= 0) hl = accel_box_hit(n.lmin, n.lmax, __uint_as_float(n.pad0), o, rcp, limit, tl);
+                if (n.rhs >= 0) hr = accel_box_hit(n.rmin, n.rmax, __uint_as_float(n.pad1), o, rcp, limit, tr);
+                if (hl && hr) {
+                    const bool l_near = tl <= tr;
+                    s_stack[(st.sp++) * kBlock + tid] = (uint32_t)(l_near ? n.rhs : n.lhs);
+                    s_stack[(st.sp++) * kBlock + tid] = (uint32_t)(l_near ? n.lhs : n.rhs);
+                } else if (hl) {
+                    s_stack[(st.sp++) * kBlock + tid] = (uint32_t)n.lhs;
+                } else if (hr) {
+                    s_stack[(st.sp++) * kBlock + tid] = (uint32_t)n.rhs;
+                }
+            }
         }
+        if (__ballot(st.active) == 0ull) break;
+        if (__popcll(__ballot(have && !st.active)) >= kReadyMin) break;
     }
-    t_out = best;
-    return idx;
 }
 
 // SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
@@ -624,7 +681,9 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
     uint32_t *s_perm = reinterpret_cast<uint32_t *>(p + (A.has_noise ? 4096 : 0));
     p += A.has_noise ? (4096 + 3072) : 0;
     uint32_t *s_bvh = reinterpret_cast<uint32_t *>(p);
-    p += BVH ? (kBvhStack * kBlock * 4) : 0;
+    p += BVH ? (A.bvh_stack_entries * kBlock * 4) : 0;
+    DWideNode *s_nodes = reinterpret_cast<DWideNode *>(p);
+    p += (BVH && A.nodes_in_lds) ? A.n_nodes * 64u : 0u;
     uint16_t *s_queue = reinterpret_cast<uint16_t *>(p);  // list mode: [kQueueCap+1][kBlock] u16
     p += BVH ? 0 : ((kQueueCap + 1) * kBlock * 2 + 15) / 16 * 16;
     uint4 *s_afrag = reinterpret_cast<uint4 *>(p);        // MFMA: [n_tiles][2][64] x 16 B
@@ -644,6 +703,11 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
         for (uint32_t k = tid; k < A.n_tiles * 128u; k += kBlock) s_afrag[k] = A.afrag[k];
         for (uint32_t k = tid; k < A.n_tiles * 32u; k += kBlock) s_tile_sphere[k] = A.tile_sphere[k];
     }
+    if (BVH && A.nodes_in_lds) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(A.wnodes);
+        uint4 *dst = reinterpret_cast<uint4 *>(s_nodes);
+        for (uint32_t k = tid; k < A.n_nodes * 4u; k += kBlock) dst[k] = src[k];
+    }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += kBlock) s_pvec[k] = A.perlin_vec[k];
         for (int k = tid; k < 768; k += kBlock) s_perm[k] = A.perlin_perm[k];
@@ -654,7 +718,8 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
     float *path = A.stack_in_lds ? (s_path + tid)
                                  : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * kBlock + tid);
 
-    bool have = false, exhausted = false, need_cam = true;
+    bool have = false, exhausted = false, need_cam = true, trav_new = false;
+    BvhTrav trav{0, kMaxT, -1, 0u, false};
     uint32_t px = 0, py = 0, boff = 0, sample = 0, depth = 0, nrays = 0;
     Rng rng{0, 0, 0, 0};
     f3 col = mk3(0.f, 0.f, 0.f), o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
@@ -715,6 +780,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             d = normalize3(dir);
             depth = 0;
             need_cam = false;
+            trav_new = true;
         }
 
         // ---- hitable.rs:39-65: closest hit (inactive lanes carry a null ray)
@@ -723,17 +789,26 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
         const float a = dot3(rd, rd);  // sphere.rs:34
         float t_hit;
         int idx;
-        if (BVH)
-            idx = intersect_bvh(A, s_bvh, ro, rd, a, have, t_hit);
-        else if (MFMA)
+        if (BVH) {
+            if (have && trav_new) {
+                bvh_start(A, s_bvh, o, d, dot3(d, d), trav);
+                trav_new = false;
+            }
+            if (A.nodes_in_lds)
+                bvh_run<true>(A, s_bvh, s_nodes, ro, rd, a, have, trav);
+            else
+                bvh_run<false>(A, s_bvh, A.wnodes, ro, rd, a, have, trav);
+            idx = trav.idx;
+            t_hit = trav.best;
+        } else if (MFMA)
             idx = intersect_list_mfma<VERIFY>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere,
                                       s_queue, ro, rd, a, have, t_hit);
         else
             idx = intersect_list(SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, (int)A.n_spheres_pad, s_queue + tid, ro, rd,
                                  a, t_hit);
 
-        // ---- scene.rs:49-71 one level of ray_trace
-        if (have) {
+        // ---- scene.rs:49-71 one level of ray_trace (BVH mode: only lanes whose traversal has finished)
+        if (have && !(BVH && trav.active)) {
             nrays += 1;
             bool terminal = true;
             f3 V;
@@ -803,6 +878,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                     o = point;
                     d = nd;
                     terminal = false;
+                    trav_new = true;
                 } else {
                     V = emitted;
                 }

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -58,6 +59,10 @@ struct pt_scene {
     DTex *d_texs = nullptr;
     float4 *d_perlin_vec = nullptr;
     uint32_t *d_perlin_perm = nullptr;
+    float4 *d_gate = nullptr;
+    uint32_t *d_bvh_large = nullptr;
+    uint32_t n_bvh_large = 0;
+    int32_t accel_root = -1;
     DWideNode *d_wnodes = nullptr;
     uint32_t *d_leaf_rank = nullptr;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
@@ -234,6 +239,95 @@ bool prepare_mfma(const pt_scene_desc *desc, MfmaPrep &out) {
 
 }  // namespace
 
+
+namespace {
+
+// ---- internal BVH for BVH mode ------------------------------------------------------------------
+// The caller's tree (bvh.rs:64-94: random split axis, median split) defines the RESULT of BVHNode::ray_hit
+// but can be arbitrarily bad for traversal (random_spheres / perlin_spheres: every sphere has the same y, so
+// a third of the levels do not separate anything: ~1800 node visits per ray in the 10k-sphere scene).
+// pt_scene_create therefore builds its own tree (longest-axis median split over sphere centres; spheres
+// with a huge radius are kept out and tested for every ray) and keeps, per sphere, the AABB of its parent in
+// the CALLER's tree, which is all that is needed to reproduce the reference's accept/reject decision.
+struct AccelBuild {
+    std::vector<DWideNode> nodes;
+    std::vector<uint32_t> large;
+    int32_t root = -1;
+    uint32_t depth = 0;
+};
+
+struct AccelItem {
+    uint32_t sphere;
+    float c[3], mn[3], mx[3], r;
+};
+
+struct AccelRef {
+    int32_t ref;
+    float mn[3], mx[3], rmin;
+    uint32_t depth;
+};
+
+AccelRef accel_build(std::vector<AccelItem> &items, size_t lo, size_t hi, std::vector<DWideNode> &nodes) {
+    if (hi - lo == 1) {
+        const AccelItem &it = items[lo];
+        AccelRef r{~(int32_t)it.sphere, {it.mn[0], it.mn[1], it.mn[2]}, {it.mx[0], it.mx[1], it.mx[2]}, it.r, 0};
+        return r;
+    }
+    float cmin[3] = {3e38f, 3e38f, 3e38f}, cmax[3] = {-3e38f, -3e38f, -3e38f};
+    for (size_t i = lo; i < hi; ++i)
+        for (int k = 0; k < 3; ++k) cmin[k] = std::min(cmin[k], items[i].c[k]), cmax[k] = std::max(cmax[k], items[i].c[k]);
+    int axis = 0;
+    for (int k = 1; k < 3; ++k)
+        if (cmax[k] - cmin[k] > cmax[axis] - cmin[axis]) axis = k;
+    const size_t mid = lo + (hi - lo) / 2;
+    std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
+                     [axis](const AccelItem &a, const AccelItem &b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.sphere < b.sphere); });
+    const AccelRef l = accel_build(items, lo, mid, nodes), r = accel_build(items, mid, hi, nodes);
+    DWideNode w;
+    memset(&w, 0, sizeof w);
+    memcpy(w.lmin, l.mn, 12), memcpy(w.lmax, l.mx, 12), memcpy(w.rmin, r.mn, 12), memcpy(w.rmax, r.mx, 12);
+    w.lhs = l.ref, w.rhs = r.ref;
+    memcpy(&w.pad0, &l.rmin, 4), memcpy(&w.pad1, &r.rmin, 4);
+    nodes.push_back(w);
+    AccelRef out;
+    out.ref = (int32_t)nodes.size() - 1;
+    for (int k = 0; k < 3; ++k) out.mn[k] = std::min(l.mn[k], r.mn[k]), out.mx[k] = std::max(l.mx[k], r.mx[k]);
+    out.rmin = std::min(l.rmin, r.rmin);
+    out.depth = 1 + std::max(l.depth, r.depth);
+    return out;
+}
+
+AccelBuild build_accel(const pt_scene_desc *desc) {
+    AccelBuild out;
+    std::vector<float> radii;
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) radii.push_back(std::fabs(desc->spheres[i].radius));
+    std::vector<float> sorted = radii;
+    std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
+    const float median = sorted[sorted.size() / 2];
+    std::vector<AccelItem> items;
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+        const pt_sphere &p = desc->spheres[i];
+        const float r = radii[i];
+        const bool finite = std::isfinite(p.cx) && std::isfinite(p.cy) && std::isfinite(p.cz) && std::isfinite(r);
+        if (!finite || r > 16.0f * median || !(r > 0.0f)) {
+            out.large.push_back(i);
+            continue;
+        }
+        AccelItem it{i, {p.cx, p.cy, p.cz}, {p.cx - r, p.cy - r, p.cz - r}, {p.cx + r, p.cy + r, p.cz + r}, r};
+        items.push_back(it);
+    }
+    if (items.size() < 2) {  // degenerate: everything is tested directly
+        for (const AccelItem &it : items) out.large.push_back(it.sphere);
+        return out;
+    }
+    const AccelRef root = accel_build(items, 0, items.size(), out.nodes);
+    out.root = root.ref;
+    out.depth = root.depth;
+    return out;
+}
+
+}  // namespace
+
 extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene **scene_out) {
     if (!desc || !scene_out) return fail(PT_ERR_INVALID_ARG, "desc/scene_out is NULL");
     *scene_out = nullptr;
@@ -271,8 +365,7 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
         if (!desc->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "bvh_nodes is NULL");
         bvh_depth = bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_spheres, desc->bvh_root);
         if (bvh_depth == 0) return fail(PT_ERR_INVALID_ARG, "malformed BVH (bad child index or cycle)");
-        if (bvh_depth + 1 > (uint32_t)kBvhStack)
-            return fail(PT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack (%d)", bvh_depth, kBvhStack - 1);
+        // (the caller's depth is irrelevant: traversal runs over the internal tree built below)
     }
     if (desc->perlin)
         for (int i = 0; i < 256; ++i)
@@ -319,36 +412,44 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
         const pt_texture &t = desc->textures[i];
         texs[i] = DTex{t.kind, t.color[0], t.color[1], t.color[2], t.odd, t.even, t.scale, 0.f};
     }
-    // Re-lay the caller's BVH out for traversal: every node carries its children's AABBs (the same
-    // float values the reference tests, just stored one level up), plus the DFS rank of every leaf.
-    std::vector<DWideNode> wnodes(desc->n_bvh_nodes);
-    std::vector<uint32_t> leaf_rank(desc->n_spheres, 0);
-    for (uint32_t i = 0; i < desc->n_bvh_nodes; ++i) {
-        const pt_bvh_node &n = desc->bvh_nodes[i];
-        DWideNode w;
-        memset(&w, 0, sizeof w);
-        w.lhs = n.lhs;
-        w.rhs = n.rhs;
-        if (n.lhs >= 0) memcpy(w.lmin, desc->bvh_nodes[n.lhs].min, 12), memcpy(w.lmax, desc->bvh_nodes[n.lhs].max, 12);
-        if (n.rhs >= 0) memcpy(w.rmin, desc->bvh_nodes[n.rhs].min, 12), memcpy(w.rmax, desc->bvh_nodes[n.rhs].max, 12);
-        wnodes[i] = w;
-    }
+    // BVH mode: per-sphere parent AABB + DFS rank from the CALLER's tree (they define the result), and the
+    // internal traversal tree.
+    std::vector<DWideNode> wnodes;
+    std::vector<uint32_t> leaf_rank(desc->n_spheres, 0), bvh_large;
+    std::vector<float4> gate(2 * (size_t)desc->n_spheres, make_float4(0, 0, 0, 0));
+    uint32_t accel_depth = 0;
     if (desc->n_bvh_nodes) {
-        memcpy(s->root_min, desc->bvh_nodes[desc->bvh_root].min, 12);
-        memcpy(s->root_max, desc->bvh_nodes[desc->bvh_root].max, 12);
+        // a sphere that is not a leaf of the caller's tree can never be hit: give it an empty gate box
+        for (uint32_t i = 0; i < desc->n_spheres; ++i) gate[2 * i] = make_float4(1, 1, 1, 0), gate[2 * i + 1] = make_float4(-1, -1, -1, 0);
         // lhs-before-rhs DFS; a sphere referenced by several leaves keeps its LAST rank (bvh.rs:73-79 lhs == rhs)
-        std::vector<int32_t> st{desc->bvh_root};
+        std::vector<std::pair<int32_t, int32_t>> st{{desc->bvh_root, -1}};
         uint32_t rank = 0;
         while (!st.empty()) {
-            const int32_t ref = st.back();
+            const auto [ref, parent] = st.back();
             st.pop_back();
             if (ref < 0) {
-                leaf_rank[~ref] = rank++;
+                const uint32_t k = (uint32_t)~ref;
+                leaf_rank[k] = rank++;
+                const pt_bvh_node &pn = desc->bvh_nodes[parent];
+                gate[2 * k] = make_float4(pn.min[0], pn.min[1], pn.min[2], 0.f);
+                gate[2 * k + 1] = make_float4(pn.max[0], pn.max[1], pn.max[2], 0.f);
             } else {
-                st.push_back(desc->bvh_nodes[ref].rhs);
-                st.push_back(desc->bvh_nodes[ref].lhs);
+                st.push_back({desc->bvh_nodes[ref].rhs, ref});
+                st.push_back({desc->bvh_nodes[ref].lhs, ref});
             }
         }
+        AccelBuild acc = build_accel(desc);
+        wnodes = std::move(acc.nodes);
+        bvh_large = std::move(acc.large);
+        s->accel_root = acc.root;
+        accel_depth = acc.depth;
+        if (accel_depth + 2 > (uint32_t)kBvhStack) {
+            pt_scene_destroy(s);
+            return fail(PT_ERR_UNSUPPORTED, "internal BVH depth %u exceeds the traversal stack", accel_depth);
+        }
+        s->bvh_depth = accel_depth;
+        s->n_nodes = (uint32_t)wnodes.size();
+        s->n_bvh_large = (uint32_t)bvh_large.size();
     }
     std::vector<float4> pvec(256, make_float4(0, 0, 0, 0));
     std::vector<uint32_t> pperm(768, 0);
@@ -365,7 +466,8 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
         (rc = upload(&s->d_sphere_mat, desc->sphere_material, desc->n_spheres)) ||
         (rc = upload(&s->d_mats, mats.data(), mats.size())) || (rc = upload(&s->d_texs, texs.data(), texs.size())) ||
         (rc = upload(&s->d_perlin_vec, pvec.data(), pvec.size())) || (rc = upload(&s->d_perlin_perm, pperm.data(), pperm.size())) ||
-        (rc = upload(&s->d_wnodes, wnodes.data(), wnodes.size())) || (rc = upload(&s->d_leaf_rank, leaf_rank.data(), leaf_rank.size()))) {
+        (rc = upload(&s->d_wnodes, wnodes.data(), wnodes.size())) || (rc = upload(&s->d_leaf_rank, leaf_rank.data(), leaf_rank.size())) ||
+        (rc = upload(&s->d_gate, gate.data(), gate.size())) || (rc = upload(&s->d_bvh_large, bvh_large.data(), bvh_large.size()))) {
         pt_scene_destroy(s);
         return rc;
     }
@@ -412,6 +514,8 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_texs);
     (void)hipFree(s->d_perlin_vec);
     (void)hipFree(s->d_perlin_perm);
+    (void)hipFree(s->d_gate);
+    (void)hipFree(s->d_bvh_large);
     (void)hipFree(s->d_wnodes);
     (void)hipFree(s->d_leaf_rank);
     (void)hipFree(s->d_afrag);
@@ -465,13 +569,16 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.texs = s->d_texs;
     A.perlin_vec = s->d_perlin_vec;
     A.perlin_perm = s->d_perlin_perm;
+    A.gate = s->d_gate;
+    A.bvh_large = s->d_bvh_large;
+    A.n_bvh_large = s->n_bvh_large;
     A.wnodes = s->d_wnodes;
     A.leaf_rank = s->d_leaf_rank;
     memcpy(A.root_min, s->root_min, 12);
     memcpy(A.root_max, s->root_max, 12);
     A.n_spheres = s->n_spheres;
     A.n_spheres_pad = (s->n_spheres + kScanUnroll - 1) / kScanUnroll * kScanUnroll;
-    A.bvh_root = s->bvh_root;
+    A.bvh_root = s->accel_root;  // root of the INTERNAL tree (-1: every sphere is in bvh_large)
     A.has_sky = s->has_sky;
     A.sky = to3(s->sky);
     A.has_noise = s->has_noise;
@@ -538,7 +645,10 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.debug = s->d_debug;
     uint32_t lds = sph_bytes;
     if (s->has_noise) lds += 4096u + 3072u;
-    if (bvh) lds += (uint32_t)kBvhStack * kBlock * 4u;
+    A.n_nodes = s->n_nodes;
+    A.bvh_stack_entries = s->bvh_depth + 2u;
+    A.nodes_in_lds = (bvh && s->n_nodes * 64u <= 32u * 1024u && (s->variant & 1u) == 0) ? 1u : 0u;
+    if (bvh) lds += A.bvh_stack_entries * kBlock * 4u + (A.nodes_in_lds ? s->n_nodes * 64u : 0u);
     if (!bvh) lds += ((kQueueCap + 1) * kBlock * 2u + 15u) / 16u * 16u;
     if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u);
     const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
