@@ -97,7 +97,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("PT_BENCH_FORCE_DIST") == "1"   # exercise the sharded path with one rank (testing)
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -118,14 +119,14 @@ def main():
     max_rows = sharding.padded_rows(H, N)
     shard = torch.zeros((max_rows, W, 3), dtype=torch.float32, device=dev)
     ray_count = torch.zeros(1, dtype=torch.int64, device=dev)
-    gathered = torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev) if N > 1 else None
+    gathered = torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev) if (N > 1 or dist is not None) else None
     frame = None
     kernel_ms = []
 
     def step():
         nonlocal frame
         shard.zero_()  # frame 0 of a fresh accumulation (offline.rs:25 starts from zeros)
-        if N == 1:
+        if N == 1 and dist is None:
             scene.update_device(params, cam, 0, shard.data_ptr(), ray_count.data_ptr(), stream.cuda_stream)
             frame = shard
         else:

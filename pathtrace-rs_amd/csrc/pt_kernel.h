@@ -43,6 +43,14 @@ struct DNode {  // 32 B, collision/bvh.rs:24-28 flattened
 
 struct DWideNode;
 
+// Per-sphere shading record: everything Material::scatter / emitted needs for the common cases, resolved at
+// scene creation so a hit costs one 64-byte fetch instead of the dependent chain
+// sphere -> material index -> material -> texture (-> checker children).
+//   q0 = (cx, cy, cz, radius)   q1 = (kind, flags, texture id, param as float bits)
+//   q2 = colour A (constant albedo / metal albedo / emitted constant / checker ODD)   q3 = checker EVEN colour
+constexpr uint32_t kShadeConst = 1u;    // texture is Constant: colour A
+constexpr uint32_t kShadeChecker2 = 2u; // texture is Checker of two Constants: odd = A, even = q3
+
 struct DCamera {  // camera.rs:8-19
     f3 origin, lower_left_corner, horizontal, vertical, u, v, w;
     float time0, time1, lens_radius;
@@ -51,6 +59,7 @@ struct DCamera {  // camera.rs:8-19
 struct KArgs {
     // scene (HBM resident)
     const float4 *spheres;       // cx, cy, cz, radius
+    const float4 *shade;         // [4*n_spheres] per-sphere shading record (DShadeRec): ONE 64-byte fetch per hit
     const float4 *spheres_r2;    // cx, cy, cz, radius*radius (sphere.rs:36), scan layout, padded to n_spheres_pad
     const uint32_t *sphere_mat;  // material index per sphere
     const DMat *mats;
@@ -822,25 +831,36 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                     V = mk3(w1 + (t * 0.5f) * 0.3f, w1 + (t * 0.7f) * 0.3f, w1 + (t * 1.0f) * 0.3f);
                 }
             } else {
-                const float4 sp = A.spheres[idx];
+                const float4 sp = A.shade[4 * idx], q1 = A.shade[4 * idx + 1], qa = A.shade[4 * idx + 2],
+                             qb = A.shade[4 * idx + 3];
                 const f3 centre = mk3(sp.x, sp.y, sp.z);
                 const f3 point = add3(o, scale3(d, t_hit));            // ray.rs:24-26
                 const f3 normal = divs3(sub3(point, centre), sp.w);    // sphere.rs:42
-                const DMat m = A.mats[A.sphere_mat[idx]];
+                struct { uint32_t kind, flags; int32_t tex; float param; } m = {
+                    __float_as_uint(q1.x), __float_as_uint(q1.y), (int32_t)__float_as_uint(q1.z), q1.w};
+                // Texture::value for this sphere's texture (texture.rs:74-91), inlined for the resolved cases
+                auto surface_colour = [&]() -> f3 {
+                    if (m.flags & kShadeConst) return mk3(qa.x, qa.y, qa.z);
+                    if (m.flags & kShadeChecker2) {
+                        const bool odd = checker_is_odd(10.0f * point.x, 10.0f * point.y, 10.0f * point.z);
+                        return odd ? mk3(qa.x, qa.y, qa.z) : mk3(qb.x, qb.y, qb.z);
+                    }
+                    return texture_value(A.texs, pn, m.tex, point);
+                };
                 f3 emitted = mk3(0.f, 0.f, 0.f);                        // material.rs:161-167
-                if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = texture_value(A.texs, pn, m.tex, point);
+                if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = surface_colour();
                 bool scattered = false;
                 f3 att = mk3(1.f, 1.f, 1.f), nd = d;
                 if (depth < A.max_depth) {
                     if (m.kind == PT_MAT_LAMBERTIAN) {  // material.rs:52-67
                         const f3 target = add3(add3(point, normal), random_unit_vector(rng));
-                        att = texture_value(A.texs, pn, m.tex, point);
+                        att = surface_colour();
                         nd = normalize3(sub3(target, point));
                         scattered = true;
                     } else if (m.kind == PT_MAT_METAL) {  // material.rs:69-89
                         const f3 reflected = reflect3(d, normal);
                         if (dot3(reflected, normal) > 0.0f) {
-                            att = mk3(m.a0, m.a1, m.a2);
+                            att = mk3(qa.x, qa.y, qa.z);
                             const f3 rs = random_in_unit_sphere(rng);
                             nd = normalize3(add3(reflected, scale3(rs, m.param)));
                             scattered = true;

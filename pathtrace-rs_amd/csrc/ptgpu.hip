@@ -53,7 +53,7 @@ struct pt_scene {
     float sky[3] = {0, 0, 0};
     uint32_t has_noise = 0;
     // device memory
-    float4 *d_spheres = nullptr, *d_spheres_r2 = nullptr;
+    float4 *d_spheres = nullptr, *d_spheres_r2 = nullptr, *d_shade = nullptr;
     uint32_t *d_sphere_mat = nullptr;
     DMat *d_mats = nullptr;
     DTex *d_texs = nullptr;
@@ -402,6 +402,32 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
         const volatile float r2 = p.radius * p.radius;  // sphere.rs:36, one f32 rounding
         sph_r2[i] = make_float4(p.cx, p.cy, p.cz, r2);
     }
+    // per-sphere shading records (one 64-byte fetch per hit)
+    std::vector<float4> shade(4 * (size_t)desc->n_spheres);
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+        const pt_sphere &p = desc->spheres[i];
+        const pt_material &m = desc->materials[desc->sphere_material[i]];
+        uint32_t flags = 0;
+        float4 qa = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], 0.f), qb = make_float4(0, 0, 0, 0);
+        if (m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_DIFFUSE_LIGHT) {
+            const pt_texture &t = desc->textures[m.texture];
+            if (t.kind == PT_TEX_CONSTANT) {
+                flags = kShadeConst;
+                qa = make_float4(t.color[0], t.color[1], t.color[2], 0.f);
+            } else if (t.kind == PT_TEX_CHECKER && desc->textures[t.odd].kind == PT_TEX_CONSTANT &&
+                       desc->textures[t.even].kind == PT_TEX_CONSTANT) {
+                flags = kShadeChecker2;
+                const pt_texture &o = desc->textures[t.odd], &e = desc->textures[t.even];
+                qa = make_float4(o.color[0], o.color[1], o.color[2], 0.f);
+                qb = make_float4(e.color[0], e.color[1], e.color[2], 0.f);
+            }
+        }
+        union { uint32_t u; float f; } k{m.kind}, fl{flags}, tx{(uint32_t)m.texture};
+        shade[4 * i] = make_float4(p.cx, p.cy, p.cz, p.radius);
+        shade[4 * i + 1] = make_float4(k.f, fl.f, tx.f, m.param);
+        shade[4 * i + 2] = qa;
+        shade[4 * i + 3] = qb;
+    }
     std::vector<DMat> mats(desc->n_materials);
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
         const pt_material &m = desc->materials[i];
@@ -462,7 +488,7 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
         }
     }
     int rc = PT_OK;
-    if ((rc = upload(&s->d_spheres, sph.data(), sph.size())) || (rc = upload(&s->d_spheres_r2, sph_r2.data(), sph_r2.size())) ||
+    if ((rc = upload(&s->d_spheres, sph.data(), sph.size())) || (rc = upload(&s->d_spheres_r2, sph_r2.data(), sph_r2.size())) || (rc = upload(&s->d_shade, shade.data(), shade.size())) ||
         (rc = upload(&s->d_sphere_mat, desc->sphere_material, desc->n_spheres)) ||
         (rc = upload(&s->d_mats, mats.data(), mats.size())) || (rc = upload(&s->d_texs, texs.data(), texs.size())) ||
         (rc = upload(&s->d_perlin_vec, pvec.data(), pvec.size())) || (rc = upload(&s->d_perlin_perm, pperm.data(), pperm.size())) ||
@@ -509,6 +535,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_spheres);
     (void)hipFree(s->d_spheres_r2);
+    (void)hipFree(s->d_shade);
     (void)hipFree(s->d_sphere_mat);
     (void)hipFree(s->d_mats);
     (void)hipFree(s->d_texs);
@@ -564,6 +591,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     memset(&A, 0, sizeof A);
     A.spheres = s->d_spheres;
     A.spheres_r2 = s->d_spheres_r2;
+    A.shade = s->d_shade;
     A.sphere_mat = s->d_sphere_mat;
     A.mats = s->d_mats;
     A.texs = s->d_texs;
