@@ -965,20 +965,48 @@ __global__ void pt_tile_class_kernel(const KArgs A, uint32_t n_work_tiles, uint3
         cls = kind == PT_MAT_DIELECTRIC ? 3u : (kind == PT_MAT_METAL ? 2u : (kind == PT_MAT_LAMBERTIAN ? 1u : 0u));
     }
     tile_class[t] = cls;
-    atomicAdd(&class_count[cls], 1u);
+    (void)class_count;  // counted by pt_tile_order_kernel (a global atomic per tile on 4 addresses cost 0.2 ms)
 }
 
 __global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile_class, const uint32_t *class_count,
                                      uint32_t *tile_order) {
-    __shared__ uint32_t cursor[4];
-    if (threadIdx.x == 0) {  // most expensive class first
-        cursor[3] = 0;
-        cursor[2] = class_count[3];
-        cursor[1] = class_count[3] + class_count[2];
-        cursor[0] = class_count[3] + class_count[2] + class_count[1];
+    __shared__ uint32_t cursor[4], count[4];
+    const int lane0 = threadIdx.x & 63;
+    if (threadIdx.x < 4) count[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t t0 = 0; t0 < n_work_tiles; t0 += blockDim.x) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t cls = (t < n_work_tiles) ? tile_class[t] : 0xffffffffu;
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            if (m != 0ull && lane0 == 0) atomicAdd(&count[c], (uint32_t)__popcll(m));
+        }
     }
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) tile_order[atomicAdd(&cursor[tile_class[t]], 1u)] = t;
+    (void)class_count;
+    if (threadIdx.x == 0) {  // most expensive class first
+        cursor[3] = 0;
+        cursor[2] = count[3];
+        cursor[1] = count[3] + count[2];
+        cursor[0] = count[3] + count[2] + count[1];
+    }
+    __syncthreads();
+    // wave-aggregated append: one LDS atomic per (wave, class) instead of one per tile
+    const int lane = threadIdx.x & 63;
+    for (uint32_t t0 = 0; t0 < n_work_tiles; t0 += blockDim.x) {
+        const uint32_t t = t0 + threadIdx.x;
+        const uint32_t cls = (t < n_work_tiles) ? tile_class[t] : 0xffffffffu;
+#pragma unroll
+        for (uint32_t c = 0; c < 4; ++c) {
+            const unsigned long long m = __ballot(cls == c);
+            if (m == 0ull) continue;
+            uint32_t base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&cursor[c], (uint32_t)__popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1);
+            if (cls == c) tile_order[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
+        }
+    }
 }
 
 }  // namespace ptdev
