@@ -86,6 +86,7 @@ struct KArgs {
     float m0, gamma;             // margin = a * (m0 + gamma * (|o - c0|^2 + Rs^2))
     uint32_t verify;             // debug: count exact-positive pairs the prefilter did not flag
     unsigned long long *debug;   // [4] misses, candidates, overflow fallbacks, exact positives
+    unsigned long long *wave_end; // optional (PTGPU_TIMING=1): wall clock at which each wave left the main loop
     int32_t bvh_root;
     uint32_t has_sky;
     f3 sky;
@@ -926,6 +927,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
         }
     }
 
+    if (A.wave_end && lane == 0) A.wave_end[blockIdx.x * (kBlock / 64) + (tid >> 6)] = wall_clock64();
     // scene.rs:118 ray_count: wave reduce, one atomic per wave
     unsigned long long total = nrays;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);

@@ -741,6 +741,11 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         kern = pt_trace_kernel<false, false, false, false>;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
+    static unsigned long long *d_wave_end = nullptr;
+    const bool timing = getenv("PTGPU_TIMING") != nullptr;
+    if (timing && !d_wave_end) (void)hipMalloc((void **)&d_wave_end, 65536 * 8);
+    A.wave_end = timing ? d_wave_end : nullptr;
+    if (timing) (void)hipMemsetAsync(d_wave_end, 0, 65536 * 8, stream);
     HIP_TRY(hipEventRecord(s->ev_start, stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, A);
     HIP_TRY(hipGetLastError());
@@ -749,6 +754,17 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     s->last_grid = grid;
     s->last_block = kBlock;
     s->last_lds = lds;
+    if (timing) {  // development aid: distribution of wave finish times
+        (void)hipStreamSynchronize(stream);
+        const uint32_t nw = grid * (kBlock / 64);
+        std::vector<unsigned long long> t(nw);
+        (void)hipMemcpy(t.data(), d_wave_end, nw * 8, hipMemcpyDeviceToHost);
+        std::sort(t.begin(), t.end());
+        const double tick_ns = 10.0;  // wall_clock64: 100 MHz
+        fprintf(stderr, "[ptgpu timing] waves %u: finish spread (ms after first finisher) p10 %.3f p50 %.3f p90 %.3f p99 %.3f last %.3f\n", nw,
+                (t[nw / 10] - t[0]) * tick_ns * 1e-6, (t[nw / 2] - t[0]) * tick_ns * 1e-6, (t[nw * 9 / 10] - t[0]) * tick_ns * 1e-6,
+                (t[nw * 99 / 100] - t[0]) * tick_ns * 1e-6, (t[nw - 1] - t[0]) * tick_ns * 1e-6);
+    }
     return PT_OK;
 }
 
