@@ -36,11 +36,6 @@ struct DTex {  // 32 B
     float scale;
     float pad;
 };
-struct DNode {  // 32 B, collision/bvh.rs:24-28 flattened
-    float minx, miny, minz, maxx, maxy, maxz;
-    int32_t lhs, rhs;
-};
-
 struct DWideNode;
 
 // Per-sphere shading record: everything Material::scatter / emitted needs for the common cases, resolved at
@@ -379,13 +374,6 @@ __device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d,
     return f;
 }
 
-__device__ __forceinline__ float max16(const float16v &v) {
-    float m = __builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), v[2]);
-#pragma unroll
-    for (int r = 3; r + 1 < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, v[r]), v[r + 1]);
-    return __builtin_fmaxf(m, v[15]);
-}
-
 // Candidate queues without atomics: a lane appends the pairs IT found to its own two sub-queues (one per
 // ray half it serves); ray rho's candidates are then the sub-queues [rho >> 5] of lanes (rho & 31) and
 // (rho & 31) + 32, i.e. of the owner lane and of lane ^ 32. Entries are fragment slots (tile*32 + row).
@@ -525,15 +513,6 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
 // aabb.rs:46-58 with the SSE min/max NaN rule (second operand on NaN)
 __device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
-__device__ __forceinline__ bool aabb_hit(const DNode &n, f3 o, f3 rcp, float tmin, float tmax) {
-    const float mnx = (n.minx - o.x) * rcp.x, mny = (n.miny - o.y) * rcp.y, mnz = (n.minz - o.z) * rcp.z;
-    const float mxx = (n.maxx - o.x) * rcp.x, mxy = (n.maxy - o.y) * rcp.y, mxz = (n.maxz - o.z) * rcp.z;
-    const float t0x = sse_min(mnx, mxx), t0y = sse_min(mny, mxy), t0z = sse_min(mnz, mxz);
-    const float t1x = sse_max(mnx, mxx), t1y = sse_max(mny, mxy), t1z = sse_max(mnz, mxz);
-    const float lox = sse_max(t0x, tmin), loy = sse_max(t0y, tmin), loz = sse_max(t0z, tmin);
-    const float hix = sse_min(t1x, tmax), hiy = sse_min(t1y, tmax), hiz = sse_min(t1z, tmax);
-    return (hix > lox) && (hiy > loy) && (hiz > loz);
-}
 
 // bvh.rs:37-62 over the CALLER's tree, restructured for the GPU without changing its result.
 //
@@ -584,12 +563,17 @@ __device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, f3 o, f3 d, f3 r
     if (disc > 0.0f) {
         float t = kMaxT;
         if (sphere_roots(a, b, disc, t)) {
-            const uint32_t rank = A.leaf_rank[k];
+            // BVH world: DFS-last leaf wins equal t (bvh.rs:47-53); list world: the lower list index (hitable_list.rs:48)
+            const uint32_t rank = A.gate ? A.leaf_rank[k] : ~(uint32_t)k;
             if (idx < 0 || t < best || (t == best && rank > best_rank)) {
-                const float4 gmn = A.gate[2 * k], gmx = A.gate[2 * k + 1];
-                const float mn[3] = {gmn.x, gmn.y, gmn.z}, mx[3] = {gmx.x, gmx.y, gmx.z};
-                float te;
-                if (aabb_hit_enter(mn, mx, o, rcp, te)) {
+                bool pass = true;
+                if (A.gate) {
+                    const float4 gmn = A.gate[2 * k], gmx = A.gate[2 * k + 1];
+                    const float mn[3] = {gmn.x, gmn.y, gmn.z}, mx[3] = {gmx.x, gmx.y, gmx.z};
+                    float te;
+                    pass = aabb_hit_enter(mn, mx, o, rcp, te);
+                }
+                if (pass) {
                     best = t;
                     idx = k;
                     best_rank = rank;

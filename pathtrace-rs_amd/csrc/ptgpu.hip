@@ -464,6 +464,9 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
                 st.push_back({desc->bvh_nodes[ref].lhs, ref});
             }
         }
+    }
+    {   // the internal tree is built for every scene: BVH mode always uses it, list mode uses it for scenes too
+        // large for the brute-force scan (there it needs no gate: closest t, ties to the lower list index)
         AccelBuild acc = build_accel(desc);
         wnodes = std::move(acc.nodes);
         bvh_large = std::move(acc.large);
@@ -583,8 +586,13 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         return fail(PT_ERR_INVALID_ARG, "width/height/samples must be non-zero");
     if ((uint64_t)params->width * params->height > 0x3fffffffull) return fail(PT_ERR_INVALID_ARG, "frame too large");
     if (shard_count == 0 || shard_index >= shard_count) return fail(PT_ERR_INVALID_ARG, "bad shard %u/%u", shard_index, shard_count);
-    const bool bvh = params->use_bvh != 0;
-    if (bvh && s->bvh_root < 0) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the scene was created without BVH nodes");
+    const bool ref_bvh = params->use_bvh != 0;   // BVHNode::ray_hit semantics (needs the caller's tree for the gates)
+    if (ref_bvh && s->bvh_root < 0) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the scene was created without BVH nodes");
+    // list mode walks the internal tree instead of scanning when the scan would be the slower option:
+    // more than kListTreeMin spheres, or a scene the MFMA prefilter cannot take (variant bit 64 forces the scan)
+    constexpr uint32_t kListTreeMin = 2048;
+    const bool list_tree = !ref_bvh && (s->variant & (4u | 64u)) == 0 && (s->n_spheres > kListTreeMin || s->n_spheres > 0xfff0u);
+    const bool bvh = ref_bvh || list_tree;       // kernel flavour: tree traversal
     HIP_TRY(hipSetDevice(s->device));
 
     KArgs A;
@@ -597,7 +605,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.texs = s->d_texs;
     A.perlin_vec = s->d_perlin_vec;
     A.perlin_perm = s->d_perlin_perm;
-    A.gate = s->d_gate;
+    A.gate = ref_bvh ? s->d_gate : nullptr;   // list semantics: no ancestor-AABB gate, ties to the lower index
     A.bvh_large = s->d_bvh_large;
     A.n_bvh_large = s->n_bvh_large;
     A.wnodes = s->d_wnodes;

@@ -108,6 +108,7 @@ def test_mfma_prefilter_never_drops_a_positive_discriminant(ptgpu, pthost, prese
     ("two_perlin_spheres", 160, 90, 4, False),
     ("two_perlin_spheres", 160, 90, 4, True),
     ("perlin_spheres", 96, 54, 2, True),
+    ("perlin_spheres", 96, 54, 2, False),   # list world on 10k spheres: walks the internal tree, list tie rule
 ])
 def test_noise_parity(ptgpu, oracle, preset, W, H, S, bvh):
     osc, out, rays = _gpu_render(ptgpu, oracle, preset, W, H, S, bvh)
@@ -150,8 +151,6 @@ def test_golden_fixture(ptgpu, pthost, path, mode):
     preset, W, H, S = str(g["preset"]), int(g["width"]), int(g["height"]), int(g["samples"])
     bvh = bool(g["use_bvh"])
     if mode == "other_world":
-        if preset == "perlin_spheres":
-            pytest.skip("10k-sphere list scan is not a BASELINE configuration")
         bvh = not bvh                    # list and BVH worlds give the same image (closest hit either way)
     hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=bvh, device=0)   # scene built by the C++ host
     out = np.zeros((H, W, 3), np.float32)
