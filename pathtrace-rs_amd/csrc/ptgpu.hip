@@ -590,7 +590,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (ref_bvh && s->bvh_root < 0) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the scene was created without BVH nodes");
     // list mode walks the internal tree instead of scanning when the scan would be the slower option:
     // more than kListTreeMin spheres, or a scene the MFMA prefilter cannot take (variant bit 64 forces the scan)
-    constexpr uint32_t kListTreeMin = 2048;
+    constexpr uint32_t kListTreeMin = 768;   // = 24 MFMA tiles: beyond that the fragments no longer leave room for 2 workgroups per CU
     const bool list_tree = !ref_bvh && (s->variant & (4u | 64u)) == 0 && (s->n_spheres > kListTreeMin || s->n_spheres > 0xfff0u);
     const bool bvh = ref_bvh || list_tree;       // kernel flavour: tree traversal
     HIP_TRY(hipSetDevice(s->device));
@@ -667,7 +667,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         sph_lds = (s->variant & 1u) == 0 && sph_bytes <= 64u * 1024u;
         if (!sph_lds) sph_bytes = 0;
     }
-    const bool mfma = !bvh && sph_lds && s->n_tiles > 0 && (s->variant & 4u) == 0;
+    const bool mfma = !bvh && sph_lds && s->n_tiles > 0 && s->n_tiles <= 24u && (s->variant & 4u) == 0;
     A.afrag = s->d_afrag;
     A.tile_sphere = s->d_tile_sphere;
     A.large = s->d_large;

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void k(const uint4 *afrag, int n_tiles, int it
     const float16v zero = {0};
     unsigned cnt0 = 0, cnt1 = 0, total = 0;
     long long t0 = clock64();
-    for (int it = 0; it < iters; ++it) {
+    for (int it = 0; it < ((MODE == 4) ? 0 : iters); ++it) {
         Frag a0, a1, n0, n1;
         a0.u = s_afrag[lane]; a1.u = s_afrag[64 + lane];
         for (int T = 0; T < n_tiles; ++T) {
@@ -61,6 +61,34 @@ __global__ __launch_bounds__(256) void k(const uint4 *afrag, int n_tiles, int it
             total += m0 + m1;
         }
     }
+    if (MODE == 4) {
+        total = 0;
+        t0 = clock64();
+        for (int it = 0; it < iters; ++it) {
+            Frag a0, a1;
+            a0.u = s_afrag[lane]; a1.u = s_afrag[64 + lane];
+            float16v p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, b0[0].h, zero, 0, 0, 0);
+            float16v p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, b1[0].h, zero, 0, 0, 0);
+            p0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, b0[1].h, p0, 0, 0, 0);
+            p1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, b1[1].h, p1, 0, 0, 0);
+            for (int T = 0; T < n_tiles; ++T) {
+                const int Tn = (T + 1 < n_tiles) ? T + 1 : T;
+                a0.u = s_afrag[(Tn * 2) * 64 + lane]; a1.u = s_afrag[(Tn * 2 + 1) * 64 + lane];
+                float16v q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, b0[0].h, zero, 0, 0, 0);
+                float16v q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, b1[0].h, zero, 0, 0, 0);
+                q0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, b0[1].h, q0, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, b1[1].h, q1, 0, 0, 0);
+                unsigned m0 = 0, m1 = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(p0[r]), 31); m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(p1[r]), 31); }
+                unsigned m = m0 | (m1 << 16);
+                m &= (it == 123456) ? 0xffffffffu : 0u;
+                while (__any(m != 0u)) { if (m != 0u) { const unsigned bit = 31u - (unsigned)__builtin_clz(m); m &= ~(1u << bit); queue[(bit & 15) * 256 + tid] = (unsigned short)bit; cnt0 += 1; } }
+                total += m0 + m1;
+                p0 = q0; p1 = q1;
+            }
+        }
+    }
     long long t1 = clock64();
     out[blockIdx.x * 256 + tid] = total + cnt0 + cnt1;
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
@@ -73,13 +101,14 @@ int main() {
     uint4 *d; unsigned *out; long long *cyc;
     (void)hipMalloc(&d, h.size() * 2); (void)hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     (void)hipMalloc(&out, 4096 * 256 * 4); (void)hipMalloc(&cyc, 4096 * 8);
-    for (int mode = 0; mode < 4; ++mode) for (int bpc : {1, 2, 3}) {
+    for (int mode = 0; mode < 5; ++mode) for (int bpc : {1, 2, 3}) {
         const int grid = 256 * bpc;
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         for (int rep = 0; rep < 2; ++rep) {
             (void)hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
             if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
+            if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
             if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
             if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
