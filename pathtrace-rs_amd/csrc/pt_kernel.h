@@ -118,22 +118,24 @@ __device__ __noinline__ float perlin_noise(const PerlinLds &pn, f3 p) {
     const float uu = u * u * (3.0f - 2.0f * u);
     const float vv = v * v * (3.0f - 2.0f * v);
     const float ww = w * w * (3.0f - 2.0f * w);
+    // perlin.rs:66-69: the trilinear weights (ii*uu + (1-ii)*(1-uu)) with ii in {0, 1} are EXACTLY (1-uu) and uu
+    // (0*x = +0 and x + 0 = x for the non-negative finite uu; NaN propagates either way), so they are folded
+    // here; products and the accumulation keep the reference's order. The 24 permutation lookups of
+    // perlin.rs:101-107 reduce to 6 distinct ones.
+    const float wu[2] = {1.0f - uu, uu}, wv[2] = {1.0f - vv, vv}, ww2[2] = {1.0f - ww, ww};
+    const uint32_t px[2] = {pn.perm[i], pn.perm[(i + 1) & 255]};
+    const uint32_t py[2] = {pn.perm[256 + j], pn.perm[256 + ((j + 1) & 255)]};
+    const uint32_t pz[2] = {pn.perm[512 + k], pn.perm[512 + ((k + 1) & 255)]};
     float accum = 0.0f;
 #pragma unroll
     for (int di = 0; di < 2; ++di) {
-        const float ii = (float)di;
 #pragma unroll
         for (int dj = 0; dj < 2; ++dj) {
-            const float jj = (float)dj;
 #pragma unroll
             for (int dk = 0; dk < 2; ++dk) {
-                const float kk = (float)dk;
-                const uint32_t idx = pn.perm[(i + di) & 255] ^ pn.perm[256 + ((j + dj) & 255)] ^
-                                     pn.perm[512 + ((k + dk) & 255)];
-                const float4 g = pn.vec[idx];
-                const f3 weight = mk3(u - ii, v - jj, w - kk);
-                accum += (ii * uu + (1.0f - ii) * (1.0f - uu)) * (jj * vv + (1.0f - jj) * (1.0f - vv)) *
-                         (kk * ww + (1.0f - kk) * (1.0f - ww)) * dot3(mk3(g.x, g.y, g.z), weight);
+                const float4 g = pn.vec[px[di] ^ py[dj] ^ pz[dk]];
+                const f3 weight = mk3(u - (float)di, v - (float)dj, w - (float)dk);
+                accum += wu[di] * wv[dj] * ww2[dk] * dot3(mk3(g.x, g.y, g.z), weight);
             }
         }
     }
