@@ -555,9 +555,8 @@ constexpr float kCullAbs = 0.02f;
 // counts if every ancestor AABB passed aabb.rs:46-58. Ancestor boxes nest (each is the union of its
 // children, aabb.rs:61-66, and the slab arithmetic is monotone in the box), so testing the sphere's PARENT
 // box with the reference's exact arithmetic decides all of them.
-__device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, f3 o, f3 d, f3 rcp, float a, float &best, int &idx,
-                                         uint32_t &best_rank) {
-    const float4 c = A.spheres[k];
+__device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, const float4 c, f3 o, f3 d, f3 rcp, float a, float &best,
+                                         int &idx, uint32_t &best_rank) {
     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
@@ -625,7 +624,10 @@ __device__ __forceinline__ void bvh_start(const KArgs &A, uint32_t *s_stack, f3 
     st.idx = -1;
     st.rank = 0;
     st.active = true;
-    for (uint32_t j = 0; j < A.n_bvh_large; ++j) bvh_leaf(A, (int)A.bvh_large[j], o, d, rcp, a, st.best, st.idx, st.rank);
+    for (uint32_t j = 0; j < A.n_bvh_large; ++j) {
+        const int k = (int)A.bvh_large[j];
+        bvh_leaf(A, k, A.spheres[k], o, d, rcp, a, st.best, st.idx, st.rank);
+    }
     if (A.bvh_root >= 0) s_stack[(st.sp++) * kBlock + threadIdx.x] = (uint32_t)A.bvh_root;
 }
 
@@ -642,8 +644,9 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
                 const int32_t ref = (int32_t)s_stack[(--st.sp) * kBlock + tid];
                 const DWideNode n = nodes[ref];
                 // leaves first: they can only shrink `best` before the inner children are considered
-                if (n.lhs < 0) bvh_leaf(A, ~n.lhs, o, d, rcp, a, st.best, st.idx, st.rank);
-                if (n.rhs < 0) bvh_leaf(A, ~n.rhs, o, d, rcp, a, st.best, st.idx, st.rank);
+                // a leaf child's box slot holds the sphere itself (centre, radius): no second fetch
+                if (n.lhs < 0) bvh_leaf(A, ~n.lhs, make_float4(n.lmin[0], n.lmin[1], n.lmin[2], n.lmax[0]), o, d, rcp, a, st.best, st.idx, st.rank);
+                if (n.rhs < 0) bvh_leaf(A, ~n.rhs, make_float4(n.rmin[0], n.rmin[1], n.rmin[2], n.rmax[0]), o, d, rcp, a, st.best, st.idx, st.rank);
                 const float limit = (st.idx >= 0) ? (st.best * kCullRel + kCullAbs) : kMaxT;
                 float tl = 0.f, tr = 0.f;
                 bool hl = false, hr = false;

@@ -258,19 +258,21 @@ struct AccelBuild {
 
 struct AccelItem {
     uint32_t sphere;
-    float c[3], mn[3], mx[3], r;
+    float c[3], mn[3], mx[3], r, signed_r;
 };
 
 struct AccelRef {
     int32_t ref;
     float mn[3], mx[3], rmin;
     uint32_t depth;
+    float sph[4];  // leaves: the sphere as given (centre, signed radius)
 };
 
 AccelRef accel_build(std::vector<AccelItem> &items, size_t lo, size_t hi, std::vector<DWideNode> &nodes) {
     if (hi - lo == 1) {
         const AccelItem &it = items[lo];
-        AccelRef r{~(int32_t)it.sphere, {it.mn[0], it.mn[1], it.mn[2]}, {it.mx[0], it.mx[1], it.mx[2]}, it.r, 0};
+        AccelRef r{~(int32_t)it.sphere, {it.mn[0], it.mn[1], it.mn[2]}, {it.mx[0], it.mx[1], it.mx[2]}, it.r, 0,
+                   {it.c[0], it.c[1], it.c[2], it.signed_r}};
         return r;
     }
     float cmin[3] = {3e38f, 3e38f, 3e38f}, cmax[3] = {-3e38f, -3e38f, -3e38f};
@@ -287,9 +289,12 @@ AccelRef accel_build(std::vector<AccelItem> &items, size_t lo, size_t hi, std::v
     memset(&w, 0, sizeof w);
     memcpy(w.lmin, l.mn, 12), memcpy(w.lmax, l.mx, 12), memcpy(w.rmin, r.mn, 12), memcpy(w.rmax, r.mx, 12);
     w.lhs = l.ref, w.rhs = r.ref;
+    // a leaf child needs no box: its slot carries the sphere (centre, signed radius) so a leaf test costs no fetch
+    if (l.ref < 0) memcpy(w.lmin, l.sph, 12), w.lmax[0] = l.sph[3];
+    if (r.ref < 0) memcpy(w.rmin, r.sph, 12), w.rmax[0] = r.sph[3];
     memcpy(&w.pad0, &l.rmin, 4), memcpy(&w.pad1, &r.rmin, 4);
     nodes.push_back(w);
-    AccelRef out;
+    AccelRef out{};
     out.ref = (int32_t)nodes.size() - 1;
     for (int k = 0; k < 3; ++k) out.mn[k] = std::min(l.mn[k], r.mn[k]), out.mx[k] = std::max(l.mx[k], r.mx[k]);
     out.rmin = std::min(l.rmin, r.rmin);
@@ -313,7 +318,7 @@ AccelBuild build_accel(const pt_scene_desc *desc) {
             out.large.push_back(i);
             continue;
         }
-        AccelItem it{i, {p.cx, p.cy, p.cz}, {p.cx - r, p.cy - r, p.cz - r}, {p.cx + r, p.cy + r, p.cz + r}, r};
+        AccelItem it{i, {p.cx, p.cy, p.cz}, {p.cx - r, p.cy - r, p.cz - r}, {p.cx + r, p.cy + r, p.cz + r}, r, p.radius};
         items.push_back(it);
     }
     if (items.size() < 2) {  // degenerate: everything is tested directly
