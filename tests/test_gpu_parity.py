@@ -227,6 +227,37 @@ def test_device_buffer_entry_point_matches_host_entry_point(ptgpu, pthost):
     assert block % 64 == 0 and grid >= 1 and lds > 0
 
 
+def test_cli_offline_render_matches_reference_harness(pthost, oracle, tmp_path):
+    """offline.rs:16-60 through the C++ host CLI: banner, `{:.2}secs {}rays {:.2}Mrays/s`, and an output.png whose
+    pixels are the oracle's frame through linear_to_srgb + vertical flip (math.rs:36-48, offline.rs:43-51)."""
+    import re
+    import struct
+    import subprocess
+    import zlib
+    exe = os.path.join(ROOT, "pathtrace-rs_amd", "_build", "pathtrace")
+    out_png = str(tmp_path / "out.png")
+    W, H, S = 200, 100, 4
+    r = subprocess.run([exe, "-O", "-P", "small", "-W", str(W), "-H", str(H), "-S", str(S), "--output", out_png],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "generating 'small' preset at 200x100 with 4 samples per pixel"      # presets.rs:19-22
+    m = re.fullmatch(r"(\d+\.\d\d)secs (\d+)rays (\d+\.\d\d)Mrays/s", lines[1])               # offline.rs:36-41
+    ref, ref_rays = oracle.OracleScene("small", W, H).update(S)
+    assert m and int(m.group(2)) == ref_rays
+    data = open(out_png, "rb").read()
+    pos, idat = 8, b""
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        if tag == b"IDAT":
+            idat += data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+    img = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(H, 1 + 3 * W)[:, 1:].reshape(H, W, 3)
+    want = np.zeros((H, W, 3), np.uint8)
+    oracle.lib().ora_frame_to_srgb8(ref.ctypes.data, W, H, want.ctypes.data)
+    assert np.array_equal(img, want)
+
+
 def test_random_seed_mode_is_deterministic_per_base_and_differs_from_fixed(ptgpu, pthost):
     W, H, S = 64, 32, 2
     hs = pthost.HostScene("small", W, H, samples=S, device=0)
