@@ -4,9 +4,15 @@
 // (scene.rs:96-102) and walks samples and bounces iteratively. When a path
 // terminates the lane regenerates the next camera ray in place; when the
 // pixel's samples are exhausted the lane pulls the next pixel from a global
-// work counter (one wave-aggregated atomic per refill). The sphere scan is
-// wave-uniform: all 64 lanes test their own ray against the same sphere,
-// whose centre/r^2 are broadcast from LDS.
+// work counter (one wave-aggregated atomic per refill).
+//
+// Closest hit, list world (hitable_list.rs:40-56): phase 1 finds a superset of the spheres whose reference
+// discriminant is positive -- by default with an f16 MFMA GEMM over lifted ray/sphere features (64 rays x
+// 32 spheres x K=32 per tile, "MFMA prefilter" below), alternatively with a wave-uniform exact VALU scan --
+// and phase 2 runs the survivors through the reference's exact arithmetic.
+// Closest hit, BVH world (bvh.rs:37-62): per-lane resumable traversal of an internal tree, with the reference's
+// accept/reject decision reproduced by a slab test on each sphere's parent AABB in the caller's tree.
+// DESIGN.md section 4 has the derivations and the error budget.
 #pragma once
 #include "pt_device.h"
 #include "ptgpu.h"
@@ -218,7 +224,8 @@ __device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float
 // in flight before its arithmetic starts; the table is padded to a multiple of 8 with
 // (3e38, 3e38, 3e38, 0) entries whose discriminant is NaN or -inf.
 constexpr int kScanUnroll = 8;
-constexpr int kQueueCap = 20;  // per-lane candidate slots (u16), drained when a lane exceeds kQueueCap - kScanUnroll
+constexpr int kQueueCap = 20;  // per-lane candidate slots (u16): exact scan drains above kQueueCap - kScanUnroll; the MFMA
+                               // path splits them into two sub-queues of kQueueCap / 2 (overflow -> exact scan for that ray)
 
 __device__ __forceinline__ void drain_candidates(const float4 *sph, const uint16_t *q, uint32_t &cnt, f3 o, f3 d,
                                                  float a, float &closest, int &idx) {
