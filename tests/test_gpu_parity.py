@@ -104,6 +104,61 @@ def test_mfma_prefilter_never_drops_a_positive_discriminant(ptgpu, pthost, prese
     assert rays == rays_exact and np.array_equal(out, exact)
 
 
+def _random_scene(ptgpu, oracle, seed, n, half, rmax, cam_dist):
+    """Synthetic sphere cloud (not a reference preset) to stress the prefilter's margins and the internal tree."""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-half, half, size=(n, 3)).astype(np.float32)
+    radii = rng.uniform(0.05, rmax, size=n).astype(np.float32)
+    spheres = np.concatenate([centres, radii[:, None]], axis=1)
+    spheres[0] = [0.0, -1000.0 - half, 0.0, 1000.0]          # a huge ground sphere like the presets
+    kinds = rng.integers(0, 3, size=n)
+    materials, textures = [], []
+    for i in range(n):
+        if kinds[i] == 0:
+            textures.append((ptgpu.TEX_CONSTANT, rng.uniform(0.1, 0.9, 3), -1, -1, 0.0))
+            materials.append((ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, len(textures) - 1))
+        elif kinds[i] == 1:
+            materials.append((ptgpu.MAT_METAL, rng.uniform(0.3, 1.0, 3), float(rng.uniform(0, 0.5)), -1))
+        else:
+            materials.append((ptgpu.MAT_DIELECTRIC, (0, 0, 0), 1.5, -1))
+    cam = np.zeros(24, np.float32)
+    look = np.array([cam_dist, 0.3 * cam_dist + 1.0, 0.2 * cam_dist], np.float32)
+    at, up = np.zeros(3, np.float32), np.array([0, 1, 0], np.float32)
+    vfov = float(np.degrees(2 * np.arctan(1.2 * half / np.linalg.norm(look))))
+    oracle.lib().ora_camera_new(look.ctypes.data, at.ctypes.data, up.ctypes.data, vfov, 1.5, 0.05,
+                                float(np.linalg.norm(look)), 0.0, 1.0, cam.ctypes.data)
+    desc = ptgpu.SceneDesc(spheres, np.arange(n, dtype=np.uint32), materials, textures)
+    return desc, ptgpu.PtCamera.from_floats(cam)
+
+
+@pytest.mark.parametrize("seed,n,half,rmax,cam_dist", [
+    (1, 64, 4.0, 0.8, 30.0), (2, 300, 15.0, 0.5, 60.0), (3, 700, 30.0, 1.0, 150.0),
+    (4, 500, 10.0, 0.2, 800.0),      # far camera: margins grow with |o - c0|^2, the filter must stay conservative
+    (5, 2500, 40.0, 0.6, 120.0),     # beyond the scan limit: list world walks the internal tree
+])
+def test_synthetic_scenes_all_scan_paths_agree(ptgpu, oracle, seed, n, half, rmax, cam_dist):
+    desc, cam = _random_scene(ptgpu, oracle, seed, n, half, rmax, cam_dist)
+    sc = ptgpu.Scene(desc, 0)
+    W, H, S = 150, 100, 4
+    p = ptgpu.PtParams(W, H, S, 10, 0, 0)
+    sc.set_tuning(0, 4 | 64)                                  # exact VALU scan: the reference semantics
+    exact = np.zeros((H, W, 3), np.float32)
+    rays_exact = sc.update(p, cam, 0, exact)
+    sc.set_tuning(0, 0)                                       # default: MFMA prefilter or internal tree
+    out = np.zeros((H, W, 3), np.float32)
+    rays = sc.update(p, cam, 0, out)
+    assert rays == rays_exact and np.array_equal(out, exact), _report(exact, out)
+    if n <= 768:
+        sc.set_tuning(0, 8)
+        sc.debug_counters(reset=True)
+        ver = np.zeros((H, W, 3), np.float32)
+        sc.update(p, cam, 0, ver)
+        c = sc.debug_counters()
+        assert c["misses"] == 0 and c["exact_positives"] > 0, c
+        assert np.array_equal(ver, exact)
+    sc.close()
+
+
 @pytest.mark.parametrize("preset,W,H,S,bvh", [
     ("two_perlin_spheres", 160, 90, 4, False),
     ("two_perlin_spheres", 160, 90, 4, True),
