@@ -106,6 +106,8 @@ struct KArgs {
     unsigned long long *ray_count;
     uint32_t *work_counter;
     const uint32_t *tile_order;  // optional permutation of the 8x8 work tiles (expensive tiles first)
+    uint32_t *tile_cost;         // optional: rays spent per work tile (accumulated when a pixel completes)
+    uint32_t pilot;              // cost-estimation pass: do not touch the frame buffer
     float *gstack;  // global path-stack fallback when max_depth*3*kBlock*4 exceeds the LDS budget
     uint32_t stack_in_lds;
     uint32_t lds_sphere_bytes;  // offsets of the dynamic LDS carve
@@ -725,6 +727,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                                  : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * kBlock + tid);
 
     bool have = false, exhausted = false, need_cam = true, trav_new = false;
+    uint32_t lane_tile = 0, pix_rays = 0;
     BvhTrav trav{0, kMaxT, -1, 0u, false};
     uint32_t px = 0, py = 0, boff = 0, sample = 0, depth = 0, nrays = 0;
     Rng rng{0, 0, 0, 0};
@@ -744,6 +747,8 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             } else {
                 const uint32_t in = item & 63u;
                 const uint32_t tile = A.tile_order ? A.tile_order[item >> 6] : (item >> 6);
+                lane_tile = tile;
+                pix_rays = 0;
                 const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
                 const uint32_t ly = (tile / A.tiles_x) * 8u + (in >> 3);
                 if (x < A.width && ly < A.local_rows) {
@@ -816,6 +821,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
         // ---- scene.rs:49-71 one level of ray_trace (BVH mode: only lanes whose traversal has finished)
         if (have && !(BVH && trav.active)) {
             nrays += 1;
+            pix_rays += 1;
             bool terminal = true;
             f3 V;
             if (idx < 0) {
@@ -913,10 +919,13 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                 if (sample == A.samples) {
                     // scene.rs:113-116
                     col = scale3(col, A.inv_ns);
-                    float *out = A.rgb + boff;
-                    out[0] = out[0] * A.mix_prev + col.x * A.mix_new;
-                    out[1] = out[1] * A.mix_prev + col.y * A.mix_new;
-                    out[2] = out[2] * A.mix_prev + col.z * A.mix_new;
+                    if (!A.pilot) {
+                        float *out = A.rgb + boff;
+                        out[0] = out[0] * A.mix_prev + col.x * A.mix_new;
+                        out[1] = out[1] * A.mix_prev + col.y * A.mix_new;
+                        out[2] = out[2] * A.mix_prev + col.z * A.mix_new;
+                    }
+                    if (A.tile_cost) atomicAdd(&A.tile_cost[lane_tile], pix_rays);
                     have = false;
                 }
             }
@@ -932,78 +941,32 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
 
 // ---- work ordering ------------------------------------------------------------------------------
 // The frame ends when the slowest lane finishes its last pixel, and a pixel's samples are inherently
-// serial (one RNG stream, scene.rs:96-111). Handing out the expensive tiles FIRST keeps that tail
-// short. The cost class of a tile is a heuristic (first hit of the tile's centre ray: glass > metal >
-// diffuse > sky); it only changes the ORDER in which pixels are rendered, never a pixel's value.
-__global__ void pt_tile_class_kernel(const KArgs A, uint32_t n_work_tiles, uint32_t *tile_class, uint32_t *class_count) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_work_tiles) return;
-    uint32_t x = (t % A.tiles_x) * 8u + 4u, ly = (t / A.tiles_x) * 8u + 4u;
-    if (x >= A.width) x = A.width - 1u;
-    if (ly >= A.local_rows) ly = A.local_rows - 1u;
-    const float u = ((float)x + 0.5f) * A.inv_nx, v = ((float)(ly * A.shard_count + A.shard_index) + 0.5f) * A.inv_ny;
-    const f3 o = A.cam.origin;
-    const f3 d = sub3(add3(add3(A.cam.lower_left_corner, scale3(A.cam.horizontal, u)), scale3(A.cam.vertical, v)), o);
-    const float a = dot3(d, d);
-    float best = kMaxT;
-    int idx = -1;
-    for (uint32_t k = 0; k < A.n_spheres; ++k) {
-        const float4 c = A.spheres_r2[k];
-        const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
-        const float b = ocx * d.x + ocy * d.y + ocz * d.z;
-        const float disc = b * b - a * (ocx * ocx + ocy * ocy + ocz * ocz - c.w);
-        if (disc > 0.0f) {
-            const float t0 = (-b - sqrtf(disc)) / a;
-            if (t0 > kMinT && t0 < best) best = t0, idx = (int)k;
-        }
-    }
-    uint32_t cls = 0;  // 0 sky / light, 1 diffuse, 2 metal, 3 glass (most bounces)
-    if (idx >= 0) {
-        const uint32_t kind = A.mats[A.sphere_mat[idx]].kind;
-        cls = kind == PT_MAT_DIELECTRIC ? 3u : (kind == PT_MAT_METAL ? 2u : (kind == PT_MAT_LAMBERTIAN ? 1u : 0u));
-    }
-    tile_class[t] = cls;
-    (void)class_count;  // counted by pt_tile_order_kernel (a global atomic per tile on 4 addresses cost 0.2 ms)
-}
-
-__global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile_class, const uint32_t *class_count,
+// serial (one RNG stream, scene.rs:96-111): a glass pixel needs ~700 dependent ray iterations, most of a
+// 15 ms frame. Handing out the expensive tiles FIRST keeps that tail short. Tile costs come from a PILOT
+// pass: the same kernel at 1 sample per pixel with throw-away seeds (random_seed path), writing nothing but
+// the rays spent per 8x8 tile (~1.5 % of the frame's work). The order only decides WHEN a pixel is rendered,
+// never its value.
+__global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile_cost, uint32_t cost_scale,
                                      uint32_t *tile_order) {
-    __shared__ uint32_t cursor[4], count[4];
-    const int lane0 = threadIdx.x & 63;
-    if (threadIdx.x < 4) count[threadIdx.x] = 0;
+    __shared__ uint32_t count[64], cursor[64];
+    if (threadIdx.x < 64) count[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t t0 = 0; t0 < n_work_tiles; t0 += blockDim.x) {
-        const uint32_t t = t0 + threadIdx.x;
-        const uint32_t cls = (t < n_work_tiles) ? tile_class[t] : 0xffffffffu;
-#pragma unroll
-        for (uint32_t c = 0; c < 4; ++c) {
-            const unsigned long long m = __ballot(cls == c);
-            if (m != 0ull && lane0 == 0) atomicAdd(&count[c], (uint32_t)__popcll(m));
+    for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
+        const uint32_t b = tile_cost[t] / cost_scale;
+        atomicAdd(&count[b < 63u ? b : 63u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // most expensive bucket first
+        uint32_t acc = 0;
+        for (int b = 63; b >= 0; --b) {
+            cursor[b] = acc;
+            acc += count[b];
         }
     }
     __syncthreads();
-    (void)class_count;
-    if (threadIdx.x == 0) {  // most expensive class first
-        cursor[3] = 0;
-        cursor[2] = count[3];
-        cursor[1] = count[3] + count[2];
-        cursor[0] = count[3] + count[2] + count[1];
-    }
-    __syncthreads();
-    // wave-aggregated append: one LDS atomic per (wave, class) instead of one per tile
-    const int lane = threadIdx.x & 63;
-    for (uint32_t t0 = 0; t0 < n_work_tiles; t0 += blockDim.x) {
-        const uint32_t t = t0 + threadIdx.x;
-        const uint32_t cls = (t < n_work_tiles) ? tile_class[t] : 0xffffffffu;
-#pragma unroll
-        for (uint32_t c = 0; c < 4; ++c) {
-            const unsigned long long m = __ballot(cls == c);
-            if (m == 0ull) continue;
-            uint32_t base = 0;
-            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&cursor[c], (uint32_t)__popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1);
-            if (cls == c) tile_order[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
-        }
+    for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
+        const uint32_t b = tile_cost[t] / cost_scale;
+        tile_order[atomicAdd(&cursor[b < 63u ? b : 63u], 1u)] = t;
     }
 }
 

@@ -74,7 +74,8 @@ struct pt_scene {
     float c0[3] = {0, 0, 0};
     float rs2 = 0.f, m0 = 0.f, gamma = 0.f;
     unsigned long long *d_debug = nullptr;    // 4 u64 counters (verify mode)
-    uint32_t *d_tile_buf = nullptr;           // [8 counters | n tile classes | n tile order]
+    uint32_t *d_tile_buf = nullptr;           // [8 scratch words | n tile costs | n tile order]
+    float *d_pilot_rgb = nullptr;             // never-read frame buffer of the pilot pass
     size_t d_tile_cap = 0;
     uint32_t *d_work_counter = nullptr;       // 1 u32
     unsigned long long *d_ray_count = nullptr; // internal counter for pt_render
@@ -558,6 +559,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_large);
     (void)hipFree(s->d_debug);
     (void)hipFree(s->d_tile_buf);
+    (void)hipFree(s->d_pilot_rgb);
     (void)hipFree(s->d_work_counter);
     (void)hipFree(s->d_ray_count);
     (void)hipFree(s->d_frame);
@@ -722,24 +724,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         A.gstack = s->d_gstack;
     }
 
-    // ---- heavy-first work order (list mode, small scenes; variant bit 32 disables it) ----------------
     A.tile_order = nullptr;
-    const uint32_t n_work_tiles = A.n_items / 64u;
-    if (!bvh && s->n_spheres <= 4096u && n_work_tiles >= 64u && (s->variant & 32u) == 0) {
-        if (n_work_tiles > s->d_tile_cap) {
-            (void)hipFree(s->d_tile_buf);
-            s->d_tile_buf = nullptr;
-            s->d_tile_cap = 0;
-            HIP_TRY(hipMalloc((void **)&s->d_tile_buf, (8 + 2 * (size_t)n_work_tiles) * sizeof(uint32_t)));
-            s->d_tile_cap = n_work_tiles;
-        }
-        uint32_t *counts = s->d_tile_buf, *cls = s->d_tile_buf + 8, *order = cls + s->d_tile_cap;
-        HIP_TRY(hipMemsetAsync(counts, 0, 8 * sizeof(uint32_t), stream));
-        hipLaunchKernelGGL(pt_tile_class_kernel, dim3((n_work_tiles + 255) / 256), dim3(256), 0, stream, A, n_work_tiles, cls, counts);
-        hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cls, counts, order);
-        HIP_TRY(hipGetLastError());
-        A.tile_order = order;
-    }
+    A.tile_cost = nullptr;
+    A.pilot = 0;
 
     void (*kern)(const KArgs) = nullptr;
     if (bvh)
@@ -759,6 +746,40 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (timing && !d_wave_end) (void)hipMalloc((void **)&d_wave_end, 65536 * 8);
     A.wave_end = timing ? d_wave_end : nullptr;
     if (timing) (void)hipMemsetAsync(d_wave_end, 0, 65536 * 8, stream);
+    // ---- heavy-first work order from a 1-spp pilot pass (variant bit 32 disables it) -------------------
+    const uint32_t n_work_tiles = A.n_items / 64u;
+    if (n_work_tiles >= 256u && params->samples >= 32u && (s->variant & 32u) == 0) {  // the pilot costs ~1 spp
+        const size_t px_floats = (size_t)n_work_tiles * 64u * 3u;
+        if (n_work_tiles > s->d_tile_cap) {
+            (void)hipFree(s->d_tile_buf);
+            (void)hipFree(s->d_pilot_rgb);
+            s->d_tile_buf = nullptr;
+            s->d_pilot_rgb = nullptr;
+            s->d_tile_cap = 0;
+            HIP_TRY(hipMalloc((void **)&s->d_tile_buf, (8 + 2 * (size_t)n_work_tiles) * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void **)&s->d_pilot_rgb, px_floats * sizeof(float)));
+            s->d_tile_cap = n_work_tiles;
+        }
+        uint32_t *scratch = s->d_tile_buf, *cost = s->d_tile_buf + 8, *order = cost + s->d_tile_cap;
+        HIP_TRY(hipMemsetAsync(scratch, 0, (8 + (size_t)s->d_tile_cap) * sizeof(uint32_t), stream));
+        KArgs P = A;
+        P.samples = 1;
+        P.inv_ns = 1.0f;
+        P.random_seed = 1;                       // throw-away seeds: the pilot must not look like frame data
+        P.seed_base = 0x9e3779b97f4a7c15ull ^ frame_num;
+        P.rgb = s->d_pilot_rgb;
+        P.pilot = 1;
+        P.tile_cost = cost;
+        P.ray_count = reinterpret_cast<unsigned long long *>(scratch);      // scratch[0..1]
+        P.verify = 0;
+        P.wave_end = nullptr;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, P);
+        hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, params->max_depth + 1u, order);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+        A.tile_order = order;
+    }
+
     HIP_TRY(hipEventRecord(s->ev_start, stream));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, A);
     HIP_TRY(hipGetLastError());
