@@ -107,7 +107,6 @@ struct KArgs {
     uint32_t *work_counter;
     const uint32_t *tile_order;  // optional permutation of the 8x8 work tiles (expensive tiles first)
     uint32_t *tile_cost;         // optional: rays spent per work tile (accumulated when a pixel completes)
-    uint32_t pilot;              // cost-estimation pass: do not touch the frame buffer
     float *gstack;  // global path-stack fallback when max_depth*3*kBlock*4 exceeds the LDS budget
     uint32_t stack_in_lds;
     uint32_t lds_sphere_bytes;  // offsets of the dynamic LDS carve
@@ -679,7 +678,8 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
 
 // SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
 // (staged once per workgroup); otherwise from HBM/L2 through wave-uniform loads.
-template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY>
+// PILOT: the 1-spp cost-estimation pass (own symbol so profiles keep it apart from the frame kernel)
+template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT>
 __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
@@ -919,13 +919,13 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                 if (sample == A.samples) {
                     // scene.rs:113-116
                     col = scale3(col, A.inv_ns);
-                    if (!A.pilot) {
+                    if (!PILOT) {
                         float *out = A.rgb + boff;
                         out[0] = out[0] * A.mix_prev + col.x * A.mix_new;
                         out[1] = out[1] * A.mix_prev + col.y * A.mix_new;
                         out[2] = out[2] * A.mix_prev + col.z * A.mix_new;
                     }
-                    if (A.tile_cost) atomicAdd(&A.tile_cost[lane_tile], pix_rays);
+                    if (PILOT) atomicAdd(&A.tile_cost[lane_tile], pix_rays);
                     have = false;
                 }
             }

@@ -726,19 +726,21 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
 
     A.tile_order = nullptr;
     A.tile_cost = nullptr;
-    A.pilot = 0;
 
     void (*kern)(const KArgs) = nullptr;
+    void (*pilot_kern)(const KArgs) = nullptr;
     if (bvh)
-        kern = pt_trace_kernel<true, false, false, false>;
+        kern = pt_trace_kernel<true, false, false, false, false>, pilot_kern = pt_trace_kernel<true, false, false, false, true>;
     else if (mfma && (A.verify & 1u))
-        kern = pt_trace_kernel<false, true, true, true>;
+        kern = pt_trace_kernel<false, true, true, true, false>;
     else if (mfma)
-        kern = pt_trace_kernel<false, true, true, false>;
+        kern = pt_trace_kernel<false, true, true, false, false>, pilot_kern = pt_trace_kernel<false, true, true, false, true>;
     else if (sph_lds)
-        kern = pt_trace_kernel<false, true, false, false>;
+        kern = pt_trace_kernel<false, true, false, false, false>, pilot_kern = pt_trace_kernel<false, true, false, false, true>;
     else
-        kern = pt_trace_kernel<false, false, false, false>;
+        kern = pt_trace_kernel<false, false, false, false, false>;
+    if (pilot_kern)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot_kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
     static unsigned long long *d_wave_end = nullptr;
@@ -748,7 +750,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (timing) (void)hipMemsetAsync(d_wave_end, 0, 65536 * 8, stream);
     // ---- heavy-first work order from a 1-spp pilot pass (variant bit 32 disables it) -------------------
     const uint32_t n_work_tiles = A.n_items / 64u;
-    if (n_work_tiles >= 256u && params->samples >= 32u && (s->variant & 32u) == 0) {  // the pilot costs ~1 spp
+    if (pilot_kern && n_work_tiles >= 256u && params->samples >= 32u && (s->variant & 32u) == 0) {  // the pilot costs ~1 spp
         const size_t px_floats = (size_t)n_work_tiles * 64u * 3u;
         if (n_work_tiles > s->d_tile_cap) {
             (void)hipFree(s->d_tile_buf);
@@ -768,12 +770,11 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         P.random_seed = 1;                       // throw-away seeds: the pilot must not look like frame data
         P.seed_base = 0x9e3779b97f4a7c15ull ^ frame_num;
         P.rgb = s->d_pilot_rgb;
-        P.pilot = 1;
         P.tile_cost = cost;
         P.ray_count = reinterpret_cast<unsigned long long *>(scratch);      // scratch[0..1]
         P.verify = 0;
         P.wave_end = nullptr;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, P);
+        hipLaunchKernelGGL(pilot_kern, dim3(grid), dim3(kBlock), lds, stream, P);
         hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, params->max_depth + 1u, order);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));

@@ -5,9 +5,16 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+
+def is_frame_kernel(name):
+    """The frame kernel (last template flag PILOT = false); the 1-spp pilot pass is a separate symbol."""
+    return re.search(r"pt_trace_kernel<[^>]*false>\(", name) is not None or ("pt_trace_kernel" in name and "<" not in name)
+
 src = os.path.join("gpurun_out", "prof_" + tag)
 os.makedirs("profiles", exist_ok=True)
 lines = []
@@ -27,13 +34,13 @@ if ks:
     for r in csv.DictReader(open(ks)):
         lines.append("%-70s calls %s total_ns %s avg_ns %s pct %s" % (r["Name"][:70], r["Calls"], r["TotalDurationNs"],
                                                                     r["AverageNs"], r["Percentage"]))
-        if "pt_trace_kernel" in r["Name"]:
+        if is_frame_kernel(r["Name"]):
             avg_ms = float(r["AverageNs"]) / 1e6
 if kt:
     durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in csv.DictReader(open(kt))
-            if "pt_trace_kernel" in r["Kernel_Name"]]
+            if is_frame_kernel(r["Kernel_Name"])]
     lines.append("pt_trace_kernel dispatch durations (ms): " + ", ".join("%.3f" % d for d in durs))
-    rows = [r for r in csv.DictReader(open(kt)) if "pt_trace_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(kt)) if is_frame_kernel(r["Kernel_Name"])]
     if rows:
         r = rows[-1]
         lines.append("launch: grid %s wg %s LDS %s VGPR %s accVGPR %s SGPR %s scratch %s" % (
@@ -48,7 +55,7 @@ for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
         continue
     agg, disp = collections.defaultdict(float), set()
     for r in csv.DictReader(open(f)):
-        if "pt_trace_kernel" in r["Kernel_Name"]:
+        if is_frame_kernel(r["Kernel_Name"]):
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             disp.add(r["Dispatch_Id"])
     n = max(1, len(disp))
