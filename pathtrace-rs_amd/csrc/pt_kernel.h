@@ -623,7 +623,7 @@ struct BvhTrav {
     uint32_t rank;
     bool active;
 };
-constexpr int kReadyMin = 32;  // shade as soon as this many lanes of the wave have a finished traversal
+constexpr int kReadyMin = 56;  // shade as soon as this many lanes of the wave have a finished traversal
 
 __device__ __forceinline__ void bvh_start(const KArgs &A, uint32_t *s_stack, f3 o, f3 d, float a, BvhTrav &st) {
     const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // ray.rs:14

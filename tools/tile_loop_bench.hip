@@ -24,13 +24,19 @@ __global__ __launch_bounds__(256) void k(const uint4 *afrag, int n_tiles, int it
         for (int T = 0; T < n_tiles; ++T) {
             const int Tn = (T + 1 < n_tiles) ? T + 1 : T;
             n0.u = s_afrag[(Tn * 2) * 64 + lane]; n1.u = s_afrag[(Tn * 2 + 1) * 64 + lane];
-            float16v acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, b0[0].h, zero, 0, 0, 0);
-            float16v acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, b1[0].h, zero, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, b0[1].h, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, b1[1].h, acc1, 0, 0, 0);
+            float16v acc0, acc1;
+            if (MODE == 5) {
+                for (int r = 0; r < 16; ++r) { acc0[r] = __uint_as_float(a0.u.x + r + T); acc1[r] = __uint_as_float(a1.u.y + r + it); }
+                asm volatile("" : "+v"(acc0), "+v"(acc1));
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, b0[0].h, zero, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, b1[0].h, zero, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, b0[1].h, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, b1[1].h, acc1, 0, 0, 0);
+            }
             a0 = n0; a1 = n1;
             unsigned m0 = 0, m1 = 0;
-            if (MODE == 0) {
+            if (MODE == 0 || MODE == 5) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(acc0[r]), 31); m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(acc1[r]), 31); }
             } else if (MODE == 1) {   // 4-way trees
@@ -101,13 +107,14 @@ int main() {
     uint4 *d; unsigned *out; long long *cyc;
     (void)hipMalloc(&d, h.size() * 2); (void)hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
     (void)hipMalloc(&out, 4096 * 256 * 4); (void)hipMalloc(&cyc, 4096 * 8);
-    for (int mode = 0; mode < 5; ++mode) for (int bpc : {1, 2, 3}) {
+    for (int mode = 0; mode < 6; ++mode) for (int bpc : {1, 2, 3}) {
         const int grid = 256 * bpc;
         hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
         for (int rep = 0; rep < 2; ++rep) {
             (void)hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
             if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
+            if (mode == 5) hipLaunchKernelGGL(k<5>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
             if (mode == 4) hipLaunchKernelGGL(k<4>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
             if (mode == 3) hipLaunchKernelGGL(k<3>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
             if (mode == 2) hipLaunchKernelGGL(k<2>, dim3(grid), dim3(256), n_tiles * 2048, 0, d, n_tiles, iters, out, cyc);
