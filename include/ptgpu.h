@@ -64,13 +64,13 @@ typedef struct pt_sphere {
     float cx, cy, cz, radius;
 } pt_sphere;
 
-/* material.rs:13-19 `Material` (Isotropic is out of scope: only cornell_smoke uses it) */
-enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3 };
+/* material.rs:13-19 `Material` (Isotropic: phase function of a ConstantMedium, general worlds only) */
+enum { PT_MAT_LAMBERTIAN = 0, PT_MAT_METAL = 1, PT_MAT_DIELECTRIC = 2, PT_MAT_DIFFUSE_LIGHT = 3, PT_MAT_ISOTROPIC = 4 };
 typedef struct pt_material {
     uint32_t kind;
     float albedo[3]; /* Metal albedo */
     float param;     /* Metal fuzz | Dielectric ref_idx */
-    int32_t texture; /* Lambertian albedo / DiffuseLight emit texture index, else -1 */
+    int32_t texture; /* Lambertian / Isotropic albedo, DiffuseLight emit texture index, else -1 */
 } pt_material;
 
 /* texture.rs:40-55 `Texture` (Image is out of scope: needs media/earthmap.jpg) */
@@ -118,6 +118,53 @@ typedef struct pt_scene_desc {
     float sky[3];
 } pt_scene_desc;
 
+/* ---- general worlds: the other Hitable arms of collision/hitable.rs:12-21 ------
+ * One pt_hitable per HitableList entry: the innermost shape plus, optionally, the Instance
+ * (instance.rs:9-13) and ConstantMedium (constant_medium.rs:11-15) wrapped around it in the order the
+ * reference's presets nest them: ConstantMedium(Instance(shape)). Other nestings are rejected. */
+enum {
+    PT_HIT_SPHERE = 0,        /* sphere.rs:8-11          p = cx cy cz radius */
+    PT_HIT_MOVING_SPHERE = 1, /* moving_sphere.rs:8-14   p = centre_start(3) centre_delta(3) radius time_start inv_time_delta */
+    PT_HIT_RECT_XY = 2,       /* rect.rs:6-31            p = a0 a1 b0 b1 k: the two in-plane ranges in the variant's */
+    PT_HIT_RECT_XZ = 3,       /*                          own order (XY: x,y  XZ: x,z  YZ: y,z) and the plane offset */
+    PT_HIT_RECT_YZ = 4,
+    PT_HIT_CUBOID = 5         /* cuboid.rs:4-23          p = p0(3) p1(3); faces derived as Cuboid::new does */
+};
+typedef struct pt_hitable {
+    uint32_t kind;
+    uint32_t material;       /* the &Material paired with the shape */
+    uint32_t flip_normals;   /* Rect */
+    int32_t transform;       /* Instance: index into transforms, -1 = none */
+    int32_t medium_material; /* ConstantMedium: index of its Isotropic phase-function material, -1 = none */
+    float density;           /* ConstantMedium */
+    float p[10];
+} pt_hitable;
+
+/* glam Affine3A (x_axis, y_axis, z_axis, translation) and its inverse, as Instance::new stores them
+ * (instance.rs:16-22); the inverse is taken from the caller so the device never inverts. */
+typedef struct pt_affine {
+    float m[12];
+    float inv[12];
+} pt_affine;
+
+/* bvh_nodes children: >= 0 node index, < 0 ~hitable_index. */
+typedef struct pt_world_desc {
+    uint32_t n_hitables;
+    const pt_hitable *hitables; /* HitableList order */
+    uint32_t n_transforms;
+    const pt_affine *transforms;
+    uint32_t n_materials;
+    const pt_material *materials;
+    uint32_t n_textures;
+    const pt_texture *textures;
+    const pt_perlin *perlin;
+    uint32_t n_bvh_nodes;
+    const pt_bvh_node *bvh_nodes;
+    int32_t bvh_root;
+    uint32_t has_sky;
+    float sky[3];
+} pt_world_desc;
+
 typedef struct pt_scene pt_scene;
 
 /* Number of visible HIP devices. */
@@ -128,6 +175,13 @@ int pt_device_count(int *count_out);
  * may free it afterwards. */
 int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene **scene_out);
 void pt_scene_destroy(pt_scene *scene);
+
+/* Scene::new for a world with any of the Hitable arms above. Every render entry point below accepts the
+ * handle. Such worlds are traced by the general kernel: HitableList::ray_hit's sequential narrowing scan
+ * (hitable_list.rs:40-56) or BVHNode::ray_hit's both-children recursion (bvh.rs:37-62) exactly as written,
+ * because ConstantMedium::ray_hit draws from the pixel's RNG inside the intersection (constant_medium.rs:60)
+ * and clamps against the running t_max, so visiting order is part of the result. */
+int pt_scene_create_world(const pt_world_desc *desc, int device, pt_scene **scene_out);
 
 /* Scene::update (scene.rs:73-121) with a HOST pixel buffer, exactly the
  * reference's contract: rgb_inout is width*height*3 floats (row 0 = bottom
@@ -182,8 +236,9 @@ int pt_scene_debug_counters(pt_scene *scene, uint64_t out4[4], int reset);
  *   PT_PROBE_POW5    out[i] = device x^5 used by schlick (math.rs:79 powf(x, 5.0))
  *   PT_PROBE_SIN/COS out[i] = sinf_cosf(in[i]) (simd.rs:107-208)
  *   PT_PROBE_RNG     in[i] reinterpreted as a u32 seed s; out[i] = the (i%16+1)-th gen::<f32>() of
- *                    Xoshiro256Plus::seed_from_u64(s) */
-enum { PT_PROBE_POW5 = 0, PT_PROBE_SIN = 1, PT_PROBE_COS = 2, PT_PROBE_RNG = 3 };
+ *                    Xoshiro256Plus::seed_from_u64(s)
+ *   PT_PROBE_LN      out[i] = device f32::ln used by ConstantMedium (constant_medium.rs:60; glibc logf) */
+enum { PT_PROBE_POW5 = 0, PT_PROBE_SIN = 1, PT_PROBE_COS = 2, PT_PROBE_RNG = 3, PT_PROBE_LN = 4 };
 int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n);
 
 /* Thread-local message describing the last error returned on this thread. */

@@ -37,15 +37,26 @@
  *  A8 slice::sort_unstable_by tie order (pdqsort internals) is NOT reproduced:
  *       the BVH build below uses a stable merge sort. BVH topology affects
  *       speed and exact-t tie breaks only, never which spheres can be hit.
+ *  A9 glam 0.20.5 Affine3A (presets.rs:383-390, instance.rs, ray.rs:28-40,52-64):
+ *       transform_vector3(v) = ((x_axis*v.x) + (y_axis*v.y)) + (z_axis*v.z);
+ *       transform_point3 = that + translation; from_rotation_translation =
+ *       { Mat3A::from_quat(q), t }; Quat::from_rotation_y(a) = (0, sin(a/2), 0, cos(a/2));
+ *       from_quat: x2=x+x.. xx=x*x2.. wx=w*x2.. cols (1-(yy+zz), xy+wz, xz-wy),
+ *       (xy-wz, 1-(xx+zz), yz+wx), (xz+wy, yz-wx, 1-(xx+yy)); inverse = Mat3A::inverse
+ *       (columns y^z, z^x, x^y scaled by 1/det, det = z.(x^y), transposed) and
+ *       translation = -(inv * t). f32::to_radians(d) = d * (PI / 180).
  */
 #include "ptref.h"
 
 #include <math.h>
 #include <pthread.h>
 #include <stdatomic.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+
+#define MAX_T_F 3.40282346638528859812e+38f /* f32::MAX */
 
 /* ======================================================================== */
 /* Vec3 (glam 0.20.5 scalar Vec3; assumption A5)                            */
@@ -389,10 +400,10 @@ static inline v3 point_at_parameter(const ray *r, float t) { return v3_add(r->or
 /* ======================================================================== */
 /* material.rs:13-167                                                       */
 /* ======================================================================== */
-enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3 };
+enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3, MAT_ISOTROPIC = 4 };
 typedef struct {
     int kind;
-    const texture *tex; /* Lambertian albedo / DiffuseLight emit */
+    const texture *tex; /* Lambertian albedo / DiffuseLight emit / Isotropic albedo */
     v3 albedo;          /* Metal */
     float fuzz;         /* Metal */
     float ref_idx;      /* Dielectric */
@@ -446,6 +457,14 @@ static int scatter_dielectric(float ref_idx, const ray *ray_in, const ray_hit *h
     return 1;
 }
 
+/* material.rs:126-136: the scattered direction is NOT normalised */
+static int scatter_isotropic(const texture *albedo, const ray *ray_in, const ray_hit *hit,
+                             xoshiro *rng, v3 *attenuation, ray *scattered) {
+    *attenuation = texture_value(albedo, hit->u, hit->v, hit->point);
+    *scattered = ray_new(hit->point, random_in_unit_sphere(rng), ray_in->time);
+    return 1;
+}
+
 /* material.rs:138-159 */
 static int material_scatter(const material *m, const ray *ray_in, const ray_hit *hit,
                             xoshiro *rng, v3 *attenuation, ray *scattered) {
@@ -453,6 +472,7 @@ static int material_scatter(const material *m, const ray *ray_in, const ray_hit 
     case MAT_LAMBERTIAN: return scatter_lambertian(m->tex, ray_in, hit, rng, attenuation, scattered);
     case MAT_METAL: return scatter_metal(m->albedo, m->fuzz, ray_in, hit, rng, attenuation, scattered);
     case MAT_DIELECTRIC: return scatter_dielectric(m->ref_idx, ray_in, hit, rng, attenuation, scattered);
+    case MAT_ISOTROPIC: return scatter_isotropic(m->tex, ray_in, hit, rng, attenuation, scattered);
     default: return 0; /* DiffuseLight */
     }
 }
@@ -525,30 +545,253 @@ static inline aabb sphere_bounding_box(const sphere *s) {
 }
 
 /* ======================================================================== */
-/* collision/hitable.rs:12-65, hitable_list.rs:40-56, bvh.rs:24-62          */
+/* collision/moving_sphere.rs:8-90                                          */
 /* ======================================================================== */
-enum { HIT_SPHERE = 0, HIT_BVHNODE = 1, HIT_LIST = 2 };
-struct bvhnode; struct hitable_list;
+typedef struct { v3 centre_start, centre_delta; float radius, time_start, inv_time_delta; } moving_sphere;
+
+/* moving_sphere.rs:18-26 */
+static moving_sphere moving_sphere_new(v3 centre0, v3 centre1, float time0, float time1, float radius) {
+    moving_sphere m;
+    m.centre_start = centre0; m.centre_delta = v3_sub(centre1, centre0); m.radius = radius;
+    m.time_start = time0; m.inv_time_delta = 1.0f / (time1 - time0);
+    return m;
+}
+/* moving_sphere.rs:29-31 */
+static inline v3 moving_sphere_centre(const moving_sphere *m, float time) {
+    return v3_add(m->centre_start, v3_scale(m->centre_delta, (time - m->time_start) * m->inv_time_delta));
+}
+/* moving_sphere.rs:38-73 */
+static int moving_sphere_ray_hit(const moving_sphere *s, const ray *r, float t_min, float t_max, ray_hit *out) {
+    v3 centre = moving_sphere_centre(s, r->time);
+    v3 oc = v3_sub(r->origin, centre);
+    float a = v3_dot(r->direction, r->direction);
+    float b = v3_dot(oc, r->direction);
+    float c = v3_dot(oc, oc) - s->radius * s->radius;
+    float discriminant = b * b - a * c;
+    if (discriminant > 0.0f) {
+        float discriminant_sqrt = sqrtf(discriminant);
+        float t = (-b - discriminant_sqrt) / a;
+        if (t < t_max && t > t_min) {
+            out->point = point_at_parameter(r, t);
+            out->normal = v3_divs(v3_sub(out->point, centre), s->radius);
+            out->t = t; out->u = 0.0f; out->v = 0.0f;
+            return 1;
+        }
+        t = (-b + discriminant_sqrt) / a;
+        if (t < t_max && t > t_min) {
+            out->point = point_at_parameter(r, t);
+            out->normal = v3_divs(v3_sub(out->point, centre), s->radius);
+            out->t = t; out->u = 0.0f; out->v = 0.0f;
+            return 1;
+        }
+    }
+    return 0;
+}
+/* moving_sphere.rs:76-89 */
+static aabb moving_sphere_bounding_box(const moving_sphere *s, float t0, float t1) {
+    v3 c0 = moving_sphere_centre(s, t0), c1 = moving_sphere_centre(s, t1), rad = v3_splat(s->radius);
+    aabb b0 = { v3_sub(c0, rad), v3_add(c0, rad) }, b1 = { v3_sub(c1, rad), v3_add(c1, rad) };
+    return aabb_add(b0, b1);
+}
+
+/* ======================================================================== */
+/* collision/rect.rs:5-230 -- one struct, `axis` selects XY / XZ / YZ; (a, b)
+ * are the two in-plane coordinates in the variant's order, k the plane       */
+/* ======================================================================== */
+enum { RECT_XY = 0, RECT_XZ = 1, RECT_YZ = 2 };
+typedef struct { int axis; float a0, a1, b0, b1, k; int flip_normals; } rect;
+static const float FLIP_SIGN[2] = { 1.0f, -1.0f }; /* rect.rs:33 */
+
+static rect rect_new(int axis, float a0, float a1, float b0, float b1, float k, int flip) {
+    rect r = { axis, a0, a1, b0, b1, k, flip }; return r;
+}
+
+/* rect.rs:73-190: the comparisons are kept in the reference's form (a NaN t or
+ * coordinate falls through every `<`/`>` test exactly as it does there) */
+static int rect_ray_hit(const rect *q, const ray *r, float t_min, float t_max, ray_hit *out) {
+    float t, a, b;
+    switch (q->axis) {
+    case RECT_XY: /* rect.rs:73-100 */
+        t = (q->k - r->origin.z) * r->rcp_direction.z;
+        if (t < t_min || t > t_max) return 0;
+        a = r->origin.x + t * r->direction.x;
+        b = r->origin.y + t * r->direction.y;
+        if (a < q->a0 || a > q->a1 || b < q->b0 || b > q->b1) return 0;
+        out->normal = V3(0.0f, 0.0f, FLIP_SIGN[q->flip_normals]);
+        break;
+    case RECT_XZ: /* rect.rs:102-130 */
+        t = (q->k - r->origin.y) * r->rcp_direction.y;
+        if (t < t_min || t > t_max) return 0;
+        a = r->origin.x + t * r->direction.x;
+        b = r->origin.z + t * r->direction.z;
+        if (a < q->a0 || a > q->a1 || b < q->b0 || b > q->b1) return 0;
+        out->normal = V3(0.0f, FLIP_SIGN[q->flip_normals], 0.0f);
+        break;
+    default: /* rect.rs:132-160 */
+        t = (q->k - r->origin.x) * r->rcp_direction.x;
+        if (t < t_min || t > t_max) return 0;
+        a = r->origin.y + t * r->direction.y;
+        b = r->origin.z + t * r->direction.z;
+        if (a < q->a0 || a > q->a1 || b < q->b0 || b > q->b1) return 0;
+        out->normal = V3(FLIP_SIGN[q->flip_normals], 0.0f, 0.0f);
+        break;
+    }
+    out->point = point_at_parameter(r, t);
+    out->t = t;
+    out->u = (a - q->a0) / (q->a1 - q->a0);
+    out->v = (b - q->b0) / (q->b1 - q->b0);
+    return 1;
+}
+
+/* rect.rs:193-229 (the YZ arm really has `k - 0.0001` in BOTH corners, rect.rs:225-226) */
+static aabb rect_bounding_box(const rect *q) {
+    aabb r;
+    switch (q->axis) {
+    case RECT_XY: r.min = V3(q->a0, q->b0, q->k - 0.0001f); r.max = V3(q->a1, q->b1, q->k + 0.0001f); break;
+    case RECT_XZ: r.min = V3(q->a0, q->k - 0.0001f, q->b0); r.max = V3(q->a1, q->k + 0.0001f, q->b1); break;
+    default:      r.min = V3(q->k - 0.0001f, q->a0, q->b0); r.max = V3(q->k - 0.0001f, q->a1, q->b1); break;
+    }
+    return r;
+}
+
+/* ======================================================================== */
+/* collision/cuboid.rs:4-42                                                 */
+/* ======================================================================== */
+typedef struct { rect faces[6]; aabb bb; } cuboid;
+
+/* cuboid.rs:11-23 */
+static cuboid cuboid_new(v3 p0, v3 p1) {
+    cuboid c;
+    c.faces[0] = rect_new(RECT_XY, p0.x, p1.x, p0.y, p1.y, p1.z, 0);
+    c.faces[1] = rect_new(RECT_XY, p0.x, p1.x, p0.y, p1.y, p0.z, 1);
+    c.faces[2] = rect_new(RECT_XZ, p0.x, p1.x, p0.z, p1.z, p1.y, 0);
+    c.faces[3] = rect_new(RECT_XZ, p0.x, p1.x, p0.z, p1.z, p0.y, 1);
+    c.faces[4] = rect_new(RECT_YZ, p0.y, p1.y, p0.z, p1.z, p1.x, 0);
+    c.faces[5] = rect_new(RECT_YZ, p0.y, p1.y, p0.z, p1.z, p0.x, 1);
+    c.bb.min = p0; c.bb.max = p1;
+    return c;
+}
+/* cuboid.rs:25-37 */
+static int cuboid_ray_hit(const cuboid *c, const ray *r, float t_min, float t_max, ray_hit *out) {
+    int found = 0;
+    if (aabb_ray_hit(&c->bb, r, t_min, t_max)) {
+        float closest_so_far = t_max;
+        for (int i = 0; i < 6; ++i) {
+            ray_hit h;
+            if (rect_ray_hit(&c->faces[i], r, t_min, closest_so_far, &h)) { *out = h; found = 1; closest_so_far = h.t; }
+        }
+    }
+    return found;
+}
+
+/* ======================================================================== */
+/* glam 0.20.5 Affine3A / Quat / Mat3A as used by presets.rs:383-390 and
+ * instance.rs / ray.rs:28-40,52-64 / aabb.rs:75-100 (assumption A9)        */
+/* ======================================================================== */
+typedef struct { v3 x_axis, y_axis, z_axis, translation; } affine3;
+
+/* Affine3A::transform_vector3: ((x_axis * v.x) + (y_axis * v.y)) + (z_axis * v.z) */
+static inline v3 affine_transform_vector3(const affine3 *m, v3 v) {
+    return v3_add(v3_add(v3_scale(m->x_axis, v.x), v3_scale(m->y_axis, v.y)), v3_scale(m->z_axis, v.z));
+}
+/* Affine3A::transform_point3: the same sum, then + translation */
+static inline v3 affine_transform_point3(const affine3 *m, v3 p) {
+    return v3_add(affine_transform_vector3(m, p), m->translation);
+}
+/* Affine3A::from_rotation_translation(Quat::from_rotation_y(angle), t):
+ * Quat::from_rotation_y = (0, sin(a/2), 0, cos(a/2)); Mat3A::from_quat */
+static affine3 affine_from_rotation_y_translation(float angle, v3 translation) {
+    float qs = sinf(angle * 0.5f), qc = cosf(angle * 0.5f);
+    float qx = 0.0f, qy = qs, qz = 0.0f, qw = qc;
+    float x2 = qx + qx, y2 = qy + qy, z2 = qz + qz;
+    float xx = qx * x2, xy = qx * y2, xz = qx * z2, yy = qy * y2, yz = qy * z2, zz = qz * z2;
+    float wx = qw * x2, wy = qw * y2, wz = qw * z2;
+    affine3 m;
+    m.x_axis = V3(1.0f - (yy + zz), xy + wz, xz - wy);
+    m.y_axis = V3(xy - wz, 1.0f - (xx + zz), yz + wx);
+    m.z_axis = V3(xz + wy, yz - wx, 1.0f - (xx + yy));
+    m.translation = translation;
+    return m;
+}
+/* Affine3A::inverse: Mat3A::inverse (cross products / determinant, transposed), translation = -(inv * t) */
+static affine3 affine_inverse(const affine3 *m) {
+    v3 tmp0 = v3_cross(m->y_axis, m->z_axis);
+    v3 tmp1 = v3_cross(m->z_axis, m->x_axis);
+    v3 tmp2 = v3_cross(m->x_axis, m->y_axis);
+    float det = v3_dot(m->z_axis, tmp2);
+    float inv_det = 1.0f / det;
+    v3 c0 = v3_scale(tmp0, inv_det), c1 = v3_scale(tmp1, inv_det), c2 = v3_scale(tmp2, inv_det);
+    affine3 r;
+    r.x_axis = V3(c0.x, c1.x, c2.x); /* transpose */
+    r.y_axis = V3(c0.y, c1.y, c2.y);
+    r.z_axis = V3(c0.z, c1.z, c2.z);
+    r.translation = V3(0.0f, 0.0f, 0.0f);
+    r.translation = v3_neg(affine_transform_vector3(&r, m->translation));
+    return r;
+}
+/* ray.rs:28-40 */
+static inline ray ray_transform(const ray *r, const affine3 *m) {
+    ray o;
+    o.origin = affine_transform_point3(m, r->origin);
+    o.direction = affine_transform_vector3(m, r->direction);
+    o.rcp_direction = v3_recip(o.direction);
+    o.time = r->time;
+    return o;
+}
+/* ray.rs:52-64 */
+static inline ray_hit ray_hit_transform(const ray_hit *h, const affine3 *m) {
+    ray_hit o = *h;
+    o.point = affine_transform_point3(m, h->point);
+    o.normal = affine_transform_vector3(m, h->normal);
+    return o;
+}
+/* aabb.rs:75-100: starts from `min = max = m.w_axis` and never reads `self`, so the
+ * result is the single point t + x_axis*t + y_axis*t + z_axis*t (component-wise
+ * products). Reproduced as written: it decides what a BVH over instances can hit. */
+static aabb aabb_transform_as_written(const affine3 *m) {
+    v3 t = m->translation;
+    v3 out = t;
+    out = v3_add(out, v3_mul(m->x_axis, t));
+    out = v3_add(out, v3_mul(m->y_axis, t));
+    out = v3_add(out, v3_mul(m->z_axis, t));
+    aabb r = { out, out };
+    return r;
+}
+
+/* ======================================================================== */
+/* collision/hitable.rs:12-65, hitable_list.rs:40-56, bvh.rs:24-62,
+ * instance.rs:9-47, constant_medium.rs:11-77                               */
+/* ======================================================================== */
+enum { HIT_SPHERE = 0, HIT_BVHNODE = 1, HIT_LIST = 2, HIT_MOVING_SPHERE = 3, HIT_RECT = 4, HIT_CUBOID = 5,
+       HIT_INSTANCE = 6, HIT_CONSTANT_MEDIUM = 7 };
+struct bvhnode; struct hitable_list; struct instance; struct constant_medium;
 typedef struct hitable {
     int kind;
-    const sphere *sph; const material *mat;  /* Sphere(&Sphere,&Material) */
+    const sphere *sph; const material *mat;  /* Sphere / MovingSphere / Rect / Cuboid carry (&shape, &Material) */
     const struct bvhnode *node;              /* BVHNode(&BVHNode) */
     const struct hitable_list *list;         /* List(&HitableList) */
+    const moving_sphere *msph;
+    const rect *rct;
+    const cuboid *cub;
+    const struct instance *inst;
+    const struct constant_medium *med;
 } hitable;
 typedef struct bvhnode { aabb bb; hitable lhs, rhs; } bvhnode;
 typedef struct hitable_list { hitable *hitables; size_t len; } hitable_list;
+typedef struct instance { hitable child; affine3 transform, inv_transform; } instance;
+typedef struct constant_medium { hitable child; material phase_function; float density; } constant_medium;
 
-static int hitable_ray_hit(const hitable *h, const ray *r, float t_min, float t_max,
+static int hitable_ray_hit(const hitable *h, const ray *r, float t_min, float t_max, xoshiro *rng,
                            ray_hit *out, const material **mat);
 
 /* hitable_list.rs:40-56 */
-static int list_ray_hit(const hitable_list *l, const ray *r, float t_min, float t_max,
+static int list_ray_hit(const hitable_list *l, const ray *r, float t_min, float t_max, xoshiro *rng,
                         ray_hit *out, const material **mat) {
     int found = 0;
     float closest_so_far = t_max;
     for (size_t i = 0; i < l->len; ++i) {
         ray_hit h; const material *m;
-        if (hitable_ray_hit(&l->hitables[i], r, t_min, closest_so_far, &h, &m)) {
+        if (hitable_ray_hit(&l->hitables[i], r, t_min, closest_so_far, rng, &h, &m)) {
             *out = h; *mat = m; found = 1;
             closest_so_far = h.t;
         }
@@ -557,12 +800,12 @@ static int list_ray_hit(const hitable_list *l, const ray *r, float t_min, float 
 }
 
 /* bvh.rs:37-62 */
-static int bvh_ray_hit(const bvhnode *n, const ray *r, float t_min, float t_max,
+static int bvh_ray_hit(const bvhnode *n, const ray *r, float t_min, float t_max, xoshiro *rng,
                        ray_hit *out, const material **mat) {
     if (aabb_ray_hit(&n->bb, r, t_min, t_max)) {
         ray_hit hl, hr; const material *ml, *mr;
-        int has_l = hitable_ray_hit(&n->lhs, r, t_min, t_max, &hl, &ml);
-        int has_r = hitable_ray_hit(&n->rhs, r, t_min, t_max, &hr, &mr);
+        int has_l = hitable_ray_hit(&n->lhs, r, t_min, t_max, rng, &hl, &ml);
+        int has_r = hitable_ray_hit(&n->rhs, r, t_min, t_max, rng, &hr, &mr);
         if (has_l && has_r) {
             if (hl.t < hr.t) { *out = hl; *mat = ml; } else { *out = hr; *mat = mr; }
             return 1;
@@ -574,22 +817,74 @@ static int bvh_ray_hit(const bvhnode *n, const ray *r, float t_min, float t_max,
     return 0;
 }
 
-/* hitable.rs:39-65 (Sphere / BVHNode / List arms) */
-static int hitable_ray_hit(const hitable *h, const ray *r, float t_min, float t_max,
-                           ray_hit *out, const material **mat) {
-    switch (h->kind) {
-    case HIT_BVHNODE: return bvh_ray_hit(h->node, r, t_min, t_max, out, mat);
-    case HIT_LIST: return list_ray_hit(h->list, r, t_min, t_max, out, mat);
-    default:
-        if (sphere_ray_hit(h->sph, r, t_min, t_max, out)) { *mat = h->mat; return 1; }
-        return 0;
+/* instance.rs:32-47 */
+static int instance_ray_hit(const instance *in, const ray *r, float t_min, float t_max, xoshiro *rng,
+                            ray_hit *out, const material **mat) {
+    ray local = ray_transform(r, &in->inv_transform);
+    ray_hit h;
+    if (hitable_ray_hit(&in->child, &local, t_min, t_max, rng, &h, mat)) {
+        *out = ray_hit_transform(&h, &in->transform);
+        return 1;
     }
+    return 0;
 }
 
-/* hitable.rs:25-36 (t0 = t1 = 0) */
+/* constant_medium.rs:32-77 (f32::ln = glibc logf, assumption A7) */
+static int constant_medium_ray_hit(const constant_medium *cm, const ray *r, float t_min, float t_max,
+                                   xoshiro *rng, ray_hit *out, const material **mat) {
+    ray_hit h1, h2; const material *unused;
+    if (hitable_ray_hit(&cm->child, r, -MAX_T_F, MAX_T_F, rng, &h1, &unused)) {
+        if (hitable_ray_hit(&cm->child, r, h1.t + 0.0001f, MAX_T_F, rng, &h2, &unused)) {
+            float t1 = h1.t, t2 = h2.t;
+            if (t1 < t_min) t1 = t_min;
+            if (t2 > t_max) t2 = t_max;
+            if (t1 >= t2) return 0;
+            if (t1 < 0.0f) t1 = 0.0f;
+            float ray_length = v3_length(r->direction);
+            float distance_inside_boundary = (t2 - t1) * ray_length;
+            float hit_distance = -(1.0f / cm->density) * logf(gen_f32(rng));
+            if (hit_distance < distance_inside_boundary) {
+                float t = t1 + hit_distance / ray_length;
+                out->point = point_at_parameter(r, t);
+                out->normal = V3(1.0f, 0.0f, 0.0f); /* Vec3::X, arbitrary */
+                out->t = t; out->u = 0.0f; out->v = 0.0f;
+                *mat = &cm->phase_function;
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+/* hitable.rs:39-65 */
+static int hitable_ray_hit(const hitable *h, const ray *r, float t_min, float t_max, xoshiro *rng,
+                           ray_hit *out, const material **mat) {
+    int hit;
+    switch (h->kind) {
+    case HIT_BVHNODE: return bvh_ray_hit(h->node, r, t_min, t_max, rng, out, mat);
+    case HIT_LIST: return list_ray_hit(h->list, r, t_min, t_max, rng, out, mat);
+    case HIT_INSTANCE: return instance_ray_hit(h->inst, r, t_min, t_max, rng, out, mat);
+    case HIT_CONSTANT_MEDIUM: return constant_medium_ray_hit(h->med, r, t_min, t_max, rng, out, mat);
+    case HIT_RECT: hit = rect_ray_hit(h->rct, r, t_min, t_max, out); break;
+    case HIT_CUBOID: hit = cuboid_ray_hit(h->cub, r, t_min, t_max, out); break;
+    case HIT_MOVING_SPHERE: hit = moving_sphere_ray_hit(h->msph, r, t_min, t_max, out); break;
+    default: hit = sphere_ray_hit(h->sph, r, t_min, t_max, out); break;
+    }
+    if (hit) { *mat = h->mat; return 1; }
+    return 0;
+}
+
+/* hitable.rs:25-36 with t0 = t1 = 0 (bvh.rs:69-70); every arm is Some for the kinds built here */
 static aabb hitable_bounding_box(const hitable *h) {
-    if (h->kind == HIT_BVHNODE) return h->node->bb;
-    return sphere_bounding_box(h->sph);
+    switch (h->kind) {
+    case HIT_BVHNODE: return h->node->bb;
+    case HIT_INSTANCE: return aabb_transform_as_written(&h->inst->transform); /* instance.rs:24-30 */
+    case HIT_CONSTANT_MEDIUM: return hitable_bounding_box(&h->med->child);      /* constant_medium.rs:28-30 */
+    case HIT_RECT: return rect_bounding_box(h->rct);
+    case HIT_CUBOID: return h->cub->bb;
+    case HIT_MOVING_SPHERE: return moving_sphere_bounding_box(h->msph, 0.0f, 0.0f);
+    default: return sphere_bounding_box(h->sph);
+    }
 }
 
 /* ======================================================================== */
@@ -642,6 +937,11 @@ typedef struct {
     material *materials; size_t n_materials, cap_materials;
     sphere *spheres; size_t n_spheres, cap_spheres;
     bvhnode *nodes; size_t n_nodes, cap_nodes;
+    moving_sphere *moving; size_t n_moving;
+    rect *rects; size_t n_rects;
+    cuboid *cuboids; size_t n_cuboids;
+    instance *instances; size_t n_instances;
+    constant_medium *media; size_t n_media;
     perlin perlin_noise;
 } storage;
 
@@ -662,9 +962,15 @@ static void storage_init(storage *st, xoshiro *rng, size_t max_items) {
     st->cap_materials = max_items + 16; st->materials = calloc(st->cap_materials, sizeof(material));
     st->cap_spheres = max_items + 16; st->spheres = calloc(st->cap_spheres, sizeof(sphere));
     st->cap_nodes = max_items + 16; st->nodes = calloc(st->cap_nodes, sizeof(bvhnode));
+    st->moving = calloc(max_items + 16, sizeof(moving_sphere));
+    st->rects = calloc(64, sizeof(rect)); st->cuboids = calloc(16, sizeof(cuboid));
+    st->instances = calloc(16, sizeof(instance)); st->media = calloc(16, sizeof(constant_medium));
     perlin_new(&st->perlin_noise, rng); /* storage.rs:41 */
 }
-static void storage_free(storage *st) { free(st->textures); free(st->materials); free(st->spheres); free(st->nodes); }
+static void storage_free(storage *st) {
+    free(st->textures); free(st->materials); free(st->spheres); free(st->nodes);
+    free(st->moving); free(st->rects); free(st->cuboids); free(st->instances); free(st->media);
+}
 
 static const texture *alloc_texture(storage *st, texture t) { st->textures[st->n_textures] = t; return &st->textures[st->n_textures++]; }
 static const material *alloc_material(storage *st, material m) { st->materials[st->n_materials] = m; return &st->materials[st->n_materials++]; }
@@ -697,9 +1003,161 @@ static hitable mk_sphere(storage *st, v3 centre, float radius, material m) {
     return h;
 }
 
+/* the `moving_sphere` closure of presets.rs:122-127 (times 0.0 .. 1.0) */
+static hitable mk_moving_sphere(storage *st, v3 centre0, v3 centre1, float radius, material m) {
+    hitable h; memset(&h, 0, sizeof h); h.kind = HIT_MOVING_SPHERE;
+    st->moving[st->n_moving] = moving_sphere_new(centre0, centre1, 0.0f, 1.0f, radius);
+    h.msph = &st->moving[st->n_moving++];
+    h.mat = alloc_material(st, m);
+    return h;
+}
+/* Hitable::Rect(storage.alloc_rect(..), material) */
+static hitable mk_rect(storage *st, rect q, const material *m) {
+    hitable h; memset(&h, 0, sizeof h); h.kind = HIT_RECT;
+    st->rects[st->n_rects] = q; h.rct = &st->rects[st->n_rects++]; h.mat = m;
+    return h;
+}
+static hitable mk_cuboid(storage *st, v3 p0, v3 p1, const material *m) {
+    hitable h; memset(&h, 0, sizeof h); h.kind = HIT_CUBOID;
+    st->cuboids[st->n_cuboids] = cuboid_new(p0, p1); h.cub = &st->cuboids[st->n_cuboids++]; h.mat = m;
+    return h;
+}
+/* instance.rs:16-22 */
+static hitable mk_instance(storage *st, hitable child, affine3 transform) {
+    hitable h; memset(&h, 0, sizeof h); h.kind = HIT_INSTANCE;
+    instance *in = &st->instances[st->n_instances++];
+    in->child = child; in->transform = transform; in->inv_transform = affine_inverse(&transform);
+    h.inst = in;
+    return h;
+}
+/* constant_medium.rs:18-26; material.rs:37-39 isotropic(albedo) */
+static hitable mk_constant_medium(storage *st, hitable child, float density, const texture *albedo) {
+    hitable h; memset(&h, 0, sizeof h); h.kind = HIT_CONSTANT_MEDIUM;
+    constant_medium *cm = &st->media[st->n_media++];
+    cm->child = child; cm->density = density;
+    memset(&cm->phase_function, 0, sizeof cm->phase_function);
+    cm->phase_function.kind = MAT_ISOTROPIC; cm->phase_function.tex = albedo;
+    h.med = cm;
+    return h;
+}
+
 /* ======================================================================== */
 /* presets.rs                                                               */
 /* ======================================================================== */
+
+/* presets.rs:89-215 random_impl(only_spheres = false): the `random` preset */
+static void preset_random(ora_scene *sc, uint32_t width, uint32_t height, xoshiro *rng, hitvec *hv) {
+    storage *st = &sc->st;
+    sc->cam = camera_new(V3(13.0f, 2.0f, 3.0f), V3(0.0f, 0.0f, 0.0f), V3(0.0f, 1.0f, 0.0f), 20.0f,
+                         (float)width / (float)height, 0.1f, 10.0f, 0.0f, 1.0f);
+    const texture *odd = alloc_texture(st, tex_constant(V3(0.2f, 0.3f, 0.1f)));
+    const texture *even = alloc_texture(st, tex_constant(V3(0.9f, 0.9f, 0.9f)));
+    const texture *chk = alloc_texture(st, tex_checker(odd, even));
+    hv_push(hv, mk_sphere(st, V3(0.0f, -1000.0f, 0.0f), 1000.0f, mat_lambertian(chk)));
+    for (int a = -11; a < 11; ++a) {
+        for (int b = -11; b < 11; ++b) {
+            float choose_material = gen_f32(rng);
+            float cx = (float)a + 0.9f * gen_f32(rng);
+            float cz = (float)b + 0.9f * gen_f32(rng);
+            v3 centre = V3(cx, 0.2f, cz);
+            if (choose_material < 0.8f) {
+                v3 centre1 = v3_add(centre, V3(0.0f, 0.5f * gen_f32(rng), 0.0f)); /* presets.rs:150 */
+                float r0 = gen_f32(rng), r1 = gen_f32(rng), r2 = gen_f32(rng),
+                      r3 = gen_f32(rng), r4 = gen_f32(rng), r5 = gen_f32(rng);
+                const texture *t = alloc_texture(st, tex_constant(V3(r0 * r1, r2 * r3, r4 * r5)));
+                hv_push(hv, mk_moving_sphere(st, centre, centre1, 0.2f, mat_lambertian(t))); /* presets.rs:162-171 */
+            } else if (choose_material < 0.95f) {
+                float ax = 0.5f * (1.0f + gen_f32(rng));
+                float ay = 0.5f * (1.0f + gen_f32(rng));
+                float az = 0.5f * (1.0f + gen_f32(rng));
+                float fuzz = 0.5f * gen_f32(rng);
+                hv_push(hv, mk_sphere(st, centre, 0.2f, mat_metal(V3(ax, ay, az), fuzz)));
+            } else {
+                hv_push(hv, mk_sphere(st, centre, 0.2f, mat_dielectric(1.5f)));
+            }
+        }
+    }
+    hv_push(hv, mk_sphere(st, V3(0.0f, 1.0f, 0.0f), 1.0f, mat_dielectric(1.5f)));
+    const texture *t = alloc_texture(st, tex_constant(V3(0.4f, 0.2f, 0.1f)));
+    hv_push(hv, mk_sphere(st, V3(-4.0f, 1.0f, 0.0f), 1.0f, mat_lambertian(t)));
+    hv_push(hv, mk_sphere(st, V3(4.0f, 1.0f, 0.0f), 1.0f, mat_metal(V3(0.7f, 0.6f, 0.5f), 0.0f)));
+    sc->has_sky = 0;
+}
+
+/* presets.rs:317-370 */
+static void preset_simple_light(ora_scene *sc, uint32_t width, uint32_t height, hitvec *hv) {
+    storage *st = &sc->st;
+    sc->cam = camera_new(V3(50.0f, 2.0f, 3.0f), V3(0.0f, 0.0f, 0.0f), V3(0.0f, 1.0f, 0.0f), 20.0f,
+                         (float)width / (float)height, 0.0f, 10.0f, 0.0f, 0.0f);
+    const texture *noise_texture = alloc_texture(st, tex_noise(&st->perlin_noise, 4.0f));
+    const texture *constant_texture = alloc_texture(st, tex_constant(V3(4.0f, 4.0f, 4.0f)));
+    hv_push(hv, mk_sphere(st, V3(0.0f, -1000.0f, 0.0f), 1000.0f, mat_lambertian(noise_texture)));
+    hv_push(hv, mk_sphere(st, V3(0.0f, 2.0f, 0.0f), 2.0f, mat_lambertian(noise_texture)));
+    hv_push(hv, mk_sphere(st, V3(0.0f, 7.0f, 0.0f), 2.0f, mat_diffuse_light(constant_texture)));
+    rect q = rect_new(RECT_XY, 3.0f, 5.0f, 1.0f, 3.0f, -2.0f, 0);
+    hitable hr = mk_rect(st, q, NULL);
+    hr.mat = alloc_material(st, mat_diffuse_light(constant_texture)); /* rect arena first, then material (presets.rs:363-366) */
+    hv_push(hv, hr);
+    sc->has_sky = 1; sc->sky = V3(0.0f, 0.0f, 0.0f);
+}
+
+/* presets.rs:372-456 (cornell_box) and 458-552 (cornell_smoke) */
+static void preset_cornell(ora_scene *sc, uint32_t width, uint32_t height, hitvec *hv, int smoke) {
+    storage *st = &sc->st;
+    sc->cam = camera_new(V3(278.0f, 278.0f, -800.0f), V3(278.0f, 278.0f, 0.0f), V3(0.0f, 1.0f, 0.0f), 40.0f,
+                         (float)width / (float)height, 0.0f, 10.0f, 0.0f, 1.0f);
+    const texture *tr = alloc_texture(st, tex_constant(V3(0.65f, 0.05f, 0.05f)));
+    const material *red = alloc_material(st, mat_lambertian(tr));
+    const texture *tw = alloc_texture(st, tex_constant(V3(0.73f, 0.73f, 0.73f)));
+    const material *white = alloc_material(st, mat_lambertian(tw));
+    const texture *tg = alloc_texture(st, tex_constant(V3(0.12f, 0.45f, 0.15f)));
+    const material *green = alloc_material(st, mat_lambertian(tg));
+    const float e = smoke ? 7.0f : 15.0f;
+    const texture *tl = alloc_texture(st, tex_constant(V3(e, e, e)));
+    const material *light = alloc_material(st, mat_diffuse_light(tl));
+    const float to_rad = PT_PI / 180.0f; /* f32::to_radians */
+    affine3 box1 = affine_from_rotation_y_translation(-18.0f * to_rad, V3(130.0f, 0.0f, 65.0f));
+    affine3 box2 = affine_from_rotation_y_translation(15.0f * to_rad, V3(265.0f, 0.0f, 295.0f));
+    hv_push(hv, mk_rect(st, rect_new(RECT_YZ, 0.0f, 555.0f, 0.0f, 555.0f, 555.0f, 1), green));
+    hv_push(hv, mk_rect(st, rect_new(RECT_YZ, 0.0f, 555.0f, 0.0f, 555.0f, 0.0f, 0), red));
+    if (smoke) hv_push(hv, mk_rect(st, rect_new(RECT_XZ, 113.0f, 443.0f, 127.0f, 432.0f, 554.0f, 0), light));
+    else hv_push(hv, mk_rect(st, rect_new(RECT_XZ, 213.0f, 343.0f, 227.0f, 332.0f, 554.0f, 0), light));
+    hv_push(hv, mk_rect(st, rect_new(RECT_XZ, 0.0f, 555.0f, 0.0f, 555.0f, 555.0f, 1), white));
+    hv_push(hv, mk_rect(st, rect_new(RECT_XZ, 0.0f, 555.0f, 0.0f, 555.0f, 0.0f, 0), white));
+    hv_push(hv, mk_rect(st, rect_new(RECT_XY, 0.0f, 555.0f, 0.0f, 555.0f, 555.0f, 1), white));
+    hitable b1 = mk_instance(st, mk_cuboid(st, V3(0.0f, 0.0f, 0.0f), V3(165.0f, 165.0f, 165.0f), white), box1);
+    if (smoke) {
+        const texture *one = alloc_texture(st, tex_constant(V3(1.0f, 1.0f, 1.0f)));
+        hv_push(hv, mk_constant_medium(st, b1, 0.01f, one));
+    } else hv_push(hv, b1);
+    hitable b2 = mk_instance(st, mk_cuboid(st, V3(0.0f, 0.0f, 0.0f), V3(165.0f, 330.0f, 165.0f), white), box2);
+    if (smoke) {
+        const texture *zero = alloc_texture(st, tex_constant(V3(0.0f, 0.0f, 0.0f)));
+        hv_push(hv, mk_constant_medium(st, b2, 0.01f, zero));
+    } else hv_push(hv, b2);
+    sc->has_sky = 1; sc->sky = V3(0.0f, 0.0f, 0.0f);
+}
+
+/* presets.rs:853-930 */
+static void preset_smallpt(ora_scene *sc, uint32_t width, uint32_t height, hitvec *hv) {
+    storage *st = &sc->st;
+    sc->cam = camera_new(V3(50.0f, 52.0f, 295.6f), V3(50.0f, 33.0f, 0.0f), V3(0.0f, 1.0f, 0.0f), 30.0f,
+                         (float)width / (float)height, 0.05f, 100.0f, 0.0f, 1.0f);
+#define LAMB(cx, cy, cz, r, ax, ay, az) do { const texture *t_ = alloc_texture(st, tex_constant(V3(ax, ay, az))); \
+        hv_push(hv, mk_sphere(st, V3(cx, cy, cz), r, mat_lambertian(t_))); } while (0)
+    LAMB(1e3f + 1.0f, 40.8f, 81.6f, 1e3f, 0.75f, 0.25f, 0.25f);   /* Left */
+    LAMB(-1e3f + 99.0f, 40.8f, 81.6f, 1e3f, 0.25f, 0.25f, 0.75f); /* Rght */
+    LAMB(50.0f, 40.8f, 1e3f, 1e3f, 0.75f, 0.75f, 0.75f);          /* Back */
+    LAMB(50.0f, 1e3f, 81.6f, 1e3f, 0.75f, 0.75f, 0.75f);          /* Botm */
+    LAMB(50.0f, -1e3f + 81.6f, 81.6f, 1e3f, 0.75f, 0.75f, 0.75f); /* Top */
+#undef LAMB
+    hv_push(hv, mk_sphere(st, V3(27.0f, 16.5f, 47.0f), 16.5f,
+                          mat_metal(v3_scale(V3(1.0f, 1.0f, 1.0f), 0.999f), 0.0f)));      /* Mirr */
+    hv_push(hv, mk_sphere(st, V3(73.0f, 16.5f, 78.0f), 16.5f, mat_dielectric(1.5f)));       /* Glas */
+    const texture *tl = alloc_texture(st, tex_constant(v3_scale(V3(4.0f, 4.0f, 4.0f), 100.0f)));
+    hv_push(hv, mk_sphere(st, V3(50.0f, 81.6f - 16.5f, 81.6f), 1.5f, mat_diffuse_light(tl))); /* Lite */
+    sc->has_sky = 1; sc->sky = V3(0.0f, 0.0f, 0.0f);
+}
 
 /* presets.rs:89-215 random_impl(only_spheres = true) */
 static void preset_random_spheres(ora_scene *sc, uint32_t width, uint32_t height, xoshiro *rng, hitvec *hv) {
@@ -928,7 +1386,12 @@ ora_scene *ora_scene_from_preset(const char *name, uint32_t width, uint32_t heig
     else if (!strcmp(name, "two_perlin_spheres")) which = 2;
     else if (!strcmp(name, "aras")) which = 3;
     else if (!strcmp(name, "perlin_spheres")) which = 4;
-    else return NULL; /* presets.rs:36 */
+    else if (!strcmp(name, "random")) which = 5;
+    else if (!strcmp(name, "simple_light")) which = 6;
+    else if (!strcmp(name, "cornell")) which = 7;
+    else if (!strcmp(name, "cornell_smoke")) which = 8;
+    else if (!strcmp(name, "smallpt")) which = 9;
+    else return NULL; /* presets.rs:36 (`earth` needs media/earthmap.jpg, `final` is an empty list) */
     (void)g_draw_probe;
 
     ora_scene *sc = calloc(1, sizeof(*sc));
@@ -942,7 +1405,12 @@ ora_scene *ora_scene_from_preset(const char *name, uint32_t width, uint32_t heig
     case 1: preset_small(sc, width, height, &hv); break;
     case 2: preset_two_perlin_spheres(sc, width, height, &hv); break;
     case 3: preset_aras(sc, width, height, &hv); break;
-    default: preset_perlin_spheres(sc, width, height, &rng, &hv); break;
+    case 4: preset_perlin_spheres(sc, width, height, &rng, &hv); break;
+    case 5: preset_random(sc, width, height, &rng, &hv); break;
+    case 6: preset_simple_light(sc, width, height, &hv); break;
+    case 7: preset_cornell(sc, width, height, &hv, 0); break;
+    case 8: preset_cornell(sc, width, height, &hv, 1); break;
+    default: preset_smallpt(sc, width, height, &hv); break;
     }
     /* params.rs:29-46 new_scene */
     sc->use_bvh = use_bvh;
@@ -992,7 +1460,7 @@ static v3 scene_ray_trace(const ora_scene *s, const ray *ray_in, uint32_t depth,
                           xoshiro *rng, uint64_t *ray_count) {
     *ray_count += 1;
     ray_hit hit; const material *mat;
-    if (hitable_ray_hit(&s->world, ray_in, MIN_T, MAX_T, &hit, &mat)) {
+    if (hitable_ray_hit(&s->world, ray_in, MIN_T, MAX_T, rng, &hit, &mat)) {
         v3 emitted = material_emitted(mat, hit.u, hit.v, hit.point);
         if (depth < max_depth) {
             v3 attenuation; ray scattered;
@@ -1103,7 +1571,14 @@ uint64_t ora_scene_update_pixels(const ora_scene *s, uint32_t width, uint32_t he
 /* flat export                                                              */
 /* ======================================================================== */
 uint32_t ora_scene_num_spheres(const ora_scene *s) { return (uint32_t)s->list.len; }
-uint32_t ora_scene_num_materials(const ora_scene *s) { return (uint32_t)s->st.n_materials; }
+/* arena materials, then one Isotropic phase function per ConstantMedium (constant_medium.rs:13) */
+uint32_t ora_scene_num_materials(const ora_scene *s) { return (uint32_t)(s->st.n_materials + s->st.n_media); }
+uint32_t ora_scene_num_hitables(const ora_scene *s) { return (uint32_t)s->list.len; }
+uint32_t ora_scene_num_transforms(const ora_scene *s) { return (uint32_t)s->st.n_instances; }
+int ora_scene_is_sphere_world(const ora_scene *s) {
+    for (size_t i = 0; i < s->list.len; ++i) if (s->list.hitables[i].kind != HIT_SPHERE) return 0;
+    return 1;
+}
 uint32_t ora_scene_num_textures(const ora_scene *s) { return (uint32_t)s->st.n_textures; }
 uint32_t ora_scene_num_bvh_nodes(const ora_scene *s) { return (uint32_t)s->st.n_nodes; }
 uint64_t ora_scene_build_draws(const ora_scene *s) { return s->build_draws; }
@@ -1133,6 +1608,62 @@ void ora_scene_export_materials(const ora_scene *s, float *rows6) {
         r[4] = m->kind == MAT_METAL ? m->fuzz : (m->kind == MAT_DIELECTRIC ? m->ref_idx : 0.0f);
         r[5] = m->tex ? (float)(m->tex - s->st.textures) : -1.0f;
     }
+    for (size_t i = 0; i < s->st.n_media; ++i) {
+        const material *m = &s->st.media[i].phase_function;
+        float *r = rows6 + 6 * (s->st.n_materials + i);
+        r[0] = (float)m->kind; r[1] = r[2] = r[3] = r[4] = 0.0f;
+        r[5] = (float)(m->tex - s->st.textures);
+    }
+}
+
+/* world export (ptref.h): one 16-word record per list entry */
+static void put_f(uint32_t *w, float f) { memcpy(w, &f, 4); }
+static void export_base(const ora_scene *s, const hitable *h, uint32_t *w) {
+    float p[10] = {0};
+    switch (h->kind) {
+    case HIT_SPHERE:
+        w[0] = 0; p[0] = h->sph->centre.x; p[1] = h->sph->centre.y; p[2] = h->sph->centre.z; p[3] = h->sph->radius; break;
+    case HIT_MOVING_SPHERE:
+        w[0] = 1;
+        p[0] = h->msph->centre_start.x; p[1] = h->msph->centre_start.y; p[2] = h->msph->centre_start.z;
+        p[3] = h->msph->centre_delta.x; p[4] = h->msph->centre_delta.y; p[5] = h->msph->centre_delta.z;
+        p[6] = h->msph->radius; p[7] = h->msph->time_start; p[8] = h->msph->inv_time_delta; break;
+    case HIT_RECT:
+        w[0] = 2 + (uint32_t)h->rct->axis; w[2] = (uint32_t)h->rct->flip_normals;
+        p[0] = h->rct->a0; p[1] = h->rct->a1; p[2] = h->rct->b0; p[3] = h->rct->b1; p[4] = h->rct->k; break;
+    default: /* HIT_CUBOID: p0, p1 (cuboid.rs:11-23 derives the faces) */
+        w[0] = 5;
+        p[0] = h->cub->bb.min.x; p[1] = h->cub->bb.min.y; p[2] = h->cub->bb.min.z;
+        p[3] = h->cub->bb.max.x; p[4] = h->cub->bb.max.y; p[5] = h->cub->bb.max.z; break;
+    }
+    w[1] = (uint32_t)(h->mat - s->st.materials);
+    for (int i = 0; i < 10; ++i) put_f(&w[6 + i], p[i]);
+}
+void ora_scene_export_world(const ora_scene *s, uint32_t *records16, float *transforms24) {
+    for (size_t i = 0; i < s->list.len; ++i) {
+        const hitable *h = &s->list.hitables[i];
+        uint32_t *w = records16 + 16 * i;
+        memset(w, 0, 64);
+        w[3] = (uint32_t)-1; w[4] = (uint32_t)-1;
+        if (h->kind == HIT_CONSTANT_MEDIUM) {
+            w[4] = (uint32_t)(s->st.n_materials + (size_t)(h->med - s->st.media));
+            put_f(&w[5], h->med->density);
+            h = &h->med->child;
+        }
+        if (h->kind == HIT_INSTANCE) {
+            w[3] = (uint32_t)(h->inst - s->st.instances);
+            h = &h->inst->child;
+        }
+        export_base(s, h, w);
+    }
+    for (size_t i = 0; i < s->st.n_instances; ++i) {
+        const affine3 *m[2] = { &s->st.instances[i].transform, &s->st.instances[i].inv_transform };
+        for (int k = 0; k < 2; ++k) {
+            float *o = transforms24 + 24 * i + 12 * k;
+            const v3 *c[4] = { &m[k]->x_axis, &m[k]->y_axis, &m[k]->z_axis, &m[k]->translation };
+            for (int j = 0; j < 4; ++j) { o[3 * j] = c[j]->x; o[3 * j + 1] = c[j]->y; o[3 * j + 2] = c[j]->z; }
+        }
+    }
 }
 
 void ora_scene_export_textures(const ora_scene *s, float *rows7) {
@@ -1156,8 +1687,10 @@ void ora_scene_export_perlin(const ora_scene *s, float *randvec, uint32_t *perm_
 
 static int32_t export_child(const ora_scene *s, const hitable *h) {
     if (h->kind == HIT_BVHNODE) return (int32_t)(h->node - s->st.nodes);
-    /* sphere: index in LIST order (spheres arena order == list order) */
-    return ~(int32_t)(h->sph - s->st.spheres);
+    /* leaf: position in LIST order (the BVH build sorts copies of the list entries) */
+    for (size_t i = 0; i < s->list.len; ++i)
+        if (!memcmp(&s->list.hitables[i], h, sizeof(hitable))) return ~(int32_t)i;
+    return ~(int32_t)0x3fffffff; /* unreachable */
 }
 
 void ora_scene_export_bvh(const ora_scene *s, float *minmax6, int32_t *lhs_rhs2) {
@@ -1199,6 +1732,25 @@ int32_t ora_xoshiro_gen_range_i32(uint64_t state[4], int32_t low, int32_t high) 
     xoshiro r; memcpy(r.s, state, 32); int32_t v = gen_range_i32(&r, low, high); memcpy(state, r.s, 32); return v;
 }
 void ora_sinf_cosf(float x, float *s, float *c) { sinf_cosf(x, s, c); }
+/* f32::ln as constant_medium.rs:60 evaluates it (glibc logf, assumption A7) */
+void ora_ln_array(const float *in, float *out, uint64_t n) { for (uint64_t i = 0; i < n; ++i) out[i] = logf(in[i]); }
+/* One Hitable::ray_hit on list entry `index` of the built scene (any kind; media draw from `state`).
+ * out7 = point3, normal3, t; returns 1 on hit and the material index (export numbering) in *material. */
+int ora_hitable_ray_hit(const ora_scene *s, uint32_t index, const float origin[3], const float direction[3], float time,
+                        float t_min, float t_max, uint64_t state[4], float out7[7], uint32_t *material_out) {
+    xoshiro r; memcpy(r.s, state, 32);
+    ray ry = ray_new(V3(origin[0], origin[1], origin[2]), V3(direction[0], direction[1], direction[2]), time);
+    ray_hit h; const material *m = NULL;
+    int hit = hitable_ray_hit(&s->list.hitables[index], &ry, t_min, t_max, &r, &h, &m);
+    memcpy(state, r.s, 32);
+    if (hit) {
+        out7[0] = h.point.x; out7[1] = h.point.y; out7[2] = h.point.z;
+        out7[3] = h.normal.x; out7[4] = h.normal.y; out7[5] = h.normal.z; out7[6] = h.t;
+        if (m >= s->st.materials && m < s->st.materials + s->st.n_materials) *material_out = (uint32_t)(m - s->st.materials);
+        else *material_out = (uint32_t)s->st.n_materials + (uint32_t)(((const constant_medium *)((const char *)m - offsetof(constant_medium, phase_function))) - s->st.media);
+    }
+    return hit;
+}
 
 int ora_sphere_ray_hit(const float cr[4], const float o[3], const float d[3], float t_min, float t_max, float out9[9]) {
     sphere s = { V3(cr[0], cr[1], cr[2]), cr[3] };

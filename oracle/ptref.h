@@ -75,8 +75,26 @@ uint64_t ora_scene_build_draws(const ora_scene *s); /* scene-build RNG ledger */
 /* spheres: n*4 floats (cx,cy,cz,radius) in list order; material: n ids */
 void ora_scene_export_spheres(const ora_scene *s, float *xyzr,
                               uint32_t *material_id);
+/* ---- general worlds (moving spheres, rects, cuboids,
+ * instances, constant media). ora_scene_export_spheres is only valid when
+ * ora_scene_is_sphere_world(); ora_scene_export_world works for every preset:
+ * one 16-word (64-byte) record per HitableList entry,
+ *   w0 kind: 0 Sphere, 1 MovingSphere, 2/3/4 Rect XY/XZ/YZ, 5 Cuboid (the innermost shape)
+ *   w1 material index   w2 flip_normals (Rect)
+ *   w3 Instance wrapper: transform index or -1
+ *   w4 ConstantMedium wrapper (outermost): index of its Isotropic phase-function material or -1
+ *   w5 density (f32)    w6..w15 ten f32 shape parameters:
+ *      Sphere cx cy cz r | MovingSphere c0(3) delta(3) r time_start inv_time_delta
+ *      Rect a0 a1 b0 b1 k (in-plane coordinates in the variant's own order) | Cuboid p0(3) p1(3)
+ * transforms: 24 floats each = Affine3A {x_axis,y_axis,z_axis,translation} then its inverse.
+ * Materials are the arena materials followed by one Isotropic per ConstantMedium. */
+uint32_t ora_scene_num_hitables(const ora_scene *s);
+uint32_t ora_scene_num_transforms(const ora_scene *s);
+int ora_scene_is_sphere_world(const ora_scene *s);
+void ora_scene_export_world(const ora_scene *s, uint32_t *records16, float *transforms24);
+
 /* materials: n rows of 6 floats: kind, a0,a1,a2, param(fuzz|ref_idx), texture_id(-1 none)
- * kinds: 0 lambertian 1 metal 2 dielectric 3 diffuse_light */
+ * kinds: 0 lambertian 1 metal 2 dielectric 3 diffuse_light 4 isotropic */
 void ora_scene_export_materials(const ora_scene *s, float *rows6);
 /* textures: n rows of 7 floats: kind, c0,c1,c2, odd_id, even_id, scale
  * kinds: 0 constant 1 checker 2 noise */
@@ -101,6 +119,11 @@ float ora_xoshiro_gen_f32(uint64_t state[4]);
 int32_t ora_xoshiro_gen_range_i32(uint64_t state[4], int32_t low, int32_t high);
 uint64_t ora_pixel_seed(uint32_t x, uint32_t y, uint32_t frame_num);
 void ora_sinf_cosf(float x, float *s, float *c);
+void ora_ln_array(const float *in, float *out, uint64_t n); /* f32::ln (constant_medium.rs:60) */
+/* Hitable::ray_hit on list entry `index` (hitable.rs:39-65, any arm); out7 = point3, normal3, t */
+int ora_hitable_ray_hit(const ora_scene *s, uint32_t index, const float origin[3],
+                        const float direction[3], float time, float t_min, float t_max,
+                        uint64_t state[4], float out7[7], uint32_t *material);
 /* Sphere::ray_hit: returns 1 on hit; out9 = point3, normal3, t, u, v */
 int ora_sphere_ray_hit(const float centre_radius[4], const float origin[3],
                        const float direction[3], float t_min, float t_max,

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "pt_kernel.h"
+#include "pt_world.h"
 
 using namespace ptdev;
 
@@ -86,6 +87,13 @@ struct pt_scene {
     uint64_t seed_base = 0x243f6a8885a308d3ull;
     // tuning
     uint32_t blocks_per_cu = 0, variant = 0;
+    // general world (pt_scene_create_world with non-sphere hitables): traced by pt_world_kernel
+    bool is_world = false;
+    uint32_t n_hitables = 0;
+    pt_hitable *d_hitables = nullptr;
+    pt_affine *d_transforms = nullptr;
+    pt_bvh_node *d_ref_nodes = nullptr;   // the caller's tree as given (BVHNode::ray_hit is followed literally)
+    uint32_t ref_bvh_depth = 0;
     // last launch
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool ev_valid = false;
@@ -138,6 +146,39 @@ uint32_t bvh_depth_checked(const pt_bvh_node *nodes, uint32_t n_nodes, uint32_t 
         }
     }
     return maxd;
+}
+
+// Texture / material tables shared by both scene constructors.
+int validate_tables(uint32_t n_materials, const pt_material *materials, uint32_t n_textures, const pt_texture *textures,
+                    const pt_perlin *perlin, bool allow_isotropic, bool *has_noise_out) {
+    bool has_noise = false;
+    for (uint32_t i = 0; i < n_textures; ++i) {
+        const pt_texture &t = textures[i];
+        if (t.kind > PT_TEX_NOISE) return fail(PT_ERR_INVALID_ARG, "texture %u: unknown kind %u", i, t.kind);
+        if (t.kind == PT_TEX_CHECKER) {
+            // arena order (storage.rs:45-48): sub-textures are allocated before the checker that
+            // references them; requiring odd/even < i also guarantees termination on device.
+            if (t.odd < 0 || t.even < 0 || (uint32_t)t.odd >= i || (uint32_t)t.even >= i)
+                return fail(PT_ERR_INVALID_ARG, "texture %u: checker children must be earlier textures", i);
+        }
+        if (t.kind == PT_TEX_NOISE) has_noise = true;
+    }
+    if (has_noise && !perlin) return fail(PT_ERR_INVALID_ARG, "noise texture without perlin tables");
+    for (uint32_t i = 0; i < n_materials; ++i) {
+        const pt_material &m = materials[i];
+        if (m.kind > (allow_isotropic ? (uint32_t)PT_MAT_ISOTROPIC : (uint32_t)PT_MAT_DIFFUSE_LIGHT))
+            return fail(PT_ERR_INVALID_ARG, "material %u: unknown kind %u", i, m.kind);
+        if (m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_DIFFUSE_LIGHT || m.kind == PT_MAT_ISOTROPIC) {
+            if (m.texture < 0 || (uint32_t)m.texture >= n_textures)
+                return fail(PT_ERR_INVALID_ARG, "material %u: texture index %d out of range", i, m.texture);
+        }
+    }
+    if (perlin)
+        for (int i = 0; i < 256; ++i)
+            if (perlin->perm_x[i] > 255 || perlin->perm_y[i] > 255 || perlin->perm_z[i] > 255)
+                return fail(PT_ERR_INVALID_ARG, "perlin permutation entry > 255");
+    *has_noise_out = has_noise;
+    return PT_OK;
 }
 
 template <typename T>
@@ -343,26 +384,7 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
     if (desc->n_textures && !desc->textures) return fail(PT_ERR_INVALID_ARG, "textures is NULL");
     if (desc->n_spheres > 0x7fffffffu) return fail(PT_ERR_INVALID_ARG, "too many spheres");
     bool has_noise = false;
-    for (uint32_t i = 0; i < desc->n_textures; ++i) {
-        const pt_texture &t = desc->textures[i];
-        if (t.kind > PT_TEX_NOISE) return fail(PT_ERR_INVALID_ARG, "texture %u: unknown kind %u", i, t.kind);
-        if (t.kind == PT_TEX_CHECKER) {
-            // arena order (storage.rs:45-48): sub-textures are allocated before the checker that
-            // references them; requiring odd/even < i also guarantees termination on device.
-            if (t.odd < 0 || t.even < 0 || (uint32_t)t.odd >= i || (uint32_t)t.even >= i)
-                return fail(PT_ERR_INVALID_ARG, "texture %u: checker children must be earlier textures", i);
-        }
-        if (t.kind == PT_TEX_NOISE) has_noise = true;
-    }
-    if (has_noise && !desc->perlin) return fail(PT_ERR_INVALID_ARG, "noise texture without perlin tables");
-    for (uint32_t i = 0; i < desc->n_materials; ++i) {
-        const pt_material &m = desc->materials[i];
-        if (m.kind > PT_MAT_DIFFUSE_LIGHT) return fail(PT_ERR_INVALID_ARG, "material %u: unknown kind %u", i, m.kind);
-        if (m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_DIFFUSE_LIGHT) {
-            if (m.texture < 0 || (uint32_t)m.texture >= desc->n_textures)
-                return fail(PT_ERR_INVALID_ARG, "material %u: texture index %d out of range", i, m.texture);
-        }
-    }
+    if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, false, &has_noise)) return rc;
     for (uint32_t i = 0; i < desc->n_spheres; ++i)
         if (desc->sphere_material[i] >= desc->n_materials)
             return fail(PT_ERR_INVALID_ARG, "sphere %u: material index out of range", i);
@@ -373,10 +395,6 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
         if (bvh_depth == 0) return fail(PT_ERR_INVALID_ARG, "malformed BVH (bad child index or cycle)");
         // (the caller's depth is irrelevant: traversal runs over the internal tree built below)
     }
-    if (desc->perlin)
-        for (int i = 0; i < 256; ++i)
-            if (desc->perlin->perm_x[i] > 255 || desc->perlin->perm_y[i] > 255 || desc->perlin->perm_z[i] > 255)
-                return fail(PT_ERR_INVALID_ARG, "perlin permutation entry > 255");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
@@ -539,9 +557,125 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
     return PT_OK;
 }
 
+// ---- general worlds --------------------------------------------------------------------------------
+extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_scene **scene_out) {
+    if (!desc || !scene_out) return fail(PT_ERR_INVALID_ARG, "desc/scene_out is NULL");
+    *scene_out = nullptr;
+    if (desc->n_hitables == 0 || !desc->hitables) return fail(PT_ERR_INVALID_ARG, "world has no hitables");
+    if (desc->n_hitables > 0x3fffffffu) return fail(PT_ERR_INVALID_ARG, "too many hitables");
+    if (desc->n_materials == 0 || !desc->materials) return fail(PT_ERR_INVALID_ARG, "world has no materials");
+    if (desc->n_textures && !desc->textures) return fail(PT_ERR_INVALID_ARG, "textures is NULL");
+    if (desc->n_transforms && !desc->transforms) return fail(PT_ERR_INVALID_ARG, "transforms is NULL");
+    bool has_noise = false;
+    if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, true, &has_noise)) return rc;
+    bool all_spheres = true;
+    for (uint32_t i = 0; i < desc->n_hitables; ++i) {
+        const pt_hitable &h = desc->hitables[i];
+        if (h.kind > PT_HIT_CUBOID) return fail(PT_ERR_INVALID_ARG, "hitable %u: unknown kind %u", i, h.kind);
+        if (h.material >= desc->n_materials) return fail(PT_ERR_INVALID_ARG, "hitable %u: material index out of range", i);
+        if (desc->materials[h.material].kind == PT_MAT_ISOTROPIC)
+            return fail(PT_ERR_INVALID_ARG, "hitable %u: Isotropic is only valid as a medium's phase function", i);
+        if (h.transform >= 0 && (uint32_t)h.transform >= desc->n_transforms)
+            return fail(PT_ERR_INVALID_ARG, "hitable %u: transform index out of range", i);
+        if (h.medium_material >= 0) {
+            if ((uint32_t)h.medium_material >= desc->n_materials || desc->materials[h.medium_material].kind != PT_MAT_ISOTROPIC)
+                return fail(PT_ERR_INVALID_ARG, "hitable %u: medium_material must index an Isotropic material", i);
+        }
+        if (h.kind != PT_HIT_SPHERE || h.transform >= 0 || h.medium_material >= 0) all_spheres = false;
+    }
+    if (desc->n_bvh_nodes) {
+        if (!desc->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "bvh_nodes is NULL");
+        if (bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_hitables, desc->bvh_root) == 0)
+            return fail(PT_ERR_INVALID_ARG, "malformed BVH (bad child index or cycle)");
+    }
+    if (all_spheres) {  // a plain sphere world: the specialised kernels (MFMA prefilter, internal tree) apply
+        std::vector<pt_sphere> sph(desc->n_hitables);
+        std::vector<uint32_t> mat(desc->n_hitables);
+        for (uint32_t i = 0; i < desc->n_hitables; ++i) {
+            const pt_hitable &h = desc->hitables[i];
+            sph[i] = pt_sphere{h.p[0], h.p[1], h.p[2], h.p[3]};
+            mat[i] = h.material;
+        }
+        pt_scene_desc d{};
+        d.n_spheres = desc->n_hitables, d.spheres = sph.data(), d.sphere_material = mat.data();
+        d.n_materials = desc->n_materials, d.materials = desc->materials;
+        d.n_textures = desc->n_textures, d.textures = desc->textures, d.perlin = desc->perlin;
+        d.n_bvh_nodes = desc->n_bvh_nodes, d.bvh_nodes = desc->bvh_nodes, d.bvh_root = desc->bvh_root;
+        d.has_sky = desc->has_sky;
+        memcpy(d.sky, desc->sky, sizeof d.sky);
+        return pt_scene_create(&d, device, scene_out);
+    }
+    uint32_t ref_depth = 0;
+    if (desc->n_bvh_nodes) {
+        ref_depth = bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_hitables, desc->bvh_root);
+        if (ref_depth + 2 > 64u) return fail(PT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", ref_depth);
+    }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    pt_scene *s = new (std::nothrow) pt_scene();
+    if (!s) return fail(PT_ERR_INVALID_ARG, "out of host memory");
+    s->device = device;
+    s->num_cus = prop.multiProcessorCount;
+    s->is_world = true;
+    s->n_hitables = desc->n_hitables;
+    s->n_materials = desc->n_materials;
+    s->n_textures = desc->n_textures;
+    s->bvh_root = desc->n_bvh_nodes ? desc->bvh_root : -1;
+    s->ref_bvh_depth = ref_depth;
+    s->has_sky = desc->has_sky ? 1u : 0u;
+    memcpy(s->sky, desc->sky, sizeof s->sky);
+    s->has_noise = has_noise ? 1u : 0u;
+    std::vector<DMat> mats(desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        const pt_material &m = desc->materials[i];
+        mats[i] = DMat{m.kind, m.albedo[0], m.albedo[1], m.albedo[2], m.param, m.texture, 0.f, 0.f};
+    }
+    std::vector<DTex> texs(desc->n_textures ? desc->n_textures : 1);
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const pt_texture &t = desc->textures[i];
+        texs[i] = DTex{t.kind, t.color[0], t.color[1], t.color[2], t.odd, t.even, t.scale, 0.f};
+    }
+    std::vector<float4> pvec(256, make_float4(0, 0, 0, 0));
+    std::vector<uint32_t> pperm(768, 0);
+    if (desc->perlin) {
+        for (int i = 0; i < 256; ++i) {
+            pvec[i] = make_float4(desc->perlin->randvec[i][0], desc->perlin->randvec[i][1], desc->perlin->randvec[i][2], 0.f);
+            pperm[i] = desc->perlin->perm_x[i];
+            pperm[256 + i] = desc->perlin->perm_y[i];
+            pperm[512 + i] = desc->perlin->perm_z[i];
+        }
+    }
+    int rc = PT_OK;
+    if ((rc = upload(&s->d_hitables, desc->hitables, desc->n_hitables)) ||
+        (rc = upload(&s->d_transforms, desc->transforms, desc->n_transforms)) ||
+        (rc = upload(&s->d_ref_nodes, desc->bvh_nodes, desc->n_bvh_nodes)) ||
+        (rc = upload(&s->d_mats, mats.data(), mats.size())) || (rc = upload(&s->d_texs, texs.data(), texs.size())) ||
+        (rc = upload(&s->d_perlin_vec, pvec.data(), pvec.size())) || (rc = upload(&s->d_perlin_perm, pperm.data(), pperm.size()))) {
+        pt_scene_destroy(s);
+        return rc;
+    }
+    if (hipMalloc((void **)&s->d_debug, 1024) != hipSuccess || hipMemset(s->d_debug, 0, 1024) != hipSuccess ||
+        hipMalloc((void **)&s->d_work_counter, 64) != hipSuccess || hipMalloc((void **)&s->d_ray_count, 64) != hipSuccess ||
+        hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess) {
+        pt_scene_destroy(s);
+        return fail(PT_ERR_HIP, "allocating counters / events failed");
+    }
+    if (const char *e = getenv("PTGPU_BLOCKS_PER_CU")) s->blocks_per_cu = (uint32_t)atoi(e);
+    *scene_out = s;
+    return PT_OK;
+}
+
 extern "C" void pt_scene_destroy(pt_scene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    (void)hipFree(s->d_hitables);
+    (void)hipFree(s->d_transforms);
+    (void)hipFree(s->d_ref_nodes);
     (void)hipFree(s->d_spheres);
     (void)hipFree(s->d_spheres_r2);
     (void)hipFree(s->d_shade);
@@ -601,6 +735,89 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     const bool list_tree = !ref_bvh && (s->variant & (4u | 64u)) == 0 && (s->n_spheres > kListTreeMin || s->n_spheres > 0xfff0u);
     const bool bvh = ref_bvh || list_tree;       // kernel flavour: tree traversal
     HIP_TRY(hipSetDevice(s->device));
+
+    if (s->is_world) {
+        WArgs W;
+        memset(&W, 0, sizeof W);
+        W.hit = s->d_hitables;
+        W.xf = s->d_transforms;
+        W.nodes = s->d_ref_nodes;
+        W.mats = s->d_mats;
+        W.texs = s->d_texs;
+        W.perlin_vec = s->d_perlin_vec;
+        W.perlin_perm = s->d_perlin_perm;
+        W.n_hit = s->n_hitables;
+        W.bvh_root = ref_bvh ? s->bvh_root : -1;
+        W.bvh_stack_entries = s->ref_bvh_depth + 2u;
+        W.has_sky = s->has_sky;
+        W.sky = to3(s->sky);
+        W.has_noise = s->has_noise;
+        W.cam.origin = to3(cam->origin);
+        W.cam.lower_left_corner = to3(cam->lower_left_corner);
+        W.cam.horizontal = to3(cam->horizontal);
+        W.cam.vertical = to3(cam->vertical);
+        W.cam.u = to3(cam->u);
+        W.cam.v = to3(cam->v);
+        W.cam.w = to3(cam->w);
+        W.cam.time0 = cam->time0;
+        W.cam.time1 = cam->time1;
+        W.cam.lens_radius = cam->lens_radius;
+        W.width = params->width, W.height = params->height, W.samples = params->samples, W.max_depth = params->max_depth;
+        W.frame_num = frame_num;
+        {
+            const volatile float one = 1.0f;  // scene.rs:82-87 in f32
+            W.inv_nx = one / (float)params->width;
+            W.inv_ny = one / (float)params->height;
+            W.inv_ns = one / (float)params->samples;
+            const volatile float mp = (float)frame_num / (float)(frame_num + 1u);
+            W.mix_prev = mp;
+            W.mix_new = one - mp;
+        }
+        W.random_seed = params->random_seed;
+        W.seed_base = s->seed_base;
+        W.shard_index = shard_index, W.shard_count = shard_count;
+        W.local_rows = pt_shard_rows(params->height, shard_index, shard_count);
+        W.tiles_x = (params->width + 7u) / 8u;
+        W.n_items = W.tiles_x * ((W.local_rows + 7u) / 8u) * 64u;
+        W.rgb = d_rgb;
+        W.ray_count = reinterpret_cast<unsigned long long *>(d_ray_count);
+        W.work_counter = s->d_work_counter;
+        HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
+        if (W.n_items == 0) return PT_OK;
+        uint32_t lds = s->has_noise ? (4096u + 3072u) : 0u;
+        if (ref_bvh) lds += W.bvh_stack_entries * kBlock * 4u;
+        const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
+        W.stack_in_lds = (lds + path_bytes <= 60u * 1024u) ? 1u : 0u;
+        if (W.stack_in_lds) lds += (uint32_t)path_bytes;
+        uint32_t bpc = s->blocks_per_cu ? s->blocks_per_cu : 2u;
+        const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
+        if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
+        if (bpc > 8u) bpc = 8u;
+        uint32_t grid = (uint32_t)s->num_cus * bpc;
+        const uint32_t need = (W.n_items + kBlock - 1) / kBlock;
+        if (grid > need) grid = need;
+        if (!W.stack_in_lds) {
+            const size_t need_floats = (size_t)grid * params->max_depth * 3ull * kBlock;
+            if (need_floats > s->d_gstack_floats) {
+                (void)hipFree(s->d_gstack);
+                s->d_gstack = nullptr;
+                s->d_gstack_floats = 0;
+                HIP_TRY(hipMalloc((void **)&s->d_gstack, need_floats * sizeof(float)));
+                s->d_gstack_floats = need_floats;
+            }
+            W.gstack = s->d_gstack;
+        }
+        void (*wk)(const WArgs) = ref_bvh ? pt_world_kernel<true> : pt_world_kernel<false>;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipEventRecord(s->ev_start, stream));
+        hipLaunchKernelGGL(wk, dim3(grid), dim3(kBlock), lds, stream, W);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(s->ev_stop, stream));
+        s->ev_valid = true;
+        s->last_grid = grid, s->last_block = kBlock, s->last_lds = lds;
+        return PT_OK;
+    }
 
     KArgs A;
     memset(&A, 0, sizeof A);
@@ -870,6 +1087,7 @@ __global__ void probe_kernel(uint32_t probe, const float *in, float *out, size_t
     case PT_PROBE_POW5: r = pow5_ref(x); break;
     case PT_PROBE_SIN: sinf_cosf_ref(x, s, c); r = s; break;
     case PT_PROBE_COS: sinf_cosf_ref(x, s, c); r = c; break;
+    case PT_PROBE_LN: r = logf_ref(x); break;
     default: {
         Rng rng;
         rng_seed_from_u64(rng, (uint64_t)__float_as_uint(x));
@@ -882,7 +1100,7 @@ __global__ void probe_kernel(uint32_t probe, const float *in, float *out, size_t
 
 extern "C" int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n) {
     if (!in || !out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
-    if (probe > PT_PROBE_RNG) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
+    if (probe > PT_PROBE_LN) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
     if (n == 0) return PT_OK;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");

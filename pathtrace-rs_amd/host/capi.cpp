@@ -17,7 +17,7 @@ struct pth_scene {
 namespace {
 thread_local char g_err[512] = "";
 void set_err(const char *msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
-uint32_t depth_of(const pt_scene_desc &d, int32_t ref) {
+uint32_t depth_of(const pt_world_desc &d, int32_t ref) {
     if (ref < 0) return 0;
     const uint32_t l = depth_of(d, d.bvh_nodes[ref].lhs), r = depth_of(d, d.bvh_nodes[ref].rhs);
     return 1 + (l > r ? l : r);
@@ -50,7 +50,7 @@ extern "C" int pth_scene_build(const char *preset, uint32_t width, uint32_t heig
         s->scene = pt::Scene::new_scene(params, rng, storage, built->hitables, built->sky, device);
         s->camera = built->camera;
         s->build_draws = rng.draws();
-        if (s->scene->desc().n_bvh_nodes) s->bvh_depth = depth_of(s->scene->desc(), s->scene->desc().bvh_root);
+        if (s->scene->world_desc().n_bvh_nodes) s->bvh_depth = depth_of(s->scene->world_desc(), s->scene->world_desc().bvh_root);
         *out = s.release();
         return 0;
     } catch (const std::exception &e) {
@@ -61,6 +61,8 @@ extern "C" int pth_scene_build(const char *preset, uint32_t width, uint32_t heig
 
 extern "C" void pth_scene_free(pth_scene *s) { delete s; }
 extern "C" const pt_scene_desc *pth_scene_desc(const pth_scene *s) { return s ? &s->scene->desc() : nullptr; }
+extern "C" const pt_world_desc *pth_scene_world_desc(const pth_scene *s) { return s ? &s->scene->world_desc() : nullptr; }
+extern "C" int pth_scene_is_world(const pth_scene *s) { return s && s->scene->is_world() ? 1 : 0; }
 extern "C" const pt_camera *pth_scene_camera(const pth_scene *s) { return s ? &s->camera.pod : nullptr; }
 extern "C" pt_scene *pth_scene_handle(const pth_scene *s) { return s ? s->scene->handle() : nullptr; }
 extern "C" uint64_t pth_scene_build_draws(const pth_scene *s) { return s ? s->build_draws : 0; }

@@ -55,17 +55,18 @@ enum class MaterialKind : uint32_t {
     Lambertian = PT_MAT_LAMBERTIAN,
     Metal = PT_MAT_METAL,
     Dielectric = PT_MAT_DIELECTRIC,
-    DiffuseLight = PT_MAT_DIFFUSE_LIGHT
+    DiffuseLight = PT_MAT_DIFFUSE_LIGHT,
+    Isotropic = PT_MAT_ISOTROPIC
 };
 
 using TextureId = int32_t;
 using MaterialId = uint32_t;
 
-// A Hitable::Sphere(&Sphere, &Material) entry of the world list (hitable.rs:12-21).
-struct SphereHitable {
-    uint32_t sphere;      // index into Storage::spheres
-    MaterialId material;  // index into Storage::materials
-};
+// One entry of the world list (hitable.rs:12-21), flattened to the nesting the reference's presets build:
+// the innermost shape (Sphere / MovingSphere / Rect / Cuboid with its &Material), optionally inside an
+// Instance, optionally inside a ConstantMedium. The POD is the C-ABI record; `medium_material` holds the
+// index into Storage::phase_functions until Scene::new_scene appends those after the arena materials.
+using Hitable = pt_hitable;
 
 // storage.rs:12-43 -- typed arenas become index-addressed vectors
 class Storage {
@@ -81,15 +82,28 @@ public:
     MaterialId alloc_diffuse_light(TextureId emit);          // material.rs:33-35
     uint32_t alloc_sphere(Vec3 centre, float radius);        // sphere.rs:15-17
 
+    // Hitable constructors (the closures of presets.rs:115-127 and the Hitable::X(...) expressions)
+    Hitable sphere(Vec3 centre, float radius, MaterialId material);                           // Hitable::Sphere
+    Hitable moving_sphere(Vec3 centre0, Vec3 centre1, float time0, float time1, float radius,
+                          MaterialId material);                                               // moving_sphere.rs:18-26
+    Hitable rect_xy(float x0, float x1, float y0, float y1, float k, bool flip, MaterialId material);  // rect.rs:37-46
+    Hitable rect_xz(float x0, float x1, float z0, float z1, float k, bool flip, MaterialId material);  // rect.rs:49-58
+    Hitable rect_yz(float y0, float y1, float z0, float z1, float k, bool flip, MaterialId material);  // rect.rs:61-70
+    Hitable cuboid(Vec3 p0, Vec3 p1, MaterialId material);                                    // cuboid.rs:11-23
+    Hitable instance(const Hitable &child, const Affine3A &transform);                        // instance.rs:16-22
+    Hitable constant_medium(const Hitable &child, float density, TextureId albedo);           // constant_medium.rs:18-26
+
     std::vector<pt_texture> textures;
     std::vector<pt_material> materials;
+    std::vector<pt_material> phase_functions;  // one Isotropic per ConstantMedium (constant_medium.rs:13)
+    std::vector<pt_affine> transforms;         // Instance { transform, inv_transform }
     std::vector<pt_sphere> spheres;
     Perlin perlin_noise;
     bool uses_noise = false;
 };
 
 struct PresetResult {
-    std::vector<SphereHitable> hitables;
+    std::vector<Hitable> hitables;
     Camera camera;
     std::optional<Vec3> sky;
 };
@@ -107,7 +121,11 @@ struct BvhBuild {
     int32_t root = -1;
     uint32_t max_depth = 0;
 };
-BvhBuild build_bvh(Xoshiro256Plus &rng, const Storage &storage, std::vector<SphereHitable> hitables);
+BvhBuild build_bvh(Xoshiro256Plus &rng, const Storage &storage, const std::vector<Hitable> &hitables);
+// Hitable::bounding_box(0, 0) (hitable.rs:25-36) including the reference's quirks: AABB::transform ignores
+// `self` (aabb.rs:75-100), the YZ rect box is flat at k - 0.0001 (rect.rs:225-226), moving spheres are
+// boxed at t = 0 only (bvh.rs:69-70).
+void bounding_box(const Storage &storage, const Hitable &h, Vec3 &min_out, Vec3 &max_out);
 
 // scene.rs:18-31 + Params::new_scene (params.rs:29-46)
 class Scene {
@@ -119,14 +137,16 @@ public:
     // Params::new_scene: List, or BVH when params.use_bvh. Throws std::runtime_error
     // with pt_last_error() when the device library refuses (the reference unwrap()s).
     static std::unique_ptr<Scene> new_scene(const Params &params, Xoshiro256Plus &rng, const Storage &storage,
-                                            const std::vector<SphereHitable> &hitables, std::optional<Vec3> sky,
+                                            const std::vector<Hitable> &hitables, std::optional<Vec3> sky,
                                             int device = 0);
 
     // Scene::update (scene.rs:73-121): buffer is width*height (r,g,b) float triples, read and written.
     size_t update(const Params &params, const Camera &camera, uint32_t frame_num, float *buffer);
 
     pt_scene *handle() const { return handle_; }
-    const pt_scene_desc &desc() const { return desc_; }
+    const pt_scene_desc &desc() const { return desc_; }   // valid when !is_world()
+    const pt_world_desc &world_desc() const { return world_; }  // always filled
+    bool is_world() const { return is_world_; }            // any non-sphere hitable: traced by the general kernel
     float last_kernel_ms() const;
 
 private:
@@ -139,7 +159,11 @@ private:
     std::vector<pt_texture> textures_;
     std::unique_ptr<pt_perlin> perlin_;
     std::vector<pt_bvh_node> bvh_nodes_;
+    std::vector<pt_hitable> hitables_;
+    std::vector<pt_affine> transforms_;
     pt_scene_desc desc_{};
+    pt_world_desc world_{};
+    bool is_world_ = false;
     friend struct SceneAccess;
 };
 

@@ -18,7 +18,9 @@ typedef struct pth_scene pth_scene;
 int pth_scene_build(const char *preset, uint32_t width, uint32_t height, uint32_t samples, int use_bvh,
                     int device, int quiet, pth_scene **out);
 void pth_scene_free(pth_scene *s);
-const pt_scene_desc *pth_scene_desc(const pth_scene *s);
+const pt_scene_desc *pth_scene_desc(const pth_scene *s);            /* sphere-only worlds (!pth_scene_is_world) */
+const pt_world_desc *pth_scene_world_desc(const pth_scene *s);      /* every world */
+int pth_scene_is_world(const pth_scene *s);                         /* 1: has non-sphere hitables (general kernel) */
 const pt_camera *pth_scene_camera(const pth_scene *s);
 pt_scene *pth_scene_handle(const pth_scene *s);
 uint64_t pth_scene_build_draws(const pth_scene *s);

@@ -112,6 +112,107 @@ uint32_t Storage::alloc_sphere(Vec3 centre, float radius) {
     return static_cast<uint32_t>(spheres.size() - 1);
 }
 
+// ---- Hitable constructors ---------------------------------------------------
+namespace {
+Hitable blank(uint32_t kind, MaterialId material) {
+    Hitable h{};
+    h.kind = kind;
+    h.material = material;
+    h.transform = -1;
+    h.medium_material = -1;
+    return h;
+}
+}  // namespace
+
+Hitable Storage::sphere(Vec3 centre, float radius, MaterialId material) {
+    alloc_sphere(centre, radius);  // Hitable::Sphere(storage.alloc_sphere(..), storage.alloc_material(..))
+    Hitable h = blank(PT_HIT_SPHERE, material);
+    h.p[0] = centre.x, h.p[1] = centre.y, h.p[2] = centre.z, h.p[3] = radius;
+    return h;
+}
+Hitable Storage::moving_sphere(Vec3 centre0, Vec3 centre1, float time0, float time1, float radius, MaterialId material) {
+    Hitable h = blank(PT_HIT_MOVING_SPHERE, material);
+    const Vec3 delta = centre1 - centre0;  // moving_sphere.rs:21
+    h.p[0] = centre0.x, h.p[1] = centre0.y, h.p[2] = centre0.z;
+    h.p[3] = delta.x, h.p[4] = delta.y, h.p[5] = delta.z;
+    h.p[6] = radius, h.p[7] = time0, h.p[8] = 1.0f / (time1 - time0);  // moving_sphere.rs:24
+    return h;
+}
+namespace {
+Hitable rect(uint32_t kind, float a0, float a1, float b0, float b1, float k, bool flip, MaterialId material) {
+    Hitable h = blank(kind, material);
+    h.flip_normals = flip ? 1u : 0u;
+    h.p[0] = a0, h.p[1] = a1, h.p[2] = b0, h.p[3] = b1, h.p[4] = k;
+    return h;
+}
+}  // namespace
+Hitable Storage::rect_xy(float x0, float x1, float y0, float y1, float k, bool flip, MaterialId m) { return rect(PT_HIT_RECT_XY, x0, x1, y0, y1, k, flip, m); }
+Hitable Storage::rect_xz(float x0, float x1, float z0, float z1, float k, bool flip, MaterialId m) { return rect(PT_HIT_RECT_XZ, x0, x1, z0, z1, k, flip, m); }
+Hitable Storage::rect_yz(float y0, float y1, float z0, float z1, float k, bool flip, MaterialId m) { return rect(PT_HIT_RECT_YZ, y0, y1, z0, z1, k, flip, m); }
+Hitable Storage::cuboid(Vec3 p0, Vec3 p1, MaterialId material) {
+    Hitable h = blank(PT_HIT_CUBOID, material);
+    h.p[0] = p0.x, h.p[1] = p0.y, h.p[2] = p0.z, h.p[3] = p1.x, h.p[4] = p1.y, h.p[5] = p1.z;
+    return h;
+}
+Hitable Storage::instance(const Hitable &child, const Affine3A &transform) {
+    if (child.transform >= 0 || child.medium_material >= 0)
+        throw std::runtime_error("Instance: only Instance(shape) nesting is supported");
+    const Affine3A inv = transform.inverse();  // instance.rs:20
+    pt_affine a{};
+    const Affine3A *src[2] = {&transform, &inv};
+    float *dst[2] = {a.m, a.inv};
+    for (int k = 0; k < 2; ++k) {
+        const Vec3 cols[4] = {src[k]->x_axis, src[k]->y_axis, src[k]->z_axis, src[k]->translation};
+        for (int j = 0; j < 4; ++j) dst[k][3 * j] = cols[j].x, dst[k][3 * j + 1] = cols[j].y, dst[k][3 * j + 2] = cols[j].z;
+    }
+    transforms.push_back(a);
+    Hitable h = child;
+    h.transform = static_cast<int32_t>(transforms.size() - 1);
+    return h;
+}
+Hitable Storage::constant_medium(const Hitable &child, float density, TextureId albedo) {
+    if (child.medium_material >= 0) throw std::runtime_error("ConstantMedium: nested media are not supported");
+    phase_functions.push_back(pt_material{PT_MAT_ISOTROPIC, {0.f, 0.f, 0.f}, 0.0f, albedo});  // material.rs:37-39
+    Hitable h = child;
+    h.medium_material = static_cast<int32_t>(phase_functions.size() - 1);  // rebased by Scene::new_scene
+    h.density = density;
+    return h;
+}
+
+// ---- hitable.rs:25-36 bounding boxes (t0 = t1 = 0, bvh.rs:69-70) ---------------
+void bounding_box(const Storage &storage, const Hitable &h, Vec3 &mn, Vec3 &mx) {
+    if (h.transform >= 0) {
+        // instance.rs:24-30 -> AABB::transform (aabb.rs:75-100) starts from min = max = w_axis and never
+        // reads the child's box: the result is one point. ConstantMedium forwards it (constant_medium.rs:28-30).
+        const float *m = storage.transforms[h.transform].m;
+        const Vec3 x(m[0], m[1], m[2]), y(m[3], m[4], m[5]), z(m[6], m[7], m[8]), t(m[9], m[10], m[11]);
+        Vec3 out = t;
+        out = out + x * t;
+        out = out + y * t;
+        out = out + z * t;
+        mn = mx = out;
+        return;
+    }
+    const float *p = h.p;
+    switch (h.kind) {
+    case PT_HIT_SPHERE: {  // sphere.rs:69-75
+        const Vec3 c(p[0], p[1], p[2]), r = Vec3::splat(p[3]);
+        mn = c - r, mx = c + r;
+        return;
+    }
+    case PT_HIT_MOVING_SPHERE: {  // moving_sphere.rs:76-89 at t0 = t1 = 0
+        const float s = (0.0f - p[7]) * p[8];
+        const Vec3 c = Vec3(p[0], p[1], p[2]) + s * Vec3(p[3], p[4], p[5]), r = Vec3::splat(p[6]);
+        mn = vmin(c - r, c - r), mx = vmax(c + r, c + r);
+        return;
+    }
+    case PT_HIT_RECT_XY: mn = Vec3(p[0], p[2], p[4] - 0.0001f), mx = Vec3(p[1], p[3], p[4] + 0.0001f); return;  // rect.rs:195-206
+    case PT_HIT_RECT_XZ: mn = Vec3(p[0], p[4] - 0.0001f, p[2]), mx = Vec3(p[1], p[4] + 0.0001f, p[3]); return;  // rect.rs:207-218
+    case PT_HIT_RECT_YZ: mn = Vec3(p[4] - 0.0001f, p[0], p[2]), mx = Vec3(p[4] - 0.0001f, p[1], p[3]); return;  // rect.rs:219-228 (sic)
+    default: mn = Vec3(p[0], p[1], p[2]), mx = Vec3(p[3], p[4], p[5]); return;                                   // cuboid.rs:39-41
+    }
+}
+
 // ---- bvh.rs:64-94,268-347 --------------------------------------------------
 namespace {
 
@@ -173,14 +274,14 @@ uint32_t depth_of(const std::vector<pt_bvh_node> &nodes, int32_t ref) {
 
 }  // namespace
 
-BvhBuild build_bvh(Xoshiro256Plus &rng, const Storage &storage, std::vector<SphereHitable> hitables) {
+BvhBuild build_bvh(Xoshiro256Plus &rng, const Storage &storage, const std::vector<Hitable> &hitables) {
     BvhBuild out;
     std::vector<BuildRef> refs;
     refs.reserve(hitables.size());
-    for (size_t i = 0; i < hitables.size(); ++i) {
-        const pt_sphere &s = storage.spheres[hitables[i].sphere];
-        const Vec3 c(s.cx, s.cy, s.cz), r = Vec3::splat(s.radius);  // sphere.rs:69-75
-        refs.push_back(BuildRef{~static_cast<int32_t>(i), Box{c - r, c + r}});
+    for (size_t i = 0; i < hitables.size(); ++i) {  // leaves are numbered by LIST position
+        Box b;
+        bounding_box(storage, hitables[i], b.min, b.max);
+        refs.push_back(BuildRef{~static_cast<int32_t>(i), b});
     }
     BvhBuilder b(rng, out);
     const size_t n = refs.size();
@@ -203,17 +304,21 @@ Scene::~Scene() {
 }
 
 std::unique_ptr<Scene> Scene::new_scene(const Params &params, Xoshiro256Plus &rng, const Storage &storage,
-                                        const std::vector<SphereHitable> &hitables, std::optional<Vec3> sky,
+                                        const std::vector<Hitable> &hitables, std::optional<Vec3> sky,
                                         int device) {
     std::unique_ptr<Scene> s(new Scene());
     // the world list in HitableList order (hitable_list.rs:13-16)
-    s->spheres_.reserve(hitables.size());
-    s->sphere_material_.reserve(hitables.size());
-    for (const SphereHitable &h : hitables) {
-        s->spheres_.push_back(storage.spheres.at(h.sphere));
-        s->sphere_material_.push_back(h.material);
-    }
+    s->hitables_ = hitables;
     s->materials_ = storage.materials;
+    const int32_t phase_base = static_cast<int32_t>(s->materials_.size());
+    s->materials_.insert(s->materials_.end(), storage.phase_functions.begin(), storage.phase_functions.end());
+    bool all_spheres = true;
+    for (Hitable &h : s->hitables_) {
+        if (h.medium_material >= 0) h.medium_material += phase_base;
+        if (h.kind != PT_HIT_SPHERE || h.transform >= 0 || h.medium_material >= 0) all_spheres = false;
+    }
+    s->is_world_ = !all_spheres;
+    s->transforms_ = storage.transforms;
     s->textures_ = storage.textures;
     if (storage.uses_noise) {
         s->perlin_.reset(new pt_perlin());
@@ -228,33 +333,46 @@ std::unique_ptr<Scene> Scene::new_scene(const Params &params, Xoshiro256Plus &rn
     }
     int32_t root = -1;
     if (params.use_bvh) {  // params.rs:36-40
-        // the list positions are the leaf ids: build over hitables re-indexed 0..n-1
-        Storage const &st = storage;
-        std::vector<SphereHitable> listed = hitables;
-        BvhBuild bvh = [&] {
-            // build_bvh reads storage.spheres[h.sphere]; leaves are numbered by LIST position
-            return build_bvh(rng, st, listed);
-        }();
+        BvhBuild bvh = build_bvh(rng, storage, hitables);
         s->bvh_nodes_ = std::move(bvh.nodes);
         root = bvh.root;
     }
-    pt_scene_desc &d = s->desc_;
-    d.n_spheres = static_cast<uint32_t>(s->spheres_.size());
-    d.spheres = s->spheres_.data();
-    d.sphere_material = s->sphere_material_.data();
-    d.n_materials = static_cast<uint32_t>(s->materials_.size());
-    d.materials = s->materials_.data();
-    d.n_textures = static_cast<uint32_t>(s->textures_.size());
-    d.textures = s->textures_.data();
-    d.perlin = s->perlin_.get();
-    d.n_bvh_nodes = static_cast<uint32_t>(s->bvh_nodes_.size());
-    d.bvh_nodes = s->bvh_nodes_.empty() ? nullptr : s->bvh_nodes_.data();
-    d.bvh_root = root;
-    d.has_sky = sky.has_value() ? 1u : 0u;
-    if (sky) d.sky[0] = sky->x, d.sky[1] = sky->y, d.sky[2] = sky->z;
+    pt_world_desc &w = s->world_;
+    w.n_hitables = static_cast<uint32_t>(s->hitables_.size());
+    w.hitables = s->hitables_.data();
+    w.n_transforms = static_cast<uint32_t>(s->transforms_.size());
+    w.transforms = s->transforms_.empty() ? nullptr : s->transforms_.data();
+    w.n_materials = static_cast<uint32_t>(s->materials_.size());
+    w.materials = s->materials_.data();
+    w.n_textures = static_cast<uint32_t>(s->textures_.size());
+    w.textures = s->textures_.data();
+    w.perlin = s->perlin_.get();
+    w.n_bvh_nodes = static_cast<uint32_t>(s->bvh_nodes_.size());
+    w.bvh_nodes = s->bvh_nodes_.empty() ? nullptr : s->bvh_nodes_.data();
+    w.bvh_root = root;
+    w.has_sky = sky.has_value() ? 1u : 0u;
+    if (sky) w.sky[0] = sky->x, w.sky[1] = sky->y, w.sky[2] = sky->z;
+    if (all_spheres) {  // the sphere-only description (the specialised kernels' entry point)
+        s->spheres_.reserve(hitables.size());
+        s->sphere_material_.reserve(hitables.size());
+        for (const Hitable &h : s->hitables_) {
+            s->spheres_.push_back(pt_sphere{h.p[0], h.p[1], h.p[2], h.p[3]});
+            s->sphere_material_.push_back(h.material);
+        }
+        pt_scene_desc &d = s->desc_;
+        d.n_spheres = static_cast<uint32_t>(s->spheres_.size());
+        d.spheres = s->spheres_.data();
+        d.sphere_material = s->sphere_material_.data();
+        d.n_materials = w.n_materials, d.materials = w.materials;
+        d.n_textures = w.n_textures, d.textures = w.textures;
+        d.perlin = w.perlin;
+        d.n_bvh_nodes = w.n_bvh_nodes, d.bvh_nodes = w.bvh_nodes, d.bvh_root = root;
+        d.has_sky = w.has_sky;
+        memcpy(d.sky, w.sky, sizeof d.sky);
+    }
     if (device >= 0) {
-        const int rc = pt_scene_create(&d, device, &s->handle_);
-        if (rc != PT_OK) throw std::runtime_error(std::string("pt_scene_create: ") + pt_last_error());
+        const int rc = all_spheres ? pt_scene_create(&s->desc_, device, &s->handle_) : pt_scene_create_world(&w, device, &s->handle_);
+        if (rc != PT_OK) throw std::runtime_error(std::string(all_spheres ? "pt_scene_create: " : "pt_scene_create_world: ") + pt_last_error());
     }
     return s;
 }

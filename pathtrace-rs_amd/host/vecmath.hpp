@@ -31,6 +31,51 @@ inline Vec3 cross(Vec3 a, Vec3 b) { return {a.y * b.z - b.y * a.z, a.z * b.x - b
 inline Vec3 vmin(Vec3 a, Vec3 b) { return {a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z}; }
 inline Vec3 vmax(Vec3 a, Vec3 b) { return {a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z}; }
 
+inline Vec3 operator*(Vec3 a, Vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline Vec3 operator-(Vec3 a) { return {-a.x, -a.y, -a.z}; }
+
+// glam 0.20 Quat (only what presets.rs:383-390 uses)
+struct Quat {
+    float x, y, z, w;
+    // Quat::from_rotation_y: (s, c) = sin_cos(angle * 0.5); (0, s, 0, c)
+    static Quat from_rotation_y(float angle) { return {0.0f, std::sin(angle * 0.5f), 0.0f, std::cos(angle * 0.5f)}; }
+};
+// f32::to_radians
+inline float to_radians(float deg) { return deg * (3.14159274101257324f / 180.0f); }
+
+// glam 0.20 Affine3A: matrix3 columns + translation
+struct Affine3A {
+    Vec3 x_axis{1.f, 0.f, 0.f}, y_axis{0.f, 1.f, 0.f}, z_axis{0.f, 0.f, 1.f}, translation{0.f, 0.f, 0.f};
+    // Mat3A::from_quat
+    static Affine3A from_rotation_translation(Quat q, Vec3 t) {
+        const float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+        const float xx = q.x * x2, xy = q.x * y2, xz = q.x * z2, yy = q.y * y2, yz = q.y * z2, zz = q.z * z2;
+        const float wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+        Affine3A m;
+        m.x_axis = Vec3(1.0f - (yy + zz), xy + wz, xz - wy);
+        m.y_axis = Vec3(xy - wz, 1.0f - (xx + zz), yz + wx);
+        m.z_axis = Vec3(xz + wy, yz - wx, 1.0f - (xx + yy));
+        m.translation = t;
+        return m;
+    }
+    // ((x_axis * v.x) + (y_axis * v.y)) + (z_axis * v.z)
+    Vec3 transform_vector3(Vec3 v) const { return (x_axis * v.x + y_axis * v.y) + z_axis * v.z; }
+    Vec3 transform_point3(Vec3 p) const { return transform_vector3(p) + translation; }
+    // Mat3A::inverse (cross products over the determinant, transposed); translation = -(inverse * t)
+    Affine3A inverse() const {
+        const Vec3 tmp0 = cross(y_axis, z_axis), tmp1 = cross(z_axis, x_axis), tmp2 = cross(x_axis, y_axis);
+        const float inv_det = 1.0f / dot(z_axis, tmp2);
+        const Vec3 c0 = tmp0 * inv_det, c1 = tmp1 * inv_det, c2 = tmp2 * inv_det;
+        Affine3A r;
+        r.x_axis = Vec3(c0.x, c1.x, c2.x);
+        r.y_axis = Vec3(c0.y, c1.y, c2.y);
+        r.z_axis = Vec3(c0.z, c1.z, c2.z);
+        r.translation = Vec3(0.f, 0.f, 0.f);
+        r.translation = -r.transform_vector3(translation);
+        return r;
+    }
+};
+
 // rand_xoshiro 0.6 Xoshiro256Plus + rand 0.8 sampling (params.rs:21-27 seeds it with 0)
 class Xoshiro256Plus {
 public:

@@ -17,7 +17,8 @@ PT_ERR_HIP = 2
 PT_ERR_NO_DEVICE = 3
 PT_ERR_UNSUPPORTED = 4
 
-MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
+HIT_SPHERE, HIT_MOVING_SPHERE, HIT_RECT_XY, HIT_RECT_XZ, HIT_RECT_YZ, HIT_CUBOID = 0, 1, 2, 3, 4, 5
 TEX_CONSTANT, TEX_CHECKER, TEX_NOISE = 0, 1, 2
 
 
@@ -73,8 +74,28 @@ class PtSceneDesc(C.Structure):
                 ("has_sky", C.c_uint32), ("sky", C.c_float * 3)]
 
 
+class PtHitable(C.Structure):  # one HitableList entry of a general world (64 bytes)
+    _fields_ = [("kind", C.c_uint32), ("material", C.c_uint32), ("flip_normals", C.c_uint32),
+                ("transform", C.c_int32), ("medium_material", C.c_int32), ("density", C.c_float),
+                ("p", C.c_float * 10)]
+
+
+class PtAffine(C.Structure):  # Affine3A columns + translation, then the inverse
+    _fields_ = [("m", C.c_float * 12), ("inv", C.c_float * 12)]
+
+
+class PtWorldDesc(C.Structure):
+    _fields_ = [("n_hitables", C.c_uint32), ("hitables", C.POINTER(PtHitable)),
+                ("n_transforms", C.c_uint32), ("transforms", C.POINTER(PtAffine)),
+                ("n_materials", C.c_uint32), ("materials", C.POINTER(PtMaterial)),
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(PtTexture)),
+                ("perlin", C.POINTER(PtPerlin)),
+                ("n_bvh_nodes", C.c_uint32), ("bvh_nodes", C.POINTER(PtBvhNode)), ("bvh_root", C.c_int32),
+                ("has_sky", C.c_uint32), ("sky", C.c_float * 3)]
+
+
 EXPORTS = [
-    "pt_device_count", "pt_scene_create", "pt_scene_destroy", "pt_render", "pt_render_device",
+    "pt_device_count", "pt_scene_create", "pt_scene_create_world", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_render_shard_device", "pt_shard_rows", "pt_scene_set_seed_base", "pt_last_kernel_ms",
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters",
 ]
@@ -99,6 +120,7 @@ def lib():
         vp = C.c_void_p
         L.pt_device_count.argtypes = [C.POINTER(C.c_int)]
         L.pt_scene_create.argtypes = [C.POINTER(PtSceneDesc), C.c_int, C.POINTER(vp)]
+        L.pt_scene_create_world.argtypes = [C.POINTER(PtWorldDesc), C.c_int, C.POINTER(vp)]
         L.pt_scene_destroy.argtypes = [vp]
         L.pt_scene_destroy.restype = None
         L.pt_render.argtypes = [vp, C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, vp, C.POINTER(C.c_uint64)]
@@ -255,7 +277,7 @@ def shard_rows(height, shard_index, shard_count):
     return lib().pt_shard_rows(height, shard_index, shard_count)
 
 
-PROBE_POW5, PROBE_SIN, PROBE_COS, PROBE_RNG = 0, 1, 2, 3
+PROBE_POW5, PROBE_SIN, PROBE_COS, PROBE_RNG, PROBE_LN = 0, 1, 2, 3, 4
 
 
 def selftest_probe(probe, values, device=0):

@@ -39,6 +39,9 @@ def lib():
         L.pth_scene_free.restype = None
         L.pth_scene_desc.argtypes = [vp]
         L.pth_scene_desc.restype = C.POINTER(ptgpu.PtSceneDesc)
+        L.pth_scene_world_desc.argtypes = [vp]
+        L.pth_scene_world_desc.restype = C.POINTER(ptgpu.PtWorldDesc)
+        L.pth_scene_is_world.argtypes = [vp]
         L.pth_scene_camera.argtypes = [vp]
         L.pth_scene_camera.restype = C.POINTER(ptgpu.PtCamera)
         L.pth_scene_handle.argtypes = [vp]
@@ -88,6 +91,15 @@ class HostScene:
         return lib().pth_scene_desc(self._h).contents
 
     @property
+    def world_desc(self):
+        return lib().pth_scene_world_desc(self._h).contents
+
+    @property
+    def is_world(self):
+        """True when the world has non-sphere hitables (traced by the general kernel)."""
+        return bool(lib().pth_scene_is_world(self._h))
+
+    @property
     def camera(self):
         return lib().pth_scene_camera(self._h).contents
 
@@ -113,10 +125,17 @@ class HostScene:
 
     # numpy views of the flattened description (copies) -- for cross-checks
     def export(self):
-        d = self.desc
-        n = d.n_spheres
-        sph = np.ctypeslib.as_array(C.cast(d.spheres, C.POINTER(C.c_float)), shape=(n, 4)).copy()
-        mid = np.ctypeslib.as_array(d.sphere_material, shape=(n,)).copy()
+        d = self.world_desc
+        n = d.n_hitables
+        records = np.ctypeslib.as_array(C.cast(d.hitables, C.POINTER(C.c_uint32)), shape=(n, 16)).copy()
+        transforms = np.zeros((d.n_transforms, 24), np.float32)
+        if d.n_transforms:
+            transforms = np.ctypeslib.as_array(C.cast(d.transforms, C.POINTER(C.c_float)), shape=(d.n_transforms, 24)).copy()
+        sph = mid = None
+        if not self.is_world:
+            sd = self.desc
+            sph = np.ctypeslib.as_array(C.cast(sd.spheres, C.POINTER(C.c_float)), shape=(n, 4)).copy()
+            mid = np.ctypeslib.as_array(sd.sphere_material, shape=(n,)).copy()
         mats = np.zeros((d.n_materials, 6), np.float32)
         for i in range(d.n_materials):
             m = d.materials[i]
@@ -138,7 +157,7 @@ class HostScene:
             minmax = raw[:, :6].copy()
             lr = raw[:, 6:].copy().view(np.int32)
         cam = np.ctypeslib.as_array(C.cast(C.pointer(self.camera), C.POINTER(C.c_float)), shape=(24,)).copy()
-        return dict(spheres=sph, sphere_material=mid, materials=mats, textures=texs, perlin=perlin, bvh_minmax=minmax,
+        return dict(hitables=records, transforms=transforms, spheres=sph, sphere_material=mid, materials=mats, textures=texs, perlin=perlin, bvh_minmax=minmax,
                     bvh_children=lr, bvh_root=d.bvh_root, camera=cam,
                     sky=(np.array(list(d.sky), np.float32) if d.has_sky else None), build_draws=self.build_draws)
 

@@ -46,6 +46,12 @@ FRAMES = [
     ("c3_random_spheres_1200x800_64spp_crop", "random_spheres", 1200, 800, 64, 10, False, (568, 330, 64, 64)),  # 3
     ("c5_perlin_spheres_1920x1080_128spp_crop_bvh", "perlin_spheres", 1920, 1080, 128, 10, True, (940, 420, 32, 32)),
     ("two_perlin_spheres_160x90_8spp", "two_perlin_spheres", 160, 90, 8, 10, False, None),
+    # the presets with non-sphere Hitable arms
+    ("w_cornell_smoke_300x200_16spp_crop", "cornell_smoke", 300, 200, 16, 10, False, (110, 50, 64, 64)),
+    ("w_cornell_300x200_16spp_crop_bvh", "cornell", 300, 200, 16, 10, True, (110, 50, 64, 64)),
+    ("w_random_600x400_8spp_crop", "random", 600, 400, 8, 10, False, (270, 150, 64, 48)),
+    ("w_simple_light_160x90_8spp_crop", "simple_light", 160, 90, 8, 10, False, (60, 20, 48, 48)),
+    ("smallpt_160x120_8spp_crop", "smallpt", 160, 120, 8, 10, False, (48, 30, 64, 64)),
 ]
 
 

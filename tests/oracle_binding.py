@@ -47,12 +47,14 @@ def _bind(L):
     L.ora_scene_update_range.argtypes = [vp, u32, u32, u32, u32, u32, vp, u64, u64, C.c_int]
     L.ora_scene_update_pixels.restype = u64
     L.ora_scene_update_pixels.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp, u64, C.c_int]
-    for n in ("num_spheres", "num_materials", "num_textures", "num_bvh_nodes"):
+    for n in ("num_spheres", "num_materials", "num_textures", "num_bvh_nodes", "num_hitables", "num_transforms"):
         f = getattr(L, "ora_scene_" + n)
         f.restype, f.argtypes = u32, [vp]
     L.ora_scene_bvh_root.restype, L.ora_scene_bvh_root.argtypes = i32, [vp]
     L.ora_scene_has_perlin_texture.restype, L.ora_scene_has_perlin_texture.argtypes = C.c_int, [vp]
     L.ora_scene_build_draws.restype, L.ora_scene_build_draws.argtypes = u64, [vp]
+    L.ora_scene_is_sphere_world.restype, L.ora_scene_is_sphere_world.argtypes = C.c_int, [vp]
+    L.ora_scene_export_world.argtypes = [vp, vp, vp]
     L.ora_scene_export_spheres.argtypes = [vp, vp, vp]
     L.ora_scene_export_materials.argtypes = [vp, vp]
     L.ora_scene_export_textures.argtypes = [vp, vp]
@@ -67,6 +69,9 @@ def _bind(L):
     L.ora_xoshiro_gen_range_i32.restype, L.ora_xoshiro_gen_range_i32.argtypes = i32, [vp, i32, i32]
     L.ora_pixel_seed.restype, L.ora_pixel_seed.argtypes = u64, [u32, u32, u32]
     L.ora_sinf_cosf.argtypes = [f32, vp, vp]
+    L.ora_ln_array.argtypes = [vp, vp, u64]
+    L.ora_hitable_ray_hit.restype = C.c_int
+    L.ora_hitable_ray_hit.argtypes = [vp, u32, vp, vp, f32, f32, f32, vp, vp, vp]
     L.ora_sphere_ray_hit.restype, L.ora_sphere_ray_hit.argtypes = C.c_int, [vp, vp, vp, f32, f32, vp]
     L.ora_aabb_ray_hit.restype, L.ora_aabb_ray_hit.argtypes = C.c_int, [vp, vp, vp, vp, f32, f32]
     L.ora_schlick.restype, L.ora_schlick.argtypes = f32, [f32, f32]
@@ -133,10 +138,17 @@ class OracleScene:
     # flat export ---------------------------------------------------------
     def export(self):
         L, h = self.L, self.h
-        n = L.ora_scene_num_spheres(h)
-        xyzr = np.zeros((n, 4), np.float32)
-        mid = np.zeros(n, np.uint32)
-        L.ora_scene_export_spheres(h, xyzr.ctypes.data, mid.ctypes.data)
+        n = L.ora_scene_num_hitables(h)
+        xyzr = mid = None
+        if L.ora_scene_is_sphere_world(h):
+            xyzr = np.zeros((n, 4), np.float32)
+            mid = np.zeros(n, np.uint32)
+            L.ora_scene_export_spheres(h, xyzr.ctypes.data, mid.ctypes.data)
+        records = np.zeros((n, 16), np.uint32)
+        ntr = L.ora_scene_num_transforms(h)
+        transforms = np.zeros((max(ntr, 1), 24), np.float32)
+        L.ora_scene_export_world(h, records.ctypes.data, transforms.ctypes.data)
+        transforms = transforms[:ntr]
         nm = L.ora_scene_num_materials(h)
         mats = np.zeros((nm, 6), np.float32)
         L.ora_scene_export_materials(h, mats.ctypes.data)
@@ -156,7 +168,7 @@ class OracleScene:
         L.ora_scene_export_camera(h, cam.ctypes.data)
         sky = np.zeros(3, np.float32)
         has_sky = L.ora_scene_export_sky(h, sky.ctypes.data)
-        return dict(spheres=xyzr, sphere_material=mid, materials=mats, textures=texs, perlin=(rv, px, py, pz),
+        return dict(hitables=records, transforms=transforms, spheres=xyzr, sphere_material=mid, materials=mats, textures=texs, perlin=(rv, px, py, pz),
                     has_perlin=bool(L.ora_scene_has_perlin_texture(h)), bvh_minmax=minmax[:nn], bvh_children=lr[:nn],
                     bvh_root=L.ora_scene_bvh_root(h), camera=cam, sky=(sky if has_sky else None),
                     build_draws=L.ora_scene_build_draws(h))

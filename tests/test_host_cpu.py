@@ -16,7 +16,9 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PRESETS = ["small", "random_spheres", "two_perlin_spheres", "aras", "perlin_spheres"]
+SPHERE_PRESETS = ["small", "random_spheres", "two_perlin_spheres", "aras", "perlin_spheres", "smallpt"]
+WORLD_PRESETS = ["random", "simple_light", "cornell", "cornell_smoke"]   # non-sphere Hitable arms: general kernel
+PRESETS = SPHERE_PRESETS + WORLD_PRESETS
 
 
 @pytest.fixture(scope="session")
@@ -50,6 +52,7 @@ def test_struct_layouts_match_the_header(ptgpu):
     assert C.sizeof(ptgpu.PtSphere) == 16 and C.sizeof(ptgpu.PtMaterial) == 24
     assert C.sizeof(ptgpu.PtTexture) == 28 and C.sizeof(ptgpu.PtBvhNode) == 32
     assert C.sizeof(ptgpu.PtPerlin) == 256 * 12 + 3 * 1024
+    assert C.sizeof(ptgpu.PtHitable) == 64 and C.sizeof(ptgpu.PtAffine) == 96
 
 
 def _tiny_desc(ptgpu, **over):
@@ -89,6 +92,60 @@ def test_scene_create_validates_before_touching_the_device(ptgpu):
     assert rc in (ptgpu.PT_OK, ptgpu.PT_ERR_NO_DEVICE), msg
 
 
+def _world_rc(ptgpu, hitables, materials=None, transforms=(), nodes=None, root=-1):
+    hs = (ptgpu.PtHitable * len(hitables))()
+    for i, kw in enumerate(hitables):
+        h = hs[i]
+        h.kind, h.material, h.transform, h.medium_material = kw.get("kind", 0), kw.get("material", 0), kw.get("transform", -1), kw.get("medium", -1)
+        for j, v in enumerate(kw.get("p", [0, 0, -1, 0.5])):
+            h.p[j] = v
+    materials = materials or [(ptgpu.MAT_LAMBERTIAN, 0)]
+    ms = (ptgpu.PtMaterial * len(materials))()
+    for i, (kind, tex) in enumerate(materials):
+        ms[i].kind, ms[i].texture = kind, tex
+    ts = (ptgpu.PtTexture * 1)()
+    ts[0].kind, ts[0].odd, ts[0].even = ptgpu.TEX_CONSTANT, -1, -1
+    xs = (ptgpu.PtAffine * max(len(transforms), 1))()
+    d = ptgpu.PtWorldDesc()
+    d.n_hitables, d.hitables = len(hitables), hs
+    d.n_transforms, d.transforms = len(transforms), xs
+    d.n_materials, d.materials, d.n_textures, d.textures = len(materials), ms, 1, ts
+    d.bvh_root = root
+    if nodes is not None:
+        ns = (ptgpu.PtBvhNode * len(nodes))()
+        for i, (l, r) in enumerate(nodes):
+            ns[i].lhs, ns[i].rhs = l, r
+        d.n_bvh_nodes, d.bvh_nodes = len(nodes), ns
+    h = C.c_void_p()
+    rc = ptgpu.lib().pt_scene_create_world(C.byref(d), 0, C.byref(h))
+    if rc == ptgpu.PT_OK:
+        ptgpu.lib().pt_scene_destroy(h)
+    return rc, ptgpu.lib().pt_last_error().decode()
+
+
+def test_world_create_validates_before_touching_the_device(ptgpu):
+    h = C.c_void_p()
+    assert ptgpu.lib().pt_scene_create_world(None, 0, C.byref(h)) == ptgpu.PT_ERR_INVALID_ARG
+    iso = [(ptgpu.MAT_LAMBERTIAN, 0), (ptgpu.MAT_ISOTROPIC, 0)]
+    bad = [
+        dict(hitables=[dict(kind=9)]),                                                   # unknown Hitable arm
+        dict(hitables=[dict(kind=ptgpu.HIT_RECT_XY, material=4)]),                       # material out of range
+        dict(hitables=[dict(kind=ptgpu.HIT_CUBOID, transform=0)]),                       # Instance without a transform table
+        dict(hitables=[dict(kind=ptgpu.HIT_CUBOID, medium=0)]),                          # phase function is not Isotropic
+        dict(hitables=[dict(kind=ptgpu.HIT_SPHERE, material=1)], materials=iso),         # Isotropic on a surface
+        dict(hitables=[dict(kind=ptgpu.HIT_RECT_XZ)], nodes=[(0, -1)], root=0),          # BVH cycle
+        dict(hitables=[dict(kind=ptgpu.HIT_RECT_XZ)], nodes=[(-3, -1)], root=0),         # BVH leaf out of range
+    ]
+    for kw in bad:
+        rc, msg = _world_rc(ptgpu, **kw)
+        assert rc == ptgpu.PT_ERR_INVALID_ARG and msg, (kw, msg)
+    ok = [dict(hitables=[dict(kind=ptgpu.HIT_CUBOID, p=[0, 0, 0, 1, 1, 1], transform=0, medium=1)], materials=iso, transforms=[0]),
+          dict(hitables=[dict(kind=ptgpu.HIT_SPHERE)])]                                   # all spheres: forwarded to pt_scene_create
+    for kw in ok:
+        rc, msg = _world_rc(ptgpu, **kw)
+        assert rc in (ptgpu.PT_OK, ptgpu.PT_ERR_NO_DEVICE), msg
+
+
 def test_null_handles_are_errors_not_crashes(ptgpu):
     L = ptgpu.lib()
     p, cam, rc = ptgpu.PtParams(8, 8, 1, 1, 0, 0), ptgpu.PtCamera(), C.c_uint64()
@@ -118,8 +175,12 @@ def test_host_presets_match_the_oracle_build(pthost, oracle, preset, bvh):
     W, H = (1200, 800) if preset != "perlin_spheres" else (1920, 1080)
     he = pthost.HostScene(preset, W, H, use_bvh=bvh).export()
     oe = oracle.OracleScene(preset, W, H, use_bvh=bvh).export()
-    for k in ("spheres", "sphere_material", "materials", "textures", "bvh_minmax", "bvh_children", "camera"):
-        assert np.array_equal(he[k], oe[k]), k
+    for k in ("hitables", "transforms", "materials", "textures", "bvh_minmax", "bvh_children", "camera"):
+        assert np.asarray(he[k]).shape == np.asarray(oe[k]).shape and np.asarray(he[k]).tobytes() == np.asarray(oe[k]).tobytes(), k
+    if preset in SPHERE_PRESETS:
+        assert np.array_equal(he["spheres"], oe["spheres"]) and np.array_equal(he["sphere_material"], oe["sphere_material"])
+    else:
+        assert he["spheres"] is None and oe["spheres"] is None
     assert he["bvh_root"] == oe["bvh_root"] and he["build_draws"] == oe["build_draws"]
     assert (he["sky"] is None) == (oe["sky"] is None)
     if he["perlin"] is not None:
@@ -130,7 +191,7 @@ def test_host_presets_match_the_oracle_build(pthost, oracle, preset, bvh):
 
 def test_unknown_preset_is_reported(pthost):
     with pytest.raises(KeyError):
-        pthost.HostScene("cornell", 64, 64)
+        pthost.HostScene("earth", 64, 64)   # needs media/earthmap.jpg, absent upstream
 
 
 def test_bvh_shape(pthost):

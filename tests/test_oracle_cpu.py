@@ -97,7 +97,7 @@ def test_random_spheres_build_ledger(oracle):
 
 def test_unknown_preset_returns_none(oracle):
     with pytest.raises(KeyError):
-        oracle.OracleScene("cornell", 64, 64)
+        oracle.OracleScene("earth", 64, 64)
 
 
 def test_sinf_cosf_accuracy_and_quadrants(oracle):
@@ -291,3 +291,104 @@ def test_oracle_reproduces_golden(oracle, path):
     _, rays = sc.update(S, int(g["depth"]), 0, buffer=buf, pixels=g["pixels"])
     assert rays == int(g["ray_count"])
     assert np.array_equal(buf.reshape(-1, 3)[g["pixels"]], g["rgb"])
+
+
+# ---- general worlds: known answers for the other Hitable arms ------------------
+def _hitable_hit(oracle, sc, index, o, d, time=0.0, tmin=0.001, tmax=3.4028234663852886e38, seed=7):
+    import ctypes
+    L = oracle.lib()
+    st = _state([0, 0, 0, 0])
+    L.ora_xoshiro_seed_from_u64(seed, st)
+    before = list(st)
+    out, mat = np.zeros(7, np.float32), ctypes.c_uint32(0)
+    o_, d_ = np.asarray(o, np.float32), np.asarray(d, np.float32)
+    ok = L.ora_hitable_ray_hit(sc.h, index, o_.ctypes.data, d_.ctypes.data, time, tmin, tmax, st, out.ctypes.data,
+                               ctypes.byref(mat))
+    return ok, out, mat.value, list(st) != before
+
+
+def test_rect_known_answers(oracle):
+    sc = oracle.OracleScene("simple_light", 64, 64)       # entry 3: Rect::XY x 3..5, y 1..3, k = -2 (presets.rs:363)
+    ok, h, _, _ = _hitable_hit(oracle, sc, 3, [4, 2, 0], [0, 0, -1])
+    assert ok and h[6] == 2.0 and h[:3].tolist() == [4, 2, -2] and h[3:6].tolist() == [0, 0, 1]   # FLIP_SIGN[0]
+    assert not _hitable_hit(oracle, sc, 3, [6, 2, 0], [0, 0, -1])[0]        # outside x1
+    assert _hitable_hit(oracle, sc, 3, [5, 3, 0], [0, 0, -1])[0]            # edges are inclusive (rect.rs:90 uses < and >)
+    assert not _hitable_hit(oracle, sc, 3, [4, 2, 0], [0, 0, 1])[0]         # behind: t = -2 < t_min
+    assert not _hitable_hit(oracle, sc, 3, [4, 2, 0], [0, 0, -1], tmax=1.5)[0]
+    assert _hitable_hit(oracle, sc, 3, [4, 2, 0], [0, 0, -1], tmax=2.0)[0]  # t == t_max is accepted (rect.rs:85: t > t_max rejects)
+    # ray parallel to the plane and in it: t = 0 * inf = NaN passes every comparison (rect.rs:85-92 as written)
+    ok, h, _, _ = _hitable_hit(oracle, sc, 3, [4, 2, -2], [1, 0, 0])
+    assert ok and np.isnan(h[6])
+
+
+def test_moving_sphere_follows_ray_time(oracle):
+    sc = oracle.OracleScene("random", 64, 64)
+    ex = sc.export()
+    k = int(np.argmax(ex["hitables"][:, 0] == 1))          # first MovingSphere
+    p = ex["hitables"][k, 6:].view(np.float32)
+    c0, delta, r = p[0:3], p[3:6], p[6]
+    assert p[7] == 0.0 and p[8] == 1.0 and delta[0] == 0 and delta[2] == 0 and 0 <= delta[1] < 0.5   # presets.rs:150
+    for time in (0.0, 0.25, 1.0):
+        centre = c0 + np.float32(time) * delta             # moving_sphere.rs:29-31
+        ok, h, _, _ = _hitable_hit(oracle, sc, k, centre + np.float32([0, 0, 5]), [0, 0, -1], time=time)
+        assert ok and abs(h[6] - (5 - r)) < 1e-5 and abs(h[5] - 1.0) < 1e-5
+
+
+def test_instance_cuboid_and_bbox_quirk(oracle):
+    sc = oracle.OracleScene("cornell", 64, 64, use_bvh=True)
+    ex = sc.export()
+    rec = ex["hitables"]
+    assert rec[:, 0].tolist() == [4, 4, 3, 3, 3, 2, 5, 5] and rec[6:, 3].view(np.int32).tolist() == [0, 1]
+    m, inv = ex["transforms"][0, :12].reshape(4, 3), ex["transforms"][0, 12:].reshape(4, 3)
+    # rotation about y by -18 degrees + translation (presets.rs:383-386); inverse really inverts
+    ang = np.deg2rad(-18.0)
+    np.testing.assert_allclose(m[0], [np.cos(ang), 0, -np.sin(ang)], atol=1e-6)
+    np.testing.assert_allclose(m[3], [130, 0, 65], atol=0)
+    pt = np.float32([10, 20, 30])
+    fwd = m[0] * pt[0] + m[1] * pt[1] + m[2] * pt[2] + m[3]
+    back = inv[0] * fwd[0] + inv[1] * fwd[1] + inv[2] * fwd[2] + inv[3]
+    np.testing.assert_allclose(back, pt, atol=2e-4)
+    # straight down onto the top face of box1 (y = 165): normal stays +y under a y rotation
+    ok, h, _, _ = _hitable_hit(oracle, sc, 6, [200, 400, 150], [0, -1, 0])
+    assert ok and abs(h[6] - 235.0) < 1e-3 and abs(h[4] - 1.0) < 1e-6
+    # AABB::transform ignores the box (aabb.rs:75-100): every Instance leaf is a single point in the BVH
+    t = m[3]
+    point = t + m[0] * t + m[1] * t + m[2] * t
+    leaf_parent = [i for i, (l, r) in enumerate(ex["bvh_children"]) if ~6 in (l, r)][0]
+    mn, mx = ex["bvh_minmax"][leaf_parent, :3], ex["bvh_minmax"][leaf_parent, 3:]
+    assert np.all(mn <= point + 1e-3) and np.all(mx >= point - 1e-3)
+    # rect.rs:225-226: the YZ rect's box has min.x == max.x == k - 0.0001
+    assert rec[0, 0] == 4
+    yz_parent = [i for i, (l, r) in enumerate(ex["bvh_children"]) if l == ~0 and r == ~1 or l == ~1 and r == ~0]
+    assert yz_parent == [] or ex["bvh_minmax"][yz_parent[0], 0] == np.float32(0.0) - np.float32(0.0001)
+
+
+def test_constant_medium_draws_only_when_the_boundary_is_crossed(oracle):
+    sc = oracle.OracleScene("cornell_smoke", 64, 64)
+    ex = sc.export()
+    assert ex["hitables"][6, 4] == len(ex["materials"]) - 2 and ex["materials"][-2, 0] == 4   # Isotropic phase functions
+    assert ex["hitables"][6, 5:6].view(np.float32)[0] == np.float32(0.01)
+    # a ray that misses box1 entirely consumes no random number (constant_medium.rs:39-43 precede the draw)
+    ok, _, _, drew = _hitable_hit(oracle, sc, 6, [500, 500, -800], [0, 0, 1])
+    assert not ok and not drew
+    # through the box: exactly one draw; hit iff -(1/density) ln(u) < path length inside (constant_medium.rs:58-62)
+    hits = 0
+    for seed in range(200):
+        ok, h, mat, drew = _hitable_hit(oracle, sc, 6, [200, 80, -800], [0, 0, 1], seed=seed)
+        assert drew
+        if ok:
+            hits += 1
+            assert mat == len(ex["materials"]) - 2 and h[3:6].tolist() == [1, 0, 0]        # Vec3::X, arbitrary
+    frac = 1 - np.exp(-0.01 * 173.0)                         # ~173 units through the rotated 165-cube
+    assert abs(hits / 200 - frac) < 0.12
+    # t_max clamps the far end (constant_medium.rs:47-52): nothing can scatter beyond it
+    ok, _, _, drew = _hitable_hit(oracle, sc, 6, [200, 80, -800], [0, 0, 1], tmax=800.0)
+    assert not ok and not drew
+
+
+def test_ln_is_the_platform_logf(oracle):
+    L = oracle.lib()
+    x = (np.arange(1, 1 << 16, dtype=np.float32) * np.float32(2.0 ** -16))
+    out = np.zeros_like(x)
+    L.ora_ln_array(x.ctypes.data, out.ctypes.data, len(x))
+    np.testing.assert_allclose(out, np.log(x.astype(np.float64)), rtol=2e-7, atol=0)
