@@ -63,6 +63,7 @@ struct KArgs {
     const float4 *shade;         // [4*n_spheres] per-sphere shading record (DShadeRec): ONE 64-byte fetch per hit
     const float4 *spheres_r2;    // cx, cy, cz, radius*radius (sphere.rs:36), scan layout, padded to n_spheres_pad
     const uint32_t *sphere_mat;  // material index per sphere
+    const float4 *motion;        // MOVING kernels: [2*n_spheres] (dx, dy, dz, inv_time_delta), (time_start, is_moving, -, -)
     const DMat *mats;
     const DTex *texs;
     const float4 *perlin_vec;    // 256 gradients (xyz, pad)
@@ -389,6 +390,22 @@ __device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d,
 // (rho & 31) + 32, i.e. of the owner lane and of lane ^ 32. Entries are fragment slots (tile*32 + row).
 constexpr int kSubCap = kQueueCap / 2;
 
+// MovingSphere::centre (moving_sphere.rs:29-31): centre_start + ((time - time_start) * inv_time_delta) * centre_delta.
+// `c` carries the sphere as stored (centre_start in xyz; w untouched). Plain spheres are returned as they are.
+template <bool MOVING>
+__device__ __forceinline__ float4 sphere_at(const KArgs &A, int k, float4 c, float time) {
+    if (MOVING) {
+        const float4 m0 = A.motion[2 * k], m1 = A.motion[2 * k + 1];
+        if (m1.y != 0.0f) {
+            const float s = (time - m1.x) * m0.w;
+            c.x = c.x + s * m0.x;
+            c.y = c.y + s * m0.y;
+            c.z = c.z + s * m0.z;
+        }
+    }
+    return c;
+}
+
 // exact reference test of one sphere, order independent: candidate t as sphere.rs:38-64 would
 // return it for t_max = f32::MAX, winner = lexicographic (t, index) minimum == the sequential
 // closest_so_far scan of hitable_list.rs:40-56 (DESIGN.md "order-independent closest hit")
@@ -408,10 +425,10 @@ __device__ __forceinline__ void exact_candidate(const float4 c, int k, f3 o, f3 
     }
 }
 
-template <bool VERIFY>
+template <bool VERIFY, bool MOVING>
 __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *sph, const uint4 *s_afrag,
                                                    const uint16_t *s_tile_sphere, uint16_t *queue,
-                                                   f3 o, f3 d, float a, bool active, float &t_out) {
+                                                   f3 o, f3 d, float a, bool active, float time, float &t_out) {
     const int tid = threadIdx.x, lane = tid & 63, wave_base = tid & ~63;
     const RayFeat rf = make_ray_features(A, o, d, a, active, lane);
     const int row_off = 4 * (lane >> 5);
@@ -465,7 +482,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     const uint32_t cnt = cnt_own + cnt_par;
     for (uint32_t j = 0; j < A.n_large; ++j) {  // wave-uniform: spheres outside the prefilter's range
         const int k = (int)A.large[j];
-        if (active) exact_candidate(sph[k], k, o, d, a, best, idx);
+        if (active) exact_candidate(sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx);
     }
     const bool overflow = cnt_own > (uint32_t)kSubCap || cnt_par > (uint32_t)kSubCap;
     if (__any(overflow || (VERIFY && active))) {
@@ -474,7 +491,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
             float vbest = kMaxT;
             int vidx = -1;
             for (int k = 0; k < (int)A.n_spheres; ++k) {
-                const float4 c = sph[k];
+                const float4 c = sphere_at<MOVING>(A, k, sph[k], time);
                 exact_candidate(c, k, o, d, a, vbest, vidx);
                 if (VERIFY && active) {
                     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
@@ -512,7 +529,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
             if (j < cnt) {
                 const uint32_t slot = (j < cnt_own) ? q_own[j * kBlock] : q_par[(j - cnt_own) * kBlock];
                 const int k = s_tile_sphere[slot];
-                exact_candidate(sph[k], k, o, d, a, best, idx);
+                exact_candidate(sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx);
             }
         }
     }
@@ -625,7 +642,8 @@ struct BvhTrav {
 };
 constexpr int kReadyMin = 56;  // shade as soon as this many lanes of the wave have a finished traversal
 
-__device__ __forceinline__ void bvh_start(const KArgs &A, uint32_t *s_stack, f3 o, f3 d, float a, BvhTrav &st) {
+template <bool MOVING>
+__device__ __forceinline__ void bvh_start(const KArgs &A, uint32_t *s_stack, f3 o, f3 d, float a, float time, BvhTrav &st) {
     const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // ray.rs:14
     st.sp = 0;
     st.best = kMaxT;
@@ -634,14 +652,14 @@ __device__ __forceinline__ void bvh_start(const KArgs &A, uint32_t *s_stack, f3 
     st.active = true;
     for (uint32_t j = 0; j < A.n_bvh_large; ++j) {
         const int k = (int)A.bvh_large[j];
-        bvh_leaf(A, k, A.spheres[k], o, d, rcp, a, st.best, st.idx, st.rank);
+        bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, rcp, a, st.best, st.idx, st.rank);
     }
     if (A.bvh_root >= 0) s_stack[(st.sp++) * kBlock + threadIdx.x] = (uint32_t)A.bvh_root;
 }
 
-template <bool NODES_LDS>
+template <bool NODES_LDS, bool MOVING>
 __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const DWideNode *nodes, f3 o, f3 d, float a,
-                                        bool have, BvhTrav &st) {
+                                        float time, bool have, BvhTrav &st) {
     const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const int tid = threadIdx.x;
     for (;;) {
@@ -653,8 +671,8 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
                 const DWideNode n = nodes[ref];
                 // leaves first: they can only shrink `best` before the inner children are considered
                 // a leaf child's box slot holds the sphere itself (centre, radius): no second fetch
-                if (n.lhs < 0) bvh_leaf(A, ~n.lhs, make_float4(n.lmin[0], n.lmin[1], n.lmin[2], n.lmax[0]), o, d, rcp, a, st.best, st.idx, st.rank);
-                if (n.rhs < 0) bvh_leaf(A, ~n.rhs, make_float4(n.rmin[0], n.rmin[1], n.rmin[2], n.rmax[0]), o, d, rcp, a, st.best, st.idx, st.rank);
+                if (n.lhs < 0) bvh_leaf(A, ~n.lhs, sphere_at<MOVING>(A, ~n.lhs, make_float4(n.lmin[0], n.lmin[1], n.lmin[2], n.lmax[0]), time), o, d, rcp, a, st.best, st.idx, st.rank);
+                if (n.rhs < 0) bvh_leaf(A, ~n.rhs, sphere_at<MOVING>(A, ~n.rhs, make_float4(n.rmin[0], n.rmin[1], n.rmin[2], n.rmax[0]), time), o, d, rcp, a, st.best, st.idx, st.rank);
                 const float limit = (st.idx >= 0) ? (st.best * kCullRel + kCullAbs) : kMaxT;
                 float tl = 0.f, tr = 0.f;
                 bool hl = false, hr = false;
@@ -679,7 +697,10 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
 // SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
 // (staged once per workgroup); otherwise from HBM/L2 through wave-uniform loads.
 // PILOT: the 1-spp cost-estimation pass (own symbol so profiles keep it apart from the frame kernel)
-template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT>
+// MOVING: the world also holds MovingSphere entries (moving_sphere.rs): rays keep their time (camera.rs:59) and
+// every exact sphere test / normal uses the centre at that time; prefilter fragments and internal-tree boxes
+// were built over the motion's whole sweep.
+template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false>
 __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
@@ -732,6 +753,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
     uint32_t px = 0, py = 0, boff = 0, sample = 0, depth = 0, nrays = 0;
     Rng rng{0, 0, 0, 0};
     f3 col = mk3(0.f, 0.f, 0.f), o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
+    float rtime = 0.f;  // ray.time (only MOVING kernels read it)
 
     for (;;) {
         // ---- refill: one wave-aggregated atomic for all lanes that need a pixel
@@ -782,7 +804,8 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             random_in_unit_disk(rng, dx, dy);
             const float rdx = A.cam.lens_radius * dx, rdy = A.cam.lens_radius * dy;
             const f3 offset = add3(scale3(A.cam.u, rdx), scale3(A.cam.v, rdy));
-            (void)rng_f32(rng);  // camera.rs:59 time draw (spheres ignore ray.time)
+            const float tdraw = rng_f32(rng);  // camera.rs:59 time draw (plain spheres ignore ray.time)
+            if (MOVING) rtime = A.cam.time0 + tdraw * (A.cam.time1 - A.cam.time0);
             const f3 dir = sub3(sub3(add3(add3(A.cam.lower_left_corner, scale3(A.cam.horizontal, u)),
                                           scale3(A.cam.vertical, v)),
                                      A.cam.origin),
@@ -802,18 +825,18 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
         int idx;
         if (BVH) {
             if (have && trav_new) {
-                bvh_start(A, s_bvh, o, d, dot3(d, d), trav);
+                bvh_start<MOVING>(A, s_bvh, o, d, dot3(d, d), rtime, trav);
                 trav_new = false;
             }
             if (A.nodes_in_lds)
-                bvh_run<true>(A, s_bvh, s_nodes, ro, rd, a, have, trav);
+                bvh_run<true, MOVING>(A, s_bvh, s_nodes, ro, rd, a, rtime, have, trav);
             else
-                bvh_run<false>(A, s_bvh, A.wnodes, ro, rd, a, have, trav);
+                bvh_run<false, MOVING>(A, s_bvh, A.wnodes, ro, rd, a, rtime, have, trav);
             idx = trav.idx;
             t_hit = trav.best;
         } else if (MFMA)
-            idx = intersect_list_mfma<VERIFY>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere,
-                                      s_queue, ro, rd, a, have, t_hit);
+            idx = intersect_list_mfma<VERIFY, MOVING>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere,
+                                                      s_queue, ro, rd, a, have, rtime, t_hit);
         else
             idx = intersect_list(SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, (int)A.n_spheres_pad, s_queue + tid, ro, rd,
                                  a, t_hit);
@@ -834,8 +857,8 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                     V = mk3(w1 + (t * 0.5f) * 0.3f, w1 + (t * 0.7f) * 0.3f, w1 + (t * 1.0f) * 0.3f);
                 }
             } else {
-                const float4 sp = A.shade[4 * idx], q1 = A.shade[4 * idx + 1], qa = A.shade[4 * idx + 2],
-                             qb = A.shade[4 * idx + 3];
+                const float4 sp = sphere_at<MOVING>(A, idx, A.shade[4 * idx], rtime), q1 = A.shade[4 * idx + 1],
+                             qa = A.shade[4 * idx + 2], qb = A.shade[4 * idx + 3];
                 const f3 centre = mk3(sp.x, sp.y, sp.z);
                 const f3 point = add3(o, scale3(d, t_hit));            // ray.rs:24-26
                 const f3 normal = divs3(sub3(point, centre), sp.w);    // sphere.rs:42

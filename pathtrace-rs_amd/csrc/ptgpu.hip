@@ -87,6 +87,12 @@ struct pt_scene {
     uint64_t seed_base = 0x243f6a8885a308d3ull;
     // tuning
     uint32_t blocks_per_cu = 0, variant = 0;
+    // worlds of Sphere + MovingSphere entries run on the sphere kernels' MOVING instantiations while the camera's
+    // shutter interval stays inside [time_lo, time_hi] (the sweep the prefilter / tree were built for); the
+    // general-world data below is the fallback
+    bool has_motion = false;
+    float4 *d_motion = nullptr;
+    float time_lo = 0.f, time_hi = 0.f;
     // general world (pt_scene_create_world with non-sphere hitables): traced by pt_world_kernel
     bool is_world = false;
     uint32_t n_hitables = 0;
@@ -193,6 +199,32 @@ int upload(T **dst, const void *src, size_t count) {
 
 namespace {
 
+// Motion of a MovingSphere entry (moving_sphere.rs:8-14) next to the pt_sphere holding centre_start / radius.
+struct MotionIn {
+    float delta[3];
+    float time_start, inv_time_delta;
+    uint32_t moving;
+};
+
+// Conservative bound of sphere i over every ray time in [t_lo, t_hi]: centre of the swept segment and the
+// half-length to add to |radius| (zero for plain spheres).
+struct Sweep {
+    double c[3];
+    double half;
+};
+Sweep sweep_of(const pt_sphere &p, const MotionIn *m, double t_lo, double t_hi) {
+    Sweep w{{p.cx, p.cy, p.cz}, 0.0};
+    if (!m || !m->moving) return w;
+    double s0 = (t_lo - (double)m->time_start) * (double)m->inv_time_delta, s1 = (t_hi - (double)m->time_start) * (double)m->inv_time_delta;
+    if (s0 > s1) std::swap(s0, s1);
+    const double padp = 1e-4 * (1.0 + std::fabs(s0) + std::fabs(s1));  // f32 rounding of time and of (time - t0) * inv
+    s0 -= padp, s1 += padp;
+    const double mid = 0.5 * (s0 + s1), len = std::sqrt((double)m->delta[0] * m->delta[0] + (double)m->delta[1] * m->delta[1] + (double)m->delta[2] * m->delta[2]);
+    for (int k = 0; k < 3; ++k) w.c[k] += mid * (double)m->delta[k];
+    w.half = 0.5 * (s1 - s0) * len * (1.0 + 1e-6) + 1e-6 * (std::fabs(w.c[0]) + std::fabs(w.c[1]) + std::fabs(w.c[2]));
+    return w;
+}
+
 // ---- MFMA prefilter preparation (DESIGN.md "MFMA prefilter") ------------------------------------
 // Spheres whose centre/radius stay within the f16 feature range relative to the set's centroid are
 // packed 32 per tile into A fragments of v_mfma_f32_32x32x16_f16; the rest ("large", e.g. the
@@ -208,6 +240,7 @@ struct MfmaPrep {
     std::vector<uint32_t> large;
     float c0[3] = {0, 0, 0};
     double rs = 0.0;
+    double sweep_ratio = 0.0;  // max over prefiltered spheres of (swept half-length / |radius|)
     uint32_t n_tiles = 0;
 };
 
@@ -217,16 +250,18 @@ uint16_t f16_bits(_Float16 h) {
     return u;
 }
 
-bool prepare_mfma(const pt_scene_desc *desc, MfmaPrep &out) {
+bool prepare_mfma(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi, MfmaPrep &out) {
     const uint32_t n = desc->n_spheres;
     if (n > 0xfff0u) return false;
     // centroid of the moderate-radius spheres, rounded to f32 (c0 must be exactly what the device subtracts)
     double cx = 0, cy = 0, cz = 0;
     uint32_t m = 0;
+    std::vector<Sweep> sw(n);
+    for (uint32_t i = 0; i < n; ++i) sw[i] = sweep_of(desc->spheres[i], motion ? &motion[i] : nullptr, t_lo, t_hi);
     for (uint32_t i = 0; i < n; ++i) {
         const pt_sphere &p = desc->spheres[i];
-        if (std::fabs((double)p.radius) <= kRadiusMax && std::isfinite(p.cx + p.cy + p.cz + p.radius)) {
-            cx += p.cx, cy += p.cy, cz += p.cz, ++m;
+        if (std::fabs((double)p.radius) + sw[i].half <= kRadiusMax && std::isfinite(sw[i].c[0] + sw[i].c[1] + sw[i].c[2] + p.radius + sw[i].half)) {
+            cx += sw[i].c[0], cy += sw[i].c[1], cz += sw[i].c[2], ++m;
         }
     }
     if (m == 0) return false;
@@ -234,11 +269,13 @@ bool prepare_mfma(const pt_scene_desc *desc, MfmaPrep &out) {
     std::vector<uint32_t> small;
     for (uint32_t i = 0; i < n; ++i) {
         const pt_sphere &p = desc->spheres[i];
-        const double dx = (double)p.cx - out.c0[0], dy = (double)p.cy - out.c0[1], dz = (double)p.cz - out.c0[2];
-        const double reach = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs((double)p.radius);
-        if (std::isfinite(reach) && std::fabs((double)p.radius) <= kRadiusMax && reach <= kFeatRange) {
+        const double dx = sw[i].c[0] - out.c0[0], dy = sw[i].c[1] - out.c0[1], dz = sw[i].c[2] - out.c0[2];
+        const double rad = std::fabs((double)p.radius) + sw[i].half;
+        const double reach = std::sqrt(dx * dx + dy * dy + dz * dz) + rad;
+        if (std::isfinite(reach) && rad <= kRadiusMax && reach <= kFeatRange && (sw[i].half == 0.0 || std::fabs((double)p.radius) > 0.0)) {
             small.push_back(i);
             if (reach > out.rs) out.rs = reach;
+            if (sw[i].half > 0.0) out.sweep_ratio = std::max(out.sweep_ratio, sw[i].half / std::fabs((double)p.radius));
         } else {
             out.large.push_back(i);
         }
@@ -254,8 +291,13 @@ bool prepare_mfma(const pt_scene_desc *desc, MfmaPrep &out) {
             if (j < small.size()) {
                 const pt_sphere &p = desc->spheres[small[j]];
                 out.tile_sphere[j] = (uint16_t)small[j];
-                const double x = (double)p.cx - out.c0[0], y = (double)p.cy - out.c0[1], z = (double)p.cz - out.c0[2];
-                const volatile float r2f = p.radius * p.radius;  // sphere.rs:36 (the reference squares in f32)
+                const Sweep &w = sw[small[j]];
+                const double x = w.c[0] - out.c0[0], y = w.c[1] - out.c0[1], z = w.c[2] - out.c0[2];
+                const volatile float r2s = p.radius * p.radius;  // sphere.rs:36 (the reference squares in f32)
+                // a moving sphere enters the prefilter as the sphere bounding its sweep: a line that meets the
+                // sphere at any covered time passes within |r| + half of the sweep's midpoint
+                const double rb = std::fabs((double)p.radius) + w.half;
+                const double r2f = w.half > 0.0 ? rb * rb : (double)r2s;
                 S[0] = x * x, S[1] = y * y, S[2] = z * z, S[3] = x * y, S[4] = x * z, S[5] = y * z;
                 S[6] = x, S[7] = y, S[8] = z, S[9] = x * x + y * y + z * z - (double)r2f;
             }
@@ -301,6 +343,7 @@ struct AccelBuild {
 struct AccelItem {
     uint32_t sphere;
     float c[3], mn[3], mx[3], r, signed_r;
+    float c_start[3];  // the sphere as stored (centre_start for a MovingSphere): what the leaf slot carries
 };
 
 struct AccelRef {
@@ -314,7 +357,7 @@ AccelRef accel_build(std::vector<AccelItem> &items, size_t lo, size_t hi, std::v
     if (hi - lo == 1) {
         const AccelItem &it = items[lo];
         AccelRef r{~(int32_t)it.sphere, {it.mn[0], it.mn[1], it.mn[2]}, {it.mx[0], it.mx[1], it.mx[2]}, it.r, 0,
-                   {it.c[0], it.c[1], it.c[2], it.signed_r}};
+                   {it.c_start[0], it.c_start[1], it.c_start[2], it.signed_r}};
         return r;
     }
     float cmin[3] = {3e38f, 3e38f, 3e38f}, cmax[3] = {-3e38f, -3e38f, -3e38f};
@@ -344,7 +387,7 @@ AccelRef accel_build(std::vector<AccelItem> &items, size_t lo, size_t hi, std::v
     return out;
 }
 
-AccelBuild build_accel(const pt_scene_desc *desc) {
+AccelBuild build_accel(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi) {
     AccelBuild out;
     std::vector<float> radii;
     for (uint32_t i = 0; i < desc->n_spheres; ++i) radii.push_back(std::fabs(desc->spheres[i].radius));
@@ -360,7 +403,18 @@ AccelBuild build_accel(const pt_scene_desc *desc) {
             out.large.push_back(i);
             continue;
         }
-        AccelItem it{i, {p.cx, p.cy, p.cz}, {p.cx - r, p.cy - r, p.cz - r}, {p.cx + r, p.cy + r, p.cz + r}, r, p.radius};
+        AccelItem it{i, {p.cx, p.cy, p.cz}, {p.cx - r, p.cy - r, p.cz - r}, {p.cx + r, p.cy + r, p.cz + r}, r, p.radius, {p.cx, p.cy, p.cz}};
+        if (motion && motion[i].moving) {  // box the whole sweep; the leaf slot keeps centre_start (sphere_at moves it)
+            const Sweep w = sweep_of(p, &motion[i], t_lo, t_hi);
+            const double len = std::sqrt((double)motion[i].delta[0] * motion[i].delta[0] + (double)motion[i].delta[1] * motion[i].delta[1] +
+                                         (double)motion[i].delta[2] * motion[i].delta[2]);
+            for (int k = 0; k < 3; ++k) {
+                const double ext = len > 0.0 ? w.half * std::fabs((double)motion[i].delta[k]) / len : 0.0;
+                it.mn[k] = (float)(w.c[k] - ext - r - 1e-5 * (1.0 + std::fabs(w.c[k])));
+                it.mx[k] = (float)(w.c[k] + ext + r + 1e-5 * (1.0 + std::fabs(w.c[k])));
+                it.c[k] = (float)w.c[k];
+            }
+        }
         items.push_back(it);
     }
     if (items.size() < 2) {  // degenerate: everything is tested directly
@@ -375,7 +429,18 @@ AccelBuild build_accel(const pt_scene_desc *desc) {
 
 }  // namespace
 
+namespace {
+int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int device, pt_scene **scene_out);
+}
+
 extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene **scene_out) {
+    return create_sphere_scene(desc, nullptr, device, scene_out);
+}
+
+namespace {
+// `motion` (optional, n_spheres entries): MovingSphere parameters of the entries that move; desc->spheres then
+// holds centre_start / radius for them.
+int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int device, pt_scene **scene_out) {
     if (!desc || !scene_out) return fail(PT_ERR_INVALID_ARG, "desc/scene_out is NULL");
     *scene_out = nullptr;
     if (desc->n_spheres == 0 || !desc->spheres || !desc->sphere_material)
@@ -384,7 +449,7 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
     if (desc->n_textures && !desc->textures) return fail(PT_ERR_INVALID_ARG, "textures is NULL");
     if (desc->n_spheres > 0x7fffffffu) return fail(PT_ERR_INVALID_ARG, "too many spheres");
     bool has_noise = false;
-    if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, false, &has_noise)) return rc;
+    if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, motion != nullptr, &has_noise)) return rc;
     for (uint32_t i = 0; i < desc->n_spheres; ++i)
         if (desc->sphere_material[i] >= desc->n_materials)
             return fail(PT_ERR_INVALID_ARG, "sphere %u: material index out of range", i);
@@ -416,6 +481,25 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
     s->has_sky = desc->has_sky ? 1u : 0u;
     memcpy(s->sky, desc->sky, sizeof s->sky);
     s->has_noise = has_noise ? 1u : 0u;
+    // the time interval the moving entries are defined over: the sweeps are bounded for ray times inside it
+    double t_lo = 0.0, t_hi = 0.0;
+    if (motion) {
+        bool first = true;
+        for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+            if (!motion[i].moving) continue;
+            const double a0 = motion[i].time_start, a1 = a0 + 1.0 / (double)motion[i].inv_time_delta;
+            if (!std::isfinite(a0) || !std::isfinite(a1)) {
+                delete s;
+                return fail(PT_ERR_UNSUPPORTED, "moving sphere %u has a degenerate time interval", i);
+            }
+            t_lo = first ? std::min(a0, a1) : std::min(t_lo, std::min(a0, a1));
+            t_hi = first ? std::max(a0, a1) : std::max(t_hi, std::max(a0, a1));
+            first = false;
+        }
+        s->has_motion = !first;
+        if (first) motion = nullptr;
+        s->time_lo = (float)t_lo, s->time_hi = (float)t_hi;
+    }
 
     // flatten to the device layouts
     const uint32_t n_pad = (desc->n_spheres + kScanUnroll - 1) / kScanUnroll * kScanUnroll;
@@ -491,7 +575,7 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
     }
     {   // the internal tree is built for every scene: BVH mode always uses it, list mode uses it for scenes too
         // large for the brute-force scan (there it needs no gate: closest t, ties to the lower list index)
-        AccelBuild acc = build_accel(desc);
+        AccelBuild acc = build_accel(desc, motion, t_lo, t_hi);
         wnodes = std::move(acc.nodes);
         bvh_large = std::move(acc.large);
         s->accel_root = acc.root;
@@ -524,9 +608,21 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
         pt_scene_destroy(s);
         return rc;
     }
+    if (motion) {
+        std::vector<float4> mot(2 * (size_t)desc->n_spheres, make_float4(0, 0, 0, 0));
+        for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+            if (!motion[i].moving) continue;
+            mot[2 * i] = make_float4(motion[i].delta[0], motion[i].delta[1], motion[i].delta[2], motion[i].inv_time_delta);
+            mot[2 * i + 1] = make_float4(motion[i].time_start, 1.0f, 0.f, 0.f);
+        }
+        if ((rc = upload(&s->d_motion, mot.data(), mot.size()))) {
+            pt_scene_destroy(s);
+            return rc;
+        }
+    }
     {
         MfmaPrep prep;
-        if (prepare_mfma(desc, prep)) {
+        if (prepare_mfma(desc, motion, t_lo, t_hi, prep)) {
             if ((rc = upload(&s->d_afrag, prep.afrag.data(), prep.afrag.size() / 8)) ||
                 (rc = upload(&s->d_tile_sphere, prep.tile_sphere.data(), prep.tile_sphere.size())) ||
                 (rc = upload(&s->d_large, prep.large.data(), prep.large.size()))) {
@@ -538,8 +634,10 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
             memcpy(s->c0, prep.c0, sizeof s->c0);
             s->rs2 = (float)(prep.rs * prep.rs * 1.0001);
             // margin = a * (m0 + gamma * (|o - c0|^2 + Rs^2)); see DESIGN.md for the derivation
-            s->m0 = (float)(1.0e-5 * prep.rs * prep.rs + 1.0e-4);
-            s->gamma = 8.0e-6f;
+            // a swept bound of half-length h moves the reference's rounding slack from radius r to r + h: scale by (1 + h/r)
+            const double widen = 1.0 + 1.5 * prep.sweep_ratio;
+            s->m0 = (float)((1.0e-5 * prep.rs * prep.rs + 1.0e-4) * widen);
+            s->gamma = (float)(8.0e-6 * widen);
         }
     }
     if (hipMalloc((void **)&s->d_debug, 1024) != hipSuccess || hipMemset(s->d_debug, 0, 1024) != hipSuccess) {
@@ -556,6 +654,7 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
     *scene_out = s;
     return PT_OK;
 }
+}  // namespace
 
 // ---- general worlds --------------------------------------------------------------------------------
 extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_scene **scene_out) {
@@ -568,7 +667,7 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
     if (desc->n_transforms && !desc->transforms) return fail(PT_ERR_INVALID_ARG, "transforms is NULL");
     bool has_noise = false;
     if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, true, &has_noise)) return rc;
-    bool all_spheres = true;
+    bool all_spheres = true, sphere_like = true;
     for (uint32_t i = 0; i < desc->n_hitables; ++i) {
         const pt_hitable &h = desc->hitables[i];
         if (h.kind > PT_HIT_CUBOID) return fail(PT_ERR_INVALID_ARG, "hitable %u: unknown kind %u", i, h.kind);
@@ -582,19 +681,31 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
                 return fail(PT_ERR_INVALID_ARG, "hitable %u: medium_material must index an Isotropic material", i);
         }
         if (h.kind != PT_HIT_SPHERE || h.transform >= 0 || h.medium_material >= 0) all_spheres = false;
+        if (h.kind > PT_HIT_MOVING_SPHERE || h.transform >= 0 || h.medium_material >= 0) sphere_like = false;
     }
     if (desc->n_bvh_nodes) {
         if (!desc->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "bvh_nodes is NULL");
         if (bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_hitables, desc->bvh_root) == 0)
             return fail(PT_ERR_INVALID_ARG, "malformed BVH (bad child index or cycle)");
     }
-    if (all_spheres) {  // a plain sphere world: the specialised kernels (MFMA prefilter, internal tree) apply
+    uint32_t ref_depth = 0;
+    if (desc->n_bvh_nodes) ref_depth = bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_hitables, desc->bvh_root);
+    if (sphere_like) {
+        // Sphere / MovingSphere entries only: the specialised kernels apply (MFMA prefilter, internal tree); with
+        // moving entries their MOVING instantiations, and the general-world data rides along as the fallback
         std::vector<pt_sphere> sph(desc->n_hitables);
         std::vector<uint32_t> mat(desc->n_hitables);
+        std::vector<MotionIn> motion(desc->n_hitables);
         for (uint32_t i = 0; i < desc->n_hitables; ++i) {
             const pt_hitable &h = desc->hitables[i];
-            sph[i] = pt_sphere{h.p[0], h.p[1], h.p[2], h.p[3]};
             mat[i] = h.material;
+            if (h.kind == PT_HIT_SPHERE) {
+                sph[i] = pt_sphere{h.p[0], h.p[1], h.p[2], h.p[3]};
+                motion[i] = MotionIn{{0, 0, 0}, 0.f, 0.f, 0u};
+            } else {
+                sph[i] = pt_sphere{h.p[0], h.p[1], h.p[2], h.p[6]};
+                motion[i] = MotionIn{{h.p[3], h.p[4], h.p[5]}, h.p[7], h.p[8], 1u};
+            }
         }
         pt_scene_desc d{};
         d.n_spheres = desc->n_hitables, d.spheres = sph.data(), d.sphere_material = mat.data();
@@ -603,13 +714,25 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
         d.n_bvh_nodes = desc->n_bvh_nodes, d.bvh_nodes = desc->bvh_nodes, d.bvh_root = desc->bvh_root;
         d.has_sky = desc->has_sky;
         memcpy(d.sky, desc->sky, sizeof d.sky);
-        return pt_scene_create(&d, device, scene_out);
+        if (all_spheres) return create_sphere_scene(&d, nullptr, device, scene_out);
+        int rc = create_sphere_scene(&d, motion.data(), device, scene_out);
+        if (rc == PT_OK) {
+            pt_scene *s = *scene_out;
+            s->n_hitables = desc->n_hitables;
+            s->ref_bvh_depth = ref_depth;
+            if (ref_depth + 2 > 64u || (rc = upload(&s->d_hitables, desc->hitables, desc->n_hitables)) ||
+                (rc = upload(&s->d_transforms, desc->transforms, desc->n_transforms)) ||
+                (rc = upload(&s->d_ref_nodes, desc->bvh_nodes, desc->n_bvh_nodes))) {
+                pt_scene_destroy(s);
+                *scene_out = nullptr;
+                return rc ? rc : fail(PT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", ref_depth);
+            }
+            return PT_OK;
+        }
+        if (rc != PT_ERR_UNSUPPORTED) return rc;
+        // (unsupported by the specialised path, e.g. a degenerate time interval: trace it as a general world)
     }
-    uint32_t ref_depth = 0;
-    if (desc->n_bvh_nodes) {
-        ref_depth = bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_hitables, desc->bvh_root);
-        if (ref_depth + 2 > 64u) return fail(PT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", ref_depth);
-    }
+    if (ref_depth + 2 > 64u) return fail(PT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", ref_depth);
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
@@ -674,6 +797,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     (void)hipFree(s->d_hitables);
+    (void)hipFree(s->d_motion);
     (void)hipFree(s->d_transforms);
     (void)hipFree(s->d_ref_nodes);
     (void)hipFree(s->d_spheres);
@@ -736,7 +860,19 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     const bool bvh = ref_bvh || list_tree;       // kernel flavour: tree traversal
     HIP_TRY(hipSetDevice(s->device));
 
-    if (s->is_world) {
+    // Sphere + MovingSphere worlds: the MOVING instantiations exist for the MFMA list kernel and the tree kernel,
+    // and their swept bounds cover ray times in [time_lo, time_hi] only. Anything else (exact-scan variants, a
+    // camera shutter outside that interval, variant bit 128) is traced by the general kernel.
+    bool moving = false;
+    if (s->has_motion) {
+        const float lo = std::min(cam->time0, cam->time1), hi = std::max(cam->time0, cam->time1);
+        const bool time_ok = std::isfinite(lo) && std::isfinite(hi) && lo >= s->time_lo && hi <= s->time_hi;
+        const uint32_t n_pad = (s->n_spheres + kScanUnroll - 1) / kScanUnroll * kScanUnroll;
+        const bool will_mfma = !bvh && (s->variant & (1u | 4u)) == 0 && n_pad * 16u <= 64u * 1024u && s->n_tiles > 0 && s->n_tiles <= 24u;
+        moving = time_ok && (bvh || will_mfma) && (s->variant & 128u) == 0;
+    }
+
+    if (s->is_world || (s->has_motion && !moving)) {
         WArgs W;
         memset(&W, 0, sizeof W);
         W.hit = s->d_hitables;
@@ -825,6 +961,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.spheres_r2 = s->d_spheres_r2;
     A.shade = s->d_shade;
     A.sphere_mat = s->d_sphere_mat;
+    A.motion = s->d_motion;
     A.mats = s->d_mats;
     A.texs = s->d_texs;
     A.perlin_vec = s->d_perlin_vec;
@@ -946,7 +1083,13 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
 
     void (*kern)(const KArgs) = nullptr;
     void (*pilot_kern)(const KArgs) = nullptr;
-    if (bvh)
+    if (moving && bvh)
+        kern = pt_trace_kernel<true, false, false, false, false, true>, pilot_kern = pt_trace_kernel<true, false, false, false, true, true>;
+    else if (moving && (A.verify & 1u))
+        kern = pt_trace_kernel<false, true, true, true, false, true>;
+    else if (moving)
+        kern = pt_trace_kernel<false, true, true, false, false, true>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true>;
+    else if (bvh)
         kern = pt_trace_kernel<true, false, false, false, false>, pilot_kern = pt_trace_kernel<true, false, false, false, true>;
     else if (mfma && (A.verify & 1u))
         kern = pt_trace_kernel<false, true, true, true, false>;

@@ -411,6 +411,49 @@ def test_world_progressive_frames_and_shards(ptgpu, pthost, oracle):
     assert total == total_full and np.array_equal(stitched.cpu().numpy(), frame0)
 
 
+def test_moving_sphere_kernels_agree_with_the_general_kernel(ptgpu, pthost, oracle):
+    """`random` (Sphere + MovingSphere) runs on the MOVING instantiations of the sphere kernels: MFMA prefilter over
+    swept bounding spheres in list mode, internal tree over swept boxes in BVH mode. They must reproduce the general
+    kernel (variant 128, itself checked against the oracle above) for the preset's shutter and for a narrower one,
+    and a shutter outside the motion's interval must fall back to the general kernel rather than miss spheres."""
+    W, H, S = 240, 160, 8
+    for bvh in (False, True):
+        hs = pthost.HostScene("random", W, H, samples=S, use_bvh=bvh, device=0)
+        sc, p = hs.device_scene(), ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0)
+        ref, ref_rays = oracle.OracleScene("random", W, H, use_bvh=bvh).update(S)
+        for t0, t1 in ((0.0, 1.0), (0.25, 0.75), (0.5, 1.5)):
+            cam = ptgpu.PtCamera.from_floats(np.ctypeslib.as_array(C.cast(C.pointer(hs.camera), C.POINTER(C.c_float)), shape=(24,)).copy())
+            cam.time0, cam.time1 = t0, t1
+            outs = []
+            for variant in (0, 128):
+                sc.set_tuning(0, variant)
+                out = np.zeros((H, W, 3), np.float32)
+                rays = sc.update(p, cam, 0, out)
+                outs.append((rays, out))
+            assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1]), (bvh, t0, t1, _report(outs[1][1], outs[0][1]))
+            if (t0, t1) == (0.0, 1.0):
+                assert outs[0][0] == ref_rays and np.array_equal(outs[0][1], ref), _report(ref, outs[0][1])
+        sc.set_tuning(0, 0)
+
+
+def test_mfma_prefilter_covers_moving_spheres(ptgpu, pthost):
+    """Verify mode on `random`: every (ray, sphere-at-ray-time) pair with a positive reference discriminant must be
+    among the candidates of the swept-bound prefilter."""
+    W, H, S = 600, 400, 2
+    hs = pthost.HostScene("random", W, H, samples=S, device=0)
+    sc = hs.device_scene()
+    sc.set_tuning(0, 8)
+    sc.debug_counters(reset=True)
+    out = np.zeros((H, W, 3), np.float32)
+    sc.update(ptgpu.PtParams(W, H, S, 10, 0, 0), hs.camera, 0, out)
+    c = sc.debug_counters(reset=True)
+    missed, queued, overflow, positives = c["misses"], c["candidates"], c["overflows"], c["exact_positives"]
+    sc.set_tuning(0, 0)
+    print("random: positives %d queued %d overflow %d missed %d" % (positives, queued, overflow, missed))
+    assert positives > 100000 and missed == 0
+    assert queued < 6 * positives          # the swept bounds stay selective
+
+
 def test_device_ln_is_glibc_logf(ptgpu, oracle):
     """constant_medium.rs:60 -(1/density) * ln(u): the value decides whether a ray scatters, so the device logf must
     equal the host's bit for bit. u is a multiple of 2^-24 in [0, 1); also sweep ordinary floats."""

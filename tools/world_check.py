@@ -24,6 +24,8 @@ for name in sys.argv[1:] or ["smallpt", "simple_light", "cornell", "cornell_smok
         dev = hs.device_scene()
         params = ptgpu.PtParams(W, H, SPP, 10, 0, 1 if bvh else 0)
         got = np.zeros((H, W, 3), np.float32)
+        if os.environ.get("WC_VARIANT"):
+            dev.set_tuning(0, int(os.environ["WC_VARIANT"]))
         t = time.time()
         rays = dev.update(params, hs.camera, 0, got)
         dt = time.time() - t
