@@ -765,16 +765,19 @@ static aabb aabb_transform_as_written(const affine3 *m) {
 enum { HIT_SPHERE = 0, HIT_BVHNODE = 1, HIT_LIST = 2, HIT_MOVING_SPHERE = 3, HIT_RECT = 4, HIT_CUBOID = 5,
        HIT_INSTANCE = 6, HIT_CONSTANT_MEDIUM = 7 };
 struct bvhnode; struct hitable_list; struct instance; struct constant_medium;
-typedef struct hitable {
+typedef struct hitable { /* 24 bytes like the Rust enum: tag + two references */
     int kind;
-    const sphere *sph; const material *mat;  /* Sphere / MovingSphere / Rect / Cuboid carry (&shape, &Material) */
-    const struct bvhnode *node;              /* BVHNode(&BVHNode) */
-    const struct hitable_list *list;         /* List(&HitableList) */
-    const moving_sphere *msph;
-    const rect *rct;
-    const cuboid *cub;
-    const struct instance *inst;
-    const struct constant_medium *med;
+    union {
+        const sphere *sph;                  /* Sphere(&Sphere, &Material) */
+        const moving_sphere *msph;          /* MovingSphere(&MovingSphere, &Material) */
+        const rect *rct;                    /* Rect(&Rect, &Material) */
+        const cuboid *cub;                  /* Cuboid(&Cuboid, &Material) */
+        const struct bvhnode *node;         /* BVHNode(&BVHNode) */
+        const struct hitable_list *list;    /* List(&HitableList) */
+        const struct instance *inst;        /* Instance(&Instance) */
+        const struct constant_medium *med;  /* ConstantMedium(&ConstantMedium) */
+    };
+    const material *mat;
 } hitable;
 typedef struct bvhnode { aabb bb; hitable lhs, rhs; } bvhnode;
 typedef struct hitable_list { hitable *hitables; size_t len; } hitable_list;

@@ -12,8 +12,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
 def is_frame_kernel(name):
-    """The frame kernel (last template flag PILOT = false); the 1-spp pilot pass is a separate symbol."""
-    return re.search(r"pt_trace_kernel<[^>]*false>\(", name) is not None or ("pt_trace_kernel" in name and "<" not in name)
+    """The frame kernel (5th template flag PILOT = false); the 1-spp pilot pass is a separate symbol."""
+    m = re.search(r"pt_(?:trace|world)_kernel<([^>]*)>", name)
+    if not m:
+        return "pt_trace_kernel" in name or "pt_world_kernel" in name
+    flags = [f.strip() for f in m.group(1).split(",")]
+    return len(flags) < 5 or flags[4] == "false"
 
 src = os.path.join("gpurun_out", "prof_" + tag)
 os.makedirs("profiles", exist_ok=True)
