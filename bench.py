@@ -7,10 +7,17 @@ A "step" is one Scene::update pass (reference src/scene.rs:73-121) over one fram
 synthetic (preset-generated) input, pixel buffer resident in HBM:
   N = 1 : preset random_spheres 1200x800, 64 spp, depth 10, list world (BASELINE config 3,
           the configuration the metric is quoted on)
-  N > 1 : the same frame at 256 spp (BASELINE config 4), rows interleaved across ranks
-          (row y -> rank y % N), each rank renders its rows with no data-path collective, then
-          ONE RCCL all_gather of the float3 shards (+ an 8-byte all_reduce of the ray count)
-          inside the timed region. Total work is fixed as N grows -> "strong".
+  N > 1 : two ways to use N GPUs, both measured, both inside the timed region end to end:
+          --mode frames (default, "weak"): the unit of work is one frame of that SAME configuration. Rank r
+              renders progressive frame frame_num = r (scene.rs:99-101 seeds depend on (x, y, frame) only) with no
+              data-path collective, ONE RCCL all_gather collects the N frames and the reference's blend
+              (scene.rs:113-116) is replayed in frame order: bit-identical to `-F N` on one GPU, N x 64 spp worth of
+              samples in the image. Per-GPU work is fixed as N grows.
+          --mode tiles ("strong"): ONE frame, rows interleaved across ranks (row y -> rank y % N), each rank
+              renders its rows, ONE all_gather of the float3 shards. Samples of a pixel are serial (one RNG stream
+              per pixel), so a 15 ms frame cannot strong-scale well; the default run reports this number too, as
+              `strong_scaling_tiles`, measured right after the timed region.
+          Both add an 8-byte all_reduce of the ray count (scene.rs:118-120).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -73,7 +80,8 @@ def main():
     ap.add_argument("--preset", default="random_spheres")
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--samples", type=int, default=0, help="0 = 64 at N=1, 256 at N>1")
+    ap.add_argument("--samples", type=int, default=64, help="samples per pixel (BASELINE config 4 = 256 with --mode tiles)")
+    ap.add_argument("--mode", choices=["frames", "tiles"], default="frames", help="how N > 1 GPUs are used (see above)")
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--bvh", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,7 +97,7 @@ def main():
     N = args.gpus
     if world != N and world > 1:
         N = world
-    S = args.samples or (64 if N == 1 else 256)
+    S = args.samples
     W, H, depth = args.width, args.height, args.depth
 
     if not torch.cuda.is_available():
@@ -111,29 +119,38 @@ def main():
     # scene + camera built by the C++ host (presets.rs / camera.rs mirror), uploaded via the C ABI
     hs = pthost.HostScene(args.preset, W, H, samples=S, use_bvh=args.bvh, device=local_rank)
     scene = hs.device_scene()
-    n_spheres = hs.desc.n_spheres
+    n_spheres = hs.world_desc.n_hitables
     params = ptgpu.PtParams(W, H, S, depth, 0, 1 if args.bvh else 0)
     cam = hs.camera
 
     stream = torch.cuda.current_stream()
+    multi = N > 1 or dist is not None
     max_rows = sharding.padded_rows(H, N)
     shard = torch.zeros((max_rows, W, 3), dtype=torch.float32, device=dev)
+    full = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     ray_count = torch.zeros(1, dtype=torch.int64, device=dev)
-    gathered = torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev) if (N > 1 or dist is not None) else None
+    gathered_rows = torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev) if multi else None
+    gathered_frames = torch.empty((N, H, W, 3), dtype=torch.float32, device=dev) if multi else None
     frame = None
     kernel_ms = []
 
-    def step():
+    def step(mode):
         nonlocal frame
-        shard.zero_()  # frame 0 of a fresh accumulation (offline.rs:25 starts from zeros)
-        if N == 1 and dist is None:
-            scene.update_device(params, cam, 0, shard.data_ptr(), ray_count.data_ptr(), stream.cuda_stream)
-            frame = shard
+        if not multi:
+            full.zero_()  # frame 0 of a fresh accumulation (offline.rs:25 starts from zeros)
+            scene.update_device(params, cam, 0, full.data_ptr(), ray_count.data_ptr(), stream.cuda_stream)
+            frame = full
+        elif mode == "frames":
+            full.zero_()
+            scene.update_device(params, cam, rank, full.data_ptr(), ray_count.data_ptr(), stream.cuda_stream)
+            # RCCL over xGMI: ONE all_gather of the N frames, blend replayed in frame order (scene.rs:113-116)
+            frame = sharding.gather_progressive(dist, full, gathered_frames, ray_count)
         else:
+            shard.zero_()
             scene.update_shard_device(params, cam, 0, rank, N, shard.data_ptr(), ray_count.data_ptr(),
                                       stream.cuda_stream)
-            # RCCL over xGMI: ONE all_gather per frame (+ 8-byte all_reduce, scene.rs:118-120), de-interleave
-            frame = sharding.gather_frame(dist, shard, gathered, ray_count, H)
+            # ONE all_gather of the row shards per frame (+ 8-byte all_reduce, scene.rs:118-120), de-interleave
+            frame = sharding.gather_frame(dist, shard, gathered_rows, ray_count, H)
         return frame
 
     def fence():
@@ -142,38 +159,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # kernel duration of this step from the HIP events recorded on the launch stream
-        # (pt_last_kernel_ms synchronises on the stop event only)
-        kernel_ms.append(scene.last_kernel_ms())
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(mode, steps, warmup):
+        """W untimed + K timed steps bracketed by barrier + synchronize; MAX over ranks."""
+        kms_list = []
+        for _ in range(warmup):
+            step(mode)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(mode)
+            # kernel duration of this step from the HIP events recorded on the launch stream
+            # (pt_last_kernel_ms synchronises on the stop event only)
+            kms_list.append(scene.last_kernel_ms())
+        fence()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el, sum(kms_list) / max(1, len(kms_list))], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].item()), float(t[1].item()), int(ray_count.item())  # ray_count: already summed over ranks
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    rays_per_step = int(ray_count.item())  # already summed over ranks
+    elapsed, kms, rays_per_step = timed(args.mode, args.steps, args.warmup)
     total_rays = rays_per_step * args.steps
     value = total_rays / 1e6 / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    kms = sum(kernel_ms) / max(1, len(kernel_ms))
-    k_t = torch.tensor([kms], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(k_t, op=dist.ReduceOp.MAX)
-    kms = float(k_t.item())
+    strong = None
+    if multi and args.mode == "frames":   # the other decomposition, reported beside the main value
+        k2 = max(2, min(args.steps, 5))
+        el2, kms2, rays2 = timed("tiles", k2, 1)
+        strong = {"value": rays2 * k2 / 1e6 / el2, "unit": "Mrays/s", "ms_per_step": el2 / k2 * 1e3, "kernel_ms": kms2,
+                  "steps": k2, "scaling": "strong",
+                  "workload": "ONE %dx%d %dspp frame, rows interleaved over %d GPUs, all_gather of the shards" % (W, H, S, N)}
 
     if rank == 0:
         grid, block, lds = scene.last_launch_info()
         # SURVEY 8(d): algorithmic bytes/ray in list mode = 16 B x N_spheres (cx,cy,cz,r^2 scanned once per
         # ray); the scan is LDS-served, so "achieved" is an EFFECTIVE rate and may exceed the HBM peak.
         bytes_per_ray = 16.0 * n_spheres
-        launch_bytes = bytes_per_ray * rays_per_step / N      # one launch = one rank's shard
+        launch_bytes = bytes_per_ray * rays_per_step / N      # one launch = one rank's frame (or shard)
         achieved = launch_bytes / (kms * 1e-3) / 1e9
         # The same algorithmic work expressed as the reference's arithmetic: 18 unfused f32 lane-ops per sphere
         # test. The kernel does NOT execute these for every pair: an f16 MFMA prefilter discards certain misses
@@ -191,15 +213,21 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mrays/sec, random_spheres 1200x800 64spp" if (args.preset == "random_spheres" and N == 1)
+            "metric": "Mrays/sec, random_spheres 1200x800 64spp" if (args.preset == "random_spheres" and (W, H, S) == (1200, 800, 64))
                       else "Mrays/sec, %s %dx%d %dspp" % (args.preset, W, H, S),
             "value": value, "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "preset %s (%d spheres) %dx%d %dspp depth %d %s, frame 0, seed 0"
-                                   % (args.preset, n_spheres, W, H, S, depth, "BVH" if args.bvh else "list"),
-                       "rays_per_step": rays_per_step, "wall_secs_per_frame": ms_per_step / 1e3,
-                       "parallelism": "rows interleaved over %d GPU(s)%s" % (N, ", RCCL all_gather" if N > 1 else ""),
+            "scaling": "weak" if (args.mode == "frames" or not multi) else "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "preset %s (%d hitables) %dx%d %dspp depth %d %s, seed 0, %s"
+                                   % (args.preset, n_spheres, W, H, S, depth, "BVH" if args.bvh else "list",
+                                      "frame 0" if not multi else ("progressive frames 0..%d, one per GPU" % (N - 1) if args.mode == "frames"
+                                                                   else "frame 0 split by rows")),
+                       "rays_per_step": rays_per_step, "wall_secs_per_step": ms_per_step / 1e3,
+                       "parallelism": ("1 GPU" if not multi else
+                                       ("frame_num = rank on each of %d GPUs, no data-path collective, RCCL all_gather of the frames + "
+                                        "blend in frame order (scene.rs:113-116)" % N if args.mode == "frames"
+                                        else "rows interleaved over %d GPUs, RCCL all_gather of the shards" % N)),
                        "grid": grid, "block": block, "lds_bytes": lds},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
@@ -212,6 +240,8 @@ def main():
                                  "DESIGN.md section 4" % (n_spheres, valu_rate, mfma_tf),
                          "valu_equiv_frac": valu_rate / 78.6, "mfma_tflops": mfma_tf, "mfma_frac": mfma_tf / 2500.0},
         }
+        if strong is not None:
+            out["strong_scaling_tiles"] = strong
         if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.preset, W, H, S, depth, args.bvh, args.cpu_secs)
         print(json.dumps(out))

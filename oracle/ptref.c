@@ -511,7 +511,7 @@ static inline aabb aabb_add(aabb a, aabb b) { aabb r = { v3_min(a.min, b.min), v
 typedef struct { v3 centre; float radius; } sphere;
 
 /* sphere.rs:29-66 */
-static int sphere_ray_hit(const sphere *s, const ray *r, float t_min, float t_max, ray_hit *out) {
+static inline __attribute__((always_inline)) int sphere_ray_hit(const sphere *s, const ray *r, float t_min, float t_max, ray_hit *out) {
     v3 oc = v3_sub(r->origin, s->centre);
     float a = v3_dot(r->direction, r->direction);
     float b = v3_dot(oc, r->direction);
@@ -794,7 +794,11 @@ static int list_ray_hit(const hitable_list *l, const ray *r, float t_min, float 
     float closest_so_far = t_max;
     for (size_t i = 0; i < l->len; ++i) {
         ray_hit h; const material *m;
-        if (hitable_ray_hit(&l->hitables[i], r, t_min, closest_so_far, rng, &h, &m)) {
+        const hitable *e = &l->hitables[i];
+        int hit;
+        if (e->kind == HIT_SPHERE) { hit = sphere_ray_hit(e->sph, r, t_min, closest_so_far, &h); m = e->mat; } /* Sphere arm, inlined */
+        else hit = hitable_ray_hit(e, r, t_min, closest_so_far, rng, &h, &m);
+        if (hit) {
             *out = h; *mat = m; found = 1;
             closest_so_far = h.t;
         }
@@ -863,6 +867,10 @@ static int constant_medium_ray_hit(const constant_medium *cm, const ray *r, floa
 static int hitable_ray_hit(const hitable *h, const ray *r, float t_min, float t_max, xoshiro *rng,
                            ray_hit *out, const material **mat) {
     int hit;
+    if (h->kind == HIT_SPHERE) { /* the common arm first; same result as the match in hitable.rs:47-57 */
+        if (sphere_ray_hit(h->sph, r, t_min, t_max, out)) { *mat = h->mat; return 1; }
+        return 0;
+    }
     switch (h->kind) {
     case HIT_BVHNODE: return bvh_ray_hit(h->node, r, t_min, t_max, rng, out, mat);
     case HIT_LIST: return list_ray_hit(h->list, r, t_min, t_max, rng, out, mat);

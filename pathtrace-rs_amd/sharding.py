@@ -5,6 +5,13 @@ buffer (the layout pt_render_shard_device writes). Per-pixel seeds depend only o
 (scene.rs:99-101), so shards render independently; the only exchange is ONE all_gather of the
 float3 shards per frame plus an 8-byte all_reduce of the ray count (scene.rs:118-120). xGMI is
 point-to-point, and the message is small (11.5 MB at 1200x800), so one collective, no ring tuning.
+
+Weak scaling uses the reference's OTHER data-parallel axis: progressive frames. Scene::update for
+frame_num f depends on earlier frames only through the blend `out = out * f/(f+1) + col * 1/(f+1)`
+(scene.rs:86-87,113-116), and its seeds depend on (x, y, f) alone, so N GPUs render frames 0..N-1 of
+the same scene concurrently (each into a zeroed buffer, which leaves col * mix_new in it), one
+all_gather collects them and the blend is replayed in frame order -- bit-identical to N sequential
+Scene::update calls (`-F N` in the reference's CLI).
 """
 import torch
 
@@ -46,3 +53,28 @@ def gather_frame(dist, shard, gathered, ray_count, height):
     dist.all_gather_into_tensor(gathered.view(world * prow, width, ch), shard)
     dist.all_reduce(ray_count)
     return deinterleave(gathered, height)
+
+
+def frame_mix_prev(frame_num):
+    """scene.rs:86: mix_prev = frame_num as f32 / (frame_num + 1) as f32, one IEEE f32 division."""
+    return float(torch.tensor(float(frame_num), dtype=torch.float32) / torch.tensor(float(frame_num + 1), dtype=torch.float32))
+
+
+def blend_frames(contribs):
+    """contribs[f] = Scene::update(frame_num = f) applied to a ZERO buffer, i.e. col_f * mix_new(f)
+    (0 * mix_prev + col * mix_new, scene.rs:114-116). Returns the buffer after frames 0..N-1 applied in order:
+    out_f = out_{f-1} * mix_prev(f) + contribs[f] -- the same two roundings per channel as the sequential run."""
+    acc = torch.zeros_like(contribs[0])
+    for f in range(contribs.shape[0]):
+        acc = acc * frame_mix_prev(f)
+        acc = acc + contribs[f]
+    return acc
+
+
+def gather_progressive(dist, frame_buf, gathered, ray_count):
+    """Rank r rendered frame_num = r of the same scene into `frame_buf` [H, W, 3] (zeroed before the launch).
+    One all_gather of the frames + the ray-count all_reduce, then the blend in frame order."""
+    world, height, width, ch = gathered.shape
+    dist.all_gather_into_tensor(gathered.view(world * height, width, ch), frame_buf)
+    dist.all_reduce(ray_count)
+    return blend_frames(gathered)

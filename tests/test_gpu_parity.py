@@ -265,6 +265,27 @@ def test_config3_shard_union_equals_full_frame(ptgpu, pthost):
     assert torch.equal(frame, full)
 
 
+def test_frames_rendered_apart_blend_like_sequential_updates(ptgpu, pthost):
+    """bench.py's weak-scaling mode: each GPU renders one progressive frame into a zeroed buffer, the blend is
+    replayed in frame order. On one GPU: frames 0..3 rendered apart and folded == four Scene::update calls."""
+    import torch
+    spec = importlib.util.spec_from_file_location("pathtrace_rs_amd_sharding_g", os.path.join(ROOT, "pathtrace-rs_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    W, H, S, N = 300, 200, 4, 4
+    hs = pthost.HostScene("random_spheres", W, H, samples=S, device=0)
+    sc, p = hs.device_scene(), ptgpu.PtParams(W, H, S, 10, 0, 0)
+    rc = torch.zeros(1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    seq = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    apart = torch.zeros((N, H, W, 3), dtype=torch.float32, device="cuda")
+    for f in range(N):
+        sc.update_device(p, hs.camera, f, seq.data_ptr(), rc.data_ptr(), stream)
+        sc.update_device(p, hs.camera, f, apart[f].data_ptr(), rc.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(sharding.blend_frames(apart), seq)
+
+
 def test_device_buffer_entry_point_matches_host_entry_point(ptgpu, pthost):
     import torch
     W, H, S = 200, 100, 4

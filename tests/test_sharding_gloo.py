@@ -63,6 +63,48 @@ def _worker(rank, world, port, W, H, S, preset, out_path):
         dist.destroy_process_group()
 
 
+def _worker_frames(rank, world, port, W, H, S, preset, out_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import oracle_binding as ob
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pathtrace_rs_amd_sharding",
+                                                  os.path.join(ROOT, "pathtrace-rs_amd", "sharding.py"))
+    sharding = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sharding)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank r renders progressive frame r into a ZEROED buffer (what bench.py does with pt_render_device)
+        buf, rays = ob.OracleScene(preset, W, H).update(S, 10, rank, nthreads=2)
+        gathered = torch.empty((world, H, W, 3), dtype=torch.float32)
+        ray_count = torch.tensor([rays], dtype=torch.int64)
+        frame = sharding.gather_progressive(dist, torch.from_numpy(buf), gathered, ray_count)
+        if rank == 0:
+            np.savez(out_path, frame=frame.numpy(), rays=int(ray_count.item()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_progressive_frames_across_ranks_equal_sequential_updates(tmp_path, oracle, world):
+    """Weak-scaling mode: frame_num = rank on each rank, one all_gather, blend replayed in order ==
+    Scene::update called for frame 0, 1, .. on one buffer (scene.rs:86-87,113-116), bit for bit."""
+    W, H, S, preset = 48, 32, 2, "small"
+    out = str(tmp_path / "frames.npz")
+    mp.spawn(_worker_frames, args=(world, _free_port(), W, H, S, preset, out), nprocs=world, join=True)
+    got = np.load(out)
+    sc = oracle.OracleScene(preset, W, H)
+    ref, total = np.zeros((H, W, 3), np.float32), 0
+    for f in range(world):
+        _, rays = sc.update(S, 10, f, buffer=ref)
+        total += rays
+    assert int(got["rays"]) == total
+    assert np.array_equal(got["frame"], ref)
+
+
 @pytest.mark.parametrize("H", [40, 41])     # even split and a ragged last row
 def test_two_rank_sharded_frame_equals_full_frame(tmp_path, oracle, H):
     W, S, preset, world = 60, 2, "small", 2
