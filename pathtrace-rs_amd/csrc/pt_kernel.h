@@ -385,10 +385,11 @@ __device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d,
     return f;
 }
 
-// Candidate queues without atomics: a lane appends the pairs IT found to its own two sub-queues (one per
-// ray half it serves); ray rho's candidates are then the sub-queues [rho >> 5] of lanes (rho & 31) and
-// (rho & 31) + 32, i.e. of the owner lane and of lane ^ 32. Entries are fragment slots (tile*32 + row).
-constexpr int kSubCap = kQueueCap / 2;
+// Candidate queue without atomics and without a per-candidate loop: per tile a lane packs the sign bits of its
+// accumulators into masks, swaps the partner ray's half with lane ^ 32, and appends the 32-bit mask of ITS OWN
+// ray when it is non-zero (~1 candidate per ray per bounce, so most tiles append nothing). Phase 2 walks the
+// set bits; bit -> fragment slot (tile*32 + row) -> sphere.
+constexpr int kEntCap = (kQueueCap + 1) / 2;  // u32 tile masks per lane in the same LDS area as the u16 scan queue
 
 // MovingSphere::centre (moving_sphere.rs:29-31): centre_start + ((time - time_start) * inv_time_delta) * centre_delta.
 // `c` carries the sphere as stored (centre_start in xyz; w untouched). Plain spheres are returned as they are.
@@ -433,7 +434,39 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     const RayFeat rf = make_ray_features(A, o, d, a, active, lane);
     const int row_off = 4 * (lane >> 5);
     const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint32_t cnt0 = 0, cnt1 = 0;  // candidates this lane found for the ray it serves in half 0 / half 1
+    // Candidates of MY ray, one 32-bit mask per tile that has any: bits 0..15 come from my own accumulators (my
+    // rows of the tile), bits 16..31 from lane ^ 32's (the other 16 rows), exchanged with one cross-half swap per
+    // tile. Non-empty masks are appended to this lane's queue; `tbits` remembers which tiles they belong to.
+    uint32_t tbits = 0, cnt = 0, ncand = 0;
+    uint32_t *queue32 = reinterpret_cast<uint32_t *>(queue);
+    // slot of bit b of a tile mask: register r = 15 - (b & 15) is row (r & 3) + 8 (r >> 2) + 4 * (half of the wave
+    // that computed it); bits 0..15 come from the low half, 16..31 from the high half
+    auto slot_of = [&](uint32_t T, uint32_t b) -> uint32_t {
+        const uint32_t r = 15u - (b & 15u);
+        return T * 32u + (r & 3u) + 8u * (r >> 2) + ((b >> 4) << 2);
+    };
+    float best = kMaxT;
+    int idx = -1;
+    // phase 2 on the queued masks: exact arithmetic for every set bit, then the queue is empty again
+    auto drain = [&]() {
+        uint32_t tb = tbits, j = 0, cur = 0, curT = 0;
+        while (__any((cur | tb) != 0u)) {
+            if (cur == 0u && tb != 0u) {  // next non-empty tile of my ray
+                curT = (uint32_t)__builtin_ctz(tb);
+                tb &= tb - 1u;
+                cur = queue32[j * kBlock + tid];
+                j += 1;
+            }
+            if (cur != 0u) {
+                const uint32_t b = (uint32_t)__builtin_ctz(cur);
+                cur &= cur - 1u;
+                const int k = s_tile_sphere[slot_of(curT, b)];
+                exact_candidate(sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx);
+            }
+        }
+        tbits = 0;
+        cnt = 0;
+    };
     union Frag { uint4 u; half8 h; };
     Frag a0, a1, n0, n1;
     a0.u = s_afrag[lane];
@@ -448,43 +481,35 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, rf.b1[1], acc1, 0, 0, 0);
         a0 = n0;
         a1 = n1;
-        // sign bits of the 2 x 16 accumulators -> one 32-bit mask per lane (v_alignbit shifts a sign in);
-        // register r of set s ends up at bit 16*s + 15 - r
+        // sign bits of the 2 x 16 accumulators -> 16-bit masks (v_alignbit shifts a sign in): register r ends up
+        // at bit 15 - r
         uint32_t m0 = 0, m1 = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             m0 = __builtin_amdgcn_alignbit(m0, __float_as_uint(acc0[r]), 31);
             m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(acc1[r]), 31);
         }
-        uint32_t m = m0 | (m1 << 16);
-        const uint32_t slot_base = T * 32 + row_off;
-        while (__any(m != 0u)) {
-            if (m != 0u) {
-                const uint32_t bit = 31u - (uint32_t)__builtin_clz(m);
-                m &= ~(1u << bit);
-                const uint32_t set = bit >> 4, r = 15u - (bit & 15u);
-                const uint32_t slot = slot_base + (r & 3u) + 8u * (r >> 2);
-                const uint32_t c = set ? cnt1 : cnt0;
-                if (c < (uint32_t)kSubCap) queue[(set * kSubCap + c) * kBlock + tid] = (uint16_t)slot;
-                cnt0 += set ^ 1u;
-                cnt1 += set;
-            }
+        // acc0 serves ray (lane & 31), acc1 ray 32 + (lane & 31). v_permlane32_swap exchanges lanes 32..63 of m0
+        // with lanes 0..31 of m1: afterwards m0 holds, in EVERY lane, the bits of that lane's own ray computed by the
+        // low half of the wave (rows +0) and m1 those computed by the high half (rows +4).
+        const auto sw = __builtin_amdgcn_permlane32_swap(m0, m1, false, false);
+        const uint32_t full = sw[0] | (sw[1] << 16);
+        if (full != 0u) {
+            if (cnt < (uint32_t)kEntCap) queue32[cnt * kBlock + tid] = full;
+            cnt += 1;
+            tbits |= 1u << T;
+            if (VERIFY) ncand += (uint32_t)__popc(full);
         }
+        // a full queue is drained on the spot (exact phase 2 on what is queued so far); verify mode keeps
+        // everything for its end-of-scan audit and treats an overflow as "every sphere is a candidate"
+        if (!VERIFY && __any(cnt >= (uint32_t)kEntCap)) drain();
     }
     // ---- phase 2: exact arithmetic on the candidates of this lane's own ray ----
-    float best = kMaxT;
-    int idx = -1;
-    const bool lo = lane < 32;
-    const uint32_t cnt_own = lo ? cnt0 : cnt1;                                  // my ray, found by me
-    const uint32_t cnt_par = (uint32_t)__shfl_xor((int)(lo ? cnt1 : cnt0), 32);   // my ray, found by lane ^ 32
-    const uint16_t *q_own = queue + (lo ? 0 : kSubCap) * kBlock + tid;
-    const uint16_t *q_par = queue + (lo ? 0 : kSubCap) * kBlock + (tid ^ 32);
-    const uint32_t cnt = cnt_own + cnt_par;
     for (uint32_t j = 0; j < A.n_large; ++j) {  // wave-uniform: spheres outside the prefilter's range
         const int k = (int)A.large[j];
         if (active) exact_candidate(sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx);
     }
-    const bool overflow = cnt_own > (uint32_t)kSubCap || cnt_par > (uint32_t)kSubCap;
+    const bool overflow = VERIFY && cnt > (uint32_t)kEntCap;
     if (__any(overflow || (VERIFY && active))) {
         if (overflow || VERIFY) {
             // queue overflow (ray far outside the prefilter's accuracy range) or verify mode: brute force
@@ -500,22 +525,27 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                     if (b * b - a * cc > 0.0f) {
                         bool found = overflow;
                         for (uint32_t j = 0; j < A.n_large && !found; ++j) found = ((int)A.large[j] == k);
-                        for (uint32_t j = 0; j < cnt_own && j < (uint32_t)kSubCap && !found; ++j) found = (s_tile_sphere[q_own[j * kBlock]] == k);
-                        for (uint32_t j = 0; j < cnt_par && j < (uint32_t)kSubCap && !found; ++j) found = (s_tile_sphere[q_par[j * kBlock]] == k);
+                        uint32_t tb = tbits;
+                        for (uint32_t j = 0; tb != 0u && j < (uint32_t)kEntCap && !found; ++j) {
+                            const uint32_t T = (uint32_t)__builtin_ctz(tb);
+                            tb &= tb - 1u;
+                            for (uint32_t mk = queue32[j * kBlock + tid]; mk != 0u && !found; mk &= mk - 1u)
+                                found = (s_tile_sphere[slot_of(T, (uint32_t)__builtin_ctz(mk))] == k);
+                        }
                         atomicAdd(&A.debug[3], 1ull);
                         if (!found) {
                             if (atomicAdd(&A.debug[0], 1ull) == 0ull) {  // record the first miss for offline analysis
                                 float *dbg = reinterpret_cast<float *>(A.debug + 4);
                                 dbg[0] = o.x, dbg[1] = o.y, dbg[2] = o.z, dbg[3] = d.x, dbg[4] = d.y, dbg[5] = d.z;
                                 dbg[6] = (float)k, dbg[7] = b * b - a * cc, dbg[8] = 0.f;
-                                dbg[9] = a, dbg[10] = (float)cnt;
+                                dbg[9] = a, dbg[10] = (float)ncand;
                             }
                         }
                     }
                 }
             }
             if (VERIFY && active) {
-                atomicAdd(&A.debug[1], (unsigned long long)cnt);
+                atomicAdd(&A.debug[1], (unsigned long long)ncand);
                 if (overflow) atomicAdd(&A.debug[2], 1ull);
             }
             if (overflow) {
@@ -524,15 +554,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
             }
         }
     }
-    if (!overflow) {
-        for (uint32_t j = 0; __any(j < cnt); ++j) {
-            if (j < cnt) {
-                const uint32_t slot = (j < cnt_own) ? q_own[j * kBlock] : q_par[(j - cnt_own) * kBlock];
-                const int k = s_tile_sphere[slot];
-                exact_candidate(sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx);
-            }
-        }
-    }
+    if (!overflow) drain();
     t_out = best;
     return idx;
 }
