@@ -372,15 +372,25 @@ __device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d,
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int e = 0; e < 8; ++e) own[c][h][e] = slot[c * 16 + h * 8 + e];
-    const bool lo = lane < 32;
+    // B operand of v_mfma_f32_32x32x16_f16: lane l supplies column (ray) l & 31, k-half l >> 5. For the MFMA over rays
+    // 0..31 the low lanes supply their own k-half 0 and the high lanes k-half 1 of ray l - 32; for rays 32..63 the
+    // low lanes supply k-half 0 of ray l + 32 and the high lanes their own k-half 1. v_permlane32_swap(X = k-half 0,
+    // Y = k-half 1) produces exactly that pair: X' = {lo: X[l], hi: Y[l-32]}, Y' = {lo: X[l+32], hi: Y[l]}.
+    (void)lane;
     RayFeat f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        const half8 mine = lo ? own[c][0] : own[c][1];   // own ray, this lane's k-half
-        const half8 give = lo ? own[c][1] : own[c][0];   // what lane^32 needs of my ray
-        const half8 other = shfl_xor32(give);            // partner ray, this lane's k-half
-        f.b0[c] = lo ? mine : other;                     // MFMA over rays 0..31
-        f.b1[c] = lo ? other : mine;                     // MFMA over rays 32..63
+        union { half8 h; uint32_t u[4]; } x, y, b0, b1;
+        x.h = own[c][0];
+        y.h = own[c][1];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(x.u[w], y.u[w], false, false);
+            b0.u[w] = sw[0];
+            b1.u[w] = sw[1];
+        }
+        f.b0[c] = b0.h;
+        f.b1[c] = b1.h;
     }
     return f;
 }
