@@ -439,10 +439,19 @@ __device__ __forceinline__ void exact_candidate(const float4 c, int k, f3 o, f3 
 template <bool VERIFY, bool MOVING>
 __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *sph, const uint4 *s_afrag,
                                                    const uint16_t *s_tile_sphere, uint16_t *queue,
-                                                   f3 o, f3 d, float a, bool active, float time, float &t_out) {
+                                                   f3 o, f3 d, float a, bool active, float time, float &t_out,
+                                                   unsigned long long *sec = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave_base = tid & ~63;
+#ifdef PT_SECTIONS
+    unsigned long long sub_last = __builtin_readcyclecounter();
+#define PT_SUB(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); sec[i] += now_ - sub_last; sub_last = now_; } while (0)
+#else
+    (void)sec;
+#define PT_SUB(i) do { } while (0)
+#endif
     const RayFeat rf = make_ray_features(A, o, d, a, active, lane);
     const int row_off = 4 * (lane >> 5);
+    PT_SUB(5);
     const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // Candidates of MY ray, one 32-bit mask per tile that has any: bits 0..15 come from my own accumulators (my
     // rows of the tile), bits 16..31 from lane ^ 32's (the other 16 rows), exchanged with one cross-half swap per
@@ -514,6 +523,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
         // everything for its end-of-scan audit and treats an overflow as "every sphere is a candidate"
         if (!VERIFY && __any(cnt >= (uint32_t)kEntCap)) drain();
     }
+    PT_SUB(6);
     // ---- phase 2: exact arithmetic on the candidates of this lane's own ray ----
     for (uint32_t j = 0; j < A.n_large; ++j) {  // wave-uniform: spheres outside the prefilter's range
         const int k = (int)A.large[j];
@@ -565,6 +575,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
         }
     }
     if (!overflow) drain();
+    PT_SUB(7);
     t_out = best;
     return idx;
 }
@@ -779,6 +790,14 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
     float *path = A.stack_in_lds ? (s_path + tid)
                                  : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * kBlock + tid);
 
+#ifdef PT_SECTIONS
+    // development aid (-DPT_SECTIONS): per-wave cycle counts of the main loop's sections (s_memtime deltas at
+    // wave-uniform points), summed into debug[16..23]; ptgpu.hip prints the shares after each launch
+    unsigned long long sec_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sec_last = __builtin_readcyclecounter();
+#define PT_SEC(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); sec_t[i] += now_ - sec_last; sec_last = now_; } while (0)
+#else
+#define PT_SEC(i) do { } while (0)
+#endif
     bool have = false, exhausted = false, need_cam = true, trav_new = false;
     uint32_t lane_tile = 0, pix_rays = 0;
     BvhTrav trav{0, kMaxT, -1, 0u, false};
@@ -827,6 +846,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             if (__ballot(!exhausted) == 0ull) break;
             continue;
         }
+        PT_SEC(0);
 
         // ---- camera.rs:56-68 + scene.rs:107-108: start the next sample
         if (have && need_cam) {
@@ -849,6 +869,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             trav_new = true;
         }
 
+        PT_SEC(1);
         // ---- hitable.rs:39-65: closest hit (inactive lanes carry a null ray)
         const f3 ro = have ? o : mk3(0.f, 0.f, 0.f);
         const f3 rd = have ? d : mk3(0.f, 0.f, 0.f);
@@ -868,11 +889,16 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             t_hit = trav.best;
         } else if (MFMA)
             idx = intersect_list_mfma<VERIFY, MOVING>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere,
-                                                      s_queue, ro, rd, a, have, rtime, t_hit);
+                                                      s_queue, ro, rd, a, have, rtime, t_hit
+#ifdef PT_SECTIONS
+                                                      , sec_t
+#endif
+                                                      );
         else
             idx = intersect_list(SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, (int)A.n_spheres_pad, s_queue + tid, ro, rd,
                                  a, t_hit);
 
+        PT_SEC(2);
         // ---- scene.rs:49-71 one level of ray_trace (BVH mode: only lanes whose traversal has finished)
         if (have && !(BVH && trav.active)) {
             nrays += 1;
@@ -985,8 +1011,14 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                 }
             }
         }
+        PT_SEC(3);
     }
 
+#ifdef PT_SECTIONS
+    PT_SEC(4);
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&A.debug[16 + i], sec_t[i]);
+#endif
     if (A.wave_end && lane == 0) A.wave_end[blockIdx.x * (kBlock / 64) + (tid >> 6)] = wall_clock64();
     // scene.rs:118 ray_count: wave reduce, one atomic per wave
     unsigned long long total = nrays;

@@ -1149,6 +1149,20 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     s->last_grid = grid;
     s->last_block = kBlock;
     s->last_lds = lds;
+#ifdef PT_SECTIONS
+    {   // development aid (-DPT_SECTIONS builds only): where the waves' cycles go
+        (void)hipStreamSynchronize(stream);
+        unsigned long long sec[8];
+        (void)hipMemcpy(sec, s->d_debug + 16, sizeof sec, hipMemcpyDeviceToHost);
+        (void)hipMemset(s->d_debug + 16, 0, sizeof sec);
+        double tot = 0;
+        for (int i = 0; i < 5; ++i) tot += (double)sec[i];
+        static const char *names[8] = {"refill", "camera", "intersect", "shade+terminal", "epilogue", "  features", "  tiles", "  phase2"};
+        fprintf(stderr, "[ptgpu sections]");
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)sec[i] / tot);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (timing) {  // development aid: distribution of wave finish times
         (void)hipStreamSynchronize(stream);
         const uint32_t nw = grid * (kBlock / 64);
