@@ -597,10 +597,10 @@ __device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : 
 // subtree's AABB test itself is the reference's, evaluated with the reference's arithmetic. Equal-t
 // ties are resolved by the precomputed DFS rank of the leaf instead of by visiting order.
 struct DWideNode {  // 64 B
-    float lmin[3], lmax[3];  // AABB of lhs when lhs is an inner node
-    float rmin[3], rmax[3];  // AABB of rhs when rhs is an inner node
+    float lmin[3], lmax[3];  // lhs inner node: box CENTRE, HALF extent; lhs leaf: the sphere (centre, lmax[0] = radius)
+    float rmin[3], rmax[3];  // same for rhs
     int32_t lhs, rhs;        // >= 0 inner node, < 0 ~sphere
-    uint32_t pad0, pad1;     // internal tree: smallest |radius| below lhs / rhs (float bits)
+    uint32_t pad0, pad1;     // 1 / smallest |radius| below lhs / rhs (float bits)
 };
 
 // aabb.rs:46-58 (exact), also returning the entry distance max(t0x, t0y, t0z, t_min) for ordering
@@ -657,15 +657,15 @@ __device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, const float4 c, 
 // <= ~1.3e-6 * a * (|o-c|^2 + r^2), i.e. a sphere behaves as if its radius were larger by at most
 // ~0.65e-6 * (|o-c|^2 + r^2) / r; the box is padded by >= 4x that bound (r_min = smallest radius below the
 // node) plus an absolute epsilon. NaNs (0 * inf) count as a hit.
-__device__ __forceinline__ bool accel_box_hit(const float mn[3], const float mx[3], float rmin, f3 o, f3 rcp, float limit,
+__device__ __forceinline__ bool accel_box_hit(const float c[3], const float h[3], float inv_rmin, f3 o, f3 rcp, float limit,
                                               float &t_enter) {
-    const float cx = 0.5f * (mn[0] + mx[0]) - o.x, cy = 0.5f * (mn[1] + mx[1]) - o.y, cz = 0.5f * (mn[2] + mx[2]) - o.z;
-    const float hx = mx[0] - mn[0], hy = mx[1] - mn[1], hz = mx[2] - mn[2];
-    const float reach2 = 2.0f * ((cx * cx + cy * cy + cz * cz) + 0.25f * (hx * hx + hy * hy + hz * hz));
-    const float pad = 3.0e-6f * reach2 / rmin + 1.0e-4f;
-    const float ax = (mn[0] - pad - o.x) * rcp.x, bx = (mx[0] + pad - o.x) * rcp.x;
-    const float ay = (mn[1] - pad - o.y) * rcp.y, by = (mx[1] + pad - o.y) * rcp.y;
-    const float az = (mn[2] - pad - o.z) * rcp.z, bz = (mx[2] + pad - o.z) * rcp.z;
+    const float cx = c[0] - o.x, cy = c[1] - o.y, cz = c[2] - o.z;
+    const float reach2 = 2.0f * ((cx * cx + cy * cy + cz * cz) + (h[0] * h[0] + h[1] * h[1] + h[2] * h[2]));
+    const float pad = 3.0e-6f * reach2 * inv_rmin + 1.0e-4f;
+    const float hx = h[0] + pad, hy = h[1] + pad, hz = h[2] + pad;
+    const float ax = (cx - hx) * rcp.x, bx = (cx + hx) * rcp.x;
+    const float ay = (cy - hy) * rcp.y, by = (cy + hy) * rcp.y;
+    const float az = (cz - hz) * rcp.z, bz = (cz + hz) * rcp.z;
     const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
     t_enter = tn;

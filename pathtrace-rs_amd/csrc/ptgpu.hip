@@ -372,12 +372,23 @@ AccelRef accel_build(std::vector<AccelItem> &items, size_t lo, size_t hi, std::v
     const AccelRef l = accel_build(items, lo, mid, nodes), r = accel_build(items, mid, hi, nodes);
     DWideNode w;
     memset(&w, 0, sizeof w);
-    memcpy(w.lmin, l.mn, 12), memcpy(w.lmax, l.mx, 12), memcpy(w.rmin, r.mn, 12), memcpy(w.rmax, r.mx, 12);
+    // inner children are stored as box centre / half extent (the slab test then needs no midpoint arithmetic);
+    // the half extent is rounded up until centre -+ half covers the box in exact arithmetic
+    auto centre_half = [](const float mn[3], const float mx[3], float c[3], float h[3]) {
+        for (int k = 0; k < 3; ++k) {
+            c[k] = (float)(0.5 * ((double)mn[k] + (double)mx[k]));
+            h[k] = (float)(0.5 * ((double)mx[k] - (double)mn[k]));
+            while ((double)c[k] - (double)h[k] > (double)mn[k] || (double)c[k] + (double)h[k] < (double)mx[k]) h[k] = std::nextafter(h[k], 3.0e38f);
+        }
+    };
+    centre_half(l.mn, l.mx, w.lmin, w.lmax);
+    centre_half(r.mn, r.mx, w.rmin, w.rmax);
     w.lhs = l.ref, w.rhs = r.ref;
     // a leaf child needs no box: its slot carries the sphere (centre, signed radius) so a leaf test costs no fetch
     if (l.ref < 0) memcpy(w.lmin, l.sph, 12), w.lmax[0] = l.sph[3];
     if (r.ref < 0) memcpy(w.rmin, r.sph, 12), w.rmax[0] = r.sph[3];
-    memcpy(&w.pad0, &l.rmin, 4), memcpy(&w.pad1, &r.rmin, 4);
+    const float inv_l = 1.0f / l.rmin, inv_r = 1.0f / r.rmin;  // the pad of the conservative box test divides by the smallest radius below
+    memcpy(&w.pad0, &inv_l, 4), memcpy(&w.pad1, &inv_r, 4);
     nodes.push_back(w);
     AccelRef out{};
     out.ref = (int32_t)nodes.size() - 1;
