@@ -967,15 +967,15 @@ struct ora_scene {
 };
 
 /* arenas are sized up-front so pointers stay stable (typed_arena semantics) */
-static void storage_init(storage *st, xoshiro *rng, size_t max_items) {
+static void storage_init(storage *st, xoshiro *rng, size_t max_items, size_t max_shapes) {
     memset(st, 0, sizeof(*st));
     st->cap_textures = max_items + 16; st->textures = calloc(st->cap_textures, sizeof(texture));
     st->cap_materials = max_items + 16; st->materials = calloc(st->cap_materials, sizeof(material));
     st->cap_spheres = max_items + 16; st->spheres = calloc(st->cap_spheres, sizeof(sphere));
     st->cap_nodes = max_items + 16; st->nodes = calloc(st->cap_nodes, sizeof(bvhnode));
     st->moving = calloc(max_items + 16, sizeof(moving_sphere));
-    st->rects = calloc(64, sizeof(rect)); st->cuboids = calloc(16, sizeof(cuboid));
-    st->instances = calloc(16, sizeof(instance)); st->media = calloc(16, sizeof(constant_medium));
+    st->rects = calloc(max_shapes + 64, sizeof(rect)); st->cuboids = calloc(max_shapes + 16, sizeof(cuboid));
+    st->instances = calloc(max_shapes + 16, sizeof(instance)); st->media = calloc(max_shapes + 16, sizeof(constant_medium));
     perlin_new(&st->perlin_noise, rng); /* storage.rs:41 */
 }
 static void storage_free(storage *st) {
@@ -1409,7 +1409,7 @@ ora_scene *ora_scene_from_preset(const char *name, uint32_t width, uint32_t heig
     xoshiro rng, rng0;
     xoshiro_seed_from_u64(&rng, 0); /* params.rs:21-27 (random_seed = false) */
     rng0 = rng;
-    storage_init(&sc->st, &rng, which == 4 ? 2 * 10100 : 2 * 600); /* storage.rs:28-43: 1536 draws */
+    storage_init(&sc->st, &rng, which == 4 ? 2 * 10100 : 2 * 600, 0); /* storage.rs:28-43: 1536 draws */
     hitvec hv = {0};
     switch (which) {
     case 0: preset_random_spheres(sc, width, height, &rng, &hv); break;
@@ -1444,6 +1444,109 @@ ora_scene *ora_scene_from_preset(const char *name, uint32_t width, uint32_t heig
         sc->build_draws = n;
     }
     return sc;
+}
+
+static camera cam_from_floats(const float *f);
+/* Test helper: a scene from the flat description ora_scene_export_* produces (ptref.h), so tests can feed
+ * arbitrary worlds to the oracle and to the product alike. The Perlin tables are those of Storage::new with the
+ * seed-0 rng (storage.rs:28-43); the BVH, when asked for, is built by BVHNode::new (bvh.rs:64-94) continuing that
+ * rng. Isotropic rows must come after all other materials (they are the media's phase functions). Returns NULL on
+ * a malformed description. */
+ora_scene *ora_scene_from_world(const uint32_t *records16, uint32_t n_hitables, const float *transforms24,
+                                uint32_t n_transforms, const float *materials6, uint32_t n_materials,
+                                const float *textures7, uint32_t n_textures, const float *cam24, int has_sky,
+                                const float *sky3, int use_bvh) {
+    if (!records16 || !n_hitables || !materials6 || !n_materials || !cam24) return NULL;
+    ora_scene *sc = calloc(1, sizeof(*sc));
+    xoshiro rng, rng0;
+    xoshiro_seed_from_u64(&rng, 0);
+    rng0 = rng;
+    storage_init(&sc->st, &rng, 2 * (size_t)n_hitables + n_materials + n_textures + 16, n_hitables);
+    storage *st = &sc->st;
+    for (uint32_t i = 0; i < n_textures; ++i) {
+        const float *r = textures7 + 7 * i;
+        texture t; memset(&t, 0, sizeof t);
+        t.kind = (int)r[0]; t.color = V3(r[1], r[2], r[3]); t.scale = r[6];
+        if (t.kind == TEX_CHECKER) {
+            if (r[4] < 0 || r[5] < 0 || (uint32_t)r[4] >= i || (uint32_t)r[5] >= i) goto bad;
+            t.odd = &st->textures[(uint32_t)r[4]]; t.even = &st->textures[(uint32_t)r[5]];
+        } else if (t.kind == TEX_NOISE) t.noise = &st->perlin_noise;
+        else if (t.kind != TEX_CONSTANT) goto bad;
+        alloc_texture(st, t);
+    }
+    uint32_t n_arena = 0;
+    for (uint32_t i = 0; i < n_materials; ++i) {
+        const float *r = materials6 + 6 * i;
+        const int kind = (int)r[0];
+        if (kind == MAT_ISOTROPIC) continue;
+        if (n_arena != i || kind < 0 || kind > MAT_DIFFUSE_LIGHT) goto bad; /* isotropic rows last */
+        material m; memset(&m, 0, sizeof m);
+        m.kind = kind; m.albedo = V3(r[1], r[2], r[3]);
+        if (kind == MAT_METAL) m.fuzz = r[4];
+        if (kind == MAT_DIELECTRIC) m.ref_idx = r[4];
+        if (kind == MAT_LAMBERTIAN || kind == MAT_DIFFUSE_LIGHT) {
+            if (r[5] < 0 || (uint32_t)r[5] >= n_textures) goto bad;
+            m.tex = &st->textures[(uint32_t)r[5]];
+        }
+        alloc_material(st, m);
+        ++n_arena;
+    }
+    {
+        hitvec hv = {0};
+        for (uint32_t i = 0; i < n_hitables; ++i) {
+            const uint32_t *w = records16 + 16 * i;
+            float p[10], density; memcpy(p, w + 6, 40); memcpy(&density, w + 5, 4);
+            const int32_t tr = (int32_t)w[3], med = (int32_t)w[4];
+            if (w[1] >= n_arena || (tr >= 0 && (uint32_t)tr >= n_transforms) || w[0] > 5) { free(hv.v); goto bad; }
+            const material *m = &st->materials[w[1]];
+            hitable h; memset(&h, 0, sizeof h);
+            switch (w[0]) {
+            case 0: { sphere sp = { V3(p[0], p[1], p[2]), p[3] }; h.kind = HIT_SPHERE; h.sph = alloc_sphere(st, sp); h.mat = m; break; }
+            case 1: {
+                moving_sphere ms; ms.centre_start = V3(p[0], p[1], p[2]); ms.centre_delta = V3(p[3], p[4], p[5]);
+                ms.radius = p[6]; ms.time_start = p[7]; ms.inv_time_delta = p[8];
+                st->moving[st->n_moving] = ms; h.kind = HIT_MOVING_SPHERE; h.msph = &st->moving[st->n_moving++]; h.mat = m; break; }
+            case 5: h = mk_cuboid(st, V3(p[0], p[1], p[2]), V3(p[3], p[4], p[5]), m); break;
+            default: h = mk_rect(st, rect_new((int)w[0] - 2, p[0], p[1], p[2], p[3], p[4], w[2] != 0), m); break;
+            }
+            if (tr >= 0) { /* Instance keeps the transform AND the inverse it was given (instance.rs:16-22 computes it once) */
+                const float *a = transforms24 + 24 * tr;
+                hitable hi; memset(&hi, 0, sizeof hi); hi.kind = HIT_INSTANCE;
+                instance *in = &st->instances[st->n_instances++];
+                in->child = h;
+                in->transform.x_axis = V3(a[0], a[1], a[2]); in->transform.y_axis = V3(a[3], a[4], a[5]);
+                in->transform.z_axis = V3(a[6], a[7], a[8]); in->transform.translation = V3(a[9], a[10], a[11]);
+                a += 12;
+                in->inv_transform.x_axis = V3(a[0], a[1], a[2]); in->inv_transform.y_axis = V3(a[3], a[4], a[5]);
+                in->inv_transform.z_axis = V3(a[6], a[7], a[8]); in->inv_transform.translation = V3(a[9], a[10], a[11]);
+                hi.inst = in; h = hi;
+            }
+            if (med >= 0) {
+                if ((uint32_t)med >= n_materials || (int)materials6[6 * med] != MAT_ISOTROPIC) { free(hv.v); goto bad; }
+                const float ti = materials6[6 * med + 5];
+                if (ti < 0 || (uint32_t)ti >= n_textures) { free(hv.v); goto bad; }
+                h = mk_constant_medium(st, h, density, &st->textures[(uint32_t)ti]);
+            }
+            hv_push(&hv, h);
+        }
+        sc->cam = cam_from_floats(cam24);
+        sc->has_sky = has_sky;
+        if (has_sky) sc->sky = V3(sky3[0], sky3[1], sky3[2]);
+        sc->use_bvh = use_bvh;
+        sc->list.hitables = malloc(hv.len * sizeof(hitable));
+        memcpy(sc->list.hitables, hv.v, hv.len * sizeof(hitable));
+        sc->list.len = hv.len;
+        memset(&sc->world, 0, sizeof sc->world);
+        if (use_bvh) { sc->world.kind = HIT_BVHNODE; sc->world.node = bvh_new(st, &rng, hv.v, hv.len); }
+        else { sc->world.kind = HIT_LIST; sc->world.list = &sc->list; }
+        free(hv.v);
+    }
+    (void)rng0;
+    return sc;
+bad:
+    storage_free(&sc->st);
+    free(sc);
+    return NULL;
 }
 
 void ora_scene_free(ora_scene *s) {

@@ -39,6 +39,16 @@ typedef struct ora_scene ora_scene;
 ora_scene *ora_scene_from_preset(const char *name, uint32_t width,
                                  uint32_t height, int use_bvh);
 void ora_scene_free(ora_scene *s);
+/* Test helper: build the scene from the flat description the export functions below produce
+ * (records16 / transforms24 / materials rows6 / textures rows7 / cam24), so arbitrary worlds can be
+ * fed to the oracle and to the product alike. Perlin tables = Storage::new with the seed-0 rng;
+ * use_bvh builds the tree with BVHNode::new (bvh.rs:64-94). Isotropic material rows (the media's
+ * phase functions) must come last. NULL on a malformed description. */
+ora_scene *ora_scene_from_world(const uint32_t *records16, uint32_t n_hitables,
+                                const float *transforms24, uint32_t n_transforms,
+                                const float *materials6, uint32_t n_materials,
+                                const float *textures7, uint32_t n_textures,
+                                const float *cam24, int has_sky, const float *sky3, int use_bvh);
 
 /* ---- Scene::update (scene.rs:73-121) ------------------------------------
  * buffer: width*height*3 floats, row 0 = bottom row, read AND written

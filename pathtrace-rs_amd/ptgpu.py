@@ -214,6 +214,36 @@ class SceneDesc:
         return d
 
 
+class WorldDesc(SceneDesc):
+    """Owns the storage behind a pt_world_desc: `hitables` is an [n, 16] uint32 array of 64-byte pt_hitable records,
+    `transforms` an [m, 24] float32 array of pt_affine (Affine3A, inverse); the tables are SceneDesc's."""
+
+    def __init__(self, hitables, transforms, materials, textures, perlin=None, bvh_nodes=None, bvh_root=-1, sky=None):
+        super().__init__(np.zeros((0, 4), np.float32), np.zeros(0, np.uint32), materials, textures, perlin=perlin,
+                         bvh_nodes=bvh_nodes, bvh_root=bvh_root, sky=sky)
+        self.hitables = np.ascontiguousarray(hitables, dtype=np.uint32).reshape(-1, 16)
+        self.transforms = np.ascontiguousarray(transforms, dtype=np.float32).reshape(-1, 24)
+
+    def struct(self):
+        d = PtWorldDesc()
+        d.n_hitables = len(self.hitables)
+        d.hitables = C.cast(self.hitables.ctypes.data, C.POINTER(PtHitable))
+        d.n_transforms = len(self.transforms)
+        d.transforms = C.cast(self.transforms.ctypes.data, C.POINTER(PtAffine)) if len(self.transforms) else None
+        d.n_materials = self.n_materials
+        d.materials = C.cast(self.materials, C.POINTER(PtMaterial))
+        d.n_textures = self.n_textures
+        d.textures = C.cast(self.textures, C.POINTER(PtTexture))
+        d.perlin = C.pointer(self.perlin) if self.perlin is not None else None
+        d.n_bvh_nodes = self.n_bvh_nodes
+        d.bvh_nodes = C.cast(self.bvh_nodes, C.POINTER(PtBvhNode)) if self.bvh_nodes is not None else None
+        d.bvh_root = self.bvh_root if self.n_bvh_nodes else -1
+        d.has_sky = 1 if self.sky is not None else 0
+        if self.sky is not None:
+            d.sky[:] = [float(c) for c in self.sky]
+        return d
+
+
 class Scene:
     """pt_scene handle (Scene::new, scene.rs:25-31)."""
 
@@ -221,7 +251,8 @@ class Scene:
         self._h = C.c_void_p()
         self._desc = desc  # keep storage alive during create
         d = desc.struct()
-        _check(lib().pt_scene_create(C.byref(d), device, C.byref(self._h)))
+        create = lib().pt_scene_create_world if isinstance(desc, WorldDesc) else lib().pt_scene_create
+        _check(create(C.byref(d), device, C.byref(self._h)))
 
     def close(self):
         if self._h:

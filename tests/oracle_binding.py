@@ -40,6 +40,8 @@ def _bind(L):
     L.ora_scene_from_preset.restype = vp
     L.ora_scene_from_preset.argtypes = [C.c_char_p, u32, u32, C.c_int]
     L.ora_scene_free.argtypes = [vp]
+    L.ora_scene_from_world.restype = vp
+    L.ora_scene_from_world.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32, vp, C.c_int, vp, C.c_int]
     L.ora_scene_free.restype = None
     L.ora_scene_update.restype = u64
     L.ora_scene_update.argtypes = [vp, u32, u32, u32, u32, u32, vp, C.c_int]
@@ -107,6 +109,26 @@ class OracleScene:
             raise KeyError("unrecognised preset %r" % preset)
         self.preset, self.width, self.height, self.use_bvh = preset, width, height, bool(use_bvh)
 
+    @classmethod
+    def from_world(cls, hitables, transforms, materials, textures, camera, width, height, sky=None, use_bvh=False,
+                   library=None):
+        """Scene from the flat description (the arrays export() returns): arbitrary worlds for parity tests."""
+        self = cls.__new__(cls)
+        self.L = library or lib()
+        rec = np.ascontiguousarray(hitables, dtype=np.uint32).reshape(-1, 16)
+        xf = np.ascontiguousarray(transforms, dtype=np.float32).reshape(-1, 24)
+        mats = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 6)
+        texs = np.ascontiguousarray(textures, dtype=np.float32).reshape(-1, 7)
+        cam = np.ascontiguousarray(camera, dtype=np.float32).reshape(24)
+        sk = np.ascontiguousarray(sky if sky is not None else [0, 0, 0], dtype=np.float32)
+        self.h = self.L.ora_scene_from_world(rec.ctypes.data, len(rec), xf.ctypes.data, len(xf), mats.ctypes.data, len(mats),
+                                             texs.ctypes.data, len(texs), cam.ctypes.data, 1 if sky is not None else 0,
+                                             sk.ctypes.data, 1 if use_bvh else 0)
+        if not self.h:
+            raise ValueError("malformed world description")
+        self.preset, self.width, self.height, self.use_bvh = "<world>", width, height, bool(use_bvh)
+        return self
+
     def close(self):
         if self.h:
             self.L.ora_scene_free(self.h)
@@ -172,6 +194,16 @@ class OracleScene:
                     has_perlin=bool(L.ora_scene_has_perlin_texture(h)), bvh_minmax=minmax[:nn], bvh_children=lr[:nn],
                     bvh_root=L.ora_scene_bvh_root(h), camera=cam, sky=(sky if has_sky else None),
                     build_draws=L.ora_scene_build_draws(h))
+
+
+def to_ptgpu_world_desc(ptgpu, ex):
+    """Oracle export -> the product's pt_world_desc (general worlds; the same description fed to both sides)."""
+    materials = [(int(r[0]), r[1:4], r[4], int(r[5])) for r in ex["materials"]]
+    textures = [(int(r[0]), r[1:4], int(r[4]), int(r[5]), r[6]) for r in ex["textures"]]
+    bvh = (ex["bvh_minmax"], ex["bvh_children"]) if len(ex["bvh_minmax"]) else None
+    return ptgpu.WorldDesc(ex["hitables"], ex["transforms"], materials, textures,
+                           perlin=ex["perlin"] if ex["has_perlin"] else None, bvh_nodes=bvh,
+                           bvh_root=ex["bvh_root"], sky=ex["sky"])
 
 
 def to_ptgpu_desc(ptgpu, ex):

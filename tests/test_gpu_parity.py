@@ -432,6 +432,103 @@ def test_world_progressive_frames_and_shards(ptgpu, pthost, oracle):
     assert total == total_full and np.array_equal(stitched.cpu().numpy(), frame0)
 
 
+def _random_world(oracle, seed, n, kinds, W, H, moving_times=((0.0, 1.0),), media=True, instances=True, sky=None):
+    """A seeded world mixing the Hitable arms in `kinds` (0 Sphere, 1 MovingSphere, 2-4 Rect, 5 Cuboid), some inside an
+    Instance (arbitrary invertible affine map, inverse supplied as Instance::new would store it) and/or a
+    ConstantMedium, with every material kind. Returned as the flat description both sides consume."""
+    rng = np.random.default_rng(seed)
+    tex = [[0, *rng.uniform(0.1, 0.9, 3), -1, -1, 0] for _ in range(5)]
+    tex.append([1, 0, 0, 0, 0, 1, 0])                                   # checker(constant, constant)
+    tex.append([0, 6.0, 5.0, 4.0, -1, -1, 0])                           # emitter colour
+    mats = [[0, 0, 0, 0, 0, t] for t in range(6)]                       # lambertians (incl. the checker)
+    mats += [[1, *rng.uniform(0.5, 1.0, 3), f, -1] for f in (0.0, 0.3)]  # metals
+    mats += [[2, 0, 0, 0, 1.5, -1], [3, 0, 0, 0, 0, 6]]                  # dielectric, diffuse light
+    n_surface = len(mats)
+    rec = np.zeros((n, 16), np.uint32)
+    pf = rec[:, 6:].view(np.float32)
+    xfs = []
+    for i in range(n):
+        k = int(rng.choice(kinds))
+        c = rng.uniform(-4, 4, 3).astype(np.float32)
+        rec[i, 0], rec[i, 1], rec[i, 3], rec[i, 4] = k, int(rng.integers(0, n_surface)), 0xffffffff, 0xffffffff
+        if k == 0:
+            pf[i, :4] = [*c, rng.uniform(0.2, 0.9) * (1 if rng.random() > 0.1 else -1)]
+        elif k == 1:
+            t0, t1 = moving_times[int(rng.integers(0, len(moving_times)))]
+            pf[i, :9] = [*c, *rng.uniform(-0.6, 0.6, 3), rng.uniform(0.2, 0.7), t0, np.float32(1.0) / (np.float32(t1) - np.float32(t0))]
+        elif k in (2, 3, 4):
+            a0, b0 = rng.uniform(-4, 2, 2)
+            pf[i, :5] = [a0, a0 + rng.uniform(0.5, 3), b0, b0 + rng.uniform(0.5, 3), rng.uniform(-4, 4)]
+            rec[i, 2] = int(rng.integers(0, 2))
+        else:
+            pf[i, :6] = [*c, *(c + rng.uniform(0.4, 2.0, 3).astype(np.float32))]
+        if instances and k >= 2 and rng.random() < 0.5:
+            m = np.linalg.qr(rng.normal(size=(3, 3)))[0] * rng.uniform(0.7, 1.4, 3)   # rotation x non-uniform scale
+            t = rng.uniform(-1, 1, 3)
+            m32, t32 = m.astype(np.float32), t.astype(np.float32)
+            inv = np.linalg.inv(m32.astype(np.float64))
+            it = -(inv @ t32.astype(np.float64))
+            xfs.append(np.concatenate([m32.T.reshape(-1), t32, inv.astype(np.float32).T.reshape(-1), it.astype(np.float32)]))  # columns
+            rec[i, 3] = len(xfs) - 1
+        if media and k in (0, 5) and rng.random() < 0.35:
+            mats.append([4, 0, 0, 0, 0, int(rng.integers(0, 5))])        # Isotropic phase function (rows at the end)
+            rec[i, 4] = len(mats) - 1
+            rec[i, 5:6].view(np.float32)[0] = rng.uniform(0.1, 0.8)
+    cam = np.zeros(24, np.float32)
+    L = oracle.lib()
+    lf, la, up = (np.asarray(v, np.float32) for v in ([9, 4, 11], [0, 0, 0], [0, 1, 0]))
+    L.ora_camera_new(lf.ctypes.data, la.ctypes.data, up.ctypes.data, 40.0, W / H, 0.1, 14.0, 0.0, 1.0, cam.ctypes.data)
+    return dict(hitables=rec, transforms=np.array(xfs, np.float32).reshape(-1, 24), materials=np.array(mats, np.float32),
+                textures=np.array(tex, np.float32), camera=cam, sky=sky)
+
+
+def _render_world_both(ptgpu, oracle, w, W, H, S, bvh, variant=0):
+    osc = oracle.OracleScene.from_world(w["hitables"], w["transforms"], w["materials"], w["textures"], w["camera"], W, H,
+                                        sky=w["sky"], use_bvh=bvh)
+    ex = osc.export()
+    assert ex["hitables"].tobytes() == w["hitables"].tobytes() and ex["transforms"].tobytes() == w["transforms"].tobytes()
+    sc = ptgpu.Scene(oracle.to_ptgpu_world_desc(ptgpu, ex), 0)
+    if variant:
+        sc.set_tuning(0, variant)
+    out = np.zeros((H, W, 3), np.float32)
+    rays = sc.update(ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0), ptgpu.PtCamera.from_floats(ex["camera"]), 0, out)
+    sc.close()
+    ref, ref_rays = osc.update(S)
+    return out, rays, ref, ref_rays
+
+
+@pytest.mark.parametrize("seed,n,kinds,bvh", [
+    (1, 24, (0, 1, 2, 3, 4, 5), False),     # every arm, list order with media drawing from the pixel's RNG
+    (2, 24, (0, 1, 2, 3, 4, 5), True),      # the same through BVHNode::ray_hit (point boxes for instances and all)
+    (3, 7, (2, 3, 4, 5), False),            # flat shapes only
+    (4, 60, (5,), True),                    # many instanced / smoky cuboids
+    (5, 1, (5,), True),                     # bvh.rs:73-79: one hitable, lhs == rhs (a medium then draws twice)
+    (6, 2, (0, 5), True),                   # bvh.rs:80-88: two hitables, one node
+])
+def test_random_general_worlds_match_the_oracle(ptgpu, oracle, seed, n, kinds, bvh):
+    W, H, S = 120, 80, 4
+    w = _random_world(oracle, seed, n, kinds, W, H, sky=(0.5, 0.6, 0.8) if seed % 2 else None)
+    out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh)
+    assert rays == ref_rays, "ray_count %d vs oracle %d; %s" % (rays, ref_rays, _report(ref, out))
+    assert np.array_equal(ref, out), _report(ref, out)
+
+
+@pytest.mark.parametrize("seed,times,bvh", [
+    (11, ((0.0, 1.0),), False),                               # one shutter interval for every moving sphere
+    (12, ((0.0, 1.0), (-0.5, 1.5), (0.0, 2.0)), False),       # per-sphere time_start / inv_time_delta
+    (13, ((0.0, 1.0), (-0.5, 1.5)), True),
+])
+def test_random_moving_sphere_worlds_on_the_fast_kernels(ptgpu, oracle, seed, times, bvh):
+    """Sphere + MovingSphere worlds big enough for the MFMA prefilter (>= 32 prefiltered spheres): the MOVING kernels,
+    the general kernel (variant 128) and the oracle must agree bit for bit."""
+    W, H, S = 160, 100, 4
+    w = _random_world(oracle, seed, 150, (0, 0, 1, 1, 1), W, H, moving_times=times, media=False, instances=False)
+    out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh)
+    assert rays == ref_rays and np.array_equal(ref, out), _report(ref, out)
+    out2, rays2, _, _ = _render_world_both(ptgpu, oracle, w, W, H, S, bvh, variant=128)
+    assert rays2 == ref_rays and np.array_equal(ref, out2), _report(ref, out2)
+
+
 def test_moving_sphere_kernels_agree_with_the_general_kernel(ptgpu, pthost, oracle):
     """`random` (Sphere + MovingSphere) runs on the MOVING instantiations of the sphere kernels: MFMA prefilter over
     swept bounding spheres in list mode, internal tree over swept boxes in BVH mode. They must reproduce the general

@@ -392,3 +392,23 @@ def test_ln_is_the_platform_logf(oracle):
     out = np.zeros_like(x)
     L.ora_ln_array(x.ctypes.data, out.ctypes.data, len(x))
     np.testing.assert_allclose(out, np.log(x.astype(np.float64)), rtol=2e-7, atol=0)
+
+
+@pytest.mark.parametrize("preset,bvh", [("cornell_smoke", False), ("random", False), ("cornell", True), ("small", True)])
+def test_scene_from_flat_description_round_trips(oracle, preset, bvh):
+    """ora_scene_from_world (what the GPU parity tests use to feed arbitrary worlds to both sides) rebuilds a preset
+    from its own export and renders the same frame, ray for ray."""
+    W, H, S = 48, 32, 3
+    a = oracle.OracleScene(preset, W, H, use_bvh=bvh)
+    ex = a.export()
+    b = oracle.OracleScene.from_world(ex["hitables"], ex["transforms"], ex["materials"], ex["textures"], ex["camera"], W, H,
+                                      sky=ex["sky"], use_bvh=bvh)
+    eb = b.export()
+    for k in ("hitables", "transforms", "materials", "textures", "camera"):
+        assert np.asarray(ex[k]).tobytes() == np.asarray(eb[k]).tobytes(), k
+    (ra, na), (rb, nb) = a.update(S), b.update(S)
+    assert na == nb and np.array_equal(ra, rb)
+    with pytest.raises(ValueError):       # material index out of range
+        bad = ex["hitables"].copy()
+        bad[0, 1] = 999
+        oracle.OracleScene.from_world(bad, ex["transforms"], ex["materials"], ex["textures"], ex["camera"], W, H)
