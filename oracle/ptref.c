@@ -1149,6 +1149,17 @@ static void preset_cornell(ora_scene *sc, uint32_t width, uint32_t height, hitve
     sc->has_sky = 1; sc->sky = V3(0.0f, 0.0f, 0.0f);
 }
 
+/* presets.rs:40-71 final_scene: camera and two textures, but the hitable list is returned EMPTY */
+static void preset_final(ora_scene *sc, uint32_t width, uint32_t height, hitvec *hv) {
+    storage *st = &sc->st;
+    (void)hv;
+    sc->cam = camera_new(V3(13.0f, 2.0f, 3.0f), V3(0.0f, 0.0f, 0.0f), V3(0.0f, 1.0f, 0.0f), 20.0f,
+                         (float)width / (float)height, 0.1f, 10.0f, 0.0f, 1.0f);
+    alloc_texture(st, tex_constant(V3(0.73f, 0.73f, 0.73f))); /* `white` / `ground`: Material VALUES, never put in the arena */
+    alloc_texture(st, tex_constant(V3(0.48f, 0.83f, 0.53f)));
+    sc->has_sky = 0;
+}
+
 /* presets.rs:853-930 */
 static void preset_smallpt(ora_scene *sc, uint32_t width, uint32_t height, hitvec *hv) {
     storage *st = &sc->st;
@@ -1402,7 +1413,9 @@ ora_scene *ora_scene_from_preset(const char *name, uint32_t width, uint32_t heig
     else if (!strcmp(name, "cornell")) which = 7;
     else if (!strcmp(name, "cornell_smoke")) which = 8;
     else if (!strcmp(name, "smallpt")) which = 9;
-    else return NULL; /* presets.rs:36 (`earth` needs media/earthmap.jpg, `final` is an empty list) */
+    else if (!strcmp(name, "final")) which = 10;
+    else return NULL; /* presets.rs:36 (`earth` needs media/earthmap.jpg, absent upstream) */
+    if (which == 10 && use_bvh) return NULL; /* BVHNode::new(&[]) is None and params.rs:37 unwraps it: the reference panics */
     (void)g_draw_probe;
 
     ora_scene *sc = calloc(1, sizeof(*sc));
@@ -1421,12 +1434,13 @@ ora_scene *ora_scene_from_preset(const char *name, uint32_t width, uint32_t heig
     case 6: preset_simple_light(sc, width, height, &hv); break;
     case 7: preset_cornell(sc, width, height, &hv, 0); break;
     case 8: preset_cornell(sc, width, height, &hv, 1); break;
-    default: preset_smallpt(sc, width, height, &hv); break;
+    case 9: preset_smallpt(sc, width, height, &hv); break;
+    default: preset_final(sc, width, height, &hv); break;
     }
     /* params.rs:29-46 new_scene */
     sc->use_bvh = use_bvh;
-    sc->list.hitables = malloc(hv.len * sizeof(hitable));
-    memcpy(sc->list.hitables, hv.v, hv.len * sizeof(hitable)); /* list order survives the BVH's in-place sort */
+    sc->list.hitables = malloc((hv.len ? hv.len : 1) * sizeof(hitable));
+    if (hv.len) memcpy(sc->list.hitables, hv.v, hv.len * sizeof(hitable)); /* list order survives the BVH's in-place sort */
     sc->list.len = hv.len;
     if (use_bvh) {
         bvhnode *root = bvh_new(&sc->st, &rng, hv.v, hv.len);
@@ -1456,7 +1470,7 @@ ora_scene *ora_scene_from_world(const uint32_t *records16, uint32_t n_hitables, 
                                 uint32_t n_transforms, const float *materials6, uint32_t n_materials,
                                 const float *textures7, uint32_t n_textures, const float *cam24, int has_sky,
                                 const float *sky3, int use_bvh) {
-    if (!records16 || !n_hitables || !materials6 || !n_materials || !cam24) return NULL;
+    if (!cam24 || (n_hitables && (!records16 || !materials6 || !n_materials)) || (use_bvh && !n_hitables)) return NULL;
     ora_scene *sc = calloc(1, sizeof(*sc));
     xoshiro rng, rng0;
     xoshiro_seed_from_u64(&rng, 0);
@@ -1533,8 +1547,8 @@ ora_scene *ora_scene_from_world(const uint32_t *records16, uint32_t n_hitables, 
         sc->has_sky = has_sky;
         if (has_sky) sc->sky = V3(sky3[0], sky3[1], sky3[2]);
         sc->use_bvh = use_bvh;
-        sc->list.hitables = malloc(hv.len * sizeof(hitable));
-        memcpy(sc->list.hitables, hv.v, hv.len * sizeof(hitable));
+        sc->list.hitables = malloc((hv.len ? hv.len : 1) * sizeof(hitable));
+        if (hv.len) memcpy(sc->list.hitables, hv.v, hv.len * sizeof(hitable));
         sc->list.len = hv.len;
         memset(&sc->world, 0, sizeof sc->world);
         if (use_bvh) { sc->world.kind = HIT_BVHNODE; sc->world.node = bvh_new(st, &rng, hv.v, hv.len); }

@@ -445,6 +445,15 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
 }
 
 extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene **scene_out) {
+    if (desc && scene_out && desc->n_spheres == 0) {  // an empty HitableList is a valid world: every ray sees the sky
+        pt_world_desc w{};
+        w.n_materials = desc->n_materials, w.materials = desc->materials;
+        w.n_textures = desc->n_textures, w.textures = desc->textures, w.perlin = desc->perlin;
+        w.n_bvh_nodes = desc->n_bvh_nodes, w.bvh_nodes = desc->bvh_nodes, w.bvh_root = desc->bvh_root;
+        w.has_sky = desc->has_sky;
+        memcpy(w.sky, desc->sky, sizeof w.sky);
+        return pt_scene_create_world(&w, device, scene_out);
+    }
     return create_sphere_scene(desc, nullptr, device, scene_out);
 }
 
@@ -671,9 +680,12 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
 extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_scene **scene_out) {
     if (!desc || !scene_out) return fail(PT_ERR_INVALID_ARG, "desc/scene_out is NULL");
     *scene_out = nullptr;
-    if (desc->n_hitables == 0 || !desc->hitables) return fail(PT_ERR_INVALID_ARG, "world has no hitables");
+    // an EMPTY list is a valid world (HitableList::ray_hit returns None for every ray: the `final` preset)
+    if (desc->n_hitables && !desc->hitables) return fail(PT_ERR_INVALID_ARG, "hitables is NULL");
     if (desc->n_hitables > 0x3fffffffu) return fail(PT_ERR_INVALID_ARG, "too many hitables");
-    if (desc->n_materials == 0 || !desc->materials) return fail(PT_ERR_INVALID_ARG, "world has no materials");
+    if (desc->n_hitables && (desc->n_materials == 0 || !desc->materials)) return fail(PT_ERR_INVALID_ARG, "world has no materials");
+    if (desc->n_materials && !desc->materials) return fail(PT_ERR_INVALID_ARG, "materials is NULL");
+    if (desc->n_hitables == 0 && desc->n_bvh_nodes) return fail(PT_ERR_INVALID_ARG, "BVH nodes over an empty list");
     if (desc->n_textures && !desc->textures) return fail(PT_ERR_INVALID_ARG, "textures is NULL");
     if (desc->n_transforms && !desc->transforms) return fail(PT_ERR_INVALID_ARG, "transforms is NULL");
     bool has_noise = false;
@@ -701,7 +713,7 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
     }
     uint32_t ref_depth = 0;
     if (desc->n_bvh_nodes) ref_depth = bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_hitables, desc->bvh_root);
-    if (sphere_like) {
+    if (sphere_like && desc->n_hitables) {
         // Sphere / MovingSphere entries only: the specialised kernels apply (MFMA prefilter, internal tree); with
         // moving entries their MOVING instantiations, and the general-world data rides along as the fallback
         std::vector<pt_sphere> sph(desc->n_hitables);

@@ -9,7 +9,8 @@
 //   cornell             presets.rs:372-456 (Rects, Instance(Cuboid))
 //   cornell_smoke       presets.rs:458-552 (ConstantMedium(Instance(Cuboid)))
 //   smallpt             presets.rs:853-930
-// `earth` needs media/earthmap.jpg (absent upstream), `final` returns an empty list (presets.rs:40-71).
+//   final               presets.rs:40-71 (returns an EMPTY list: sky only; with -B the reference panics)
+// `earth` needs media/earthmap.jpg (absent upstream).
 #include <cstdio>
 
 #include "host.hpp"
@@ -112,6 +113,15 @@ PresetResult cornell(const Params &params, Storage &st, bool smoke) {
     if (smoke) b.push(st.constant_medium(box2, 0.01f, st.alloc_constant(Vec3(0.0f, 0.0f, 0.0f))));
     else b.push(box2);
     return PresetResult{std::move(b.hitables), camera, Vec3(0.0f, 0.0f, 0.0f)};
+}
+
+// presets.rs:40-71: camera and two textures, but the list is returned EMPTY (every ray sees the sky)
+PresetResult final_scene(const Params &params, Storage &st) {
+    const Camera camera = Camera::create(Vec3(13.0f, 2.0f, 3.0f), Vec3(0.0f, 0.0f, 0.0f), Vec3(0.0f, 1.0f, 0.0f), 20.0f,
+                                         aspect_of(params), 0.1f, 10.0f, 0.0f, 1.0f);
+    (void)st.alloc_constant(Vec3(0.73f, 0.73f, 0.73f));  // `white` and `ground` are Material values, never arena entries
+    (void)st.alloc_constant(Vec3(0.48f, 0.83f, 0.53f));
+    return PresetResult{{}, camera, std::nullopt};
 }
 
 PresetResult smallpt(const Params &params, Storage &st) {  // presets.rs:853-930
@@ -229,7 +239,7 @@ PresetResult perlin_spheres(const Params &params, Xoshiro256Plus &rng, Storage &
 }  // namespace
 
 std::vector<std::string> names() {
-    return {"small", "random_spheres", "two_perlin_spheres", "aras", "perlin_spheres", "random", "simple_light", "cornell", "cornell_smoke", "smallpt"};
+    return {"small", "random_spheres", "two_perlin_spheres", "aras", "perlin_spheres", "random", "simple_light", "cornell", "cornell_smoke", "smallpt", "final"};
 }
 
 std::optional<PresetResult> from_name(const std::string &name, const Params &params, Xoshiro256Plus &rng,
@@ -243,6 +253,7 @@ std::optional<PresetResult> from_name(const std::string &name, const Params &par
     if (name == "cornell") return cornell(params, storage, false);
     if (name == "cornell_smoke") return cornell(params, storage, true);
     if (name == "smallpt") return smallpt(params, storage);
+    if (name == "final") return final_scene(params, storage);
     if (name == "small") return small(params, storage);
     if (name == "two_perlin_spheres") return two_perlin_spheres(params, storage);
     if (name == "aras") return aras(params, storage);

@@ -317,6 +317,7 @@ std::unique_ptr<Scene> Scene::new_scene(const Params &params, Xoshiro256Plus &rn
         if (h.medium_material >= 0) h.medium_material += phase_base;
         if (h.kind != PT_HIT_SPHERE || h.transform >= 0 || h.medium_material >= 0) all_spheres = false;
     }
+    if (s->hitables_.empty()) all_spheres = false;  // an empty world is traced (to the sky) by the general kernel
     s->is_world_ = !all_spheres;
     s->transforms_ = storage.transforms;
     s->textures_ = storage.textures;
@@ -333,17 +334,18 @@ std::unique_ptr<Scene> Scene::new_scene(const Params &params, Xoshiro256Plus &rn
     }
     int32_t root = -1;
     if (params.use_bvh) {  // params.rs:36-40
+        if (hitables.empty()) throw std::runtime_error("BVHNode::new on an empty list (params.rs:37 unwraps None)");
         BvhBuild bvh = build_bvh(rng, storage, hitables);
         s->bvh_nodes_ = std::move(bvh.nodes);
         root = bvh.root;
     }
     pt_world_desc &w = s->world_;
     w.n_hitables = static_cast<uint32_t>(s->hitables_.size());
-    w.hitables = s->hitables_.data();
+    w.hitables = s->hitables_.empty() ? nullptr : s->hitables_.data();
     w.n_transforms = static_cast<uint32_t>(s->transforms_.size());
     w.transforms = s->transforms_.empty() ? nullptr : s->transforms_.data();
     w.n_materials = static_cast<uint32_t>(s->materials_.size());
-    w.materials = s->materials_.data();
+    w.materials = s->materials_.empty() ? nullptr : s->materials_.data();
     w.n_textures = static_cast<uint32_t>(s->textures_.size());
     w.textures = s->textures_.data();
     w.perlin = s->perlin_.get();

@@ -127,7 +127,9 @@ class HostScene:
     def export(self):
         d = self.world_desc
         n = d.n_hitables
-        records = np.ctypeslib.as_array(C.cast(d.hitables, C.POINTER(C.c_uint32)), shape=(n, 16)).copy()
+        records = np.zeros((0, 16), np.uint32)
+        if n:
+            records = np.ctypeslib.as_array(C.cast(d.hitables, C.POINTER(C.c_uint32)), shape=(n, 16)).copy()
         transforms = np.zeros((d.n_transforms, 24), np.float32)
         if d.n_transforms:
             transforms = np.ctypeslib.as_array(C.cast(d.transforms, C.POINTER(C.c_float)), shape=(d.n_transforms, 24)).copy()

@@ -389,6 +389,16 @@ def test_world_presets_match_the_oracle(ptgpu, pthost, oracle, preset, bvh):
         assert np.array_equal(ref, out), _report(ref, out)
 
 
+def test_empty_world_renders_the_sky(ptgpu, pthost, oracle):
+    """`final` (presets.rs:40-71) has no hitables: one ray per sample, the gradient of scene.rs:40-47, bit for bit."""
+    W, H, S = 160, 100, 3
+    hs, out, rays = _world_render(ptgpu, pthost, "final", W, H, S, False)
+    ref, ref_rays = oracle.OracleScene("final", W, H).update(S)
+    assert rays == ref_rays == W * H * S and np.array_equal(ref, out), _report(ref, out)
+    with pytest.raises(ptgpu.PtError):      # -B on an empty list: the reference panics, the ABI reports UNSUPPORTED
+        hs.device_scene().update(ptgpu.PtParams(W, H, S, 10, 0, 1), hs.camera, 0, out)
+
+
 @pytest.mark.parametrize("preset,W,H,S,bvh", [("cornell_smoke", 1200, 800, 16, False), ("random", 1200, 800, 8, False),
                                               ("cornell", 1280, 720, 16, True)])
 def test_world_full_size_sampled_against_oracle(ptgpu, pthost, oracle, preset, W, H, S, bvh):

@@ -167,6 +167,24 @@ def test_shard_rows(ptgpu):
     assert ptgpu.shard_rows(10, 3, 2) == 0 and ptgpu.shard_rows(10, 0, 0) == 0
 
 
+def test_final_preset_is_an_empty_world(pthost, oracle, ptgpu):
+    """presets.rs:40-71 returns an EMPTY hitable list: list mode renders the sky, -B panics in the reference
+    (BVHNode::new(&[]) is None, params.rs:37 unwraps)."""
+    he, oe = pthost.HostScene("final", 300, 200).export(), oracle.OracleScene("final", 300, 200).export()
+    assert len(he["hitables"]) == 0 and len(oe["hitables"]) == 0 and len(he["materials"]) == 0
+    assert np.array_equal(he["textures"], oe["textures"]) and len(he["textures"]) == 2
+    assert np.array_equal(he["camera"], oe["camera"]) and he["build_draws"] == oe["build_draws"] == 1536
+    with pytest.raises(RuntimeError):
+        pthost.HostScene("final", 300, 200, use_bvh=True)
+    with pytest.raises(KeyError):
+        oracle.OracleScene("final", 300, 200, use_bvh=True)
+    # the C ABI accepts the empty list through both constructors (validation happens before the device is touched)
+    rc, msg = _world_rc(ptgpu, [], materials=[(ptgpu.MAT_LAMBERTIAN, 0)])
+    assert rc in (ptgpu.PT_OK, ptgpu.PT_ERR_NO_DEVICE), msg
+    rc, msg = _create_rc(ptgpu, _tiny_desc(ptgpu, spheres=np.zeros((0, 4), np.float32), sphere_material=[]))
+    assert rc in (ptgpu.PT_OK, ptgpu.PT_ERR_NO_DEVICE), msg
+
+
 @pytest.mark.parametrize("preset", PRESETS)
 @pytest.mark.parametrize("bvh", [False, True])
 def test_host_presets_match_the_oracle_build(pthost, oracle, preset, bvh):
