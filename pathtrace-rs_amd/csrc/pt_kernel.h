@@ -936,17 +936,20 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                 bool scattered = false;
                 f3 att = mk3(1.f, 1.f, 1.f), nd = d;
                 if (depth < A.max_depth) {
+                    // every scatter ends in `.normalize()` of some vector (material.rs:63,84,112,119): the branches
+                    // only produce that vector, the normalisation is issued once for the whole wave
+                    f3 raw = d;
                     if (m.kind == PT_MAT_LAMBERTIAN) {  // material.rs:52-67
                         const f3 target = add3(add3(point, normal), random_unit_vector(rng));
                         att = surface_colour();
-                        nd = normalize3(sub3(target, point));
+                        raw = sub3(target, point);
                         scattered = true;
                     } else if (m.kind == PT_MAT_METAL) {  // material.rs:69-89
                         const f3 reflected = reflect3(d, normal);
                         if (dot3(reflected, normal) > 0.0f) {
                             att = mk3(qa.x, qa.y, qa.z);
                             const f3 rs = random_in_unit_sphere(rng);
-                            nd = normalize3(add3(reflected, scale3(rs, m.param)));
+                            raw = add3(reflected, scale3(rs, m.param));
                             scattered = true;
                         }
                     } else if (m.kind == PT_MAT_DIELECTRIC) {  // material.rs:91-124
@@ -970,9 +973,10 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                             const float reflect_prob = schlick_ref(cosine, ref_idx);
                             if (rng_f32(rng) > reflect_prob) use_refract = true;
                         }
-                        nd = use_refract ? normalize3(refracted) : normalize3(reflect3(d, normal));
+                        raw = use_refract ? refracted : reflect3(d, normal);
                         scattered = true;
                     }
+                    if (scattered) nd = normalize3(raw);
                 }
                 if (scattered) {
                     path[(depth * 3 + 0) * kBlock] = att.x;
