@@ -144,32 +144,36 @@ __device__ __forceinline__ bool w_rect(uint32_t axis, float a0, float a1, float 
     return true;
 }
 
-// aabb.rs:46-58 (Vec3A min/max = _mm_min_ps/_mm_max_ps: the SECOND operand wins on NaN)
-__device__ __forceinline__ bool w_aabb_hit(const float mn[3], const float mx[3], const WRay &r, float tmin, float tmax) {
-    const float o[3] = {r.o.x, r.o.y, r.o.z}, rc[3] = {r.rcp.x, r.rcp.y, r.rcp.z};
-    bool all = true;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const float lo = (mn[i] - o[i]) * rc[i], hi = (mx[i] - o[i]) * rc[i];
-        const float t0 = sse_min(lo, hi), t1 = sse_max(lo, hi);
-        all = all && (sse_min(t1, tmax) > sse_max(t0, tmin));
-    }
-    return all;
+// aabb.rs:46-58 (Vec3A min/max = _mm_min_ps/_mm_max_ps: the SECOND operand wins on NaN), one axis
+__device__ __forceinline__ bool w_slab(float mn, float mx, float o, float rc, float tmin, float tmax) {
+    const float lo = (mn - o) * rc, hi = (mx - o) * rc;
+    const float t0 = sse_min(lo, hi), t1 = sse_max(lo, hi);
+    return sse_min(t1, tmax) > sse_max(t0, tmin);
+}
+__device__ __forceinline__ bool w_aabb_hit(f3 mn, f3 mx, const WRay &r, float tmin, float tmax) {
+    const bool x = w_slab(mn.x, mx.x, r.o.x, r.rcp.x, tmin, tmax);
+    const bool y = w_slab(mn.y, mx.y, r.o.y, r.rcp.y, tmin, tmax);
+    const bool z = w_slab(mn.z, mx.z, r.o.z, r.rcp.z, tmin, tmax);
+    return x && y && z;
 }
 
-// cuboid.rs:11-37: AABB test, then the six faces in construction order with narrowing
-__device__ __forceinline__ bool w_cuboid(const float p[10], const WRay &r, float t_min, float t_max, WHit &h) {
-    const float mn[3] = {p[0], p[1], p[2]}, mx[3] = {p[3], p[4], p[5]};
-    if (!w_aabb_hit(mn, mx, r, t_min, t_max)) return false;
+// cuboid.rs:11-37: AABB test, then the six faces in construction order with narrowing. One rect routine, called
+// from a loop (the faces differ only in their parameters), keeps the code small.
+__device__ __forceinline__ bool w_cuboid(f3 p0, f3 p1, const WRay &r, float t_min, float t_max, WHit &h) {
+    if (!w_aabb_hit(p0, p1, r, t_min, t_max)) return false;
     bool found = false;
     float closest = t_max;
-    WHit f;
-    if (w_rect(0u, p[0], p[3], p[1], p[4], p[5], false, r, t_min, closest, f)) h = f, closest = f.t, found = true;
-    if (w_rect(0u, p[0], p[3], p[1], p[4], p[2], true, r, t_min, closest, f)) h = f, closest = f.t, found = true;
-    if (w_rect(1u, p[0], p[3], p[2], p[5], p[4], false, r, t_min, closest, f)) h = f, closest = f.t, found = true;
-    if (w_rect(1u, p[0], p[3], p[2], p[5], p[1], true, r, t_min, closest, f)) h = f, closest = f.t, found = true;
-    if (w_rect(2u, p[1], p[4], p[2], p[5], p[3], false, r, t_min, closest, f)) h = f, closest = f.t, found = true;
-    if (w_rect(2u, p[1], p[4], p[2], p[5], p[0], true, r, t_min, closest, f)) h = f, closest = f.t, found = true;
+#pragma clang loop unroll(disable)
+    for (uint32_t face = 0; face < 6u; ++face) {
+        const uint32_t axis = face >> 1;          // 0,1: XY  2,3: XZ  4,5: YZ
+        const bool flip = (face & 1u) != 0u;      // odd faces sit at p0 and face the other way
+        float a0, a1, b0, b1, k;
+        if (axis == 0u) a0 = p0.x, a1 = p1.x, b0 = p0.y, b1 = p1.y, k = flip ? p0.z : p1.z;
+        else if (axis == 1u) a0 = p0.x, a1 = p1.x, b0 = p0.z, b1 = p1.z, k = flip ? p0.y : p1.y;
+        else a0 = p0.y, a1 = p1.y, b0 = p0.z, b1 = p1.z, k = flip ? p0.x : p1.x;
+        WHit f;
+        if (w_rect(axis, a0, a1, b0, b1, k, flip, r, t_min, closest, f)) h = f, closest = f.t, found = true;
+    }
     return found;
 }
 
@@ -182,7 +186,7 @@ __device__ __forceinline__ bool w_shape(const pt_hitable &H, const WRay &r, floa
         const f3 centre = add3(mk3(H.p[0], H.p[1], H.p[2]), scale3(mk3(H.p[3], H.p[4], H.p[5]), s));
         return w_sphere(centre, H.p[6], r, t_min, t_max, h);
     }
-    case PT_HIT_CUBOID: return w_cuboid(H.p, r, t_min, t_max, h);
+    case PT_HIT_CUBOID: return w_cuboid(mk3(H.p[0], H.p[1], H.p[2]), mk3(H.p[3], H.p[4], H.p[5]), r, t_min, t_max, h);
     default: return w_rect(H.kind - PT_HIT_RECT_XY, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], H.flip_normals != 0u, r, t_min, t_max, h);
     }
 }
@@ -206,21 +210,31 @@ __device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine
     return true;
 }
 
-// One HitableList entry. Returns the material to shade with in `mat`.
-__device__ __forceinline__ bool w_hitable(const pt_hitable &H, const pt_affine *xf, const WRay &r, float t_min, float t_max,
-                                          Rng &rng, WHit &h, uint32_t &mat) {
-    if (H.medium_material < 0) {
-        mat = H.material;
-        return w_instanced(H, xf, r, t_min, t_max, h);
+// One HitableList entry. Returns the material to shade with in `mat`. A ConstantMedium asks its boundary twice
+// (constant_medium.rs:39-43): the shape code is reached through ONE call site in a two-trip loop so it exists once.
+// Returns the material index, or -1 for no hit.
+__device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *xf, const WRay &r, float t_min, float t_max,
+                                         Rng &rng, WHit &h) {
+    const bool medium = H.medium_material >= 0;
+    float lo = medium ? -kMaxT : t_min, hi = medium ? kMaxT : t_max;
+    float t_first = 0.f;
+    bool ok = true;
+#pragma clang loop unroll(disable)
+    for (int pass = 0; pass < (medium ? 2 : 1); ++pass) {
+        if (ok) {
+            ok = w_instanced(H, xf, r, lo, hi, h);
+            if (pass == 0) t_first = h.t;
+            lo = h.t + 0.0001f;   // constant_medium.rs:41
+            hi = kMaxT;
+        }
     }
-    // constant_medium.rs:32-77
-    WHit h1, h2;
-    if (!w_instanced(H, xf, r, -kMaxT, kMaxT, h1)) return false;
-    if (!w_instanced(H, xf, r, h1.t + 0.0001f, kMaxT, h2)) return false;
-    float t1 = h1.t, t2 = h2.t;
+    if (!medium) return ok ? (int)H.material : -1;
+    if (!ok) return -1;
+    // constant_medium.rs:44-76
+    float t1 = t_first, t2 = h.t;
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
-    if (t1 >= t2) return false;
+    if (t1 >= t2) return -1;
     if (t1 < 0.0f) t1 = 0.0f;
     const float ray_length = length3(r.d);
     const float distance_inside_boundary = (t2 - t1) * ray_length;
@@ -230,10 +244,9 @@ __device__ __forceinline__ bool w_hitable(const pt_hitable &H, const pt_affine *
         h.point = add3(r.o, scale3(r.d, t));
         h.normal = mk3(1.0f, 0.0f, 0.0f);  // Vec3::X, arbitrary
         h.t = t;
-        mat = (uint32_t)H.medium_material;
-        return true;
+        return H.medium_material;
     }
-    return false;
+    return -1;
 }
 
 template <bool BVH>
@@ -328,9 +341,9 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
                 float closest = kMaxT;
                 for (uint32_t k = 0; k < A.n_hit; ++k) {
                     WHit h;
-                    uint32_t m;
-                    if (w_hitable(A.hit[k], A.xf, ray, kMinT, closest, rng, h, m)) {
-                        best = h, best_mat = m, found = true;
+                    const int m = w_hitable(A.hit[k], A.xf, ray, kMinT, closest, rng, h);
+                    if (m >= 0) {
+                        best = h, best_mat = (uint32_t)m, found = true;
                         closest = h.t;
                     }
                 }
@@ -341,15 +354,15 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
                     const int32_t ref = s_stack[--sp * kBlock + tid];
                     if (ref < 0) {
                         WHit h;
-                        uint32_t m;
-                        if (w_hitable(A.hit[~ref], A.xf, ray, kMinT, kMaxT, rng, h, m)) {
+                        const int m = w_hitable(A.hit[~ref], A.xf, ray, kMinT, kMaxT, rng, h);
+                        if (m >= 0) {
                             // bvh.rs:48-53: lhs only when lhs.t < rhs.t -> an equal t goes to the later leaf
-                            if (!found || !(best.t < h.t)) best = h, best_mat = m;
+                            if (!found || !(best.t < h.t)) best = h, best_mat = (uint32_t)m;
                             found = true;
                         }
                     } else {
                         const pt_bvh_node nd = A.nodes[ref];
-                        if (w_aabb_hit(nd.min, nd.max, ray, kMinT, kMaxT)) {
+                        if (w_aabb_hit(mk3(nd.min[0], nd.min[1], nd.min[2]), mk3(nd.max[0], nd.max[1], nd.max[2]), ray, kMinT, kMaxT)) {
                             s_stack[sp++ * kBlock + tid] = nd.rhs;
                             s_stack[sp++ * kBlock + tid] = nd.lhs;
                         }
@@ -372,14 +385,16 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
             } else {
                 const DMat m = A.mats[best_mat];
                 const f3 point = best.point, normal = best.normal, d = ray.d;
+                // Texture::value (texture.rs:74-91); Constant textures were folded into the material record
+                auto colour = [&]() -> f3 { return m.pad0 != 0.0f ? mk3(m.a0, m.a1, m.a2) : texture_value(A.texs, pn, m.tex, point); };
                 f3 emitted = mk3(0.f, 0.f, 0.f);  // material.rs:161-167
-                if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = texture_value(A.texs, pn, m.tex, point);
+                if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = colour();
                 bool scattered = false;
                 f3 att = mk3(1.f, 1.f, 1.f), nd = d;
                 if (depth < A.max_depth) {
                     if (m.kind == PT_MAT_LAMBERTIAN) {  // material.rs:52-67
                         const f3 target = add3(add3(point, normal), random_unit_vector(rng));
-                        att = texture_value(A.texs, pn, m.tex, point);
+                        att = colour();
                         nd = normalize3(sub3(target, point));
                         scattered = true;
                     } else if (m.kind == PT_MAT_METAL) {  // material.rs:69-89
@@ -414,7 +429,7 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
                         nd = use_refract ? normalize3(refracted) : normalize3(reflect3(d, normal));
                         scattered = true;
                     } else if (m.kind == PT_MAT_ISOTROPIC) {  // material.rs:126-136: direction NOT normalised
-                        att = texture_value(A.texs, pn, m.tex, point);
+                        att = colour();
                         nd = random_in_unit_sphere(rng);
                         scattered = true;
                     }

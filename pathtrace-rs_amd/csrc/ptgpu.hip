@@ -780,6 +780,12 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
         const pt_material &m = desc->materials[i];
         mats[i] = DMat{m.kind, m.albedo[0], m.albedo[1], m.albedo[2], m.param, m.texture, 0.f, 0.f};
+        // a Constant texture is resolved here: the general kernel then needs no texture call for it (pad0 = 1)
+        if ((m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_DIFFUSE_LIGHT || m.kind == PT_MAT_ISOTROPIC) &&
+            desc->textures[m.texture].kind == PT_TEX_CONSTANT) {
+            const pt_texture &t = desc->textures[m.texture];
+            mats[i].a0 = t.color[0], mats[i].a1 = t.color[1], mats[i].a2 = t.color[2], mats[i].pad0 = 1.0f;
+        }
     }
     std::vector<DTex> texs(desc->n_textures ? desc->n_textures : 1);
     for (uint32_t i = 0; i < desc->n_textures; ++i) {
@@ -949,7 +955,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
         W.stack_in_lds = (lds + path_bytes <= 60u * 1024u) ? 1u : 0u;
         if (W.stack_in_lds) lds += (uint32_t)path_bytes;
-        uint32_t bpc = s->blocks_per_cu ? s->blocks_per_cu : 2u;
+        uint32_t bpc = s->blocks_per_cu ? s->blocks_per_cu : 3u;
         const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
         if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
         if (bpc > 8u) bpc = 8u;
