@@ -441,7 +441,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                                                    const uint16_t *s_tile_sphere, uint16_t *queue,
                                                    f3 o, f3 d, float a, bool active, float time, float &t_out,
                                                    unsigned long long *sec = nullptr) {
-    const int tid = threadIdx.x, lane = tid & 63, wave_base = tid & ~63;
+    const int tid = threadIdx.x, lane = tid & 63;
 #ifdef PT_SECTIONS
     unsigned long long sub_last = __builtin_readcyclecounter();
 #define PT_SUB(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); sec[i] += now_ - sub_last; sub_last = now_; } while (0)
@@ -450,7 +450,6 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
 #define PT_SUB(i) do { } while (0)
 #endif
     const RayFeat rf = make_ray_features(A, o, d, a, active, lane);
-    const int row_off = 4 * (lane >> 5);
     PT_SUB(5);
     const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // Candidates of MY ray, one 32-bit mask per tile that has any: bits 0..15 come from my own accumulators (my
