@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--bvh", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: run the collective on the render stream (no double buffering)")
     ap.add_argument("--cpu-secs", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -126,32 +127,49 @@ def main():
     stream = torch.cuda.current_stream()
     multi = N > 1 or dist is not None
     max_rows = sharding.padded_rows(H, N)
-    shard = torch.zeros((max_rows, W, 3), dtype=torch.float32, device=dev)
-    full = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    ray_count = torch.zeros(1, dtype=torch.int64, device=dev)
-    gathered_rows = torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev) if multi else None
-    gathered_frames = torch.empty((N, H, W, 3), dtype=torch.float32, device=dev) if multi else None
-    frame = None
-    kernel_ms = []
+    # Two buffer sets: the collective + blend of step k run on their own HIP stream while the kernel of step k + 1
+    # already renders into the other set (the persistent grid leaves CUs to RCCL as its workgroups retire).
+    overlap = multi and not args.no_overlap
+    comm = torch.cuda.Stream(device=dev) if overlap else stream
+    sets = [dict(full=torch.zeros((H, W, 3), dtype=torch.float32, device=dev),
+                 shard=torch.zeros((max_rows, W, 3), dtype=torch.float32, device=dev),
+                 rays=torch.zeros(1, dtype=torch.int64, device=dev),
+                 rows=torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev) if multi else None,
+                 frames=torch.empty((N, H, W, 3), dtype=torch.float32, device=dev) if multi else None,
+                 done=None) for _ in range(2 if overlap else 1)]
+    state = {"k": 0, "last": sets[0], "frame": None}
 
     def step(mode):
-        nonlocal frame
+        b = sets[state["k"] % len(sets)]
+        state["k"] += 1
+        state["last"] = b
+        if overlap and b["done"] is not None:
+            stream.wait_event(b["done"])      # the collective that read this set two steps ago has finished
         if not multi:
-            full.zero_()  # frame 0 of a fresh accumulation (offline.rs:25 starts from zeros)
-            scene.update_device(params, cam, 0, full.data_ptr(), ray_count.data_ptr(), stream.cuda_stream)
-            frame = full
-        elif mode == "frames":
-            full.zero_()
-            scene.update_device(params, cam, rank, full.data_ptr(), ray_count.data_ptr(), stream.cuda_stream)
-            # RCCL over xGMI: ONE all_gather of the N frames, blend replayed in frame order (scene.rs:113-116)
-            frame = sharding.gather_progressive(dist, full, gathered_frames, ray_count)
+            b["full"].zero_()  # frame 0 of a fresh accumulation (offline.rs:25 starts from zeros)
+            scene.update_device(params, cam, 0, b["full"].data_ptr(), b["rays"].data_ptr(), stream.cuda_stream)
+            state["frame"] = b["full"]
+            return
+        if mode == "frames":
+            b["full"].zero_()
+            scene.update_device(params, cam, rank, b["full"].data_ptr(), b["rays"].data_ptr(), stream.cuda_stream)
         else:
-            shard.zero_()
-            scene.update_shard_device(params, cam, 0, rank, N, shard.data_ptr(), ray_count.data_ptr(),
-                                      stream.cuda_stream)
-            # ONE all_gather of the row shards per frame (+ 8-byte all_reduce, scene.rs:118-120), de-interleave
-            frame = sharding.gather_frame(dist, shard, gathered_rows, ray_count, H)
-        return frame
+            b["shard"].zero_()
+            scene.update_shard_device(params, cam, 0, rank, N, b["shard"].data_ptr(), b["rays"].data_ptr(), stream.cuda_stream)
+        if overlap:
+            ready = torch.cuda.Event()
+            ready.record(stream)
+            comm.wait_event(ready)
+        with torch.cuda.stream(comm):
+            if mode == "frames":
+                # RCCL over xGMI: ONE all_gather of the N frames, blend replayed in frame order (scene.rs:113-116)
+                state["frame"] = sharding.gather_progressive(dist, b["full"], b["frames"], b["rays"])
+            else:
+                # ONE all_gather of the row shards per frame (+ 8-byte all_reduce, scene.rs:118-120), de-interleave
+                state["frame"] = sharding.gather_frame(dist, b["shard"], b["rows"], b["rays"], H)
+            if overlap:
+                b["done"] = torch.cuda.Event()
+                b["done"].record(comm)
 
     def fence():
         torch.cuda.synchronize()
@@ -176,7 +194,7 @@ def main():
         t = torch.tensor([el, sum(kms_list) / max(1, len(kms_list))], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t[0].item()), float(t[1].item()), int(ray_count.item())  # ray_count: already summed over ranks
+        return float(t[0].item()), float(t[1].item()), int(state["last"]["rays"].item())  # already summed over ranks
 
     elapsed, kms, rays_per_step = timed(args.mode, args.steps, args.warmup)
     total_rays = rays_per_step * args.steps
@@ -189,6 +207,28 @@ def main():
         strong = {"value": rays2 * k2 / 1e6 / el2, "unit": "Mrays/s", "ms_per_step": el2 / k2 * 1e3, "kernel_ms": kms2,
                   "steps": k2, "scaling": "strong",
                   "workload": "ONE %dx%d %dspp frame, rows interleaved over %d GPUs, all_gather of the shards" % (W, H, S, N)}
+
+    if multi and os.environ.get("PT_BENCH_CHECK") == "1":
+        # self-check of the double-buffered pipeline: its last frame must equal a plain serial step, bit for bit
+        for _ in range(3):
+            step(args.mode)
+        fence()
+        got = state["frame"].clone()
+        ref_full = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        ref_shard = torch.zeros((max_rows, W, 3), dtype=torch.float32, device=dev)
+        rc2 = torch.zeros(1, dtype=torch.int64, device=dev)
+        if args.mode == "frames":
+            scene.update_device(params, cam, rank, ref_full.data_ptr(), rc2.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            want = sharding.gather_progressive(dist, ref_full, torch.empty((N, H, W, 3), dtype=torch.float32, device=dev), rc2)
+        else:
+            scene.update_shard_device(params, cam, 0, rank, N, ref_shard.data_ptr(), rc2.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            want = sharding.gather_frame(dist, ref_shard, torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev), rc2, H)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and int(rc2.item()) == int(state["last"]["rays"].item()), "pipelined frame differs from the serial one"
+        if rank == 0:
+            print("[bench check] pipelined %s frame == serial frame, %d rays" % (args.mode, int(rc2.item())), file=sys.stderr)
 
     if rank == 0:
         grid, block, lds = scene.last_launch_info()
@@ -228,6 +268,8 @@ def main():
                                        ("frame_num = rank on each of %d GPUs, no data-path collective, RCCL all_gather of the frames + "
                                         "blend in frame order (scene.rs:113-116)" % N if args.mode == "frames"
                                         else "rows interleaved over %d GPUs, RCCL all_gather of the shards" % N)),
+                       "overlap": ("collective + blend of step k on a second HIP stream under the kernel of step k + 1" if overlap
+                                   else "none"),
                        "grid": grid, "block": block, "lds_bytes": lds},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
