@@ -73,7 +73,9 @@ struct KArgs {
     float root_min[3], root_max[3];
     uint32_t n_nodes, nodes_in_lds, bvh_stack_entries;
     // BVH mode acceleration structure built by pt_scene_create (the caller's tree only defines the RESULT)
-    const float4 *gate;          // [2*n_spheres] AABB (min, max) of each sphere's parent node in the caller's tree
+    const float4 *gate;          // [2*n_spheres] AABB (min, max) of each sphere's parent node in the caller's tree;
+                                 // .w of the pair = count / offset of further ancestors in gate_chain (count ~0: never hit)
+    const float4 *gate_chain;    // ancestors whose test is not implied by the box below them (inverted boxes only)
     const uint32_t *bvh_large;   // spheres kept out of the internal tree (huge radius): tested for every ray
     uint32_t n_bvh_large;
     uint32_t n_spheres;
@@ -639,7 +641,16 @@ __device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, const float4 c, 
                     const float4 gmn = A.gate[2 * k], gmx = A.gate[2 * k + 1];
                     const float mn[3] = {gmn.x, gmn.y, gmn.z}, mx[3] = {gmx.x, gmx.y, gmx.z};
                     float te;
-                    pass = aabb_hit_enter(mn, mx, o, rcp, te);
+                    const uint32_t extra = __float_as_uint(gmn.w);
+                    pass = extra != 0xffffffffu && aabb_hit_enter(mn, mx, o, rcp, te);
+                    if (pass && extra != 0u) {   // rare: ancestors above an inverted (negative-radius) box
+                        const float4 *ch = A.gate_chain + 2u * __float_as_uint(gmx.w);
+                        for (uint32_t j = 0; j < extra && pass; ++j) {
+                            const float4 cmn = ch[2 * j], cmx = ch[2 * j + 1];
+                            const float bmn[3] = {cmn.x, cmn.y, cmn.z}, bmx[3] = {cmx.x, cmx.y, cmx.z};
+                            pass = aabb_hit_enter(bmn, bmx, o, rcp, te);
+                        }
+                    }
                 }
                 if (pass) {
                     best = t;

@@ -60,7 +60,7 @@ struct pt_scene {
     DTex *d_texs = nullptr;
     float4 *d_perlin_vec = nullptr;
     uint32_t *d_perlin_perm = nullptr;
-    float4 *d_gate = nullptr;
+    float4 *d_gate = nullptr, *d_gate_chain = nullptr;
     uint32_t *d_bvh_large = nullptr;
     uint32_t n_bvh_large = 0;
     int32_t accel_root = -1;
@@ -570,26 +570,55 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
     // internal traversal tree.
     std::vector<DWideNode> wnodes;
     std::vector<uint32_t> leaf_rank(desc->n_spheres, 0), bvh_large;
-    std::vector<float4> gate(2 * (size_t)desc->n_spheres, make_float4(0, 0, 0, 0));
+    std::vector<float4> gate(2 * (size_t)desc->n_spheres, make_float4(0, 0, 0, 0)), gate_chain;
     uint32_t accel_depth = 0;
     if (desc->n_bvh_nodes) {
-        // a sphere that is not a leaf of the caller's tree can never be hit: give it an empty gate box
-        for (uint32_t i = 0; i < desc->n_spheres; ++i) gate[2 * i] = make_float4(1, 1, 1, 0), gate[2 * i + 1] = make_float4(-1, -1, -1, 0);
+        union FU { uint32_t u; float f; };
+        // a sphere that is not a leaf of the caller's tree can never be hit: chain count 0xffffffff = "never"
+        const FU never{0xffffffffu};
+        for (uint32_t i = 0; i < desc->n_spheres; ++i) gate[2 * i] = make_float4(0, 0, 0, never.f);
+        // The slab test (aabb.rs:46-58) takes min/max of the two plane distances, so a box acts as the interval
+        // [min(mn, mx), max(mn, mx)] per axis; when an ancestor's interval contains its child's on every axis,
+        // passing the child implies passing the ancestor (the arithmetic is monotone). Boxes built by
+        // AABB::add (aabb.rs:61-66) nest like that, EXCEPT above inverted boxes (a negative radius gives
+        // min > max, sphere.rs:69-75): there an ancestor can reject a ray its descendant accepts. Each leaf
+        // therefore gets its parent's box plus every ancestor that is not implied by the one below it.
+        auto implied_by = [&](const pt_bvh_node &up, const pt_bvh_node &low) {
+            for (int a = 0; a < 3; ++a) {
+                const float ul = std::min(up.min[a], up.max[a]), uh = std::max(up.min[a], up.max[a]);
+                const float ll = std::min(low.min[a], low.max[a]), lh = std::max(low.min[a], low.max[a]);
+                if (!(ul <= ll && uh >= lh)) return false;
+            }
+            return true;
+        };
         // lhs-before-rhs DFS; a sphere referenced by several leaves keeps its LAST rank (bvh.rs:73-79 lhs == rhs)
-        std::vector<std::pair<int32_t, int32_t>> st{{desc->bvh_root, -1}};
+        struct Item { int32_t ref; int32_t parent; uint32_t depth; };
+        std::vector<Item> st{{desc->bvh_root, -1, 0}};
+        std::vector<int32_t> path;   // ancestors of the item being visited, root first
         uint32_t rank = 0;
         while (!st.empty()) {
-            const auto [ref, parent] = st.back();
+            const Item it = st.back();
             st.pop_back();
-            if (ref < 0) {
-                const uint32_t k = (uint32_t)~ref;
+            path.resize(it.depth);
+            if (it.ref < 0) {
+                const uint32_t k = (uint32_t)~it.ref;
                 leaf_rank[k] = rank++;
-                const pt_bvh_node &pn = desc->bvh_nodes[parent];
-                gate[2 * k] = make_float4(pn.min[0], pn.min[1], pn.min[2], 0.f);
-                gate[2 * k + 1] = make_float4(pn.max[0], pn.max[1], pn.max[2], 0.f);
+                const pt_bvh_node &pn = desc->bvh_nodes[it.parent];
+                FU cnt{0}, off{(uint32_t)(gate_chain.size() / 2)};
+                for (size_t j = path.size() - 1; j-- > 0;) {   // grandparent upwards
+                    const pt_bvh_node &up = desc->bvh_nodes[path[j]], &low = desc->bvh_nodes[path[j + 1]];
+                    if (!implied_by(up, low)) {
+                        gate_chain.push_back(make_float4(up.min[0], up.min[1], up.min[2], 0.f));
+                        gate_chain.push_back(make_float4(up.max[0], up.max[1], up.max[2], 0.f));
+                        ++cnt.u;
+                    }
+                }
+                gate[2 * k] = make_float4(pn.min[0], pn.min[1], pn.min[2], cnt.f);
+                gate[2 * k + 1] = make_float4(pn.max[0], pn.max[1], pn.max[2], off.f);
             } else {
-                st.push_back({desc->bvh_nodes[ref].rhs, ref});
-                st.push_back({desc->bvh_nodes[ref].lhs, ref});
+                path.push_back(it.ref);
+                st.push_back({desc->bvh_nodes[it.ref].rhs, it.ref, it.depth + 1});
+                st.push_back({desc->bvh_nodes[it.ref].lhs, it.ref, it.depth + 1});
             }
         }
     }
@@ -624,7 +653,8 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
         (rc = upload(&s->d_mats, mats.data(), mats.size())) || (rc = upload(&s->d_texs, texs.data(), texs.size())) ||
         (rc = upload(&s->d_perlin_vec, pvec.data(), pvec.size())) || (rc = upload(&s->d_perlin_perm, pperm.data(), pperm.size())) ||
         (rc = upload(&s->d_wnodes, wnodes.data(), wnodes.size())) || (rc = upload(&s->d_leaf_rank, leaf_rank.data(), leaf_rank.size())) ||
-        (rc = upload(&s->d_gate, gate.data(), gate.size())) || (rc = upload(&s->d_bvh_large, bvh_large.data(), bvh_large.size()))) {
+        (rc = upload(&s->d_gate, gate.data(), gate.size())) || (rc = upload(&s->d_gate_chain, gate_chain.data(), gate_chain.size())) ||
+        (rc = upload(&s->d_bvh_large, bvh_large.data(), bvh_large.size()))) {
         pt_scene_destroy(s);
         return rc;
     }
@@ -838,6 +868,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_perlin_vec);
     (void)hipFree(s->d_perlin_perm);
     (void)hipFree(s->d_gate);
+    (void)hipFree(s->d_gate_chain);
     (void)hipFree(s->d_bvh_large);
     (void)hipFree(s->d_wnodes);
     (void)hipFree(s->d_leaf_rank);
@@ -996,6 +1027,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.perlin_vec = s->d_perlin_vec;
     A.perlin_perm = s->d_perlin_perm;
     A.gate = ref_bvh ? s->d_gate : nullptr;   // list semantics: no ancestor-AABB gate, ties to the lower index
+    A.gate_chain = s->d_gate_chain;
     A.bvh_large = s->d_bvh_large;
     A.n_bvh_large = s->n_bvh_large;
     A.wnodes = s->d_wnodes;

@@ -523,6 +523,47 @@ def test_random_general_worlds_match_the_oracle(ptgpu, oracle, seed, n, kinds, b
     assert np.array_equal(ref, out), _report(ref, out)
 
 
+def _random_sphere_world(oracle, seed, n, W, H, spread, rmax, extras=()):
+    """Sphere-only world with every material kind, duplicates (exact t ties), negative radii (hollow glass) and the
+    listed edge-case spheres appended: the specialised sphere kernels (MFMA prefilter / exact scan / internal tree)."""
+    rng = np.random.default_rng(seed)
+    tex = [[0, *rng.uniform(0.1, 0.9, 3), -1, -1, 0] for _ in range(4)] + [[1, 0, 0, 0, 0, 1, 0], [0, 5.0, 4.0, 3.0, -1, -1, 0]]
+    mats = [[0, 0, 0, 0, 0, t] for t in range(5)] + [[1, *rng.uniform(0.5, 1, 3), f, -1] for f in (0.0, 0.4)]
+    mats += [[2, 0, 0, 0, 1.5, -1], [2, 0, 0, 0, 2.4, -1], [3, 0, 0, 0, 0, 5]]
+    sph = np.concatenate([rng.uniform(-spread, spread, (n, 3)), rng.uniform(0.05, rmax, (n, 1))], axis=1).astype(np.float32)
+    sph[rng.random(n) < 0.08, 3] *= -1                      # presets.rs:265 style negative radius
+    sph[n // 2] = sph[n // 3]                                # an exact duplicate: equal t, the lower list index must win
+    if len(extras):
+        sph = np.concatenate([sph, np.asarray(extras, np.float32)])
+    rec = np.zeros((len(sph), 16), np.uint32)
+    rec[:, 1] = rng.integers(0, len(mats), len(sph))
+    rec[:, 3] = rec[:, 4] = 0xffffffff
+    rec[:, 6:10] = sph.view(np.uint32)
+    cam = np.zeros(24, np.float32)
+    lf, la, up = (np.asarray(v, np.float32) for v in ([0.3 * spread, 0.4 * spread, 1.6 * spread], [0, 0, 0], [0, 1, 0]))
+    oracle.lib().ora_camera_new(lf.ctypes.data, la.ctypes.data, up.ctypes.data, 45.0, W / H, 0.05, 1.5 * spread, 0.0, 1.0, cam.ctypes.data)
+    return dict(hitables=rec, transforms=np.zeros((0, 24), np.float32), materials=np.array(mats, np.float32),
+                textures=np.array(tex, np.float32), camera=cam, sky=None)
+
+
+@pytest.mark.parametrize("seed,n,spread,rmax,extras", [
+    (21, 300, 6.0, 0.5, ()),                                             # MFMA prefilter territory
+    (22, 40, 3.0, 0.8, ()),                                              # two tiles
+    (23, 12, 2.0, 0.9, ()),                                              # too few spheres for the prefilter: exact scan
+    (24, 200, 6.0, 0.4, ([0, -500, 0, 498], [0, 0, 0, 30], [1e4, 0, 0, 0.5], [0.3, 0.4, 1.6, 0.01])),  # ground, a sphere
+    #                      around the whole scene (camera inside), one far outside the f16 feature range, one tiny
+    (25, 100, 4.0, 0.5, ([0, 0, 0, 0.0], [1, 1, 1, 1e-20])),             # r = 0 and r^2 underflowing to 0
+    (26, 900, 12.0, 0.4, ()),                                            # > 768 spheres: list mode walks the internal tree
+])
+@pytest.mark.parametrize("bvh", [False, True])
+def test_random_sphere_worlds_match_the_oracle(ptgpu, oracle, seed, n, spread, rmax, extras, bvh):
+    W, H, S = 128, 96, 4
+    w = _random_sphere_world(oracle, seed, n, W, H, spread, rmax, extras)
+    out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh)
+    assert rays == ref_rays, "ray_count %d vs oracle %d; %s" % (rays, ref_rays, _report(ref, out))
+    assert np.array_equal(ref, out, equal_nan=True), _report(ref, out)
+
+
 @pytest.mark.parametrize("seed,times,bvh", [
     (11, ((0.0, 1.0),), False),                               # one shutter interval for every moving sphere
     (12, ((0.0, 1.0), (-0.5, 1.5), (0.0, 2.0)), False),       # per-sphere time_start / inv_time_delta
