@@ -492,7 +492,7 @@ def _random_world(oracle, seed, n, kinds, W, H, moving_times=((0.0, 1.0),), medi
                 textures=np.array(tex, np.float32), camera=cam, sky=sky)
 
 
-def _render_world_both(ptgpu, oracle, w, W, H, S, bvh, variant=0):
+def _render_world_both(ptgpu, oracle, w, W, H, S, bvh, variant=0, depth=10, frame=0):
     osc = oracle.OracleScene.from_world(w["hitables"], w["transforms"], w["materials"], w["textures"], w["camera"], W, H,
                                         sky=w["sky"], use_bvh=bvh)
     ex = osc.export()
@@ -501,9 +501,9 @@ def _render_world_both(ptgpu, oracle, w, W, H, S, bvh, variant=0):
     if variant:
         sc.set_tuning(0, variant)
     out = np.zeros((H, W, 3), np.float32)
-    rays = sc.update(ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0), ptgpu.PtCamera.from_floats(ex["camera"]), 0, out)
+    rays = sc.update(ptgpu.PtParams(W, H, S, depth, 0, 1 if bvh else 0), ptgpu.PtCamera.from_floats(ex["camera"]), frame, out)
     sc.close()
-    ref, ref_rays = osc.update(S)
+    ref, ref_rays = osc.update(S, max_depth=depth, frame_num=frame)
     return out, rays, ref, ref_rays
 
 
