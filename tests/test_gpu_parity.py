@@ -238,6 +238,20 @@ def test_config3_full_size_sampled_against_oracle(ptgpu, pthost, oracle):
     assert np.isfinite(out).all() and out.min() >= 0.0
 
 
+@pytest.mark.parametrize("preset,W,H,S,bvh", [("random_spheres", 1200, 800, 64, False),      # BASELINE config 3, EVERY pixel
+                                              ("aras", 1280, 720, 16, False),                # config 2
+                                              ("random", 1200, 800, 16, False)])             # motion blur on the MOVING kernels
+def test_full_frames_at_baseline_size_are_bit_exact(ptgpu, pthost, oracle, preset, W, H, S, bvh):
+    """The whole frame at the size the metric is quoted on, against the oracle on all host threads (~20 s of CPU)."""
+    lib = oracle.lib(oracle.build_native(os.path.join(ROOT, "gpurun_out", "ora_native")))
+    hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=bvh, device=0)
+    out = np.zeros((H, W, 3), np.float32)
+    rays = hs.device_scene().update(ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0), hs.camera, 0, out)
+    ref, ref_rays = oracle.OracleScene(preset, W, H, use_bvh=bvh, library=lib).update(S)
+    assert rays == ref_rays, "ray_count %d vs oracle %d; %s" % (rays, ref_rays, _report(ref, out))
+    assert np.array_equal(ref, out), _report(ref, out)
+
+
 def test_config3_shard_union_equals_full_frame(ptgpu, pthost):
     """Disjoint row shards (the multi-GPU decomposition) reproduce the single-launch frame bit for bit,
     and their ray counts add up -- checked at the full 1200x800 size with 8 shards on one GPU."""
