@@ -113,6 +113,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    if not os.path.exists(os.path.join(ROOT, "pathtrace-rs_amd", "_build", "libpthost.so")):
+        if local_rank == 0:   # a checkout without the in-tree build: compile it once (never a fallback path)
+            import subprocess
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "pathtrace-rs_amd"), "all"], stdout=subprocess.DEVNULL)
+        if dist is not None:
+            dist.barrier()
     ptgpu = _load("pathtrace_rs_amd_ptgpu", "pathtrace-rs_amd/ptgpu.py")
     pthost = _load("pathtrace_rs_amd_pthost", "pathtrace-rs_amd/pthost.py")
     sharding = _load("pathtrace_rs_amd_sharding", "pathtrace-rs_amd/sharding.py")

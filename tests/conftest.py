@@ -13,8 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _ensure_built():
+    """The in-tree build normally travels with the snapshot; compile it if this checkout has none (hipcc
+    cross-compiles gfx950 without a GPU). The product itself never falls back to anything: it needs the library."""
+    lib = os.path.join(ROOT, "pathtrace-rs_amd", "_build", "libptgpu.so")
+    host = os.path.join(ROOT, "pathtrace-rs_amd", "_build", "libpthost.so")
+    if not (os.path.exists(lib) and os.path.exists(host)):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "pathtrace-rs_amd"), "all"])
+
+
 def load_ptgpu():
     """The product package directory is `pathtrace-rs_amd` (not an importable identifier)."""
+    _ensure_built()
     name = "pathtrace_rs_amd_ptgpu"
     if name in sys.modules:
         return sys.modules[name]
