@@ -904,6 +904,49 @@ namespace {
 
 f3 to3(const float *p) { return f3{p[0], p[1], p[2]}; }
 
+// The per-frame arguments both kernels share (KArgs and WArgs use the same member names).
+template <typename Args>
+void fill_frame_args(Args &X, const pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t frame_num,
+                     uint32_t shard_index, uint32_t shard_count, float *d_rgb, uint64_t *d_ray_count) {
+    X.has_sky = s->has_sky;
+    X.sky = to3(s->sky);
+    X.has_noise = s->has_noise;
+    X.cam.origin = to3(cam->origin);
+    X.cam.lower_left_corner = to3(cam->lower_left_corner);
+    X.cam.horizontal = to3(cam->horizontal);
+    X.cam.vertical = to3(cam->vertical);
+    X.cam.u = to3(cam->u);
+    X.cam.v = to3(cam->v);
+    X.cam.w = to3(cam->w);
+    X.cam.time0 = cam->time0;
+    X.cam.time1 = cam->time1;
+    X.cam.lens_radius = cam->lens_radius;
+    X.width = params->width;
+    X.height = params->height;
+    X.samples = params->samples;
+    X.max_depth = params->max_depth;
+    X.frame_num = frame_num;
+    {   // scene.rs:82-87, evaluated in f32 exactly like the reference
+        const volatile float one = 1.0f;
+        X.inv_nx = one / (float)params->width;
+        X.inv_ny = one / (float)params->height;
+        X.inv_ns = one / (float)params->samples;
+        const volatile float mp = (float)frame_num / (float)(frame_num + 1u);
+        X.mix_prev = mp;
+        X.mix_new = one - mp;
+    }
+    X.random_seed = params->random_seed;
+    X.seed_base = s->seed_base;
+    X.shard_index = shard_index;
+    X.shard_count = shard_count;
+    X.local_rows = pt_shard_rows(params->height, shard_index, shard_count);
+    X.tiles_x = (params->width + 7u) / 8u;
+    X.n_items = X.tiles_x * ((X.local_rows + 7u) / 8u) * 64u;
+    X.rgb = d_rgb;
+    X.ray_count = reinterpret_cast<unsigned long long *>(d_ray_count);
+    X.work_counter = s->d_work_counter;
+}
+
 int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t frame_num, uint32_t shard_index,
            uint32_t shard_count, float *d_rgb, uint64_t *d_ray_count, hipStream_t stream) {
     if (!s || !params || !cam || !d_rgb || !d_ray_count) return fail(PT_ERR_INVALID_ARG, "NULL argument");
@@ -945,39 +988,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         W.n_hit = s->n_hitables;
         W.bvh_root = ref_bvh ? s->bvh_root : -1;
         W.bvh_stack_entries = s->ref_bvh_depth + 2u;
-        W.has_sky = s->has_sky;
-        W.sky = to3(s->sky);
-        W.has_noise = s->has_noise;
-        W.cam.origin = to3(cam->origin);
-        W.cam.lower_left_corner = to3(cam->lower_left_corner);
-        W.cam.horizontal = to3(cam->horizontal);
-        W.cam.vertical = to3(cam->vertical);
-        W.cam.u = to3(cam->u);
-        W.cam.v = to3(cam->v);
-        W.cam.w = to3(cam->w);
-        W.cam.time0 = cam->time0;
-        W.cam.time1 = cam->time1;
-        W.cam.lens_radius = cam->lens_radius;
-        W.width = params->width, W.height = params->height, W.samples = params->samples, W.max_depth = params->max_depth;
-        W.frame_num = frame_num;
-        {
-            const volatile float one = 1.0f;  // scene.rs:82-87 in f32
-            W.inv_nx = one / (float)params->width;
-            W.inv_ny = one / (float)params->height;
-            W.inv_ns = one / (float)params->samples;
-            const volatile float mp = (float)frame_num / (float)(frame_num + 1u);
-            W.mix_prev = mp;
-            W.mix_new = one - mp;
-        }
-        W.random_seed = params->random_seed;
-        W.seed_base = s->seed_base;
-        W.shard_index = shard_index, W.shard_count = shard_count;
-        W.local_rows = pt_shard_rows(params->height, shard_index, shard_count);
-        W.tiles_x = (params->width + 7u) / 8u;
-        W.n_items = W.tiles_x * ((W.local_rows + 7u) / 8u) * 64u;
-        W.rgb = d_rgb;
-        W.ray_count = reinterpret_cast<unsigned long long *>(d_ray_count);
-        W.work_counter = s->d_work_counter;
+        fill_frame_args(W, s, params, cam, frame_num, shard_index, shard_count, d_rgb, d_ray_count);
         HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
         if (W.n_items == 0) return PT_OK;
@@ -1037,46 +1048,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.n_spheres = s->n_spheres;
     A.n_spheres_pad = (s->n_spheres + kScanUnroll - 1) / kScanUnroll * kScanUnroll;
     A.bvh_root = s->accel_root;  // root of the INTERNAL tree (-1: every sphere is in bvh_large)
-    A.has_sky = s->has_sky;
-    A.sky = to3(s->sky);
-    A.has_noise = s->has_noise;
-    A.cam.origin = to3(cam->origin);
-    A.cam.lower_left_corner = to3(cam->lower_left_corner);
-    A.cam.horizontal = to3(cam->horizontal);
-    A.cam.vertical = to3(cam->vertical);
-    A.cam.u = to3(cam->u);
-    A.cam.v = to3(cam->v);
-    A.cam.w = to3(cam->w);
-    A.cam.time0 = cam->time0;
-    A.cam.time1 = cam->time1;
-    A.cam.lens_radius = cam->lens_radius;
-    A.width = params->width;
-    A.height = params->height;
-    A.samples = params->samples;
-    A.max_depth = params->max_depth;
-    A.frame_num = frame_num;
-    // scene.rs:82-87, evaluated in f32 exactly like the reference
-    {
-        const volatile float one = 1.0f;
-        A.inv_nx = one / (float)params->width;
-        A.inv_ny = one / (float)params->height;
-        A.inv_ns = one / (float)params->samples;
-        const volatile float mp = (float)frame_num / (float)(frame_num + 1u);
-        A.mix_prev = mp;
-        A.mix_new = one - mp;
-    }
-    A.random_seed = params->random_seed;
-    A.seed_base = s->seed_base;
-    A.shard_index = shard_index;
-    A.shard_count = shard_count;
-    A.local_rows = pt_shard_rows(params->height, shard_index, shard_count);
-    A.tiles_x = (params->width + 7u) / 8u;
-    const uint32_t tiles_y = (A.local_rows + 7u) / 8u;
-    A.n_items = A.tiles_x * tiles_y * 64u;
-    A.rgb = d_rgb;
-    A.ray_count = reinterpret_cast<unsigned long long *>(d_ray_count);
-    A.work_counter = s->d_work_counter;
-
+    fill_frame_args(A, s, params, cam, frame_num, shard_index, shard_count, d_rgb, d_ray_count);
     HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
     if (A.n_items == 0) return PT_OK;
