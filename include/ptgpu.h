@@ -183,6 +183,12 @@ void pt_scene_destroy(pt_scene *scene);
  * and clamps against the running t_max, so visiting order is part of the result. */
 int pt_scene_create_world(const pt_world_desc *desc, int device, pt_scene **scene_out);
 
+/* Optional, part of Scene::new: allocates the per-frame device buffers (frame + pinned staging copy, path
+ * stacks, tile-order scratch) for `params` and runs the kernels once on a throw-away 1-spp frame, so that the
+ * first pt_render measures rendering and not hipMalloc / code-object loading (the reference's timer spans
+ * Scene::update only, offline.rs:27-34). Rendering works without it. */
+int pt_scene_prepare(pt_scene *scene, const pt_params *params);
+
 /* Scene::update (scene.rs:73-121) with a HOST pixel buffer, exactly the
  * reference's contract: rgb_inout is width*height*3 floats (row 0 = bottom
  * row, offline.rs:44), READ (frame blend scene.rs:114-116) and written;

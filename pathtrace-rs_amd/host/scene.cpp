@@ -375,6 +375,9 @@ std::unique_ptr<Scene> Scene::new_scene(const Params &params, Xoshiro256Plus &rn
     if (device >= 0) {
         const int rc = all_spheres ? pt_scene_create(&s->desc_, device, &s->handle_) : pt_scene_create_world(&w, device, &s->handle_);
         if (rc != PT_OK) throw std::runtime_error(std::string(all_spheres ? "pt_scene_create: " : "pt_scene_create_world: ") + pt_last_error());
+        // still Scene::new: size the per-frame buffers now, so Scene::update's timer sees rendering only
+        const pt_params p = params.c_params();
+        if (pt_scene_prepare(s->handle_, &p) != PT_OK) throw std::runtime_error(std::string("pt_scene_prepare: ") + pt_last_error());
     }
     return s;
 }

@@ -95,7 +95,7 @@ class PtWorldDesc(C.Structure):
 
 
 EXPORTS = [
-    "pt_device_count", "pt_scene_create", "pt_scene_create_world", "pt_scene_destroy", "pt_render", "pt_render_device",
+    "pt_device_count", "pt_scene_create", "pt_scene_create_world", "pt_scene_prepare", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_render_shard_device", "pt_shard_rows", "pt_scene_set_seed_base", "pt_last_kernel_ms",
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters",
 ]
@@ -121,6 +121,7 @@ def lib():
         L.pt_device_count.argtypes = [C.POINTER(C.c_int)]
         L.pt_scene_create.argtypes = [C.POINTER(PtSceneDesc), C.c_int, C.POINTER(vp)]
         L.pt_scene_create_world.argtypes = [C.POINTER(PtWorldDesc), C.c_int, C.POINTER(vp)]
+        L.pt_scene_prepare.argtypes = [vp, C.POINTER(PtParams)]
         L.pt_scene_destroy.argtypes = [vp]
         L.pt_scene_destroy.restype = None
         L.pt_render.argtypes = [vp, C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, vp, C.POINTER(C.c_uint64)]
