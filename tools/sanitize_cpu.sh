@@ -1,0 +1,35 @@
+#!/bin/bash
+# ASan + UBSan over the CPU code (GPU sanitizers are not available on the pool): the oracle renders every preset
+# (list and BVH, plus the flat-description round trip), the C++ host builds every preset's description.
+# Usage (repo root, needs pathtrace-rs_amd/_build/libptgpu.so for linking): bash tools/sanitize_cpu.sh
+set -e
+OUT=${TMPDIR:-/tmp}/pt_sanitize
+mkdir -p "$OUT"
+gcc -O1 -g -std=c11 -D_GNU_SOURCE -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -shared \
+    -o "$OUT/libptref.so" oracle/ptref.c -lm -lpthread
+g++ -O1 -g -std=c++17 -ffp-contract=off -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -Iinclude -Ipathtrace-rs_amd/host \
+    -shared pathtrace-rs_amd/host/scene.cpp pathtrace-rs_amd/host/presets.cpp pathtrace-rs_amd/host/offline.cpp \
+    pathtrace-rs_amd/host/capi.cpp -o "$OUT/libpthost.so" -Lpathtrace-rs_amd/_build -lptgpu -Wl,-rpath,"$PWD/pathtrace-rs_amd/_build"
+cat > "$OUT/run.py" <<PY
+import importlib, sys
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+import oracle_binding as ob
+L = ob.lib("$OUT/libptref.so")
+pthost = importlib.import_module("pathtrace-rs_amd.pthost")
+pthost.LIB_PATH = "$OUT/libpthost.so"
+for name in ["small", "random_spheres", "two_perlin_spheres", "aras", "random", "simple_light", "cornell", "cornell_smoke", "smallpt", "final"]:
+    for bvh in (False, True):
+        if name == "final" and bvh:
+            continue          # throws by design (params.rs:37 unwraps None)
+        sc = ob.OracleScene(name, 40, 30, use_bvh=bvh, library=L)
+        ex = sc.export()
+        sc.update(2, nthreads=2)
+        b = ob.OracleScene.from_world(ex["hitables"], ex["transforms"], ex["materials"], ex["textures"], ex["camera"], 40, 30,
+                                      sky=ex["sky"], use_bvh=bvh, library=L)
+        b.update(1, nthreads=1)
+        h = pthost.HostScene(name, 64, 48, use_bvh=bvh)
+        h.export()
+print("sanitize_cpu: clean")
+PY
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so)" \
+    ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 python "$OUT/run.py"
