@@ -238,6 +238,11 @@ int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t varian
  * pairs }. Synchronises the device. */
 int pt_scene_debug_counters(pt_scene *scene, uint64_t out4[4], int reset);
 
+/* Traversal counters of the tree kernels in verify mode (variant bit 8 with use_bvh, or a list world large enough
+ * to walk the internal tree): out2 = { nodes of the internal tree fetched, spheres tested exactly } summed over
+ * all rays since the last reset (reported next to the oracle's counts for the caller's tree). */
+int pt_scene_traversal_counters(pt_scene *scene, uint64_t out2[2], int reset);
+
 /* Device self-test probes (diagnostics for the parity tests; not part of the reference's
  * interface): evaluate one device primitive on n host inputs.
  *   PT_PROBE_POW5    out[i] = device x^5 used by schlick (math.rs:79 powf(x, 5.0))

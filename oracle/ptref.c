@@ -806,10 +806,16 @@ static int list_ray_hit(const hitable_list *l, const ray *r, float t_min, float 
     return found;
 }
 
+/* optional instrumentation: BVHNode::ray_hit calls and leaf (non-node) hitables tested below them */
+static __thread uint64_t tl_bvh_nodes, tl_bvh_leaves;
+static atomic_ullong g_bvh_nodes, g_bvh_leaves;
+
 /* bvh.rs:37-62 */
 static int bvh_ray_hit(const bvhnode *n, const ray *r, float t_min, float t_max, xoshiro *rng,
                        ray_hit *out, const material **mat) {
+    tl_bvh_nodes += 1;
     if (aabb_ray_hit(&n->bb, r, t_min, t_max)) {
+        tl_bvh_leaves += (n->lhs.kind != HIT_BVHNODE) + (n->rhs.kind != HIT_BVHNODE);
         ray_hit hl, hr; const material *ml, *mr;
         int has_l = hitable_ray_hit(&n->lhs, r, t_min, t_max, rng, &hl, &ml);
         int has_r = hitable_ray_hit(&n->rhs, r, t_min, t_max, rng, &hr, &mr);
@@ -1655,6 +1661,8 @@ static void *worker(void *arg) {
         }
     }
     atomic_fetch_add(&j->ray_count, local); /* scene.rs:118 */
+    atomic_fetch_add(&g_bvh_nodes, tl_bvh_nodes); atomic_fetch_add(&g_bvh_leaves, tl_bvh_leaves);
+    tl_bvh_nodes = tl_bvh_leaves = 0;
     return NULL;
 }
 
@@ -1861,6 +1869,11 @@ int32_t ora_xoshiro_gen_range_i32(uint64_t state[4], int32_t low, int32_t high) 
 }
 void ora_sinf_cosf(float x, float *s, float *c) { sinf_cosf(x, s, c); }
 /* f32::ln as constant_medium.rs:60 evaluates it (glibc logf, assumption A7) */
+/* BVHNode::ray_hit invocations and leaf hitables tested since the last reset (all update calls, all threads) */
+void ora_bvh_counters(uint64_t out2[2], int reset) {
+    out2[0] = atomic_load(&g_bvh_nodes); out2[1] = atomic_load(&g_bvh_leaves);
+    if (reset) { atomic_store(&g_bvh_nodes, 0); atomic_store(&g_bvh_leaves, 0); }
+}
 void ora_ln_array(const float *in, float *out, uint64_t n) { for (uint64_t i = 0; i < n; ++i) out[i] = logf(in[i]); }
 /* One Hitable::ray_hit on list entry `index` of the built scene (any kind; media draw from `state`).
  * out7 = point3, normal3, t; returns 1 on hit and the material index (export numbering) in *material. */

@@ -129,6 +129,9 @@ float ora_xoshiro_gen_f32(uint64_t state[4]);
 int32_t ora_xoshiro_gen_range_i32(uint64_t state[4], int32_t low, int32_t high);
 uint64_t ora_pixel_seed(uint32_t x, uint32_t y, uint32_t frame_num);
 void ora_sinf_cosf(float x, float *s, float *c);
+/* SURVEY 8d instrumentation: out2 = { BVHNode::ray_hit calls, leaf hitables tested } over every
+ * ora_scene_update* call since the last reset */
+void ora_bvh_counters(uint64_t out2[2], int reset);
 void ora_ln_array(const float *in, float *out, uint64_t n); /* f32::ln (constant_medium.rs:60) */
 /* Hitable::ray_hit on list entry `index` (hitable.rs:39-65, any arm); out7 = point3, normal3, t */
 int ora_hitable_ray_hit(const ora_scene *s, uint32_t index, const float origin[3],

@@ -687,6 +687,7 @@ __device__ __forceinline__ bool accel_box_hit(const float c[3], const float h[3]
 // long-tail lanes simply keep their stack and continue in the next round -- otherwise every wave would
 // run as long as its slowest ray (measured: 19 % lane utilisation with lockstep iterations).
 struct BvhTrav {
+    uint32_t visits, leaves;   // VERIFY kernels: internal-tree nodes fetched / spheres tested (SURVEY 8d counters)
     int sp;
     float best;
     int idx;
@@ -710,7 +711,7 @@ __device__ __forceinline__ void bvh_start(const KArgs &A, uint32_t *s_stack, f3 
     if (A.bvh_root >= 0) s_stack[(st.sp++) * kBlock + threadIdx.x] = (uint32_t)A.bvh_root;
 }
 
-template <bool NODES_LDS, bool MOVING>
+template <bool NODES_LDS, bool MOVING, bool COUNT>
 __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const DWideNode *nodes, f3 o, f3 d, float a,
                                         float time, bool have, BvhTrav &st) {
     const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -722,6 +723,7 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
             } else {
                 const int32_t ref = (int32_t)s_stack[(--st.sp) * kBlock + tid];
                 const DWideNode n = nodes[ref];
+                if (COUNT) st.visits += 1u, st.leaves += (uint32_t)(n.lhs < 0) + (uint32_t)(n.rhs < 0);
                 // leaves first: they can only shrink `best` before the inner children are considered
                 // a leaf child's box slot holds the sphere itself (centre, radius): no second fetch
                 if (n.lhs < 0) bvh_leaf(A, ~n.lhs, sphere_at<MOVING>(A, ~n.lhs, make_float4(n.lmin[0], n.lmin[1], n.lmin[2], n.lmax[0]), time), o, d, rcp, a, st.best, st.idx, st.rank);
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
 #endif
     bool have = false, exhausted = false, need_cam = true, trav_new = false;
     uint32_t lane_tile = 0, pix_rays = 0;
-    BvhTrav trav{0, kMaxT, -1, 0u, false};
+    BvhTrav trav{0u, 0u, 0, kMaxT, -1, 0u, false};
     uint32_t px = 0, py = 0, boff = 0, sample = 0, depth = 0, nrays = 0;
     Rng rng{0, 0, 0, 0};
     f3 col = mk3(0.f, 0.f, 0.f), o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
@@ -892,9 +894,9 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                 trav_new = false;
             }
             if (A.nodes_in_lds)
-                bvh_run<true, MOVING>(A, s_bvh, s_nodes, ro, rd, a, rtime, have, trav);
+                bvh_run<true, MOVING, VERIFY>(A, s_bvh, s_nodes, ro, rd, a, rtime, have, trav);
             else
-                bvh_run<false, MOVING>(A, s_bvh, A.wnodes, ro, rd, a, rtime, have, trav);
+                bvh_run<false, MOVING, VERIFY>(A, s_bvh, A.wnodes, ro, rd, a, rtime, have, trav);
             idx = trav.idx;
             t_hit = trav.best;
         } else if (MFMA)
@@ -1034,6 +1036,10 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
         for (int i = 0; i < 8; ++i) atomicAdd(&A.debug[16 + i], sec_t[i]);
 #endif
     if (A.wave_end && lane == 0) A.wave_end[blockIdx.x * (kBlock / 64) + (tid >> 6)] = wall_clock64();
+    if (BVH && VERIFY) {   // traversal counters (accumulate over the lane's whole life: never reset per ray)
+        atomicAdd(&A.debug[8], (unsigned long long)trav.visits);
+        atomicAdd(&A.debug[9], (unsigned long long)trav.leaves + (unsigned long long)nrays * A.n_bvh_large);
+    }
     // scene.rs:118 ray_count: wave reduce, one atomic per wave
     unsigned long long total = nrays;
     for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);

@@ -1118,7 +1118,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
 
     void (*kern)(const KArgs) = nullptr;
     void (*pilot_kern)(const KArgs) = nullptr;
-    if (moving && bvh)
+    if (bvh && (A.verify & 1u))   // variant 8 on a tree kernel: count node fetches / sphere tests (no pilot: one launch to count)
+        kern = moving ? pt_trace_kernel<true, false, false, true, false, true> : pt_trace_kernel<true, false, false, true, false, false>;
+    else if (moving && bvh)
         kern = pt_trace_kernel<true, false, false, false, false, true>, pilot_kern = pt_trace_kernel<true, false, false, false, true, true>;
     else if (moving && (A.verify & 1u))
         kern = pt_trace_kernel<false, true, true, true, false, true>;
@@ -1360,6 +1362,15 @@ extern "C" int pt_selftest_probe(int device, uint32_t probe, const float *in, fl
     (void)hipFree(d_in);
     (void)hipFree(d_out);
     if (e != hipSuccess) return fail(PT_ERR_HIP, "probe failed: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
+extern "C" int pt_scene_traversal_counters(pt_scene *s, uint64_t out2[2], int reset) {
+    if (!s || !out2) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out2, s->d_debug + 8, 16, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(s->d_debug + 8, 0, 16));
     return PT_OK;
 }
 

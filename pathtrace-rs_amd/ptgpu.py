@@ -97,7 +97,7 @@ class PtWorldDesc(C.Structure):
 EXPORTS = [
     "pt_device_count", "pt_scene_create", "pt_scene_create_world", "pt_scene_prepare", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_render_shard_device", "pt_shard_rows", "pt_scene_set_seed_base", "pt_last_kernel_ms",
-    "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters",
+    "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
 ]
 
 _lib = None
@@ -136,6 +136,7 @@ def lib():
         L.pt_scene_set_tuning.argtypes = [vp, C.c_uint32, C.c_uint32]
         L.pt_selftest_probe.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_size_t]
         L.pt_scene_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+        L.pt_scene_traversal_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.pt_last_error.restype = C.c_char_p
         L.pt_version.restype = C.c_char_p
         _lib = L
@@ -293,6 +294,11 @@ class Scene:
         out = (C.c_uint64 * 4)()
         _check(lib().pt_scene_debug_counters(self._h, out, 1 if reset else 0))
         return dict(misses=out[0], candidates=out[1], overflows=out[2], exact_positives=out[3])
+
+    def traversal_counters(self, reset=True):
+        out = (C.c_uint64 * 2)()
+        _check(lib().pt_scene_traversal_counters(self._h, out, 1 if reset else 0))
+        return dict(nodes=out[0], sphere_tests=out[1])
 
     def last_kernel_ms(self):
         ms = C.c_float(0)

@@ -72,6 +72,7 @@ def _bind(L):
     L.ora_pixel_seed.restype, L.ora_pixel_seed.argtypes = u64, [u32, u32, u32]
     L.ora_sinf_cosf.argtypes = [f32, vp, vp]
     L.ora_ln_array.argtypes = [vp, vp, u64]
+    L.ora_bvh_counters.argtypes = [vp, C.c_int]
     L.ora_hitable_ray_hit.restype = C.c_int
     L.ora_hitable_ray_hit.argtypes = [vp, u32, vp, vp, f32, f32, f32, vp, vp, vp]
     L.ora_sphere_ray_hit.restype, L.ora_sphere_ray_hit.argtypes = C.c_int, [vp, vp, vp, f32, f32, vp]

@@ -637,6 +637,31 @@ def test_mfma_prefilter_covers_moving_spheres(ptgpu, pthost):
     assert queued < 6 * positives          # the swept bounds stay selective
 
 
+def test_traversal_counters_report_internal_tree_work(ptgpu, pthost, oracle):
+    """BVH-mode work is reported as node visits / sphere tests per ray. Verify mode on a tree kernel counts
+    them for the device's internal tree; the oracle counts the reference's both-children traversal. The image must
+    not depend on the counting kernel, and the internal tree must visit far fewer nodes than the reference."""
+    W, H, S = 240, 160, 2
+    hs = pthost.HostScene("random_spheres", W, H, samples=S, use_bvh=True, device=0)
+    sc, p = hs.device_scene(), ptgpu.PtParams(W, H, S, 10, 0, 1)
+    plain = np.zeros((H, W, 3), np.float32)
+    rays = sc.update(p, hs.camera, 0, plain)
+    sc.set_tuning(0, 8)
+    sc.traversal_counters(reset=True)
+    counted = np.zeros((H, W, 3), np.float32)
+    assert sc.update(p, hs.camera, 0, counted) == rays and np.array_equal(plain, counted)
+    t = sc.traversal_counters(reset=True)
+    sc.set_tuning(0, 0)
+    c = (C.c_uint64 * 2)()
+    oracle.lib().ora_bvh_counters(c, 1)
+    _, ref_rays = oracle.OracleScene("random_spheres", W, H, use_bvh=True).update(S)
+    oracle.lib().ora_bvh_counters(c, 1)
+    assert ref_rays == rays
+    print("per ray: reference %.1f nodes / %.1f leaf tests, internal tree %.1f nodes / %.1f sphere tests" % (
+        c[0] / rays, c[1] / rays, t["nodes"] / rays, t["sphere_tests"] / rays))
+    assert 1 < t["nodes"] / rays < c[0] / rays and t["sphere_tests"] > 0
+
+
 def test_device_ln_is_glibc_logf(ptgpu, oracle):
     """constant_medium.rs:60 -(1/density) * ln(u): the value decides whether a ray scatters, so the device logf must
     equal the host's bit for bit. u is a multiple of 2^-24 in [0, 1); also sweep ordinary floats."""
