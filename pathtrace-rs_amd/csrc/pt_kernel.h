@@ -403,6 +403,56 @@ __device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d,
 // set bits; bit -> fragment slot (tile*32 + row) -> sphere.
 constexpr int kEntCap = (kQueueCap + 1) / 2;  // u32 tile masks per lane in the same LDS area as the u16 scan queue
 
+// aabb.rs:46-58 with the SSE min/max NaN rule (second operand on NaN)
+__device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
+
+// aabb.rs:46-58 (exact), also returning the entry distance max(t0x, t0y, t0z, t_min) for ordering
+__device__ __forceinline__ bool aabb_hit_enter(const float mn[3], const float mx[3], f3 o, f3 rcp, float &t_enter) {
+    const float mnx = (mn[0] - o.x) * rcp.x, mny = (mn[1] - o.y) * rcp.y, mnz = (mn[2] - o.z) * rcp.z;
+    const float mxx = (mx[0] - o.x) * rcp.x, mxy = (mx[1] - o.y) * rcp.y, mxz = (mx[2] - o.z) * rcp.z;
+    const float t0x = sse_min(mnx, mxx), t0y = sse_min(mny, mxy), t0z = sse_min(mnz, mxz);
+    const float t1x = sse_max(mnx, mxx), t1y = sse_max(mny, mxy), t1z = sse_max(mnz, mxz);
+    const float lox = sse_max(t0x, kMinT), loy = sse_max(t0y, kMinT), loz = sse_max(t0z, kMinT);
+    const float hix = sse_min(t1x, kMaxT), hiy = sse_min(t1y, kMaxT), hiz = sse_min(t1z, kMaxT);
+    t_enter = fmaxf(fmaxf(lox, loy), loz);
+    return (hix > lox) && (hiy > loy) && (hiz > loz);
+}
+
+// BVH-world acceptance of a sphere hit (bvh.rs:37-62): the sphere only counts if every ancestor AABB of its leaf in
+// the CALLER's tree passes aabb.rs:46-58. Ancestor boxes nest, so the parent's box decides (plus the few ancestors
+// recorded in gate_chain above inverted boxes). A.gate == nullptr: list world, every hit counts.
+__device__ __forceinline__ bool gate_pass(const KArgs &A, int k, f3 o, f3 rcp) {
+    const float4 gmn = A.gate[2 * k], gmx = A.gate[2 * k + 1];
+    const float mn[3] = {gmn.x, gmn.y, gmn.z}, mx[3] = {gmx.x, gmx.y, gmx.z};
+    float te;
+    const uint32_t extra = __float_as_uint(gmn.w);
+    bool pass = extra != 0xffffffffu && aabb_hit_enter(mn, mx, o, rcp, te);
+    if (pass && extra != 0u) {   // rare: ancestors above an inverted (negative-radius) box
+        const float4 *ch = A.gate_chain + 2u * __float_as_uint(gmx.w);
+        for (uint32_t j = 0; j < extra && pass; ++j) {
+            const float4 cmn = ch[2 * j], cmx = ch[2 * j + 1];
+            const float bmn[3] = {cmn.x, cmn.y, cmn.z}, bmx[3] = {cmx.x, cmx.y, cmx.z};
+            pass = aabb_hit_enter(bmn, bmx, o, rcp, te);
+        }
+    }
+    return pass;
+}
+
+// One accepted-hit rule for both worlds: smaller t wins; equal t goes to the higher RANK, which is the DFS position of
+// the leaf in a BVH world (bvh.rs:47-53: `lhs.t < rhs.t ? lhs : rhs`) and ~index in a list world (hitable_list.rs:48:
+// the earlier entry keeps an equal t).
+__device__ __forceinline__ void accept_hit(const KArgs &A, int k, float t, f3 o, f3 d, float &best, int &idx, uint32_t &best_rank) {
+    const uint32_t rank = A.gate ? A.leaf_rank[k] : ~(uint32_t)k;
+    if (idx < 0 || t < best || (t == best && rank > best_rank)) {
+        if (!A.gate || gate_pass(A, k, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) {   // ray.rs:14 rcp_direction
+            best = t;
+            idx = k;
+            best_rank = rank;
+        }
+    }
+}
+
 // MovingSphere::centre (moving_sphere.rs:29-31): centre_start + ((time - time_start) * inv_time_delta) * centre_delta.
 // `c` carries the sphere as stored (centre_start in xyz; w untouched). Plain spheres are returned as they are.
 template <bool MOVING>
@@ -422,19 +472,15 @@ __device__ __forceinline__ float4 sphere_at(const KArgs &A, int k, float4 c, flo
 // exact reference test of one sphere, order independent: candidate t as sphere.rs:38-64 would
 // return it for t_max = f32::MAX, winner = lexicographic (t, index) minimum == the sequential
 // closest_so_far scan of hitable_list.rs:40-56 (DESIGN.md "order-independent closest hit")
-__device__ __forceinline__ void exact_candidate(const float4 c, int k, f3 o, f3 d, float a, float &best, int &idx) {
+__device__ __forceinline__ void exact_candidate(const KArgs &A, const float4 c, int k, f3 o, f3 d, float a, float &best, int &idx,
+                                                uint32_t &best_rank) {
     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
     const float disc = b * b - a * cc;
     if (disc > 0.0f) {
         float t = kMaxT;
-        if (sphere_roots(a, b, disc, t)) {
-            if (t < best || (t == best && k < idx) || idx < 0) {
-                best = t;
-                idx = k;
-            }
-        }
+        if (sphere_roots(a, b, disc, t)) accept_hit(A, k, t, o, d, best, idx, best_rank);
     }
 }
 
@@ -467,6 +513,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     };
     float best = kMaxT;
     int idx = -1;
+    uint32_t best_rank = 0;
     // phase 2 on the queued masks: exact arithmetic for every set bit, then the queue is empty again
     auto drain = [&]() {
         uint32_t tb = tbits, j = 0, cur = 0, curT = 0;
@@ -481,7 +528,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                 const uint32_t b = (uint32_t)__builtin_ctz(cur);
                 cur &= cur - 1u;
                 const int k = s_tile_sphere[slot_of(curT, b)];
-                exact_candidate(sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx);
+                exact_candidate(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
             }
         }
         tbits = 0;
@@ -528,7 +575,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     // ---- phase 2: exact arithmetic on the candidates of this lane's own ray ----
     for (uint32_t j = 0; j < A.n_large; ++j) {  // wave-uniform: spheres outside the prefilter's range
         const int k = (int)A.large[j];
-        if (active) exact_candidate(sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx);
+        if (active) exact_candidate(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
     }
     const bool overflow = VERIFY && cnt > (uint32_t)kEntCap;
     if (__any(overflow || (VERIFY && active))) {
@@ -536,9 +583,10 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
             // queue overflow (ray far outside the prefilter's accuracy range) or verify mode: brute force
             float vbest = kMaxT;
             int vidx = -1;
+            uint32_t vrank = 0;
             for (int k = 0; k < (int)A.n_spheres; ++k) {
                 const float4 c = sphere_at<MOVING>(A, k, sph[k], time);
-                exact_candidate(c, k, o, d, a, vbest, vidx);
+                exact_candidate(A, c, k, o, d, a, vbest, vidx, vrank);
                 if (VERIFY && active) {
                     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
                     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
@@ -581,10 +629,6 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     return idx;
 }
 
-// aabb.rs:46-58 with the SSE min/max NaN rule (second operand on NaN)
-__device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
-__device__ __forceinline__ float sse_max(float a, float b) { return a > b ? a : b; }
-
 // bvh.rs:37-62 over the CALLER's tree, restructured for the GPU without changing its result.
 //
 // Reference semantics: a leaf sphere is tested (with t_max = f32::MAX) iff every ancestor node's
@@ -603,18 +647,6 @@ struct DWideNode {  // 64 B
     int32_t lhs, rhs;        // >= 0 inner node, < 0 ~sphere
     uint32_t pad0, pad1;     // 1 / smallest |radius| below lhs / rhs (float bits)
 };
-
-// aabb.rs:46-58 (exact), also returning the entry distance max(t0x, t0y, t0z, t_min) for ordering
-__device__ __forceinline__ bool aabb_hit_enter(const float mn[3], const float mx[3], f3 o, f3 rcp, float &t_enter) {
-    const float mnx = (mn[0] - o.x) * rcp.x, mny = (mn[1] - o.y) * rcp.y, mnz = (mn[2] - o.z) * rcp.z;
-    const float mxx = (mx[0] - o.x) * rcp.x, mxy = (mx[1] - o.y) * rcp.y, mxz = (mx[2] - o.z) * rcp.z;
-    const float t0x = sse_min(mnx, mxx), t0y = sse_min(mny, mxy), t0z = sse_min(mnz, mxz);
-    const float t1x = sse_max(mnx, mxx), t1y = sse_max(mny, mxy), t1z = sse_max(mnz, mxz);
-    const float lox = sse_max(t0x, kMinT), loy = sse_max(t0y, kMinT), loz = sse_max(t0z, kMinT);
-    const float hix = sse_min(t1x, kMaxT), hiy = sse_min(t1y, kMaxT), hiz = sse_min(t1z, kMaxT);
-    t_enter = fmaxf(fmaxf(lox, loy), loz);
-    return (hix > lox) && (hiy > loy) && (hiz > loz);
-}
 
 // relative / absolute slack of the distance cull (DESIGN.md "BVH culling slack")
 constexpr float kCullRel = 1.02f;
@@ -636,23 +668,7 @@ __device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, const float4 c, 
             // BVH world: DFS-last leaf wins equal t (bvh.rs:47-53); list world: the lower list index (hitable_list.rs:48)
             const uint32_t rank = A.gate ? A.leaf_rank[k] : ~(uint32_t)k;
             if (idx < 0 || t < best || (t == best && rank > best_rank)) {
-                bool pass = true;
-                if (A.gate) {
-                    const float4 gmn = A.gate[2 * k], gmx = A.gate[2 * k + 1];
-                    const float mn[3] = {gmn.x, gmn.y, gmn.z}, mx[3] = {gmx.x, gmx.y, gmx.z};
-                    float te;
-                    const uint32_t extra = __float_as_uint(gmn.w);
-                    pass = extra != 0xffffffffu && aabb_hit_enter(mn, mx, o, rcp, te);
-                    if (pass && extra != 0u) {   // rare: ancestors above an inverted (negative-radius) box
-                        const float4 *ch = A.gate_chain + 2u * __float_as_uint(gmx.w);
-                        for (uint32_t j = 0; j < extra && pass; ++j) {
-                            const float4 cmn = ch[2 * j], cmx = ch[2 * j + 1];
-                            const float bmn[3] = {cmn.x, cmn.y, cmn.z}, bmx[3] = {cmx.x, cmx.y, cmx.z};
-                            pass = aabb_hit_enter(bmn, bmx, o, rcp, te);
-                        }
-                    }
-                }
-                if (pass) {
+                if (!A.gate || gate_pass(A, k, o, rcp)) {
                     best = t;
                     idx = k;
                     best_rank = rank;

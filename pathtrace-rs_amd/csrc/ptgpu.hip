@@ -962,7 +962,11 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     // more than kListTreeMin spheres, or a scene the MFMA prefilter cannot take (variant bit 64 forces the scan)
     constexpr uint32_t kListTreeMin = 768;   // = 24 MFMA tiles: beyond that the fragments no longer leave room for 2 workgroups per CU
     const bool list_tree = !ref_bvh && (s->variant & (4u | 64u)) == 0 && (s->n_spheres > kListTreeMin || s->n_spheres > 0xfff0u);
-    const bool bvh = ref_bvh || list_tree;       // kernel flavour: tree traversal
+    // A BVH WORLD is a list world plus two rules applied when a hit is accepted (ancestor-AABB gate, DFS-rank ties),
+    // so scenes the MFMA prefilter can take run on it in BVH mode as well (the tree kernel: variant bit 256, or 4)
+    const uint32_t n_pad0 = (s->n_spheres + kScanUnroll - 1) / kScanUnroll * kScanUnroll;
+    const bool mfma_fits = !s->is_world && (s->variant & (1u | 4u)) == 0 && n_pad0 * 16u <= 64u * 1024u && s->n_tiles > 0 && s->n_tiles <= 24u;
+    const bool bvh = (ref_bvh && !(mfma_fits && (s->variant & 256u) == 0)) || list_tree;   // kernel flavour: tree traversal
     HIP_TRY(hipSetDevice(s->device));
 
     // Sphere + MovingSphere worlds: the MOVING instantiations exist for the MFMA list kernel and the tree kernel,
@@ -972,9 +976,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (s->has_motion) {
         const float lo = std::min(cam->time0, cam->time1), hi = std::max(cam->time0, cam->time1);
         const bool time_ok = std::isfinite(lo) && std::isfinite(hi) && lo >= s->time_lo && hi <= s->time_hi;
-        const uint32_t n_pad = (s->n_spheres + kScanUnroll - 1) / kScanUnroll * kScanUnroll;
-        const bool will_mfma = !bvh && (s->variant & (1u | 4u)) == 0 && n_pad * 16u <= 64u * 1024u && s->n_tiles > 0 && s->n_tiles <= 24u;
-        moving = time_ok && (bvh || will_mfma) && (s->variant & 128u) == 0;
+        moving = time_ok && (bvh || mfma_fits) && (s->variant & 128u) == 0;
     }
 
     if (s->is_world || (s->has_motion && !moving)) {

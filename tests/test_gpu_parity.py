@@ -637,6 +637,22 @@ def test_mfma_prefilter_covers_moving_spheres(ptgpu, pthost):
     assert queued < 6 * positives          # the swept bounds stay selective
 
 
+@pytest.mark.parametrize("preset", ["random_spheres", "aras", "small", "random"])
+def test_bvh_world_on_the_prefilter_kernel_equals_the_tree_kernel(ptgpu, pthost, oracle, preset):
+    """A BVH world is a list world + the ancestor-AABB gate + DFS-rank ties at hit acceptance, so it runs on the MFMA
+    list kernel when the scene fits it. Both kernels and the oracle's BVHNode::ray_hit recursion must agree."""
+    W, H, S = 240, 160, 4
+    hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=True, device=0)
+    sc, p = hs.device_scene(), ptgpu.PtParams(W, H, S, 10, 0, 1)
+    ref, ref_rays = oracle.OracleScene(preset, W, H, use_bvh=True).update(S)
+    for variant in (0, 256, 8):        # default, tree kernel, verify mode of the default
+        sc.set_tuning(0, variant)
+        out = np.zeros((H, W, 3), np.float32)
+        rays = sc.update(p, hs.camera, 0, out)
+        assert rays == ref_rays and np.array_equal(ref, out), (variant, _report(ref, out))
+    sc.set_tuning(0, 0)
+
+
 def test_traversal_counters_report_internal_tree_work(ptgpu, pthost, oracle):
     """BVH-mode work is reported as node visits / sphere tests per ray. Verify mode on a tree kernel counts
     them for the device's internal tree; the oracle counts the reference's both-children traversal. The image must
@@ -646,7 +662,7 @@ def test_traversal_counters_report_internal_tree_work(ptgpu, pthost, oracle):
     sc, p = hs.device_scene(), ptgpu.PtParams(W, H, S, 10, 0, 1)
     plain = np.zeros((H, W, 3), np.float32)
     rays = sc.update(p, hs.camera, 0, plain)
-    sc.set_tuning(0, 8)
+    sc.set_tuning(0, 8 | 256)       # count on the tree kernel (256: do not use the MFMA list kernel for this BVH world)
     sc.traversal_counters(reset=True)
     counted = np.zeros((H, W, 3), np.float32)
     assert sc.update(p, hs.camera, 0, counted) == rays and np.array_equal(plain, counted)

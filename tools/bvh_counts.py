@@ -29,7 +29,7 @@ print("  reference traversal (oracle, %d rays): %.1f BVHNode::ray_hit calls, %.1
     rays, c[0] / rays, c[1] / rays, L.ora_scene_num_bvh_nodes(sc.h)))
 hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=True, device=0)
 dev = hs.device_scene()
-dev.set_tuning(0, 8)
+dev.set_tuning(0, 8 | 256)   # verify mode on the tree kernel
 dev.traversal_counters(reset=True)
 out = np.zeros((H, W, 3), np.float32)
 rays = dev.update(ptgpu.PtParams(W, H, S, 10, 0, 1), hs.camera, 0, out)

@@ -37,6 +37,9 @@ for seed in range(first, first + count):
     for bvh in (False, True):
         out, rays, ref, ref_rays = tgp._render_world_both(ptgpu, ob, w, W, H, S, bvh, depth=depth, frame=frame)
         ok = rays == ref_rays and np.array_equal(ref, out, equal_nan=True)
+        if ok and bvh and kind != 1:     # BVH worlds also have a second device path: the internal-tree kernel
+            out2, rays2, _, _ = tgp._render_world_both(ptgpu, ob, w, W, H, S, bvh, variant=256, depth=depth, frame=frame)
+            ok = rays2 == ref_rays and np.array_equal(ref, out2, equal_nan=True)
         if not ok:
             bad += 1
             print("MISMATCH seed %d kind %d bvh %s: rays %d vs %d, %s" % (seed, kind, bvh, rays, ref_rays, tgp._report(ref, out)))
