@@ -442,10 +442,19 @@ __device__ __forceinline__ bool gate_pass(const KArgs &A, int k, f3 o, f3 rcp) {
 // One accepted-hit rule for both worlds: smaller t wins; equal t goes to the higher RANK, which is the DFS position of
 // the leaf in a BVH world (bvh.rs:47-53: `lhs.t < rhs.t ? lhs : rhs`) and ~index in a list world (hitable_list.rs:48:
 // the earlier entry keeps an equal t).
+// GATED = false compiles the list-world rule alone (no rank register, no gate code in the hot list kernel).
+template <bool GATED>
 __device__ __forceinline__ void accept_hit(const KArgs &A, int k, float t, f3 o, f3 d, float &best, int &idx, uint32_t &best_rank) {
-    const uint32_t rank = A.gate ? A.leaf_rank[k] : ~(uint32_t)k;
+    if (!GATED) {
+        if (idx < 0 || t < best || (t == best && k < idx)) {
+            best = t;
+            idx = k;
+        }
+        return;
+    }
+    const uint32_t rank = A.leaf_rank[k];
     if (idx < 0 || t < best || (t == best && rank > best_rank)) {
-        if (!A.gate || gate_pass(A, k, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) {   // ray.rs:14 rcp_direction
+        if (gate_pass(A, k, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) {   // ray.rs:14 rcp_direction
             best = t;
             idx = k;
             best_rank = rank;
@@ -472,6 +481,7 @@ __device__ __forceinline__ float4 sphere_at(const KArgs &A, int k, float4 c, flo
 // exact reference test of one sphere, order independent: candidate t as sphere.rs:38-64 would
 // return it for t_max = f32::MAX, winner = lexicographic (t, index) minimum == the sequential
 // closest_so_far scan of hitable_list.rs:40-56 (DESIGN.md "order-independent closest hit")
+template <bool GATED>
 __device__ __forceinline__ void exact_candidate(const KArgs &A, const float4 c, int k, f3 o, f3 d, float a, float &best, int &idx,
                                                 uint32_t &best_rank) {
     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
@@ -480,11 +490,11 @@ __device__ __forceinline__ void exact_candidate(const KArgs &A, const float4 c, 
     const float disc = b * b - a * cc;
     if (disc > 0.0f) {
         float t = kMaxT;
-        if (sphere_roots(a, b, disc, t)) accept_hit(A, k, t, o, d, best, idx, best_rank);
+        if (sphere_roots(a, b, disc, t)) accept_hit<GATED>(A, k, t, o, d, best, idx, best_rank);
     }
 }
 
-template <bool VERIFY, bool MOVING>
+template <bool VERIFY, bool MOVING, bool GATED>
 __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *sph, const uint4 *s_afrag,
                                                    const uint16_t *s_tile_sphere, uint16_t *queue,
                                                    f3 o, f3 d, float a, bool active, float time, float &t_out,
@@ -528,7 +538,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                 const uint32_t b = (uint32_t)__builtin_ctz(cur);
                 cur &= cur - 1u;
                 const int k = s_tile_sphere[slot_of(curT, b)];
-                exact_candidate(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+                exact_candidate<GATED>(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
             }
         }
         tbits = 0;
@@ -575,7 +585,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     // ---- phase 2: exact arithmetic on the candidates of this lane's own ray ----
     for (uint32_t j = 0; j < A.n_large; ++j) {  // wave-uniform: spheres outside the prefilter's range
         const int k = (int)A.large[j];
-        if (active) exact_candidate(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+        if (active) exact_candidate<GATED>(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
     }
     const bool overflow = VERIFY && cnt > (uint32_t)kEntCap;
     if (__any(overflow || (VERIFY && active))) {
@@ -586,7 +596,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
             uint32_t vrank = 0;
             for (int k = 0; k < (int)A.n_spheres; ++k) {
                 const float4 c = sphere_at<MOVING>(A, k, sph[k], time);
-                exact_candidate(A, c, k, o, d, a, vbest, vidx, vrank);
+                exact_candidate<GATED>(A, c, k, o, d, a, vbest, vidx, vrank);
                 if (VERIFY && active) {
                     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
                     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
@@ -771,7 +781,8 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
 // MOVING: the world also holds MovingSphere entries (moving_sphere.rs): rays keep their time (camera.rs:59) and
 // every exact sphere test / normal uses the centre at that time; prefilter fragments and internal-tree boxes
 // were built over the motion's whole sweep.
-template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false>
+// GATE: a BVH world on the MFMA list kernel (ancestor-AABB gate + DFS-rank ties at hit acceptance).
+template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false, bool GATE = false>
 __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
@@ -916,7 +927,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             idx = trav.idx;
             t_hit = trav.best;
         } else if (MFMA)
-            idx = intersect_list_mfma<VERIFY, MOVING>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere,
+            idx = intersect_list_mfma<VERIFY, MOVING, GATE>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere,
                                                       s_queue, ro, rd, a, have, rtime, t_hit
 #ifdef PT_SECTIONS
                                                       , sec_t

@@ -1124,6 +1124,14 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         kern = moving ? pt_trace_kernel<true, false, false, true, false, true> : pt_trace_kernel<true, false, false, true, false, false>;
     else if (moving && bvh)
         kern = pt_trace_kernel<true, false, false, false, false, true>, pilot_kern = pt_trace_kernel<true, false, false, false, true, true>;
+    else if (mfma && ref_bvh && moving && (A.verify & 1u))
+        kern = pt_trace_kernel<false, true, true, true, false, true, true>;
+    else if (mfma && ref_bvh && moving)
+        kern = pt_trace_kernel<false, true, true, false, false, true, true>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true, true>;
+    else if (mfma && ref_bvh && (A.verify & 1u))
+        kern = pt_trace_kernel<false, true, true, true, false, false, true>;
+    else if (mfma && ref_bvh)
+        kern = pt_trace_kernel<false, true, true, false, false, false, true>, pilot_kern = pt_trace_kernel<false, true, true, false, true, false, true>;
     else if (moving && (A.verify & 1u))
         kern = pt_trace_kernel<false, true, true, true, false, true>;
     else if (moving)
