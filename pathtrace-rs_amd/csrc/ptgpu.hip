@@ -1181,7 +1181,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         P.ray_count = reinterpret_cast<unsigned long long *>(scratch);      // scratch[0..1]
         P.verify = 0;
         P.wave_end = nullptr;
-        hipLaunchKernelGGL(pilot_kern, dim3(grid), dim3(kBlock), lds, stream, P);
+        // a third of the frame's grid: the pilot has ~100x less work, and each workgroup stages the scene into LDS
+        hipLaunchKernelGGL(pilot_kern, dim3((grid + 2u) / 3u), dim3(kBlock), lds, stream, P);
         hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, params->max_depth + 1u, order);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
