@@ -720,6 +720,10 @@ struct BvhTrav {
     uint32_t rank;
     bool active;
 };
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 4
+#endif
+constexpr int kRefillMin = PT_REFILL_MIN;  // lanes that must be waiting before a wave fetches new pixels
 constexpr int kReadyMin = 56;  // shade as soon as this many lanes of the wave have a finished traversal
 
 template <bool MOVING>
@@ -846,8 +850,12 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
     float rtime = 0.f;  // ray.time (only MOVING kernels read it)
 
     for (;;) {
-        // ---- refill: one wave-aggregated atomic for all lanes that need a pixel
-        if (!have && !exhausted) {
+        // ---- refill: one wave-aggregated atomic for all lanes that need a pixel. The refill code (a global atomic
+        // round trip and four SplitMix64 steps of 64-bit multiplies) runs for the whole wave whenever ANY lane needs
+        // it, so lanes wait until kRefillMin of them do (or nobody has work left): fewer, fuller refills.
+        const unsigned long long want = __ballot(!have && !exhausted);
+        const bool refill_now = __popcll(want) >= kRefillMin || __ballot(have) == 0ull;
+        if (!have && !exhausted && refill_now) {
             const unsigned long long m = __ballot(1);
             const int leader = __ffsll((long long)m) - 1;
             uint32_t base = 0;
