@@ -100,6 +100,7 @@ struct KArgs {
     uint32_t width, height, samples, max_depth, frame_num;
     float inv_nx, inv_ny, inv_ns, mix_prev, mix_new;  // scene.rs:82-87 (computed on the host in f32)
     uint32_t random_seed;
+    uint32_t refill_min;         // lanes that must be waiting before a wave fetches new pixels (4; 8 below 32 spp)
     uint64_t seed_base;
     // sharding: rows y with y % shard_count == shard_index, compact buffer
     uint32_t shard_index, shard_count, local_rows;
@@ -720,10 +721,6 @@ struct BvhTrav {
     uint32_t rank;
     bool active;
 };
-#ifndef PT_REFILL_MIN
-#define PT_REFILL_MIN 4
-#endif
-constexpr int kRefillMin = PT_REFILL_MIN;  // lanes that must be waiting before a wave fetches new pixels
 constexpr int kReadyMin = 56;  // shade as soon as this many lanes of the wave have a finished traversal
 
 template <bool MOVING>
@@ -852,9 +849,9 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
     for (;;) {
         // ---- refill: one wave-aggregated atomic for all lanes that need a pixel. The refill code (a global atomic
         // round trip and four SplitMix64 steps of 64-bit multiplies) runs for the whole wave whenever ANY lane needs
-        // it, so lanes wait until kRefillMin of them do (or nobody has work left): fewer, fuller refills.
+        // it, so lanes wait until A.refill_min of them do (or nobody has work left): fewer, fuller refills.
         const unsigned long long want = __ballot(!have && !exhausted);
-        const bool refill_now = __popcll(want) >= kRefillMin || __ballot(have) == 0ull;
+        const bool refill_now = __popcll(want) >= (int)A.refill_min || __ballot(have) == 0ull;
         if (!have && !exhausted && refill_now) {
             const unsigned long long m = __ballot(1);
             const int leader = __ffsll((long long)m) - 1;

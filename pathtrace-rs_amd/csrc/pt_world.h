@@ -36,6 +36,7 @@ struct WArgs {
     uint32_t width, height, samples, max_depth, frame_num;
     float inv_nx, inv_ny, inv_ns, mix_prev, mix_new;
     uint32_t random_seed;
+    uint32_t refill_min;
     uint64_t seed_base;
     uint32_t shard_index, shard_count, local_rows;
     uint32_t tiles_x, n_items;
@@ -277,8 +278,10 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
     WRay ray = w_ray_new(mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 1.f), 0.f);
 
     for (;;) {
-        // ---- refill (same scheme as pt_trace_kernel: one wave-aggregated atomic, 8x8 pixel tiles)
-        if (!have && !exhausted) {
+        // ---- refill (same scheme as pt_trace_kernel: one wave-aggregated atomic, 8x8 pixel tiles, batched until
+        // A.refill_min lanes are waiting)
+        const bool refill_now = __popcll(__ballot(!have && !exhausted)) >= (int)A.refill_min || __ballot(have) == 0ull;
+        if (!have && !exhausted && refill_now) {
             const unsigned long long m = __ballot(1);
             const int leader = __ffsll((long long)m) - 1;
             uint32_t base = 0;

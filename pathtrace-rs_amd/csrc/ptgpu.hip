@@ -938,6 +938,8 @@ void fill_frame_args(Args &X, const pt_scene *s, const pt_params *params, const 
         X.mix_new = one - mp;
     }
     X.random_seed = params->random_seed;
+    // refills are batched: measured best at 4 waiting lanes for long pixels, 8 when pixels are short (< 32 spp)
+    X.refill_min = params->samples < 32u ? 8u : 4u;
     X.seed_base = s->seed_base;
     X.shard_index = shard_index;
     X.shard_count = shard_count;
