@@ -838,7 +838,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
 #else
 #define PT_SEC(i) do { } while (0)
 #endif
-    bool have = false, exhausted = false, need_cam = true, trav_new = false;
+    bool have = false, exhausted = false, need_cam = true, trav_new = false, finished = false;
     uint32_t lane_tile = 0, pix_rays = 0;
     BvhTrav trav{0u, 0u, 0, kMaxT, -1, 0u, false};
     uint32_t px = 0, py = 0, boff = 0, sample = 0, depth = 0, nrays = 0;
@@ -853,6 +853,18 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
         const unsigned long long want = __ballot(!have && !exhausted);
         const bool refill_now = __popcll(want) >= (int)A.refill_min || __ballot(have) == 0ull;
         if (!have && !exhausted && refill_now) {
+            if (finished) {
+                // scene.rs:113-116
+                finished = false;
+                col = scale3(col, A.inv_ns);
+                if (!PILOT) {
+                    float *out = A.rgb + boff;
+                    out[0] = out[0] * A.mix_prev + col.x * A.mix_new;
+                    out[1] = out[1] * A.mix_prev + col.y * A.mix_new;
+                    out[2] = out[2] * A.mix_prev + col.z * A.mix_new;
+                }
+                if (PILOT) atomicAdd(&A.tile_cost[lane_tile], pix_rays);
+            }
             const unsigned long long m = __ballot(1);
             const int leader = __ffsll((long long)m) - 1;
             uint32_t base = 0;
@@ -1048,16 +1060,10 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                 sample += 1;
                 need_cam = true;
                 if (sample == A.samples) {
-                    // scene.rs:113-116
-                    col = scale3(col, A.inv_ns);
-                    if (!PILOT) {
-                        float *out = A.rgb + boff;
-                        out[0] = out[0] * A.mix_prev + col.x * A.mix_new;
-                        out[1] = out[1] * A.mix_prev + col.y * A.mix_new;
-                        out[2] = out[2] * A.mix_prev + col.z * A.mix_new;
-                    }
-                    if (PILOT) atomicAdd(&A.tile_cost[lane_tile], pix_rays);
+                    // the pixel is written when the lane fetches its next one (the refill below is batched over
+                    // several lanes, and so is this read-modify-write of the frame buffer)
                     have = false;
+                    finished = true;
                 }
             }
         }
