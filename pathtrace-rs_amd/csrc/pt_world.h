@@ -26,7 +26,7 @@ struct WArgs {
     const DTex *texs;
     const float4 *perlin_vec;
     const uint32_t *perlin_perm;
-    uint32_t n_hit;
+    uint32_t n_hit, n_xf;
     int32_t bvh_root;        // >= 0: BVHNode::ray_hit over `nodes`; < 0: HitableList::ray_hit
     uint32_t bvh_stack_entries;
     uint32_t has_sky;
@@ -250,7 +250,10 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
     return -1;
 }
 
-template <bool BVH>
+// HIT_LDS: the hitable records and transforms are staged in LDS (worlds up to 16 KB: every preset); the list scan
+// then reads them at LDS latency instead of waiting on the scalar cache for each entry (58 % of the wave-cycles of
+// cornell_smoke were such waits), and BVH mode gathers them per lane from LDS instead of L2.
+template <bool BVH, bool HIT_LDS>
 __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *p = smem;
@@ -259,16 +262,30 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
     p += A.has_noise ? (4096 + 3072) : 0;
     int32_t *s_stack = reinterpret_cast<int32_t *>(p);
     p += BVH ? (A.bvh_stack_entries * kBlock * 4) : 0;
+    const pt_hitable *s_hit = reinterpret_cast<const pt_hitable *>(p);
+    p += HIT_LDS ? A.n_hit * 64u : 0u;
+    const pt_affine *s_xf = reinterpret_cast<const pt_affine *>(p);
+    p += HIT_LDS ? A.n_xf * 96u : 0u;
     float *s_path = reinterpret_cast<float *>(p);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    if (HIT_LDS) {
+        uint4 *dh = reinterpret_cast<uint4 *>(const_cast<pt_hitable *>(s_hit));
+        const uint4 *sh = reinterpret_cast<const uint4 *>(A.hit);
+        for (uint32_t k = tid; k < A.n_hit * 4u; k += kBlock) dh[k] = sh[k];
+        uint4 *dx = reinterpret_cast<uint4 *>(const_cast<pt_affine *>(s_xf));
+        const uint4 *sx = reinterpret_cast<const uint4 *>(A.xf);
+        for (uint32_t k = tid; k < A.n_xf * 6u; k += kBlock) dx[k] = sx[k];
+    }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += kBlock) s_pvec[k] = A.perlin_vec[k];
         for (int k = tid; k < 768; k += kBlock) s_perm[k] = A.perlin_perm[k];
     }
     __syncthreads();
     PerlinLds pn{s_pvec, s_perm};
+    const pt_hitable *hit = HIT_LDS ? s_hit : A.hit;
+    const pt_affine *xf = HIT_LDS ? s_xf : A.xf;
     float *path = A.stack_in_lds ? (s_path + tid) : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * kBlock + tid);
 
     bool have = false, exhausted = false, need_cam = true;
@@ -344,7 +361,7 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
                 float closest = kMaxT;
                 for (uint32_t k = 0; k < A.n_hit; ++k) {
                     WHit h;
-                    const int m = w_hitable(A.hit[k], A.xf, ray, kMinT, closest, rng, h);
+                    const int m = w_hitable(hit[k], xf, ray, kMinT, closest, rng, h);
                     if (m >= 0) {
                         best = h, best_mat = (uint32_t)m, found = true;
                         closest = h.t;
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
                     const int32_t ref = s_stack[--sp * kBlock + tid];
                     if (ref < 0) {
                         WHit h;
-                        const int m = w_hitable(A.hit[~ref], A.xf, ray, kMinT, kMaxT, rng, h);
+                        const int m = w_hitable(hit[~ref], xf, ray, kMinT, kMaxT, rng, h);
                         if (m >= 0) {
                             // bvh.rs:48-53: lhs only when lhs.t < rhs.t -> an equal t goes to the later leaf
                             if (!found || !(best.t < h.t)) best = h, best_mat = (uint32_t)m;

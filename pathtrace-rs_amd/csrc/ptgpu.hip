@@ -96,7 +96,7 @@ struct pt_scene {
     float time_lo = 0.f, time_hi = 0.f;
     // general world (pt_scene_create_world with non-sphere hitables): traced by pt_world_kernel
     bool is_world = false;
-    uint32_t n_hitables = 0;
+    uint32_t n_hitables = 0, n_world_xf = 0;
     pt_hitable *d_hitables = nullptr;
     pt_affine *d_transforms = nullptr;
     pt_bvh_node *d_ref_nodes = nullptr;   // the caller's tree as given (BVHNode::ray_hit is followed literally)
@@ -800,6 +800,7 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
     s->num_cus = prop.multiProcessorCount;
     s->is_world = true;
     s->n_hitables = desc->n_hitables;
+    s->n_world_xf = desc->n_transforms;
     s->n_materials = desc->n_materials;
     s->n_textures = desc->n_textures;
     s->bvh_root = desc->n_bvh_nodes ? desc->bvh_root : -1;
@@ -1000,6 +1001,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         if (W.n_items == 0) return PT_OK;
         uint32_t lds = s->has_noise ? (4096u + 3072u) : 0u;
         if (ref_bvh) lds += W.bvh_stack_entries * kBlock * 4u;
+        W.n_xf = s->n_world_xf;
+        const bool hit_lds = s->n_hitables * 64u + s->n_world_xf * 96u <= 40960u;   // records + transforms staged in LDS
+        if (hit_lds) lds += s->n_hitables * 64u + s->n_world_xf * 96u;
         const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
         W.stack_in_lds = (lds + path_bytes <= 60u * 1024u) ? 1u : 0u;
         if (W.stack_in_lds) lds += (uint32_t)path_bytes;
@@ -1021,7 +1025,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
             }
             W.gstack = s->d_gstack;
         }
-        void (*wk)(const WArgs) = ref_bvh ? pt_world_kernel<true> : pt_world_kernel<false>;
+        void (*wk)(const WArgs) = ref_bvh ? (hit_lds ? pt_world_kernel<true, true> : pt_world_kernel<true, false>)
+                                          : (hit_lds ? pt_world_kernel<false, true> : pt_world_kernel<false, false>);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipEventRecord(s->ev_start, stream));
         hipLaunchKernelGGL(wk, dim3(grid), dim3(kBlock), lds, stream, W);
