@@ -25,6 +25,11 @@ namespace ptdev {
 #ifndef PT_MINWAVES
 #define PT_MINWAVES 2
 #endif
+#ifndef PT_TILE_LOG2
+#define PT_TILE_LOG2 3
+#endif
+constexpr uint32_t kTileLog2 = PT_TILE_LOG2;             // work tiles are (1 << kTileLog2)^2 pixels
+constexpr uint32_t kTileSide = 1u << kTileLog2, kTilePix = kTileSide * kTileSide;
 constexpr int kBlock = PT_BLOCK;  // threads per workgroup (the main loop never synchronises across waves)
 constexpr int kBvhStack = 32;    // per-lane traversal stack entries (LDS)
 
@@ -874,12 +879,12 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             if (item >= A.n_items) {
                 exhausted = true;
             } else {
-                const uint32_t in = item & 63u;
-                const uint32_t tile = A.tile_order ? A.tile_order[item >> 6] : (item >> 6);
+                const uint32_t in = item & (kTilePix - 1u);
+                const uint32_t tile = A.tile_order ? A.tile_order[item >> (2u * kTileLog2)] : (item >> (2u * kTileLog2));
                 lane_tile = tile;
                 pix_rays = 0;
-                const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
-                const uint32_t ly = (tile / A.tiles_x) * 8u + (in >> 3);
+                const uint32_t x = (tile % A.tiles_x) * kTileSide + (in & (kTileSide - 1u));
+                const uint32_t ly = (tile / A.tiles_x) * kTileSide + (in >> kTileLog2);
                 // (the list kernels' cost-estimation pilot samples one pixel per 2x2 block: a quarter of the rays orders
                 //  the tiles as well as all of them did and costs 0.2 ms less; the tree kernels keep every pixel, measured)
                 if (x < A.width && ly < A.local_rows && !(PILOT && !BVH && ((x | ly) & 1u))) {

@@ -308,9 +308,9 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
             if (item >= A.n_items) {
                 exhausted = true;
             } else {
-                const uint32_t in = item & 63u, tile = item >> 6;
-                const uint32_t x = (tile % A.tiles_x) * 8u + (in & 7u);
-                const uint32_t ly = (tile / A.tiles_x) * 8u + (in >> 3);
+                const uint32_t in = item & (kTilePix - 1u), tile = item >> (2u * kTileLog2);
+                const uint32_t x = (tile % A.tiles_x) * kTileSide + (in & (kTileSide - 1u));
+                const uint32_t ly = (tile / A.tiles_x) * kTileSide + (in >> kTileLog2);
                 if (x < A.width && ly < A.local_rows) {
                     have = true;
                     px = x;

@@ -946,8 +946,8 @@ void fill_frame_args(Args &X, const pt_scene *s, const pt_params *params, const 
     X.shard_index = shard_index;
     X.shard_count = shard_count;
     X.local_rows = pt_shard_rows(params->height, shard_index, shard_count);
-    X.tiles_x = (params->width + 7u) / 8u;
-    X.n_items = X.tiles_x * ((X.local_rows + 7u) / 8u) * 64u;
+    X.tiles_x = (params->width + kTileSide - 1u) / kTileSide;
+    X.n_items = X.tiles_x * ((X.local_rows + kTileSide - 1u) / kTileSide) * kTilePix;
     X.rgb = d_rgb;
     X.ray_count = reinterpret_cast<unsigned long long *>(d_ray_count);
     X.work_counter = s->d_work_counter;
@@ -1164,9 +1164,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.wave_end = timing ? d_wave_end : nullptr;
     if (timing) (void)hipMemsetAsync(d_wave_end, 0, 65536 * 8, stream);
     // ---- heavy-first work order from a 1-spp pilot pass (variant bit 32 disables it) -------------------
-    const uint32_t n_work_tiles = A.n_items / 64u;
+    const uint32_t n_work_tiles = A.n_items / kTilePix;
     if (pilot_kern && n_work_tiles >= 256u && params->samples >= kPilotMinSamples && (s->variant & 32u) == 0) {  // the pilot costs ~0.3 ms
-        const size_t px_floats = (size_t)n_work_tiles * 64u * 3u;
+        const size_t px_floats = (size_t)n_work_tiles * kTilePix * 3u;
         if (n_work_tiles > s->d_tile_cap) {
             (void)hipFree(s->d_tile_buf);
             (void)hipFree(s->d_pilot_rgb);
