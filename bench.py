@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--bvh", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="N = 1: skip the extra measurement of overlapped independent frames")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: run the collective on the render stream (no double buffering)")
     ap.add_argument("--cpu-secs", type=float, default=15.0)
     args = ap.parse_args()
@@ -214,6 +215,37 @@ def main():
                   "steps": k2, "scaling": "strong",
                   "workload": "ONE %dx%d %dspp frame, rows interleaved over %d GPUs, all_gather of the shards" % (W, H, S, N)}
 
+    pipelined = None
+    if not multi and not args.no_pipeline:
+        # Extra figure, never `value`: independent frames back to back on two scene handles / two HIP streams, so the
+        # tail of frame k (its last, serial pixels) and the pilot pass of frame k + 1 overlap. A single frame cannot
+        # use this; a renderer producing a sequence of independent frames (animation, tiles of a bigger image) can.
+        hs2 = pthost.HostScene(args.preset, W, H, samples=S, use_bvh=args.bvh, device=local_rank)
+        handles = [(scene, stream, torch.zeros((H, W, 3), dtype=torch.float32, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)),
+                   (hs2.device_scene(), torch.cuda.Stream(device=dev), torch.zeros((H, W, 3), dtype=torch.float32, device=dev),
+                    torch.zeros(1, dtype=torch.int64, device=dev))]
+
+        def pstep(k):
+            sc, st, buf, rc = handles[k % 2]
+            with torch.cuda.stream(st):
+                buf.zero_()
+                sc.update_device(params, cam, 0, buf.data_ptr(), rc.data_ptr(), st.cuda_stream)
+
+        kp = max(4, args.steps)
+        for k in range(2):
+            pstep(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(kp):
+            pstep(k)
+        torch.cuda.synchronize()
+        elp = time.perf_counter() - t0
+        assert int(handles[0][3].item()) == rays_per_step and int(handles[1][3].item()) == rays_per_step
+        assert torch.equal(handles[0][2], state["frame"]) and torch.equal(handles[1][2], state["frame"])
+        pipelined = {"value": rays_per_step * kp / 1e6 / elp, "unit": "Mrays/s", "ms_per_frame": elp / kp * 1e3, "frames": kp,
+                     "note": "independent frames alternating over two scene handles and two HIP streams (the tail of one frame "
+                             "overlaps the start of the next); each frame is bit-identical to the single-frame result"}
+
     if multi and os.environ.get("PT_BENCH_CHECK") == "1":
         # self-check of the double-buffered pipeline: its last frame must equal a plain serial step, bit for bit
         for _ in range(3):
@@ -290,6 +322,8 @@ def main():
         }
         if strong is not None:
             out["strong_scaling_tiles"] = strong
+        if pipelined is not None:
+            out["pipelined_frames"] = pipelined
         if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.preset, W, H, S, depth, args.bvh, args.cpu_secs)
         print(json.dumps(out))

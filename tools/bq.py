@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Brief bench wrapper: runs bench.py with the given args and prints value / ms / launch geometry."""
 import json, subprocess, sys
-out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline"] + sys.argv[1:], capture_output=True, text=True)
+out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--no-pipeline"] + sys.argv[1:], capture_output=True, text=True)
 line = [l for l in out.stdout.splitlines() if l.startswith("{")]
 if not line:
     print("FAILED", out.stdout[-500:], out.stderr[-1500:]); sys.exit(1)
