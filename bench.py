@@ -134,8 +134,9 @@ def main():
     stream = torch.cuda.current_stream()
     multi = N > 1 or dist is not None
     max_rows = sharding.padded_rows(H, N)
-    # Two buffer sets: the collective + blend of step k run on their own HIP stream while the kernel of step k + 1
-    # already renders into the other set (the persistent grid leaves CUs to RCCL as its workgroups retire).
+    # Three buffer sets: the collective + blend of step k run on their own HIP stream while the kernels of steps k + 1
+    # and k + 2 render into the other sets. The persistent grid holds every CU, so the exchange of step k actually runs
+    # when the workgroups of step k + 1 retire; with only two sets step k + 2 would have to wait for it.
     overlap = multi and not args.no_overlap
     comm = torch.cuda.Stream(device=dev) if overlap else stream
     sets = [dict(full=torch.zeros((H, W, 3), dtype=torch.float32, device=dev),
@@ -143,7 +144,7 @@ def main():
                  rays=torch.zeros(1, dtype=torch.int64, device=dev),
                  rows=torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev) if multi else None,
                  frames=torch.empty((N, H, W, 3), dtype=torch.float32, device=dev) if multi else None,
-                 done=None) for _ in range(2 if overlap else 1)]
+                 done=None) for _ in range(3 if overlap else 1)]
     state = {"k": 0, "last": sets[0], "frame": None}
 
     def step(mode):
@@ -193,11 +194,15 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step(mode)
-            # kernel duration of this step from the HIP events recorded on the launch stream
-            # (pt_last_kernel_ms synchronises on the stop event only)
-            kms_list.append(scene.last_kernel_ms())
+            # kernel duration of this step from the HIP events recorded on the launch stream (pt_last_kernel_ms
+            # synchronises on the stop event only). In the overlapped multi-GPU pipeline the host must not wait per
+            # step (the next kernel is enqueued behind the running one): there the last step's duration is read.
+            if not overlap:
+                kms_list.append(scene.last_kernel_ms())
         fence()
         el = time.perf_counter() - t0
+        if overlap:
+            kms_list.append(scene.last_kernel_ms())
         t = torch.tensor([el, sum(kms_list) / max(1, len(kms_list))], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
