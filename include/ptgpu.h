@@ -73,12 +73,14 @@ typedef struct pt_material {
     int32_t texture; /* Lambertian / Isotropic albedo, DiffuseLight emit texture index, else -1 */
 } pt_material;
 
-/* texture.rs:40-55 `Texture` (Image is out of scope: needs media/earthmap.jpg) */
-enum { PT_TEX_CONSTANT = 0, PT_TEX_CHECKER = 1, PT_TEX_NOISE = 2 };
+/* texture.rs:40-55 `Texture`. Image (texture.rs:5-37 RgbImage) is sampled at the hit's (u, v): Rect hits carry real
+ * coordinates (rect.rs:97-98), every sphere hit of the live path has u = v = 0 (sphere.rs:47-48), i.e. reads the
+ * first texel of the LAST row. Images belong to general worlds (pt_world_desc.images). */
+enum { PT_TEX_CONSTANT = 0, PT_TEX_CHECKER = 1, PT_TEX_NOISE = 2, PT_TEX_IMAGE = 3 };
 typedef struct pt_texture {
     uint32_t kind;
     float color[3]; /* Constant */
-    int32_t odd;    /* Checker: texture indices (may nest) */
+    int32_t odd;    /* Checker: texture indices (may nest) | Image: index into pt_world_desc.images */
     int32_t even;
     float scale;    /* Noise */
 } pt_texture;
@@ -147,6 +149,12 @@ typedef struct pt_affine {
     float inv[12];
 } pt_affine;
 
+/* texture.rs:5-10 `RgbImage`: tightly packed RGB8 rows as image::open(..).to_rgb8().into_raw() yields them */
+typedef struct pt_image {
+    uint32_t width, height;
+    const uint8_t *rgb; /* width * height * 3 bytes */
+} pt_image;
+
 /* bvh_nodes children: >= 0 node index, < 0 ~hitable_index. */
 typedef struct pt_world_desc {
     uint32_t n_hitables;
@@ -163,6 +171,8 @@ typedef struct pt_world_desc {
     int32_t bvh_root;
     uint32_t has_sky;
     float sky[3];
+    uint32_t n_images;          /* Texture::Image sources (0 / NULL when unused) */
+    const pt_image *images;
 } pt_world_desc;
 
 typedef struct pt_scene pt_scene;

@@ -357,18 +357,41 @@ static float perlin_turb(const perlin *pn, v3 p) {
 /* ======================================================================== */
 /* texture.rs:40-91                                                         */
 /* ======================================================================== */
-enum { TEX_CONSTANT = 0, TEX_CHECKER = 1, TEX_NOISE = 2 };
+enum { TEX_CONSTANT = 0, TEX_CHECKER = 1, TEX_NOISE = 2, TEX_IMAGE = 3 };
+/* texture.rs:5-10 */
+typedef struct { uint32_t width, height; const uint8_t *data; } rgb_image;
 typedef struct texture {
     int kind;
     v3 color;
     const struct texture *odd, *even;
     const perlin *noise;
     float scale;
+    const rgb_image *image;
 } texture;
+
+/* Rust `f32 as i32`: saturating, NaN -> 0 */
+static inline int32_t f32_as_i32(float f) {
+    if (!(f == f)) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)f;
+}
+/* texture.rs:27-37 */
+static v3 rgb_image_value(const rgb_image *im, float u, float v) {
+    int32_t i = f32_as_i32(u * (float)im->width);
+    int32_t j = f32_as_i32((1.0f - v) * (float)im->height - 0.001f);
+    int32_t wi = (int32_t)im->width - 1, hi = (int32_t)im->height - 1;
+    i = i > 0 ? i : 0; i = i < wi ? i : wi;   /* i.max(0).min(width - 1) */
+    j = j > 0 ? j : 0; j = j < hi ? j : hi;
+    size_t at = 3 * (size_t)i + 3 * (size_t)im->width * (size_t)j;
+    return V3((float)im->data[at] / 255.0f, (float)im->data[at + 1] / 255.0f, (float)im->data[at + 2] / 255.0f);
+}
 
 /* texture.rs:74-91 */
 static v3 texture_value(const texture *t, float u, float v, v3 p) {
     switch (t->kind) {
+    case TEX_IMAGE:
+        return rgb_image_value(t->image, u, v);
     case TEX_CONSTANT:
         return t->color;
     case TEX_CHECKER: {
@@ -959,6 +982,7 @@ typedef struct {
     cuboid *cuboids; size_t n_cuboids;
     instance *instances; size_t n_instances;
     constant_medium *media; size_t n_media;
+    rgb_image *images; size_t n_images; uint8_t *image_bytes;
     perlin perlin_noise;
 } storage;
 
@@ -987,6 +1011,7 @@ static void storage_init(storage *st, xoshiro *rng, size_t max_items, size_t max
 static void storage_free(storage *st) {
     free(st->textures); free(st->materials); free(st->spheres); free(st->nodes);
     free(st->moving); free(st->rects); free(st->cuboids); free(st->instances); free(st->media);
+    free(st->images); free(st->image_bytes);
 }
 
 static const texture *alloc_texture(storage *st, texture t) { st->textures[st->n_textures] = t; return &st->textures[st->n_textures++]; }
@@ -1475,7 +1500,8 @@ static camera cam_from_floats(const float *f);
 ora_scene *ora_scene_from_world(const uint32_t *records16, uint32_t n_hitables, const float *transforms24,
                                 uint32_t n_transforms, const float *materials6, uint32_t n_materials,
                                 const float *textures7, uint32_t n_textures, const float *cam24, int has_sky,
-                                const float *sky3, int use_bvh) {
+                                const float *sky3, int use_bvh, const uint32_t *image_wh, const uint8_t *image_bytes,
+                                uint32_t n_images) {
     if (!cam24 || (n_hitables && (!records16 || !materials6 || !n_materials)) || (use_bvh && !n_hitables)) return NULL;
     ora_scene *sc = calloc(1, sizeof(*sc));
     xoshiro rng, rng0;
@@ -1483,6 +1509,21 @@ ora_scene *ora_scene_from_world(const uint32_t *records16, uint32_t n_hitables, 
     rng0 = rng;
     storage_init(&sc->st, &rng, 2 * (size_t)n_hitables + n_materials + n_textures + 16, n_hitables);
     storage *st = &sc->st;
+    if (n_images) {   /* RgbImage sources: (width, height) pairs, pixel data concatenated */
+        size_t total = 0;
+        for (uint32_t i = 0; i < n_images; ++i) total += 3 * (size_t)image_wh[2 * i] * image_wh[2 * i + 1];
+        st->images = calloc(n_images, sizeof(rgb_image));
+        st->image_bytes = malloc(total ? total : 1);
+        memcpy(st->image_bytes, image_bytes, total);
+        size_t off = 0;
+        for (uint32_t i = 0; i < n_images; ++i) {
+            st->images[i].width = image_wh[2 * i]; st->images[i].height = image_wh[2 * i + 1];
+            st->images[i].data = st->image_bytes + off;
+            off += 3 * (size_t)image_wh[2 * i] * image_wh[2 * i + 1];
+            if (!st->images[i].width || !st->images[i].height) goto bad;
+        }
+        st->n_images = n_images;
+    }
     for (uint32_t i = 0; i < n_textures; ++i) {
         const float *r = textures7 + 7 * i;
         texture t; memset(&t, 0, sizeof t);
@@ -1491,7 +1532,10 @@ ora_scene *ora_scene_from_world(const uint32_t *records16, uint32_t n_hitables, 
             if (r[4] < 0 || r[5] < 0 || (uint32_t)r[4] >= i || (uint32_t)r[5] >= i) goto bad;
             t.odd = &st->textures[(uint32_t)r[4]]; t.even = &st->textures[(uint32_t)r[5]];
         } else if (t.kind == TEX_NOISE) t.noise = &st->perlin_noise;
-        else if (t.kind != TEX_CONSTANT) goto bad;
+        else if (t.kind == TEX_IMAGE) {
+            if (r[4] < 0 || (uint32_t)r[4] >= n_images) goto bad;
+            t.image = &st->images[(uint32_t)r[4]];
+        } else if (t.kind != TEX_CONSTANT) goto bad;
         alloc_texture(st, t);
     }
     uint32_t n_arena = 0;
@@ -1807,7 +1851,7 @@ void ora_scene_export_textures(const ora_scene *s, float *rows7) {
         const texture *t = &s->st.textures[i];
         float *r = rows7 + 7 * i;
         r[0] = (float)t->kind; r[1] = t->color.x; r[2] = t->color.y; r[3] = t->color.z;
-        r[4] = t->odd ? (float)(t->odd - s->st.textures) : -1.0f;
+        r[4] = t->odd ? (float)(t->odd - s->st.textures) : (t->image ? (float)(t->image - s->st.images) : -1.0f);
         r[5] = t->even ? (float)(t->even - s->st.textures) : -1.0f;
         r[6] = t->scale;
     }

@@ -48,7 +48,9 @@ ora_scene *ora_scene_from_world(const uint32_t *records16, uint32_t n_hitables,
                                 const float *transforms24, uint32_t n_transforms,
                                 const float *materials6, uint32_t n_materials,
                                 const float *textures7, uint32_t n_textures,
-                                const float *cam24, int has_sky, const float *sky3, int use_bvh);
+                                const float *cam24, int has_sky, const float *sky3, int use_bvh,
+                                const uint32_t *image_wh, const uint8_t *image_bytes, uint32_t n_images);
+/* (Texture::Image rows: kind 3, odd_id = image index; images = (width, height) pairs + concatenated RGB8 rows) */
 
 /* ---- Scene::update (scene.rs:73-121) ------------------------------------
  * buffer: width*height*3 floats, row 0 = bottom row, read AND written
@@ -107,7 +109,7 @@ void ora_scene_export_world(const ora_scene *s, uint32_t *records16, float *tran
  * kinds: 0 lambertian 1 metal 2 dielectric 3 diffuse_light 4 isotropic */
 void ora_scene_export_materials(const ora_scene *s, float *rows6);
 /* textures: n rows of 7 floats: kind, c0,c1,c2, odd_id, even_id, scale
- * kinds: 0 constant 1 checker 2 noise */
+ * kinds: 0 constant 1 checker 2 noise 3 image (odd_id = image index) */
 void ora_scene_export_textures(const ora_scene *s, float *rows7);
 /* perlin: randvec 256*3 floats, perm_x/y/z 256 u32 each */
 void ora_scene_export_perlin(const ora_scene *s, float *randvec,

@@ -188,17 +188,37 @@ __device__ __forceinline__ bool checker_is_odd(float sx, float sy, float sz) {
     return (neg ^ sgn) != 0;
 }
 
-// texture.rs:74-91 (Constant / Checker / Noise; Checker may nest)
-__device__ __noinline__ f3 texture_value(const DTex *texs, const PerlinLds &pn, int32_t tex, f3 p) {
+// texture.rs:5-37 RgbImage sources of a general world: (byte offset, width, height) per image + one byte blob
+struct DImages {
+    const uint4 *table;
+    const uint8_t *bytes;
+};
+
+// texture.rs:27-37 (Rust `as i32` saturates and maps NaN to 0, like v_cvt_i32_f32)
+__device__ __forceinline__ f3 image_value(const DImages &im, int32_t index, float u, float v) {
+    const uint4 e = im.table[index];
+    const float fi = u * (float)e.y, fj = (1.0f - v) * (float)e.z - 0.001f;
+    int32_t i = (fi == fi) ? (int32_t)fminf(fmaxf(fi, -2147483648.0f), 2147483520.0f) : 0;
+    int32_t j = (fj == fj) ? (int32_t)fminf(fmaxf(fj, -2147483648.0f), 2147483520.0f) : 0;
+    i = max(i, 0), i = min(i, (int32_t)e.y - 1);
+    j = max(j, 0), j = min(j, (int32_t)e.z - 1);
+    const uint8_t *px = im.bytes + e.x + 3u * (uint32_t)i + 3u * e.y * (uint32_t)j;
+    return mk3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+
+// texture.rs:74-91 (Constant / Checker / Noise / Image; Checker may nest). (u, v, images) only matter for Image.
+__device__ __noinline__ f3 texture_value(const DTex *texs, const PerlinLds &pn, int32_t tex, f3 p, float u = 0.0f, float v = 0.0f,
+                                         DImages images = DImages{nullptr, nullptr}) {
     DTex t = texs[tex];
     while (t.kind == PT_TEX_CHECKER) {
         const f3 s = mk3(10.0f * p.x, 10.0f * p.y, 10.0f * p.z);
         t = texs[checker_is_odd(s.x, s.y, s.z) ? t.odd : t.even];
     }
     if (t.kind == PT_TEX_NOISE) {
-        const float v = 1.0f + sinf(t.scale * p.z + 10.0f * perlin_turb(pn, p));
-        return mk3(0.5f * v, 0.5f * v, 0.5f * v);  // vec3(1,1,1) * 0.5 * (1 + sin(..))
+        const float v1 = 1.0f + sinf(t.scale * p.z + 10.0f * perlin_turb(pn, p));
+        return mk3(0.5f * v1, 0.5f * v1, 0.5f * v1);  // vec3(1,1,1) * 0.5 * (1 + sin(..))
     }
+    if (t.kind == PT_TEX_IMAGE) return image_value(images, t.odd, u, v);
     return mk3(t.c0, t.c1, t.c2);
 }
 

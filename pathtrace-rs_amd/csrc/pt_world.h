@@ -26,6 +26,9 @@ struct WArgs {
     const DTex *texs;
     const float4 *perlin_vec;
     const uint32_t *perlin_perm;
+    const uint4 *image_table;   // Texture::Image sources: (byte offset, width, height, -) per image
+    const uint8_t *image_bytes;
+    uint32_t has_image;         // some texture is an Image: rect hits then compute (u, v) (rect.rs:97-98)
     uint32_t n_hit, n_xf;
     int32_t bvh_root;        // >= 0: BVHNode::ray_hit over `nodes`; < 0: HitableList::ray_hit
     uint32_t bvh_stack_entries;
@@ -51,9 +54,9 @@ struct WRay {  // ray.rs:4-9
     f3 o, d, rcp;
     float time;
 };
-struct WHit {  // ray.rs:43-50 without u, v (only Image textures read them, texture.rs:74-91)
+struct WHit {  // ray.rs:43-50; (u, v) are only computed when the world has an Image texture (nothing else reads them)
     f3 point, normal;
-    float t;
+    float t, u, v;
 };
 
 // ray.rs:13-21
@@ -116,6 +119,7 @@ __device__ __forceinline__ bool w_sphere(f3 centre, float radius, const WRay &r,
         h.point = add3(r.o, scale3(r.d, t));
         h.normal = divs3(sub3(h.point, centre), radius);
         h.t = t;
+        h.u = h.v = 0.0f;   // sphere.rs:47-48
         return true;
     }
     return false;
@@ -124,7 +128,7 @@ __device__ __forceinline__ bool w_sphere(f3 centre, float radius, const WRay &r,
 // rect.rs:73-190. `axis` 0/1/2 = XY/XZ/YZ. The comparisons keep the reference's form: a NaN t or
 // coordinate falls through every test exactly as it does there.
 __device__ __forceinline__ bool w_rect(uint32_t axis, float a0, float a1, float b0, float b1, float k, bool flip,
-                                       const WRay &r, float t_min, float t_max, WHit &h) {
+                                       const WRay &r, float t_min, float t_max, WHit &h, bool want_uv) {
     float ok, rk, oa, da, ob, db;
     if (axis == 0u) {
         ok = r.o.z, rk = r.rcp.z, oa = r.o.x, da = r.d.x, ob = r.o.y, db = r.d.y;
@@ -142,6 +146,8 @@ __device__ __forceinline__ bool w_rect(uint32_t axis, float a0, float a1, float 
     h.normal = axis == 0u ? mk3(0.0f, 0.0f, sgn) : (axis == 1u ? mk3(0.0f, sgn, 0.0f) : mk3(sgn, 0.0f, 0.0f));
     h.point = add3(r.o, scale3(r.d, t));
     h.t = t;
+    h.u = want_uv ? (a - a0) / (a1 - a0) : 0.0f;   // rect.rs:97-98
+    h.v = want_uv ? (b - b0) / (b1 - b0) : 0.0f;
     return true;
 }
 
@@ -160,7 +166,7 @@ __device__ __forceinline__ bool w_aabb_hit(f3 mn, f3 mx, const WRay &r, float tm
 
 // cuboid.rs:11-37: AABB test, then the six faces in construction order with narrowing. One rect routine, called
 // from a loop (the faces differ only in their parameters), keeps the code small.
-__device__ __forceinline__ bool w_cuboid(f3 p0, f3 p1, const WRay &r, float t_min, float t_max, WHit &h) {
+__device__ __forceinline__ bool w_cuboid(f3 p0, f3 p1, const WRay &r, float t_min, float t_max, WHit &h, bool want_uv) {
     if (!w_aabb_hit(p0, p1, r, t_min, t_max)) return false;
     bool found = false;
     float closest = t_max;
@@ -173,13 +179,13 @@ __device__ __forceinline__ bool w_cuboid(f3 p0, f3 p1, const WRay &r, float t_mi
         else if (axis == 1u) a0 = p0.x, a1 = p1.x, b0 = p0.z, b1 = p1.z, k = flip ? p0.y : p1.y;
         else a0 = p0.y, a1 = p1.y, b0 = p0.z, b1 = p1.z, k = flip ? p0.x : p1.x;
         WHit f;
-        if (w_rect(axis, a0, a1, b0, b1, k, flip, r, t_min, closest, f)) h = f, closest = f.t, found = true;
+        if (w_rect(axis, a0, a1, b0, b1, k, flip, r, t_min, closest, f, want_uv)) h = f, closest = f.t, found = true;
     }
     return found;
 }
 
 // The innermost shape (hitable.rs:50-56)
-__device__ __forceinline__ bool w_shape(const pt_hitable &H, const WRay &r, float t_min, float t_max, WHit &h) {
+__device__ __forceinline__ bool w_shape(const pt_hitable &H, const WRay &r, float t_min, float t_max, WHit &h, bool want_uv) {
     switch (H.kind) {
     case PT_HIT_SPHERE: return w_sphere(mk3(H.p[0], H.p[1], H.p[2]), H.p[3], r, t_min, t_max, h);
     case PT_HIT_MOVING_SPHERE: {  // moving_sphere.rs:29-31,38-73
@@ -187,8 +193,8 @@ __device__ __forceinline__ bool w_shape(const pt_hitable &H, const WRay &r, floa
         const f3 centre = add3(mk3(H.p[0], H.p[1], H.p[2]), scale3(mk3(H.p[3], H.p[4], H.p[5]), s));
         return w_sphere(centre, H.p[6], r, t_min, t_max, h);
     }
-    case PT_HIT_CUBOID: return w_cuboid(mk3(H.p[0], H.p[1], H.p[2]), mk3(H.p[3], H.p[4], H.p[5]), r, t_min, t_max, h);
-    default: return w_rect(H.kind - PT_HIT_RECT_XY, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], H.flip_normals != 0u, r, t_min, t_max, h);
+    case PT_HIT_CUBOID: return w_cuboid(mk3(H.p[0], H.p[1], H.p[2]), mk3(H.p[3], H.p[4], H.p[5]), r, t_min, t_max, h, want_uv);
+    default: return w_rect(H.kind - PT_HIT_RECT_XY, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], H.flip_normals != 0u, r, t_min, t_max, h, want_uv);
     }
 }
 
@@ -200,12 +206,12 @@ __device__ __forceinline__ f3 w_xf_point(const float m[12], f3 p) { return add3(
 
 // instance.rs:32-47 around the shape (ray.rs:28-40, 52-64)
 __device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine *xf, const WRay &r, float t_min, float t_max,
-                                            WHit &h) {
-    if (H.transform < 0) return w_shape(H, r, t_min, t_max, h);
+                                            WHit &h, bool want_uv) {
+    if (H.transform < 0) return w_shape(H, r, t_min, t_max, h, want_uv);
     const pt_affine &T = xf[H.transform];
     const f3 lo = w_xf_point(T.inv, r.o), ld = w_xf_vector(T.inv, r.d);
     const WRay local = w_ray_new(lo, ld, r.time);
-    if (!w_shape(H, local, t_min, t_max, h)) return false;
+    if (!w_shape(H, local, t_min, t_max, h, want_uv)) return false;
     h.point = w_xf_point(T.m, h.point);
     h.normal = w_xf_vector(T.m, h.normal);
     return true;
@@ -215,7 +221,7 @@ __device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine
 // (constant_medium.rs:39-43): the shape code is reached through ONE call site in a two-trip loop so it exists once.
 // Returns the material index, or -1 for no hit.
 __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *xf, const WRay &r, float t_min, float t_max,
-                                         Rng &rng, WHit &h) {
+                                         Rng &rng, WHit &h, bool want_uv) {
     const bool medium = H.medium_material >= 0;
     float lo = medium ? -kMaxT : t_min, hi = medium ? kMaxT : t_max;
     float t_first = 0.f;
@@ -223,7 +229,7 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < (medium ? 2 : 1); ++pass) {
         if (ok) {
-            ok = w_instanced(H, xf, r, lo, hi, h);
+            ok = w_instanced(H, xf, r, lo, hi, h, want_uv);
             if (pass == 0) t_first = h.t;
             lo = h.t + 0.0001f;   // constant_medium.rs:41
             hi = kMaxT;
@@ -245,6 +251,7 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
         h.point = add3(r.o, scale3(r.d, t));
         h.normal = mk3(1.0f, 0.0f, 0.0f);  // Vec3::X, arbitrary
         h.t = t;
+        h.u = h.v = 0.0f;
         return H.medium_material;
     }
     return -1;
@@ -284,6 +291,7 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
     }
     __syncthreads();
     PerlinLds pn{s_pvec, s_perm};
+    const bool want_uv = A.has_image != 0u;
     const pt_hitable *hit = HIT_LDS ? s_hit : A.hit;
     const pt_affine *xf = HIT_LDS ? s_xf : A.xf;
     float *path = A.stack_in_lds ? (s_path + tid) : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * kBlock + tid);
@@ -357,11 +365,12 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
             uint32_t best_mat = 0;
             best.t = kMaxT;
             best.point = best.normal = mk3(0.f, 0.f, 0.f);
+            best.u = best.v = 0.0f;
             if (!BVH) {  // hitable_list.rs:40-56
                 float closest = kMaxT;
                 for (uint32_t k = 0; k < A.n_hit; ++k) {
                     WHit h;
-                    const int m = w_hitable(hit[k], xf, ray, kMinT, closest, rng, h);
+                    const int m = w_hitable(hit[k], xf, ray, kMinT, closest, rng, h, want_uv);
                     if (m >= 0) {
                         best = h, best_mat = (uint32_t)m, found = true;
                         closest = h.t;
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
                     const int32_t ref = s_stack[--sp * kBlock + tid];
                     if (ref < 0) {
                         WHit h;
-                        const int m = w_hitable(hit[~ref], xf, ray, kMinT, kMaxT, rng, h);
+                        const int m = w_hitable(hit[~ref], xf, ray, kMinT, kMaxT, rng, h, want_uv);
                         if (m >= 0) {
                             // bvh.rs:48-53: lhs only when lhs.t < rhs.t -> an equal t goes to the later leaf
                             if (!found || !(best.t < h.t)) best = h, best_mat = (uint32_t)m;
@@ -406,7 +415,9 @@ __global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
                 const DMat m = A.mats[best_mat];
                 const f3 point = best.point, normal = best.normal, d = ray.d;
                 // Texture::value (texture.rs:74-91); Constant textures were folded into the material record
-                auto colour = [&]() -> f3 { return m.pad0 != 0.0f ? mk3(m.a0, m.a1, m.a2) : texture_value(A.texs, pn, m.tex, point); };
+                auto colour = [&]() -> f3 {
+                    return m.pad0 != 0.0f ? mk3(m.a0, m.a1, m.a2) : texture_value(A.texs, pn, m.tex, point, best.u, best.v, DImages{A.image_table, A.image_bytes});
+                };
                 f3 emitted = mk3(0.f, 0.f, 0.f);  // material.rs:161-167
                 if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = colour();
                 bool scattered = false;

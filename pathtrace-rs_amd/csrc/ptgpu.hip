@@ -101,6 +101,9 @@ struct pt_scene {
     pt_hitable *d_hitables = nullptr;
     pt_affine *d_transforms = nullptr;
     pt_bvh_node *d_ref_nodes = nullptr;   // the caller's tree as given (BVHNode::ray_hit is followed literally)
+    uint4 *d_image_table = nullptr;       // Texture::Image sources: (byte offset, width, height, 0)
+    uint8_t *d_image_bytes = nullptr;
+    uint32_t has_image = 0;
     uint32_t ref_bvh_depth = 0;
     // last launch
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -158,11 +161,18 @@ uint32_t bvh_depth_checked(const pt_bvh_node *nodes, uint32_t n_nodes, uint32_t 
 
 // Texture / material tables shared by both scene constructors.
 int validate_tables(uint32_t n_materials, const pt_material *materials, uint32_t n_textures, const pt_texture *textures,
-                    const pt_perlin *perlin, bool allow_isotropic, bool *has_noise_out) {
+                    const pt_perlin *perlin, bool allow_isotropic, bool *has_noise_out, uint32_t n_images = 0,
+                    const pt_image *images = nullptr) {
     bool has_noise = false;
+    for (uint32_t i = 0; i < n_images; ++i)
+        if (!images || !images[i].rgb || images[i].width == 0 || images[i].height == 0 ||
+            (uint64_t)images[i].width * images[i].height > (1ull << 28))
+            return fail(PT_ERR_INVALID_ARG, "image %u: empty, NULL or larger than 2^28 pixels", i);
     for (uint32_t i = 0; i < n_textures; ++i) {
         const pt_texture &t = textures[i];
-        if (t.kind > PT_TEX_NOISE) return fail(PT_ERR_INVALID_ARG, "texture %u: unknown kind %u", i, t.kind);
+        if (t.kind > PT_TEX_IMAGE) return fail(PT_ERR_INVALID_ARG, "texture %u: unknown kind %u", i, t.kind);
+        if (t.kind == PT_TEX_IMAGE && (t.odd < 0 || (uint32_t)t.odd >= n_images))
+            return fail(PT_ERR_INVALID_ARG, "texture %u: image index %d out of range (images belong to pt_world_desc)", i, t.odd);
         if (t.kind == PT_TEX_CHECKER) {
             // arena order (storage.rs:45-48): sub-textures are allocated before the checker that
             // references them; requiring odd/even < i also guarantees termination on device.
@@ -721,7 +731,10 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
     if (desc->n_textures && !desc->textures) return fail(PT_ERR_INVALID_ARG, "textures is NULL");
     if (desc->n_transforms && !desc->transforms) return fail(PT_ERR_INVALID_ARG, "transforms is NULL");
     bool has_noise = false;
-    if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, true, &has_noise)) return rc;
+    if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, true, &has_noise,
+                                 desc->n_images, desc->images)) return rc;
+    bool has_image = false;
+    for (uint32_t i = 0; i < desc->n_textures; ++i) has_image = has_image || desc->textures[i].kind == PT_TEX_IMAGE;
     bool all_spheres = true, sphere_like = true;
     for (uint32_t i = 0; i < desc->n_hitables; ++i) {
         const pt_hitable &h = desc->hitables[i];
@@ -762,10 +775,25 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
                 motion[i] = MotionIn{{h.p[3], h.p[4], h.p[5]}, h.p[7], h.p[8], 1u};
             }
         }
+        // Sphere hits have u = v = 0 (sphere.rs:47-48), so an Image texture is one texel for them: i = 0,
+        // j = ((1 - 0) * height - 0.001) as i32 = height - 1 (texture.rs:28-33). Fold it into a Constant.
+        std::vector<pt_texture> folded(desc->textures, desc->textures + desc->n_textures);
+        for (pt_texture &t : folded) {
+            if (t.kind != PT_TEX_IMAGE) continue;
+            const pt_image &im = desc->images[t.odd];
+            const volatile float fj = (1.0f - 0.0f) * (float)im.height - 0.001f;
+            int64_t j = (int64_t)fj;
+            j = std::max<int64_t>(0, std::min<int64_t>(j, (int64_t)im.height - 1));
+            const uint8_t *px = im.rgb + 3ull * im.width * (uint64_t)j;
+            const volatile float k255 = 255.0f;
+            t.kind = PT_TEX_CONSTANT;
+            t.color[0] = (float)px[0] / k255, t.color[1] = (float)px[1] / k255, t.color[2] = (float)px[2] / k255;
+            t.odd = t.even = -1;
+        }
         pt_scene_desc d{};
         d.n_spheres = desc->n_hitables, d.spheres = sph.data(), d.sphere_material = mat.data();
         d.n_materials = desc->n_materials, d.materials = desc->materials;
-        d.n_textures = desc->n_textures, d.textures = desc->textures, d.perlin = desc->perlin;
+        d.n_textures = desc->n_textures, d.textures = folded.data(), d.perlin = desc->perlin;
         d.n_bvh_nodes = desc->n_bvh_nodes, d.bvh_nodes = desc->bvh_nodes, d.bvh_root = desc->bvh_root;
         d.has_sky = desc->has_sky;
         memcpy(d.sky, desc->sky, sizeof d.sky);
@@ -836,6 +864,24 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
         }
     }
     int rc = PT_OK;
+    if (has_image) {
+        std::vector<uint4> table(desc->n_images);
+        std::vector<uint8_t> blob;
+        for (uint32_t i = 0; i < desc->n_images; ++i) {
+            const pt_image &im = desc->images[i];
+            table[i] = make_uint4((uint32_t)blob.size(), im.width, im.height, 0u);
+            blob.insert(blob.end(), im.rgb, im.rgb + 3ull * im.width * im.height);
+        }
+        if (blob.size() > 0xf0000000ull) {
+            pt_scene_destroy(s);
+            return fail(PT_ERR_UNSUPPORTED, "image textures exceed 3.75 GB");
+        }
+        if ((rc = upload(&s->d_image_table, table.data(), table.size())) || (rc = upload(&s->d_image_bytes, blob.data(), blob.size()))) {
+            pt_scene_destroy(s);
+            return rc;
+        }
+        s->has_image = 1u;
+    }
     if ((rc = upload(&s->d_hitables, desc->hitables, desc->n_hitables)) ||
         (rc = upload(&s->d_transforms, desc->transforms, desc->n_transforms)) ||
         (rc = upload(&s->d_ref_nodes, desc->bvh_nodes, desc->n_bvh_nodes)) ||
@@ -862,6 +908,8 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_motion);
     (void)hipFree(s->d_transforms);
     (void)hipFree(s->d_ref_nodes);
+    (void)hipFree(s->d_image_table);
+    (void)hipFree(s->d_image_bytes);
     (void)hipFree(s->d_spheres);
     (void)hipFree(s->d_spheres_r2);
     (void)hipFree(s->d_shade);
@@ -993,6 +1041,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         W.texs = s->d_texs;
         W.perlin_vec = s->d_perlin_vec;
         W.perlin_perm = s->d_perlin_perm;
+        W.image_table = s->d_image_table;
+        W.image_bytes = s->d_image_bytes;
+        W.has_image = s->has_image;
         W.n_hit = s->n_hitables;
         W.bvh_root = ref_bvh ? s->bvh_root : -1;
         W.bvh_stack_entries = s->ref_bvh_depth + 2u;

@@ -50,7 +50,7 @@ struct Perlin {
     explicit Perlin(Xoshiro256Plus &rng);  // perlin.rs:43-51
 };
 
-enum class TextureKind : uint32_t { Constant = PT_TEX_CONSTANT, Checker = PT_TEX_CHECKER, Noise = PT_TEX_NOISE };
+enum class TextureKind : uint32_t { Constant = PT_TEX_CONSTANT, Checker = PT_TEX_CHECKER, Noise = PT_TEX_NOISE, Image = PT_TEX_IMAGE };
 enum class MaterialKind : uint32_t {
     Lambertian = PT_MAT_LAMBERTIAN,
     Metal = PT_MAT_METAL,
@@ -76,6 +76,10 @@ public:
     TextureId alloc_constant(Vec3 color);                   // texture.rs:57-59
     TextureId alloc_checker(TextureId odd, TextureId even);  // texture.rs:61-63
     TextureId alloc_noise(float scale);                      // texture.rs:65-67 (&storage.perlin_noise)
+    // texture.rs:5-25,69-71: an RgbImage as image::open(..).to_rgb8().into_raw() yields it (no decoder here: the
+    // caller supplies the RGB8 rows), and the Texture::Image over it
+    uint32_t alloc_image(uint32_t width, uint32_t height, const uint8_t *rgb);
+    TextureId alloc_rgb_image(uint32_t image);
     MaterialId alloc_lambertian(TextureId albedo);           // material.rs:21-23
     MaterialId alloc_metal(Vec3 albedo, float fuzz);         // material.rs:25-27
     MaterialId alloc_dielectric(float ref_idx);              // material.rs:29-31
@@ -97,6 +101,11 @@ public:
     std::vector<pt_material> materials;
     std::vector<pt_material> phase_functions;  // one Isotropic per ConstantMedium (constant_medium.rs:13)
     std::vector<pt_affine> transforms;         // Instance { transform, inv_transform }
+    struct Image {
+        uint32_t width, height;
+        std::vector<uint8_t> rgb;
+    };
+    std::vector<Image> images;                 // RgbImage arena
     std::vector<pt_sphere> spheres;
     Perlin perlin_noise;
     bool uses_noise = false;
@@ -161,6 +170,8 @@ private:
     std::vector<pt_bvh_node> bvh_nodes_;
     std::vector<pt_hitable> hitables_;
     std::vector<pt_affine> transforms_;
+    std::vector<Storage::Image> image_store_;
+    std::vector<pt_image> images_;
     pt_scene_desc desc_{};
     pt_world_desc world_{};
     bool is_world_ = false;

@@ -91,6 +91,16 @@ TextureId Storage::alloc_noise(float scale) {
     textures.push_back(pt_texture{PT_TEX_NOISE, {0.f, 0.f, 0.f}, -1, -1, scale});
     return static_cast<TextureId>(textures.size() - 1);
 }
+uint32_t Storage::alloc_image(uint32_t width, uint32_t height, const uint8_t *rgb) {
+    if (!width || !height || !rgb) throw std::runtime_error("RgbImage: empty image");
+    images.push_back(Image{width, height, std::vector<uint8_t>(rgb, rgb + 3ull * width * height)});
+    return static_cast<uint32_t>(images.size() - 1);
+}
+TextureId Storage::alloc_rgb_image(uint32_t image) {
+    if (image >= images.size()) throw std::runtime_error("rgb_image: no such image");
+    textures.push_back(pt_texture{PT_TEX_IMAGE, {0.f, 0.f, 0.f}, static_cast<int32_t>(image), -1, 0.0f});
+    return static_cast<TextureId>(textures.size() - 1);
+}
 MaterialId Storage::alloc_lambertian(TextureId albedo) {
     materials.push_back(pt_material{PT_MAT_LAMBERTIAN, {0.f, 0.f, 0.f}, 0.0f, albedo});
     return static_cast<MaterialId>(materials.size() - 1);
@@ -318,6 +328,9 @@ std::unique_ptr<Scene> Scene::new_scene(const Params &params, Xoshiro256Plus &rn
         if (h.kind != PT_HIT_SPHERE || h.transform >= 0 || h.medium_material >= 0) all_spheres = false;
     }
     if (s->hitables_.empty()) all_spheres = false;  // an empty world is traced (to the sky) by the general kernel
+    s->image_store_ = storage.images;
+    for (const Storage::Image &im : s->image_store_) s->images_.push_back(pt_image{im.width, im.height, im.rgb.data()});
+    if (!s->images_.empty()) all_spheres = false;   // Image textures travel in pt_world_desc (the library folds them for sphere worlds)
     s->is_world_ = !all_spheres;
     s->transforms_ = storage.transforms;
     s->textures_ = storage.textures;
@@ -354,6 +367,8 @@ std::unique_ptr<Scene> Scene::new_scene(const Params &params, Xoshiro256Plus &rn
     w.bvh_root = root;
     w.has_sky = sky.has_value() ? 1u : 0u;
     if (sky) w.sky[0] = sky->x, w.sky[1] = sky->y, w.sky[2] = sky->z;
+    w.n_images = static_cast<uint32_t>(s->images_.size());
+    w.images = s->images_.empty() ? nullptr : s->images_.data();
     if (all_spheres) {  // the sphere-only description (the specialised kernels' entry point)
         s->spheres_.reserve(hitables.size());
         s->sphere_material_.reserve(hitables.size());

@@ -19,7 +19,7 @@ PT_ERR_UNSUPPORTED = 4
 
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
 HIT_SPHERE, HIT_MOVING_SPHERE, HIT_RECT_XY, HIT_RECT_XZ, HIT_RECT_YZ, HIT_CUBOID = 0, 1, 2, 3, 4, 5
-TEX_CONSTANT, TEX_CHECKER, TEX_NOISE = 0, 1, 2
+TEX_CONSTANT, TEX_CHECKER, TEX_NOISE, TEX_IMAGE = 0, 1, 2, 3
 
 
 class PtParams(C.Structure):  # params.rs:11-18
@@ -84,6 +84,10 @@ class PtAffine(C.Structure):  # Affine3A columns + translation, then the inverse
     _fields_ = [("m", C.c_float * 12), ("inv", C.c_float * 12)]
 
 
+class PtImage(C.Structure):  # texture.rs:5-10 RgbImage
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.POINTER(C.c_uint8))]
+
+
 class PtWorldDesc(C.Structure):
     _fields_ = [("n_hitables", C.c_uint32), ("hitables", C.POINTER(PtHitable)),
                 ("n_transforms", C.c_uint32), ("transforms", C.POINTER(PtAffine)),
@@ -91,7 +95,8 @@ class PtWorldDesc(C.Structure):
                 ("n_textures", C.c_uint32), ("textures", C.POINTER(PtTexture)),
                 ("perlin", C.POINTER(PtPerlin)),
                 ("n_bvh_nodes", C.c_uint32), ("bvh_nodes", C.POINTER(PtBvhNode)), ("bvh_root", C.c_int32),
-                ("has_sky", C.c_uint32), ("sky", C.c_float * 3)]
+                ("has_sky", C.c_uint32), ("sky", C.c_float * 3),
+                ("n_images", C.c_uint32), ("images", C.POINTER(PtImage))]
 
 
 EXPORTS = [
@@ -220,11 +225,17 @@ class WorldDesc(SceneDesc):
     """Owns the storage behind a pt_world_desc: `hitables` is an [n, 16] uint32 array of 64-byte pt_hitable records,
     `transforms` an [m, 24] float32 array of pt_affine (Affine3A, inverse); the tables are SceneDesc's."""
 
-    def __init__(self, hitables, transforms, materials, textures, perlin=None, bvh_nodes=None, bvh_root=-1, sky=None):
+    def __init__(self, hitables, transforms, materials, textures, perlin=None, bvh_nodes=None, bvh_root=-1, sky=None,
+                 images=()):
         super().__init__(np.zeros((0, 4), np.float32), np.zeros(0, np.uint32), materials, textures, perlin=perlin,
                          bvh_nodes=bvh_nodes, bvh_root=bvh_root, sky=sky)
         self.hitables = np.ascontiguousarray(hitables, dtype=np.uint32).reshape(-1, 16)
         self.transforms = np.ascontiguousarray(transforms, dtype=np.float32).reshape(-1, 24)
+        self.image_arrays = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]   # [H, W, 3] each
+        self.images = (PtImage * max(1, len(self.image_arrays)))()
+        for i, im in enumerate(self.image_arrays):
+            self.images[i].width, self.images[i].height = im.shape[1], im.shape[0]
+            self.images[i].rgb = C.cast(im.ctypes.data, C.POINTER(C.c_uint8))
 
     def struct(self):
         d = PtWorldDesc()
@@ -243,6 +254,8 @@ class WorldDesc(SceneDesc):
         d.has_sky = 1 if self.sky is not None else 0
         if self.sky is not None:
             d.sky[:] = [float(c) for c in self.sky]
+        d.n_images = len(self.image_arrays)
+        d.images = C.cast(self.images, C.POINTER(PtImage)) if self.image_arrays else None
         return d
 
 

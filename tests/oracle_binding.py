@@ -41,7 +41,7 @@ def _bind(L):
     L.ora_scene_from_preset.argtypes = [C.c_char_p, u32, u32, C.c_int]
     L.ora_scene_free.argtypes = [vp]
     L.ora_scene_from_world.restype = vp
-    L.ora_scene_from_world.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32, vp, C.c_int, vp, C.c_int]
+    L.ora_scene_from_world.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32, vp, C.c_int, vp, C.c_int, vp, vp, u32]
     L.ora_scene_free.restype = None
     L.ora_scene_update.restype = u64
     L.ora_scene_update.argtypes = [vp, u32, u32, u32, u32, u32, vp, C.c_int]
@@ -112,7 +112,7 @@ class OracleScene:
 
     @classmethod
     def from_world(cls, hitables, transforms, materials, textures, camera, width, height, sky=None, use_bvh=False,
-                   library=None):
+                   library=None, images=()):
         """Scene from the flat description (the arrays export() returns): arbitrary worlds for parity tests."""
         self = cls.__new__(cls)
         self.L = library or lib()
@@ -122,9 +122,12 @@ class OracleScene:
         texs = np.ascontiguousarray(textures, dtype=np.float32).reshape(-1, 7)
         cam = np.ascontiguousarray(camera, dtype=np.float32).reshape(24)
         sk = np.ascontiguousarray(sky if sky is not None else [0, 0, 0], dtype=np.float32)
+        # images: list of [H, W, 3] uint8 arrays (RgbImage, texture.rs:5-10)
+        wh = np.array([[im.shape[1], im.shape[0]] for im in images], np.uint32).reshape(-1, 2)
+        blob = np.concatenate([np.ascontiguousarray(im, np.uint8).reshape(-1) for im in images]) if len(images) else np.zeros(1, np.uint8)
         self.h = self.L.ora_scene_from_world(rec.ctypes.data, len(rec), xf.ctypes.data, len(xf), mats.ctypes.data, len(mats),
                                              texs.ctypes.data, len(texs), cam.ctypes.data, 1 if sky is not None else 0,
-                                             sk.ctypes.data, 1 if use_bvh else 0)
+                                             sk.ctypes.data, 1 if use_bvh else 0, wh.ctypes.data, blob.ctypes.data, len(images))
         if not self.h:
             raise ValueError("malformed world description")
         self.preset, self.width, self.height, self.use_bvh = "<world>", width, height, bool(use_bvh)
@@ -197,14 +200,14 @@ class OracleScene:
                     build_draws=L.ora_scene_build_draws(h))
 
 
-def to_ptgpu_world_desc(ptgpu, ex):
+def to_ptgpu_world_desc(ptgpu, ex, images=()):
     """Oracle export -> the product's pt_world_desc (general worlds; the same description fed to both sides)."""
     materials = [(int(r[0]), r[1:4], r[4], int(r[5])) for r in ex["materials"]]
     textures = [(int(r[0]), r[1:4], int(r[4]), int(r[5]), r[6]) for r in ex["textures"]]
     bvh = (ex["bvh_minmax"], ex["bvh_children"]) if len(ex["bvh_minmax"]) else None
     return ptgpu.WorldDesc(ex["hitables"], ex["transforms"], materials, textures,
                            perlin=ex["perlin"] if ex["has_perlin"] else None, bvh_nodes=bvh,
-                           bvh_root=ex["bvh_root"], sky=ex["sky"])
+                           bvh_root=ex["bvh_root"], sky=ex["sky"], images=images)
 
 
 def to_ptgpu_desc(ptgpu, ex):

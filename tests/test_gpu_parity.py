@@ -507,11 +507,12 @@ def _random_world(oracle, seed, n, kinds, W, H, moving_times=((0.0, 1.0),), medi
 
 
 def _render_world_both(ptgpu, oracle, w, W, H, S, bvh, variant=0, depth=10, frame=0):
+    images = w.get("images", ())
     osc = oracle.OracleScene.from_world(w["hitables"], w["transforms"], w["materials"], w["textures"], w["camera"], W, H,
-                                        sky=w["sky"], use_bvh=bvh)
+                                        sky=w["sky"], use_bvh=bvh, images=images)
     ex = osc.export()
     assert ex["hitables"].tobytes() == w["hitables"].tobytes() and ex["transforms"].tobytes() == w["transforms"].tobytes()
-    sc = ptgpu.Scene(oracle.to_ptgpu_world_desc(ptgpu, ex), 0)
+    sc = ptgpu.Scene(oracle.to_ptgpu_world_desc(ptgpu, ex, images=images), 0)
     if variant:
         sc.set_tuning(0, variant)
     out = np.zeros((H, W, 3), np.float32)
@@ -576,6 +577,36 @@ def test_random_sphere_worlds_match_the_oracle(ptgpu, oracle, seed, n, spread, r
     out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh)
     assert rays == ref_rays, "ray_count %d vs oracle %d; %s" % (rays, ref_rays, _report(ref, out))
     assert np.array_equal(ref, out, equal_nan=True), _report(ref, out)
+
+
+def _with_image_textures(w, seed):
+    """Repoint some lambertians / the emitter of a random world at Texture::Image sources (texture.rs:5-37)."""
+    rng = np.random.default_rng(seed)
+    images = [rng.integers(0, 256, (3, 5, 3), dtype=np.uint8), rng.integers(0, 256, (32, 64, 3), dtype=np.uint8)]
+    tex = w["textures"].copy()
+    base = len(tex)
+    tex = np.concatenate([tex, np.array([[3, 0, 0, 0, 0, -1, 0], [3, 0, 0, 0, 1, -1, 0], [1, 0, 0, 0, base, 1, 0]], np.float32)])
+    mats = w["materials"].copy()
+    mats[0, 5], mats[2, 5] = base, base + 2                   # a lambertian image, a checker alternating image 0 / constant
+    mats[mats[:, 0] == 3, 5] = base + 1                       # DiffuseLight emits the big image
+    mats[mats[:, 0] == 4, 5] = base + 1                       # ... and so do the media's Isotropic phase functions (u = v = 0)
+    out = dict(w)
+    out.update(textures=tex, materials=mats, images=images)
+    return out
+
+
+@pytest.mark.parametrize("seed,n,kinds,bvh", [
+    (31, 20, (2, 3, 4, 5), False),          # rects and cuboid faces carry real (u, v) (rect.rs:97-98), also under instances
+    (32, 24, (0, 1, 2, 3, 4, 5), True),
+    (33, 40, (0,), False),                  # sphere worlds: u = v = 0, one texel per image, folded at scene creation
+    (34, 60, (0, 1), True),                 # ... also on the MOVING kernels
+])
+def test_image_textures_match_the_oracle(ptgpu, oracle, seed, n, kinds, bvh):
+    W, H, S = 120, 80, 4
+    w = _with_image_textures(_random_world(oracle, seed, n, kinds, W, H, sky=(0.4, 0.5, 0.6)), seed)
+    out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh)
+    assert rays == ref_rays, "ray_count %d vs oracle %d; %s" % (rays, ref_rays, _report(ref, out))
+    assert np.array_equal(ref, out), _report(ref, out)
 
 
 @pytest.mark.parametrize("seed,times,bvh", [

@@ -412,3 +412,34 @@ def test_scene_from_flat_description_round_trips(oracle, preset, bvh):
         bad = ex["hitables"].copy()
         bad[0, 1] = 999
         oracle.OracleScene.from_world(bad, ex["transforms"], ex["materials"], ex["textures"], ex["camera"], W, H)
+
+
+def test_image_texture_sampling(oracle):
+    """texture.rs:27-37: i = (u * w) as i32, j = ((1 - v) * h - 0.001) as i32, both clamped; sphere hits have
+    u = v = 0 and therefore read texel (0, h - 1)."""
+    W, H = 32, 24
+    img = np.arange(4 * 3 * 3, dtype=np.uint8).reshape(3, 4, 3) * 7           # height 3, width 4
+    rec = np.zeros((2, 16), np.uint32)
+    rec[:, 3] = rec[:, 4] = 0xffffffff
+    rec[0, 0], rec[0, 1] = 2, 0                                                # Rect::XY x 0..4, y 0..3 at z = 0
+    rec[0, 6:11] = np.float32([0, 4, 0, 3, 0]).view(np.uint32)
+    rec[1, 0], rec[1, 1] = 0, 0                                                # a sphere with the same material
+    rec[1, 6:10] = np.float32([10, 10, 0, 1]).view(np.uint32)
+    mats = np.float32([[3, 0, 0, 0, 0, 0]])                                    # DiffuseLight(Image): emitted = texel
+    texs = np.float32([[3, 0, 0, 0, 0, -1, 0]])
+    cam = np.zeros(24, np.float32)
+    sc = oracle.OracleScene.from_world(rec, np.zeros((0, 24), np.float32), mats, texs, cam, W, H, images=[img])
+    L = oracle.lib()
+    st = _state([1, 2, 3, 4])
+
+    def trace(o, d):
+        rgb, rc = np.zeros(3, np.float32), np.zeros(1, np.uint64)
+        o_, d_ = np.asarray(o, np.float32), np.asarray(d, np.float32)
+        L.ora_ray_trace(sc.h, o_.ctypes.data, d_.ctypes.data, 0.0, 10, st, rgb.ctypes.data, rc.ctypes.data)
+        return rgb
+    # (x, y) = (2.5, 2.9): u = 0.625 -> i = 2; v = 0.9667 -> j = (0.0333 * 3 - 0.001) as i32 = 0 (top row)
+    np.testing.assert_array_equal(trace([2.5, 2.9, 5], [0, 0, -1]), img[0, 2].astype(np.float32) / np.float32(255))
+    # (x, y) = (3.99, 0.01): i = 3, j = 2 (bottom row of the decoded image)
+    np.testing.assert_array_equal(trace([3.99, 0.01, 5], [0, 0, -1]), img[2, 3].astype(np.float32) / np.float32(255))
+    # the sphere: u = v = 0 (sphere.rs:47-48) -> texel (0, h - 1)
+    np.testing.assert_array_equal(trace([10, 10, 5], [0, 0, -1]), img[2, 0].astype(np.float32) / np.float32(255))
