@@ -30,6 +30,8 @@ for seed in range(first, first + count):
         w = tgp._random_sphere_world(ob, seed, n, W, H, float(rng.uniform(2, 15)), float(rng.uniform(0.1, 1.5)), extras)
     elif kind == 1:    # general worlds
         w = tgp._random_world(ob, seed, int(rng.integers(1, 40)), (0, 1, 2, 3, 4, 5), W, H, sky=(0.3, 0.3, 0.3) if seed & 1 else None)
+        if seed % 4 == 1:
+            w = tgp._with_image_textures(w, seed)    # Texture::Image on lambertians, the emitter and the media
     else:              # sphere + moving sphere worlds (fast MOVING kernels when >= 32 prefiltered)
         times = [((0.0, 1.0),), ((0.0, 1.0), (-1.0, 2.0)), ((0.25, 0.5),)][int(rng.integers(0, 3))]
         w = tgp._random_world(ob, seed, int(rng.choice([10, 60, 200])), (0, 1, 1), W, H, moving_times=times, media=False, instances=False)
