@@ -869,6 +869,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
     uint32_t px = 0, py = 0, boff = 0, sample = 0, depth = 0, nrays = 0;
     Rng rng{0, 0, 0, 0};
     f3 col = mk3(0.f, 0.f, 0.f), o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
+    f3 att0 = mk3(1.f, 1.f, 1.f);   // attenuation of the first bounce (deeper ones: the stack)
     float rtime = 0.f;  // ray.time (only MOVING kernels read it)
 
     for (;;) {
@@ -1062,9 +1063,16 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                     if (scattered) nd = normalize3(raw);
                 }
                 if (scattered) {
-                    path[(depth * 3 + 0) * kBlock] = att.x;
-                    path[(depth * 3 + 1) * kBlock] = att.y;
-                    path[(depth * 3 + 2) * kBlock] = att.z;
+                    // the first scatter's attenuation stays in registers (measured best: 0 levels -1.5 %, 2 levels -2.3 %;
+                    // it also removes 40 % of the stack's HBM writes); deeper levels go to the per-lane stack, level d
+                    // at slot d - 1
+                    if (depth == 0u) {
+                        att0 = att;
+                    } else {
+                        path[((depth - 1u) * 3 + 0) * kBlock] = att.x;
+                        path[((depth - 1u) * 3 + 1) * kBlock] = att.y;
+                        path[((depth - 1u) * 3 + 2) * kBlock] = att.z;
+                    }
                     depth += 1;
                     o = point;
                     d = nd;
@@ -1076,11 +1084,12 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             }
             if (terminal) {
                 // scene.rs:62-64 unwound: emitted(=0) + attenuation * deeper, innermost first
-                for (int k = (int)depth - 1; k >= 0; --k) {
-                    V.x = 0.0f + path[(k * 3 + 0) * kBlock] * V.x;
-                    V.y = 0.0f + path[(k * 3 + 1) * kBlock] * V.y;
-                    V.z = 0.0f + path[(k * 3 + 2) * kBlock] * V.z;
+                for (int k = (int)depth - 1; k >= 1; --k) {
+                    V.x = 0.0f + path[((k - 1) * 3 + 0) * kBlock] * V.x;
+                    V.y = 0.0f + path[((k - 1) * 3 + 1) * kBlock] * V.y;
+                    V.z = 0.0f + path[((k - 1) * 3 + 2) * kBlock] * V.z;
                 }
+                if (depth > 0u) V = mk3(0.0f + att0.x * V.x, 0.0f + att0.y * V.y, 0.0f + att0.z * V.z);
                 col = add3(col, V);  // scene.rs:110
                 sample += 1;
                 need_cam = true;
