@@ -520,7 +520,7 @@ __device__ __forceinline__ void exact_candidate(const KArgs &A, const float4 c, 
     }
 }
 
-template <bool VERIFY, bool MOVING, bool GATED>
+template <bool VERIFY, bool MOVING, bool GATED, int BLK>
 __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *sph, const uint4 *s_afrag,
                                                    const uint16_t *s_tile_sphere, uint16_t *queue,
                                                    f3 o, f3 d, float a, bool active, float time, float &t_out,
@@ -557,7 +557,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
             if (cur == 0u && tb != 0u) {  // next non-empty tile of my ray
                 curT = (uint32_t)__builtin_ctz(tb);
                 tb &= tb - 1u;
-                cur = queue32[j * kBlock + tid];
+                cur = queue32[j * BLK + tid];
                 j += 1;
             }
             if (cur != 0u) {
@@ -598,7 +598,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
         const auto sw = __builtin_amdgcn_permlane32_swap(m0, m1, false, false);
         const uint32_t full = sw[0] | (sw[1] << 16);
         if (full != 0u) {
-            if (cnt < (uint32_t)kEntCap) queue32[cnt * kBlock + tid] = full;
+            if (cnt < (uint32_t)kEntCap) queue32[cnt * BLK + tid] = full;
             cnt += 1;
             tbits |= 1u << T;
             if (VERIFY) ncand += (uint32_t)__popc(full);
@@ -634,7 +634,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                         for (uint32_t j = 0; tb != 0u && j < (uint32_t)kEntCap && !found; ++j) {
                             const uint32_t T = (uint32_t)__builtin_ctz(tb);
                             tb &= tb - 1u;
-                            for (uint32_t mk = queue32[j * kBlock + tid]; mk != 0u && !found; mk &= mk - 1u)
+                            for (uint32_t mk = queue32[j * BLK + tid]; mk != 0u && !found; mk &= mk - 1u)
                                 found = (s_tile_sphere[slot_of(T, (uint32_t)__builtin_ctz(mk))] == k);
                         }
                         atomicAdd(&A.debug[3], 1ull);
@@ -808,8 +808,12 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
 // every exact sphere test / normal uses the centre at that time; prefilter fragments and internal-tree boxes
 // were built over the motion's whole sweep.
 // GATE: a BVH world on the MFMA list kernel (ancestor-AABB gate + DFS-rank ties at hit acceptance).
-template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false, bool GATE = false>
-__global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KArgs A) {
+// BLK: threads per workgroup. 256 (three workgroups per CU) everywhere except the MFMA list kernels, which run ONE
+// 768-thread workgroup per CU when the scene allows: the sphere fragments are then staged once per CU instead of three
+// times, and the LDS that frees holds the per-lane attenuation stacks (no HBM traffic for them).
+template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false, bool GATE = false, int BLK = kBlock>
+__global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_trace_kernel(const KArgs A) {
+    static_assert(BLK == kBlock || (MFMA && !BVH), "only the MFMA list kernels take another workgroup size");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
     float4 *s_sph = reinterpret_cast<float4 *>(smem);  // list mode: n_spheres x (cx,cy,cz,r^2)
@@ -818,42 +822,42 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
     uint32_t *s_perm = reinterpret_cast<uint32_t *>(p + (A.has_noise ? 4096 : 0));
     p += A.has_noise ? (4096 + 3072) : 0;
     uint32_t *s_bvh = reinterpret_cast<uint32_t *>(p);
-    p += BVH ? (A.bvh_stack_entries * kBlock * 4) : 0;
+    p += BVH ? (A.bvh_stack_entries * BLK * 4) : 0;
     DWideNode *s_nodes = reinterpret_cast<DWideNode *>(p);
     p += (BVH && A.nodes_in_lds) ? A.n_nodes * 64u : 0u;
-    uint16_t *s_queue = reinterpret_cast<uint16_t *>(p);  // list mode: [kQueueCap+1][kBlock] u16
-    p += BVH ? 0 : ((kQueueCap + 1) * kBlock * 2 + 15) / 16 * 16;
+    uint16_t *s_queue = reinterpret_cast<uint16_t *>(p);  // list mode: [kQueueCap+1][BLK] u16
+    p += BVH ? 0 : ((kQueueCap + 1) * BLK * 2 + 15) / 16 * 16;
     uint4 *s_afrag = reinterpret_cast<uint4 *>(p);        // MFMA: [n_tiles][2][64] x 16 B
     p += MFMA ? A.n_tiles * 2048u : 0u;
     uint16_t *s_tile_sphere = reinterpret_cast<uint16_t *>(p);
     p += MFMA ? ((A.n_tiles * 64u + 15u) & ~15u) : 0u;
 
-    float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][kBlock] attenuation stack
+    float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][BLK] attenuation stack
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
 
     if (!BVH && SPH_LDS) {
-        for (uint32_t k = tid; k < A.n_spheres_pad; k += kBlock) s_sph[k] = A.spheres_r2[k];
+        for (uint32_t k = tid; k < A.n_spheres_pad; k += BLK) s_sph[k] = A.spheres_r2[k];
     }
     if (MFMA) {
-        for (uint32_t k = tid; k < A.n_tiles * 128u; k += kBlock) s_afrag[k] = A.afrag[k];
-        for (uint32_t k = tid; k < A.n_tiles * 32u; k += kBlock) s_tile_sphere[k] = A.tile_sphere[k];
+        for (uint32_t k = tid; k < A.n_tiles * 128u; k += BLK) s_afrag[k] = A.afrag[k];
+        for (uint32_t k = tid; k < A.n_tiles * 32u; k += BLK) s_tile_sphere[k] = A.tile_sphere[k];
     }
     if (BVH && A.nodes_in_lds) {
         const uint4 *src = reinterpret_cast<const uint4 *>(A.wnodes);
         uint4 *dst = reinterpret_cast<uint4 *>(s_nodes);
-        for (uint32_t k = tid; k < A.n_nodes * 4u; k += kBlock) dst[k] = src[k];
+        for (uint32_t k = tid; k < A.n_nodes * 4u; k += BLK) dst[k] = src[k];
     }
     if (A.has_noise) {
-        for (int k = tid; k < 256; k += kBlock) s_pvec[k] = A.perlin_vec[k];
-        for (int k = tid; k < 768; k += kBlock) s_perm[k] = A.perlin_perm[k];
+        for (int k = tid; k < 256; k += BLK) s_pvec[k] = A.perlin_vec[k];
+        for (int k = tid; k < 768; k += BLK) s_perm[k] = A.perlin_perm[k];
     }
     __syncthreads();
 
     PerlinLds pn{s_pvec, s_perm};
     float *path = A.stack_in_lds ? (s_path + tid)
-                                 : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * kBlock + tid);
+                                 : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * BLK + tid);
 
 #ifdef PT_SECTIONS
     // development aid (-DPT_SECTIONS): per-wave cycle counts of the main loop's sections (s_memtime deltas at
@@ -972,7 +976,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             idx = trav.idx;
             t_hit = trav.best;
         } else if (MFMA)
-            idx = intersect_list_mfma<VERIFY, MOVING, GATE>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere,
+            idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere,
                                                       s_queue, ro, rd, a, have, rtime, t_hit
 #ifdef PT_SECTIONS
                                                       , sec_t
@@ -1069,9 +1073,9 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
                     if (depth == 0u) {
                         att0 = att;
                     } else {
-                        path[((depth - 1u) * 3 + 0) * kBlock] = att.x;
-                        path[((depth - 1u) * 3 + 1) * kBlock] = att.y;
-                        path[((depth - 1u) * 3 + 2) * kBlock] = att.z;
+                        path[((depth - 1u) * 3 + 0) * BLK] = att.x;
+                        path[((depth - 1u) * 3 + 1) * BLK] = att.y;
+                        path[((depth - 1u) * 3 + 2) * BLK] = att.z;
                     }
                     depth += 1;
                     o = point;
@@ -1085,9 +1089,9 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
             if (terminal) {
                 // scene.rs:62-64 unwound: emitted(=0) + attenuation * deeper, innermost first
                 for (int k = (int)depth - 1; k >= 1; --k) {
-                    V.x = 0.0f + path[((k - 1) * 3 + 0) * kBlock] * V.x;
-                    V.y = 0.0f + path[((k - 1) * 3 + 1) * kBlock] * V.y;
-                    V.z = 0.0f + path[((k - 1) * 3 + 2) * kBlock] * V.z;
+                    V.x = 0.0f + path[((k - 1) * 3 + 0) * BLK] * V.x;
+                    V.y = 0.0f + path[((k - 1) * 3 + 1) * BLK] * V.y;
+                    V.z = 0.0f + path[((k - 1) * 3 + 2) * BLK] * V.z;
                 }
                 if (depth > 0u) V = mk3(0.0f + att0.x * V.x, 0.0f + att0.y * V.y, 0.0f + att0.z * V.z);
                 col = add3(col, V);  // scene.rs:110
@@ -1109,7 +1113,7 @@ __global__ __launch_bounds__(kBlock, PT_MINWAVES) void pt_trace_kernel(const KAr
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&A.debug[16 + i], sec_t[i]);
 #endif
-    if (A.wave_end && lane == 0) A.wave_end[blockIdx.x * (kBlock / 64) + (tid >> 6)] = wall_clock64();
+    if (A.wave_end && lane == 0) A.wave_end[blockIdx.x * (BLK / 64) + (tid >> 6)] = wall_clock64();
     if (BVH && VERIFY) {   // traversal counters (accumulate over the lane's whole life: never reset per ray)
         atomicAdd(&A.debug[8], (unsigned long long)trav.visits);
         atomicAdd(&A.debug[9], (unsigned long long)trav.leaves + (unsigned long long)nrays * A.n_bvh_large);

@@ -41,6 +41,7 @@ int fail(int code, const char *fmt, ...) {
 
 constexpr uint32_t kLdsBudget = 160u * 1024u;       // LDS per CU on gfx950
 constexpr uint32_t kPilotMinSamples = 16u;          // heavy-first tile ordering pays from 16 spp on (measured: +10 % at 16, -1 % at 8)
+constexpr uint32_t kWideBlock = 768u;              // MFMA list kernels: one workgroup of 12 waves per CU (see launch())
 constexpr uint32_t kLdsPerBlockMax = 96u * 1024u;   // leave room for >= 1 co-resident block's statics
 
 }  // namespace
@@ -1142,28 +1143,39 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.bvh_stack_entries = s->bvh_depth + 2u;
     A.nodes_in_lds = (bvh && s->n_nodes * 64u <= 32u * 1024u && (s->variant & 1u) == 0) ? 1u : 0u;
     if (bvh) lds += A.bvh_stack_entries * kBlock * 4u + (A.nodes_in_lds ? s->n_nodes * 64u : 0u);
-    if (!bvh) lds += ((kQueueCap + 1) * kBlock * 2u + 15u) / 16u * 16u;
+    // Workgroup size. The MFMA list kernels run ONE 768-thread workgroup per CU when everything fits: the sphere
+    // fragments (identical in every workgroup) are staged once per CU, and the LDS that frees holds the per-lane
+    // attenuation stacks (levels 1..max_depth-1; level 0 lives in registers), which otherwise stream through L2 to HBM
+    // (1.3 GB per 1200x800x64 frame). Variant bit 2 keeps the three 256-thread workgroups with the stack in HBM.
+    const uint32_t stack_levels = params->max_depth > 1u ? params->max_depth - 1u : 1u;
+    uint32_t blk = kBlock;
+    if (mfma && (s->variant & 2u) == 0 && (A.verify & 1u) == 0 && s->blocks_per_cu == 0) {
+        const uint64_t wide = (uint64_t)lds + ((kQueueCap + 1) * kWideBlock * 2u + 15u) / 16u * 16u + s->n_tiles * 2048u +
+                              ((s->n_tiles * 64u + 15u) & ~15u) + (uint64_t)stack_levels * 3ull * kWideBlock * 4ull;
+        if (wide <= kLdsBudget) blk = kWideBlock;
+    }
+    if (!bvh) lds += ((kQueueCap + 1) * blk * 2u + 15u) / 16u * 16u;
     if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u);
-    const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
-    // the MFMA variant keeps the attenuation stack in HBM: its LDS goes to the A fragments, and 3 resident
+    const uint64_t path_bytes = (uint64_t)stack_levels * 3ull * blk * 4ull;
+    // the 256-thread MFMA variant keeps the attenuation stack in HBM: its LDS goes to the A fragments, and 3 resident
     // workgroups per CU beat 1 with an LDS stack (measured 7.5 vs 3.0 Grays/s)
-    A.stack_in_lds = (!bvh && !mfma && (s->variant & 2u) == 0 && lds + path_bytes <= kLdsPerBlockMax) ? 1u : 0u;
+    A.stack_in_lds = (blk == kWideBlock) || (!bvh && !mfma && (s->variant & 2u) == 0 && lds + path_bytes <= kLdsPerBlockMax) ? 1u : 0u;
     if (A.stack_in_lds) lds += (uint32_t)path_bytes;
     A.lds_sphere_bytes = sph_bytes;
 
     // ---- persistent grid: CUs x resident blocks --------------------------------
     uint32_t bpc = s->blocks_per_cu;
-    if (bpc == 0) bpc = bvh ? 4u : 3u;
+    if (bpc == 0) bpc = (blk == kWideBlock) ? 1u : (bvh ? 4u : 3u);
     const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
     if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
     if (bpc > 8u) bpc = 8u;
     uint32_t grid = (uint32_t)s->num_cus * bpc;
-    const uint32_t need = (A.n_items + kBlock - 1) / kBlock;
+    const uint32_t need = (A.n_items + blk - 1) / blk;
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
 
     if (!A.stack_in_lds) {
-        const size_t need_floats = (size_t)grid * params->max_depth * 3ull * kBlock;
+        const size_t need_floats = (size_t)grid * params->max_depth * 3ull * blk;
         if (need_floats > s->d_gstack_floats) {
             (void)hipFree(s->d_gstack);
             s->d_gstack = nullptr;
@@ -1185,20 +1197,28 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         kern = pt_trace_kernel<true, false, false, false, false, true>, pilot_kern = pt_trace_kernel<true, false, false, false, true, true>;
     else if (mfma && ref_bvh && moving && (A.verify & 1u))
         kern = pt_trace_kernel<false, true, true, true, false, true, true>;
+    else if (mfma && ref_bvh && moving && blk == kWideBlock)
+        kern = pt_trace_kernel<false, true, true, false, false, true, true, kWideBlock>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true, true, kWideBlock>;
     else if (mfma && ref_bvh && moving)
         kern = pt_trace_kernel<false, true, true, false, false, true, true>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true, true>;
     else if (mfma && ref_bvh && (A.verify & 1u))
         kern = pt_trace_kernel<false, true, true, true, false, false, true>;
+    else if (mfma && ref_bvh && blk == kWideBlock)
+        kern = pt_trace_kernel<false, true, true, false, false, false, true, kWideBlock>, pilot_kern = pt_trace_kernel<false, true, true, false, true, false, true, kWideBlock>;
     else if (mfma && ref_bvh)
         kern = pt_trace_kernel<false, true, true, false, false, false, true>, pilot_kern = pt_trace_kernel<false, true, true, false, true, false, true>;
     else if (moving && (A.verify & 1u))
         kern = pt_trace_kernel<false, true, true, true, false, true>;
+    else if (moving && blk == kWideBlock)
+        kern = pt_trace_kernel<false, true, true, false, false, true, false, kWideBlock>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true, false, kWideBlock>;
     else if (moving)
         kern = pt_trace_kernel<false, true, true, false, false, true>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true>;
     else if (bvh)
         kern = pt_trace_kernel<true, false, false, false, false>, pilot_kern = pt_trace_kernel<true, false, false, false, true>;
     else if (mfma && (A.verify & 1u))
         kern = pt_trace_kernel<false, true, true, true, false>;
+    else if (mfma && blk == kWideBlock)
+        kern = pt_trace_kernel<false, true, true, false, false, false, false, kWideBlock>, pilot_kern = pt_trace_kernel<false, true, true, false, true, false, false, kWideBlock>;
     else if (mfma)
         kern = pt_trace_kernel<false, true, true, false, false>, pilot_kern = pt_trace_kernel<false, true, true, false, true>;
     else if (sph_lds)
@@ -1241,7 +1261,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         P.verify = 0;
         P.wave_end = nullptr;
         // a third of the frame's grid: the pilot has ~100x less work, and each workgroup stages the scene into LDS
-        hipLaunchKernelGGL(pilot_kern, dim3((grid + 2u) / 3u), dim3(kBlock), lds, stream, P);
+        hipLaunchKernelGGL(pilot_kern, dim3((grid + 2u) / 3u), dim3(blk), lds, stream, P);
         hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, params->max_depth + 1u, order);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
@@ -1249,12 +1269,12 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     }
 
     HIP_TRY(hipEventRecord(s->ev_start, stream));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, stream, A);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(blk), lds, stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_stop, stream));
     s->ev_valid = true;
     s->last_grid = grid;
-    s->last_block = kBlock;
+    s->last_block = blk;
     s->last_lds = lds;
 #ifdef PT_SECTIONS
     {   // development aid (-DPT_SECTIONS builds only): where the waves' cycles go
@@ -1272,7 +1292,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
 #endif
     if (timing) {  // development aid: distribution of wave finish times
         (void)hipStreamSynchronize(stream);
-        const uint32_t nw = grid * (kBlock / 64);
+        const uint32_t nw = grid * (blk / 64);
         std::vector<unsigned long long> t(nw);
         (void)hipMemcpy(t.data(), d_wave_end, nw * 8, hipMemcpyDeviceToHost);
         std::sort(t.begin(), t.end());
