@@ -238,7 +238,8 @@ int pt_last_launch_info(pt_scene *scene, uint32_t *grid_out, uint32_t *block_out
 
 /* Tuning knobs (0 = library default): workgroups resident per CU for the persistent grid, and a
  * kernel-variant bit mask (DESIGN.md "kernel variants"): 1 = scan table from HBM/L2 instead of LDS,
- * 2 = attenuation stack in HBM, 4 = disable the MFMA prefilter (exact VALU scan), 8 = verify mode,
+ * 2 = attenuation stack in HBM (MFMA kernels: 3 x 256 threads per CU instead of 1 x 768),
+ * 4 = disable the MFMA prefilter (exact VALU scan), 8 = verify mode,
  * 32 = no heavy-first tile ordering, 64 = never walk the internal tree in list mode (forces the scan),
  * 128 = trace Sphere + MovingSphere worlds with the general kernel instead of the MOVING sphere kernels,
  * 256 = use_bvh worlds always walk the internal tree (default: the MFMA list kernel + ancestor gate when it fits). */
