@@ -93,6 +93,13 @@ struct KArgs {
     float c0[3];                 // feature-space origin (f32-exact), radius bound of the prefiltered set
     float rs2;                   // Rs^2, Rs >= max(|c - c0| + |r|) over prefiltered spheres
     float m0, gamma;             // margin = a * (m0 + gamma * (|o - c0|^2 + Rs^2))
+    // tile culling (DESIGN.md "tile culling"): tiles hold spheres sorted along cull_axis; a wave runs only the tiles
+    // some lane's ray segment (origin .. nearest exact hit so far, clipped to the sorted spheres' box) can overlap
+    const uint32_t *cull_tab;    // [64] tiles reaching up to cell c or beyond | [64] tiles starting at cell c or before
+    uint32_t cull_axis;          // 0..2; 3 = culling off
+    uint32_t cull_always;        // tiles that are always run (they hold spheres outside the sorted set)
+    float cull_u0, cull_inv_cell;
+    float clip_min[3], clip_max[3];  // box of the sorted spheres, already padded
     uint32_t verify;             // debug: count exact-positive pairs the prefilter did not flag
     unsigned long long *debug;   // [4] misses, candidates, overflow fallbacks, exact positives
     unsigned long long *wave_end; // optional (PTGPU_TIMING=1): wall clock at which each wave left the main loop
@@ -520,9 +527,51 @@ __device__ __forceinline__ void exact_candidate(const KArgs &A, const float4 c, 
     }
 }
 
+// OR over the 64 lanes of a wave, returned wave-uniform (four DPP steps inside each row of 16, then one lane per row)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+    v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true);  // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) | (uint32_t)__builtin_amdgcn_readlane((int)v, 16) |
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// Tiles this lane's ray can still find a WINNING hit in. A hit on a sorted sphere lies inside the (padded) box of
+// the sorted spheres and at t in (t_min, t_end], t_end = the nearest exact hit known so far (the always-tested large
+// spheres, e.g. the ground) -- a farther hit cannot be the closest one. The ray is clipped to that box and range;
+// the extent of the clipped segment along the sort axis selects the tiles whose own extent overlaps it (two table
+// lookups on a 64-cell grid). Approximate reciprocals are fine: every bound is padded far beyond their error, and a
+// NaN anywhere yields "no tile", which is what the reference's `discriminant > 0` does with such a ray as well.
+__device__ __forceinline__ uint32_t lane_tile_mask(const KArgs &A, const uint32_t *s_cull, f3 o, f3 d, bool active, float t_end) {
+    float t0 = 0.0f, t1 = t_end * 1.00001f + 1.0e-5f;
+    bool inside = active;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (__builtin_fabsf(dd[k]) > 1.0e-12f) {
+            const float inv = __builtin_amdgcn_rcpf(dd[k]);
+            const float ta = (A.clip_min[k] - oo[k]) * inv, tb = (A.clip_max[k] - oo[k]) * inv;
+            t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+            t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+        } else {
+            inside = inside && oo[k] >= A.clip_min[k] && oo[k] <= A.clip_max[k];
+        }
+    }
+    const float slack = 1.0e-3f * (1.0f + t1);     // relative to the distance travelled: covers rcp and f32 rounding
+    t0 = t0 - slack, t1 = t1 + slack;
+    const float ou = oo[A.cull_axis == 0u ? 0 : (A.cull_axis == 1u ? 1 : 2)], du = dd[A.cull_axis == 0u ? 0 : (A.cull_axis == 1u ? 1 : 2)];
+    const float ua = ou + t0 * du, ub = ou + t1 * du;
+    const float lo = __builtin_fminf(ua, ub) - 1.0e-3f, hi = __builtin_fmaxf(ua, ub) + 1.0e-3f;
+    if (!(inside && t0 <= t1 && lo <= hi)) return A.cull_always;
+    const float cl = __builtin_fminf(__builtin_fmaxf((lo - A.cull_u0) * A.cull_inv_cell, 0.0f), 63.0f);
+    const float ch = __builtin_fminf(__builtin_fmaxf((hi - A.cull_u0) * A.cull_inv_cell, 0.0f), 63.0f);
+    return (s_cull[(int)cl] & s_cull[64 + (int)ch]) | A.cull_always;
+}
+
 template <bool VERIFY, bool MOVING, bool GATED, int BLK>
 __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *sph, const uint4 *s_afrag,
-                                                   const uint16_t *s_tile_sphere, uint16_t *queue,
+                                                   const uint16_t *s_tile_sphere, const uint32_t *s_cull, uint16_t *queue,
                                                    f3 o, f3 d, float a, bool active, float time, float &t_out,
                                                    unsigned long long *sec = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -570,12 +619,25 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
         tbits = 0;
         cnt = 0;
     };
+    // the always-tested spheres first (wave-uniform): their nearest hit bounds the segment the tiles are culled against
+    for (uint32_t j = 0; j < A.n_large; ++j) {
+        const int k = (int)A.large[j];
+        if (active) exact_candidate<GATED>(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+    }
+    // wave-uniform set of tiles to run: the union of the lanes' tile masks (verify mode audits every tile)
+    uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
+    if (!VERIFY && A.cull_axis < 3u) rem = wave_or(lane_tile_mask(A, s_cull, o, d, active, best));
     union Frag { uint4 u; half8 h; };
     Frag a0, a1, n0, n1;
-    a0.u = s_afrag[lane];
-    a1.u = s_afrag[64 + lane];
-    for (uint32_t T = 0; T < A.n_tiles; ++T) {
-        const uint32_t Tn = (T + 1 < A.n_tiles) ? T + 1 : T;   // prefetch the next tile's fragments
+    {
+        const uint32_t T0 = rem ? (uint32_t)__builtin_ctz(rem) : 0u;
+        a0.u = s_afrag[(T0 * 2 + 0) * 64 + lane];
+        a1.u = s_afrag[(T0 * 2 + 1) * 64 + lane];
+    }
+    while (rem != 0u) {
+        const uint32_t T = (uint32_t)__builtin_ctz(rem);
+        rem &= rem - 1u;
+        const uint32_t Tn = rem ? (uint32_t)__builtin_ctz(rem) : T;   // prefetch the next tile's fragments
         n0.u = s_afrag[(Tn * 2 + 0) * 64 + lane];
         n1.u = s_afrag[(Tn * 2 + 1) * 64 + lane];
         float16v acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, rf.b0[0], zero, 0, 0, 0);
@@ -609,10 +671,6 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     }
     PT_SUB(6);
     // ---- phase 2: exact arithmetic on the candidates of this lane's own ray ----
-    for (uint32_t j = 0; j < A.n_large; ++j) {  // wave-uniform: spheres outside the prefilter's range
-        const int k = (int)A.large[j];
-        if (active) exact_candidate<GATED>(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
-    }
     const bool overflow = VERIFY && cnt > (uint32_t)kEntCap;
     if (__any(overflow || (VERIFY && active))) {
         if (overflow || VERIFY) {
@@ -831,6 +889,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
     p += MFMA ? A.n_tiles * 2048u : 0u;
     uint16_t *s_tile_sphere = reinterpret_cast<uint16_t *>(p);
     p += MFMA ? ((A.n_tiles * 64u + 15u) & ~15u) : 0u;
+    uint32_t *s_cull = reinterpret_cast<uint32_t *>(p);   // MFMA: tile-culling tables, 2 x 64 words
+    p += MFMA ? 512u : 0u;
 
     float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][BLK] attenuation stack
 
@@ -843,6 +903,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
     if (MFMA) {
         for (uint32_t k = tid; k < A.n_tiles * 128u; k += BLK) s_afrag[k] = A.afrag[k];
         for (uint32_t k = tid; k < A.n_tiles * 32u; k += BLK) s_tile_sphere[k] = A.tile_sphere[k];
+        if (A.cull_axis < 3u && tid < 128) s_cull[tid] = A.cull_tab[tid];
     }
     if (BVH && A.nodes_in_lds) {
         const uint4 *src = reinterpret_cast<const uint4 *>(A.wnodes);
@@ -976,7 +1037,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
             idx = trav.idx;
             t_hit = trav.best;
         } else if (MFMA)
-            idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere,
+            idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_cull,
                                                       s_queue, ro, rd, a, have, rtime, t_hit
 #ifdef PT_SECTIONS
                                                       , sec_t

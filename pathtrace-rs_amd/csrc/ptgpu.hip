@@ -76,6 +76,9 @@ struct pt_scene {
     uint32_t n_tiles = 0, n_large = 0;
     float c0[3] = {0, 0, 0};
     float rs2 = 0.f, m0 = 0.f, gamma = 0.f;
+    uint32_t *d_cull_tab = nullptr;           // tile-culling tables (cull_axis == 3: off)
+    uint32_t cull_axis = 3, cull_always = 0;
+    float cull_u0 = 0.f, cull_inv_cell = 0.f, clip_min[3] = {0, 0, 0}, clip_max[3] = {0, 0, 0};
     unsigned long long *d_debug = nullptr;    // 4 u64 counters (verify mode)
     uint32_t *d_tile_buf = nullptr;           // [8 scratch words | n tile costs | n tile order]
     float *d_pilot_rgb = nullptr;             // never-read frame buffer of the pilot pass
@@ -255,6 +258,10 @@ struct MfmaPrep {
     double rs = 0.0;
     double sweep_ratio = 0.0;  // max over prefiltered spheres of (swept half-length / |radius|)
     uint32_t n_tiles = 0;
+    // tile culling: sort axis (3 = off), tiles that are always run, 64-cell lookup tables, padded box of the sorted spheres
+    uint32_t cull_axis = 3, cull_always = 0;
+    std::vector<uint32_t> cull_tab;
+    float cull_u0 = 0.f, cull_inv_cell = 0.f, clip_min[3] = {0, 0, 0}, clip_max[3] = {0, 0, 0};
 };
 
 uint16_t f16_bits(_Float16 h) {
@@ -295,6 +302,83 @@ bool prepare_mfma(const pt_scene_desc *desc, const MotionIn *motion, double t_lo
     }
     if (out.large.size() > kMaxLarge || small.size() < 32) return false;
     out.n_tiles = (uint32_t)((small.size() + 31) / 32);
+    // ---- tile culling: give the tiles a spatial meaning -------------------------------------------------------
+    // Spheres of ordinary size are sorted along one axis, so a tile of 32 consecutive ones covers a short interval of
+    // that axis and a wave can skip the tiles no ray of it comes near (pt_kernel.h lane_tile_mask). Oversized spheres
+    // go last; a tile holding any of them is always run. The axis is the one on which the tiles come out narrowest.
+    // The order of the prefiltered spheres never affects the image (closest hit by (t, index)).
+    if (out.n_tiles >= 4 && out.n_tiles <= 32) {
+        auto radius_of = [&](uint32_t i) { return std::fabs((double)desc->spheres[i].radius) + sw[i].half; };
+        std::vector<double> rr;
+        for (uint32_t i : small) rr.push_back(radius_of(i));
+        std::nth_element(rr.begin(), rr.begin() + rr.size() / 2, rr.end());
+        const double r_med = rr[rr.size() / 2];
+        std::vector<uint32_t> regular, big;
+        for (uint32_t i : small) (radius_of(i) <= 3.0 * r_med ? regular : big).push_back(i);
+        const size_t full_tiles = regular.size() / 32;   // tiles made of sorted spheres only
+        int forced = -1;
+        if (const char *e = getenv("PTGPU_CULL_AXIS")) forced = atoi(e);
+        double best_score = 1e300;
+        int best_axis = 3;
+        for (int ax = 0; ax < 3 && full_tiles >= 3; ++ax) {
+            std::vector<uint32_t> ord = regular;
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return sw[a].c[ax] < sw[b].c[ax]; });
+            double lo_all = 1e300, hi_all = -1e300, sum = 0;
+            for (size_t T = 0; T < full_tiles; ++T) {
+                double lo = 1e300, hi = -1e300;
+                for (size_t j = T * 32; j < T * 32 + 32; ++j)
+                    lo = std::min(lo, sw[ord[j]].c[ax] - radius_of(ord[j])), hi = std::max(hi, sw[ord[j]].c[ax] + radius_of(ord[j]));
+                sum += hi - lo, lo_all = std::min(lo_all, lo), hi_all = std::max(hi_all, hi);
+            }
+            const double score = sum / ((double)full_tiles * std::max(hi_all - lo_all, 1e-30));   // mean tile extent / set extent
+            if ((forced < 0 && score < best_score) || forced == ax) best_score = score, best_axis = ax;
+        }
+        if (forced == 3) best_axis = 3;
+        if (best_axis < 3 && (best_score < 0.5 || forced >= 0)) {
+            const int ax = best_axis;
+            std::stable_sort(regular.begin(), regular.end(), [&](uint32_t a, uint32_t b) { return sw[a].c[ax] < sw[b].c[ax]; });
+            small = regular;
+            small.insert(small.end(), big.begin(), big.end());
+            std::vector<double> lo(out.n_tiles, 0.0), hi(out.n_tiles, 0.0);
+            double bmin[3] = {1e300, 1e300, 1e300}, bmax[3] = {-1e300, -1e300, -1e300};
+            for (uint32_t T = 0; T < out.n_tiles; ++T) {
+                if (T >= full_tiles) {
+                    out.cull_always |= 1u << T;
+                    continue;
+                }
+                lo[T] = 1e300, hi[T] = -1e300;
+                for (size_t j = (size_t)T * 32; j < (size_t)T * 32 + 32; ++j) {
+                    const uint32_t i = small[j];
+                    const double r = radius_of(i);
+                    lo[T] = std::min(lo[T], sw[i].c[ax] - r), hi[T] = std::max(hi[T], sw[i].c[ax] + r);
+                    for (int k = 0; k < 3; ++k) bmin[k] = std::min(bmin[k], sw[i].c[k] - r), bmax[k] = std::max(bmax[k], sw[i].c[k] + r);
+                }
+            }
+            // the box and the tile intervals are padded by 2e-3 + 1e-5 of their magnitude: the reference's f32 hit test
+            // sees a sphere inflated by ~1e-6 relative, and a moving sphere's sweep bound already carries its own slack
+            for (int k = 0; k < 3; ++k) {
+                const double pad = 2e-3 + 1e-5 * std::max(std::fabs(bmin[k]), std::fabs(bmax[k]));
+                out.clip_min[k] = std::nextafter((float)(bmin[k] - pad), -3.0e38f);
+                out.clip_max[k] = std::nextafter((float)(bmax[k] + pad), 3.0e38f);
+            }
+            out.cull_axis = (uint32_t)ax;
+            out.cull_u0 = out.clip_min[ax];
+            const double cell = std::max(((double)out.clip_max[ax] - (double)out.clip_min[ax]) / 64.0, 1e-30);
+            out.cull_inv_cell = (float)(1.0 / cell);
+            out.cull_tab.assign(128, 0u);
+            for (int c = 0; c < 64; ++c) {
+                // cell c as the DEVICE sees it: a coordinate u lands in cell clamp(int((u - u0) * inv_cell)); one extra cell
+                // of slack on each side covers the f32 rounding of that expression
+                const double c_lo = (c == 0) ? -1e300 : (double)out.cull_u0 + (c - 1) * cell;
+                const double c_hi = (c == 63) ? 1e300 : (double)out.cull_u0 + (c + 2) * cell;
+                for (uint32_t T = 0; T < (uint32_t)full_tiles; ++T) {
+                    const double pad = 2e-3 + 1e-5 * std::max(std::fabs(lo[T]), std::fabs(hi[T]));
+                    if (hi[T] + pad >= c_lo) out.cull_tab[c] |= 1u << T;        // tiles reaching cell c or beyond
+                    if (lo[T] - pad <= c_hi) out.cull_tab[64 + c] |= 1u << T;   // tiles starting at cell c or before
+                }
+            }
+        }
+    }
     out.tile_sphere.assign((size_t)out.n_tiles * 32, 0xffffu);
     out.afrag.assign((size_t)out.n_tiles * 2 * 64 * 8, 0);
     for (uint32_t T = 0; T < out.n_tiles; ++T) {
@@ -692,6 +776,15 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
                 pt_scene_destroy(s);
                 return rc;
             }
+            if (prep.cull_axis < 3u) {
+                if ((rc = upload(&s->d_cull_tab, prep.cull_tab.data(), prep.cull_tab.size()))) {
+                    pt_scene_destroy(s);
+                    return rc;
+                }
+                s->cull_axis = prep.cull_axis, s->cull_always = prep.cull_always;
+                s->cull_u0 = prep.cull_u0, s->cull_inv_cell = prep.cull_inv_cell;
+                memcpy(s->clip_min, prep.clip_min, 12), memcpy(s->clip_max, prep.clip_max, 12);
+            }
             s->n_tiles = prep.n_tiles;
             s->n_large = (uint32_t)prep.large.size();
             memcpy(s->c0, prep.c0, sizeof s->c0);
@@ -926,6 +1019,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_leaf_rank);
     (void)hipFree(s->d_afrag);
     (void)hipFree(s->d_tile_sphere);
+    (void)hipFree(s->d_cull_tab);
     (void)hipFree(s->d_large);
     (void)hipFree(s->d_debug);
     (void)hipFree(s->d_tile_buf);
@@ -1128,6 +1222,11 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     const bool mfma = !bvh && sph_lds && s->n_tiles > 0 && s->n_tiles <= 24u && (s->variant & 4u) == 0;
     A.afrag = s->d_afrag;
     A.tile_sphere = s->d_tile_sphere;
+    A.cull_tab = s->d_cull_tab;
+    A.cull_axis = (s->variant & 1024u) ? 3u : s->cull_axis;   // variant bit 1024: run every tile
+    A.cull_always = s->cull_always;
+    A.cull_u0 = s->cull_u0, A.cull_inv_cell = s->cull_inv_cell;
+    memcpy(A.clip_min, s->clip_min, 12), memcpy(A.clip_max, s->clip_max, 12);
     A.large = s->d_large;
     A.n_tiles = mfma ? s->n_tiles : 0u;
     A.n_large = s->n_large;
@@ -1151,11 +1250,11 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     uint32_t blk = kBlock;
     if (mfma && (s->variant & 2u) == 0 && (A.verify & 1u) == 0 && s->blocks_per_cu == 0) {
         const uint64_t wide = (uint64_t)lds + ((kQueueCap + 1) * kWideBlock * 2u + 15u) / 16u * 16u + s->n_tiles * 2048u +
-                              ((s->n_tiles * 64u + 15u) & ~15u) + (uint64_t)stack_levels * 3ull * kWideBlock * 4ull;
+                              ((s->n_tiles * 64u + 15u) & ~15u) + 512u + (uint64_t)stack_levels * 3ull * kWideBlock * 4ull;
         if (wide <= kLdsBudget) blk = kWideBlock;
     }
     if (!bvh) lds += ((kQueueCap + 1) * blk * 2u + 15u) / 16u * 16u;
-    if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u);
+    if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + 512u;
     const uint64_t path_bytes = (uint64_t)stack_levels * 3ull * blk * 4ull;
     // the 256-thread MFMA variant keeps the attenuation stack in HBM: its LDS goes to the A fragments, and 3 resident
     // workgroups per CU beat 1 with an LDS stack (measured 7.5 vs 3.0 Grays/s)
