@@ -62,6 +62,8 @@ struct DCamera {  // camera.rs:8-19
     float time0, time1, lens_radius;
 };
 
+constexpr int kCullCells = 256;   // resolution of the tile-culling lookup along the sort axis
+
 struct KArgs {
     // scene (HBM resident)
     const float4 *spheres;       // cx, cy, cz, radius
@@ -95,7 +97,7 @@ struct KArgs {
     float m0, gamma;             // margin = a * (m0 + gamma * (|o - c0|^2 + Rs^2))
     // tile culling (DESIGN.md "tile culling"): tiles hold spheres sorted along cull_axis; a wave runs only the tiles
     // some lane's ray segment (origin .. nearest exact hit so far, clipped to the sorted spheres' box) can overlap
-    const uint32_t *cull_tab;    // [64] tiles reaching up to cell c or beyond | [64] tiles starting at cell c or before
+    const uint32_t *cull_tab;    // [kCullCells] tiles reaching up to cell c or beyond | [kCullCells] tiles starting at cell c or before
     uint32_t cull_axis;          // 0..2; 3 = culling off
     uint32_t cull_always;        // tiles that are always run (they hold spheres outside the sorted set)
     float cull_u0, cull_inv_cell;
@@ -541,7 +543,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // the sorted spheres and at t in (t_min, t_end], t_end = the nearest exact hit known so far (the always-tested large
 // spheres, e.g. the ground) -- a farther hit cannot be the closest one. The ray is clipped to that box and range;
 // the extent of the clipped segment along the sort axis selects the tiles whose own extent overlaps it (two table
-// lookups on a 64-cell grid). Approximate reciprocals are fine: every bound is padded far beyond their error, and a
+// lookups on a grid of kCullCells cells). Approximate reciprocals are fine: every bound is padded far beyond their error, and a
 // NaN anywhere yields "no tile", which is what the reference's `discriminant > 0` does with such a ray as well.
 __device__ __forceinline__ uint32_t lane_tile_mask(const KArgs &A, const uint32_t *s_cull, f3 o, f3 d, bool active, float t_end) {
     float t0 = 0.0f, t1 = t_end * 1.00001f + 1.0e-5f;
@@ -564,9 +566,9 @@ __device__ __forceinline__ uint32_t lane_tile_mask(const KArgs &A, const uint32_
     const float ua = ou + t0 * du, ub = ou + t1 * du;
     const float lo = __builtin_fminf(ua, ub) - 1.0e-3f, hi = __builtin_fmaxf(ua, ub) + 1.0e-3f;
     if (!(inside && t0 <= t1 && lo <= hi)) return A.cull_always;
-    const float cl = __builtin_fminf(__builtin_fmaxf((lo - A.cull_u0) * A.cull_inv_cell, 0.0f), 63.0f);
-    const float ch = __builtin_fminf(__builtin_fmaxf((hi - A.cull_u0) * A.cull_inv_cell, 0.0f), 63.0f);
-    return (s_cull[(int)cl] & s_cull[64 + (int)ch]) | A.cull_always;
+    const float cl = __builtin_fminf(__builtin_fmaxf((lo - A.cull_u0) * A.cull_inv_cell, 0.0f), (float)(kCullCells - 1));
+    const float ch = __builtin_fminf(__builtin_fmaxf((hi - A.cull_u0) * A.cull_inv_cell, 0.0f), (float)(kCullCells - 1));
+    return (s_cull[(int)cl] & s_cull[kCullCells + (int)ch]) | A.cull_always;
 }
 
 template <bool VERIFY, bool MOVING, bool GATED, int BLK>
@@ -626,7 +628,24 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     }
     // wave-uniform set of tiles to run: the union of the lanes' tile masks (verify mode audits every tile)
     uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
-    if (!VERIFY && A.cull_axis < 3u) rem = wave_or(lane_tile_mask(A, s_cull, o, d, active, best));
+    if (!VERIFY && A.cull_axis < 3u) {
+        const uint32_t mine = lane_tile_mask(A, s_cull, o, d, active, best);
+        rem = wave_or(mine);
+#ifdef PT_CULLSTATS
+        // development aid: debug[24] wave-iterations, [25] tiles run, [26] active lanes, [27] tiles the lanes asked for,
+        // [28 + min(n, 17)] histogram of tiles run per wave-iteration, [48 + min(n, 17)] of tiles asked for per lane
+        if (lane == 0) {
+            atomicAdd(&A.debug[24], 1ull);
+            atomicAdd(&A.debug[25], (unsigned long long)__popc(rem));
+            atomicAdd(&A.debug[28 + (__popc(rem) < 17 ? __popc(rem) : 17)], 1ull);
+        }
+        if (active) {
+            atomicAdd(&A.debug[26], 1ull);
+            atomicAdd(&A.debug[27], (unsigned long long)__popc(mine));
+            atomicAdd(&A.debug[48 + (__popc(mine) < 17 ? __popc(mine) : 17)], 1ull);
+        }
+#endif
+    }
     union Frag { uint4 u; half8 h; };
     Frag a0, a1, n0, n1;
     {
@@ -710,6 +729,16 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
             if (VERIFY && active) {
                 atomicAdd(&A.debug[1], (unsigned long long)ncand);
                 if (overflow) atomicAdd(&A.debug[2], 1ull);
+                // audit of the tile culling (which verify mode itself does not apply): the tile holding the brute-force
+                // WINNER must be among the tiles this lane would have asked for; a culled winner counts as a miss
+                if (A.cull_axis < 3u && vidx >= 0) {
+                    const uint32_t mine = lane_tile_mask(A, s_cull, o, d, active, best);   // `best`: the large spheres only so far
+                    bool is_large = false;
+                    for (uint32_t j = 0; j < A.n_large; ++j) is_large = is_large || ((int)A.large[j] == vidx);
+                    uint32_t slot = 0;
+                    while (slot < A.n_tiles * 32u && (int)s_tile_sphere[slot] != vidx) ++slot;
+                    if (!is_large && !((mine >> (slot >> 5)) & 1u)) atomicAdd(&A.debug[0], 1ull);
+                }
             }
             if (overflow) {
                 best = vbest;
@@ -889,8 +918,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
     p += MFMA ? A.n_tiles * 2048u : 0u;
     uint16_t *s_tile_sphere = reinterpret_cast<uint16_t *>(p);
     p += MFMA ? ((A.n_tiles * 64u + 15u) & ~15u) : 0u;
-    uint32_t *s_cull = reinterpret_cast<uint32_t *>(p);   // MFMA: tile-culling tables, 2 x 64 words
-    p += MFMA ? 512u : 0u;
+    uint32_t *s_cull = reinterpret_cast<uint32_t *>(p);   // MFMA: tile-culling tables, 2 x kCullCells words
+    p += MFMA ? 8u * kCullCells : 0u;
 
     float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][BLK] attenuation stack
 
@@ -903,7 +932,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
     if (MFMA) {
         for (uint32_t k = tid; k < A.n_tiles * 128u; k += BLK) s_afrag[k] = A.afrag[k];
         for (uint32_t k = tid; k < A.n_tiles * 32u; k += BLK) s_tile_sphere[k] = A.tile_sphere[k];
-        if (A.cull_axis < 3u && tid < 128) s_cull[tid] = A.cull_tab[tid];
+        if (A.cull_axis < 3u)
+            for (uint32_t k = tid; k < 2u * kCullCells; k += BLK) s_cull[k] = A.cull_tab[k];
     }
     if (BVH && A.nodes_in_lds) {
         const uint4 *src = reinterpret_cast<const uint4 *>(A.wnodes);

@@ -258,7 +258,7 @@ struct MfmaPrep {
     double rs = 0.0;
     double sweep_ratio = 0.0;  // max over prefiltered spheres of (swept half-length / |radius|)
     uint32_t n_tiles = 0;
-    // tile culling: sort axis (3 = off), tiles that are always run, 64-cell lookup tables, padded box of the sorted spheres
+    // tile culling: sort axis (3 = off), tiles that are always run, lookup tables (kCullCells cells), padded box of the sorted spheres
     uint32_t cull_axis = 3, cull_always = 0;
     std::vector<uint32_t> cull_tab;
     float cull_u0 = 0.f, cull_inv_cell = 0.f, clip_min[3] = {0, 0, 0}, clip_max[3] = {0, 0, 0};
@@ -363,18 +363,18 @@ bool prepare_mfma(const pt_scene_desc *desc, const MotionIn *motion, double t_lo
             }
             out.cull_axis = (uint32_t)ax;
             out.cull_u0 = out.clip_min[ax];
-            const double cell = std::max(((double)out.clip_max[ax] - (double)out.clip_min[ax]) / 64.0, 1e-30);
+            const double cell = std::max(((double)out.clip_max[ax] - (double)out.clip_min[ax]) / (double)kCullCells, 1e-30);
             out.cull_inv_cell = (float)(1.0 / cell);
-            out.cull_tab.assign(128, 0u);
-            for (int c = 0; c < 64; ++c) {
+            out.cull_tab.assign(2 * kCullCells, 0u);
+            for (int c = 0; c < kCullCells; ++c) {
                 // cell c as the DEVICE sees it: a coordinate u lands in cell clamp(int((u - u0) * inv_cell)); one extra cell
                 // of slack on each side covers the f32 rounding of that expression
                 const double c_lo = (c == 0) ? -1e300 : (double)out.cull_u0 + (c - 1) * cell;
-                const double c_hi = (c == 63) ? 1e300 : (double)out.cull_u0 + (c + 2) * cell;
+                const double c_hi = (c == kCullCells - 1) ? 1e300 : (double)out.cull_u0 + (c + 2) * cell;
                 for (uint32_t T = 0; T < (uint32_t)full_tiles; ++T) {
                     const double pad = 2e-3 + 1e-5 * std::max(std::fabs(lo[T]), std::fabs(hi[T]));
                     if (hi[T] + pad >= c_lo) out.cull_tab[c] |= 1u << T;        // tiles reaching cell c or beyond
-                    if (lo[T] - pad <= c_hi) out.cull_tab[64 + c] |= 1u << T;   // tiles starting at cell c or before
+                    if (lo[T] - pad <= c_hi) out.cull_tab[kCullCells + c] |= 1u << T;   // tiles starting at cell c or before
                 }
             }
         }
@@ -1250,11 +1250,11 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     uint32_t blk = kBlock;
     if (mfma && (s->variant & 2u) == 0 && (A.verify & 1u) == 0 && s->blocks_per_cu == 0) {
         const uint64_t wide = (uint64_t)lds + ((kQueueCap + 1) * kWideBlock * 2u + 15u) / 16u * 16u + s->n_tiles * 2048u +
-                              ((s->n_tiles * 64u + 15u) & ~15u) + 512u + (uint64_t)stack_levels * 3ull * kWideBlock * 4ull;
+                              ((s->n_tiles * 64u + 15u) & ~15u) + 8u * kCullCells + (uint64_t)stack_levels * 3ull * kWideBlock * 4ull;
         if (wide <= kLdsBudget) blk = kWideBlock;
     }
     if (!bvh) lds += ((kQueueCap + 1) * blk * 2u + 15u) / 16u * 16u;
-    if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + 512u;
+    if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + 8u * kCullCells;
     const uint64_t path_bytes = (uint64_t)stack_levels * 3ull * blk * 4ull;
     // the 256-thread MFMA variant keeps the attenuation stack in HBM: its LDS goes to the A fragments, and 3 resident
     // workgroups per CU beat 1 with an LDS stack (measured 7.5 vs 3.0 Grays/s)
@@ -1375,6 +1375,22 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     s->last_grid = grid;
     s->last_block = blk;
     s->last_lds = lds;
+#ifdef PT_CULLSTATS
+    {   // development aid (-DPT_CULLSTATS builds only): how many tiles the culling leaves
+        (void)hipStreamSynchronize(stream);
+        unsigned long long c[48];
+        (void)hipMemcpy(c, s->d_debug + 24, sizeof c, hipMemcpyDeviceToHost);
+        (void)hipMemset(s->d_debug + 24, 0, sizeof c);
+        if (c[0]) {
+            fprintf(stderr, "[ptgpu cull] wave-iterations %llu, tiles run per iteration %.2f of %u; lanes asked for %.2f tiles each\n  run histogram:",
+                    c[0], (double)c[1] / (double)c[0], A.n_tiles, (double)c[3] / (double)(c[2] ? c[2] : 1));
+            for (int i = 0; i < 18; ++i) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double)c[4 + i] / (double)c[0]);
+            fprintf(stderr, "\n  lane histogram:");
+            for (int i = 0; i < 18; ++i) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double)c[24 + i] / (double)(c[2] ? c[2] : 1));
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
 #ifdef PT_SECTIONS
     {   // development aid (-DPT_SECTIONS builds only): where the waves' cycles go
         (void)hipStreamSynchronize(stream);

@@ -87,7 +87,8 @@ def test_scan_variants_agree(ptgpu, oracle):
 def test_mfma_prefilter_never_drops_a_positive_discriminant(ptgpu, pthost, preset, W, H, S):
     """Verify mode (variant 8): for EVERY ray of the frame, every sphere whose reference discriminant
     (sphere.rs:33-37) is > 0 must have been flagged by the MFMA prefilter (or be in the always-exact
-    'large' set). The prefilter may over-report, never under-report."""
+    'large' set). The prefilter may over-report, never under-report. The same run audits the tile culling: the
+    tile holding each ray's brute-force winner must be one the ray's lane asks for (a culled winner is a miss)."""
     hs = pthost.HostScene(preset, W, H, samples=S, device=0)
     sc = hs.device_scene()
     p = ptgpu.PtParams(W, H, S, 10, 0, 0)
