@@ -628,8 +628,9 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     }
     // wave-uniform set of tiles to run: the union of the lanes' tile masks (verify mode audits every tile)
     uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
+    uint32_t mine = rem;   // tiles THIS lane's ray can find its winner in; the wave runs the union
     if (!VERIFY && A.cull_axis < 3u) {
-        const uint32_t mine = lane_tile_mask(A, s_cull, o, d, active, best);
+        mine = lane_tile_mask(A, s_cull, o, d, active, best);
         rem = wave_or(mine);
 #ifdef PT_CULLSTATS
         // development aid: debug[24] wave-iterations, [25] tiles run, [26] active lanes, [27] tiles the lanes asked for,
@@ -678,7 +679,9 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
         // low half of the wave (rows +0) and m1 those computed by the high half (rows +4).
         const auto sw = __builtin_amdgcn_permlane32_swap(m0, m1, false, false);
         const uint32_t full = sw[0] | (sw[1] << 16);
-        if (full != 0u) {
+        // candidates in a tile the lane did not ask for (run for another lane's sake) are behind the ray's origin or
+        // beyond its nearest hit so far: dropped here instead of going through phase 2
+        if (full != 0u && ((mine >> T) & 1u)) {
             if (cnt < (uint32_t)kEntCap) queue32[cnt * BLK + tid] = full;
             cnt += 1;
             tbits |= 1u << T;
