@@ -294,14 +294,21 @@ def main():
         # and only survivors run the exact arithmetic, so this "equivalent" rate may exceed the VALU ceiling.
         valu_ops = (18.0 * n_spheres + 150.0) * rays_per_step / N
         valu_rate = valu_ops / (kms * 1e-3) / 1e12
-        # matrix-core work actually issued by the prefilter: ceil(n/32) tiles x 4 v_mfma_f32_32x32x16_f16
-        # (32768 flop each) per 64 rays (list mode only)
-        mfma_tf = 0.0 if args.bvh else (-(-n_spheres // 32) * 4 * 32768.0 / 64.0) * rays_per_step / N / (kms * 1e-3) / 1e12
+        # matrix-core work of the prefilter if EVERY tile ran: ceil(n/32) tiles x 4 v_mfma_f32_32x32x16_f16 (32768 flop
+        # each) per 64 rays (list mode only). Tile culling skips tiles wave by wave, so what was actually issued is
+        # taken from the committed rocprofv3 counters (SQ_INSTS_MFMA per launch) when they are for this workload.
+        mfma_tf_max = 0.0 if args.bvh else (-(-n_spheres // 32) * 4 * 32768.0 / 64.0) * rays_per_step / N / (kms * 1e-3) / 1e12
+        mfma_tf = mfma_tf_max
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                prof = json.load(open(pmc))
+                traffic = prof.get("hbm_bytes_per_launch")
+                same = prof.get("bench_line_under_profiler", {}).get("config", {}).get("rays_per_step") == rays_per_step // N
+                insts = prof.get("pmc_per_launch", {}).get("SQ_INSTS_MFMA")
+                if same and insts and not args.bvh:
+                    mfma_tf = insts * 32768.0 / (kms * 1e-3) / 1e12
             except Exception:
                 traffic = None
         out = {
@@ -329,9 +336,10 @@ def main():
                          "note": "effective scan bandwidth: 16 B x %d spheres per ray, served from LDS (never HBM), so it "
                                  "exceeds the HBM peak by construction; measured HBM traffic is in `traffic`. The reference's "
                                  "arithmetic for that scan equals %.1f T f32 lane-ops/s (VALU ceiling ~67 T measured, 78.6 T "
-                                 "nominal); the kernel replaces most of it by an f16 MFMA prefilter running at %.0f TFLOP/s "
-                                 "(dense f16 peak ~2500) and is bound by divergent shading + per-iteration latency, see "
-                                 "DESIGN.md section 4" % (n_spheres, valu_rate, mfma_tf),
+                                 "nominal); the kernel replaces most of it by an f16 MFMA prefilter that issues %.0f TFLOP/s "
+                                 "(%.0f if no tile were culled; dense f16 peak ~2500) and is bound by VALU issue in the tile "
+                                 "loop, the exact phase 2 and divergent shading, see DESIGN.md section 4"
+                                 % (n_spheres, valu_rate, mfma_tf, mfma_tf_max),
                          "valu_equiv_frac": valu_rate / 78.6, "mfma_tflops": mfma_tf, "mfma_frac": mfma_tf / 2500.0},
         }
         if strong is not None:

@@ -53,8 +53,9 @@ if kt:
     rows = [r for r in csv.DictReader(open(kt)) if is_frame_kernel(r["Kernel_Name"])]
     if rows:
         r = rows[-1]
-        lines.append("launch: grid %s wg %s LDS %s VGPR %s accVGPR %s SGPR %s scratch %s" % (
-            r.get("Grid_Size"), r.get("Workgroup_Size"), r.get("LDS_Block_Size"), r.get("VGPR_Count"),
+        lines.append("launch (as rocprofv3 reports it; the LDS is dynamic, see lds_bytes in the bench line): grid %s threads, "
+                     "workgroup %s, VGPR %s accVGPR %s SGPR %s scratch %s" % (
+            r.get("Grid_Size_X", r.get("Grid_Size")), r.get("Workgroup_Size_X", r.get("Workgroup_Size")), r.get("VGPR_Count"),
             r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("Scratch_Size")))
 
 # 2. PMC passes (sum over dispatches of the trace kernel, then per launch)
