@@ -242,7 +242,8 @@ int pt_last_launch_info(pt_scene *scene, uint32_t *grid_out, uint32_t *block_out
  * 4 = disable the MFMA prefilter (exact VALU scan), 8 = verify mode,
  * 32 = no heavy-first tile ordering, 64 = never walk the internal tree in list mode (forces the scan),
  * 128 = trace Sphere + MovingSphere worlds with the general kernel instead of the MOVING sphere kernels,
- * 256 = use_bvh worlds always walk the internal tree (default: the MFMA list kernel + ancestor gate when it fits). */
+ * 256 = use_bvh worlds always walk the internal tree (default: the MFMA list kernel + ancestor gate when it fits),
+ * 1024 = the MFMA kernels run every sphere tile for every wave (no tile culling). */
 int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
 
 /* Verify-mode counters of the MFMA prefilter (variant bit 8): out4 = { exact-positive pairs the

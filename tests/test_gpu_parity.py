@@ -74,11 +74,11 @@ def test_exact_parity(ptgpu, oracle, preset, W, H, S, bvh):
 def test_scan_variants_agree(ptgpu, oracle):
     """Kernel variants are the same function: MFMA-prefiltered scan in one 768-thread workgroup per CU with the
     attenuation stacks in LDS (default), the same in three 256-thread workgroups with the stacks in HBM (2), exact
-    VALU scan from LDS (4), exact scan from HBM/L2 (4|1), exact scan with the stack in HBM (4|2), no tile reordering (32)."""
+    VALU scan from LDS (4), exact scan from HBM/L2 (4|1), exact scan with the stack in HBM (4|2), no tile reordering (32), no tile culling (1024)."""
     osc, a, ra = _gpu_render(ptgpu, oracle, "random_spheres", 96, 64, 4, False, variant=0)
     ref, ref_rays = osc.update(4)
     assert ra == ref_rays and np.array_equal(a, ref)
-    for variant in (2, 4, 5, 6, 32):
+    for variant in (2, 4, 5, 6, 32, 1024):
         _, b, rb = _gpu_render(ptgpu, oracle, "random_spheres", 96, 64, 4, False, variant=variant)
         assert rb == ref_rays and np.array_equal(b, ref), "variant %d: %s" % (variant, _report(ref, b))
 
