@@ -263,8 +263,7 @@ __device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float
 // in flight before its arithmetic starts; the table is padded to a multiple of 8 with
 // (3e38, 3e38, 3e38, 0) entries whose discriminant is NaN or -inf.
 constexpr int kScanUnroll = 8;
-constexpr int kQueueCap = 20;  // per-lane candidate slots (u16): exact scan drains above kQueueCap - kScanUnroll; the MFMA
-                               // path splits them into two sub-queues of kQueueCap / 2 (overflow -> exact scan for that ray)
+constexpr int kQueueCap = 20;  // per-lane candidate slots (u16) of the exact scan, drained above kQueueCap - kScanUnroll
 
 __device__ __forceinline__ void drain_candidates(const float4 *sph, const uint16_t *q, uint32_t &cnt, f3 o, f3 d,
                                                  float a, float &closest, int &idx) {
@@ -436,7 +435,29 @@ __device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d,
 // accumulators into masks, swaps the partner ray's half with lane ^ 32, and appends the 32-bit mask of ITS OWN
 // ray when it is non-zero (~1 candidate per ray per bounce, so most tiles append nothing). Phase 2 walks the
 // set bits; bit -> fragment slot (tile*32 + row) -> sphere.
-constexpr int kEntCap = (kQueueCap + 1) / 2;  // u32 tile masks per lane in the same LDS area as the u16 scan queue
+constexpr int kEntCap = 4;      // u32 tile masks a lane can hold between two drains (a lane only queues tiles of its own mask)
+// Phase 2 is balanced over the wave: the lanes' candidates are expanded into one list of (ray, sphere) pairs per wave and
+// every lane takes one PAIR per round, whoever's ray it belongs to (a lane-owns-its-candidates loop ran 4.0 rounds per
+// bounce at 23 % lane utilisation: 59 candidates per wave, unevenly spread). Per wave: the pair list and one 64-bit
+// (t, tie-break) key per ray that the pairs' exact tests are reduced into with ds_min_u64.
+constexpr int kPairCap = 192;
+constexpr uint32_t kWavePairBytes = kPairCap * 4u + 64u * 8u;
+__host__ __device__ constexpr uint32_t mfma_queue_bytes(uint32_t blk) { return (uint32_t)kEntCap * blk * 4u + (blk / 64u) * kWavePairBytes; }
+__host__ __device__ constexpr uint32_t scan_queue_bytes(uint32_t blk) { return ((uint32_t)(kQueueCap + 1) * blk * 2u + 15u) / 16u * 16u; }
+
+// inclusive prefix sum over the 64 lanes of a wave (row_shr 1/2/4/8 inside each row of 16, then row_bcast 15 and 31)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+__device__ __forceinline__ float lane_fetch(uint32_t src_lane, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
+}
 
 // aabb.rs:46-58 with the SSE min/max NaN rule (second operand on NaN)
 __device__ __forceinline__ float sse_min(float a, float b) { return a < b ? a : b; }
@@ -574,6 +595,7 @@ __device__ __forceinline__ uint32_t lane_tile_mask(const KArgs &A, const uint32_
 template <bool VERIFY, bool MOVING, bool GATED, int BLK>
 __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *sph, const uint4 *s_afrag,
                                                    const uint16_t *s_tile_sphere, const uint32_t *s_cull, uint16_t *queue,
+                                                   uint32_t *w_pairs, unsigned long long *w_keys,
                                                    f3 o, f3 d, float a, bool active, float time, float &t_out,
                                                    unsigned long long *sec = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -602,20 +624,97 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     int idx = -1;
     uint32_t best_rank = 0;
     // phase 2 on the queued masks: exact arithmetic for every set bit, then the queue is empty again
+    // one exact test: the candidate t as sphere.rs:38-64 returns it for t_max = f32::MAX, reduced into the owner's key.
+    // Key = (bits of t, tie-break): smaller t wins; on equal t the lower list index (hitable_list.rs:48) or, in a BVH
+    // world, the higher DFS rank (bvh.rs:47-53) -- the same order-independent rule as accept_hit.
+    auto key_of = [&](float t, int k, uint32_t rank) -> unsigned long long {
+        const uint32_t low = GATED ? (((0xffffu - rank) << 16) | (uint32_t)k) : (uint32_t)k;
+        return ((unsigned long long)__float_as_uint(t) << 32) | low;
+    };
     auto drain = [&]() {
-        uint32_t tb = tbits, j = 0, cur = 0, curT = 0;
-        while (__any((cur | tb) != 0u)) {
-            if (cur == 0u && tb != 0u) {  // next non-empty tile of my ray
-                curT = (uint32_t)__builtin_ctz(tb);
+        // 1. how many candidates does the wave hold, and where do mine go in its list
+        uint32_t mine_n = 0;
+        {
+            uint32_t tb = tbits, j = 0;
+            while (tb != 0u) {
                 tb &= tb - 1u;
-                cur = queue32[j * BLK + tid];
+                mine_n += (uint32_t)__popc(queue32[j * BLK + tid]);
                 j += 1;
             }
-            if (cur != 0u) {
-                const uint32_t b = (uint32_t)__builtin_ctz(cur);
-                cur &= cur - 1u;
-                const int k = s_tile_sphere[slot_of(curT, b)];
-                exact_candidate<GATED>(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+        }
+        const uint32_t incl = wave_inclusive_sum(mine_n);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (total > (uint32_t)kPairCap) {
+            // more pairs than the list holds (rays far outside the prefilter's accuracy range): every lane walks its own
+            uint32_t tb = tbits, j = 0, cur = 0, curT = 0;
+            while (__any((cur | tb) != 0u)) {
+                if (cur == 0u && tb != 0u) {  // next non-empty tile of my ray
+                    curT = (uint32_t)__builtin_ctz(tb);
+                    tb &= tb - 1u;
+                    cur = queue32[j * BLK + tid];
+                    j += 1;
+                }
+                if (cur != 0u) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(cur);
+                    cur &= cur - 1u;
+                    const int k = s_tile_sphere[slot_of(curT, b)];
+                    exact_candidate<GATED>(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+                }
+            }
+        } else if (total != 0u) {
+            // 2. expand my masks into (owner lane, sphere) pairs at my offset of the wave's list
+            {
+                uint32_t tb = tbits, j = 0, pos = incl - mine_n;
+                while (tb != 0u) {
+                    const uint32_t T = (uint32_t)__builtin_ctz(tb);
+                    tb &= tb - 1u;
+                    uint32_t mk = queue32[j * BLK + tid];
+                    j += 1;
+                    while (mk != 0u) {
+                        const uint32_t b = (uint32_t)__builtin_ctz(mk);
+                        mk &= mk - 1u;
+                        w_pairs[pos++] = ((uint32_t)lane << 16) | (uint32_t)s_tile_sphere[slot_of(T, b)];
+                    }
+                }
+            }
+            const unsigned long long key0 = idx < 0 ? ~0ull : key_of(best, idx, best_rank);
+            w_keys[lane] = key0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // 3. one pair per lane and round, with the owner's ray fetched across lanes
+            for (uint32_t base = 0; base < total; base += 64u) {
+                const bool valid = base + (uint32_t)lane < total;
+                const uint32_t e = valid ? w_pairs[base + lane] : 0u;
+                const uint32_t owner = e >> 16;
+                const int k = (int)(e & 0xffffu);
+                const f3 po = mk3(lane_fetch(owner, o.x), lane_fetch(owner, o.y), lane_fetch(owner, o.z));
+                const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));
+                const float pa = lane_fetch(owner, a);
+                const float ptime = MOVING ? lane_fetch(owner, time) : 0.0f;
+                if (valid) {
+                    const float4 c = sphere_at<MOVING>(A, k, sph[k], ptime);
+                    const float ocx = po.x - c.x, ocy = po.y - c.y, ocz = po.z - c.z;
+                    const float b = (ocx * pd.x + ocy * pd.y) + ocz * pd.z;
+                    const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
+                    const float disc = b * b - pa * cc;
+                    if (disc > 0.0f) {
+                        float t = kMaxT;
+                        if (sphere_roots(pa, b, disc, t)) {
+                            const uint32_t rank = GATED ? A.leaf_rank[k] : 0u;
+                            if (!GATED || gate_pass(A, k, po, mk3(1.0f / pd.x, 1.0f / pd.y, 1.0f / pd.z)))   // ray.rs:14 rcp_direction
+                                atomicMin(&w_keys[owner], key_of(t, k, rank));
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // 4. my ray's winner
+            const unsigned long long key = w_keys[lane];
+            if (key != key0) {
+                best = __uint_as_float((uint32_t)(key >> 32));
+                idx = (int)((uint32_t)key & 0xffffu);
+                if (GATED) best_rank = 0xffffu - (((uint32_t)key >> 16) & 0xffffu);
             }
         }
         tbits = 0;
@@ -682,9 +781,11 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
         // candidates in a tile the lane did not ask for (run for another lane's sake) are behind the ray's origin or
         // beyond its nearest hit so far: dropped here instead of going through phase 2
         if (full != 0u && ((mine >> T) & 1u)) {
-            if (cnt < (uint32_t)kEntCap) queue32[cnt * BLK + tid] = full;
+            if (cnt < (uint32_t)kEntCap) {   // (only verify mode can get past the capacity: everyone else drains when full)
+                queue32[cnt * BLK + tid] = full;
+                tbits |= 1u << T;
+            }
             cnt += 1;
-            tbits |= 1u << T;
             if (VERIFY) ncand += (uint32_t)__popc(full);
         }
         // a full queue is drained on the spot (exact phase 2 on what is queued so far); verify mode keeps
@@ -694,12 +795,12 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     PT_SUB(6);
     // ---- phase 2: exact arithmetic on the candidates of this lane's own ray ----
     const bool overflow = VERIFY && cnt > (uint32_t)kEntCap;
+    float vbest = kMaxT;   // verify mode: the brute-force winner
+    int vidx = -1;
+    uint32_t vrank = 0;
     if (__any(overflow || (VERIFY && active))) {
         if (overflow || VERIFY) {
-            // queue overflow (ray far outside the prefilter's accuracy range) or verify mode: brute force
-            float vbest = kMaxT;
-            int vidx = -1;
-            uint32_t vrank = 0;
+            // verify mode (and its queue overflows, where the masks of a ray were not all kept): brute force
             for (int k = 0; k < (int)A.n_spheres; ++k) {
                 const float4 c = sphere_at<MOVING>(A, k, sph[k], time);
                 exact_candidate<GATED>(A, c, k, o, d, a, vbest, vidx, vrank);
@@ -743,13 +844,10 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                     if (!is_large && !((mine >> (slot >> 5)) & 1u)) atomicAdd(&A.debug[0], 1ull);
                 }
             }
-            if (overflow) {
-                best = vbest;
-                idx = vidx;
-            }
         }
     }
-    if (!overflow) drain();
+    drain();   // wave-wide (prefix sums, cross-lane fetches): every lane takes part
+    if (overflow) best = vbest, idx = vidx, best_rank = vrank;
     PT_SUB(7);
     t_out = best;
     return idx;
@@ -915,8 +1013,10 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
     p += BVH ? (A.bvh_stack_entries * BLK * 4) : 0;
     DWideNode *s_nodes = reinterpret_cast<DWideNode *>(p);
     p += (BVH && A.nodes_in_lds) ? A.n_nodes * 64u : 0u;
-    uint16_t *s_queue = reinterpret_cast<uint16_t *>(p);  // list mode: [kQueueCap+1][BLK] u16
-    p += BVH ? 0 : ((kQueueCap + 1) * BLK * 2 + 15) / 16 * 16;
+    uint16_t *s_queue = reinterpret_cast<uint16_t *>(p);  // exact scan: [kQueueCap+1][BLK] u16; MFMA: [kEntCap][BLK] u32 tile masks + per-wave pair lists
+    uint32_t *w_pairs = reinterpret_cast<uint32_t *>(p + kEntCap * BLK * 4 + (threadIdx.x >> 6) * kWavePairBytes);
+    unsigned long long *w_keys = reinterpret_cast<unsigned long long *>(w_pairs + kPairCap);
+    p += BVH ? 0u : (MFMA ? mfma_queue_bytes(BLK) : scan_queue_bytes(BLK));
     uint4 *s_afrag = reinterpret_cast<uint4 *>(p);        // MFMA: [n_tiles][2][64] x 16 B
     p += MFMA ? A.n_tiles * 2048u : 0u;
     uint16_t *s_tile_sphere = reinterpret_cast<uint16_t *>(p);
@@ -1071,7 +1171,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
             t_hit = trav.best;
         } else if (MFMA)
             idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_cull,
-                                                      s_queue, ro, rd, a, have, rtime, t_hit
+                                                      s_queue, w_pairs, w_keys, ro, rd, a, have, rtime, t_hit
 #ifdef PT_SECTIONS
                                                       , sec_t
 #endif

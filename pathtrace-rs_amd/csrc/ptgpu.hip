@@ -1249,11 +1249,11 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     const uint32_t stack_levels = params->max_depth > 1u ? params->max_depth - 1u : 1u;
     uint32_t blk = kBlock;
     if (mfma && (s->variant & 2u) == 0 && (A.verify & 1u) == 0 && s->blocks_per_cu == 0) {
-        const uint64_t wide = (uint64_t)lds + ((kQueueCap + 1) * kWideBlock * 2u + 15u) / 16u * 16u + s->n_tiles * 2048u +
+        const uint64_t wide = (uint64_t)lds + mfma_queue_bytes(kWideBlock) + s->n_tiles * 2048u +
                               ((s->n_tiles * 64u + 15u) & ~15u) + 8u * kCullCells + (uint64_t)stack_levels * 3ull * kWideBlock * 4ull;
         if (wide <= kLdsBudget) blk = kWideBlock;
     }
-    if (!bvh) lds += ((kQueueCap + 1) * blk * 2u + 15u) / 16u * 16u;
+    if (!bvh) lds += mfma ? mfma_queue_bytes(blk) : scan_queue_bytes(blk);
     if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + 8u * kCullCells;
     const uint64_t path_bytes = (uint64_t)stack_levels * 3ull * blk * 4ull;
     // the 256-thread MFMA variant keeps the attenuation stack in HBM: its LDS goes to the A fragments, and 3 resident
