@@ -62,6 +62,13 @@ struct DCamera {  // camera.rs:8-19
     float time0, time1, lens_radius;
 };
 
+// Frame parameters the main loop needs in vector registers are staged in LDS once per workgroup (one ds_read_b128 per
+// group where they are used). Left as kernel arguments they are ~45 SGPRs that the compiler keeps live across the whole
+// loop and spills into VGPR lanes (v_readlane / v_writelane around every use).
+//   [0] clip_min.xyz, cull_u0   [1] clip_max.xyz, cull_inv_cell   [2] c0.xyz, rs2   [3] m0, gamma, inv_nx, inv_ny
+//   [4..9] DCamera (24 floats, camera.rs:8-19 order)   [10] inv_ns, mix_prev, mix_new, -
+constexpr uint32_t kLdsParamBytes = 11u * 16u;
+
 constexpr int kCullCells = 256;   // resolution of the tile-culling lookup along the sort axis
 
 struct KArgs {
@@ -353,10 +360,11 @@ __device__ __forceinline__ half8 shfl_xor32(half8 v) {
     return r.h;
 }
 
-__device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d, float a, bool active, int lane) {
+__device__ __forceinline__ RayFeat make_ray_features(const float4 *P, f3 o, f3 d, float a, bool active, int lane) {
+    const float4 pc = P[2], pm = P[3];   // c0.xyz, rs2 | m0, gamma
     // origin relative to c0, moved along the ray to the point closest to c0 (any point of the line
     // is valid; rounding here only needs to be covered by the margin)
-    const f3 ot = mk3(o.x - A.c0[0], o.y - A.c0[1], o.z - A.c0[2]);
+    const f3 ot = mk3(o.x - pc.x, o.y - pc.y, o.z - pc.z);
     const float od0 = __builtin_fmaf(ot.z, d.z, __builtin_fmaf(ot.y, d.y, ot.x * d.x));
     const float s = active ? (-od0 / a) : 0.0f;
     const f3 op = mk3(__builtin_fmaf(s, d.x, ot.x), __builtin_fmaf(s, d.y, ot.y), __builtin_fmaf(s, d.z, ot.z));
@@ -371,7 +379,7 @@ __device__ __forceinline__ RayFeat make_ray_features(const KArgs &A, f3 o, f3 d,
     R[7] = __builtin_fmaf(a2, op.y, -od2 * d.y);
     R[8] = __builtin_fmaf(a2, op.z, -od2 * d.z);
     R[9] = -a;
-    const float margin = a * __builtin_fmaf(A.gamma, ot2 + A.rs2, A.m0);
+    const float margin = a * __builtin_fmaf(pm.y, ot2 + pc.w, pm.x);
     // a ray whose line passes farther than sqrt(oo) > Rs (+ margin) from c0 still gets the generic test
     // candidate <=> S.R > thr. The tile GEMM evaluates thr - S.R directly (sphere fragments hold -S, and
     // slots 30/31 hold 1 x thr_hi, 1 x thr_lo), so a candidate is simply a NEGATIVE accumulator.
@@ -566,34 +574,35 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // the extent of the clipped segment along the sort axis selects the tiles whose own extent overlaps it (two table
 // lookups on a grid of kCullCells cells). Approximate reciprocals are fine: every bound is padded far beyond their error, and a
 // NaN anywhere yields "no tile", which is what the reference's `discriminant > 0` does with such a ray as well.
-__device__ __forceinline__ uint32_t lane_tile_mask(const KArgs &A, const uint32_t *s_cull, f3 o, f3 d, bool active, float t_end) {
+__device__ __forceinline__ uint32_t lane_tile_mask(const KArgs &A, const float4 *P, const uint32_t *s_cull, f3 o, f3 d, bool active,
+                                                   float t_end) {
+    const float4 bmin = P[0], bmax = P[1];   // clip_min.xyz, cull_u0 | clip_max.xyz, cull_inv_cell
     float t0 = 0.0f, t1 = t_end * 1.00001f + 1.0e-5f;
     bool inside = active;
     const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    const float mn[3] = {bmin.x, bmin.y, bmin.z}, mx[3] = {bmax.x, bmax.y, bmax.z};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (__builtin_fabsf(dd[k]) > 1.0e-12f) {
-            const float inv = __builtin_amdgcn_rcpf(dd[k]);
-            const float ta = (A.clip_min[k] - oo[k]) * inv, tb = (A.clip_max[k] - oo[k]) * inv;
-            t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
-            t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
-        } else {
-            inside = inside && oo[k] >= A.clip_min[k] && oo[k] <= A.clip_max[k];
-        }
+    for (int k = 0; k < 3; ++k) {   // branch-free slabs: an axis the ray (nearly) does not move along only asks "inside?"
+        const bool flat = !(__builtin_fabsf(dd[k]) > 1.0e-12f);
+        const float inv = __builtin_amdgcn_rcpf(flat ? 1.0f : dd[k]);
+        const float ta = (mn[k] - oo[k]) * inv, tb = (mx[k] - oo[k]) * inv;
+        t0 = __builtin_fmaxf(t0, flat ? 0.0f : __builtin_fminf(ta, tb));
+        t1 = __builtin_fminf(t1, flat ? kMaxT : __builtin_fmaxf(ta, tb));
+        inside = inside && (!flat || (oo[k] >= mn[k] && oo[k] <= mx[k]));
     }
     const float slack = 1.0e-3f * (1.0f + t1);     // relative to the distance travelled: covers rcp and f32 rounding
     t0 = t0 - slack, t1 = t1 + slack;
     const float ou = oo[A.cull_axis == 0u ? 0 : (A.cull_axis == 1u ? 1 : 2)], du = dd[A.cull_axis == 0u ? 0 : (A.cull_axis == 1u ? 1 : 2)];
     const float ua = ou + t0 * du, ub = ou + t1 * du;
     const float lo = __builtin_fminf(ua, ub) - 1.0e-3f, hi = __builtin_fmaxf(ua, ub) + 1.0e-3f;
-    if (!(inside && t0 <= t1 && lo <= hi)) return A.cull_always;
-    const float cl = __builtin_fminf(__builtin_fmaxf((lo - A.cull_u0) * A.cull_inv_cell, 0.0f), (float)(kCullCells - 1));
-    const float ch = __builtin_fminf(__builtin_fmaxf((hi - A.cull_u0) * A.cull_inv_cell, 0.0f), (float)(kCullCells - 1));
-    return (s_cull[(int)cl] & s_cull[kCullCells + (int)ch]) | A.cull_always;
+    const float cl = __builtin_fminf(__builtin_fmaxf((lo - bmin.w) * bmax.w, 0.0f), (float)(kCullCells - 1));
+    const float ch = __builtin_fminf(__builtin_fmaxf((hi - bmin.w) * bmax.w, 0.0f), (float)(kCullCells - 1));
+    const uint32_t tiles = s_cull[(int)cl] & s_cull[kCullCells + (int)ch];
+    return ((inside && t0 <= t1 && lo <= hi) ? tiles : 0u) | A.cull_always;
 }
 
 template <bool VERIFY, bool MOVING, bool GATED, int BLK>
-__device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *sph, const uint4 *s_afrag,
+__device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *P, const float4 *sph, const uint4 *s_afrag,
                                                    const uint16_t *s_tile_sphere, const uint32_t *s_cull, uint16_t *queue,
                                                    uint32_t *w_pairs, unsigned long long *w_keys,
                                                    f3 o, f3 d, float a, bool active, float time, float &t_out,
@@ -606,7 +615,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     (void)sec;
 #define PT_SUB(i) do { } while (0)
 #endif
-    const RayFeat rf = make_ray_features(A, o, d, a, active, lane);
+    const RayFeat rf = make_ray_features(P, o, d, a, active, lane);
     PT_SUB(5);
     const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // Candidates of MY ray, one 32-bit mask per tile that has any: bits 0..15 come from my own accumulators (my
@@ -729,7 +738,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
     uint32_t mine = rem;   // tiles THIS lane's ray can find its winner in; the wave runs the union
     if (!VERIFY && A.cull_axis < 3u) {
-        mine = lane_tile_mask(A, s_cull, o, d, active, best);
+        mine = lane_tile_mask(A, P, s_cull, o, d, active, best);
         rem = wave_or(mine);
 #ifdef PT_CULLSTATS
         // development aid: debug[24] wave-iterations, [25] tiles run, [26] active lanes, [27] tiles the lanes asked for,
@@ -836,7 +845,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                 // audit of the tile culling (which verify mode itself does not apply): the tile holding the brute-force
                 // WINNER must be among the tiles this lane would have asked for; a culled winner counts as a miss
                 if (A.cull_axis < 3u && vidx >= 0) {
-                    const uint32_t mine = lane_tile_mask(A, s_cull, o, d, active, best);   // `best`: the large spheres only so far
+                    const uint32_t mine = lane_tile_mask(A, P, s_cull, o, d, active, best);   // `best`: the large spheres only so far
                     bool is_large = false;
                     for (uint32_t j = 0; j < A.n_large; ++j) is_large = is_large || ((int)A.large[j] == vidx);
                     uint32_t slot = 0;
@@ -1024,6 +1033,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
     uint32_t *s_cull = reinterpret_cast<uint32_t *>(p);   // MFMA: tile-culling tables, 2 x kCullCells words
     p += MFMA ? 8u * kCullCells : 0u;
 
+    const float4 *s_par = reinterpret_cast<const float4 *>(p);   // frame parameters (kLdsParamBytes)
+    p += kLdsParamBytes;
     float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][BLK] attenuation stack
 
     const int tid = threadIdx.x;
@@ -1042,6 +1053,20 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
         const uint4 *src = reinterpret_cast<const uint4 *>(A.wnodes);
         uint4 *dst = reinterpret_cast<uint4 *>(s_nodes);
         for (uint32_t k = tid; k < A.n_nodes * 4u; k += BLK) dst[k] = src[k];
+    }
+    if (tid == 0) {
+        float4 *w = const_cast<float4 *>(s_par);
+        w[0] = make_float4(A.clip_min[0], A.clip_min[1], A.clip_min[2], A.cull_u0);
+        w[1] = make_float4(A.clip_max[0], A.clip_max[1], A.clip_max[2], A.cull_inv_cell);
+        w[2] = make_float4(A.c0[0], A.c0[1], A.c0[2], A.rs2);
+        w[3] = make_float4(A.m0, A.gamma, A.inv_nx, A.inv_ny);
+        w[4] = make_float4(A.cam.origin.x, A.cam.origin.y, A.cam.origin.z, A.cam.lower_left_corner.x);
+        w[5] = make_float4(A.cam.lower_left_corner.y, A.cam.lower_left_corner.z, A.cam.horizontal.x, A.cam.horizontal.y);
+        w[6] = make_float4(A.cam.horizontal.z, A.cam.vertical.x, A.cam.vertical.y, A.cam.vertical.z);
+        w[7] = make_float4(A.cam.u.x, A.cam.u.y, A.cam.u.z, A.cam.v.x);
+        w[8] = make_float4(A.cam.v.y, A.cam.v.z, A.cam.w.x, A.cam.w.y);
+        w[9] = make_float4(A.cam.w.z, A.cam.time0, A.cam.time1, A.cam.lens_radius);
+        w[10] = make_float4(A.inv_ns, A.mix_prev, A.mix_new, 0.0f);
     }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += BLK) s_pvec[k] = A.perlin_vec[k];
@@ -1080,12 +1105,13 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
             if (finished) {
                 // scene.rs:113-116
                 finished = false;
-                col = scale3(col, A.inv_ns);
+                const float4 pf = s_par[10];   // inv_ns, mix_prev, mix_new
+                col = scale3(col, pf.x);
                 if (!PILOT) {
                     float *out = A.rgb + boff;
-                    out[0] = out[0] * A.mix_prev + col.x * A.mix_new;
-                    out[1] = out[1] * A.mix_prev + col.y * A.mix_new;
-                    out[2] = out[2] * A.mix_prev + col.z * A.mix_new;
+                    out[0] = out[0] * pf.y + col.x * pf.z;
+                    out[1] = out[1] * pf.y + col.y * pf.z;
+                    out[2] = out[2] * pf.y + col.z * pf.z;
                 }
                 if (PILOT) atomicAdd(&A.tile_cost[lane_tile], pix_rays);
             }
@@ -1132,19 +1158,20 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
 
         // ---- camera.rs:56-68 + scene.rs:107-108: start the next sample
         if (have && need_cam) {
-            const float u = ((float)px + rng_f32(rng)) * A.inv_nx;
-            const float v = ((float)py + rng_f32(rng)) * A.inv_ny;
+            const float4 c0 = s_par[4], c1 = s_par[5], c2 = s_par[6], c3 = s_par[7], c4 = s_par[8], c5 = s_par[9], pn2 = s_par[3];
+            const f3 cam_origin = mk3(c0.x, c0.y, c0.z), cam_llc = mk3(c0.w, c1.x, c1.y), cam_horizontal = mk3(c1.z, c1.w, c2.x),
+                     cam_vertical = mk3(c2.y, c2.z, c2.w), cam_u = mk3(c3.x, c3.y, c3.z), cam_v = mk3(c3.w, c4.x, c4.y);
+            const float cam_time0 = c5.y, cam_time1 = c5.z, cam_lens_radius = c5.w;
+            const float u = ((float)px + rng_f32(rng)) * pn2.z;
+            const float v = ((float)py + rng_f32(rng)) * pn2.w;
             float dx, dy;
             random_in_unit_disk(rng, dx, dy);
-            const float rdx = A.cam.lens_radius * dx, rdy = A.cam.lens_radius * dy;
-            const f3 offset = add3(scale3(A.cam.u, rdx), scale3(A.cam.v, rdy));
+            const float rdx = cam_lens_radius * dx, rdy = cam_lens_radius * dy;
+            const f3 offset = add3(scale3(cam_u, rdx), scale3(cam_v, rdy));
             const float tdraw = rng_f32(rng);  // camera.rs:59 time draw (plain spheres ignore ray.time)
-            if (MOVING) rtime = A.cam.time0 + tdraw * (A.cam.time1 - A.cam.time0);
-            const f3 dir = sub3(sub3(add3(add3(A.cam.lower_left_corner, scale3(A.cam.horizontal, u)),
-                                          scale3(A.cam.vertical, v)),
-                                     A.cam.origin),
-                                offset);
-            o = add3(A.cam.origin, offset);
+            if (MOVING) rtime = cam_time0 + tdraw * (cam_time1 - cam_time0);
+            const f3 dir = sub3(sub3(add3(add3(cam_llc, scale3(cam_horizontal, u)), scale3(cam_vertical, v)), cam_origin), offset);
+            o = add3(cam_origin, offset);
             d = normalize3(dir);
             depth = 0;
             need_cam = false;
@@ -1170,7 +1197,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
             idx = trav.idx;
             t_hit = trav.best;
         } else if (MFMA)
-            idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_cull,
+            idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, s_par, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_cull,
                                                       s_queue, w_pairs, w_keys, ro, rd, a, have, rtime, t_hit
 #ifdef PT_SECTIONS
                                                       , sec_t

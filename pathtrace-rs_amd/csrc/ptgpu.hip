@@ -1236,7 +1236,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.gamma = s->gamma;
     A.verify = ((s->variant & 8u) ? 1u : 0u) | ((s->variant & 16u) ? 2u : 0u);  // bit 16: timing experiment, no stack
     A.debug = s->d_debug;
-    uint32_t lds = sph_bytes;
+    uint32_t lds = sph_bytes + kLdsParamBytes;
     if (s->has_noise) lds += 4096u + 3072u;
     A.n_nodes = s->n_nodes;
     A.bvh_stack_entries = s->bvh_depth + 2u;
