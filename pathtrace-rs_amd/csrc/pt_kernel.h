@@ -66,8 +66,8 @@ struct DCamera {  // camera.rs:8-19
 // group where they are used). Left as kernel arguments they are ~45 SGPRs that the compiler keeps live across the whole
 // loop and spills into VGPR lanes (v_readlane / v_writelane around every use).
 //   [0] clip_min.xyz, cull_u0   [1] clip_max.xyz, cull_inv_cell   [2] c0.xyz, rs2   [3] m0, gamma, inv_nx, inv_ny
-//   [4..9] DCamera (24 floats, camera.rs:8-19 order)   [10] inv_ns, mix_prev, mix_new, -
-constexpr uint32_t kLdsParamBytes = 11u * 16u;
+//   [4..9] DCamera (24 floats, camera.rs:8-19 order)   [10] inv_ns, mix_prev, mix_new, -   [11] sky.xyz, has_sky
+constexpr uint32_t kLdsParamBytes = 12u * 16u;
 
 constexpr int kCullCells = 256;   // resolution of the tile-culling lookup along the sort axis
 
@@ -1067,6 +1067,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
         w[8] = make_float4(A.cam.v.y, A.cam.v.z, A.cam.w.x, A.cam.w.y);
         w[9] = make_float4(A.cam.w.z, A.cam.time0, A.cam.time1, A.cam.lens_radius);
         w[10] = make_float4(A.inv_ns, A.mix_prev, A.mix_new, 0.0f);
+        w[11] = make_float4(A.sky.x, A.sky.y, A.sky.z, A.has_sky ? 1.0f : 0.0f);
     }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += BLK) s_pvec[k] = A.perlin_vec[k];
@@ -1075,8 +1076,17 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
     __syncthreads();
 
     PerlinLds pn{s_pvec, s_perm};
-    float *path = A.stack_in_lds ? (s_path + tid)
-                                 : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * BLK + tid);
+    // attenuation stack of this lane: the 768-thread kernels always have it in LDS (plain ds_read / ds_write); the
+    // others choose at launch, which makes `path` a generic pointer (flat loads and stores)
+    float *path = (BLK != kBlock || A.stack_in_lds) ? (s_path + tid)
+                                                    : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * BLK + tid);
+    auto path_ld = [&](uint32_t slot) -> float { return BLK != kBlock ? s_path[slot * BLK + tid] : path[slot * BLK]; };
+    auto path_st = [&](uint32_t slot, float v) {
+        if (BLK != kBlock)
+            s_path[slot * BLK + tid] = v;
+        else
+            path[slot * BLK] = v;
+    };
 
 #ifdef PT_SECTIONS
     // development aid (-DPT_SECTIONS): per-wave cycle counts of the main loop's sections (s_memtime deltas at
@@ -1216,8 +1226,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
             f3 V;
             if (idx < 0) {
                 // scene.rs:40-47
-                if (A.has_sky) {
-                    V = A.sky;
+                const float4 psky = s_par[11];
+                if (psky.w != 0.0f) {
+                    V = mk3(psky.x, psky.y, psky.z);
                 } else {
                     const float t = 0.5f * (d.y + 1.0f);
                     const float w1 = 1.0f - t;
@@ -1294,9 +1305,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
                     if (depth == 0u) {
                         att0 = att;
                     } else {
-                        path[((depth - 1u) * 3 + 0) * BLK] = att.x;
-                        path[((depth - 1u) * 3 + 1) * BLK] = att.y;
-                        path[((depth - 1u) * 3 + 2) * BLK] = att.z;
+                        path_st((depth - 1u) * 3u + 0u, att.x);
+                        path_st((depth - 1u) * 3u + 1u, att.y);
+                        path_st((depth - 1u) * 3u + 2u, att.z);
                     }
                     depth += 1;
                     o = point;
@@ -1310,9 +1321,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
             if (terminal) {
                 // scene.rs:62-64 unwound: emitted(=0) + attenuation * deeper, innermost first
                 for (int k = (int)depth - 1; k >= 1; --k) {
-                    V.x = 0.0f + path[((k - 1) * 3 + 0) * BLK] * V.x;
-                    V.y = 0.0f + path[((k - 1) * 3 + 1) * BLK] * V.y;
-                    V.z = 0.0f + path[((k - 1) * 3 + 2) * BLK] * V.z;
+                    V.x = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 0u) * V.x;
+                    V.y = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 1u) * V.y;
+                    V.z = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 2u) * V.z;
                 }
                 if (depth > 0u) V = mk3(0.0f + att0.x * V.x, 0.0f + att0.y * V.y, 0.0f + att0.z * V.z);
                 col = add3(col, V);  // scene.rs:110
