@@ -1258,13 +1258,16 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     const uint64_t path_bytes = (uint64_t)stack_levels * 3ull * blk * 4ull;
     // the 256-thread MFMA variant keeps the attenuation stack in HBM: its LDS goes to the A fragments, and 3 resident
     // workgroups per CU beat 1 with an LDS stack (measured 7.5 vs 3.0 Grays/s)
-    A.stack_in_lds = (blk == kWideBlock) || (!bvh && !mfma && (s->variant & 2u) == 0 && lds + path_bytes <= kLdsPerBlockMax) ? 1u : 0u;
+    // the tree kernels hold 3 workgroups per CU (144 VGPRs): the stack goes to LDS whenever three of them still fit
+    const bool tree_lds_stack = bvh && (s->variant & 2u) == 0 && 3ull * (lds + path_bytes) <= kLdsBudget;
+    A.stack_in_lds = (blk == kWideBlock) || tree_lds_stack ||
+                     (!bvh && !mfma && (s->variant & 2u) == 0 && lds + path_bytes <= kLdsPerBlockMax) ? 1u : 0u;
     if (A.stack_in_lds) lds += (uint32_t)path_bytes;
     A.lds_sphere_bytes = sph_bytes;
 
     // ---- persistent grid: CUs x resident blocks --------------------------------
     uint32_t bpc = s->blocks_per_cu;
-    if (bpc == 0) bpc = (blk == kWideBlock) ? 1u : (bvh ? 4u : 3u);
+    if (bpc == 0) bpc = (blk == kWideBlock) ? 1u : ((bvh && !tree_lds_stack) ? 4u : 3u);
     const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
     if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
     if (bpc > 8u) bpc = 8u;
