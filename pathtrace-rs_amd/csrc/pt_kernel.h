@@ -756,7 +756,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
 #endif
     }
     union Frag { uint4 u; half8 h; };
-    Frag a0, a1, n0, n1;
+    Frag a0, a1;
     {
         const uint32_t T0 = rem ? (uint32_t)__builtin_ctz(rem) : 0u;
         a0.u = s_afrag[(T0 * 2 + 0) * 64 + lane];
@@ -765,15 +765,15 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     while (rem != 0u) {
         const uint32_t T = (uint32_t)__builtin_ctz(rem);
         rem &= rem - 1u;
-        const uint32_t Tn = rem ? (uint32_t)__builtin_ctz(rem) : T;   // prefetch the next tile's fragments
-        n0.u = s_afrag[(Tn * 2 + 0) * 64 + lane];
-        n1.u = s_afrag[(Tn * 2 + 1) * 64 + lane];
+        const uint32_t Tn = rem ? (uint32_t)__builtin_ctz(rem) : T;   // the next tile's fragments are fetched under this one
         float16v acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, rf.b0[0], zero, 0, 0, 0);
         float16v acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, rf.b1[0], zero, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // each fragment is reloaded in place right after its last use (no register copies)
+        a0.u = s_afrag[(Tn * 2 + 0) * 64 + lane];
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, rf.b0[1], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.h, rf.b1[1], acc1, 0, 0, 0);
-        a0 = n0;
-        a1 = n1;
+        __builtin_amdgcn_sched_barrier(0);
+        a1.u = s_afrag[(Tn * 2 + 1) * 64 + lane];
         // sign bits of the 2 x 16 accumulators -> 16-bit masks (v_alignbit shifts a sign in): register r ends up
         // at bit 15 - r
         uint32_t m0 = 0, m1 = 0;
