@@ -67,7 +67,8 @@ struct DCamera {  // camera.rs:8-19
 // loop and spills into VGPR lanes (v_readlane / v_writelane around every use).
 //   [0] clip_min.xyz, cull_u0   [1] clip_max.xyz, cull_inv_cell   [2] c0.xyz, rs2   [3] m0, gamma, inv_nx, inv_ny
 //   [4..9] DCamera (24 floats, camera.rs:8-19 order)   [10] inv_ns, mix_prev, mix_new, -   [11] sky.xyz, has_sky
-constexpr uint32_t kLdsParamBytes = 12u * 16u;
+//   [12] as u32 bits: cull_axis, cull_always, max_depth, samples
+constexpr uint32_t kLdsParamBytes = 13u * 16u;
 
 constexpr int kCullCells = 256;   // resolution of the tile-culling lookup along the sort axis
 
@@ -574,8 +575,8 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // the extent of the clipped segment along the sort axis selects the tiles whose own extent overlaps it (two table
 // lookups on a grid of kCullCells cells). Approximate reciprocals are fine: every bound is padded far beyond their error, and a
 // NaN anywhere yields "no tile", which is what the reference's `discriminant > 0` does with such a ray as well.
-__device__ __forceinline__ uint32_t lane_tile_mask(const KArgs &A, const float4 *P, const uint32_t *s_cull, f3 o, f3 d, bool active,
-                                                   float t_end) {
+__device__ __forceinline__ uint32_t lane_tile_mask(const float4 *P, const uint32_t *s_cull, f3 o, f3 d, bool active, float t_end,
+                                                   uint32_t cull_axis, uint32_t cull_always) {
     const float4 bmin = P[0], bmax = P[1];   // clip_min.xyz, cull_u0 | clip_max.xyz, cull_inv_cell
     float t0 = 0.0f, t1 = t_end * 1.00001f + 1.0e-5f;
     bool inside = active;
@@ -592,13 +593,13 @@ __device__ __forceinline__ uint32_t lane_tile_mask(const KArgs &A, const float4 
     }
     const float slack = 1.0e-3f * (1.0f + t1);     // relative to the distance travelled: covers rcp and f32 rounding
     t0 = t0 - slack, t1 = t1 + slack;
-    const float ou = oo[A.cull_axis == 0u ? 0 : (A.cull_axis == 1u ? 1 : 2)], du = dd[A.cull_axis == 0u ? 0 : (A.cull_axis == 1u ? 1 : 2)];
+    const float ou = cull_axis == 0u ? oo[0] : (cull_axis == 1u ? oo[1] : oo[2]), du = cull_axis == 0u ? dd[0] : (cull_axis == 1u ? dd[1] : dd[2]);
     const float ua = ou + t0 * du, ub = ou + t1 * du;
     const float lo = __builtin_fminf(ua, ub) - 1.0e-3f, hi = __builtin_fmaxf(ua, ub) + 1.0e-3f;
     const float cl = __builtin_fminf(__builtin_fmaxf((lo - bmin.w) * bmax.w, 0.0f), (float)(kCullCells - 1));
     const float ch = __builtin_fminf(__builtin_fmaxf((hi - bmin.w) * bmax.w, 0.0f), (float)(kCullCells - 1));
     const uint32_t tiles = s_cull[(int)cl] & s_cull[kCullCells + (int)ch];
-    return ((inside && t0 <= t1 && lo <= hi) ? tiles : 0u) | A.cull_always;
+    return ((inside && t0 <= t1 && lo <= hi) ? tiles : 0u) | cull_always;
 }
 
 template <bool VERIFY, bool MOVING, bool GATED, int BLK>
@@ -737,8 +738,10 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     // wave-uniform set of tiles to run: the union of the lanes' tile masks (verify mode audits every tile)
     uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
     uint32_t mine = rem;   // tiles THIS lane's ray can find its winner in; the wave runs the union
-    if (!VERIFY && A.cull_axis < 3u) {
-        mine = lane_tile_mask(A, P, s_cull, o, d, active, best);
+    const float4 pcull = P[12];
+    const uint32_t cull_axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(pcull.x)), cull_always = __float_as_uint(pcull.y);
+    if (!VERIFY && cull_axis < 3u) {
+        mine = lane_tile_mask(P, s_cull, o, d, active, best, cull_axis, cull_always);
         rem = wave_or(mine);
 #ifdef PT_CULLSTATS
         // development aid: debug[24] wave-iterations, [25] tiles run, [26] active lanes, [27] tiles the lanes asked for,
@@ -844,8 +847,8 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                 if (overflow) atomicAdd(&A.debug[2], 1ull);
                 // audit of the tile culling (which verify mode itself does not apply): the tile holding the brute-force
                 // WINNER must be among the tiles this lane would have asked for; a culled winner counts as a miss
-                if (A.cull_axis < 3u && vidx >= 0) {
-                    const uint32_t mine = lane_tile_mask(A, P, s_cull, o, d, active, best);   // `best`: the large spheres only so far
+                if (cull_axis < 3u && vidx >= 0) {
+                    const uint32_t mine = lane_tile_mask(P, s_cull, o, d, active, best, cull_axis, cull_always);   // `best`: the large spheres only so far
                     bool is_large = false;
                     for (uint32_t j = 0; j < A.n_large; ++j) is_large = is_large || ((int)A.large[j] == vidx);
                     uint32_t slot = 0;
@@ -1068,6 +1071,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
         w[9] = make_float4(A.cam.w.z, A.cam.time0, A.cam.time1, A.cam.lens_radius);
         w[10] = make_float4(A.inv_ns, A.mix_prev, A.mix_new, 0.0f);
         w[11] = make_float4(A.sky.x, A.sky.y, A.sky.z, A.has_sky ? 1.0f : 0.0f);
+        w[12] = make_float4(__uint_as_float(A.cull_axis), __uint_as_float(A.cull_always), __uint_as_float(A.max_depth), __uint_as_float(A.samples));
     }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += BLK) s_pvec[k] = A.perlin_vec[k];
@@ -1255,7 +1259,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
                 if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = surface_colour();
                 bool scattered = false;
                 f3 att = mk3(1.f, 1.f, 1.f), nd = d;
-                if (depth < A.max_depth) {
+                if (depth < __float_as_uint(s_par[12].z)) {   // max_depth
                     // every scatter ends in `.normalize()` of some vector (material.rs:63,84,112,119): the branches
                     // only produce that vector, the normalisation is issued once for the whole wave
                     f3 raw = d;
@@ -1329,7 +1333,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
                 col = add3(col, V);  // scene.rs:110
                 sample += 1;
                 need_cam = true;
-                if (sample == A.samples) {
+                if (sample == __float_as_uint(s_par[12].w)) {   // samples
                     // the pixel is written when the lane fetches its next one (the refill below is batched over
                     // several lanes, and so is this read-modify-write of the frame buffer)
                     have = false;
