@@ -9,7 +9,9 @@
 // Closest hit, list world (hitable_list.rs:40-56): phase 1 finds a superset of the spheres whose reference
 // discriminant is positive -- by default with an f16 MFMA GEMM over lifted ray/sphere features (64 rays x
 // 32 spheres x K=32 per tile, "MFMA prefilter" below), alternatively with a wave-uniform exact VALU scan --
-// and phase 2 runs the survivors through the reference's exact arithmetic.
+// and phase 2 runs the survivors through the reference's exact arithmetic. The MFMA kernels only run the sphere
+// tiles some lane's clipped ray segment can reach ("tile culling") and balance phase 2 over the wave (one
+// (ray, sphere) pair per lane and round, reduced per ray with a 64-bit LDS atomic min).
 // Closest hit, BVH world (bvh.rs:37-62): per-lane resumable traversal of an internal tree, with the reference's
 // accept/reject decision reproduced by a slab test on each sphere's parent AABB in the caller's tree.
 // DESIGN.md section 4 has the derivations and the error budget.
