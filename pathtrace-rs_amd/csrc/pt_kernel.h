@@ -226,7 +226,7 @@ __device__ __forceinline__ f3 image_value(const DImages &im, int32_t index, floa
 }
 
 // texture.rs:74-91 (Constant / Checker / Noise / Image; Checker may nest). (u, v, images) only matter for Image.
-__device__ __noinline__ f3 texture_value(const DTex *texs, const PerlinLds &pn, int32_t tex, f3 p, float u = 0.0f, float v = 0.0f,
+__device__ __forceinline__ f3 texture_value(const DTex *texs, const PerlinLds &pn, int32_t tex, f3 p, float u = 0.0f, float v = 0.0f,
                                          DImages images = DImages{nullptr, nullptr}) {
     DTex t = texs[tex];
     while (t.kind == PT_TEX_CHECKER) {
