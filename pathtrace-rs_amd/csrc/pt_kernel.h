@@ -136,7 +136,7 @@ struct KArgs {
     const uint32_t *tile_order;  // optional permutation of the 8x8 work tiles (expensive tiles first)
     uint32_t *tile_cost;         // optional: rays spent per work tile (accumulated when a pixel completes)
     float *gstack;  // global path-stack fallback when max_depth*3*kBlock*4 exceeds the LDS budget
-    uint32_t stack_in_lds;
+    uint32_t stack_in_lds;       // 256-thread kernels: number of attenuation-stack slots (3 per level) kept in LDS; the rest in gstack
     uint32_t lds_sphere_bytes;  // offsets of the dynamic LDS carve
 };
 
@@ -146,7 +146,7 @@ struct PerlinLds {
     const uint32_t *perm;    // 768
 };
 
-__device__ __noinline__ float perlin_noise(const PerlinLds &pn, f3 p) {
+__device__ __forceinline__ float perlin_noise(const PerlinLds &pn, f3 p) {
     const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
     const uint32_t i = floor_as_usize_low8(fx), j = floor_as_usize_low8(fy), k = floor_as_usize_low8(fz);
@@ -1082,16 +1082,19 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
     __syncthreads();
 
     PerlinLds pn{s_pvec, s_perm};
-    // attenuation stack of this lane: the 768-thread kernels always have it in LDS (plain ds_read / ds_write); the
-    // others choose at launch, which makes `path` a generic pointer (flat loads and stores)
-    float *path = (BLK != kBlock || A.stack_in_lds) ? (s_path + tid)
-                                                    : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * BLK + tid);
-    auto path_ld = [&](uint32_t slot) -> float { return BLK != kBlock ? s_path[slot * BLK + tid] : path[slot * BLK]; };
+    // attenuation stack of this lane: the 768-thread kernels always have it in LDS; the 256-thread ones keep the first
+    // A.stack_in_lds slots (3 per level) in LDS and deeper, rarely reached levels in HBM/L2 (what fits next to four
+    // resident workgroups of a tree kernel)
+    float *gpath = A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * BLK + tid;
+    auto path_ld = [&](uint32_t slot) -> float {
+        if (BLK != kBlock || slot < A.stack_in_lds) return s_path[slot * BLK + tid];
+        return gpath[slot * BLK];
+    };
     auto path_st = [&](uint32_t slot, float v) {
-        if (BLK != kBlock)
+        if (BLK != kBlock || slot < A.stack_in_lds)
             s_path[slot * BLK + tid] = v;
         else
-            path[slot * BLK] = v;
+            gpath[slot * BLK] = v;
     };
 
 #ifdef PT_SECTIONS

@@ -1258,16 +1258,25 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     const uint64_t path_bytes = (uint64_t)stack_levels * 3ull * blk * 4ull;
     // the 256-thread MFMA variant keeps the attenuation stack in HBM: its LDS goes to the A fragments, and 3 resident
     // workgroups per CU beat 1 with an LDS stack (measured 7.5 vs 3.0 Grays/s)
-    // the tree kernels hold 3 workgroups per CU (144 VGPRs): the stack goes to LDS whenever three of them still fit
-    const bool tree_lds_stack = bvh && (s->variant & 2u) == 0 && 3ull * (lds + path_bytes) <= kLdsBudget;
-    A.stack_in_lds = (blk == kWideBlock) || tree_lds_stack ||
-                     (!bvh && !mfma && (s->variant & 2u) == 0 && lds + path_bytes <= kLdsPerBlockMax) ? 1u : 0u;
-    if (A.stack_in_lds) lds += (uint32_t)path_bytes;
+    // Stack slots (3 per level) kept in LDS. 768-thread kernels: all of them (that is what made them fit). Tree kernels
+    // run four workgroups per CU (123 VGPRs): as many levels as fit next to four of them, deeper ones in HBM/L2.
+    // Exact-scan list kernels: all or nothing.
+    uint32_t lds_levels = 0;
+    if (blk == kWideBlock) {
+        lds_levels = stack_levels;
+    } else if (bvh && (s->variant & 2u) == 0) {
+        const uint32_t per_block = kLdsBudget / 4u;
+        if (per_block > lds) lds_levels = std::min<uint32_t>(stack_levels, (per_block - lds) / (3u * blk * 4u));
+    } else if (!bvh && !mfma && (s->variant & 2u) == 0 && lds + path_bytes <= kLdsPerBlockMax) {
+        lds_levels = stack_levels;
+    }
+    A.stack_in_lds = lds_levels * 3u;
+    lds += lds_levels * 3u * blk * 4u;
     A.lds_sphere_bytes = sph_bytes;
 
     // ---- persistent grid: CUs x resident blocks --------------------------------
     uint32_t bpc = s->blocks_per_cu;
-    if (bpc == 0) bpc = (blk == kWideBlock) ? 1u : ((bvh && !tree_lds_stack) ? 4u : 3u);
+    if (bpc == 0) bpc = (blk == kWideBlock) ? 1u : (bvh ? 4u : 3u);
     const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
     if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
     if (bpc > 8u) bpc = 8u;
@@ -1276,7 +1285,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
 
-    if (!A.stack_in_lds) {
+    if (lds_levels < stack_levels) {
         const size_t need_floats = (size_t)grid * params->max_depth * 3ull * blk;
         if (need_floats > s->d_gstack_floats) {
             (void)hipFree(s->d_gstack);
