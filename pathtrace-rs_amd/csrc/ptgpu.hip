@@ -1240,8 +1240,12 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (s->has_noise) lds += 4096u + 3072u;
     A.n_nodes = s->n_nodes;
     A.bvh_stack_entries = s->bvh_depth + 2u;
-    A.nodes_in_lds = (bvh && s->n_nodes * 64u <= 32u * 1024u && (s->variant & 1u) == 0) ? 1u : 0u;
-    if (bvh) lds += A.bvh_stack_entries * kBlock * 4u + (A.nodes_in_lds ? s->n_nodes * 64u : 0u);
+    // tree nodes go to LDS only while FOUR workgroups still fit on the CU (with two levels of attenuation stack each):
+    // the fourth wave per SIMD is worth more than LDS-resident nodes (random_spheres -B on the tree kernel: 7.4 vs 6.3
+    // Grays/s), and the nodes stay L2-resident anyway
+    if (bvh) lds += A.bvh_stack_entries * kBlock * 4u;
+    A.nodes_in_lds = (bvh && (s->variant & 1u) == 0 && lds + s->n_nodes * 64u + 2u * 3u * kBlock * 4u <= kLdsBudget / 4u) ? 1u : 0u;
+    if (A.nodes_in_lds) lds += s->n_nodes * 64u;
     // Workgroup size. The MFMA list kernels run ONE 768-thread workgroup per CU when everything fits: the sphere
     // fragments (identical in every workgroup) are staged once per CU, and the LDS that frees holds the per-lane
     // attenuation stacks (levels 1..max_depth-1; level 0 lives in registers), which otherwise stream through L2 to HBM
