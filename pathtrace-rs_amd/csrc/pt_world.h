@@ -260,8 +260,11 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
 // HIT_LDS: the hitable records and transforms are staged in LDS (worlds up to 16 KB: every preset); the list scan
 // then reads them at LDS latency instead of waiting on the scalar cache for each entry (58 % of the wave-cycles of
 // cornell_smoke were such waits), and BVH mode gathers them per lane from LDS instead of L2.
-template <bool BVH, bool HIT_LDS>
-__global__ __launch_bounds__(kBlock, 2) void pt_world_kernel(const WArgs A) {
+// OCC: waves per SIMD the kernel is compiled for. 4 (128 VGPRs, a few spills) pays for worlds without noise textures
+// whose LDS lets four workgroups share a CU (cornell +7 %, cornell_smoke +11 %); with Perlin noise inlined the spills
+// cost more than the fourth wave brings (simple_light -6 %), so those keep 2 (the compiler then uses ~160 VGPRs).
+template <bool BVH, bool HIT_LDS, int OCC = 2>
+__global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *p = smem;
     float4 *s_pvec = reinterpret_cast<float4 *>(p);

@@ -1154,7 +1154,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
         W.stack_in_lds = (lds + path_bytes <= 60u * 1024u) ? 1u : 0u;
         if (W.stack_in_lds) lds += (uint32_t)path_bytes;
-        uint32_t bpc = s->blocks_per_cu ? s->blocks_per_cu : 3u;
+        const bool occ4 = !s->has_noise && s->blocks_per_cu == 0 && 4u * lds <= kLdsBudget;   // see pt_world_kernel's OCC
+        uint32_t bpc = s->blocks_per_cu ? s->blocks_per_cu : (occ4 ? 4u : 3u);
         const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
         if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
         if (bpc > 8u) bpc = 8u;
@@ -1172,8 +1173,13 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
             }
             W.gstack = s->d_gstack;
         }
-        void (*wk)(const WArgs) = ref_bvh ? (hit_lds ? pt_world_kernel<true, true> : pt_world_kernel<true, false>)
-                                          : (hit_lds ? pt_world_kernel<false, true> : pt_world_kernel<false, false>);
+        void (*wk)(const WArgs) = nullptr;
+        if (occ4)
+            wk = ref_bvh ? (hit_lds ? pt_world_kernel<true, true, 4> : pt_world_kernel<true, false, 4>)
+                         : (hit_lds ? pt_world_kernel<false, true, 4> : pt_world_kernel<false, false, 4>);
+        else
+            wk = ref_bvh ? (hit_lds ? pt_world_kernel<true, true> : pt_world_kernel<true, false>)
+                         : (hit_lds ? pt_world_kernel<false, true> : pt_world_kernel<false, false>);
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIP_TRY(hipEventRecord(s->ev_start, stream));
         hipLaunchKernelGGL(wk, dim3(grid), dim3(kBlock), lds, stream, W);
