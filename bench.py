@@ -2,29 +2,28 @@
 """bench.py -- Mrays/s of the path-tracing hot path (Scene::update) on N MI355X GPUs.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL.
-A "step" is one Scene::update pass (reference src/scene.rs:73-121) over one frame of
-synthetic (preset-generated) input, pixel buffer resident in HBM:
-  N = 1 : preset random_spheres 1200x800, 64 spp, depth 10, list world (BASELINE config 3,
-          the configuration the metric is quoted on)
-  N > 1 : two ways to use N GPUs, both measured, both inside the timed region end to end:
-          --mode frames (default, "weak"): the unit of work is one frame of that SAME configuration. Rank r
-              renders progressive frame frame_num = r (scene.rs:99-101 seeds depend on (x, y, frame) only) with no
-              data-path collective, ONE RCCL all_gather collects the N frames and the reference's blend
-              (scene.rs:113-116) is replayed in frame order: bit-identical to `-F N` on one GPU, N x 64 spp worth of
-              samples in the image. Per-GPU work is fixed as N grows.
-          --mode tiles ("strong"): ONE frame, rows interleaved across ranks (row y -> rank y % N), each rank
-              renders its rows, ONE all_gather of the float3 shards. Samples of a pixel are serial (one RNG stream
-              per pixel), so a 15 ms frame cannot strong-scale well; the default run reports this number too, as
-              `strong_scaling_tiles`, measured right after the timed region.
-          Both add an 8-byte all_reduce of the ray count (scene.rs:118-120).
+  N > 1 is launched by torch.distributed.run, one rank per GPU over RCCL; started WITHOUT a launcher
+  (`python bench.py --gpus 4`) it starts that launcher itself as a child process (never exec) and exits with its code:
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
+A "step" is one Scene::update pass (reference src/scene.rs:73-121) over one frame of synthetic (preset-generated)
+input, pixel buffer resident in HBM:
+  N = 1 : BASELINE config 3, the configuration the metric is quoted on: preset random_spheres 1200x800, 64 spp,
+          depth 10, list world.
+  N > 1 : BASELINE config 4: ONE random_spheres 1200x800 frame at 256 spp, split over the N GPUs by rows (row y ->
+          rank y % N, disjoint pixels as scene.rs:90-93), no collective while rendering, then ONE RCCL gather of the
+          float3 shards + an 8-byte all-reduce of the ray count (scene.rs:118-120) -- both issued by the C ABI
+          (pt_comm_gather_frame / pt_render_sharded in include/ptgpu.h; ncclAllGather + ncclAllReduce on xGMI) and
+          both inside the timed region. "scaling": "strong" (total work fixed as N grows).
+          --mode frames is the other data-parallel axis (rank r renders progressive frame r of the 64-spp frame;
+          bit-identical to `-F N`); the default run reports it as the extra `weak_scaling_frames`, never as `value`.
 Prints ONE JSON line on rank 0.
 """
 import argparse
-import ctypes
+import glob
 import importlib.util
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -81,6 +80,87 @@ def cpu_baseline(preset, W, H, S, depth, use_bvh, target_secs=15.0):
     }
 
 
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz, a wave64 VALU instruction issues over 2 cycles
+VALU_PEAK_TLANEOPS = 256 * 4 * 2.4e9 / 2 * 64 / 1e12      # 78.6 T lane-ops/s nominal
+VALU_PEAK_MEASURED = 67.0                                  # tools/valu_bench.hip on the GPU box (2.3 cycles / wave-instruction)
+HBM_PEAK_GBS = 8000.0
+N_SIMD = 1024
+
+
+def committed_counters(preset, W, H, S, use_bvh):
+    """rocprofv3 PMC counters of the frame kernel for this workload, per RAY, from the newest committed
+    profiles/r*_pmc_traffic.json whose bench line matches (tools/profile.sh + tools/profile_summary.py write them;
+    PMC passes cannot run inside bench.py). Returns (per-ray dict, per-launch dict, file name) or None."""
+    want = "preset %s " % preset
+    shape = " %dx%d %dspp " % (W, H, S)
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        try:
+            prof = json.load(open(f))
+            line = prof["bench_line_under_profiler"]
+            wl = line["config"]["workload"]
+            if line.get("n_gpus", 1) != 1 or want not in wl or shape not in wl or ((" BVH" in wl) != bool(use_bvh)):
+                continue
+            rays = float(line["config"]["rays_per_step"])
+            per_launch = dict(prof["pmc_per_launch"])
+            for k in ("hbm_bytes_per_launch", "hbm_read_bytes_corrected", "hbm_write_bytes"):
+                if k in prof:
+                    per_launch[k] = prof[k]
+            per_launch["kernel_avg_ms_rocprof"] = prof.get("kernel_avg_ms")
+            best = ({k: v / rays for k, v in per_launch.items() if isinstance(v, (int, float))}, per_launch, os.path.basename(f))
+            break
+        except Exception:
+            continue
+    return best
+
+
+def roofline_block(kernel_name, kms, rays_launch, n_hitables, use_bvh, counters):
+    """Counter-derived fractions of the resources the frame kernel uses. Nothing here is an "effective" figure:
+    SURVEY 8(d)'s scan-equivalent rate is kept apart under `algorithmic_equiv`."""
+    ksec = kms * 1e-3
+    out = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_TLANEOPS, "peak_measured": VALU_PEAK_MEASURED,
+           "unit": "T lane-ops/s", "frac": None, "traffic": None, "kernel": kernel_name, "kernel_ms": kms}
+    if counters is not None:
+        per_ray, per_launch, fname = counters
+        valu = per_ray.get("SQ_INSTS_VALU", 0.0) * rays_launch               # wave-instructions this launch issued
+        out["achieved"] = valu * 64.0 / ksec / 1e12
+        out["frac"] = out["achieved"] / VALU_PEAK_TLANEOPS
+        out["frac_of_measured_peak"] = out["achieved"] / VALU_PEAK_MEASURED
+        out["valu_wave_insts_per_64_rays"] = per_ray.get("SQ_INSTS_VALU", 0.0) * 64.0
+        if "hbm_bytes_per_launch" in per_ray:
+            out["traffic"] = per_ray["hbm_bytes_per_launch"] * rays_launch
+            out["hbm_gbs"] = out["traffic"] / ksec / 1e9
+            out["hbm_frac"] = out["hbm_gbs"] / HBM_PEAK_GBS
+        if "SQ_BUSY_CYCLES" in per_launch and per_launch.get("kernel_avg_ms_rocprof"):
+            # SQ_BUSY_CYCLES sums the 32 shader engines; / 32 = cycles the kernel ran = the clock it really had
+            cyc = per_launch["SQ_BUSY_CYCLES"] / 32.0
+            out["shader_clock_ghz"] = cyc / (per_launch["kernel_avg_ms_rocprof"] * 1e-3) / 1e9
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in per_launch:
+                out["mfma_busy_frac"] = per_launch["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * N_SIMD)
+            if "SQ_WAIT_INST_ANY" in per_launch and "SQ_WAVE_CYCLES" in per_launch:
+                out["issue_stall_frac_of_wave_cycles"] = per_launch["SQ_WAIT_INST_ANY"] / per_launch["SQ_WAVE_CYCLES"]
+                out["parked_frac_of_wave_cycles"] = per_launch.get("SQ_WAIT_ANY", 0.0) / per_launch["SQ_WAVE_CYCLES"]
+        if "SQ_INSTS_LDS" in per_ray:
+            out["lds_wave_insts"] = per_ray["SQ_INSTS_LDS"] * rays_launch
+            out["lds_bank_conflict_cycles_per_inst"] = per_launch.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(per_launch["SQ_INSTS_LDS"], 1.0)
+        if "SQ_INSTS_SALU" in per_ray:
+            out["salu_per_valu"] = per_ray["SQ_INSTS_SALU"] / max(per_ray.get("SQ_INSTS_VALU", 0.0), 1e-30)
+        out["counters_from"] = "profiles/" + fname + " (rocprofv3 --pmc passes of this workload, scaled per ray to this launch)"
+    else:
+        out["note_counters"] = "no committed rocprofv3 counters for this workload (profiles/r*_pmc_traffic.json): fractions unavailable"
+    # SURVEY 8(d): the reference's scan reads 16 B x N spheres per ray (list) -- what the kernel would have to stream if
+    # it performed that scan. It does not (MFMA prefilter + tile culling, or the internal tree), so this is NOT a
+    # fraction of anything the hardware did; kept only so rounds can be compared in the survey's unit.
+    if not use_bvh:
+        eq = 16.0 * n_hitables * rays_launch / ksec / 1e9
+        out["algorithmic_equiv"] = {"scan_bytes_per_ray": 16.0 * n_hitables, "scan_equiv_gbs": eq,
+                                    "note": "reference-scan equivalent rate (SURVEY 8d), LDS/matrix-core served; not a roofline fraction"}
+    out["note"] = ("the path is bound by VALU issue + dependency/divergence stalls, not by HBM or MFMA (SURVEY 8d): frac = "
+                   "SQ_INSTS_VALU x 64 lanes / kernel time against 78.6 T lane-ops/s (256 CU x 4 SIMD x 2.4 GHz / 2 cycles); "
+                   "hbm_frac = measured FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE bytes / kernel time against 8 TB/s")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,15 +169,24 @@ def main():
     ap.add_argument("--preset", default="random_spheres")
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=800)
-    ap.add_argument("--samples", type=int, default=64, help="samples per pixel (BASELINE config 4 = 256 with --mode tiles)")
-    ap.add_argument("--mode", choices=["frames", "tiles"], default="frames", help="how N > 1 GPUs are used (see above)")
+    ap.add_argument("--samples", type=int, default=0, help="samples per pixel (default: 64 on one GPU = BASELINE config 3, 256 in tiles mode = config 4)")
+    ap.add_argument("--mode", choices=["tiles", "frames"], default="tiles", help="how N > 1 GPUs are used (see above)")
     ap.add_argument("--depth", type=int, default=10)
     ap.add_argument("--bvh", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="N = 1: skip the extra measurement of overlapped independent frames")
-    ap.add_argument("--no-overlap", action="store_true", help="N > 1: run the collective on the render stream (no double buffering)")
+    ap.add_argument("--no-extras", action="store_true", help="skip every extra measurement (host-buffer contract, other multi-GPU mode)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather on the render stream through pt_render_sharded (no double buffering)")
     ap.add_argument("--cpu-secs", type=float, default=15.0)
     args = ap.parse_args()
+
+    # ---- self-launch: `python bench.py --gpus N` without a launcher (nothing has touched the GPU yet)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("PT_BENCH_FORCE_DIST") != "1":
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] --gpus %d without a launcher: starting  %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+        raise SystemExit(subprocess.call(cmd))
 
     import numpy as np
     import torch
@@ -108,7 +197,6 @@ def main():
     N = args.gpus
     if world != N and world > 1:
         N = world
-    S = args.samples
     W, H, depth = args.width, args.height, args.depth
 
     if not torch.cuda.is_available():
@@ -121,11 +209,15 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+    multi = N > 1 or dist is not None
+    S = args.samples if args.samples > 0 else (256 if (multi and args.mode == "tiles") else 64)
 
     if not os.path.exists(os.path.join(ROOT, "pathtrace-rs_amd", "_build", "libpthost.so")):
         if local_rank == 0:   # a checkout without the in-tree build: compile it once (never a fallback path)
-            import subprocess
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "pathtrace-rs_amd"), "all"], stdout=subprocess.DEVNULL)
         if dist is not None:
             dist.barrier()
@@ -137,26 +229,32 @@ def main():
     hs = pthost.HostScene(args.preset, W, H, samples=S, use_bvh=args.bvh, device=local_rank)
     scene = hs.device_scene()
     n_spheres = hs.world_desc.n_hitables
-    params = ptgpu.PtParams(W, H, S, depth, 0, 1 if args.bvh else 0)
     cam = hs.camera
 
+    def params_for(spp):
+        return ptgpu.PtParams(W, H, spp, depth, 0, 1 if args.bvh else 0)
+
     stream = torch.cuda.current_stream()
-    multi = N > 1 or dist is not None
+    comm = None
+    if multi:
+        # the RCCL communicator of the C ABI: rank 0's ncclUniqueId travels over the launcher's process group
+        box = [ptgpu.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = ptgpu.Comm.create(box[0], rank, N, local_rank)
     max_rows = sharding.padded_rows(H, N)
-    # Three buffer sets: the collective + blend of step k run on their own HIP stream while the kernels of steps k + 1
-    # and k + 2 render into the other sets. The persistent grid holds every CU, so the exchange of step k actually runs
+    # Three buffer sets: the collective of step k runs on its own HIP stream while the kernels of steps k + 1 and
+    # k + 2 render into the other sets. The persistent grid holds every CU, so the exchange of step k actually runs
     # when the workgroups of step k + 1 retire; with only two sets step k + 2 would have to wait for it.
     overlap = multi and not args.no_overlap
-    comm = torch.cuda.Stream(device=dev) if overlap else stream
+    comm_stream = torch.cuda.Stream(device=dev) if overlap else stream
     sets = [dict(full=torch.zeros((H, W, 3), dtype=torch.float32, device=dev),
                  shard=torch.zeros((max_rows, W, 3), dtype=torch.float32, device=dev),
                  rays=torch.zeros(1, dtype=torch.int64, device=dev),
-                 rows=torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev) if multi else None,
-                 frames=torch.empty((N, H, W, 3), dtype=torch.float32, device=dev) if multi else None,
-                 done=None) for _ in range(3 if overlap else 1)]
+                 frames=None, done=None) for _ in range(3 if overlap else 1)]
     state = {"k": 0, "last": sets[0], "frame": None}
 
-    def step(mode):
+    def step(mode, spp):
+        p = params_for(spp)
         b = sets[state["k"] % len(sets)]
         state["k"] += 1
         state["last"] = b
@@ -164,29 +262,38 @@ def main():
             stream.wait_event(b["done"])      # the collective that read this set two steps ago has finished
         if not multi:
             b["full"].zero_()  # frame 0 of a fresh accumulation (offline.rs:25 starts from zeros)
-            scene.update_device(params, cam, 0, b["full"].data_ptr(), b["rays"].data_ptr(), stream.cuda_stream)
+            scene.update_device(p, cam, 0, b["full"].data_ptr(), b["rays"].data_ptr(), stream.cuda_stream)
+            state["frame"] = b["full"]
+            return
+        if mode == "tiles" and not overlap:
+            # the whole sharded Scene::update in one C-ABI call on one stream: pack, render, RCCL gather, unpack
+            b["full"].zero_()
+            scene.update_sharded(comm, p, cam, 0, b["full"].data_ptr(), b["rays"].data_ptr(), -1, stream.cuda_stream)
             state["frame"] = b["full"]
             return
         if mode == "frames":
             b["full"].zero_()
-            scene.update_device(params, cam, rank, b["full"].data_ptr(), b["rays"].data_ptr(), stream.cuda_stream)
+            scene.update_device(p, cam, rank, b["full"].data_ptr(), b["rays"].data_ptr(), stream.cuda_stream)
         else:
             b["shard"].zero_()
-            scene.update_shard_device(params, cam, 0, rank, N, b["shard"].data_ptr(), b["rays"].data_ptr(), stream.cuda_stream)
+            scene.update_shard_device(p, cam, 0, rank, N, b["shard"].data_ptr(), b["rays"].data_ptr(), stream.cuda_stream)
         if overlap:
             ready = torch.cuda.Event()
             ready.record(stream)
-            comm.wait_event(ready)
-        with torch.cuda.stream(comm):
+            comm_stream.wait_event(ready)
+        with torch.cuda.stream(comm_stream):
             if mode == "frames":
-                # RCCL over xGMI: ONE all_gather of the N frames, blend replayed in frame order (scene.rs:113-116)
+                # ONE all_gather of the N frames, blend replayed in frame order (scene.rs:113-116)
+                if b["frames"] is None:
+                    b["frames"] = torch.empty((N, H, W, 3), dtype=torch.float32, device=dev)
                 state["frame"] = sharding.gather_progressive(dist, b["full"], b["frames"], b["rays"])
             else:
-                # ONE all_gather of the row shards per frame (+ 8-byte all_reduce, scene.rs:118-120), de-interleave
-                state["frame"] = sharding.gather_frame(dist, b["shard"], b["rows"], b["rays"], H)
+                # ONE ncclAllGather of the row shards + 8-byte ncclAllReduce (scene.rs:118-120) + de-interleave, C ABI
+                comm.gather_frame(W, H, b["shard"].data_ptr(), b["full"].data_ptr(), b["rays"].data_ptr(), -1, comm_stream.cuda_stream)
+                state["frame"] = b["full"]
             if overlap:
                 b["done"] = torch.cuda.Event()
-                b["done"].record(comm)
+                b["done"].record(comm_stream)
 
     def fence():
         torch.cuda.synchronize()
@@ -194,43 +301,88 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(mode, steps, warmup):
+    def timed(mode, spp, steps, warmup):
         """W untimed + K timed steps bracketed by barrier + synchronize; MAX over ranks."""
-        kms_list = []
+        kms_list, pms_list = [], []
         for _ in range(warmup):
-            step(mode)
+            step(mode, spp)
         fence()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step(mode)
+            step(mode, spp)
             # kernel duration of this step from the HIP events recorded on the launch stream (pt_last_kernel_ms
             # synchronises on the stop event only). In the overlapped multi-GPU pipeline the host must not wait per
             # step (the next kernel is enqueued behind the running one): there the last step's duration is read.
             if not overlap:
                 kms_list.append(scene.last_kernel_ms())
+                pms_list.append(scene.last_pass_ms())
         fence()
         el = time.perf_counter() - t0
         if overlap:
             kms_list.append(scene.last_kernel_ms())
-        t = torch.tensor([el, sum(kms_list) / max(1, len(kms_list))], dtype=torch.float64, device=dev)
+            pms_list.append(scene.last_pass_ms())
+        t = torch.tensor([el, sum(kms_list) / max(1, len(kms_list)), sum(pms_list) / max(1, len(pms_list))], dtype=torch.float64, device=dev)
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t[0].item()), float(t[1].item()), int(state["last"]["rays"].item())  # already summed over ranks
+        return float(t[0].item()), float(t[1].item()), float(t[2].item()), int(state["last"]["rays"].item())  # rays already summed over ranks
 
-    elapsed, kms, rays_per_step = timed(args.mode, args.steps, args.warmup)
+    elapsed, kms, pms, rays_per_step = timed(args.mode, S, args.steps, args.warmup)
     total_rays = rays_per_step * args.steps
     value = total_rays / 1e6 / elapsed
     ms_per_step = elapsed / args.steps * 1e3
-    strong = None
-    if multi and args.mode == "frames":   # the other decomposition, reported beside the main value
+    rays_this_launch = int(sets[0]["rays"].item()) if not multi else rays_per_step / N   # tiles: ~1/N of the frame's rays per rank
+
+    if multi and os.environ.get("PT_BENCH_CHECK") == "1":
+        # self-check of the pipelined / sharded path: its last frame must equal this rank's own full render, bit for bit
+        for _ in range(3):
+            step(args.mode, S)
+        fence()
+        got = state["frame"].clone()
+        ref_full = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        rc2 = torch.zeros(1, dtype=torch.int64, device=dev)
+        if args.mode == "tiles":
+            scene.update_device(params_for(S), cam, 0, ref_full.data_ptr(), rc2.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            want = ref_full
+        else:
+            scene.update_device(params_for(S), cam, rank, ref_full.data_ptr(), rc2.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            want = sharding.gather_progressive(dist, ref_full, torch.empty((N, H, W, 3), dtype=torch.float32, device=dev), rc2)
+            torch.cuda.synchronize()
+        assert torch.equal(got, want) and int(rc2.item()) == int(state["last"]["rays"].item()), "sharded frame differs from the single-GPU frame"
+        if rank == 0:
+            print("[bench check] %s frame over %d rank(s) == single-GPU frame, %d rays" % (args.mode, N, int(rc2.item())), file=sys.stderr)
+
+    other = None
+    if multi and not args.no_extras:   # the other decomposition, reported beside the main value
         k2 = max(2, min(args.steps, 5))
-        el2, kms2, rays2 = timed("tiles", k2, 1)
-        strong = {"value": rays2 * k2 / 1e6 / el2, "unit": "Mrays/s", "ms_per_step": el2 / k2 * 1e3, "kernel_ms": kms2,
-                  "steps": k2, "scaling": "strong",
-                  "workload": "ONE %dx%d %dspp frame, rows interleaved over %d GPUs, all_gather of the shards" % (W, H, S, N)}
+        m2, s2 = ("frames", 64) if args.mode == "tiles" else ("tiles", 256)
+        el2, kms2, _, rays2 = timed(m2, s2, k2, 1)
+        other = {"value": rays2 * k2 / 1e6 / el2, "unit": "Mrays/s", "ms_per_step": el2 / k2 * 1e3, "kernel_ms": kms2, "steps": k2,
+                 "scaling": "weak" if m2 == "frames" else "strong",
+                 "workload": ("progressive frames 0..%d of the %dx%d %dspp frame, one per GPU, all_gather + blend in frame order "
+                              "(bit-identical to -F %d)" % (N - 1, W, H, s2, N)) if m2 == "frames" else
+                             ("ONE %dx%d %dspp frame, rows interleaved over %d GPUs, RCCL gather of the shards" % (W, H, s2, N))}
 
     pipelined = None
-    if not multi and not args.no_pipeline:
+    host_buffer = None
+    if not multi and not args.no_extras:
+        # Extra, never `value`: the reference's own contract -- Scene::update on a HOST buffer (offline.rs:27-34 times
+        # exactly this call): pt_render = H2D of the previous frame + kernels + D2H, PCIe inclusive.
+        hb = np.zeros((H, W, 3), np.float32)
+        scene.update(params_for(S), cam, 0, hb)
+        kh = max(3, min(args.steps, 10))
+        th = 0.0
+        for _ in range(kh):
+            hb[:] = 0.0
+            t0 = time.perf_counter()
+            rays_h = scene.update(params_for(S), cam, 0, hb)
+            th += time.perf_counter() - t0
+        assert rays_h == rays_per_step and np.array_equal(hb, state["frame"].cpu().numpy())
+        host_buffer = {"value": rays_h * kh / 1e6 / th, "unit": "Mrays/s", "ms_per_step": th / kh * 1e3, "steps": kh,
+                       "note": "pt_render with a pageable host buffer, read + written (PCIe inclusive): the contract "
+                               "offline.rs:27-34 times; frame identical to the device-resident one"}
+    if not multi and not args.no_pipeline and not args.no_extras:
         # Extra figure, never `value`: independent frames back to back on two scene handles / two HIP streams, so the
         # tail of frame k (its last, serial pixels) and the pilot pass of frame k + 1 overlap. A single frame cannot
         # use this; a renderer producing a sequence of independent frames (animation, tiles of a bigger image) can.
@@ -243,7 +395,7 @@ def main():
             sc, st, buf, rc = handles[k % 2]
             with torch.cuda.stream(st):
                 buf.zero_()
-                sc.update_device(params, cam, 0, buf.data_ptr(), rc.data_ptr(), st.cuda_stream)
+                sc.update_device(params_for(S), cam, 0, buf.data_ptr(), rc.data_ptr(), st.cuda_stream)
 
         kp = max(4, args.steps)
         for k in range(2):
@@ -260,95 +412,46 @@ def main():
                      "note": "independent frames alternating over two scene handles and two HIP streams (the tail of one frame "
                              "overlaps the start of the next); each frame is bit-identical to the single-frame result"}
 
-    if multi and os.environ.get("PT_BENCH_CHECK") == "1":
-        # self-check of the double-buffered pipeline: its last frame must equal a plain serial step, bit for bit
-        for _ in range(3):
-            step(args.mode)
-        fence()
-        got = state["frame"].clone()
-        ref_full = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-        ref_shard = torch.zeros((max_rows, W, 3), dtype=torch.float32, device=dev)
-        rc2 = torch.zeros(1, dtype=torch.int64, device=dev)
-        if args.mode == "frames":
-            scene.update_device(params, cam, rank, ref_full.data_ptr(), rc2.data_ptr(), stream.cuda_stream)
-            torch.cuda.synchronize()
-            want = sharding.gather_progressive(dist, ref_full, torch.empty((N, H, W, 3), dtype=torch.float32, device=dev), rc2)
-        else:
-            scene.update_shard_device(params, cam, 0, rank, N, ref_shard.data_ptr(), rc2.data_ptr(), stream.cuda_stream)
-            torch.cuda.synchronize()
-            want = sharding.gather_frame(dist, ref_shard, torch.empty((N, max_rows, W, 3), dtype=torch.float32, device=dev), rc2, H)
-        torch.cuda.synchronize()
-        assert torch.equal(got, want) and int(rc2.item()) == int(state["last"]["rays"].item()), "pipelined frame differs from the serial one"
-        if rank == 0:
-            print("[bench check] pipelined %s frame == serial frame, %d rays" % (args.mode, int(rc2.item())), file=sys.stderr)
-
     if rank == 0:
         grid, block, lds = scene.last_launch_info()
-        # algorithmic bytes/ray in list mode = 16 B x N_spheres (cx,cy,cz,r^2 scanned once per
-        # ray); the scan is LDS-served, so "achieved" is an EFFECTIVE rate and may exceed the HBM peak.
-        bytes_per_ray = 16.0 * n_spheres
-        launch_bytes = bytes_per_ray * rays_per_step / N      # one launch = one rank's frame (or shard)
-        achieved = launch_bytes / (kms * 1e-3) / 1e9
-        # The same algorithmic work expressed as the reference's arithmetic: 18 unfused f32 lane-ops per sphere
-        # test. The kernel does NOT execute these for every pair: an f16 MFMA prefilter discards certain misses
-        # and only survivors run the exact arithmetic, so this "equivalent" rate may exceed the VALU ceiling.
-        valu_ops = (18.0 * n_spheres + 150.0) * rays_per_step / N
-        valu_rate = valu_ops / (kms * 1e-3) / 1e12
-        # matrix-core work of the prefilter if EVERY tile ran: ceil(n/32) tiles x 4 v_mfma_f32_32x32x16_f16 (32768 flop
-        # each) per 64 rays (list mode only). Tile culling skips tiles wave by wave, so what was actually issued is
-        # taken from the committed rocprofv3 counters (SQ_INSTS_MFMA per launch) when they are for this workload.
-        mfma_tf_max = 0.0 if args.bvh else (-(-n_spheres // 32) * 4 * 32768.0 / 64.0) * rays_per_step / N / (kms * 1e-3) / 1e12
-        mfma_tf = mfma_tf_max
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                prof = json.load(open(pmc))
-                traffic = prof.get("hbm_bytes_per_launch")
-                same = prof.get("bench_line_under_profiler", {}).get("config", {}).get("rays_per_step") == rays_per_step // N
-                insts = prof.get("pmc_per_launch", {}).get("SQ_INSTS_MFMA")
-                if same and insts and not args.bvh:
-                    mfma_tf = insts * 32768.0 / (kms * 1e-3) / 1e12
-            except Exception:
-                traffic = None
+        tiles = multi and args.mode == "tiles"
+        counters = committed_counters(args.preset, W, H, S, args.bvh)
+        roof = roofline_block("pt_trace_kernel" if not hs.is_world else "pt_world_kernel", kms, float(rays_this_launch), n_spheres, args.bvh, counters)
+        roof["pass_ms"] = pms
+        roof["note_pass"] = "kernel_ms = the frame kernel alone (what rocprofv3 reports); pass_ms adds the 1-spp pilot pass and the tile sort that precede it"
+        is_headline = args.preset == "random_spheres" and (W, H) == (1200, 800) and not args.bvh and ((not multi and S == 64) or (tiles and S == 256))
         out = {
-            "metric": "Mrays/sec, random_spheres 1200x800 64spp" if (args.preset == "random_spheres" and (W, H, S) == (1200, 800, 64))
-                      else "Mrays/sec, %s %dx%d %dspp" % (args.preset, W, H, S),
+            "metric": ("Mrays/sec, random_spheres 1200x800 %dspp" % S) if is_headline else "Mrays/sec, %s %dx%d %dspp" % (args.preset, W, H, S),
             "value": value, "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak" if (args.mode == "frames" or not multi) else "strong", "vs_baseline": None, "dtype": "f32",
+            "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "preset %s (%d hitables) %dx%d %dspp depth %d %s, seed 0, %s"
                                    % (args.preset, n_spheres, W, H, S, depth, "BVH" if args.bvh else "list",
-                                      "frame 0" if not multi else ("progressive frames 0..%d, one per GPU" % (N - 1) if args.mode == "frames"
-                                                                   else "frame 0 split by rows")),
+                                      "frame 0" if not multi else ("frame 0 split by rows over %d GPUs (BASELINE config 4)" % N if tiles
+                                                                   else "progressive frames 0..%d, one per GPU" % (N - 1))),
                        "rays_per_step": rays_per_step, "wall_secs_per_step": ms_per_step / 1e3,
                        "parallelism": ("1 GPU" if not multi else
-                                       ("frame_num = rank on each of %d GPUs, no data-path collective, RCCL all_gather of the frames + "
-                                        "blend in frame order (scene.rs:113-116)" % N if args.mode == "frames"
-                                        else "rows interleaved over %d GPUs, RCCL all_gather of the shards" % N)),
-                       "overlap": ("collective + blend of step k on a second HIP stream under the kernel of step k + 1" if overlap
-                                   else "none"),
+                                       ("rows y %% %d == rank on each GPU, no collective while rendering, then ONE ncclAllGather of the "
+                                        "float3 shards + 8-byte ncclAllReduce of the ray count through the C ABI (pt_comm_gather_frame)" % N if tiles
+                                        else "frame_num = rank on each of %d GPUs, no data-path collective, all_gather of the frames + "
+                                             "blend in frame order (scene.rs:113-116)" % N)),
+                       "overlap": ("collective of step k on a second HIP stream under the kernel of step k + 1" if overlap else "none"),
                        "grid": grid, "block": block, "lds_bytes": lds},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "pt_trace_kernel", "kernel_ms": kms,
-                         "note": "effective scan bandwidth: 16 B x %d spheres per ray, served from LDS (never HBM), so it "
-                                 "exceeds the HBM peak by construction; measured HBM traffic is in `traffic`. The reference's "
-                                 "arithmetic for that scan equals %.1f T f32 lane-ops/s (VALU ceiling ~67 T measured, 78.6 T "
-                                 "nominal); the kernel replaces most of it by an f16 MFMA prefilter that issues %.0f TFLOP/s "
-                                 "(%.0f if no tile were culled; dense f16 peak ~2500) and is bound by VALU issue in the tile "
-                                 "loop, the exact phase 2 and divergent shading, see DESIGN.md section 4"
-                                 % (n_spheres, valu_rate, mfma_tf, mfma_tf_max),
-                         "valu_equiv_frac": valu_rate / 78.6, "mfma_tflops": mfma_tf, "mfma_frac": mfma_tf / 2500.0},
+            "roofline": roof,
         }
-        if strong is not None:
-            out["strong_scaling_tiles"] = strong
+        if other is not None:
+            out["weak_scaling_frames" if args.mode == "tiles" else "strong_scaling_tiles"] = other
+        if host_buffer is not None:
+            out["host_buffer"] = host_buffer
         if pipelined is not None:
             out["pipelined_frames"] = pipelined
-        if N == 1 and not args.no_cpu_baseline:
+        if N == 1 and not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.preset, W, H, S, depth, args.bvh, args.cpu_secs)
         print(json.dumps(out))
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -225,6 +225,47 @@ int pt_render_shard_device(pt_scene *scene, const pt_params *params, const pt_ca
                            float *d_rgb_shard_inout, uint64_t *d_ray_count, void *hip_stream);
 uint32_t pt_shard_rows(uint32_t height, uint32_t shard_index, uint32_t shard_count);
 
+/* ---- multi-GPU frames (SURVEY 8b "multi-GPU variant takes a device list / communicator", 8e) ----------------
+ * One frame of Scene::update split over the ranks of an RCCL communicator: rank r renders the rows y with
+ * y % world == r (disjoint pixels, scene.rs:90-93), the float3 shards are collected with ONE ncclAllGather (or
+ * ncclGather to `root`) over xGMI and the per-rank ray counts are summed with an 8-byte ncclAllReduce
+ * (scene.rs:118-120). No collective happens while rendering. One process per GPU (pt_comm_create, the unique id
+ * travels over any host channel) or one process driving several GPUs (pt_comm_create_all with a device list). */
+typedef struct pt_comm pt_comm;
+#define PT_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+
+/* ncclGetUniqueId: called once (by rank 0), then handed to every rank's pt_comm_create. */
+int pt_comm_unique_id(uint8_t id_out[PT_COMM_ID_BYTES]);
+/* ncclCommInitRank on `device`; collective over the `world` ranks sharing `id`. */
+int pt_comm_create(const uint8_t id[PT_COMM_ID_BYTES], uint32_t rank, uint32_t world, int device, pt_comm **comm_out);
+/* ncclCommInitAll: `n` communicators of one process, comms_out[i] on devices[i] (rank i). */
+int pt_comm_create_all(const int *devices, uint32_t n, pt_comm **comms_out);
+void pt_comm_destroy(pt_comm *comm);
+int pt_comm_rank(const pt_comm *comm, uint32_t *rank_out, uint32_t *world_out);
+
+/* The exchange step alone, asynchronous on `hip_stream`: d_rgb_shard is this rank's compact shard as
+ * pt_render_shard_device wrote it (pt_shard_rows(height, rank, world) rows); d_rgb_full (width*height*3 floats)
+ * receives the whole frame on every rank (root < 0: ncclAllGather) or on rank `root` only (ncclGather; other ranks
+ * may pass NULL); d_ray_count (8 bytes) is replaced by the sum over ranks on every rank. */
+int pt_comm_gather_frame(pt_comm *comm, uint32_t width, uint32_t height, const float *d_rgb_shard,
+                         float *d_rgb_full, uint64_t *d_ray_count, int root, void *hip_stream);
+
+/* Scene::update on `world` GPUs: pack this rank's rows out of d_rgb_full_inout (the blend reads the previous frame,
+ * scene.rs:114-116), pt_render_shard_device, pt_comm_gather_frame -- all enqueued on `hip_stream`. Every rank
+ * passes the same params / camera / frame_num and a scene created from the same description on its own device;
+ * d_rgb_full_inout must hold the same previous frame on every rank (it does after an all-gather call). */
+int pt_render_sharded(pt_scene *scene, pt_comm *comm, const pt_params *params, const pt_camera *camera,
+                      uint32_t frame_num, float *d_rgb_full_inout, uint64_t *d_ray_count, int root,
+                      void *hip_stream);
+
+/* The two layout kernels of the sharded path, exposed so that a single GPU can check them (and so that a caller
+ * with its own transport can reuse them): full frame -> one rank's compact shard, and the gathered
+ * [shard_count][ceil(height/shard_count)][width][3] buffer -> full frame (row y = gathered[y % N][y / N]). */
+int pt_shard_pack(const float *d_rgb_full, float *d_rgb_shard, uint32_t width, uint32_t height,
+                  uint32_t shard_index, uint32_t shard_count, void *hip_stream);
+int pt_shard_unpack_all(const float *d_gathered, float *d_rgb_full, uint32_t width, uint32_t height,
+                        uint32_t shard_count, void *hip_stream);
+
 /* Base seed used when params->random_seed != 0 (scene.rs:96-97 uses
  * rand::random(), i.e. non-reproducible by design). */
 int pt_scene_set_seed_base(pt_scene *scene, uint64_t seed_base);
@@ -233,6 +274,9 @@ int pt_scene_set_seed_base(pt_scene *scene, uint64_t seed_base);
  * handle, measured with HIP events on the launch stream (synchronises on the
  * stop event). Also the launch geometry, for roofline bookkeeping. */
 int pt_last_kernel_ms(pt_scene *scene, float *ms_out);
+/* Same for the whole pass of that render: the 1-spp pilot pass and the tile sort that order the work (when the
+ * frame is large enough to use them) plus the frame kernel. */
+int pt_last_pass_ms(pt_scene *scene, float *ms_out);
 int pt_last_launch_info(pt_scene *scene, uint32_t *grid_out, uint32_t *block_out,
                         uint32_t *lds_bytes_out);
 

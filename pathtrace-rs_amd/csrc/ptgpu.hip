@@ -6,6 +6,7 @@
 #include "ptgpu.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -110,9 +111,15 @@ struct pt_scene {
     uint32_t has_image = 0;
     uint32_t ref_bvh_depth = 0;
     // last launch
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // around the frame kernel alone (what rocprofv3 reports for it)
+    hipEvent_t ev_pass = nullptr;                        // before the pilot pass: ev_pass..ev_stop = the whole Scene::update
     bool ev_valid = false;
+    const void *attr_kern[2] = {nullptr, nullptr};       // kernels whose dynamic-LDS limit is already set to attr_lds
+    uint32_t attr_lds[2] = {0, 0};
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
+    // PTGPU_TIMING=1 (read once in pt_scene_create): per-wave finish times of the last launch, on this scene's device
+    bool timing = false;
+    unsigned long long *d_wave_end = nullptr;
 };
 
 extern "C" const char *pt_last_error(void) { return g_err; }
@@ -801,12 +808,13 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
         return fail(PT_ERR_HIP, "allocating debug counters failed");
     }
     if (hipMalloc((void **)&s->d_work_counter, 64) != hipSuccess || hipMalloc((void **)&s->d_ray_count, 64) != hipSuccess ||
-        hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess) {
+        hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess || hipEventCreate(&s->ev_pass) != hipSuccess) {
         pt_scene_destroy(s);
         return fail(PT_ERR_HIP, "allocating work counters / events failed");
     }
     if (const char *e = getenv("PTGPU_BLOCKS_PER_CU")) s->blocks_per_cu = (uint32_t)atoi(e);
     if (const char *e = getenv("PTGPU_VARIANT")) s->variant = (uint32_t)atoi(e);
+    if (getenv("PTGPU_TIMING") != nullptr && hipMalloc((void **)&s->d_wave_end, 65536 * 8) == hipSuccess) s->timing = true;
     *scene_out = s;
     return PT_OK;
 }
@@ -986,7 +994,7 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
     }
     if (hipMalloc((void **)&s->d_debug, 1024) != hipSuccess || hipMemset(s->d_debug, 0, 1024) != hipSuccess ||
         hipMalloc((void **)&s->d_work_counter, 64) != hipSuccess || hipMalloc((void **)&s->d_ray_count, 64) != hipSuccess ||
-        hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess) {
+        hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess || hipEventCreate(&s->ev_pass) != hipSuccess) {
         pt_scene_destroy(s);
         return fail(PT_ERR_HIP, "allocating counters / events failed");
     }
@@ -1029,8 +1037,10 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_frame);
     (void)hipHostFree(s->h_stage);
     (void)hipFree(s->d_gstack);
+    (void)hipFree(s->d_wave_end);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);
     if (s->ev_stop) (void)hipEventDestroy(s->ev_stop);
+    if (s->ev_pass) (void)hipEventDestroy(s->ev_pass);
     delete s;
 }
 
@@ -1050,6 +1060,15 @@ extern "C" int pt_scene_set_tuning(pt_scene *s, uint32_t blocks_per_cu, uint32_t
 namespace {
 
 f3 to3(const float *p) { return f3{p[0], p[1], p[2]}; }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per kernel: set it when the kernel or its LDS size changes, not
+// on every frame
+int set_lds_limit(pt_scene *s, int slot, const void *kern, uint32_t lds) {
+    if (s->attr_kern[slot] == kern && s->attr_lds[slot] == lds) return PT_OK;
+    HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    s->attr_kern[slot] = kern, s->attr_lds[slot] = lds;
+    return PT_OK;
+}
 
 // The per-frame arguments both kernels share (KArgs and WArgs use the same member names).
 template <typename Args>
@@ -1180,7 +1199,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         else
             wk = ref_bvh ? (hit_lds ? pt_world_kernel<true, true> : pt_world_kernel<true, false>)
                          : (hit_lds ? pt_world_kernel<false, true> : pt_world_kernel<false, false>);
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(wk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (int rc = set_lds_limit(s, 0, reinterpret_cast<const void *>(wk), lds)) return rc;
+        HIP_TRY(hipEventRecord(s->ev_pass, stream));
         HIP_TRY(hipEventRecord(s->ev_start, stream));
         hipLaunchKernelGGL(wk, dim3(grid), dim3(kBlock), lds, stream, W);
         HIP_TRY(hipGetLastError());
@@ -1347,12 +1367,12 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     else
         kern = pt_trace_kernel<false, false, false, false, false>;
     if (pilot_kern)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(pilot_kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (int rc = set_lds_limit(s, 1, reinterpret_cast<const void *>(pilot_kern), lds)) return rc;
+    if (int rc = set_lds_limit(s, 0, reinterpret_cast<const void *>(kern), lds)) return rc;
+    HIP_TRY(hipEventRecord(s->ev_pass, stream));
 
-    static unsigned long long *d_wave_end = nullptr;
-    const bool timing = getenv("PTGPU_TIMING") != nullptr;
-    if (timing && !d_wave_end) (void)hipMalloc((void **)&d_wave_end, 65536 * 8);
+    const bool timing = s->timing;
+    unsigned long long *const d_wave_end = s->d_wave_end;
     A.wave_end = timing ? d_wave_end : nullptr;
     if (timing) (void)hipMemsetAsync(d_wave_end, 0, 65536 * 8, stream);
     // ---- heavy-first work order from a 1-spp pilot pass (variant bit 32 disables it) -------------------
@@ -1537,12 +1557,217 @@ extern "C" int pt_last_kernel_ms(pt_scene *s, float *ms_out) {
     return PT_OK;
 }
 
+extern "C" int pt_last_pass_ms(pt_scene *s, float *ms_out) {
+    if (!s || !ms_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (!s->ev_valid) return fail(PT_ERR_INVALID_ARG, "no render has been launched on this scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms_out, s->ev_pass, s->ev_stop));
+    return PT_OK;
+}
+
 extern "C" int pt_last_launch_info(pt_scene *s, uint32_t *grid_out, uint32_t *block_out, uint32_t *lds_bytes_out) {
     if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
     if (grid_out) *grid_out = s->last_grid;
     if (block_out) *block_out = s->last_block;
     if (lds_bytes_out) *lds_bytes_out = s->last_lds;
     return PT_OK;
+}
+
+// ---- multi-GPU frames: RCCL communicator behind the C ABI -------------------------
+// One frame is split by rows (row y -> rank y % world, disjoint pixels as scene.rs:90-93); the only exchange is ONE
+// ncclAllGather / ncclGather of the float3 shards plus an 8-byte ncclAllReduce of the ray count (scene.rs:118-120).
+// xGMI is point-to-point and the message is small (11.5 MB at 1200x800), so one collective, no ring tuning.
+struct pt_comm {
+    ncclComm_t comm = nullptr;
+    int device = 0;
+    uint32_t rank = 0, world = 1;
+    float *d_gather = nullptr;       // [world][ceil(H / world)][W][3]; this rank's shard is rendered in place in slot `rank`
+    size_t gather_floats = 0;
+};
+
+#define NCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess) return fail(PT_ERR_HIP, "%s failed: %s", #expr, ncclGetErrorString(r_)); \
+    } while (0)
+
+namespace {
+
+__global__ void shard_pack_kernel(const float *full, float *shard, uint32_t row_floats, uint32_t rows, uint32_t index, uint32_t count) {
+    const size_t n = (size_t)rows * row_floats;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t j = i / row_floats, x = i - j * row_floats;
+        shard[i] = full[(j * count + index) * row_floats + x];
+    }
+}
+
+// row y of the frame = gathered[y % count][y / count]
+__global__ void shard_unpack_kernel(const float *gathered, float *full, uint32_t row_floats, uint32_t height, uint32_t count, uint32_t prow) {
+    const size_t n = (size_t)height * row_floats;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t y = i / row_floats, x = i - y * row_floats;
+        full[i] = gathered[((y % count) * prow + y / count) * row_floats + x];
+    }
+}
+
+uint32_t copy_grid(size_t n) { return (uint32_t)std::min<size_t>((n + 255) / 256, 4096); }
+
+int comm_ensure(pt_comm *c, uint32_t width, uint32_t height) {
+    const uint32_t prow = (height + c->world - 1) / c->world;
+    const size_t need = (size_t)c->world * prow * width * 3u;
+    if (need <= c->gather_floats) return PT_OK;
+    (void)hipFree(c->d_gather);
+    c->d_gather = nullptr;
+    c->gather_floats = 0;
+    HIP_TRY(hipMalloc((void **)&c->d_gather, need * sizeof(float)));
+    HIP_TRY(hipMemset(c->d_gather, 0, need * sizeof(float)));   // ranks with one row less send a zero row
+    c->gather_floats = need;
+    return PT_OK;
+}
+
+// shard already sits in slot `rank` of c->d_gather
+int comm_exchange(pt_comm *c, uint32_t width, uint32_t height, float *d_rgb_full, uint64_t *d_ray_count, int root, hipStream_t stream) {
+    const uint32_t prow = (height + c->world - 1) / c->world;
+    const size_t slot = (size_t)prow * width * 3u;
+    const bool have_frame = root < 0 || (uint32_t)root == c->rank;
+    if (have_frame && !d_rgb_full) return fail(PT_ERR_INVALID_ARG, "d_rgb_full is NULL on a rank that receives the frame");
+    {   // (a one-rank communicator goes through the same calls: that is what a 1-GPU box can test)
+        NCCL_TRY(ncclGroupStart());
+        if (root < 0)
+            NCCL_TRY(ncclAllGather(c->d_gather + (size_t)c->rank * slot, c->d_gather, slot, ncclFloat, c->comm, stream));
+        else
+            NCCL_TRY(ncclGather(c->d_gather + (size_t)c->rank * slot, c->d_gather, slot, ncclFloat, root, c->comm, stream));
+        NCCL_TRY(ncclAllReduce(d_ray_count, d_ray_count, 1, ncclUint64, ncclSum, c->comm, stream));
+        NCCL_TRY(ncclGroupEnd());
+    }
+    if (have_frame) {
+        const size_t n = (size_t)height * width * 3u;
+        hipLaunchKernelGGL(shard_unpack_kernel, dim3(copy_grid(n)), dim3(256), 0, stream, c->d_gather, d_rgb_full, width * 3u, height, c->world, prow);
+        HIP_TRY(hipGetLastError());
+    }
+    return PT_OK;
+}
+
+}  // namespace
+
+extern "C" int pt_comm_unique_id(uint8_t id_out[PT_COMM_ID_BYTES]) {
+    static_assert(sizeof(ncclUniqueId) == PT_COMM_ID_BYTES, "PT_COMM_ID_BYTES must equal sizeof(ncclUniqueId)");
+    if (!id_out) return fail(PT_ERR_INVALID_ARG, "id_out is NULL");
+    ncclUniqueId id;
+    NCCL_TRY(ncclGetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return PT_OK;
+}
+
+extern "C" int pt_comm_create(const uint8_t id[PT_COMM_ID_BYTES], uint32_t rank, uint32_t world, int device, pt_comm **comm_out) {
+    if (!id || !comm_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    *comm_out = nullptr;
+    if (world == 0 || rank >= world) return fail(PT_ERR_INVALID_ARG, "bad rank %u of %u", rank, world);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID_ARG, "device %d out of range (%d devices)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    pt_comm *c = new (std::nothrow) pt_comm();
+    if (!c) return fail(PT_ERR_INVALID_ARG, "out of host memory");
+    c->device = device, c->rank = rank, c->world = world;
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    const ncclResult_t r = ncclCommInitRank(&c->comm, (int)world, uid, (int)rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(PT_ERR_HIP, "ncclCommInitRank failed: %s", ncclGetErrorString(r));
+    }
+    *comm_out = c;
+    return PT_OK;
+}
+
+extern "C" int pt_comm_create_all(const int *devices, uint32_t n, pt_comm **comms_out) {
+    if (!devices || !comms_out || n == 0) return fail(PT_ERR_INVALID_ARG, "NULL argument / no devices");
+    for (uint32_t i = 0; i < n; ++i) comms_out[i] = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
+    for (uint32_t i = 0; i < n; ++i)
+        if (devices[i] < 0 || devices[i] >= ndev) return fail(PT_ERR_INVALID_ARG, "device %d out of range (%d devices)", devices[i], ndev);
+    std::vector<ncclComm_t> cs(n, nullptr);
+    NCCL_TRY(ncclCommInitAll(cs.data(), (int)n, devices));
+    for (uint32_t i = 0; i < n; ++i) {
+        pt_comm *c = new (std::nothrow) pt_comm();
+        if (!c) return fail(PT_ERR_INVALID_ARG, "out of host memory");
+        c->comm = cs[i], c->device = devices[i], c->rank = i, c->world = n;
+        comms_out[i] = c;
+    }
+    return PT_OK;
+}
+
+extern "C" void pt_comm_destroy(pt_comm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    (void)hipFree(c->d_gather);
+    delete c;
+}
+
+extern "C" int pt_comm_rank(const pt_comm *c, uint32_t *rank_out, uint32_t *world_out) {
+    if (!c) return fail(PT_ERR_INVALID_ARG, "comm is NULL");
+    if (rank_out) *rank_out = c->rank;
+    if (world_out) *world_out = c->world;
+    return PT_OK;
+}
+
+extern "C" int pt_shard_pack(const float *d_rgb_full, float *d_rgb_shard, uint32_t width, uint32_t height, uint32_t shard_index,
+                             uint32_t shard_count, void *hip_stream) {
+    if (!d_rgb_full || !d_rgb_shard || width == 0 || height == 0) return fail(PT_ERR_INVALID_ARG, "NULL argument / empty frame");
+    if (shard_count == 0 || shard_index >= shard_count) return fail(PT_ERR_INVALID_ARG, "bad shard %u/%u", shard_index, shard_count);
+    const uint32_t rows = pt_shard_rows(height, shard_index, shard_count);
+    if (rows == 0) return PT_OK;
+    const size_t n = (size_t)rows * width * 3u;
+    hipLaunchKernelGGL(shard_pack_kernel, dim3(copy_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), d_rgb_full, d_rgb_shard,
+                       width * 3u, rows, shard_index, shard_count);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+extern "C" int pt_shard_unpack_all(const float *d_gathered, float *d_rgb_full, uint32_t width, uint32_t height, uint32_t shard_count,
+                                   void *hip_stream) {
+    if (!d_gathered || !d_rgb_full || width == 0 || height == 0 || shard_count == 0) return fail(PT_ERR_INVALID_ARG, "NULL argument / empty frame");
+    const size_t n = (size_t)height * width * 3u;
+    hipLaunchKernelGGL(shard_unpack_kernel, dim3(copy_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), d_gathered, d_rgb_full,
+                       width * 3u, height, shard_count, (height + shard_count - 1) / shard_count);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+
+extern "C" int pt_comm_gather_frame(pt_comm *c, uint32_t width, uint32_t height, const float *d_rgb_shard, float *d_rgb_full,
+                                    uint64_t *d_ray_count, int root, void *hip_stream) {
+    if (!c || !d_rgb_shard || !d_ray_count || width == 0 || height == 0) return fail(PT_ERR_INVALID_ARG, "NULL argument / empty frame");
+    if (root >= (int)c->world) return fail(PT_ERR_INVALID_ARG, "root %d out of range (%u ranks)", root, c->world);
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = comm_ensure(c, width, height)) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    const uint32_t prow = (height + c->world - 1) / c->world, rows = pt_shard_rows(height, c->rank, c->world);
+    if (rows)
+        HIP_TRY(hipMemcpyAsync(c->d_gather + (size_t)c->rank * prow * width * 3u, d_rgb_shard, (size_t)rows * width * 3u * sizeof(float),
+                               hipMemcpyDeviceToDevice, stream));
+    return comm_exchange(c, width, height, d_rgb_full, d_ray_count, root, stream);
+}
+
+extern "C" int pt_render_sharded(pt_scene *s, pt_comm *c, const pt_params *params, const pt_camera *cam, uint32_t frame_num,
+                                 float *d_rgb_full_inout, uint64_t *d_ray_count, int root, void *hip_stream) {
+    if (!s || !c || !params || !cam || !d_rgb_full_inout || !d_ray_count) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (params->width == 0 || params->height == 0 || params->samples == 0)
+        return fail(PT_ERR_INVALID_ARG, "width/height/samples must be non-zero");
+    if (s->device != c->device) return fail(PT_ERR_INVALID_ARG, "scene lives on device %d, communicator on %d", s->device, c->device);
+    if (root >= (int)c->world) return fail(PT_ERR_INVALID_ARG, "root %d out of range (%u ranks)", root, c->world);
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = comm_ensure(c, params->width, params->height)) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    const uint32_t prow = (params->height + c->world - 1) / c->world;
+    float *slot = c->d_gather + (size_t)c->rank * prow * params->width * 3u;
+    // the blend reads the previous frame (scene.rs:114-116): this rank's rows, compacted into its gather slot
+    if (int rc = pt_shard_pack(d_rgb_full_inout, slot, params->width, params->height, c->rank, c->world, hip_stream)) return rc;
+    if (int rc = launch(s, params, cam, frame_num, c->rank, c->world, slot, d_ray_count, stream)) return rc;
+    return comm_exchange(c, params->width, params->height, d_rgb_full_inout, d_ray_count, root, stream);
 }
 
 // ---- device self-test probes ---------------------------------------------------

@@ -103,7 +103,10 @@ EXPORTS = [
     "pt_device_count", "pt_scene_create", "pt_scene_create_world", "pt_scene_prepare", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_render_shard_device", "pt_shard_rows", "pt_scene_set_seed_base", "pt_last_kernel_ms",
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
+    "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
+    "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all",
 ]
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -142,6 +145,17 @@ def lib():
         L.pt_selftest_probe.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_size_t]
         L.pt_scene_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.pt_scene_traversal_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+        L.pt_last_pass_ms.argtypes = [vp, C.POINTER(C.c_float)]
+        L.pt_comm_unique_id.argtypes = [vp]
+        L.pt_comm_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
+        L.pt_comm_create_all.argtypes = [C.POINTER(C.c_int), C.c_uint32, C.POINTER(vp)]
+        L.pt_comm_destroy.argtypes = [vp]
+        L.pt_comm_destroy.restype = None
+        L.pt_comm_rank.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.pt_comm_gather_frame.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_int, vp]
+        L.pt_render_sharded.argtypes = [vp, vp, C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, vp, vp, C.c_int, vp]
+        L.pt_shard_pack.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        L.pt_shard_unpack_all.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         L.pt_last_error.restype = C.c_char_p
         L.pt_version.restype = C.c_char_p
         _lib = L
@@ -318,10 +332,64 @@ class Scene:
         _check(lib().pt_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
 
+    def last_pass_ms(self):
+        """Pilot pass + tile sort + frame kernel of the last render (HIP events on the launch stream)."""
+        ms = C.c_float(0)
+        _check(lib().pt_last_pass_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def update_sharded(self, comm, params, camera, frame_num, d_rgb_full_ptr, d_ray_count_ptr, root=-1, stream=0):
+        """Scene::update over the ranks of `comm` (pt_render_sharded): rows y % world == rank, RCCL gather."""
+        _check(lib().pt_render_sharded(self._h, comm._h, C.byref(params), C.byref(camera), frame_num, d_rgb_full_ptr,
+                                       d_ray_count_ptr, root, stream))
+
     def last_launch_info(self):
         g, b, l = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         _check(lib().pt_last_launch_info(self._h, C.byref(g), C.byref(b), C.byref(l)))
         return g.value, b.value, l.value
+
+
+class Comm:
+    """pt_comm handle: the RCCL communicator of the sharded frame path (one rank per GPU)."""
+
+    def __init__(self, handle, rank, world):
+        self._h, self.rank, self.world = handle, rank, world
+
+    @staticmethod
+    def unique_id():
+        """ncclGetUniqueId as bytes (rank 0 calls it; every rank passes the same bytes to Comm.create)."""
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        _check(lib().pt_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, uid, rank, world, device):
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        _check(lib().pt_comm_create(buf, rank, world, device, C.byref(h)))
+        return cls(h, rank, world)
+
+    def gather_frame(self, width, height, d_shard_ptr, d_full_ptr, d_ray_count_ptr, root=-1, stream=0):
+        _check(lib().pt_comm_gather_frame(self._h, width, height, d_shard_ptr, d_full_ptr, d_ray_count_ptr, root, stream))
+
+    def close(self):
+        if self._h:
+            lib().pt_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def shard_pack(d_full_ptr, d_shard_ptr, width, height, shard_index, shard_count, stream=0):
+    _check(lib().pt_shard_pack(d_full_ptr, d_shard_ptr, width, height, shard_index, shard_count, stream))
+
+
+def shard_unpack_all(d_gathered_ptr, d_full_ptr, width, height, shard_count, stream=0):
+    _check(lib().pt_shard_unpack_all(d_gathered_ptr, d_full_ptr, width, height, shard_count, stream))
 
 
 def shard_rows(height, shard_index, shard_count):

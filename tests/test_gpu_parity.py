@@ -281,6 +281,78 @@ def test_config3_shard_union_equals_full_frame(ptgpu, pthost):
     assert torch.equal(frame, full)
 
 
+def test_config4_shards_at_256spp_match_the_oracle_and_the_full_frame(ptgpu, pthost, oracle):
+    """BASELINE config 4 (random_spheres 1200x800, 256 spp, rows y % 8 over 8 GPUs) with the eight shards rendered one
+    after the other on one GPU into the layout ncclAllGather produces, de-interleaved by the C ABI's own kernel
+    (pt_shard_unpack_all): every 1777th pixel equals the oracle at 256 spp bit for bit, the assembled frame equals the
+    unsharded render, and the shards' ray counts add up to its count (scene.rs:90-118: disjoint pixels, summed count)."""
+    import torch
+    W, H, S, N = 1200, 800, 256, 8
+    hs = pthost.HostScene("random_spheres", W, H, samples=S, device=0)
+    sc = hs.device_scene()
+    p = ptgpu.PtParams(W, H, S, 10, 0, 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    rc = torch.zeros(1, dtype=torch.int64, device="cuda")
+    prow = (H + N - 1) // N
+    gathered = torch.zeros((N, prow, W, 3), dtype=torch.float32, device="cuda")
+    total = 0
+    for r in range(N):
+        sc.update_shard_device(p, hs.camera, 0, r, N, gathered[r].data_ptr(), rc.data_ptr(), stream)
+        torch.cuda.synchronize()
+        total += int(rc.item())
+    frame = torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda")
+    ptgpu.shard_unpack_all(gathered.data_ptr(), frame.data_ptr(), W, H, N, stream)
+    full = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    sc.update_device(p, hs.camera, 0, full.data_ptr(), rc.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert total == int(rc.item())
+    assert torch.equal(frame, full)
+    px = np.arange(0, W * H, 1777, dtype=np.uint32)
+    ref = np.zeros((H, W, 3), np.float32)
+    oracle.OracleScene("random_spheres", W, H).update(S, pixels=px, buffer=ref)
+    a, b = frame.cpu().numpy().reshape(-1, 3)[px], ref.reshape(-1, 3)[px]
+    assert np.array_equal(a, b), _report(b, a)
+    # the inverse layout kernel: packing rank 3's rows out of the frame returns its shard
+    shard = torch.zeros((ptgpu.shard_rows(H, 3, N), W, 3), dtype=torch.float32, device="cuda")
+    ptgpu.shard_pack(frame.data_ptr(), shard.data_ptr(), W, H, 3, N, stream)
+    torch.cuda.synchronize()
+    assert torch.equal(shard, gathered[3, :shard.shape[0]])
+
+
+def test_sharded_update_through_the_rccl_communicator(ptgpu, pthost):
+    """pt_render_sharded / pt_comm_gather_frame on a one-rank RCCL communicator (all a 1-GPU box can form): the calls
+    go through ncclAllGather / ncclGather / ncclAllReduce and must reproduce pt_render_device, including the
+    progressive blend of a second frame (the pack step reads the previous frame, scene.rs:114-116)."""
+    import torch
+    W, H, S = 301, 203, 4          # odd sizes: rows are not a multiple of anything
+    hs = pthost.HostScene("random_spheres", W, H, samples=S, device=0)
+    sc = hs.device_scene()
+    p = ptgpu.PtParams(W, H, S, 10, 0, 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    comm = ptgpu.Comm.create(ptgpu.Comm.unique_id(), 0, 1, 0)
+    ref = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    got = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    rc_ref = torch.zeros(1, dtype=torch.int64, device="cuda")
+    rc = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for f, root in ((0, -1), (1, 0)):            # all-gather form, then gather-to-root form
+        sc.update_device(p, hs.camera, f, ref.data_ptr(), rc_ref.data_ptr(), stream)
+        sc.update_sharded(comm, p, hs.camera, f, got.data_ptr(), rc.data_ptr(), root, stream)
+        torch.cuda.synchronize()
+        assert int(rc.item()) == int(rc_ref.item()) and torch.equal(got, ref)
+    # the exchange step alone, on a shard the caller rendered itself
+    shard = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    sc.update_shard_device(p, hs.camera, 0, 0, 1, shard.data_ptr(), rc.data_ptr(), stream)
+    out = torch.zeros_like(shard)
+    comm.gather_frame(W, H, shard.data_ptr(), out.data_ptr(), rc.data_ptr(), -1, stream)
+    torch.cuda.synchronize()
+    sc.update_device(p, hs.camera, 0, ref.zero_().data_ptr(), rc_ref.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and int(rc.item()) == int(rc_ref.item())
+    with pytest.raises(ptgpu.PtError):
+        sc.update_sharded(comm, p, hs.camera, 0, got.data_ptr(), rc.data_ptr(), 5, stream)   # root out of range
+    comm.close()
+
+
 def test_frames_rendered_apart_blend_like_sequential_updates(ptgpu, pthost):
     """bench.py's weak-scaling mode: each GPU renders one progressive frame into a zeroed buffer, the blend is
     replayed in frame order. On one GPU: frames 0..3 rendered apart and folded == four Scene::update calls."""

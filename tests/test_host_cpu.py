@@ -156,6 +156,32 @@ def test_null_handles_are_errors_not_crashes(ptgpu):
     assert L.pt_last_kernel_ms(None, C.byref(ms)) == ptgpu.PT_ERR_INVALID_ARG
     L.pt_scene_destroy(None)  # no-op
     assert L.pt_selftest_probe(0, 99, buf.ctypes.data, buf.ctypes.data, 4) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_last_pass_ms(None, C.byref(ms)) == ptgpu.PT_ERR_INVALID_ARG
+
+
+def test_comm_entry_points_validate_without_a_device(ptgpu):
+    """The multi-GPU part of the ABI (RCCL communicator, shard layout kernels): argument errors are status codes, and
+    without a GPU communicator creation reports PT_ERR_NO_DEVICE / a HIP error instead of aborting."""
+    L = ptgpu.lib()
+    h = C.c_void_p()
+    uid = (C.c_uint8 * ptgpu.COMM_ID_BYTES)()
+    assert L.pt_comm_create(None, 0, 1, 0, C.byref(h)) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_comm_create(uid, 2, 2, 0, C.byref(h)) == ptgpu.PT_ERR_INVALID_ARG          # rank >= world
+    assert L.pt_comm_create(uid, 0, 0, 0, C.byref(h)) == ptgpu.PT_ERR_INVALID_ARG
+    if ptgpu.device_count() == 0:
+        assert L.pt_comm_create(uid, 0, 1, 0, C.byref(h)) == ptgpu.PT_ERR_NO_DEVICE and not h.value
+        devs = (C.c_int * 1)(0)
+        assert L.pt_comm_create_all(devs, 1, C.byref(h)) == ptgpu.PT_ERR_NO_DEVICE
+    assert L.pt_comm_create_all(None, 1, C.byref(h)) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_comm_unique_id(None) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_comm_rank(None, None, None) == ptgpu.PT_ERR_INVALID_ARG
+    L.pt_comm_destroy(None)  # no-op
+    p, cam = ptgpu.PtParams(8, 8, 1, 1, 0, 0), ptgpu.PtCamera()
+    assert L.pt_render_sharded(None, None, C.byref(p), C.byref(cam), 0, None, None, -1, None) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_comm_gather_frame(None, 8, 8, None, None, None, -1, None) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_shard_pack(None, None, 8, 8, 0, 2, None) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_shard_unpack_all(None, None, 8, 8, 2, None) == ptgpu.PT_ERR_INVALID_ARG
+    assert b"NULL" in L.pt_last_error()
 
 
 def test_shard_rows(ptgpu):
