@@ -27,6 +27,9 @@ namespace ptdev {
 #ifndef PT_MINWAVES
 #define PT_MINWAVES 2
 #endif
+#ifndef PT_TREE4_WAVES
+#define PT_TREE4_WAVES 4   // waves per SIMD the 4-wide tree kernels are compiled for (128 VGPRs)
+#endif
 #ifndef PT_TILE_LOG2
 #define PT_TILE_LOG2 3
 #endif
@@ -50,6 +53,7 @@ struct DTex {  // 32 B
     float pad;
 };
 struct DWideNode;
+struct DNode4;
 
 // Per-sphere shading record: everything Material::scatter / emitted needs for the common cases, resolved at
 // scene creation so a hit costs one 64-byte fetch instead of the dependent chain
@@ -85,7 +89,9 @@ struct KArgs {
     const DTex *texs;
     const float4 *perlin_vec;    // 256 gradients (xyz, pad)
     const uint32_t *perlin_perm; // 768 entries: perm_x | perm_y | perm_z
-    const DWideNode *wnodes;  // caller's BVH re-laid out: children's AABBs inside the parent
+    const DWideNode *wnodes;  // binary internal tree (variant bit 2048): children's AABBs inside the parent
+    const DNode4 *nodes4;     // 4-wide internal tree (default of the tree kernels), root = node 0
+    const uint32_t *rank_sphere;     // BVH worlds: sphere of each DFS leaf rank (inverse of leaf_rank; decodes the hit key)
     const uint32_t *leaf_rank;       // DFS (lhs before rhs) order of each sphere's leaf, for equal-t ties
     float root_min[3], root_max[3];
     uint32_t n_nodes, nodes_in_lds, bvh_stack_entries;
@@ -1003,6 +1009,216 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
     }
 }
 
+// ---- 4-wide internal tree ------------------------------------------------------------------------------------
+// The tree kernels' default traversal structure (DESIGN.md "tree kernel"). One 128-byte node holds the boxes of up
+// to four children as plane arrays (SoA), so a visit is eight 16-byte loads and FOUR box tests of identical, branch-free
+// code; a child is an inner node or ONE sphere (leaf). Per visit the lane
+//   * pads all four boxes by ONE node-level bound of the reference's f32 discriminant error (same bound as
+//     accel_box_hit, taken over the node: every sphere below lies within |c_node - o| + |h_node| of the origin),
+//   * evaluates each plane with one FMA, t = plane * rcp_d + (-o * rcp_d -+ pad * |rcp_d|) -- the near / far plane
+//     arrays are picked by the ray's direction signs through the load ADDRESS, not by selects on the data,
+//   * pushes the inner children it hit far-to-near (4 sort keys = entry distance bits | slot, a 5-exchange network of
+//     v_min_u32 / v_max_u32), keeps the nearest in a register as the next node, and
+//   * appends the leaf children it hit to its queue of (sphere) candidates.
+// Candidates are NOT tested by the lane that found them: like phase 2 of the MFMA list kernel they are expanded into one
+// (owner ray, sphere) pair list per wave and every lane takes one pair per round (exact reference arithmetic, bvh_leaf's
+// accept rule, ds_min_u64 on the owner's (t, tie-break) key), so the exact tests run on full waves whatever the spread
+// of the lanes' traversals. A lane's nearest hit so far (`best`, the culling limit) is refreshed from its key after
+// every drain.
+struct DNode4 {  // 128 B
+    float lo[3][4];      // child boxes, plane arrays: lo[axis][child]
+    float hi[3][4];
+    int32_t child[4];    // inner children first: consecutive nodes, child[j] = child[0] + j (>= 0); then leaves (~sphere < 0); kNoChild4 = empty
+    float cx, cy, cz;    // centre of the node's own box
+    uint32_t padh;       // two f16 (rounded up): lo = 6e-6 / r_min below the node, hi = that * |h_node|^2 + 1e-4
+};
+constexpr int32_t kNoChild4 = 0x7fffffff;
+constexpr int kLeafQ = 8;            // per-lane candidate slots; drained when a lane holds more than kLeafQ - 4
+constexpr uint32_t kPairLaneShift = 26u;   // pair = owner lane << 26 | sphere (scenes up to 2^26 spheres)
+__host__ __device__ constexpr uint32_t tree4_queue_bytes(uint32_t blk) { return (uint32_t)kLeafQ * blk * 4u + (blk / 64u) * kWavePairBytes; }
+
+struct Trav4 {
+    uint32_t visits, leaves;   // VERIFY kernels: nodes fetched / exact sphere tests (SURVEY 8d counters)
+    int sp;                    // stack entries of this lane
+    int32_t cur;               // node to visit next (kNoChild4: pop)
+    uint32_t qn;               // queued leaf candidates
+    float best;                // nearest accepted hit so far (register copy of the key's t)
+    bool active;
+};
+
+// key of an accepted hit: smaller t wins; equal t goes to the lower list index (hitable_list.rs:48) or, in a BVH world,
+// to the DFS-later leaf (bvh.rs:47-53) -- the order-independent form of both scans (accept_hit / bvh_leaf)
+__device__ __forceinline__ unsigned long long key4_of(const KArgs &A, float t, int k) {
+    const uint32_t low = A.gate ? (0xffffffffu - A.leaf_rank[k]) : (uint32_t)k;
+    return ((unsigned long long)__float_as_uint(t) << 32) | low;
+}
+
+// exact reference test of one (ray, sphere) pair reduced into the owner's key (sphere.rs:29-66 with t_max = f32::MAX,
+// then the ancestor-AABB gate of a BVH world)
+__device__ __forceinline__ void pair_test4(const KArgs &A, int k, const float4 c, f3 o, f3 d, float a, unsigned long long *key) {
+    const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
+    const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+    const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
+    const float disc = b * b - a * cc;
+    if (disc > 0.0f) {
+        float t = kMaxT;
+        if (sphere_roots(a, b, disc, t)) {
+            const unsigned long long kk = key4_of(A, t, k);
+            if (kk < *key && (!A.gate || gate_pass(A, k, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z)))) atomicMin(key, kk);
+        }
+    }
+}
+
+template <bool MOVING, int BLK>
+__device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, f3 o, f3 d, float a,
+                                       float time, Trav4 &st) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t incl = wave_inclusive_sum(st.qn);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total == 0u) return;
+    if (total > (uint32_t)kPairCap) {
+        // more pairs than the wave's list holds: every lane tests its own (rare: the queues drain at > 4 entries)
+        for (uint32_t j = 0; __any(j < st.qn); ++j)
+            if (j < st.qn) {
+                const int k = (int)leafq[j * BLK + tid];
+                pair_test4(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, a, &w_keys[lane]);
+            }
+    } else {
+        uint32_t pos = incl - st.qn;
+        for (uint32_t j = 0; j < st.qn; ++j) w_pairs[pos++] = ((uint32_t)lane << kPairLaneShift) | leafq[j * BLK + tid];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t base = 0; base < total; base += 64u) {
+            const bool valid = base + (uint32_t)lane < total;
+            const uint32_t e = valid ? w_pairs[base + lane] : 0u;
+            const uint32_t owner = e >> kPairLaneShift;
+            const int k = (int)(e & ((1u << kPairLaneShift) - 1u));
+            const f3 po = mk3(lane_fetch(owner, o.x), lane_fetch(owner, o.y), lane_fetch(owner, o.z));
+            const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));
+            const float pa = lane_fetch(owner, a);
+            const float ptime = MOVING ? lane_fetch(owner, time) : 0.0f;
+            if (valid) pair_test4(A, k, sphere_at<MOVING>(A, k, A.spheres[k], ptime), po, pd, pa, &w_keys[owner]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    st.qn = 0;
+    st.best = __uint_as_float((uint32_t)(w_keys[lane] >> 32));
+}
+
+template <bool MOVING>
+__device__ __forceinline__ void bvh4_start(const KArgs &A, unsigned long long *w_keys, f3 o, f3 d, float a, float time, Trav4 &st) {
+    const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // ray.rs:14
+    float best = kMaxT;
+    int idx = -1;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < A.n_bvh_large; ++j) {   // spheres kept out of the tree: tested for every ray
+        const int k = (int)A.bvh_large[j];
+        bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, rcp, a, best, idx, rank);
+    }
+    w_keys[threadIdx.x & 63] = idx < 0 ? ~0ull : key4_of(A, best, idx);
+    st.best = idx < 0 ? kMaxT : best;
+    st.sp = 0;
+    st.qn = 0;
+    st.cur = A.bvh_root >= 0 ? 0 : kNoChild4;
+    st.active = true;
+}
+
+template <bool MOVING, bool COUNT, int BLK>
+__device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys,
+                                         f3 o, f3 d, float a, float time, bool have, Trav4 &st, unsigned long long *sec = nullptr) {
+    const int tid = threadIdx.x;
+#ifdef PT_SECTIONS
+    unsigned long long sub_last = __builtin_readcyclecounter();   // sec[5] node visits, sec[6] drains, sec[7] trips (count)
+#define PT_SUB4(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); sec[i] += now_ - sub_last; sub_last = now_; } while (0)
+#else
+    (void)sec;
+#define PT_SUB4(i) do { } while (0)
+#endif
+    const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // per-ray constants of the plane test: t = plane * rcp + B; the FMA form loses ~eps * |o| of position against
+    // (plane - o) * rcp, which the pad below carries on top of the node's bound
+    const float Bx = -o.x * rcp.x, By = -o.y * rcp.y, Bz = -o.z * rcp.z;
+    const float arx = __builtin_fabsf(rcp.x), ary = __builtin_fabsf(rcp.y), arz = __builtin_fabsf(rcp.z);
+    const float pad_ray = 1.0e-6f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z));
+    // byte offsets of the near / far plane arrays of each axis inside a node (lo at 0/16/32, hi at 48/64/80)
+    const uint32_t nxo = d.x < 0.0f ? 48u : 0u, nyo = d.y < 0.0f ? 64u : 16u, nzo = d.z < 0.0f ? 80u : 32u;
+    const uint32_t fxo = 48u - nxo, fyo = 80u - nyo, fzo = 112u - nzo;
+    const char *base = reinterpret_cast<const char *>(A.nodes4);
+    for (;;) {
+        if (st.active) {
+            if (st.cur == kNoChild4) {
+                if (st.sp == 0) st.active = false;
+                else st.cur = (int32_t)s_stack[(--st.sp) * BLK + tid];
+            }
+            if (st.active) {
+                const uint32_t off = (uint32_t)st.cur << 7;
+                const float4 pnx = *reinterpret_cast<const float4 *>(base + (size_t)(off + nxo));
+                const float4 pny = *reinterpret_cast<const float4 *>(base + (size_t)(off + nyo));
+                const float4 pnz = *reinterpret_cast<const float4 *>(base + (size_t)(off + nzo));
+                const float4 pfx = *reinterpret_cast<const float4 *>(base + (size_t)(off + fxo));
+                const float4 pfy = *reinterpret_cast<const float4 *>(base + (size_t)(off + fyo));
+                const float4 pfz = *reinterpret_cast<const float4 *>(base + (size_t)(off + fzo));
+                const int4 ch = *reinterpret_cast<const int4 *>(base + (size_t)off + 96);
+                const float4 meta = *reinterpret_cast<const float4 *>(base + (size_t)off + 112);
+                if (COUNT) st.visits += 1u;
+                // node-level pad: 6e-6 / r_min * (|c - o|^2 + |h|^2) + 1e-4 (+ the FMA form's own loss)
+                const uint32_t ph = __float_as_uint(meta.w);
+                const float pk = (float)__builtin_bit_cast(_Float16, (unsigned short)(ph & 0xffffu));
+                const float p0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(ph >> 16));
+                const float ex = meta.x - o.x, ey = meta.y - o.y, ez = meta.z - o.z;
+                const float pad = __builtin_fmaf(pk, __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)), p0) + pad_ray;
+                const float Bnx = __builtin_fmaf(-pad, arx, Bx), Bny = __builtin_fmaf(-pad, ary, By), Bnz = __builtin_fmaf(-pad, arz, Bz);
+                const float Bfx = __builtin_fmaf(pad, arx, Bx), Bfy = __builtin_fmaf(pad, ary, By), Bfz = __builtin_fmaf(pad, arz, Bz);
+                const float limit = st.best < kMaxT ? (st.best * kCullRel + kCullAbs) : kMaxT;
+                const float nx[4] = {pnx.x, pnx.y, pnx.z, pnx.w}, ny[4] = {pny.x, pny.y, pny.z, pny.w}, nz[4] = {pnz.x, pnz.y, pnz.z, pnz.w};
+                const float fx[4] = {pfx.x, pfx.y, pfx.z, pfx.w}, fy[4] = {pfy.x, pfy.y, pfy.z, pfy.w}, fz[4] = {pfz.x, pfz.y, pfz.z, pfz.w};
+                const int32_t cr[4] = {ch.x, ch.y, ch.z, ch.w};
+                // Inner children occupy the first slots and are consecutive nodes (child[j] = child[0] + j), leaves (~sphere)
+                // follow, empty slots last. Everything below is branch-free: a slot's queue / stack entry is written
+                // unconditionally and only COUNTED when the child was hit.
+                uint32_t key[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // NaNs (0 * inf) drop out of max3 / min3: that axis then imposes nothing, i.e. they count as a hit
+                    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(nx[j], rcp.x, Bnx), __builtin_fmaf(ny[j], rcp.y, Bny)),
+                                                                     __builtin_fmaf(nz[j], rcp.z, Bnz)), 0.0f);
+                    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(fx[j], rcp.x, Bfx), __builtin_fmaf(fy[j], rcp.y, Bfy)),
+                                                     __builtin_fmaf(fz[j], rcp.z, Bfz));
+                    const bool hit = !(tf < tn) && !(tn > limit) && cr[j] != kNoChild4;
+                    leafq[st.qn * BLK + tid] = (uint32_t)~cr[j];
+                    st.qn += (hit && cr[j] < 0) ? 1u : 0u;       // leaf child: one more candidate for the exact test
+                    if (COUNT) st.leaves += (hit && cr[j] < 0) ? 1u : 0u;
+                    key[j] = (hit && cr[j] >= 0) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xffffffffu;
+                }
+                // sort the inner children by entry distance (5 compare-exchanges), push far-to-near, continue with the nearest
+#define PT_CE(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+                PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+                const uint32_t cbase = (uint32_t)cr[0];
+                // (16-bit stack entries: the 4-wide tree is only used while it has fewer than 65536 nodes)
+                s_stack[st.sp * BLK + tid] = (uint16_t)(cbase + (key[3] & 3u));
+                st.sp += key[3] != 0xffffffffu ? 1 : 0;
+                s_stack[st.sp * BLK + tid] = (uint16_t)(cbase + (key[2] & 3u));
+                st.sp += key[2] != 0xffffffffu ? 1 : 0;
+                s_stack[st.sp * BLK + tid] = (uint16_t)(cbase + (key[1] & 3u));
+                st.sp += key[1] != 0xffffffffu ? 1 : 0;
+                st.cur = key[0] != 0xffffffffu ? (int32_t)(cbase + (key[0] & 3u)) : kNoChild4;
+                if (st.cur == kNoChild4 && st.sp == 0) st.active = false;
+            }
+        }
+        const unsigned long long act = __ballot(st.active);
+        const bool stop = act == 0ull || __popcll(__ballot(have && !st.active)) >= kReadyMin;
+        PT_SUB4(5);
+#ifdef PT_SECTIONS
+        sec[7] += 1ull;
+#endif
+        if (stop || __any(st.qn > (uint32_t)(kLeafQ - 4))) drain4<MOVING, BLK>(A, leafq, w_pairs, w_keys, o, d, a, time, st);
+        PT_SUB4(6);
+        if (stop) break;
+    }
+}
+
 // SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
 // (staged once per workgroup); otherwise from HBM/L2 through wave-uniform loads.
 // PILOT: the 1-spp cost-estimation pass (own symbol so profiles keep it apart from the frame kernel)
@@ -1014,8 +1230,9 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
 // 768-thread workgroup per CU when the scene allows: the sphere fragments are then staged once per CU instead of three
 // times, and the LDS that frees holds the per-lane attenuation stacks (no HBM traffic for them).
 template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false, bool GATE = false, int BLK = kBlock>
-__global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_trace_kernel(const KArgs A) {
+__global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4_WAVES : PT_MINWAVES) : 1) void pt_trace_kernel(const KArgs A) {
     static_assert(BLK == kBlock || (MFMA && !BVH), "only the MFMA list kernels take another workgroup size");
+    constexpr bool TREE4 = BVH && SPH_LDS;   // tree kernels: SPH_LDS selects the 4-wide tree (false: the binary one, variant bit 2048)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
     float4 *s_sph = reinterpret_cast<float4 *>(smem);  // list mode: n_spheres x (cx,cy,cz,r^2)
@@ -1024,13 +1241,14 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
     uint32_t *s_perm = reinterpret_cast<uint32_t *>(p + (A.has_noise ? 4096 : 0));
     p += A.has_noise ? (4096 + 3072) : 0;
     uint32_t *s_bvh = reinterpret_cast<uint32_t *>(p);
-    p += BVH ? (A.bvh_stack_entries * BLK * 4) : 0;
+    p += BVH ? (A.bvh_stack_entries * BLK * (TREE4 ? 2 : 4)) : 0;   // (4-wide tree: 16-bit entries, an even number of them)
     DWideNode *s_nodes = reinterpret_cast<DWideNode *>(p);
     p += (BVH && A.nodes_in_lds) ? A.n_nodes * 64u : 0u;
     uint16_t *s_queue = reinterpret_cast<uint16_t *>(p);  // exact scan: [kQueueCap+1][BLK] u16; MFMA: [kEntCap][BLK] u32 tile masks + per-wave pair lists
-    uint32_t *w_pairs = reinterpret_cast<uint32_t *>(p + kEntCap * BLK * 4 + (threadIdx.x >> 6) * kWavePairBytes);
+    //                                                   4-wide tree: [kLeafQ][BLK] u32 leaf candidates + per-wave pair lists
+    uint32_t *w_pairs = reinterpret_cast<uint32_t *>(p + (TREE4 ? kLeafQ : kEntCap) * BLK * 4 + (threadIdx.x >> 6) * kWavePairBytes);
     unsigned long long *w_keys = reinterpret_cast<unsigned long long *>(w_pairs + kPairCap);
-    p += BVH ? 0u : (MFMA ? mfma_queue_bytes(BLK) : scan_queue_bytes(BLK));
+    p += BVH ? (TREE4 ? tree4_queue_bytes(BLK) : 0u) : (MFMA ? mfma_queue_bytes(BLK) : scan_queue_bytes(BLK));
     uint4 *s_afrag = reinterpret_cast<uint4 *>(p);        // MFMA: [n_tiles][2][64] x 16 B
     p += MFMA ? A.n_tiles * 2048u : 0u;
     uint16_t *s_tile_sphere = reinterpret_cast<uint16_t *>(p);
@@ -1108,6 +1326,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
     bool have = false, exhausted = false, need_cam = true, trav_new = false, finished = false;
     uint32_t lane_tile = 0, pix_rays = 0;
     BvhTrav trav{0u, 0u, 0, kMaxT, -1, 0u, false};
+    Trav4 trav4{0u, 0u, 0, kNoChild4, 0u, kMaxT, false};
     uint32_t px = 0, py = 0, boff = 0, sample = 0, depth = 0, nrays = 0;
     Rng rng{0, 0, 0, 0};
     f3 col = mk3(0.f, 0.f, 0.f), o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
@@ -1204,7 +1423,24 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
         const float a = dot3(rd, rd);  // sphere.rs:34
         float t_hit;
         int idx;
-        if (BVH) {
+        if (TREE4) {
+            if (have && trav_new) {
+                bvh4_start<MOVING>(A, w_keys, o, d, dot3(d, d), rtime, trav4);
+                trav_new = false;
+            }
+            bvh4_run<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint16_t *>(s_bvh), reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, ro, rd, a, rtime, have, trav4
+#ifdef PT_SECTIONS
+                                          , sec_t
+#endif
+                                          );
+            idx = -1, t_hit = kMaxT;
+            if (have && !trav4.active) {   // (lanes without a finished ray hold a stale or never-written key)
+                const unsigned long long key = w_keys[lane];
+                const uint32_t low = (uint32_t)key;
+                if (key != ~0ull) idx = (int)(A.gate ? A.rank_sphere[0xffffffffu - low] : low);
+                t_hit = __uint_as_float((uint32_t)(key >> 32));
+            }
+        } else if (BVH) {
             if (have && trav_new) {
                 bvh_start<MOVING>(A, s_bvh, o, d, dot3(d, d), rtime, trav);
                 trav_new = false;
@@ -1228,7 +1464,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
 
         PT_SEC(2);
         // ---- scene.rs:49-71 one level of ray_trace (BVH mode: only lanes whose traversal has finished)
-        if (have && !(BVH && trav.active)) {
+        if (have && !(BVH && (TREE4 ? trav4.active : trav.active))) {
             nrays += 1;
             pix_rays += 1;
             bool terminal = true;
@@ -1356,8 +1592,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? PT_MINWAVES : 1) void pt_tra
 #endif
     if (A.wave_end && lane == 0) A.wave_end[blockIdx.x * (BLK / 64) + (tid >> 6)] = wall_clock64();
     if (BVH && VERIFY) {   // traversal counters (accumulate over the lane's whole life: never reset per ray)
-        atomicAdd(&A.debug[8], (unsigned long long)trav.visits);
-        atomicAdd(&A.debug[9], (unsigned long long)trav.leaves + (unsigned long long)nrays * A.n_bvh_large);
+        atomicAdd(&A.debug[8], (unsigned long long)(TREE4 ? trav4.visits : trav.visits));
+        atomicAdd(&A.debug[9], (unsigned long long)(TREE4 ? trav4.leaves : trav.leaves) + (unsigned long long)nrays * A.n_bvh_large);
     }
     // scene.rs:118 ray_count: wave reduce, one atomic per wave
     unsigned long long total = nrays;

@@ -68,7 +68,9 @@ struct pt_scene {
     uint32_t n_bvh_large = 0;
     int32_t accel_root = -1;
     DWideNode *d_wnodes = nullptr;
-    uint32_t *d_leaf_rank = nullptr;
+    DNode4 *d_nodes4 = nullptr;               // 4-wide internal tree (default of the tree kernels)
+    uint32_t n_nodes4 = 0, depth4 = 0;
+    uint32_t *d_leaf_rank = nullptr, *d_rank_sphere = nullptr;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     // MFMA prefilter data (n_tiles == 0: prefilter not applicable to this scene)
     uint4 *d_afrag = nullptr;
@@ -502,8 +504,9 @@ AccelRef accel_build(std::vector<AccelItem> &items, size_t lo, size_t hi, std::v
     return out;
 }
 
-AccelBuild build_accel(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi) {
-    AccelBuild out;
+// Spheres that go into the internal tree (with the box of their whole sweep when they move); the rest -- huge,
+// degenerate or non-finite ones -- are returned in `large` and tested for every ray.
+std::vector<AccelItem> accel_items(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi, std::vector<uint32_t> &large) {
     std::vector<float> radii;
     for (uint32_t i = 0; i < desc->n_spheres; ++i) radii.push_back(std::fabs(desc->spheres[i].radius));
     std::vector<float> sorted = radii;
@@ -515,7 +518,7 @@ AccelBuild build_accel(const pt_scene_desc *desc, const MotionIn *motion, double
         const float r = radii[i];
         const bool finite = std::isfinite(p.cx) && std::isfinite(p.cy) && std::isfinite(p.cz) && std::isfinite(r);
         if (!finite || r > 16.0f * median || !(r > 0.0f)) {
-            out.large.push_back(i);
+            large.push_back(i);
             continue;
         }
         AccelItem it{i, {p.cx, p.cy, p.cz}, {p.cx - r, p.cy - r, p.cz - r}, {p.cx + r, p.cy + r, p.cz + r}, r, p.radius, {p.cx, p.cy, p.cz}};
@@ -533,12 +536,127 @@ AccelBuild build_accel(const pt_scene_desc *desc, const MotionIn *motion, double
         items.push_back(it);
     }
     if (items.size() < 2) {  // degenerate: everything is tested directly
-        for (const AccelItem &it : items) out.large.push_back(it.sphere);
-        return out;
+        for (const AccelItem &it : items) large.push_back(it.sphere);
+        items.clear();
     }
+    return items;
+}
+
+AccelBuild build_accel(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi) {
+    AccelBuild out;
+    std::vector<AccelItem> items = accel_items(desc, motion, t_lo, t_hi, out.large);
+    if (items.empty()) return out;
     const AccelRef root = accel_build(items, 0, items.size(), out.nodes);
     out.root = root.ref;
     out.depth = root.depth;
+    return out;
+}
+
+// ---- 4-wide internal tree (pt_kernel.h DNode4) -----------------------------------------------------------------
+// Same split rule as the binary tree (longest axis of the centroid bounds, ties by sphere index) applied twice per
+// node; a segment of n spheres gets ceil(n / m) children of equal size, m = the smallest power of 4 with 4 m >= n, so
+// the tree is balanced and its bottom nodes are mostly full. A child with one sphere is a leaf slot (~sphere).
+struct Accel4Build {
+    std::vector<DNode4> nodes;
+    std::vector<uint32_t> large;
+    uint32_t depth = 0;
+};
+struct Accel4Ref {
+    int32_t ref;
+    float mn[3], mx[3], rmin;
+    uint32_t depth;
+};
+
+void accel4_split(std::vector<AccelItem> &items, size_t lo, size_t hi, size_t at) {   // items[lo, at) | items[at, hi) along the longest axis
+    float cmin[3] = {3e38f, 3e38f, 3e38f}, cmax[3] = {-3e38f, -3e38f, -3e38f};
+    for (size_t i = lo; i < hi; ++i)
+        for (int k = 0; k < 3; ++k) cmin[k] = std::min(cmin[k], items[i].c[k]), cmax[k] = std::max(cmax[k], items[i].c[k]);
+    int axis = 0;
+    for (int k = 1; k < 3; ++k)
+        if (cmax[k] - cmin[k] > cmax[axis] - cmin[axis]) axis = k;
+    std::nth_element(items.begin() + lo, items.begin() + at, items.begin() + hi,
+                     [axis](const AccelItem &a, const AccelItem &b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.sphere < b.sphere); });
+}
+
+uint16_t f16_up(double v) {   // smallest f16 >= v (v > 0, far below the f16 range limit)
+    _Float16 h = (_Float16)v;
+    while ((double)h < v) {
+        uint16_t u = f16_bits(h);
+        ++u;
+        memcpy(&h, &u, 2);
+    }
+    return f16_bits(h);
+}
+
+// Builds the node `self` (already allocated) over items[lo, hi), n >= 2. Inner children take the node's first slots and
+// consecutive node indices (the kernel addresses them as child[0] + slot); single spheres follow as leaf slots.
+Accel4Ref accel4_build(std::vector<AccelItem> &items, size_t lo, size_t hi, std::vector<DNode4> &nodes, int32_t self) {
+    const size_t n = hi - lo;
+    size_t m = 1;
+    while (4 * m < n) m *= 4;
+    const size_t c = (n + m - 1) / m;                 // 2..4 children
+    size_t cut[5];
+    for (size_t j = 0; j <= c; ++j) cut[j] = lo + n * j / c;
+    const size_t half = (c + 1) / 2;                  // children on the low side of the first split
+    accel4_split(items, lo, hi, cut[half]);
+    if (half == 2) accel4_split(items, lo, cut[2], cut[1]);
+    if (c - half == 2) accel4_split(items, cut[half], hi, cut[half + 1]);
+    std::vector<size_t> order;                        // inner children (more than one sphere) first, then leaves
+    for (size_t j = 0; j < c; ++j)
+        if (cut[j + 1] - cut[j] > 1) order.push_back(j);
+    const size_t n_inner = order.size();
+    for (size_t j = 0; j < c; ++j)
+        if (cut[j + 1] - cut[j] == 1) order.push_back(j);
+    const int32_t first = (int32_t)nodes.size();
+    nodes.resize(nodes.size() + n_inner);
+    Accel4Ref out{self, {3e38f, 3e38f, 3e38f}, {-3e38f, -3e38f, -3e38f}, 3e38f, 0};
+    DNode4 w;
+    memset(&w, 0, sizeof w);
+    for (size_t j = 0; j < 4; ++j) {
+        if (j >= c) {   // empty slot: never hit (and checked by its ref)
+            for (int k = 0; k < 3; ++k) w.lo[k][j] = 3.0e38f, w.hi[k][j] = -3.0e38f;
+            w.child[j] = kNoChild4;
+            continue;
+        }
+        const size_t a = cut[order[j]], b = cut[order[j] + 1];
+        Accel4Ref ch;
+        if (b - a == 1) {
+            const AccelItem &it = items[a];
+            ch = Accel4Ref{~(int32_t)it.sphere, {it.mn[0], it.mn[1], it.mn[2]}, {it.mx[0], it.mx[1], it.mx[2]}, it.r, 0};
+        } else {
+            ch = accel4_build(items, a, b, nodes, first + (int32_t)j);
+        }
+        for (int k = 0; k < 3; ++k) {
+            w.lo[k][j] = ch.mn[k], w.hi[k][j] = ch.mx[k];
+            out.mn[k] = std::min(out.mn[k], ch.mn[k]), out.mx[k] = std::max(out.mx[k], ch.mx[k]);
+        }
+        w.child[j] = ch.ref;
+        out.rmin = std::min(out.rmin, ch.rmin);
+        out.depth = std::max(out.depth, ch.depth + 1);
+    }
+    // node-level pad of the conservative box test: >= 4x the bound on how far the reference's f32 discriminant inflates a
+    // sphere (0.65e-6 (|o - c|^2 + r^2) / r), with |o - c_sphere|^2 <= 2 (|o - c_node|^2 + |h_node|^2); stored as two
+    // f16 rounded UP: k = 6e-6 / r_min and k |h|^2 + 1e-4 (+ f32 rounding of the centre)
+    double h2 = 0.0, cmag = 0.0;
+    float ctr[3];
+    for (int k = 0; k < 3; ++k) {
+        ctr[k] = (float)(0.5 * ((double)out.mn[k] + (double)out.mx[k]));
+        const double h = std::max((double)out.mx[k] - (double)ctr[k], (double)ctr[k] - (double)out.mn[k]);
+        h2 += h * h, cmag += std::fabs((double)ctr[k]);
+    }
+    const double pk = 6.0e-6 / (double)out.rmin;
+    w.cx = ctr[0], w.cy = ctr[1], w.cz = ctr[2];
+    w.padh = (uint32_t)f16_up(pk * 1.001) | ((uint32_t)f16_up((pk * h2 + 1.0e-4 + 1.0e-6 * cmag) * 1.001) << 16);
+    nodes[self] = w;
+    return out;
+}
+
+Accel4Build build_accel4(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi) {
+    Accel4Build out;
+    std::vector<AccelItem> items = accel_items(desc, motion, t_lo, t_hi, out.large);
+    if (items.empty()) return out;
+    out.nodes.resize(1);
+    out.depth = accel4_build(items, 0, items.size(), out.nodes, 0).depth;
     return out;
 }
 
@@ -673,7 +791,7 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
     // BVH mode: per-sphere parent AABB + DFS rank from the CALLER's tree (they define the result), and the
     // internal traversal tree.
     std::vector<DWideNode> wnodes;
-    std::vector<uint32_t> leaf_rank(desc->n_spheres, 0), bvh_large;
+    std::vector<uint32_t> leaf_rank(desc->n_spheres, 0), bvh_large, rank_sphere;
     std::vector<float4> gate(2 * (size_t)desc->n_spheres, make_float4(0, 0, 0, 0)), gate_chain;
     uint32_t accel_depth = 0;
     if (desc->n_bvh_nodes) {
@@ -706,6 +824,7 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
             path.resize(it.depth);
             if (it.ref < 0) {
                 const uint32_t k = (uint32_t)~it.ref;
+                rank_sphere.push_back(k);
                 leaf_rank[k] = rank++;
                 const pt_bvh_node &pn = desc->bvh_nodes[it.parent];
                 FU cnt{0}, off{(uint32_t)(gate_chain.size() / 2)};
@@ -741,6 +860,13 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
         s->n_nodes = (uint32_t)wnodes.size();
         s->n_bvh_large = (uint32_t)bvh_large.size();
     }
+    std::vector<DNode4> nodes4;
+    {
+        Accel4Build acc4 = build_accel4(desc, motion, t_lo, t_hi);
+        nodes4 = std::move(acc4.nodes);
+        s->n_nodes4 = (uint32_t)nodes4.size();
+        s->depth4 = acc4.depth;
+    }
     std::vector<float4> pvec(256, make_float4(0, 0, 0, 0));
     std::vector<uint32_t> pperm(768, 0);
     if (desc->perlin) {
@@ -758,7 +884,8 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
         (rc = upload(&s->d_perlin_vec, pvec.data(), pvec.size())) || (rc = upload(&s->d_perlin_perm, pperm.data(), pperm.size())) ||
         (rc = upload(&s->d_wnodes, wnodes.data(), wnodes.size())) || (rc = upload(&s->d_leaf_rank, leaf_rank.data(), leaf_rank.size())) ||
         (rc = upload(&s->d_gate, gate.data(), gate.size())) || (rc = upload(&s->d_gate_chain, gate_chain.data(), gate_chain.size())) ||
-        (rc = upload(&s->d_bvh_large, bvh_large.data(), bvh_large.size()))) {
+        (rc = upload(&s->d_bvh_large, bvh_large.data(), bvh_large.size())) || (rc = upload(&s->d_nodes4, nodes4.data(), nodes4.size())) ||
+        (rc = upload(&s->d_rank_sphere, rank_sphere.data(), rank_sphere.size()))) {
         pt_scene_destroy(s);
         return rc;
     }
@@ -1024,6 +1151,8 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_gate_chain);
     (void)hipFree(s->d_bvh_large);
     (void)hipFree(s->d_wnodes);
+    (void)hipFree(s->d_nodes4);
+    (void)hipFree(s->d_rank_sphere);
     (void)hipFree(s->d_leaf_rank);
     (void)hipFree(s->d_afrag);
     (void)hipFree(s->d_tile_sphere);
@@ -1063,6 +1192,17 @@ f3 to3(const float *p) { return f3{p[0], p[1], p[2]}; }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is sticky per kernel: set it when the kernel or its LDS size changes, not
 // on every frame
+// Workgroups of `blk` threads one CU can hold by registers: the unified VGPR file gives min(8, 512 / alloc) waves per SIMD,
+// alloc = the kernel's VGPR count rounded up to the granule of 8 (MI355X_MICROARCH.md "Register files"). A persistent grid
+// must not exceed it: a workgroup that does not fit only starts when another one retires.
+uint32_t blocks_per_cu_by_registers(const void *kern, uint32_t blk) {
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, kern) != hipSuccess || attr.numRegs <= 0) return 8u;
+    const uint32_t alloc = ((uint32_t)attr.numRegs + 7u) / 8u * 8u;
+    const uint32_t waves_per_simd = std::min<uint32_t>(8u, 512u / alloc);
+    return std::max<uint32_t>(1u, waves_per_simd * 4u / (blk / 64u));
+}
+
 int set_lds_limit(pt_scene *s, int slot, const void *kern, uint32_t lds) {
     if (s->attr_kern[slot] == kern && s->attr_lds[slot] == lds) return PT_OK;
     HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1226,6 +1366,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.bvh_large = s->d_bvh_large;
     A.n_bvh_large = s->n_bvh_large;
     A.wnodes = s->d_wnodes;
+    A.nodes4 = s->d_nodes4;
+    A.rank_sphere = s->d_rank_sphere;
     A.leaf_rank = s->d_leaf_rank;
     memcpy(A.root_min, s->root_min, 12);
     memcpy(A.root_max, s->root_max, 12);
@@ -1265,12 +1407,17 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     uint32_t lds = sph_bytes + kLdsParamBytes;
     if (s->has_noise) lds += 4096u + 3072u;
     A.n_nodes = s->n_nodes;
-    A.bvh_stack_entries = s->bvh_depth + 2u;
+    // 4-wide tree (default; variant bit 2048: the binary tree): a visit pushes at most three siblings per level
+    // (its stack entries are 16-bit node indices; a bigger tree -- more than ~190 000 spheres -- walks the binary one)
+    const bool tree4 = bvh && (s->variant & 2048u) == 0 && s->n_nodes4 < 65536u && (s->n_nodes4 > 0 || s->accel_root < 0);
+    // a visit pushes at most three siblings, and only above the bottom level; +3 slots for the unconditional writes, even count
+    A.bvh_stack_entries = tree4 ? ((3u * (s->depth4 ? s->depth4 - 1u : 0u) + 4u) & ~1u) : (s->bvh_depth + 2u);
     // tree nodes go to LDS only while FOUR workgroups still fit on the CU (with two levels of attenuation stack each):
     // the fourth wave per SIMD is worth more than LDS-resident nodes (random_spheres -B on the tree kernel: 7.4 vs 6.3
     // Grays/s), and the nodes stay L2-resident anyway
-    if (bvh) lds += A.bvh_stack_entries * kBlock * 4u;
-    A.nodes_in_lds = (bvh && (s->variant & 1u) == 0 && lds + s->n_nodes * 64u + 2u * 3u * kBlock * 4u <= kLdsBudget / 4u) ? 1u : 0u;
+    if (bvh) lds += A.bvh_stack_entries * kBlock * (tree4 ? 2u : 4u);
+    if (tree4) lds += tree4_queue_bytes(kBlock);
+    A.nodes_in_lds = (bvh && !tree4 && (s->variant & 1u) == 0 && lds + s->n_nodes * 64u + 2u * 3u * kBlock * 4u <= kLdsBudget / 4u) ? 1u : 0u;
     if (A.nodes_in_lds) lds += s->n_nodes * 64u;
     // Workgroup size. The MFMA list kernels run ONE 768-thread workgroup per CU when everything fits: the sphere
     // fragments (identical in every workgroup) are staged once per CU, and the LDS that frees holds the per-lane
@@ -1295,7 +1442,10 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (blk == kWideBlock) {
         lds_levels = stack_levels;
     } else if (bvh && (s->variant & 2u) == 0) {
-        const uint32_t per_block = kLdsBudget / 4u;
+        // workgroups per CU the registers allow (4 for the binary tree kernel's 123 VGPRs)
+        const uint32_t wg_regs = tree4 ? blocks_per_cu_by_registers(moving ? reinterpret_cast<const void *>(pt_trace_kernel<true, true, false, false, false, true>)
+                                                                           : reinterpret_cast<const void *>(pt_trace_kernel<true, true, false, false, false, false>), kBlock) : 4u;
+        const uint32_t per_block = kLdsBudget / std::min(4u, std::max(1u, wg_regs));
         if (per_block > lds) lds_levels = std::min<uint32_t>(stack_levels, (per_block - lds) / (3u * blk * 4u));
     } else if (!bvh && !mfma && (s->variant & 2u) == 0 && lds + path_bytes <= kLdsPerBlockMax) {
         lds_levels = stack_levels;
@@ -1304,38 +1454,17 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     lds += lds_levels * 3u * blk * 4u;
     A.lds_sphere_bytes = sph_bytes;
 
-    // ---- persistent grid: CUs x resident blocks --------------------------------
-    uint32_t bpc = s->blocks_per_cu;
-    if (bpc == 0) bpc = (blk == kWideBlock) ? 1u : (bvh ? 4u : 3u);
-    const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
-    if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
-    if (bpc > 8u) bpc = 8u;
-    uint32_t grid = (uint32_t)s->num_cus * bpc;
-    const uint32_t need = (A.n_items + blk - 1) / blk;
-    if (grid > need) grid = need;
-    if (grid == 0) grid = 1;
-
-    if (lds_levels < stack_levels) {
-        const size_t need_floats = (size_t)grid * params->max_depth * 3ull * blk;
-        if (need_floats > s->d_gstack_floats) {
-            (void)hipFree(s->d_gstack);
-            s->d_gstack = nullptr;
-            s->d_gstack_floats = 0;
-            HIP_TRY(hipMalloc((void **)&s->d_gstack, need_floats * sizeof(float)));
-            s->d_gstack_floats = need_floats;
-        }
-        A.gstack = s->d_gstack;
-    }
-
     A.tile_order = nullptr;
     A.tile_cost = nullptr;
 
     void (*kern)(const KArgs) = nullptr;
     void (*pilot_kern)(const KArgs) = nullptr;
     if (bvh && (A.verify & 1u))   // variant 8 on a tree kernel: count node fetches / sphere tests (no pilot: one launch to count)
-        kern = moving ? pt_trace_kernel<true, false, false, true, false, true> : pt_trace_kernel<true, false, false, true, false, false>;
+        kern = tree4 ? (moving ? pt_trace_kernel<true, true, false, true, false, true> : pt_trace_kernel<true, true, false, true, false, false>)
+                     : (moving ? pt_trace_kernel<true, false, false, true, false, true> : pt_trace_kernel<true, false, false, true, false, false>);
     else if (moving && bvh)
-        kern = pt_trace_kernel<true, false, false, false, false, true>, pilot_kern = pt_trace_kernel<true, false, false, false, true, true>;
+        kern = tree4 ? pt_trace_kernel<true, true, false, false, false, true> : pt_trace_kernel<true, false, false, false, false, true>,
+        pilot_kern = tree4 ? pt_trace_kernel<true, true, false, false, true, true> : pt_trace_kernel<true, false, false, false, true, true>;
     else if (mfma && ref_bvh && moving && (A.verify & 1u))
         kern = pt_trace_kernel<false, true, true, true, false, true, true>;
     else if (mfma && ref_bvh && moving && blk == kWideBlock)
@@ -1355,7 +1484,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     else if (moving)
         kern = pt_trace_kernel<false, true, true, false, false, true>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true>;
     else if (bvh)
-        kern = pt_trace_kernel<true, false, false, false, false>, pilot_kern = pt_trace_kernel<true, false, false, false, true>;
+        kern = tree4 ? pt_trace_kernel<true, true, false, false, false> : pt_trace_kernel<true, false, false, false, false>,
+        pilot_kern = tree4 ? pt_trace_kernel<true, true, false, false, true> : pt_trace_kernel<true, false, false, false, true>;
     else if (mfma && (A.verify & 1u))
         kern = pt_trace_kernel<false, true, true, true, false>;
     else if (mfma && blk == kWideBlock)
@@ -1366,6 +1496,30 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         kern = pt_trace_kernel<false, true, false, false, false>, pilot_kern = pt_trace_kernel<false, true, false, false, true>;
     else
         kern = pt_trace_kernel<false, false, false, false, false>;
+    // ---- persistent grid: CUs x resident blocks --------------------------------
+    uint32_t bpc = s->blocks_per_cu;
+    if (bpc == 0) bpc = (blk == kWideBlock) ? 1u : (bvh ? 4u : 3u);
+    const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
+    if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
+    if (bpc > 8u) bpc = 8u;
+    if (s->blocks_per_cu == 0) bpc = std::min(bpc, blocks_per_cu_by_registers(reinterpret_cast<const void *>(kern), blk));
+    uint32_t grid = (uint32_t)s->num_cus * bpc;
+    const uint32_t need = (A.n_items + blk - 1) / blk;
+    if (grid > need) grid = need;
+    if (grid == 0) grid = 1;
+
+    if (lds_levels < stack_levels) {
+        const size_t need_floats = (size_t)grid * params->max_depth * 3ull * blk;
+        if (need_floats > s->d_gstack_floats) {
+            (void)hipFree(s->d_gstack);
+            s->d_gstack = nullptr;
+            s->d_gstack_floats = 0;
+            HIP_TRY(hipMalloc((void **)&s->d_gstack, need_floats * sizeof(float)));
+            s->d_gstack_floats = need_floats;
+        }
+        A.gstack = s->d_gstack;
+    }
+
     if (pilot_kern)
         if (int rc = set_lds_limit(s, 1, reinterpret_cast<const void *>(pilot_kern), lds)) return rc;
     if (int rc = set_lds_limit(s, 0, reinterpret_cast<const void *>(kern), lds)) return rc;
@@ -1444,7 +1598,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         static const char *names[8] = {"refill", "camera", "intersect", "shade+terminal", "epilogue", "  features", "  tiles", "  phase2"};
         fprintf(stderr, "[ptgpu sections]");
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)sec[i] / tot);
-        fprintf(stderr, "\n");
+        // (4-wide tree kernels: features = node visits, tiles = candidate drains, and the last slot COUNTS wave-trips)
+        fprintf(stderr, "  | raw: intersect %.3g cycles, slot7 %.3g, total %.3g\n", (double)sec[2], (double)sec[7], tot);
     }
 #endif
     if (timing) {  // development aid: distribution of wave finish times
