@@ -280,6 +280,15 @@ int pt_last_pass_ms(pt_scene *scene, float *ms_out);
 int pt_last_launch_info(pt_scene *scene, uint32_t *grid_out, uint32_t *block_out,
                         uint32_t *lds_bytes_out);
 
+/* The traversal tree the library builds for itself in pt_scene_create (it never affects results): a
+ * 4-wide tree over the sphere centres / sweeps, built ON THE DEVICE (level-synchronous: one global stable radix sort per
+ * phase, csrc/pt_build.hip) -- it replaces, for traversal only, BVHNode::new (bvh.rs:64-94,268-333). build_ms = device time
+ * of that build (HIP events), n_nodes / depth = its size, on_device = 0 when the host restatement ran instead
+ * (PTGPU_HOST_BUILD=1, or no device scratch). pt_scene_debug_tree downloads the 128-byte nodes (tests compare the two
+ * builders byte for byte). */
+int pt_scene_build_info(pt_scene *scene, float *build_ms_out, uint32_t *n_nodes_out, uint32_t *depth_out, uint32_t *on_device_out);
+int pt_scene_debug_tree(pt_scene *scene, void *nodes_out, size_t capacity_bytes);
+
 /* Tuning knobs (0 = library default): workgroups resident per CU for the persistent grid, and a
  * kernel-variant bit mask (DESIGN.md "kernel variants"): 1 = scan table from HBM/L2 instead of LDS,
  * 2 = attenuation stack in HBM (MFMA kernels: 3 x 256 threads per CU instead of 1 x 768),
@@ -287,7 +296,8 @@ int pt_last_launch_info(pt_scene *scene, uint32_t *grid_out, uint32_t *block_out
  * 32 = no heavy-first tile ordering, 64 = never walk the internal tree in list mode (forces the scan),
  * 128 = trace Sphere + MovingSphere worlds with the general kernel instead of the MOVING sphere kernels,
  * 256 = use_bvh worlds always walk the internal tree (default: the MFMA list kernel + ancestor gate when it fits),
- * 1024 = the MFMA kernels run every sphere tile for every wave (no tile culling). */
+ * 1024 = the MFMA kernels run every sphere tile for every wave (no tile culling),
+ * 2048 = the tree kernels walk the binary internal tree (host-built) instead of the 4-wide one. */
 int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
 
 /* Verify-mode counters of the MFMA prefilter (variant bit 8): out4 = { exact-positive pairs the

@@ -195,11 +195,12 @@ __device__ __forceinline__ float schlick_ref(float cosine, float ref_idx) {
     return r0 + (1.0f - r0) * pow5_ref(1.0f - cosine);
 }
 
-// Rust `f32 as usize` (saturating, NaN -> 0) followed by `& 255`
+// Rust `f32 as usize` (saturating, NaN -> 0) followed by `& 255`, branch-free. A float >= 2^31 is a multiple of 256
+// (its ulp is), so its low byte is 0 -- except at saturation (f >= 2^64 -> usize::MAX, low byte 255); below 2^31 the
+// 32-bit conversion is exact. v_cvt_u32_f32 itself maps NaN and negatives to 0.
 __device__ __forceinline__ uint32_t floor_as_usize_low8(float f) {
-    if (!(f > 0.0f)) return 0u;
-    if (f >= 18446744073709551616.0f) return 255u;
-    return (uint32_t)((unsigned long long)f) & 255u;
+    const uint32_t low = (uint32_t)__builtin_fminf(__builtin_fmaxf(f, 0.0f), 2147483520.0f) & 255u;   // NaN -> 0 (fmaxf returns the number)
+    return f >= 18446744073709551616.0f ? 255u : (f >= 2147483648.0f ? 0u : low);
 }
 
 }  // namespace ptdev

@@ -17,6 +17,7 @@
 // DESIGN.md section 4 has the derivations and the error budget.
 #pragma once
 #include "pt_device.h"
+#include "pt_tree4.h"
 #include "ptgpu.h"
 
 namespace ptdev {
@@ -53,7 +54,6 @@ struct DTex {  // 32 B
     float pad;
 };
 struct DWideNode;
-struct DNode4;
 
 // Per-sphere shading record: everything Material::scatter / emitted needs for the common cases, resolved at
 // scene creation so a hit costs one 64-byte fetch instead of the dependent chain
@@ -131,6 +131,8 @@ struct KArgs {
     float inv_nx, inv_ny, inv_ns, mix_prev, mix_new;  // scene.rs:82-87 (computed on the host in f32)
     uint32_t random_seed;
     uint32_t refill_min;         // lanes that must be waiting before a wave fetches new pixels (4; 8 below 32 spp)
+    uint32_t ready_min;          // 4-wide tree: lanes with a finished traversal before the wave leaves the traversal loop to shade
+    uint32_t drain_at;           // 4-wide tree: a lane holding more than this many leaf candidates triggers the wave's drain
     uint64_t seed_base;
     // sharding: rows y with y % shard_count == shard_index, compact buffer
     uint32_t shard_index, shard_count, local_rows;
@@ -167,6 +169,11 @@ __device__ __forceinline__ float perlin_noise(const PerlinLds &pn, f3 p) {
     const uint32_t px[2] = {pn.perm[i], pn.perm[(i + 1) & 255]};
     const uint32_t py[2] = {pn.perm[256 + j], pn.perm[256 + ((j + 1) & 255)]};
     const uint32_t pz[2] = {pn.perm[512 + k], pn.perm[512 + ((k + 1) & 255)]};
+    // all eight gradient fetches are issued before the arithmetic starts (one LDS round trip per octave instead of eight)
+    float4 g[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) g[c] = pn.vec[px[c >> 2] ^ py[(c >> 1) & 1] ^ pz[c & 1]];
+    __builtin_amdgcn_sched_barrier(0);
     float accum = 0.0f;
 #pragma unroll
     for (int di = 0; di < 2; ++di) {
@@ -174,9 +181,9 @@ __device__ __forceinline__ float perlin_noise(const PerlinLds &pn, f3 p) {
         for (int dj = 0; dj < 2; ++dj) {
 #pragma unroll
             for (int dk = 0; dk < 2; ++dk) {
-                const float4 g = pn.vec[px[di] ^ py[dj] ^ pz[dk]];
+                const float4 gc = g[di * 4 + dj * 2 + dk];
                 const f3 weight = mk3(u - (float)di, v - (float)dj, w - (float)dk);
-                accum += wu[di] * wv[dj] * ww2[dk] * dot3(mk3(g.x, g.y, g.z), weight);
+                accum += wu[di] * wv[dj] * ww2[dk] * dot3(mk3(gc.x, gc.y, gc.z), weight);
             }
         }
     }
@@ -1025,15 +1032,10 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
 // accept rule, ds_min_u64 on the owner's (t, tie-break) key), so the exact tests run on full waves whatever the spread
 // of the lanes' traversals. A lane's nearest hit so far (`best`, the culling limit) is refreshed from its key after
 // every drain.
-struct DNode4 {  // 128 B
-    float lo[3][4];      // child boxes, plane arrays: lo[axis][child]
-    float hi[3][4];
-    int32_t child[4];    // inner children first: consecutive nodes, child[j] = child[0] + j (>= 0); then leaves (~sphere < 0); kNoChild4 = empty
-    float cx, cy, cz;    // centre of the node's own box
-    uint32_t padh;       // two f16 (rounded up): lo = 6e-6 / r_min below the node, hi = that * |h_node|^2 + 1e-4
-};
-constexpr int32_t kNoChild4 = 0x7fffffff;
-constexpr int kLeafQ = 8;            // per-lane candidate slots; drained when a lane holds more than kLeafQ - 4
+#ifndef PT_LEAFQ
+#define PT_LEAFQ 8
+#endif
+constexpr int kLeafQ = PT_LEAFQ;   // per-lane candidate slots; drained when a lane holds more than kLeafQ - 4
 constexpr uint32_t kPairLaneShift = 26u;   // pair = owner lane << 26 | sphere (scenes up to 2^26 spheres)
 __host__ __device__ constexpr uint32_t tree4_queue_bytes(uint32_t blk) { return (uint32_t)kLeafQ * blk * 4u + (blk / 64u) * kWavePairBytes; }
 
@@ -1208,12 +1210,12 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
             }
         }
         const unsigned long long act = __ballot(st.active);
-        const bool stop = act == 0ull || __popcll(__ballot(have && !st.active)) >= kReadyMin;
+        const bool stop = act == 0ull || __popcll(__ballot(have && !st.active)) >= (int)A.ready_min;
         PT_SUB4(5);
 #ifdef PT_SECTIONS
         sec[7] += 1ull;
 #endif
-        if (stop || __any(st.qn > (uint32_t)(kLeafQ - 4))) drain4<MOVING, BLK>(A, leafq, w_pairs, w_keys, o, d, a, time, st);
+        if (stop || __any(st.qn > A.drain_at)) drain4<MOVING, BLK>(A, leafq, w_pairs, w_keys, o, d, a, time, st);
         PT_SUB4(6);
         if (stop) break;
     }

@@ -1,0 +1,120 @@
+// pt_tree4.h -- the 4-wide internal tree of the tree kernels: node layout and the build rules shared by the DEVICE
+// builder (pt_build.hip) and its host restatement (ptgpu.hip, used as the reference the device build is tested against
+// and as the fallback when no sort scratch can be allocated).
+//
+// The tree replaces, for TRAVERSAL only, the caller's BVHNode tree (bvh.rs:64-94,268-333: random split axis, median
+// split): results never depend on it (closest hit by (t, tie-break)). Build rule, level by level:
+// a segment of n >= 2 spheres gets c = ceil(n / m) children of (nearly) equal size, m = the smallest power of 4 with
+// 4 m >= n; the segment is first ordered along the longest axis of its centroid bounds and cut after the first
+// ceil(c / 2) children, then each side holding two children is ordered along ITS longest axis and cut again. Ordering
+// is a STABLE sort by the coordinate (ties keep the order they had), which is what one global stable radix sort per
+// phase does on the device. A child with one sphere is a leaf slot; inner children come first in the node and get
+// consecutive node indices in level order.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+namespace ptdev {
+
+#if defined(__HIPCC__)
+#define PT_HD __host__ __device__ inline
+#else
+#define PT_HD inline
+#endif
+
+struct DNode4 {  // 128 B
+    float lo[3][4];      // child boxes, plane arrays: lo[axis][child]
+    float hi[3][4];
+    int32_t child[4];    // inner children first: consecutive nodes, child[j] = child[0] + j (>= 0); then leaves (~sphere < 0); kNoChild4 = empty
+    float cx, cy, cz;    // centre of the node's own box
+    uint32_t padh;       // two f16 (rounded up): lo = 6e-6 / r_min below the node, hi = that * |h_node|^2 + 1e-4
+};
+constexpr int32_t kNoChild4 = 0x7fffffff;
+
+// One sphere as the builders see it: centre used for the splits and the box of its whole sweep (moving spheres).
+struct TreeItem {
+    uint32_t sphere;
+    float c[3], mn[3], mx[3], r;
+};
+
+// Box + smallest radius of a subtree (what a parent needs from a child).
+struct TreeBox {
+    float mn[3], mx[3], rmin;
+};
+
+// f32 -> u32 whose unsigned order is the float order (-0 < +0, NaNs at the ends; the builders never see NaN centres)
+PT_HD uint32_t tree_orderable(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Children of a segment of n >= 2 spheres: count c (2..4), cut[j] = offset of child j inside the segment, and how many
+// children lie on the low side of the first cut.
+struct TreePlan {
+    uint32_t c, half, cut[5];
+};
+PT_HD TreePlan tree_plan(uint32_t n) {
+    uint64_t m = 1;
+    while (4 * m < n) m *= 4;
+    TreePlan p;
+    p.c = (uint32_t)((n + m - 1) / m);
+    for (uint32_t j = 0; j <= 4; ++j) p.cut[j] = j <= p.c ? (uint32_t)((uint64_t)n * j / p.c) : n;
+    p.half = (p.c + 1) / 2;
+    return p;
+}
+
+// axis a segment is ordered along: the longest extent of its centroid bounds (max - min per axis, f32), the lower axis on ties
+PT_HD int tree_axis_of_extents(float ex, float ey, float ez) {
+    int axis = 0;
+    float best = ex;
+    if (ey > best) axis = 1, best = ey;
+    if (ez > best) axis = 2;
+    return axis;
+}
+
+// smallest f16 >= v (0 < v far below the f16 limit), independent of how the first conversion rounds
+PT_HD double tree_f16_value(uint16_t bits) { return (double)(float)__builtin_bit_cast(_Float16, bits); }
+PT_HD uint16_t tree_f16_up(double v) {
+    uint16_t u = __builtin_bit_cast(uint16_t, (_Float16)(float)v);
+    while (tree_f16_value(u) < v) ++u;
+    while (u > 0 && tree_f16_value((uint16_t)(u - 1)) >= v) --u;
+    return u;
+}
+
+// Finishes node `w` once its child slots (boxes, refs) are filled: the node's own box, its centre and the pad constants
+// of the conservative box test -- >= 4x the bound on how far the reference's f32 discriminant inflates a sphere
+// (0.65e-6 (|o - c|^2 + r^2) / r), with |o - c_sphere|^2 <= 2 (|o - c_node|^2 + |h_node|^2); stored as two f16 rounded
+// UP: k = 6e-6 / r_min and k |h|^2 + 1e-4 (+ f32 rounding of the centre). Returns the node's box for its parent.
+PT_HD TreeBox tree_finish_node(DNode4 &w, const TreeBox ch[4], uint32_t c) {
+    TreeBox out;
+    for (int k = 0; k < 3; ++k) out.mn[k] = 3e38f, out.mx[k] = -3e38f;
+    out.rmin = 3e38f;
+    for (uint32_t j = 0; j < 4; ++j) {
+        if (j >= c) {   // empty slot: never hit (and checked by its ref)
+            for (int k = 0; k < 3; ++k) w.lo[k][j] = 3.0e38f, w.hi[k][j] = -3.0e38f;
+            w.child[j] = kNoChild4;
+            continue;
+        }
+        for (int k = 0; k < 3; ++k) {
+            w.lo[k][j] = ch[j].mn[k], w.hi[k][j] = ch[j].mx[k];
+            out.mn[k] = ch[j].mn[k] < out.mn[k] ? ch[j].mn[k] : out.mn[k];
+            out.mx[k] = ch[j].mx[k] > out.mx[k] ? ch[j].mx[k] : out.mx[k];
+        }
+        out.rmin = ch[j].rmin < out.rmin ? ch[j].rmin : out.rmin;
+    }
+    double h2 = 0.0, cmag = 0.0;
+    float ctr[3];
+    for (int k = 0; k < 3; ++k) {
+        ctr[k] = (float)(0.5 * ((double)out.mn[k] + (double)out.mx[k]));
+        const double ha = (double)out.mx[k] - (double)ctr[k], hb = (double)ctr[k] - (double)out.mn[k];
+        const double h = ha > hb ? ha : hb;
+        h2 += h * h, cmag += ctr[k] < 0.0f ? -(double)ctr[k] : (double)ctr[k];
+    }
+    const double pk = 6.0e-6 / (double)out.rmin;
+    w.cx = ctr[0], w.cy = ctr[1], w.cz = ctr[2];
+    w.padh = (uint32_t)tree_f16_up(pk * 1.001) | ((uint32_t)tree_f16_up((pk * h2 + 1.0e-4 + 1.0e-6 * cmag) * 1.001) << 16);
+    return out;
+}
+
+}  // namespace ptdev

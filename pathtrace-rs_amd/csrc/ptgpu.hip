@@ -17,6 +17,9 @@
 #include <new>
 #include <vector>
 
+#include <array>
+
+#include "pt_build.h"
 #include "pt_kernel.h"
 #include "pt_world.h"
 
@@ -47,6 +50,15 @@ constexpr uint32_t kLdsPerBlockMax = 96u * 1024u;   // leave room for >= 1 co-re
 
 }  // namespace
 
+namespace {
+// Motion of a MovingSphere entry (moving_sphere.rs:8-14) next to the pt_sphere holding centre_start / radius.
+struct MotionIn {
+    float delta[3];
+    float time_start, inv_time_delta;
+    uint32_t moving;
+};
+}  // namespace
+
 struct pt_scene {
     int device = 0;
     int num_cus = 0;
@@ -66,10 +78,18 @@ struct pt_scene {
     float4 *d_gate = nullptr, *d_gate_chain = nullptr;
     uint32_t *d_bvh_large = nullptr;
     uint32_t n_bvh_large = 0;
-    int32_t accel_root = -1;
     DWideNode *d_wnodes = nullptr;
-    DNode4 *d_nodes4 = nullptr;               // 4-wide internal tree (default of the tree kernels)
+    DNode4 *d_nodes4 = nullptr;               // 4-wide internal tree (default of the tree kernels), built on the device
     uint32_t n_nodes4 = 0, depth4 = 0;
+    float tree_build_ms = 0.f;                // device time of that build (HIP events)
+    bool tree_on_device = false;
+    // the binary tree (variant bit 2048, scenes beyond the 4-wide tree's 65535 nodes) is built on the host when first needed
+    std::vector<pt_sphere> h_spheres;
+    std::vector<MotionIn> h_motion;
+    int32_t bin_root = -1;
+    bool has_tree_items = false;              // some sphere is inside the internal tree (else every one is in d_bvh_large)
+    double h_t_lo = 0.0, h_t_hi = 0.0;
+    bool binary_built = false;
     uint32_t *d_leaf_rank = nullptr, *d_rank_sphere = nullptr;
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     // MFMA prefilter data (n_tiles == 0: prefilter not applicable to this scene)
@@ -224,12 +244,6 @@ int upload(T **dst, const void *src, size_t count) {
 
 namespace {
 
-// Motion of a MovingSphere entry (moving_sphere.rs:8-14) next to the pt_sphere holding centre_start / radius.
-struct MotionIn {
-    float delta[3];
-    float time_start, inv_time_delta;
-    uint32_t moving;
-};
 
 // Conservative bound of sphere i over every ray time in [t_lo, t_hi]: centre of the swept segment and the
 // half-length to add to |radius| (zero for plain spheres).
@@ -552,111 +566,91 @@ AccelBuild build_accel(const pt_scene_desc *desc, const MotionIn *motion, double
     return out;
 }
 
-// ---- 4-wide internal tree (pt_kernel.h DNode4) -----------------------------------------------------------------
-// Same split rule as the binary tree (longest axis of the centroid bounds, ties by sphere index) applied twice per
-// node; a segment of n spheres gets ceil(n / m) children of equal size, m = the smallest power of 4 with 4 m >= n, so
-// the tree is balanced and its bottom nodes are mostly full. A child with one sphere is a leaf slot (~sphere).
-struct Accel4Build {
+// ---- 4-wide internal tree: host restatement of the DEVICE build (pt_build.hip; rules in pt_tree4.h) ----------------
+// Used as the reference the device build is tested against (PTGPU_HOST_BUILD=1 selects it) and when the device build
+// cannot run. Level by level like the device: order every segment along its longest centroid axis (stable, by the
+// orderable coordinate), cut, order the halves that are cut again, emit the children; boxes bottom-up at the end.
+struct Tree4Host {
     std::vector<DNode4> nodes;
-    std::vector<uint32_t> large;
     uint32_t depth = 0;
 };
-struct Accel4Ref {
-    int32_t ref;
-    float mn[3], mx[3], rmin;
-    uint32_t depth;
-};
 
-void accel4_split(std::vector<AccelItem> &items, size_t lo, size_t hi, size_t at) {   // items[lo, at) | items[at, hi) along the longest axis
-    float cmin[3] = {3e38f, 3e38f, 3e38f}, cmax[3] = {-3e38f, -3e38f, -3e38f};
+void tree4_order_range(std::vector<TreeItem> &items, size_t lo, size_t hi) {
+    float cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0};
+    uint32_t umin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, umax[3] = {0, 0, 0};
     for (size_t i = lo; i < hi; ++i)
-        for (int k = 0; k < 3; ++k) cmin[k] = std::min(cmin[k], items[i].c[k]), cmax[k] = std::max(cmax[k], items[i].c[k]);
-    int axis = 0;
-    for (int k = 1; k < 3; ++k)
-        if (cmax[k] - cmin[k] > cmax[axis] - cmin[axis]) axis = k;
-    std::nth_element(items.begin() + lo, items.begin() + at, items.begin() + hi,
-                     [axis](const AccelItem &a, const AccelItem &b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.sphere < b.sphere); });
-}
-
-uint16_t f16_up(double v) {   // smallest f16 >= v (v > 0, far below the f16 range limit)
-    _Float16 h = (_Float16)v;
-    while ((double)h < v) {
-        uint16_t u = f16_bits(h);
-        ++u;
-        memcpy(&h, &u, 2);
-    }
-    return f16_bits(h);
-}
-
-// Builds the node `self` (already allocated) over items[lo, hi), n >= 2. Inner children take the node's first slots and
-// consecutive node indices (the kernel addresses them as child[0] + slot); single spheres follow as leaf slots.
-Accel4Ref accel4_build(std::vector<AccelItem> &items, size_t lo, size_t hi, std::vector<DNode4> &nodes, int32_t self) {
-    const size_t n = hi - lo;
-    size_t m = 1;
-    while (4 * m < n) m *= 4;
-    const size_t c = (n + m - 1) / m;                 // 2..4 children
-    size_t cut[5];
-    for (size_t j = 0; j <= c; ++j) cut[j] = lo + n * j / c;
-    const size_t half = (c + 1) / 2;                  // children on the low side of the first split
-    accel4_split(items, lo, hi, cut[half]);
-    if (half == 2) accel4_split(items, lo, cut[2], cut[1]);
-    if (c - half == 2) accel4_split(items, cut[half], hi, cut[half + 1]);
-    std::vector<size_t> order;                        // inner children (more than one sphere) first, then leaves
-    for (size_t j = 0; j < c; ++j)
-        if (cut[j + 1] - cut[j] > 1) order.push_back(j);
-    const size_t n_inner = order.size();
-    for (size_t j = 0; j < c; ++j)
-        if (cut[j + 1] - cut[j] == 1) order.push_back(j);
-    const int32_t first = (int32_t)nodes.size();
-    nodes.resize(nodes.size() + n_inner);
-    Accel4Ref out{self, {3e38f, 3e38f, 3e38f}, {-3e38f, -3e38f, -3e38f}, 3e38f, 0};
-    DNode4 w;
-    memset(&w, 0, sizeof w);
-    for (size_t j = 0; j < 4; ++j) {
-        if (j >= c) {   // empty slot: never hit (and checked by its ref)
-            for (int k = 0; k < 3; ++k) w.lo[k][j] = 3.0e38f, w.hi[k][j] = -3.0e38f;
-            w.child[j] = kNoChild4;
-            continue;
-        }
-        const size_t a = cut[order[j]], b = cut[order[j] + 1];
-        Accel4Ref ch;
-        if (b - a == 1) {
-            const AccelItem &it = items[a];
-            ch = Accel4Ref{~(int32_t)it.sphere, {it.mn[0], it.mn[1], it.mn[2]}, {it.mx[0], it.mx[1], it.mx[2]}, it.r, 0};
-        } else {
-            ch = accel4_build(items, a, b, nodes, first + (int32_t)j);
-        }
         for (int k = 0; k < 3; ++k) {
-            w.lo[k][j] = ch.mn[k], w.hi[k][j] = ch.mx[k];
-            out.mn[k] = std::min(out.mn[k], ch.mn[k]), out.mx[k] = std::max(out.mx[k], ch.mx[k]);
+            const uint32_t u = tree_orderable(items[i].c[k]);
+            if (u < umin[k]) umin[k] = u, cmin[k] = items[i].c[k];
+            if (u > umax[k]) umax[k] = u, cmax[k] = items[i].c[k];
         }
-        w.child[j] = ch.ref;
-        out.rmin = std::min(out.rmin, ch.rmin);
-        out.depth = std::max(out.depth, ch.depth + 1);
-    }
-    // node-level pad of the conservative box test: >= 4x the bound on how far the reference's f32 discriminant inflates a
-    // sphere (0.65e-6 (|o - c|^2 + r^2) / r), with |o - c_sphere|^2 <= 2 (|o - c_node|^2 + |h_node|^2); stored as two
-    // f16 rounded UP: k = 6e-6 / r_min and k |h|^2 + 1e-4 (+ f32 rounding of the centre)
-    double h2 = 0.0, cmag = 0.0;
-    float ctr[3];
-    for (int k = 0; k < 3; ++k) {
-        ctr[k] = (float)(0.5 * ((double)out.mn[k] + (double)out.mx[k]));
-        const double h = std::max((double)out.mx[k] - (double)ctr[k], (double)ctr[k] - (double)out.mn[k]);
-        h2 += h * h, cmag += std::fabs((double)ctr[k]);
-    }
-    const double pk = 6.0e-6 / (double)out.rmin;
-    w.cx = ctr[0], w.cy = ctr[1], w.cz = ctr[2];
-    w.padh = (uint32_t)f16_up(pk * 1.001) | ((uint32_t)f16_up((pk * h2 + 1.0e-4 + 1.0e-6 * cmag) * 1.001) << 16);
-    nodes[self] = w;
-    return out;
+    const volatile float ex = cmax[0] - cmin[0], ey = cmax[1] - cmin[1], ez = cmax[2] - cmin[2];
+    const int axis = tree_axis_of_extents(ex, ey, ez);
+    std::stable_sort(items.begin() + lo, items.begin() + hi,
+                     [axis](const TreeItem &a, const TreeItem &b) { return tree_orderable(a.c[axis]) < tree_orderable(b.c[axis]); });
 }
 
-Accel4Build build_accel4(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi) {
-    Accel4Build out;
-    std::vector<AccelItem> items = accel_items(desc, motion, t_lo, t_hi, out.large);
-    if (items.empty()) return out;
+Tree4Host tree4_build_host(std::vector<TreeItem> items) {
+    Tree4Host out;
+    struct Seg { uint32_t lo, hi, node; };
+    std::vector<Seg> segs{{0u, (uint32_t)items.size(), 0u}};
+    std::vector<std::array<uint32_t, 4>> leaf_item(1);
+    std::vector<std::pair<uint32_t, uint32_t>> levels;   // (first node, count)
     out.nodes.resize(1);
-    out.depth = accel4_build(items, 0, items.size(), out.nodes, 0).depth;
+    while (!segs.empty()) {
+        for (const Seg &sg : segs) tree4_order_range(items, sg.lo, sg.hi);
+        for (const Seg &sg : segs) {
+            const TreePlan pl = tree_plan(sg.hi - sg.lo);
+            if (pl.half == 2u) tree4_order_range(items, sg.lo, sg.lo + pl.cut[2]);
+            if (pl.c - pl.half == 2u) tree4_order_range(items, sg.lo + pl.cut[pl.half], sg.hi);
+        }
+        levels.push_back({(uint32_t)out.nodes.size() - (uint32_t)segs.size(), (uint32_t)segs.size()});
+        std::vector<Seg> next;
+        for (const Seg &sg : segs) {
+            const TreePlan pl = tree_plan(sg.hi - sg.lo);
+            uint32_t slot = 0;
+            int32_t child[4] = {kNoChild4, kNoChild4, kNoChild4, kNoChild4};
+            std::array<uint32_t, 4> li{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            for (int pass = 0; pass < 2; ++pass)
+                for (uint32_t j = 0; j < pl.c; ++j) {
+                    const uint32_t a = sg.lo + pl.cut[j], b = sg.lo + pl.cut[j + 1];
+                    if ((b - a > 1u) != (pass == 0)) continue;
+                    if (pass == 0) {
+                        const uint32_t node = (uint32_t)out.nodes.size();
+                        out.nodes.emplace_back();
+                        leaf_item.emplace_back();
+                        child[slot] = (int32_t)node;
+                        next.push_back({a, b, node});
+                    } else {
+                        child[slot] = ~(int32_t)items[a].sphere;
+                        li[slot] = a;
+                    }
+                    ++slot;
+                }
+            memcpy(out.nodes[sg.node].child, child, sizeof child);
+            leaf_item[sg.node] = li;
+        }
+        segs.swap(next);
+    }
+    std::vector<TreeBox> box(out.nodes.size());
+    for (size_t l = levels.size(); l-- > 0;)
+        for (uint32_t node = levels[l].first; node < levels[l].first + levels[l].second; ++node) {
+            DNode4 w = out.nodes[node];
+            TreeBox ch[4];
+            uint32_t c = 0;
+            for (uint32_t j = 0; j < 4u && w.child[j] != kNoChild4; ++j, ++c) {
+                if (w.child[j] >= 0) {
+                    ch[j] = box[w.child[j]];
+                } else {
+                    const TreeItem &it = items[leaf_item[node][j]];
+                    for (int k = 0; k < 3; ++k) ch[j].mn[k] = it.mn[k], ch[j].mx[k] = it.mx[k];
+                    ch[j].rmin = it.r;
+                }
+            }
+            box[node] = tree_finish_node(w, ch, c);
+            out.nodes[node] = w;
+        }
+    out.depth = (uint32_t)levels.size();
     return out;
 }
 
@@ -790,10 +784,8 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
     }
     // BVH mode: per-sphere parent AABB + DFS rank from the CALLER's tree (they define the result), and the
     // internal traversal tree.
-    std::vector<DWideNode> wnodes;
     std::vector<uint32_t> leaf_rank(desc->n_spheres, 0), bvh_large, rank_sphere;
     std::vector<float4> gate(2 * (size_t)desc->n_spheres, make_float4(0, 0, 0, 0)), gate_chain;
-    uint32_t accel_depth = 0;
     if (desc->n_bvh_nodes) {
         union FU { uint32_t u; float f; };
         // a sphere that is not a leaf of the caller's tree can never be hit: chain count 0xffffffff = "never"
@@ -845,27 +837,36 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
             }
         }
     }
+    DNode4 *d_nodes4_built = nullptr;
     {   // the internal tree is built for every scene: BVH mode always uses it, list mode uses it for scenes too
         // large for the brute-force scan (there it needs no gate: closest t, ties to the lower list index)
-        AccelBuild acc = build_accel(desc, motion, t_lo, t_hi);
-        wnodes = std::move(acc.nodes);
-        bvh_large = std::move(acc.large);
-        s->accel_root = acc.root;
-        accel_depth = acc.depth;
-        if (accel_depth + 2 > (uint32_t)kBvhStack) {
-            pt_scene_destroy(s);
-            return fail(PT_ERR_UNSUPPORTED, "internal BVH depth %u exceeds the traversal stack", accel_depth);
-        }
-        s->bvh_depth = accel_depth;
-        s->n_nodes = (uint32_t)wnodes.size();
+        const std::vector<AccelItem> items = accel_items(desc, motion, t_lo, t_hi, bvh_large);
         s->n_bvh_large = (uint32_t)bvh_large.size();
-    }
-    std::vector<DNode4> nodes4;
-    {
-        Accel4Build acc4 = build_accel4(desc, motion, t_lo, t_hi);
-        nodes4 = std::move(acc4.nodes);
-        s->n_nodes4 = (uint32_t)nodes4.size();
-        s->depth4 = acc4.depth;
+        s->has_tree_items = !items.empty();
+        s->h_spheres.assign(desc->spheres, desc->spheres + desc->n_spheres);
+        if (motion) s->h_motion.assign(motion, motion + desc->n_spheres);
+        s->h_t_lo = t_lo, s->h_t_hi = t_hi;
+        if (!items.empty()) {
+            std::vector<TreeItem> titems(items.size());
+            for (size_t i = 0; i < items.size(); ++i) {
+                titems[i].sphere = items[i].sphere, titems[i].r = items[i].r;
+                memcpy(titems[i].c, items[i].c, 12), memcpy(titems[i].mn, items[i].mn, 12), memcpy(titems[i].mx, items[i].mx, 12);
+            }
+            // 4-wide tree: built ON THE DEVICE (pt_build.hip); PTGPU_HOST_BUILD=1 runs the host restatement instead (tests)
+            int brc = getenv("PTGPU_HOST_BUILD") ? -1 : tree4_build_device(titems.data(), (uint32_t)titems.size(), nullptr, &d_nodes4_built, &s->n_nodes4, &s->depth4,
+                                                                         &s->tree_build_ms);
+            if (brc == 0) {
+                s->tree_on_device = true;
+            } else {
+                const Tree4Host t4 = tree4_build_host(titems);
+                s->n_nodes4 = (uint32_t)t4.nodes.size(), s->depth4 = t4.depth;
+                if (upload(&d_nodes4_built, t4.nodes.data(), t4.nodes.size()) != PT_OK) {
+                    pt_scene_destroy(s);
+                    return fail(PT_ERR_HIP, "uploading the internal tree failed");
+                }
+            }
+        }
+        s->d_nodes4 = d_nodes4_built;
     }
     std::vector<float4> pvec(256, make_float4(0, 0, 0, 0));
     std::vector<uint32_t> pperm(768, 0);
@@ -882,10 +883,9 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
         (rc = upload(&s->d_sphere_mat, desc->sphere_material, desc->n_spheres)) ||
         (rc = upload(&s->d_mats, mats.data(), mats.size())) || (rc = upload(&s->d_texs, texs.data(), texs.size())) ||
         (rc = upload(&s->d_perlin_vec, pvec.data(), pvec.size())) || (rc = upload(&s->d_perlin_perm, pperm.data(), pperm.size())) ||
-        (rc = upload(&s->d_wnodes, wnodes.data(), wnodes.size())) || (rc = upload(&s->d_leaf_rank, leaf_rank.data(), leaf_rank.size())) ||
+        (rc = upload(&s->d_leaf_rank, leaf_rank.data(), leaf_rank.size())) ||
         (rc = upload(&s->d_gate, gate.data(), gate.size())) || (rc = upload(&s->d_gate_chain, gate_chain.data(), gate_chain.size())) ||
-        (rc = upload(&s->d_bvh_large, bvh_large.data(), bvh_large.size())) || (rc = upload(&s->d_nodes4, nodes4.data(), nodes4.size())) ||
-        (rc = upload(&s->d_rank_sphere, rank_sphere.data(), rank_sphere.size()))) {
+        (rc = upload(&s->d_bvh_large, bvh_large.data(), bvh_large.size())) || (rc = upload(&s->d_rank_sphere, rank_sphere.data(), rank_sphere.size()))) {
         pt_scene_destroy(s);
         return rc;
     }
@@ -1255,6 +1255,23 @@ void fill_frame_args(Args &X, const pt_scene *s, const pt_params *params, const 
     X.work_counter = s->d_work_counter;
 }
 
+// The binary internal tree (variant bit 2048 for A/B runs, and scenes whose 4-wide tree would exceed 65535 nodes) is
+// built on the host the first time a launch needs it.
+int ensure_binary_tree(pt_scene *s) {
+    if (s->binary_built) return PT_OK;
+    pt_scene_desc d{};
+    d.n_spheres = (uint32_t)s->h_spheres.size();
+    d.spheres = s->h_spheres.data();
+    AccelBuild acc = build_accel(&d, s->h_motion.empty() ? nullptr : s->h_motion.data(), s->h_t_lo, s->h_t_hi);
+    if (acc.depth + 2 > (uint32_t)kBvhStack) return fail(PT_ERR_UNSUPPORTED, "internal BVH depth %u exceeds the traversal stack", acc.depth);
+    if (int rc = upload(&s->d_wnodes, acc.nodes.data(), acc.nodes.size())) return rc;
+    s->bin_root = acc.root;
+    s->bvh_depth = acc.depth;
+    s->n_nodes = (uint32_t)acc.nodes.size();
+    s->binary_built = true;
+    return PT_OK;
+}
+
 int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t frame_num, uint32_t shard_index,
            uint32_t shard_count, float *d_rgb, uint64_t *d_ray_count, hipStream_t stream) {
     if (!s || !params || !cam || !d_rgb || !d_ray_count) return fail(PT_ERR_INVALID_ARG, "NULL argument");
@@ -1365,7 +1382,6 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.gate_chain = s->d_gate_chain;
     A.bvh_large = s->d_bvh_large;
     A.n_bvh_large = s->n_bvh_large;
-    A.wnodes = s->d_wnodes;
     A.nodes4 = s->d_nodes4;
     A.rank_sphere = s->d_rank_sphere;
     A.leaf_rank = s->d_leaf_rank;
@@ -1373,7 +1389,6 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     memcpy(A.root_max, s->root_max, 12);
     A.n_spheres = s->n_spheres;
     A.n_spheres_pad = (s->n_spheres + kScanUnroll - 1) / kScanUnroll * kScanUnroll;
-    A.bvh_root = s->accel_root;  // root of the INTERNAL tree (-1: every sphere is in bvh_large)
     fill_frame_args(A, s, params, cam, frame_num, shard_index, shard_count, d_rgb, d_ray_count);
     HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
     HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
@@ -1406,10 +1421,17 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.debug = s->d_debug;
     uint32_t lds = sph_bytes + kLdsParamBytes;
     if (s->has_noise) lds += 4096u + 3072u;
-    A.n_nodes = s->n_nodes;
+    A.ready_min = (uint32_t)kReadyMin, A.drain_at = (uint32_t)(kLeafQ - 4);
+    if (const char *e = getenv("PTGPU_READY")) A.ready_min = (uint32_t)atoi(e);          // (development knobs)
+    if (const char *e = getenv("PTGPU_DRAIN")) A.drain_at = std::min<uint32_t>((uint32_t)atoi(e), (uint32_t)(kLeafQ - 4));
     // 4-wide tree (default; variant bit 2048: the binary tree): a visit pushes at most three siblings per level
     // (its stack entries are 16-bit node indices; a bigger tree -- more than ~190 000 spheres -- walks the binary one)
-    const bool tree4 = bvh && (s->variant & 2048u) == 0 && s->n_nodes4 < 65536u && (s->n_nodes4 > 0 || s->accel_root < 0);
+    const bool tree4 = bvh && (s->variant & 2048u) == 0 && s->n_nodes4 < 65536u;
+    if (bvh && !tree4)
+        if (int rc = ensure_binary_tree(s)) return rc;
+    A.wnodes = s->d_wnodes;
+    A.n_nodes = s->n_nodes;
+    A.bvh_root = tree4 ? (s->has_tree_items ? 0 : -1) : s->bin_root;   // (-1: every sphere is in bvh_large)
     // a visit pushes at most three siblings, and only above the bottom level; +3 slots for the unconditional writes, even count
     A.bvh_stack_entries = tree4 ? ((3u * (s->depth4 ? s->depth4 - 1u : 0u) + 4u) & ~1u) : (s->bvh_depth + 2u);
     // tree nodes go to LDS only while FOUR workgroups still fit on the CU (with two levels of attenuation stack each):
@@ -1718,6 +1740,24 @@ extern "C" int pt_last_pass_ms(pt_scene *s, float *ms_out) {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventSynchronize(s->ev_stop));
     HIP_TRY(hipEventElapsedTime(ms_out, s->ev_pass, s->ev_stop));
+    return PT_OK;
+}
+
+extern "C" int pt_scene_build_info(pt_scene *s, float *build_ms_out, uint32_t *n_nodes_out, uint32_t *depth_out, uint32_t *on_device_out) {
+    if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
+    if (build_ms_out) *build_ms_out = s->tree_build_ms;
+    if (n_nodes_out) *n_nodes_out = s->n_nodes4;
+    if (depth_out) *depth_out = s->depth4;
+    if (on_device_out) *on_device_out = s->tree_on_device ? 1u : 0u;
+    return PT_OK;
+}
+
+extern "C" int pt_scene_debug_tree(pt_scene *s, void *nodes_out, size_t capacity_bytes) {
+    if (!s || !nodes_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    const size_t bytes = (size_t)s->n_nodes4 * sizeof(DNode4);
+    if (capacity_bytes < bytes) return fail(PT_ERR_INVALID_ARG, "buffer holds %zu bytes, the tree has %zu", capacity_bytes, bytes);
+    HIP_TRY(hipSetDevice(s->device));
+    if (bytes) HIP_TRY(hipMemcpy(nodes_out, s->d_nodes4, bytes, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

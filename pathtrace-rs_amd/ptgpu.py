@@ -104,7 +104,7 @@ EXPORTS = [
     "pt_render_shard_device", "pt_shard_rows", "pt_scene_set_seed_base", "pt_last_kernel_ms",
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
-    "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all",
+    "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree",
 ]
 COMM_ID_BYTES = 128
 
@@ -156,6 +156,8 @@ def lib():
         L.pt_render_sharded.argtypes = [vp, vp, C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, vp, vp, C.c_int, vp]
         L.pt_shard_pack.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         L.pt_shard_unpack_all.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        L.pt_scene_build_info.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.pt_scene_debug_tree.argtypes = [vp, vp, C.c_size_t]
         L.pt_last_error.restype = C.c_char_p
         L.pt_version.restype = C.c_char_p
         _lib = L
@@ -342,6 +344,19 @@ class Scene:
         """Scene::update over the ranks of `comm` (pt_render_sharded): rows y % world == rank, RCCL gather."""
         _check(lib().pt_render_sharded(self._h, comm._h, C.byref(params), C.byref(camera), frame_num, d_rgb_full_ptr,
                                        d_ray_count_ptr, root, stream))
+
+    def build_info(self):
+        """The library's own traversal tree: device build time (ms), node count, depth, built on the device?"""
+        ms, n, d, dev = C.c_float(0), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        _check(lib().pt_scene_build_info(self._h, C.byref(ms), C.byref(n), C.byref(d), C.byref(dev)))
+        return dict(build_ms=ms.value, n_nodes=n.value, depth=d.value, on_device=bool(dev.value))
+
+    def debug_tree(self):
+        """The 4-wide tree's nodes as a [n_nodes, 32] uint32 array (128-byte records)."""
+        n = self.build_info()["n_nodes"]
+        out = np.zeros((max(n, 1), 32), np.uint32)
+        _check(lib().pt_scene_debug_tree(self._h, out.ctypes.data, out.nbytes))
+        return out[:n]
 
     def last_launch_info(self):
         g, b, l = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)

@@ -758,6 +758,33 @@ def test_bvh_world_on_the_prefilter_kernel_equals_the_tree_kernel(ptgpu, pthost,
     sc.set_tuning(0, 0)
 
 
+@pytest.mark.parametrize("preset,bvh", [("perlin_spheres", True), ("random_spheres", True), ("random", True), ("two_perlin_spheres", False),
+                                        ("small", True), ("aras", False)])
+def test_device_tree_build_equals_the_host_restatement(ptgpu, pthost, preset, bvh):
+    """the traversal tree is built on the device (level-synchronous radix sorts, csrc/pt_build.hip).
+    Byte for byte it must be the tree the host restatement of the same rules builds (PTGPU_HOST_BUILD=1)."""
+    hs = pthost.HostScene(preset, 64, 48, samples=1, use_bvh=bvh, device=0)
+    info = hs.device_scene().build_info()
+    dev_nodes = hs.device_scene().debug_tree()
+    os.environ["PTGPU_HOST_BUILD"] = "1"
+    try:
+        hs2 = pthost.HostScene(preset, 64, 48, samples=1, use_bvh=bvh, device=0)
+    finally:
+        del os.environ["PTGPU_HOST_BUILD"]
+    info2 = hs2.device_scene().build_info()
+    host_nodes = hs2.device_scene().debug_tree()
+    assert info["on_device"] and not info2["on_device"]
+    assert info["n_nodes"] == info2["n_nodes"] > 0 and info["depth"] == info2["depth"]
+    assert info["build_ms"] > 0.0
+    assert np.array_equal(dev_nodes, host_nodes), "first differing node %d" % int(np.argmax((dev_nodes != host_nodes).any(axis=1)))
+    # every sphere of the tree appears exactly once as a leaf, every inner child exactly once
+    child = dev_nodes[:, 24:28].view(np.int32)
+    inner = child[(child >= 0) & (child != 0x7fffffff)]
+    assert sorted(inner.tolist()) == list(range(1, info["n_nodes"]))
+    leaves = ~child[child < 0]
+    assert len(set(leaves.tolist())) == len(leaves)
+
+
 def test_traversal_counters_report_internal_tree_work(ptgpu, pthost, oracle):
     """BVH-mode work is reported as node visits / sphere tests per ray. Verify mode on a tree kernel counts
     them for the device's internal tree; the oracle counts the reference's both-children traversal. The image must
