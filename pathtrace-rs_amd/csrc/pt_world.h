@@ -164,23 +164,28 @@ __device__ __forceinline__ bool w_aabb_hit(f3 mn, f3 mx, const WRay &r, float tm
     return x && y && z;
 }
 
-// cuboid.rs:11-37: AABB test, then the six faces in construction order with narrowing. One rect routine, called
-// from a loop (the faces differ only in their parameters), keeps the code small.
+// cuboid.rs:11-37: AABB test, then the six faces in construction order with narrowing. The faces are written out (axis
+// and side are compile-time constants of each call): a loop over a face index made the compiler keep p0 / p1 in scratch
+// memory and index them dynamically.
+template <int AXIS, bool FLIP>
+__device__ __forceinline__ void w_cuboid_face(f3 p0, f3 p1, const WRay &r, float t_min, float &closest, WHit &h, bool &found, bool want_uv) {
+    float a0, a1, b0, b1, k;
+    if (AXIS == 0) a0 = p0.x, a1 = p1.x, b0 = p0.y, b1 = p1.y, k = FLIP ? p0.z : p1.z;        // XY
+    else if (AXIS == 1) a0 = p0.x, a1 = p1.x, b0 = p0.z, b1 = p1.z, k = FLIP ? p0.y : p1.y;   // XZ
+    else a0 = p0.y, a1 = p1.y, b0 = p0.z, b1 = p1.z, k = FLIP ? p0.x : p1.x;                   // YZ
+    WHit f;
+    if (w_rect((uint32_t)AXIS, a0, a1, b0, b1, k, FLIP, r, t_min, closest, f, want_uv)) h = f, closest = f.t, found = true;
+}
 __device__ __forceinline__ bool w_cuboid(f3 p0, f3 p1, const WRay &r, float t_min, float t_max, WHit &h, bool want_uv) {
     if (!w_aabb_hit(p0, p1, r, t_min, t_max)) return false;
     bool found = false;
     float closest = t_max;
-#pragma clang loop unroll(disable)
-    for (uint32_t face = 0; face < 6u; ++face) {
-        const uint32_t axis = face >> 1;          // 0,1: XY  2,3: XZ  4,5: YZ
-        const bool flip = (face & 1u) != 0u;      // odd faces sit at p0 and face the other way
-        float a0, a1, b0, b1, k;
-        if (axis == 0u) a0 = p0.x, a1 = p1.x, b0 = p0.y, b1 = p1.y, k = flip ? p0.z : p1.z;
-        else if (axis == 1u) a0 = p0.x, a1 = p1.x, b0 = p0.z, b1 = p1.z, k = flip ? p0.y : p1.y;
-        else a0 = p0.y, a1 = p1.y, b0 = p0.z, b1 = p1.z, k = flip ? p0.x : p1.x;
-        WHit f;
-        if (w_rect(axis, a0, a1, b0, b1, k, flip, r, t_min, closest, f, want_uv)) h = f, closest = f.t, found = true;
-    }
+    w_cuboid_face<0, false>(p0, p1, r, t_min, closest, h, found, want_uv);   // odd faces sit at p0 and face the other way
+    w_cuboid_face<0, true>(p0, p1, r, t_min, closest, h, found, want_uv);
+    w_cuboid_face<1, false>(p0, p1, r, t_min, closest, h, found, want_uv);
+    w_cuboid_face<1, true>(p0, p1, r, t_min, closest, h, found, want_uv);
+    w_cuboid_face<2, false>(p0, p1, r, t_min, closest, h, found, want_uv);
+    w_cuboid_face<2, true>(p0, p1, r, t_min, closest, h, found, want_uv);
     return found;
 }
 
@@ -194,7 +199,11 @@ __device__ __forceinline__ bool w_shape(const pt_hitable &H, const WRay &r, floa
         return w_sphere(centre, H.p[6], r, t_min, t_max, h);
     }
     case PT_HIT_CUBOID: return w_cuboid(mk3(H.p[0], H.p[1], H.p[2]), mk3(H.p[3], H.p[4], H.p[5]), r, t_min, t_max, h, want_uv);
-    default: return w_rect(H.kind - PT_HIT_RECT_XY, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], H.flip_normals != 0u, r, t_min, t_max, h, want_uv);
+    // (one call per plane orientation, each with a constant axis: a run-time axis made the compiler index the ray's
+    //  components through scratch memory)
+    case PT_HIT_RECT_XY: return w_rect(0u, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], H.flip_normals != 0u, r, t_min, t_max, h, want_uv);
+    case PT_HIT_RECT_XZ: return w_rect(1u, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], H.flip_normals != 0u, r, t_min, t_max, h, want_uv);
+    default: return w_rect(2u, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], H.flip_normals != 0u, r, t_min, t_max, h, want_uv);
     }
 }
 
@@ -220,9 +229,10 @@ __device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine
 // One HitableList entry. Returns the material to shade with in `mat`. A ConstantMedium asks its boundary twice
 // (constant_medium.rs:39-43): the shape code is reached through ONE call site in a two-trip loop so it exists once.
 // Returns the material index, or -1 for no hit.
+template <bool MEDIA>
 __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *xf, const WRay &r, float t_min, float t_max,
                                          Rng &rng, WHit &h, bool want_uv) {
-    const bool medium = H.medium_material >= 0;
+    const bool medium = MEDIA && H.medium_material >= 0;   // MEDIA = false: the world has no ConstantMedium (its code, and the RNG's liveness across the scan, drop out)
     float lo = medium ? -kMaxT : t_min, hi = medium ? kMaxT : t_max;
     float t_first = 0.f;
     bool ok = true;
@@ -263,7 +273,8 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
 // OCC: waves per SIMD the kernel is compiled for. 4 (128 VGPRs, a few spills) pays for worlds without noise textures
 // whose LDS lets four workgroups share a CU (cornell +7 %, cornell_smoke +11 %); with Perlin noise inlined the spills
 // cost more than the fourth wave brings (simple_light -6 %), so those keep 2 (the compiler then uses ~160 VGPRs).
-template <bool BVH, bool HIT_LDS, int OCC = 2>
+// MEDIA: some hitable is a ConstantMedium (own instantiations: worlds without media do not carry that path's registers).
+template <bool BVH, bool HIT_LDS, int OCC = 3, bool MEDIA = true>
 __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *p = smem;
@@ -276,6 +287,8 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
     p += HIT_LDS ? A.n_hit * 64u : 0u;
     const pt_affine *s_xf = reinterpret_cast<const pt_affine *>(p);
     p += HIT_LDS ? A.n_xf * 96u : 0u;
+    float *s_best = reinterpret_cast<float *>(p) + threadIdx.x;   // [8][kBlock]: the closest hit record of the running scan (point, normal, u, v)
+    p += 8 * kBlock * 4;
     float *s_path = reinterpret_cast<float *>(p);
 
     const int tid = threadIdx.x;
@@ -363,19 +376,24 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
             }
 
             // ---- Hitable::ray_hit(ray, MIN_T, MAX_T) on the world (scene.rs:58)
+            // The running closest-hit record lives in LDS: it is written when a closer hit is accepted and read once after
+            // the scan, instead of holding nine registers across the whole intersection code.
             bool found = false;
-            WHit best;
             uint32_t best_mat = 0;
-            best.t = kMaxT;
-            best.point = best.normal = mk3(0.f, 0.f, 0.f);
-            best.u = best.v = 0.0f;
+            float best_t = kMaxT;
+            auto keep = [&](const WHit &h) {
+                s_best[0 * kBlock] = h.point.x, s_best[1 * kBlock] = h.point.y, s_best[2 * kBlock] = h.point.z;
+                s_best[3 * kBlock] = h.normal.x, s_best[4 * kBlock] = h.normal.y, s_best[5 * kBlock] = h.normal.z;
+                s_best[6 * kBlock] = h.u, s_best[7 * kBlock] = h.v;
+                best_t = h.t;
+            };
             if (!BVH) {  // hitable_list.rs:40-56
                 float closest = kMaxT;
                 for (uint32_t k = 0; k < A.n_hit; ++k) {
                     WHit h;
-                    const int m = w_hitable(hit[k], xf, ray, kMinT, closest, rng, h, want_uv);
+                    const int m = w_hitable<MEDIA>(hit[k], xf, ray, kMinT, closest, rng, h, want_uv);
                     if (m >= 0) {
-                        best = h, best_mat = (uint32_t)m, found = true;
+                        keep(h), best_mat = (uint32_t)m, found = true;
                         closest = h.t;
                     }
                 }
@@ -386,10 +404,10 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
                     const int32_t ref = s_stack[--sp * kBlock + tid];
                     if (ref < 0) {
                         WHit h;
-                        const int m = w_hitable(hit[~ref], xf, ray, kMinT, kMaxT, rng, h, want_uv);
+                        const int m = w_hitable<MEDIA>(hit[~ref], xf, ray, kMinT, kMaxT, rng, h, want_uv);
                         if (m >= 0) {
                             // bvh.rs:48-53: lhs only when lhs.t < rhs.t -> an equal t goes to the later leaf
-                            if (!found || !(best.t < h.t)) best = h, best_mat = (uint32_t)m;
+                            if (!found || !(best_t < h.t)) keep(h), best_mat = (uint32_t)m;
                             found = true;
                         }
                     } else {
@@ -416,10 +434,12 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
                 }
             } else {
                 const DMat m = A.mats[best_mat];
-                const f3 point = best.point, normal = best.normal, d = ray.d;
+                const f3 point = mk3(s_best[0 * kBlock], s_best[1 * kBlock], s_best[2 * kBlock]);
+                const f3 normal = mk3(s_best[3 * kBlock], s_best[4 * kBlock], s_best[5 * kBlock]), d = ray.d;
+                const float best_u = want_uv ? s_best[6 * kBlock] : 0.0f, best_v = want_uv ? s_best[7 * kBlock] : 0.0f;
                 // Texture::value (texture.rs:74-91); Constant textures were folded into the material record
                 auto colour = [&]() -> f3 {
-                    return m.pad0 != 0.0f ? mk3(m.a0, m.a1, m.a2) : texture_value(A.texs, pn, m.tex, point, best.u, best.v, DImages{A.image_table, A.image_bytes});
+                    return m.pad0 != 0.0f ? mk3(m.a0, m.a1, m.a2) : texture_value(A.texs, pn, m.tex, point, best_u, best_v, DImages{A.image_table, A.image_bytes});
                 };
                 f3 emitted = mk3(0.f, 0.f, 0.f);  // material.rs:161-167
                 if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = colour();

@@ -131,6 +131,7 @@ struct pt_scene {
     uint4 *d_image_table = nullptr;       // Texture::Image sources: (byte offset, width, height, 0)
     uint8_t *d_image_bytes = nullptr;
     uint32_t has_image = 0;
+    bool has_media = false;               // some hitable is a ConstantMedium
     uint32_t ref_bvh_depth = 0;
     // last launch
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // around the frame kernel alone (what rocprofv3 reports for it)
@@ -964,7 +965,7 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
                                  desc->n_images, desc->images)) return rc;
     bool has_image = false;
     for (uint32_t i = 0; i < desc->n_textures; ++i) has_image = has_image || desc->textures[i].kind == PT_TEX_IMAGE;
-    bool all_spheres = true, sphere_like = true;
+    bool all_spheres = true, sphere_like = true, has_media = false;
     for (uint32_t i = 0; i < desc->n_hitables; ++i) {
         const pt_hitable &h = desc->hitables[i];
         if (h.kind > PT_HIT_CUBOID) return fail(PT_ERR_INVALID_ARG, "hitable %u: unknown kind %u", i, h.kind);
@@ -977,6 +978,7 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
             if ((uint32_t)h.medium_material >= desc->n_materials || desc->materials[h.medium_material].kind != PT_MAT_ISOTROPIC)
                 return fail(PT_ERR_INVALID_ARG, "hitable %u: medium_material must index an Isotropic material", i);
         }
+        has_media = has_media || h.medium_material >= 0;
         if (h.kind != PT_HIT_SPHERE || h.transform >= 0 || h.medium_material >= 0) all_spheres = false;
         if (h.kind > PT_HIT_MOVING_SPHERE || h.transform >= 0 || h.medium_material >= 0) sphere_like = false;
     }
@@ -1057,6 +1059,7 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
     s->device = device;
     s->num_cus = prop.multiProcessorCount;
     s->is_world = true;
+    s->has_media = has_media;
     s->n_hitables = desc->n_hitables;
     s->n_world_xf = desc->n_transforms;
     s->n_materials = desc->n_materials;
@@ -1327,11 +1330,22 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         W.n_xf = s->n_world_xf;
         const bool hit_lds = s->n_hitables * 64u + s->n_world_xf * 96u <= 40960u;   // records + transforms staged in LDS
         if (hit_lds) lds += s->n_hitables * 64u + s->n_world_xf * 96u;
+        lds += 8u * kBlock * 4u;                                                    // the running closest-hit record
         const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
         W.stack_in_lds = (lds + path_bytes <= 60u * 1024u) ? 1u : 0u;
         if (W.stack_in_lds) lds += (uint32_t)path_bytes;
-        const bool occ4 = !s->has_noise && s->blocks_per_cu == 0 && 4u * lds <= kLdsBudget;   // see pt_world_kernel's OCC
-        uint32_t bpc = s->blocks_per_cu ? s->blocks_per_cu : (occ4 ? 4u : 3u);
+        const bool occ4 = !s->has_noise && s->blocks_per_cu == 0 && 4u * lds <= kLdsBudget && !getenv("PTGPU_WORLD_OCC3");   // see pt_world_kernel's OCC
+        // one instantiation per (traversal, records in LDS, waves per SIMD, world has media); worlds whose records do not
+        // fit LDS (more than ~600 hitables) share the MEDIA = true code
+        const bool media = s->has_media || !hit_lds || s->has_motion;
+        void (*wk)(const WArgs) = nullptr;
+        if (occ4)
+            wk = ref_bvh ? (hit_lds ? (media ? pt_world_kernel<true, true, 4, true> : pt_world_kernel<true, true, 4, false>) : pt_world_kernel<true, false, 4, true>)
+                         : (hit_lds ? (media ? pt_world_kernel<false, true, 4, true> : pt_world_kernel<false, true, 4, false>) : pt_world_kernel<false, false, 4, true>);
+        else
+            wk = ref_bvh ? (hit_lds ? (media ? pt_world_kernel<true, true, 3, true> : pt_world_kernel<true, true, 3, false>) : pt_world_kernel<true, false, 3, true>)
+                         : (hit_lds ? (media ? pt_world_kernel<false, true, 3, true> : pt_world_kernel<false, true, 3, false>) : pt_world_kernel<false, false, 3, true>);
+        uint32_t bpc = s->blocks_per_cu ? s->blocks_per_cu : std::min(occ4 ? 4u : 3u, blocks_per_cu_by_registers(reinterpret_cast<const void *>(wk), kBlock));
         const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
         if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
         if (bpc > 8u) bpc = 8u;
@@ -1349,13 +1363,6 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
             }
             W.gstack = s->d_gstack;
         }
-        void (*wk)(const WArgs) = nullptr;
-        if (occ4)
-            wk = ref_bvh ? (hit_lds ? pt_world_kernel<true, true, 4> : pt_world_kernel<true, false, 4>)
-                         : (hit_lds ? pt_world_kernel<false, true, 4> : pt_world_kernel<false, false, 4>);
-        else
-            wk = ref_bvh ? (hit_lds ? pt_world_kernel<true, true> : pt_world_kernel<true, false>)
-                         : (hit_lds ? pt_world_kernel<false, true> : pt_world_kernel<false, false>);
         if (int rc = set_lds_limit(s, 0, reinterpret_cast<const void *>(wk), lds)) return rc;
         HIP_TRY(hipEventRecord(s->ev_pass, stream));
         HIP_TRY(hipEventRecord(s->ev_start, stream));
