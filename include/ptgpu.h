@@ -206,6 +206,13 @@ int pt_scene_prepare(pt_scene *scene, const pt_params *params);
 int pt_render(pt_scene *scene, const pt_params *params, const pt_camera *camera,
               uint32_t frame_num, float *rgb_inout, uint64_t *ray_count_out);
 
+/* Optional, for a host that keeps ONE pixel buffer alive across calls (offline.rs:25 allocates it once; the preview
+ * window reuses it every frame, glium_window.rs:94-133): pins and maps `bytes` of host memory so that pt_render on any
+ * sub-range of it renders IN PLACE over PCIe -- the previous frame is read and the new one written pixel by pixel while
+ * the kernel runs, with no staging copy before or after. The caller must unregister before freeing the memory. */
+int pt_buffer_register(void *host_ptr, size_t bytes);
+int pt_buffer_unregister(void *host_ptr);
+
 /* Same with a DEVICE-resident buffer on `hip_stream` (hipStream_t, NULL =
  * default stream); asynchronous. d_ray_count (device, 8 bytes) is overwritten
  * with this call's ray count. The accumulation buffer stays in HBM across

@@ -105,6 +105,7 @@ EXPORTS = [
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
     "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree",
+    "pt_buffer_register", "pt_buffer_unregister",
 ]
 COMM_ID_BYTES = 128
 
@@ -158,6 +159,8 @@ def lib():
         L.pt_shard_unpack_all.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         L.pt_scene_build_info.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.pt_scene_debug_tree.argtypes = [vp, vp, C.c_size_t]
+        L.pt_buffer_register.argtypes = [vp, C.c_size_t]
+        L.pt_buffer_unregister.argtypes = [vp]
         L.pt_last_error.restype = C.c_char_p
         L.pt_version.restype = C.c_char_p
         _lib = L
@@ -397,6 +400,15 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def buffer_register(array):
+    """pt_buffer_register on a numpy array the caller keeps alive: pt_render then works in place on it."""
+    _check(lib().pt_buffer_register(array.ctypes.data, array.nbytes))
+
+
+def buffer_unregister(array):
+    _check(lib().pt_buffer_unregister(array.ctypes.data))
 
 
 def shard_pack(d_full_ptr, d_shard_ptr, width, height, shard_index, shard_count, stream=0):

@@ -394,6 +394,28 @@ def test_device_buffer_entry_point_matches_host_entry_point(ptgpu, pthost):
     assert block % 64 == 0 and grid >= 1 and lds > 0
 
 
+def test_registered_host_buffer_renders_in_place(ptgpu, pthost):
+    """pt_buffer_register: pt_render on a pinned + mapped caller buffer works in place over PCIe (no staging) and gives the
+    same frames as the staged path, including the progressive blend that reads the previous frame from that buffer."""
+    W, H, S = 320, 200, 8
+    hs = pthost.HostScene("random_spheres", W, H, samples=S, device=0)
+    sc, p = hs.device_scene(), ptgpu.PtParams(W, H, S, 10, 0, 0)
+    staged = np.zeros((H, W, 3), np.float32)
+    big = np.zeros((H + 7, W, 3), np.float32)          # the frame is a sub-range of the registered allocation
+    inplace = big[3:3 + H]
+    ptgpu.buffer_register(big)
+    try:
+        for f in range(3):
+            ra = sc.update(p, hs.camera, f, staged)
+            rb = sc.update(p, hs.camera, f, inplace)
+            assert ra == rb and np.array_equal(staged, inplace), "frame %d" % f
+        assert not big[:3].any() and not big[3 + H:].any()
+    finally:
+        ptgpu.buffer_unregister(big)
+    with pytest.raises(ptgpu.PtError):
+        ptgpu.buffer_unregister(big)                   # not registered any more
+
+
 def test_cli_offline_render_matches_reference_harness(pthost, oracle, tmp_path):
     """offline.rs:16-60 through the C++ host CLI: banner, `{:.2}secs {}rays {:.2}Mrays/s`, and an output.png whose
     pixels are the oracle's frame through linear_to_srgb + vertical flip (math.rs:36-48, offline.rs:43-51)."""

@@ -157,6 +157,10 @@ def test_null_handles_are_errors_not_crashes(ptgpu):
     L.pt_scene_destroy(None)  # no-op
     assert L.pt_selftest_probe(0, 99, buf.ctypes.data, buf.ctypes.data, 4) == ptgpu.PT_ERR_INVALID_ARG
     assert L.pt_last_pass_ms(None, C.byref(ms)) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_buffer_register(None, 16) == ptgpu.PT_ERR_INVALID_ARG and L.pt_buffer_unregister(None) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_buffer_unregister(buf.ctypes.data) == ptgpu.PT_ERR_INVALID_ARG      # never registered
+    assert L.pt_scene_build_info(None, None, None, None, None) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_scene_debug_tree(None, None, 0) == ptgpu.PT_ERR_INVALID_ARG
 
 
 def test_comm_entry_points_validate_without_a_device(ptgpu):
