@@ -117,7 +117,7 @@ struct KArgs {
     uint32_t cull_axis;          // 0..2; 3 = culling off
     uint32_t cull_always;        // tiles that are always run (they hold spheres outside the sorted set)
     float cull_u0, cull_inv_cell;
-    float clip_min[3], clip_max[3];  // box of the sorted spheres, already padded
+    float clip_min[3], clip_max[3];  // box of the sorted spheres, padded (launch() widens it by the reach of the reference's f32 rounding)
     uint32_t verify;             // debug: count exact-positive pairs the prefilter did not flag
     unsigned long long *debug;   // [4] misses, candidates, overflow fallbacks, exact positives
     unsigned long long *wave_end; // optional (PTGPU_TIMING=1): wall clock at which each wave left the main loop

@@ -102,7 +102,7 @@ struct pt_scene {
     float rs2 = 0.f, m0 = 0.f, gamma = 0.f;
     uint32_t *d_cull_tab = nullptr;           // tile-culling tables (cull_axis == 3: off)
     uint32_t cull_axis = 3, cull_always = 0;
-    float cull_u0 = 0.f, cull_inv_cell = 0.f, clip_min[3] = {0, 0, 0}, clip_max[3] = {0, 0, 0};
+    float cull_u0 = 0.f, cull_inv_cell = 0.f, cull_rmin = 0.f, cull_rmax = 0.f, cull_cell = 0.f, rs_small = 0.f, clip_min[3] = {0, 0, 0}, clip_max[3] = {0, 0, 0};
     unsigned long long *d_debug = nullptr;    // 4 u64 counters (verify mode)
     uint32_t *d_tile_buf = nullptr;           // [8 scratch words | n tile costs | n tile order]
     float *d_pilot_rgb = nullptr;             // never-read frame buffer of the pilot pass
@@ -286,7 +286,7 @@ struct MfmaPrep {
     // tile culling: sort axis (3 = off), tiles that are always run, lookup tables (kCullCells cells), padded box of the sorted spheres
     uint32_t cull_axis = 3, cull_always = 0;
     std::vector<uint32_t> cull_tab;
-    float cull_u0 = 0.f, cull_inv_cell = 0.f, clip_min[3] = {0, 0, 0}, clip_max[3] = {0, 0, 0};
+    float cull_u0 = 0.f, cull_inv_cell = 0.f, cull_rmin = 0.f, cull_rmax = 0.f, cull_cell = 0.f, clip_min[3] = {0, 0, 0}, clip_max[3] = {0, 0, 0};
 };
 
 uint16_t f16_bits(_Float16 h) {
@@ -389,6 +389,12 @@ bool prepare_mfma(const pt_scene_desc *desc, const MotionIn *motion, double t_lo
             out.cull_axis = (uint32_t)ax;
             out.cull_u0 = out.clip_min[ax];
             const double cell = std::max(((double)out.clip_max[ax] - (double)out.clip_min[ax]) / (double)kCullCells, 1e-30);
+            double rmin = 1e300, rmax = 0.0;
+            for (size_t j = 0; j < full_tiles * 32; ++j) {
+                const double r = std::fabs((double)desc->spheres[small[j]].radius);
+                rmin = std::min(rmin, r), rmax = std::max(rmax, r);
+            }
+            out.cull_rmin = (float)rmin, out.cull_rmax = (float)rmax, out.cull_cell = (float)cell;
             out.cull_inv_cell = (float)(1.0 / cell);
             out.cull_tab.assign(2 * kCullCells, 0u);
             for (int c = 0; c < kCullCells; ++c) {
@@ -919,6 +925,7 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
                 }
                 s->cull_axis = prep.cull_axis, s->cull_always = prep.cull_always;
                 s->cull_u0 = prep.cull_u0, s->cull_inv_cell = prep.cull_inv_cell;
+                s->cull_rmin = prep.cull_rmin, s->cull_rmax = prep.cull_rmax, s->cull_cell = prep.cull_cell, s->rs_small = (float)prep.rs;
                 memcpy(s->clip_min, prep.clip_min, 12), memcpy(s->clip_max, prep.clip_max, 12);
             }
             s->n_tiles = prep.n_tiles;
@@ -1418,6 +1425,28 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.cull_always = s->cull_always;
     A.cull_u0 = s->cull_u0, A.cull_inv_cell = s->cull_inv_cell;
     memcpy(A.clip_min, s->clip_min, 12), memcpy(A.clip_max, s->clip_max, 12);
+    if (A.cull_axis < 3u) {
+        // How far can the reference's f32 discriminant (sphere.rs:33-37) inflate a sorted sphere for THIS camera? Its error is
+        // <= ~1.3e-6 a (|o - c|^2 + r^2); every ray origin is the lens or a point of the scene, so
+        // |o - c| <= max(|camera - c0| + lens, Rs) + Rs. A hit then lies within sqrt(r^2 + E) - r of the true sphere: the
+        // clip box is widened by that reach (4x safety), and when it nears the one cell of slack the tables carry, the
+        // launch runs every tile instead.
+        const double dx = (double)cam->origin[0] - s->c0[0], dy = (double)cam->origin[1] - s->c0[1], dz = (double)cam->origin[2] - s->c0[2];
+        const double ulen = std::sqrt((double)cam->u[0] * cam->u[0] + (double)cam->u[1] * cam->u[1] + (double)cam->u[2] * cam->u[2]);
+        const double vlen = std::sqrt((double)cam->v[0] * cam->v[0] + (double)cam->v[1] * cam->v[1] + (double)cam->v[2] * cam->v[2]);
+        const double lens = std::fabs((double)cam->lens_radius) * (ulen + vlen);
+        const double dmax = std::max(std::sqrt(dx * dx + dy * dy + dz * dz) + lens, (double)s->rs_small) + (double)s->rs_small;
+        const double E = 4.0 * 1.3e-6 * (dmax * dmax + (double)s->cull_rmax * s->cull_rmax);
+        const double reach = std::sqrt((double)s->cull_rmin * s->cull_rmin + E) - (double)s->cull_rmin;
+        if (!(reach < 0.6 * (double)s->cull_cell)) {
+            A.cull_axis = 3u;
+        } else {
+            for (int k = 0; k < 3; ++k) {
+                A.clip_min[k] = std::nextafter((float)((double)A.clip_min[k] - reach), -3.0e38f);
+                A.clip_max[k] = std::nextafter((float)((double)A.clip_max[k] + reach), 3.0e38f);
+            }
+        }
+    }
     A.large = s->d_large;
     A.n_tiles = mfma ? s->n_tiles : 0u;
     A.n_large = s->n_large;

@@ -107,7 +107,7 @@ def test_mfma_prefilter_never_drops_a_positive_discriminant(ptgpu, pthost, prese
     assert rays == rays_exact and np.array_equal(out, exact)
 
 
-def _random_scene(ptgpu, oracle, seed, n, half, rmax, cam_dist):
+def _random_scene(ptgpu, oracle, seed, n, half, rmax, cam_dist, look_perm=(0, 1, 2)):
     """Synthetic sphere cloud (not a reference preset) to stress the prefilter's margins and the internal tree."""
     rng = np.random.default_rng(seed)
     centres = rng.uniform(-half, half, size=(n, 3)).astype(np.float32)
@@ -125,7 +125,7 @@ def _random_scene(ptgpu, oracle, seed, n, half, rmax, cam_dist):
         else:
             materials.append((ptgpu.MAT_DIELECTRIC, (0, 0, 0), 1.5, -1))
     cam = np.zeros(24, np.float32)
-    look = np.array([cam_dist, 0.3 * cam_dist + 1.0, 0.2 * cam_dist], np.float32)
+    look = np.array([cam_dist, 0.3 * cam_dist + 1.0, 0.2 * cam_dist], np.float32)[list(look_perm)]
     at, up = np.zeros(3, np.float32), np.array([0, 1, 0], np.float32)
     vfov = float(np.degrees(2 * np.arctan(1.2 * half / np.linalg.norm(look))))
     oracle.lib().ora_camera_new(look.ctypes.data, at.ctypes.data, up.ctypes.data, vfov, 1.5, 0.05,
@@ -159,6 +159,27 @@ def test_synthetic_scenes_all_scan_paths_agree(ptgpu, oracle, seed, n, half, rma
         c = sc.debug_counters()
         assert c["misses"] == 0 and c["exact_positives"] > 0, c
         assert np.array_equal(ver, exact)
+    sc.close()
+
+
+@pytest.mark.parametrize("perm", [(0, 1, 2), (2, 0, 1), (1, 2, 0), (2, 1, 0)])
+@pytest.mark.parametrize("cam_dist", [300.0, 3000.0])
+def test_far_camera_on_every_axis_keeps_tile_culling_exact(ptgpu, oracle, perm, cam_dist):
+    """Small spheres seen from 10-100x the scene extent: the reference's f32 discriminant then accepts rays passing well
+    outside a sphere, so the tile culling must widen (or switch itself off) with the same error budget as the MFMA margin.
+    Camera placed towards each axis in turn (the tiles are sorted along ONE of them); default kernel == exact scan."""
+    desc, cam = _random_scene(ptgpu, oracle, 11, 500, 10.0, 0.2, cam_dist, look_perm=perm)
+    sc = ptgpu.Scene(desc, 0)
+    W, H, S = 150, 100, 4
+    p = ptgpu.PtParams(W, H, S, 10, 0, 0)
+    sc.set_tuning(0, 4 | 64)
+    exact = np.zeros((H, W, 3), np.float32)
+    rays_exact = sc.update(p, cam, 0, exact)
+    for variant in (0, 1024):
+        sc.set_tuning(0, variant)
+        out = np.zeros((H, W, 3), np.float32)
+        rays = sc.update(p, cam, 0, out)
+        assert rays == rays_exact and np.array_equal(out, exact), "variant %d: %s" % (variant, _report(exact, out))
     sc.close()
 
 
@@ -673,6 +694,39 @@ def test_random_sphere_worlds_match_the_oracle(ptgpu, oracle, seed, n, spread, r
     out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh)
     assert rays == ref_rays, "ray_count %d vs oracle %d; %s" % (rays, ref_rays, _report(ref, out))
     assert np.array_equal(ref, out, equal_nan=True), _report(ref, out)
+
+
+@pytest.mark.parametrize("first", [70000, 70060, 70120, 70180])
+def test_fuzz_slice_of_seeded_random_worlds(ptgpu, oracle, first):
+    """A bounded slice (4 x 60 worlds x list/BVH) of tools/fuzz_worlds.py inside the suite: sphere worlds of assorted sizes
+    with extreme extras, general worlds (rects, cuboids, instances, media, image textures) and moving-sphere worlds, random
+    depth / frame number, every one bit-exact against the oracle; BVH sphere worlds additionally on the tree kernel."""
+    W, H, S = 64, 48, 2
+    bad = []
+    for seed in range(first, first + 60):
+        rng = np.random.default_rng(seed)
+        kind = seed % 3
+        if kind == 0:
+            n = int(rng.choice([3, 20, 33, 64, 150, 400, 800]))
+            extras = [(), ([0, -300, 0, 298],), ([0, 0, 0, 0.0], [2, 2, 2, -1e-3]), ([0, 0, 0, 25],)][int(rng.integers(0, 4))]
+            w = _random_sphere_world(oracle, seed, n, W, H, float(rng.uniform(2, 15)), float(rng.uniform(0.1, 1.5)), extras)
+        elif kind == 1:
+            w = _random_world(oracle, seed, int(rng.integers(1, 40)), (0, 1, 2, 3, 4, 5), W, H, sky=(0.3, 0.3, 0.3) if seed & 1 else None)
+            if seed % 4 == 1:
+                w = _with_image_textures(w, seed)
+        else:
+            times = [((0.0, 1.0),), ((0.0, 1.0), (-1.0, 2.0)), ((0.25, 0.5),)][int(rng.integers(0, 3))]
+            w = _random_world(oracle, seed, int(rng.choice([10, 60, 200])), (0, 1, 1), W, H, moving_times=times, media=False, instances=False)
+        depth, frame = int(rng.choice([0, 1, 2, 5, 10, 10, 10, 25])), int(rng.choice([0, 0, 1, 7]))
+        for bvh in (False, True):
+            out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh, depth=depth, frame=frame)
+            ok = rays == ref_rays and np.array_equal(ref, out, equal_nan=True)
+            if ok and bvh and kind != 1:
+                out2, rays2, _, _ = _render_world_both(ptgpu, oracle, w, W, H, S, bvh, variant=256, depth=depth, frame=frame)
+                ok = rays2 == ref_rays and np.array_equal(ref, out2, equal_nan=True)
+            if not ok:
+                bad.append((seed, kind, bvh))
+    assert not bad, bad
 
 
 def _with_image_textures(w, seed):

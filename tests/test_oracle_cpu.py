@@ -35,6 +35,16 @@ def test_splitmix64_seed0(oracle):
     assert ["%016x" % v for v in out] == KAT["splitmix64_seed0"]
 
 
+def test_splitmix64_public_vector_seed_1234567(oracle):
+    """The widely published SplitMix64 known-answer vector (seed 1234567; e.g. the reference C implementation's test
+    and rand_core's own unit test): pins the seeding half of Xoshiro256Plus::seed_from_u64 to a value nobody here made up."""
+    import ctypes
+    L = oracle.lib()
+    out = (ctypes.c_uint64 * 5)()
+    L.ora_splitmix64(1234567, out, 5)
+    assert list(out) == KAT["splitmix64_seed1234567"]
+
+
 def test_seed_from_u64_streams(oracle):
     L = oracle.lib()
     st = _state([0, 0, 0, 0])
