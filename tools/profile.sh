@@ -10,7 +10,7 @@ EXTRA="$*"   # optional bench.py arguments (e.g. --preset perlin_spheres --bvh .
 OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline $EXTRA"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $BENCH > $OUT/stats.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY \
   --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- $BENCH > $OUT/pmc_sq.log 2>&1
