@@ -1235,6 +1235,12 @@ template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVIN
 __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4_WAVES : PT_MINWAVES) : 1) void pt_trace_kernel(const KArgs A) {
     static_assert(BLK == kBlock || (MFMA && !BVH), "only the MFMA list kernels take another workgroup size");
     constexpr bool TREE4 = BVH && SPH_LDS;   // tree kernels: SPH_LDS selects the 4-wide tree (false: the binary one, variant bit 2048)
+    // Wide (one workgroup per CU) MFMA kernels: every attenuation a path can pick up is one of a finite PALETTE -- a sphere's
+    // constant / metal albedo, one of its two checker colours, or white (dielectric) -- so the per-lane attenuation stack
+    // holds 16-bit codes (sphere index | even-checker bit; 0x7fff = white) instead of three floats, and the fold reads the
+    // colours back from the per-sphere shading records, which live in LDS here. 18 instead of 108 bytes of LDS per lane.
+    // (launch() only picks a wide kernel for scenes whose textures are all Constant or Checker-of-two-Constants.)
+    constexpr bool PAL = (BLK != kBlock);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
     float4 *s_sph = reinterpret_cast<float4 *>(smem);  // list mode: n_spheres x (cx,cy,cz,r^2)
@@ -1260,7 +1266,10 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 
     const float4 *s_par = reinterpret_cast<const float4 *>(p);   // frame parameters (kLdsParamBytes)
     p += kLdsParamBytes;
-    float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][BLK] attenuation stack
+    float4 *s_shade = reinterpret_cast<float4 *>(p);    // PAL: the per-sphere shading records (64 B each)
+    p += PAL ? (A.n_spheres + 1u) * 64u : 0u;
+    float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][BLK] attenuation stack (PAL: u16 [max_depth][BLK] palette codes)
+    uint16_t *s_pal = reinterpret_cast<uint16_t *>(p);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1273,6 +1282,10 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         for (uint32_t k = tid; k < A.n_tiles * 32u; k += BLK) s_tile_sphere[k] = A.tile_sphere[k];
         if (A.cull_axis < 3u)
             for (uint32_t k = tid; k < 2u * kCullCells; k += BLK) s_cull[k] = A.cull_tab[k];
+    }
+    if (PAL) {
+        for (uint32_t k = tid; k < A.n_spheres * 4u; k += BLK) s_shade[k] = A.shade[k];
+        if (tid < 4) s_shade[A.n_spheres * 4u + tid] = make_float4(1.f, 1.f, 1.f, 0.f);   // the white entry (Dielectric, material.rs:117)
     }
     if (BVH && A.nodes_in_lds) {
         const uint4 *src = reinterpret_cast<const uint4 *>(A.wnodes);
@@ -1333,6 +1346,13 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     Rng rng{0, 0, 0, 0};
     f3 col = mk3(0.f, 0.f, 0.f), o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
     f3 att0 = mk3(1.f, 1.f, 1.f);   // attenuation of the first bounce (deeper ones: the stack)
+    uint32_t att0c = 0u;            // PAL: its palette code
+    const float4 *shade = PAL ? (const float4 *)s_shade : A.shade;
+    const uint32_t kWhite = A.n_spheres;   // PAL: code of (1, 1, 1): one extra record behind the spheres'
+    auto palette_colour = [&](uint32_t code) -> f3 {   // PAL: the colour behind a stack entry
+        const float4 q = s_shade[4u * (code & 0x7fffu) + 2u + (code >> 15)];
+        return mk3(q.x, q.y, q.z);
+    };
     float rtime = 0.f;  // ray.time (only MOVING kernels read it)
 
     for (;;) {
@@ -1482,8 +1502,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     V = mk3(w1 + (t * 0.5f) * 0.3f, w1 + (t * 0.7f) * 0.3f, w1 + (t * 1.0f) * 0.3f);
                 }
             } else {
-                const float4 sp = sphere_at<MOVING>(A, idx, A.shade[4 * idx], rtime), q1 = A.shade[4 * idx + 1],
-                             qa = A.shade[4 * idx + 2], qb = A.shade[4 * idx + 3];
+                const float4 sp = sphere_at<MOVING>(A, idx, shade[4 * idx], rtime), q1 = shade[4 * idx + 1],
+                             qa = shade[4 * idx + 2], qb = shade[4 * idx + 3];
                 const f3 centre = mk3(sp.x, sp.y, sp.z);
                 const f3 point = add3(o, scale3(d, t_hit));            // ray.rs:24-26
                 const f3 normal = divs3(sub3(point, centre), sp.w);    // sphere.rs:42
@@ -1502,19 +1522,26 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = surface_colour();
                 bool scattered = false;
                 f3 att = mk3(1.f, 1.f, 1.f), nd = d;
+                uint32_t attc = kWhite;    // PAL: palette code of `att` (white unless a branch says otherwise)
                 if (depth < __float_as_uint(s_par[12].z)) {   // max_depth
                     // every scatter ends in `.normalize()` of some vector (material.rs:63,84,112,119): the branches
                     // only produce that vector, the normalisation is issued once for the whole wave
                     f3 raw = d;
                     if (m.kind == PT_MAT_LAMBERTIAN) {  // material.rs:52-67
                         const f3 target = add3(add3(point, normal), random_unit_vector(rng));
-                        att = surface_colour();
+                        if (PAL) {
+                            const bool even = (m.flags & kShadeChecker2) && !checker_is_odd(10.0f * point.x, 10.0f * point.y, 10.0f * point.z);
+                            attc = (uint32_t)idx | (even ? 0x8000u : 0u);
+                        } else {
+                            att = surface_colour();
+                        }
                         raw = sub3(target, point);
                         scattered = true;
                     } else if (m.kind == PT_MAT_METAL) {  // material.rs:69-89
                         const f3 reflected = reflect3(d, normal);
                         if (dot3(reflected, normal) > 0.0f) {
                             att = mk3(qa.x, qa.y, qa.z);
+                            attc = (uint32_t)idx;
                             const f3 rs = random_in_unit_sphere(rng);
                             raw = add3(reflected, scale3(rs, m.param));
                             scattered = true;
@@ -1549,7 +1576,10 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     // the first scatter's attenuation stays in registers (measured best: 0 levels -1.5 %, 2 levels -2.3 %;
                     // it also removes 40 % of the stack's HBM writes); deeper levels go to the per-lane stack, level d
                     // at slot d - 1
-                    if (depth == 0u) {
+                    if (PAL) {
+                        if (depth == 0u) att0c = attc;
+                        else s_pal[(depth - 1u) * BLK + tid] = (uint16_t)attc;
+                    } else if (depth == 0u) {
                         att0 = att;
                     } else {
                         path_st((depth - 1u) * 3u + 0u, att.x);
@@ -1567,12 +1597,31 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             }
             if (terminal) {
                 // scene.rs:62-64 unwound: emitted(=0) + attenuation * deeper, innermost first
-                for (int k = (int)depth - 1; k >= 1; --k) {
-                    V.x = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 0u) * V.x;
-                    V.y = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 1u) * V.y;
-                    V.z = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 2u) * V.z;
+                if (PAL) {
+                    // three levels per trip: the codes, then the colours, are fetched together (two LDS round trips per
+                    // trip instead of two per level); the products keep the innermost-first order
+                    for (int k = (int)depth - 1; k >= 1; k -= 3) {
+                        const uint32_t ca = s_pal[(uint32_t)(k - 1) * BLK + tid];
+                        const uint32_t cb = s_pal[(uint32_t)(k >= 2 ? k - 2 : 0) * BLK + tid];
+                        const uint32_t cc = s_pal[(uint32_t)(k >= 3 ? k - 3 : 0) * BLK + tid];
+                        const f3 qa3 = palette_colour(ca), qb3 = palette_colour(cb), qc3 = palette_colour(cc);
+                        V = mk3(0.0f + qa3.x * V.x, 0.0f + qa3.y * V.y, 0.0f + qa3.z * V.z);
+                        if (k >= 2) V = mk3(0.0f + qb3.x * V.x, 0.0f + qb3.y * V.y, 0.0f + qb3.z * V.z);
+                        if (k >= 3) V = mk3(0.0f + qc3.x * V.x, 0.0f + qc3.y * V.y, 0.0f + qc3.z * V.z);
+                    }
                 }
-                if (depth > 0u) V = mk3(0.0f + att0.x * V.x, 0.0f + att0.y * V.y, 0.0f + att0.z * V.z);
+                for (int k = PAL ? 0 : (int)depth - 1; k >= 1; --k) {
+                    if (PAL) {
+                    } else {
+                        V.x = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 0u) * V.x;
+                        V.y = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 1u) * V.y;
+                        V.z = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 2u) * V.z;
+                    }
+                }
+                if (depth > 0u) {
+                    const f3 c0 = PAL ? palette_colour(att0c) : att0;
+                    V = mk3(0.0f + c0.x * V.x, 0.0f + c0.y * V.y, 0.0f + c0.z * V.z);
+                }
                 col = add3(col, V);  // scene.rs:110
                 sample += 1;
                 need_cam = true;

@@ -69,6 +69,7 @@ struct pt_scene {
     uint32_t has_sky = 0;
     float sky[3] = {0, 0, 0};
     uint32_t has_noise = 0;
+    bool palette_ok = false;   // wide MFMA kernels keep palette codes on the attenuation stack (pt_kernel.h PAL)
     // device memory
     float4 *d_spheres = nullptr, *d_spheres_r2 = nullptr, *d_shade = nullptr;
     uint32_t *d_sphere_mat = nullptr;
@@ -756,6 +757,7 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
     }
     // per-sphere shading records (one 64-byte fetch per hit)
     std::vector<float4> shade(4 * (size_t)desc->n_spheres);
+    bool palette_ok = true;   // every scattering material's attenuation is a per-sphere constant or one of two checker colours
     for (uint32_t i = 0; i < desc->n_spheres; ++i) {
         const pt_sphere &p = desc->spheres[i];
         const pt_material &m = desc->materials[desc->sphere_material[i]];
@@ -774,12 +776,15 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
                 qb = make_float4(e.color[0], e.color[1], e.color[2], 0.f);
             }
         }
+        if (m.kind == PT_MAT_LAMBERTIAN && flags == 0) palette_ok = false;
+        if (m.kind > PT_MAT_DIFFUSE_LIGHT) palette_ok = false;
         union { uint32_t u; float f; } k{m.kind}, fl{flags}, tx{(uint32_t)m.texture};
         shade[4 * i] = make_float4(p.cx, p.cy, p.cz, p.radius);
         shade[4 * i + 1] = make_float4(k.f, fl.f, tx.f, m.param);
         shade[4 * i + 2] = qa;
         shade[4 * i + 3] = qb;
     }
+    s->palette_ok = palette_ok;
     std::vector<DMat> mats(desc->n_materials);
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
         const pt_material &m = desc->materials[i];
@@ -1484,10 +1489,15 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     // (1.3 GB per 1200x800x64 frame). Variant bit 2 keeps the three 256-thread workgroups with the stack in HBM.
     const uint32_t stack_levels = params->max_depth > 1u ? params->max_depth - 1u : 1u;
     uint32_t blk = kBlock;
-    if (mfma && (s->variant & 2u) == 0 && (A.verify & 1u) == 0 && s->blocks_per_cu == 0) {
-        const uint64_t wide = (uint64_t)lds + mfma_queue_bytes(kWideBlock) + s->n_tiles * 2048u +
-                              ((s->n_tiles * 64u + 15u) & ~15u) + 8u * kCullCells + (uint64_t)stack_levels * 3ull * kWideBlock * 4ull;
-        if (wide <= kLdsBudget) blk = kWideBlock;
+    // wide kernels: 16-bit palette codes on the attenuation stack + the shading records in LDS (pt_kernel.h PAL)
+    const auto wide_extra = [&](uint32_t b) { return ((uint64_t)s->n_spheres + 1ull) * 64ull + (((uint64_t)stack_levels * 2ull * b + 15ull) & ~15ull); };
+    if (mfma && s->palette_ok && (s->variant & 2u) == 0 && (A.verify & 1u) == 0 && s->blocks_per_cu == 0) {
+        const auto wide_lds = [&](uint32_t b) {
+            return (uint64_t)lds + mfma_queue_bytes(b) + s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + 8u * kCullCells + wide_extra(b);
+        };
+        // 16 waves per CU (four per SIMD, 128 VGPRs) when the LDS allows, else 12 (variant bit 4096 keeps 12 for A/B runs)
+        if (wide_lds(1024u) <= kLdsBudget && (s->variant & 4096u) == 0) blk = 1024u;
+        else if (wide_lds(kWideBlock) <= kLdsBudget) blk = kWideBlock;
     }
     if (!bvh) lds += mfma ? mfma_queue_bytes(blk) : scan_queue_bytes(blk);
     if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + 8u * kCullCells;
@@ -1498,8 +1508,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     // run four workgroups per CU (123 VGPRs): as many levels as fit next to four of them, deeper ones in HBM/L2.
     // Exact-scan list kernels: all or nothing.
     uint32_t lds_levels = 0;
-    if (blk == kWideBlock) {
-        lds_levels = stack_levels;
+    if (blk == kWideBlock || blk == 1024u) {
+        lds_levels = 0;   // (the palette stack is accounted for below)
     } else if (bvh && (s->variant & 2u) == 0) {
         // workgroups per CU the registers allow (4 for the binary tree kernel's 123 VGPRs)
         const uint32_t wg_regs = tree4 ? blocks_per_cu_by_registers(moving ? reinterpret_cast<const void *>(pt_trace_kernel<true, true, false, false, false, true>)
@@ -1511,53 +1521,53 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     }
     A.stack_in_lds = lds_levels * 3u;
     lds += lds_levels * 3u * blk * 4u;
+    if (blk == kWideBlock || blk == 1024u) lds += (uint32_t)wide_extra(blk);
     A.lds_sphere_bytes = sph_bytes;
 
     A.tile_order = nullptr;
     A.tile_cost = nullptr;
 
-    void (*kern)(const KArgs) = nullptr;
-    void (*pilot_kern)(const KArgs) = nullptr;
-    if (bvh && (A.verify & 1u))   // variant 8 on a tree kernel: count node fetches / sphere tests (no pilot: one launch to count)
-        kern = tree4 ? (moving ? pt_trace_kernel<true, true, false, true, false, true> : pt_trace_kernel<true, true, false, true, false, false>)
-                     : (moving ? pt_trace_kernel<true, false, false, true, false, true> : pt_trace_kernel<true, false, false, true, false, false>);
-    else if (moving && bvh)
-        kern = tree4 ? pt_trace_kernel<true, true, false, false, false, true> : pt_trace_kernel<true, false, false, false, false, true>,
-        pilot_kern = tree4 ? pt_trace_kernel<true, true, false, false, true, true> : pt_trace_kernel<true, false, false, false, true, true>;
-    else if (mfma && ref_bvh && moving && (A.verify & 1u))
-        kern = pt_trace_kernel<false, true, true, true, false, true, true>;
-    else if (mfma && ref_bvh && moving && blk == kWideBlock)
-        kern = pt_trace_kernel<false, true, true, false, false, true, true, kWideBlock>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true, true, kWideBlock>;
-    else if (mfma && ref_bvh && moving)
-        kern = pt_trace_kernel<false, true, true, false, false, true, true>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true, true>;
-    else if (mfma && ref_bvh && (A.verify & 1u))
-        kern = pt_trace_kernel<false, true, true, true, false, false, true>;
-    else if (mfma && ref_bvh && blk == kWideBlock)
-        kern = pt_trace_kernel<false, true, true, false, false, false, true, kWideBlock>, pilot_kern = pt_trace_kernel<false, true, true, false, true, false, true, kWideBlock>;
-    else if (mfma && ref_bvh)
-        kern = pt_trace_kernel<false, true, true, false, false, false, true>, pilot_kern = pt_trace_kernel<false, true, true, false, true, false, true>;
-    else if (moving && (A.verify & 1u))
-        kern = pt_trace_kernel<false, true, true, true, false, true>;
-    else if (moving && blk == kWideBlock)
-        kern = pt_trace_kernel<false, true, true, false, false, true, false, kWideBlock>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true, false, kWideBlock>;
-    else if (moving)
-        kern = pt_trace_kernel<false, true, true, false, false, true>, pilot_kern = pt_trace_kernel<false, true, true, false, true, true>;
-    else if (bvh)
-        kern = tree4 ? pt_trace_kernel<true, true, false, false, false> : pt_trace_kernel<true, false, false, false, false>,
-        pilot_kern = tree4 ? pt_trace_kernel<true, true, false, false, true> : pt_trace_kernel<true, false, false, false, true>;
-    else if (mfma && (A.verify & 1u))
-        kern = pt_trace_kernel<false, true, true, true, false>;
-    else if (mfma && blk == kWideBlock)
-        kern = pt_trace_kernel<false, true, true, false, false, false, false, kWideBlock>, pilot_kern = pt_trace_kernel<false, true, true, false, true, false, false, kWideBlock>;
-    else if (mfma)
-        kern = pt_trace_kernel<false, true, true, false, false>, pilot_kern = pt_trace_kernel<false, true, true, false, true>;
-    else if (sph_lds)
+    // kernel flavour: pt_trace_kernel<BVH, SPH_LDS, MFMA, VERIFY, PILOT, MOVING, GATE, BLK>; the pilot pass is the PILOT twin
+    typedef void (*Kern)(const KArgs);
+    Kern kern = nullptr, pilot_kern = nullptr;
+    const bool verify = (A.verify & 1u) != 0;
+    if (bvh) {   // tree kernels (SPH_LDS = true: the 4-wide tree); verify: count node fetches / sphere tests, one launch, no pilot
+        static const Kern tree[2][2][3] = {   // [tree4][moving][main, pilot, verify]
+            {{pt_trace_kernel<true, false, false, false, false, false>, pt_trace_kernel<true, false, false, false, true, false>, pt_trace_kernel<true, false, false, true, false, false>},
+             {pt_trace_kernel<true, false, false, false, false, true>, pt_trace_kernel<true, false, false, false, true, true>, pt_trace_kernel<true, false, false, true, false, true>}},
+            {{pt_trace_kernel<true, true, false, false, false, false>, pt_trace_kernel<true, true, false, false, true, false>, pt_trace_kernel<true, true, false, true, false, false>},
+             {pt_trace_kernel<true, true, false, false, false, true>, pt_trace_kernel<true, true, false, false, true, true>, pt_trace_kernel<true, true, false, true, false, true>}}};
+        const Kern *t = tree[tree4 ? 1 : 0][moving ? 1 : 0];
+        kern = verify ? t[2] : t[0], pilot_kern = verify ? nullptr : t[1];
+    } else if (mfma) {   // MFMA list kernels; GATE = a BVH world's accept rules; wide = one 768- or 1024-thread workgroup per CU
+        static const Kern list[2][2][7] = {   // [gate][moving][256 main, 256 pilot, verify, 768 main, 768 pilot, 1024 main, 1024 pilot]
+            {{pt_trace_kernel<false, true, true, false, false, false, false>, pt_trace_kernel<false, true, true, false, true, false, false>,
+              pt_trace_kernel<false, true, true, true, false, false, false>,
+              pt_trace_kernel<false, true, true, false, false, false, false, 768>, pt_trace_kernel<false, true, true, false, true, false, false, 768>,
+              pt_trace_kernel<false, true, true, false, false, false, false, 1024>, pt_trace_kernel<false, true, true, false, true, false, false, 1024>},
+             {pt_trace_kernel<false, true, true, false, false, true, false>, pt_trace_kernel<false, true, true, false, true, true, false>,
+              pt_trace_kernel<false, true, true, true, false, true, false>,
+              pt_trace_kernel<false, true, true, false, false, true, false, 768>, pt_trace_kernel<false, true, true, false, true, true, false, 768>,
+              pt_trace_kernel<false, true, true, false, false, true, false, 1024>, pt_trace_kernel<false, true, true, false, true, true, false, 1024>}},
+            {{pt_trace_kernel<false, true, true, false, false, false, true>, pt_trace_kernel<false, true, true, false, true, false, true>,
+              pt_trace_kernel<false, true, true, true, false, false, true>,
+              pt_trace_kernel<false, true, true, false, false, false, true, 768>, pt_trace_kernel<false, true, true, false, true, false, true, 768>,
+              pt_trace_kernel<false, true, true, false, false, false, true, 1024>, pt_trace_kernel<false, true, true, false, true, false, true, 1024>},
+             {pt_trace_kernel<false, true, true, false, false, true, true>, pt_trace_kernel<false, true, true, false, true, true, true>,
+              pt_trace_kernel<false, true, true, true, false, true, true>,
+              pt_trace_kernel<false, true, true, false, false, true, true, 768>, pt_trace_kernel<false, true, true, false, true, true, true, 768>,
+              pt_trace_kernel<false, true, true, false, false, true, true, 1024>, pt_trace_kernel<false, true, true, false, true, true, true, 1024>}}};
+        const Kern *t = list[ref_bvh ? 1 : 0][moving ? 1 : 0];
+        const int w = blk == 1024u ? 5 : (blk == kWideBlock ? 3 : 0);
+        kern = verify ? t[2] : t[w], pilot_kern = verify ? nullptr : t[w + 1];
+    } else if (sph_lds) {
         kern = pt_trace_kernel<false, true, false, false, false>, pilot_kern = pt_trace_kernel<false, true, false, false, true>;
-    else
+    } else {
         kern = pt_trace_kernel<false, false, false, false, false>;
+    }
     // ---- persistent grid: CUs x resident blocks --------------------------------
     uint32_t bpc = s->blocks_per_cu;
-    if (bpc == 0) bpc = (blk == kWideBlock) ? 1u : (bvh ? 4u : 3u);
+    if (bpc == 0) bpc = (blk == kWideBlock || blk == 1024u) ? 1u : (bvh ? 4u : 3u);
     const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
     if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
     if (bpc > 8u) bpc = 8u;
@@ -1567,7 +1577,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (grid > need) grid = need;
     if (grid == 0) grid = 1;
 
-    if (lds_levels < stack_levels) {
+    if (blk == kBlock && lds_levels < stack_levels) {
         const size_t need_floats = (size_t)grid * params->max_depth * 3ull * blk;
         if (need_floats > s->d_gstack_floats) {
             (void)hipFree(s->d_gstack);
