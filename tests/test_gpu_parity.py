@@ -696,6 +696,22 @@ def test_random_sphere_worlds_match_the_oracle(ptgpu, oracle, seed, n, spread, r
     assert np.array_equal(ref, out, equal_nan=True), _report(ref, out)
 
 
+@pytest.mark.parametrize("n,bvh", [(120, False), (120, True), (500, False)])
+def test_sphere_world_with_a_nested_checker_leaves_the_palette_kernels(ptgpu, oracle, n, bvh):
+    """The wide MFMA kernels keep 16-bit palette codes on the attenuation stack, which needs every texture to be a Constant
+    or a Checker of two Constants. A Checker whose child is itself a Checker (texture.rs:78-85 recurses) is not: such a
+    world must fall back to the float stack (256-thread MFMA kernel) and still match the oracle bit for bit."""
+    W, H, S = 96, 64, 3
+    w = _random_sphere_world(oracle, 4242 + n, n, W, H, 6.0, 0.7)
+    tex = np.concatenate([w["textures"], np.array([[1, 0, 0, 0, 4, 2, 0]], np.float32)])       # checker(odd = checker #4, even = constant #2)
+    mats = np.concatenate([w["materials"], np.array([[0, 0, 0, 0, 0, len(tex) - 1]], np.float32)])
+    rec = w["hitables"].copy()
+    rec[::3, 1] = len(mats) - 1
+    w = dict(w, textures=tex, materials=mats, hitables=rec)
+    out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh)
+    assert rays == ref_rays and np.array_equal(ref, out, equal_nan=True), _report(ref, out)
+
+
 @pytest.mark.parametrize("first", [70000, 70060, 70120, 70180])
 def test_fuzz_slice_of_seeded_random_worlds(ptgpu, oracle, first):
     """A bounded slice (4 x 60 worlds x list/BVH) of tools/fuzz_worlds.py inside the suite: sphere worlds of assorted sizes
