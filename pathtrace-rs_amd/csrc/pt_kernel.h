@@ -144,7 +144,8 @@ struct KArgs {
     const uint32_t *tile_order;  // optional permutation of the 8x8 work tiles (expensive tiles first)
     uint32_t *tile_cost;         // optional: rays spent per work tile (accumulated when a pixel completes)
     float *gstack;  // global path-stack fallback when max_depth*3*kBlock*4 exceeds the LDS budget
-    uint32_t stack_in_lds;       // 256-thread kernels: number of attenuation-stack slots (3 per level) kept in LDS; the rest in gstack
+    uint32_t stack_in_lds;       // 256-thread kernels: number of attenuation-stack slots (3 per level, 1 when mono) kept in LDS; the rest in gstack
+    uint32_t mono;               // every attenuation of the scene has three equal components (noise textures, greys, glass): one slot per level
     uint32_t lds_sphere_bytes;  // offsets of the dynamic LDS carve
 };
 
@@ -1581,6 +1582,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         else s_pal[(depth - 1u) * BLK + tid] = (uint16_t)attc;
                     } else if (depth == 0u) {
                         att0 = att;
+                    } else if (A.mono) {
+                        path_st(depth - 1u, att.x);
                     } else {
                         path_st((depth - 1u) * 3u + 0u, att.x);
                         path_st((depth - 1u) * 3u + 1u, att.y);
@@ -1612,6 +1615,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 }
                 for (int k = PAL ? 0 : (int)depth - 1; k >= 1; --k) {
                     if (PAL) {
+                    } else if (A.mono) {
+                        const float c = path_ld((uint32_t)(k - 1));
+                        V = mk3(0.0f + c * V.x, 0.0f + c * V.y, 0.0f + c * V.z);
                     } else {
                         V.x = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 0u) * V.x;
                         V.y = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 1u) * V.y;

@@ -70,6 +70,7 @@ struct pt_scene {
     float sky[3] = {0, 0, 0};
     uint32_t has_noise = 0;
     bool palette_ok = false;   // wide MFMA kernels keep palette codes on the attenuation stack (pt_kernel.h PAL)
+    bool mono_ok = false;      // every attenuation has three equal components: the float stack holds one value per level
     // device memory
     float4 *d_spheres = nullptr, *d_spheres_r2 = nullptr, *d_shade = nullptr;
     uint32_t *d_sphere_mat = nullptr;
@@ -785,6 +786,22 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
         shade[4 * i + 3] = qb;
     }
     s->palette_ok = palette_ok;
+    {   // "mono": Noise textures yield (v, v, v) (texture.rs:86-89), Dielectric attenuates by (1, 1, 1); constants / metal albedos count when grey
+        bool mono = true;
+        auto grey = [](const float c[3]) { return c[0] == c[1] && c[1] == c[2]; };
+        std::vector<int> tex_mono(desc->n_textures, 0);
+        for (uint32_t i = 0; i < desc->n_textures; ++i) {   // (children precede their checker: validate_tables)
+            const pt_texture &t = desc->textures[i];
+            tex_mono[i] = t.kind == PT_TEX_NOISE || (t.kind == PT_TEX_CONSTANT && grey(t.color)) ||
+                          (t.kind == PT_TEX_CHECKER && tex_mono[t.odd] && tex_mono[t.even]);
+        }
+        for (uint32_t i = 0; i < desc->n_spheres && mono; ++i) {
+            const pt_material &m = desc->materials[desc->sphere_material[i]];
+            if (m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_ISOTROPIC) mono = tex_mono[m.texture] != 0;
+            else if (m.kind == PT_MAT_METAL) mono = grey(m.albedo);
+        }
+        s->mono_ok = mono;
+    }
     std::vector<DMat> mats(desc->n_materials);
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
         const pt_material &m = desc->materials[i];
@@ -1474,8 +1491,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.wnodes = s->d_wnodes;
     A.n_nodes = s->n_nodes;
     A.bvh_root = tree4 ? (s->has_tree_items ? 0 : -1) : s->bin_root;   // (-1: every sphere is in bvh_large)
-    // a visit pushes at most three siblings, and only above the bottom level; +3 slots for the unconditional writes, even count
-    A.bvh_stack_entries = tree4 ? ((3u * (s->depth4 ? s->depth4 - 1u : 0u) + 4u) & ~1u) : (s->bvh_depth + 2u);
+    // a visit pushes at most three siblings, and only above the bottom level (3 (depth - 1) entries at most); a bottom node
+    // still WRITES its three slots (uncounted), hence + 3. 512 bytes per entry keep every later LDS region 16-byte aligned.
+    A.bvh_stack_entries = tree4 ? (3u * (s->depth4 ? s->depth4 - 1u : 0u) + 3u) : (s->bvh_depth + 2u);
     // tree nodes go to LDS only while FOUR workgroups still fit on the CU (with two levels of attenuation stack each):
     // the fourth wave per SIMD is worth more than LDS-resident nodes (random_spheres -B on the tree kernel: 7.4 vs 6.3
     // Grays/s), and the nodes stay L2-resident anyway
@@ -1501,7 +1519,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     }
     if (!bvh) lds += mfma ? mfma_queue_bytes(blk) : scan_queue_bytes(blk);
     if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + 8u * kCullCells;
-    const uint64_t path_bytes = (uint64_t)stack_levels * 3ull * blk * 4ull;
+    const uint32_t slots = s->mono_ok ? 1u : 3u;   // attenuation-stack slots per level (float stacks)
+    A.mono = s->mono_ok ? 1u : 0u;
+    const uint64_t path_bytes = (uint64_t)stack_levels * slots * blk * 4ull;
     // the 256-thread MFMA variant keeps the attenuation stack in HBM: its LDS goes to the A fragments, and 3 resident
     // workgroups per CU beat 1 with an LDS stack (measured 7.5 vs 3.0 Grays/s)
     // Stack slots (3 per level) kept in LDS. 768-thread kernels: all of them (that is what made them fit). Tree kernels
@@ -1515,12 +1535,12 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         const uint32_t wg_regs = tree4 ? blocks_per_cu_by_registers(moving ? reinterpret_cast<const void *>(pt_trace_kernel<true, true, false, false, false, true>)
                                                                            : reinterpret_cast<const void *>(pt_trace_kernel<true, true, false, false, false, false>), kBlock) : 4u;
         const uint32_t per_block = kLdsBudget / std::min(4u, std::max(1u, wg_regs));
-        if (per_block > lds) lds_levels = std::min<uint32_t>(stack_levels, (per_block - lds) / (3u * blk * 4u));
+        if (per_block > lds) lds_levels = std::min<uint32_t>(stack_levels, (per_block - lds) / (slots * blk * 4u));
     } else if (!bvh && !mfma && (s->variant & 2u) == 0 && lds + path_bytes <= kLdsPerBlockMax) {
         lds_levels = stack_levels;
     }
-    A.stack_in_lds = lds_levels * 3u;
-    lds += lds_levels * 3u * blk * 4u;
+    A.stack_in_lds = lds_levels * slots;
+    lds += lds_levels * slots * blk * 4u;
     if (blk == kWideBlock || blk == 1024u) lds += (uint32_t)wide_extra(blk);
     A.lds_sphere_bytes = sph_bytes;
 
