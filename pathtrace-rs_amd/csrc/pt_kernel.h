@@ -62,6 +62,7 @@ struct DWideNode;
 //   q2 = colour A (constant albedo / metal albedo / emitted constant / checker ODD)   q3 = checker EVEN colour
 constexpr uint32_t kShadeConst = 1u;    // texture is Constant: colour A
 constexpr uint32_t kShadeChecker2 = 2u; // texture is Checker of two Constants: odd = A, even = q3
+constexpr uint32_t kShadeNoise = 4u;    // texture is Noise: scale in A.x (texture.rs:86-89)
 
 struct DCamera {  // camera.rs:8-19
     f3 origin, lower_left_corner, horizontal, vertical, u, v, w;
@@ -1516,6 +1517,10 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     if (m.flags & kShadeChecker2) {
                         const bool odd = checker_is_odd(10.0f * point.x, 10.0f * point.y, 10.0f * point.z);
                         return odd ? mk3(qa.x, qa.y, qa.z) : mk3(qb.x, qb.y, qb.z);
+                    }
+                    if (m.flags & kShadeNoise) {   // texture.rs:86-89, resolved here: no dependent fetch of the texture record
+                        const float v1 = 1.0f + sinf(qa.x * point.z + 10.0f * perlin_turb(pn, point));
+                        return mk3(0.5f * v1, 0.5f * v1, 0.5f * v1);
                     }
                     return texture_value(A.texs, pn, m.tex, point);
                 };

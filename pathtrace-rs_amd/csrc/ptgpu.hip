@@ -775,9 +775,12 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
                 const pt_texture &o = desc->textures[t.odd], &e = desc->textures[t.even];
                 qa = make_float4(o.color[0], o.color[1], o.color[2], 0.f);
                 qb = make_float4(e.color[0], e.color[1], e.color[2], 0.f);
+            } else if (t.kind == PT_TEX_NOISE) {
+                flags = kShadeNoise;
+                qa = make_float4(t.scale, 0.f, 0.f, 0.f);
             }
         }
-        if (m.kind == PT_MAT_LAMBERTIAN && flags == 0) palette_ok = false;
+        if (m.kind == PT_MAT_LAMBERTIAN && (flags & (kShadeConst | kShadeChecker2)) == 0) palette_ok = false;
         if (m.kind > PT_MAT_DIFFUSE_LIGHT) palette_ok = false;
         union { uint32_t u; float f; } k{m.kind}, fl{flags}, tx{(uint32_t)m.texture};
         shade[4 * i] = make_float4(p.cx, p.cy, p.cz, p.radius);
