@@ -93,6 +93,7 @@ struct KArgs {
     const DWideNode *wnodes;  // binary internal tree (variant bit 2048): children's AABBs inside the parent
     const DNode4 *nodes4;     // 4-wide internal tree (default of the tree kernels), root = node 0
     const uint32_t *rank_sphere;     // BVH worlds: sphere of each DFS leaf rank (inverse of leaf_rank; decodes the hit key)
+    const float4 *leafrec;           // BVH worlds, 4-wide tree: [4*n] per sphere (sphere | gate min, chain count | gate max, chain offset | rank bits): ONE 64-byte fetch per exact test
     const uint32_t *leaf_rank;       // DFS (lhs before rhs) order of each sphere's leaf, for equal-t ties
     float root_min[3], root_max[3];
     uint32_t n_nodes, nodes_in_lds, bvh_stack_entries;
@@ -504,8 +505,11 @@ __device__ __forceinline__ bool aabb_hit_enter(const float mn[3], const float mx
 // BVH-world acceptance of a sphere hit (bvh.rs:37-62): the sphere only counts if every ancestor AABB of its leaf in
 // the CALLER's tree passes aabb.rs:46-58. Ancestor boxes nest, so the parent's box decides (plus the few ancestors
 // recorded in gate_chain above inverted boxes). A.gate == nullptr: list world, every hit counts.
+__device__ __forceinline__ bool gate_pass_loaded(const KArgs &A, const float4 gmn, const float4 gmx, f3 o, f3 rcp);
 __device__ __forceinline__ bool gate_pass(const KArgs &A, int k, f3 o, f3 rcp) {
-    const float4 gmn = A.gate[2 * k], gmx = A.gate[2 * k + 1];
+    return gate_pass_loaded(A, A.gate[2 * k], A.gate[2 * k + 1], o, rcp);
+}
+__device__ __forceinline__ bool gate_pass_loaded(const KArgs &A, const float4 gmn, const float4 gmx, f3 o, f3 rcp) {
     const float mn[3] = {gmn.x, gmn.y, gmn.z}, mx[3] = {gmx.x, gmx.y, gmx.z};
     float te;
     const uint32_t extra = __float_as_uint(gmn.w);
@@ -1059,7 +1063,14 @@ __device__ __forceinline__ unsigned long long key4_of(const KArgs &A, float t, i
 
 // exact reference test of one (ray, sphere) pair reduced into the owner's key (sphere.rs:29-66 with t_max = f32::MAX,
 // then the ancestor-AABB gate of a BVH world)
-__device__ __forceinline__ void pair_test4(const KArgs &A, int k, const float4 c, f3 o, f3 d, float a, unsigned long long *key) {
+// (BVH worlds fetch the sphere together with its gate box and rank: the accept rule then needs no dependent loads)
+template <bool MOVING>
+__device__ __forceinline__ void pair_test4(const KArgs &A, int k, float time, f3 o, f3 d, float a, unsigned long long *key) {
+    const bool gated = A.gate != nullptr;
+    const float4 *R = A.leafrec + 4 * k;
+    float4 c = gated ? R[0] : A.spheres[k], g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0;
+    if (gated) g0 = R[1], g1 = R[2], g2 = R[3];
+    c = sphere_at<MOVING>(A, k, c, time);
     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
@@ -1067,8 +1078,9 @@ __device__ __forceinline__ void pair_test4(const KArgs &A, int k, const float4 c
     if (disc > 0.0f) {
         float t = kMaxT;
         if (sphere_roots(a, b, disc, t)) {
-            const unsigned long long kk = key4_of(A, t, k);
-            if (kk < *key && (!A.gate || gate_pass(A, k, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z)))) atomicMin(key, kk);
+            const uint32_t low = gated ? (0xffffffffu - __float_as_uint(g2.x)) : (uint32_t)k;
+            const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | low;
+            if (kk < *key && (!gated || gate_pass_loaded(A, g0, g1, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z)))) atomicMin(key, kk);
         }
     }
 }
@@ -1085,7 +1097,7 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
         for (uint32_t j = 0; __any(j < st.qn); ++j)
             if (j < st.qn) {
                 const int k = (int)leafq[j * BLK + tid];
-                pair_test4(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, a, &w_keys[lane]);
+                pair_test4<MOVING>(A, k, time, o, d, a, &w_keys[lane]);
             }
     } else {
         uint32_t pos = incl - st.qn;
@@ -1101,7 +1113,7 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
             const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));
             const float pa = lane_fetch(owner, a);
             const float ptime = MOVING ? lane_fetch(owner, time) : 0.0f;
-            if (valid) pair_test4(A, k, sphere_at<MOVING>(A, k, A.spheres[k], ptime), po, pd, pa, &w_keys[owner]);
+            if (valid) pair_test4<MOVING>(A, k, ptime, po, pd, pa, &w_keys[owner]);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
