@@ -93,6 +93,7 @@ struct KArgs {
     const DWideNode *wnodes;  // binary internal tree (variant bit 2048): children's AABBs inside the parent
     const DNode4 *nodes4;     // 4-wide internal tree (default of the tree kernels), root = node 0
     const uint32_t *rank_sphere;     // BVH worlds: sphere of each DFS leaf rank (inverse of leaf_rank; decodes the hit key)
+    const float4 *shade_rank;        // BVH worlds, 4-wide tree: the shading records in DFS-rank order (the hit key carries the rank)
     const float4 *leafrec;           // BVH worlds, 4-wide tree: [4*n] per sphere (sphere | gate min, chain count | gate max, chain offset | rank bits): ONE 64-byte fetch per exact test
     const uint32_t *leaf_rank;       // DFS (lhs before rhs) order of each sphere's leaf, for equal-t ties
     float root_min[3], root_max[3];
@@ -1361,7 +1362,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     f3 col = mk3(0.f, 0.f, 0.f), o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
     f3 att0 = mk3(1.f, 1.f, 1.f);   // attenuation of the first bounce (deeper ones: the stack)
     uint32_t att0c = 0u;            // PAL: its palette code
-    const float4 *shade = PAL ? (const float4 *)s_shade : A.shade;
+    const float4 *shade = PAL ? (const float4 *)s_shade : ((TREE4 && !MOVING && A.gate) ? A.shade_rank : A.shade);
     const uint32_t kWhite = A.n_spheres;   // PAL: code of (1, 1, 1): one extra record behind the spheres'
     auto palette_colour = [&](uint32_t code) -> f3 {   // PAL: the colour behind a stack entry
         const float4 q = s_shade[4u * (code & 0x7fffu) + 2u + (code >> 15)];
@@ -1473,7 +1474,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             if (have && !trav4.active) {   // (lanes without a finished ray hold a stale or never-written key)
                 const unsigned long long key = w_keys[lane];
                 const uint32_t low = (uint32_t)key;
-                if (key != ~0ull) idx = (int)(A.gate ? A.rank_sphere[0xffffffffu - low] : low);
+                // BVH world: the key carries the leaf's DFS rank; shading reads the rank-ordered copy of the records, so
+                // the sphere index itself (one more dependent load) is only needed for a moving sphere's motion record
+                if (key != ~0ull) idx = (int)(A.gate ? (MOVING ? A.rank_sphere[0xffffffffu - low] : (0xffffffffu - low)) : low);
                 t_hit = __uint_as_float((uint32_t)(key >> 32));
             }
         } else if (BVH) {

@@ -94,7 +94,7 @@ struct pt_scene {
     double h_t_lo = 0.0, h_t_hi = 0.0;
     bool binary_built = false;
     uint32_t *d_leaf_rank = nullptr, *d_rank_sphere = nullptr;
-    float4 *d_leafrec = nullptr;              // BVH worlds: sphere + gate + rank per sphere (pt_kernel.h KArgs::leafrec)
+    float4 *d_leafrec = nullptr, *d_shade_rank = nullptr;              // BVH worlds: sphere + gate + rank per sphere (pt_kernel.h KArgs::leafrec)
     float root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
     // MFMA prefilter data (n_tiles == 0: prefilter not applicable to this scene)
     uint4 *d_afrag = nullptr;
@@ -921,8 +921,11 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
             leafrec[4 * i + 3] = make_float4(rk.f, 0.f, 0.f, 0.f);
         }
     }
+    std::vector<float4> shade_rank(4 * rank_sphere.size());
+    for (size_t r = 0; r < rank_sphere.size(); ++r)
+        for (int q = 0; q < 4; ++q) shade_rank[4 * r + q] = shade[4 * (size_t)rank_sphere[r] + q];
     int rc = PT_OK;
-    if ((rc = upload(&s->d_leafrec, leafrec.data(), leafrec.size())) || (rc = upload(&s->d_spheres, sph.data(), sph.size())) || (rc = upload(&s->d_spheres_r2, sph_r2.data(), sph_r2.size())) || (rc = upload(&s->d_shade, shade.data(), shade.size())) ||
+    if ((rc = upload(&s->d_shade_rank, shade_rank.data(), shade_rank.size())) || (rc = upload(&s->d_leafrec, leafrec.data(), leafrec.size())) || (rc = upload(&s->d_spheres, sph.data(), sph.size())) || (rc = upload(&s->d_spheres_r2, sph_r2.data(), sph_r2.size())) || (rc = upload(&s->d_shade, shade.data(), shade.size())) ||
         (rc = upload(&s->d_sphere_mat, desc->sphere_material, desc->n_spheres)) ||
         (rc = upload(&s->d_mats, mats.data(), mats.size())) || (rc = upload(&s->d_texs, texs.data(), texs.size())) ||
         (rc = upload(&s->d_perlin_vec, pvec.data(), pvec.size())) || (rc = upload(&s->d_perlin_perm, pperm.data(), pperm.size())) ||
@@ -1200,6 +1203,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_nodes4);
     (void)hipFree(s->d_rank_sphere);
     (void)hipFree(s->d_leafrec);
+    (void)hipFree(s->d_shade_rank);
     (void)hipFree(s->d_leaf_rank);
     (void)hipFree(s->d_afrag);
     (void)hipFree(s->d_tile_sphere);
@@ -1436,6 +1440,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.nodes4 = s->d_nodes4;
     A.rank_sphere = s->d_rank_sphere;
     A.leafrec = s->d_leafrec;
+    A.shade_rank = s->d_shade_rank;
     A.leaf_rank = s->d_leaf_rank;
     memcpy(A.root_min, s->root_min, 12);
     memcpy(A.root_max, s->root_max, 12);
