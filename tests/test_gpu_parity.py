@@ -958,3 +958,21 @@ def test_device_pow5_vs_host_powf_mismatch_rate(ptgpu, oracle):
     assert rate < 0.02
     exact = (x.astype(np.float64) ** 5).astype(np.float32)       # correctly rounded reference
     assert (got != exact).mean() < 1e-4
+
+
+def test_bench_sharded_path_self_check():
+    """bench.py's N > 1 path (BASELINE config 4 through pt_comm_gather_frame, three buffer sets, exchange on a second stream)
+    on the one rank a 1-GPU box can form, at a reduced sample count: PT_BENCH_CHECK makes the script assert that the gathered
+    frame equals the rank's own full render bit for bit; the JSON line must say strong scaling and carry the roofline block."""
+    import json
+    import subprocess
+    env = dict(os.environ, PT_BENCH_FORCE_DIST="1", PT_BENCH_CHECK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    for extra in ([], ["--no-overlap"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--samples", "8",
+                              "--no-extras", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert "[bench check] tiles frame over 1 rank(s) == single-GPU frame" in out.stderr
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        assert d["scaling"] == "strong" and d["unit"] == "Mrays/s" and d["value"] > 0 and "roofline" in d
+        assert "split by rows" in d["config"]["workload"]
