@@ -147,8 +147,7 @@ struct KArgs {
     const uint32_t *tile_order;  // optional permutation of the 8x8 work tiles (expensive tiles first)
     uint32_t *tile_cost;         // optional: rays spent per work tile (accumulated when a pixel completes)
     float *gstack;  // global path-stack fallback when max_depth*3*kBlock*4 exceeds the LDS budget
-    uint32_t stack_in_lds;       // 256-thread kernels: number of attenuation-stack slots (3 per level, 1 when mono) kept in LDS; the rest in gstack
-    uint32_t mono;               // every attenuation of the scene has three equal components (noise textures, greys, glass): one slot per level
+    uint32_t stack_in_lds;       // 256-thread kernels: number of attenuation-stack slots (3 per level; 1 on the 4-wide tree kernels, WST below) kept in LDS; the rest in gstack
     uint32_t lds_sphere_bytes;  // offsets of the dynamic LDS carve
 };
 
@@ -156,6 +155,8 @@ struct KArgs {
 struct PerlinLds {
     const float4 *vec;       // 256 x float4
     const uint32_t *perm;    // 768
+    bool prefetch;           // fetch the eight gradients of an octave before its arithmetic (32 more live registers: kernels
+                             // compiled for 128 VGPRs spill with it, the general-world kernel gains 10 % from it)
 };
 
 __device__ __forceinline__ float perlin_noise(const PerlinLds &pn, f3 p) {
@@ -173,12 +174,27 @@ __device__ __forceinline__ float perlin_noise(const PerlinLds &pn, f3 p) {
     const uint32_t px[2] = {pn.perm[i], pn.perm[(i + 1) & 255]};
     const uint32_t py[2] = {pn.perm[256 + j], pn.perm[256 + ((j + 1) & 255)]};
     const uint32_t pz[2] = {pn.perm[512 + k], pn.perm[512 + ((k + 1) & 255)]};
+    float accum = 0.0f;
+    if (!pn.prefetch) {
+#pragma unroll
+        for (int di = 0; di < 2; ++di) {
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+#pragma unroll
+                for (int dk = 0; dk < 2; ++dk) {
+                    const float4 gc = pn.vec[px[di] ^ py[dj] ^ pz[dk]];
+                    const f3 weight = mk3(u - (float)di, v - (float)dj, w - (float)dk);
+                    accum += wu[di] * wv[dj] * ww2[dk] * dot3(mk3(gc.x, gc.y, gc.z), weight);
+                }
+            }
+        }
+        return accum;
+    }
     // all eight gradient fetches are issued before the arithmetic starts (one LDS round trip per octave instead of eight)
     float4 g[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) g[c] = pn.vec[px[c >> 2] ^ py[(c >> 1) & 1] ^ pz[c & 1]];
     __builtin_amdgcn_sched_barrier(0);
-    float accum = 0.0f;
 #pragma unroll
     for (int di = 0; di < 2; ++di) {
 #pragma unroll
@@ -1256,6 +1272,14 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     // colours back from the per-sphere shading records, which live in LDS here. 18 instead of 108 bytes of LDS per lane.
     // (launch() only picks a wide kernel for scenes whose textures are all Constant or Checker-of-two-Constants.)
     constexpr bool PAL = (BLK != kBlock);
+    // 4-wide tree kernels: ONE 32-bit word per attenuation-stack level -- the grey value of a Noise texture as its float bits
+    // (texture.rs:86-89 yields (v, v, v)), or a palette code like PAL's for everything else: 0xFFE00000 | even-checker bit << 20 |
+    // record index (0xFFFFF = white). No arithmetic produces such a NaN pattern (canonical NaNs are 0x7FC00000 / 0xFFC00000).
+    // A quarter of the LDS (and of the HBM traffic of the levels that do not fit) of three floats, and one register instead
+    // of three for the first bounce. (launch() only walks this tree for scenes whose textures are Noise, Constant or
+    // Checker-of-two-Constants; others use the binary tree kernel with the float stack.)
+    constexpr bool WST = TREE4;
+    constexpr uint32_t kWstCode = 0xFFE00000u, kWstWhite = kWstCode | 0xFFFFFu;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS carve (all offsets multiples of 16)
     float4 *s_sph = reinterpret_cast<float4 *>(smem);  // list mode: n_spheres x (cx,cy,cz,r^2)
@@ -1329,7 +1353,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     }
     __syncthreads();
 
-    PerlinLds pn{s_pvec, s_perm};
+    PerlinLds pn{s_pvec, s_perm, false};
     // attenuation stack of this lane: the 768-thread kernels always have it in LDS; the 256-thread ones keep the first
     // A.stack_in_lds slots (3 per level) in LDS and deeper, rarely reached levels in HBM/L2 (what fits next to four
     // resident workgroups of a tree kernel)
@@ -1357,13 +1381,27 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     uint32_t lane_tile = 0, pix_rays = 0;
     BvhTrav trav{0u, 0u, 0, kMaxT, -1, 0u, false};
     Trav4 trav4{0u, 0u, 0, kNoChild4, 0u, kMaxT, false};
-    uint32_t px = 0, py = 0, boff = 0, sample = 0, depth = 0, nrays = 0;
+    // per-lane bookkeeping, packed (every register counts: the 4-waves-per-SIMD kernels are compiled for 128 VGPRs):
+    //   pxy = pixel column | local row << 16 (launch() keeps width and height below 65536)
+    //   sd  = bounce depth (12 bits) | sample number << 12 (launch(): max_depth <= 4095, samples < 2^20)
+    uint32_t pxy = 0, sd = 0;
+    unsigned long long wave_rays = 0;   // scene.rs:57 ray_count of this WAVE (wave-uniform: lives in scalar registers)
+#define PT_DEPTH (sd & 0xfffu)
     Rng rng{0, 0, 0, 0};
     f3 col = mk3(0.f, 0.f, 0.f), o = mk3(0.f, 0.f, 0.f), d = mk3(0.f, 0.f, 0.f);
     f3 att0 = mk3(1.f, 1.f, 1.f);   // attenuation of the first bounce (deeper ones: the stack)
-    uint32_t att0c = 0u;            // PAL: its palette code
+    uint32_t att0c = 0u;            // PAL: its palette code; WST: its word
     const float4 *shade = PAL ? (const float4 *)s_shade : ((TREE4 && !MOVING && A.gate) ? A.shade_rank : A.shade);
     const uint32_t kWhite = A.n_spheres;   // PAL: code of (1, 1, 1): one extra record behind the spheres'
+    auto word_colour = [&](uint32_t w) -> f3 {   // WST: the attenuation behind a stack word
+        if ((w & kWstCode) != kWstCode) {
+            const float v = __uint_as_float(w);
+            return mk3(v, v, v);
+        }
+        if (w == kWstWhite) return mk3(1.f, 1.f, 1.f);
+        const float4 q = shade[4u * (w & 0xFFFFFu) + 2u + ((w >> 20) & 1u)];
+        return mk3(q.x, q.y, q.z);
+    };
     auto palette_colour = [&](uint32_t code) -> f3 {   // PAL: the colour behind a stack entry
         const float4 q = s_shade[4u * (code & 0x7fffu) + 2u + (code >> 15)];
         return mk3(q.x, q.y, q.z);
@@ -1383,7 +1421,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 const float4 pf = s_par[10];   // inv_ns, mix_prev, mix_new
                 col = scale3(col, pf.x);
                 if (!PILOT) {
-                    float *out = A.rgb + boff;
+                    float *out = A.rgb + ((pxy >> 16) * A.width + (pxy & 0xffffu)) * 3u;
                     out[0] = out[0] * pf.y + col.x * pf.z;
                     out[1] = out[1] * pf.y + col.y * pf.z;
                     out[2] = out[2] * pf.y + col.z * pf.z;
@@ -1409,10 +1447,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 //  the tiles as well as all of them did and costs 0.2 ms less; the tree kernels keep every pixel, measured)
                 if (x < A.width && ly < A.local_rows && !(PILOT && !BVH && ((x | ly) & 1u))) {
                     have = true;
-                    px = x;
-                    py = ly * A.shard_count + A.shard_index;
-                    boff = (ly * A.width + x) * 3u;
-                    sample = 0;
+                    pxy = x | (ly << 16);
+                    sd = 0;
+                    const uint32_t px = x, py = ly * A.shard_count + A.shard_index;
                     need_cam = true;
                     col = mk3(0.f, 0.f, 0.f);
                     // scene.rs:96-102
@@ -1437,6 +1474,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             const f3 cam_origin = mk3(c0.x, c0.y, c0.z), cam_llc = mk3(c0.w, c1.x, c1.y), cam_horizontal = mk3(c1.z, c1.w, c2.x),
                      cam_vertical = mk3(c2.y, c2.z, c2.w), cam_u = mk3(c3.x, c3.y, c3.z), cam_v = mk3(c3.w, c4.x, c4.y);
             const float cam_time0 = c5.y, cam_time1 = c5.z, cam_lens_radius = c5.w;
+            const uint32_t px = pxy & 0xffffu, py = (pxy >> 16) * A.shard_count + A.shard_index;
             const float u = ((float)px + rng_f32(rng)) * pn2.z;
             const float v = ((float)py + rng_f32(rng)) * pn2.w;
             float dx, dy;
@@ -1448,7 +1486,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             const f3 dir = sub3(sub3(add3(add3(cam_llc, scale3(cam_horizontal, u)), scale3(cam_vertical, v)), cam_origin), offset);
             o = add3(cam_origin, offset);
             d = normalize3(dir);
-            depth = 0;
+            sd &= ~0xfffu;   // depth = 0
             need_cam = false;
             trav_new = true;
         }
@@ -1503,8 +1541,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 
         PT_SEC(2);
         // ---- scene.rs:49-71 one level of ray_trace (BVH mode: only lanes whose traversal has finished)
-        if (have && !(BVH && (TREE4 ? trav4.active : trav.active))) {
-            nrays += 1;
+        const bool shading = have && !(BVH && (TREE4 ? trav4.active : trav.active));
+        wave_rays += (unsigned long long)__popcll(__ballot(shading));   // scene.rs:57 `ray_count += 1` for every lane shaded below
+        if (shading) {
             pix_rays += 1;
             bool terminal = true;
             f3 V;
@@ -1543,8 +1582,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = surface_colour();
                 bool scattered = false;
                 f3 att = mk3(1.f, 1.f, 1.f), nd = d;
-                uint32_t attc = kWhite;    // PAL: palette code of `att` (white unless a branch says otherwise)
-                if (depth < __float_as_uint(s_par[12].z)) {   // max_depth
+                uint32_t attc = WST ? kWstWhite : kWhite;    // PAL / WST: code of `att` (white unless a branch says otherwise)
+                if (PT_DEPTH < __float_as_uint(s_par[12].z)) {   // max_depth
                     // every scatter ends in `.normalize()` of some vector (material.rs:63,84,112,119): the branches
                     // only produce that vector, the normalisation is issued once for the whole wave
                     f3 raw = d;
@@ -1553,6 +1592,13 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         if (PAL) {
                             const bool even = (m.flags & kShadeChecker2) && !checker_is_odd(10.0f * point.x, 10.0f * point.y, 10.0f * point.z);
                             attc = (uint32_t)idx | (even ? 0x8000u : 0u);
+                        } else if (WST) {
+                            if (m.flags & kShadeNoise) {
+                                attc = __float_as_uint(surface_colour().x);
+                            } else {
+                                const bool even = (m.flags & kShadeChecker2) && !checker_is_odd(10.0f * point.x, 10.0f * point.y, 10.0f * point.z);
+                                attc = kWstCode | (uint32_t)idx | (even ? (1u << 20) : 0u);
+                            }
                         } else {
                             att = surface_colour();
                         }
@@ -1562,7 +1608,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         const f3 reflected = reflect3(d, normal);
                         if (dot3(reflected, normal) > 0.0f) {
                             att = mk3(qa.x, qa.y, qa.z);
-                            attc = (uint32_t)idx;
+                            attc = (WST ? kWstCode : 0u) | (uint32_t)idx;
                             const f3 rs = random_in_unit_sphere(rng);
                             raw = add3(reflected, scale3(rs, m.param));
                             scattered = true;
@@ -1598,18 +1644,19 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     // it also removes 40 % of the stack's HBM writes); deeper levels go to the per-lane stack, level d
                     // at slot d - 1
                     if (PAL) {
-                        if (depth == 0u) att0c = attc;
-                        else s_pal[(depth - 1u) * BLK + tid] = (uint16_t)attc;
-                    } else if (depth == 0u) {
+                        if (PT_DEPTH == 0u) att0c = attc;
+                        else s_pal[(PT_DEPTH - 1u) * BLK + tid] = (uint16_t)attc;
+                    } else if (WST) {
+                        if (PT_DEPTH == 0u) att0c = attc;
+                        else path_st(PT_DEPTH - 1u, __uint_as_float(attc));
+                    } else if (PT_DEPTH == 0u) {
                         att0 = att;
-                    } else if (A.mono) {
-                        path_st(depth - 1u, att.x);
                     } else {
-                        path_st((depth - 1u) * 3u + 0u, att.x);
-                        path_st((depth - 1u) * 3u + 1u, att.y);
-                        path_st((depth - 1u) * 3u + 2u, att.z);
+                        path_st((PT_DEPTH - 1u) * 3u + 0u, att.x);
+                        path_st((PT_DEPTH - 1u) * 3u + 1u, att.y);
+                        path_st((PT_DEPTH - 1u) * 3u + 2u, att.z);
                     }
-                    depth += 1;
+                    sd += 1u;   // depth += 1
                     o = point;
                     d = nd;
                     terminal = false;
@@ -1623,7 +1670,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 if (PAL) {
                     // three levels per trip: the codes, then the colours, are fetched together (two LDS round trips per
                     // trip instead of two per level); the products keep the innermost-first order
-                    for (int k = (int)depth - 1; k >= 1; k -= 3) {
+                    for (int k = (int)PT_DEPTH - 1; k >= 1; k -= 3) {
                         const uint32_t ca = s_pal[(uint32_t)(k - 1) * BLK + tid];
                         const uint32_t cb = s_pal[(uint32_t)(k >= 2 ? k - 2 : 0) * BLK + tid];
                         const uint32_t cc = s_pal[(uint32_t)(k >= 3 ? k - 3 : 0) * BLK + tid];
@@ -1633,25 +1680,25 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         if (k >= 3) V = mk3(0.0f + qc3.x * V.x, 0.0f + qc3.y * V.y, 0.0f + qc3.z * V.z);
                     }
                 }
-                for (int k = PAL ? 0 : (int)depth - 1; k >= 1; --k) {
+                for (int k = PAL ? 0 : (int)PT_DEPTH - 1; k >= 1; --k) {
                     if (PAL) {
-                    } else if (A.mono) {
-                        const float c = path_ld((uint32_t)(k - 1));
-                        V = mk3(0.0f + c * V.x, 0.0f + c * V.y, 0.0f + c * V.z);
+                    } else if (WST) {
+                        const f3 c = word_colour(__float_as_uint(path_ld((uint32_t)(k - 1))));
+                        V = mk3(0.0f + c.x * V.x, 0.0f + c.y * V.y, 0.0f + c.z * V.z);
                     } else {
                         V.x = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 0u) * V.x;
                         V.y = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 1u) * V.y;
                         V.z = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 2u) * V.z;
                     }
                 }
-                if (depth > 0u) {
-                    const f3 c0 = PAL ? palette_colour(att0c) : att0;
+                if (PT_DEPTH > 0u) {
+                    const f3 c0 = PAL ? palette_colour(att0c) : (WST ? word_colour(att0c) : att0);
                     V = mk3(0.0f + c0.x * V.x, 0.0f + c0.y * V.y, 0.0f + c0.z * V.z);
                 }
                 col = add3(col, V);  // scene.rs:110
-                sample += 1;
+                sd += 0x1000u;   // sample += 1
                 need_cam = true;
-                if (sample == __float_as_uint(s_par[12].w)) {   // samples
+                if ((sd >> 12) == __float_as_uint(s_par[12].w)) {   // samples
                     // the pixel is written when the lane fetches its next one (the refill below is batched over
                     // several lanes, and so is this read-modify-write of the frame buffer)
                     have = false;
@@ -1670,12 +1717,11 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     if (A.wave_end && lane == 0) A.wave_end[blockIdx.x * (BLK / 64) + (tid >> 6)] = wall_clock64();
     if (BVH && VERIFY) {   // traversal counters (accumulate over the lane's whole life: never reset per ray)
         atomicAdd(&A.debug[8], (unsigned long long)(TREE4 ? trav4.visits : trav.visits));
-        atomicAdd(&A.debug[9], (unsigned long long)(TREE4 ? trav4.leaves : trav.leaves) + (unsigned long long)nrays * A.n_bvh_large);
+        atomicAdd(&A.debug[9], (unsigned long long)(TREE4 ? trav4.leaves : trav.leaves) + (lane == 0 ? wave_rays * A.n_bvh_large : 0ull));
     }
     // scene.rs:118 ray_count: wave reduce, one atomic per wave
-    unsigned long long total = nrays;
-    for (int off = 32; off > 0; off >>= 1) total += __shfl_down(total, off);
-    if (lane == 0) atomicAdd(A.ray_count, total);
+    if (lane == 0) atomicAdd(A.ray_count, wave_rays);
+#undef PT_DEPTH
 }
 
 // ---- work ordering ------------------------------------------------------------------------------

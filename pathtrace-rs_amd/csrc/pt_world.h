@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
         for (int k = tid; k < 768; k += kBlock) s_perm[k] = A.perlin_perm[k];
     }
     __syncthreads();
-    PerlinLds pn{s_pvec, s_perm};
+    PerlinLds pn{s_pvec, s_perm, OCC < 4};
     const bool want_uv = A.has_image != 0u;
     const pt_hitable *hit = HIT_LDS ? s_hit : A.hit;
     const pt_affine *xf = HIT_LDS ? s_xf : A.xf;

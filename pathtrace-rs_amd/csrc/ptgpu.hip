@@ -70,7 +70,7 @@ struct pt_scene {
     float sky[3] = {0, 0, 0};
     uint32_t has_noise = 0;
     bool palette_ok = false;   // wide MFMA kernels keep palette codes on the attenuation stack (pt_kernel.h PAL)
-    bool mono_ok = false;      // every attenuation has three equal components: the float stack holds one value per level
+    bool word_ok = false;      // 4-wide tree kernels: every attenuation fits one stack word (pt_kernel.h WST)
     // device memory
     float4 *d_spheres = nullptr, *d_spheres_r2 = nullptr, *d_shade = nullptr;
     uint32_t *d_sphere_mat = nullptr;
@@ -790,21 +790,19 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
         shade[4 * i + 3] = qb;
     }
     s->palette_ok = palette_ok;
-    {   // "mono": Noise textures yield (v, v, v) (texture.rs:86-89), Dielectric attenuates by (1, 1, 1); constants / metal albedos count when grey
-        bool mono = true;
-        auto grey = [](const float c[3]) { return c[0] == c[1] && c[1] == c[2]; };
-        std::vector<int> tex_mono(desc->n_textures, 0);
-        for (uint32_t i = 0; i < desc->n_textures; ++i) {   // (children precede their checker: validate_tables)
-            const pt_texture &t = desc->textures[i];
-            tex_mono[i] = t.kind == PT_TEX_NOISE || (t.kind == PT_TEX_CONSTANT && grey(t.color)) ||
-                          (t.kind == PT_TEX_CHECKER && tex_mono[t.odd] && tex_mono[t.even]);
-        }
-        for (uint32_t i = 0; i < desc->n_spheres && mono; ++i) {
+    {   // can every attenuation be one stack word (pt_kernel.h WST)? Noise -> its grey value; Constant / Checker2 / metal / glass -> a code
+        bool ok = true;
+        for (uint32_t i = 0; i < desc->n_spheres && ok; ++i) {
             const pt_material &m = desc->materials[desc->sphere_material[i]];
-            if (m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_ISOTROPIC) mono = tex_mono[m.texture] != 0;
-            else if (m.kind == PT_MAT_METAL) mono = grey(m.albedo);
+            if (m.kind == PT_MAT_LAMBERTIAN) {
+                const pt_texture &t = desc->textures[m.texture];
+                ok = t.kind == PT_TEX_NOISE || t.kind == PT_TEX_CONSTANT ||
+                     (t.kind == PT_TEX_CHECKER && desc->textures[t.odd].kind == PT_TEX_CONSTANT && desc->textures[t.even].kind == PT_TEX_CONSTANT);
+            } else if (m.kind > PT_MAT_DIFFUSE_LIGHT) {
+                ok = false;
+            }
         }
-        s->mono_ok = mono;
+        s->word_ok = ok && desc->n_spheres < 0xFFFFFu;
     }
     std::vector<DMat> mats(desc->n_materials);
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
@@ -1330,6 +1328,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (params->width == 0 || params->height == 0 || params->samples == 0)
         return fail(PT_ERR_INVALID_ARG, "width/height/samples must be non-zero");
     if ((uint64_t)params->width * params->height > 0x3fffffffull) return fail(PT_ERR_INVALID_ARG, "frame too large");
+    // the sphere kernels pack a lane's pixel and its (depth, sample) counters into one register each
+    if (!s->is_world && (params->width > 0xffffu || params->height > 0xffffu || params->max_depth > 0xfffu || params->samples > 0xfffffu))
+        return fail(PT_ERR_UNSUPPORTED, "sphere kernels take width, height < 65536, max_depth < 4096, samples < 2^20");
     if (shard_count == 0 || shard_index >= shard_count) return fail(PT_ERR_INVALID_ARG, "bad shard %u/%u", shard_index, shard_count);
     const bool ref_bvh = params->use_bvh != 0;   // BVHNode::ray_hit semantics (needs the caller's tree for the gates)
     if (ref_bvh && s->bvh_root < 0) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the scene was created without BVH nodes");
@@ -1506,7 +1507,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (const char *e = getenv("PTGPU_DRAIN")) A.drain_at = std::min<uint32_t>((uint32_t)atoi(e), (uint32_t)(kLeafQ - 4));
     // 4-wide tree (default; variant bit 2048: the binary tree): a visit pushes at most three siblings per level
     // (its stack entries are 16-bit node indices; a bigger tree -- more than ~190 000 spheres -- walks the binary one)
-    const bool tree4 = bvh && (s->variant & 2048u) == 0 && s->n_nodes4 < 65536u;
+    const bool tree4 = bvh && (s->variant & 2048u) == 0 && s->n_nodes4 < 65536u && s->word_ok;
     if (bvh && !tree4)
         if (int rc = ensure_binary_tree(s)) return rc;
     A.wnodes = s->d_wnodes;
@@ -1540,8 +1541,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     }
     if (!bvh) lds += mfma ? mfma_queue_bytes(blk) : scan_queue_bytes(blk);
     if (mfma) lds += s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + 8u * kCullCells;
-    const uint32_t slots = s->mono_ok ? 1u : 3u;   // attenuation-stack slots per level (float stacks)
-    A.mono = s->mono_ok ? 1u : 0u;
+    const uint32_t slots = tree4 ? 1u : 3u;   // attenuation-stack slots per level (4-wide tree kernels: one word, pt_kernel.h WST)
     const uint64_t path_bytes = (uint64_t)stack_levels * slots * blk * 4ull;
     // the 256-thread MFMA variant keeps the attenuation stack in HBM: its LDS goes to the A fragments, and 3 resident
     // workgroups per CU beat 1 with an LDS stack (measured 7.5 vs 3.0 Grays/s)
@@ -1561,6 +1561,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         lds_levels = stack_levels;
     }
     A.stack_in_lds = lds_levels * slots;
+    if (getenv("PTGPU_DEBUG")) fprintf(stderr, "[ptgpu launch] bvh %d tree4 %d mfma %d blk %u slots %u stack_levels %u lds_levels %u lds %u\n", (int)bvh, (int)tree4, (int)mfma, blk, slots, stack_levels, lds_levels, lds);
     lds += lds_levels * slots * blk * 4u;
     if (blk == kWideBlock || blk == 1024u) lds += (uint32_t)wide_extra(blk);
     A.lds_sphere_bytes = sph_bytes;
@@ -1668,7 +1669,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         P.verify = 0;
         P.wave_end = nullptr;
         // a third of the frame's grid: the pilot has ~100x less work, and each workgroup stages the scene into LDS
-        hipLaunchKernelGGL(pilot_kern, dim3((grid + 2u) / 3u), dim3(blk), lds, stream, P);
+        uint32_t pilot_div = 3u;
+        if (const char *e = getenv("PTGPU_PILOT_DIV")) pilot_div = std::max(1, atoi(e));   // (development knob)
+        hipLaunchKernelGGL(pilot_kern, dim3((grid + pilot_div - 1u) / pilot_div), dim3(blk), lds, stream, P);
         hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, params->max_depth + 1u, order);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
