@@ -1617,8 +1617,11 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (bpc > 8u) bpc = 8u;
     if (s->blocks_per_cu == 0) bpc = std::min(bpc, blocks_per_cu_by_registers(reinterpret_cast<const void *>(kern), blk));
     uint32_t grid = (uint32_t)s->num_cus * bpc;
+    // Fewer pixels than lanes (a shard of an 8-GPU frame: 120 000 pixels for 262 144 lanes): the waves that win the race for
+    // work should be spread over ALL CUs -- two waves on a SIMD iterate faster than four -- so a one-workgroup-per-CU grid is
+    // not cut down to the workgroups the pixels would fill (a wave that finds the queue empty leaves at once).
     const uint32_t need = (A.n_items + blk - 1) / blk;
-    if (grid > need) grid = need;
+    if (grid > need && !((blk == kWideBlock || blk == 1024u) && need * 4u >= grid && !getenv("PTGPU_CLAMP_GRID"))) grid = need;
     if (grid == 0) grid = 1;
 
     if (blk == kBlock && lds_levels < stack_levels) {

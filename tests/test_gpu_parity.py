@@ -494,6 +494,12 @@ def test_error_reporting_on_device(ptgpu, pthost):
     with pytest.raises(ptgpu.PtError) as e:
         sc.update(ptgpu.PtParams(32, 16, 0, 10, 0, 0), hs.camera, 0, buf)
     assert e.value.code == ptgpu.PT_ERR_INVALID_ARG
+    # the sphere kernels pack (depth, sample) into one register: beyond these limits the call is refused, not wrong
+    for bad in (ptgpu.PtParams(32, 16, 1, 4096, 0, 0), ptgpu.PtParams(32, 16, 1 << 20, 10, 0, 0)):
+        with pytest.raises(ptgpu.PtError) as e:
+            sc.update(bad, hs.camera, 0, buf)
+        assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED
+    assert sc.update(ptgpu.PtParams(32, 16, 1, 4095, 0, 0), hs.camera, 0, buf) > 0
 
 
 # ---- general worlds: MovingSphere, Rect, Cuboid, Instance, ConstantMedium ----------------
