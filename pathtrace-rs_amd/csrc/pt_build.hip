@@ -174,6 +174,29 @@ __global__ void iota_kernel(uint32_t *perm, uint32_t n) {
     if (i < n) perm[i] = i;
 }
 
+// packed nodes (tree_pack_node) + the slot records of the leaves: record (node * 4 + slot) = the sphere's 64-byte leaf record
+// (BVH worlds: sphere | gate min | gate max | rank) or its (cx, cy, cz, r) alone (list worlds), with the sphere index in [3].y
+__global__ void pack_kernel(const DNode4 *nodes, uint32_t n_nodes, const float4 *spheres, const float4 *leafrec, DNode4Q *packed, float4 *slotrec,
+                            uint32_t *failed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const DNode4 w = nodes[i];
+    DNode4Q q;
+    if (!tree_pack_node(w, q)) atomicOr(failed, 1u);
+    packed[i] = q;
+    for (uint32_t j = 0; j < 4u; ++j) {
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+        if (w.child[j] != kNoChild4 && w.child[j] < 0) {
+            const uint32_t k = (uint32_t)~w.child[j];
+            if (leafrec) r0 = leafrec[4 * k], r1 = leafrec[4 * k + 1], r2 = leafrec[4 * k + 2], r3 = leafrec[4 * k + 3];
+            else r0 = spheres[k];
+            r3.y = __uint_as_float(k);
+        }
+        float4 *out = slotrec + 4 * ((size_t)i * 4u + j);
+        out[0] = r0, out[1] = r1, out[2] = r2, out[3] = r3;
+    }
+}
+
 #define BUILD_TRY(expr)                     \
     do {                                    \
         const hipError_t e_ = (expr);       \
@@ -283,6 +306,32 @@ done:
     (void)hipFree(d_tmp);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    return rc;
+}
+
+int tree4_pack_device(const DNode4 *d_nodes, uint32_t n_nodes, const float4 *d_spheres, const float4 *d_leafrec, hipStream_t stream,
+                      DNode4Q **d_packed_out, float4 **d_slotrec_out, bool *ok_out) {
+    *d_packed_out = nullptr, *d_slotrec_out = nullptr, *ok_out = false;
+    if (n_nodes == 0) return 0;
+    int rc = 0;
+    DNode4Q *d_packed = nullptr;
+    float4 *d_slotrec = nullptr;
+    uint32_t *d_failed = nullptr, failed = 1;
+    BUILD_TRY(hipMalloc((void **)&d_packed, (size_t)n_nodes * sizeof(DNode4Q)));
+    BUILD_TRY(hipMalloc((void **)&d_slotrec, (size_t)n_nodes * 4 * 4 * sizeof(float4)));
+    BUILD_TRY(hipMalloc((void **)&d_failed, 64));
+    BUILD_TRY(hipMemsetAsync(d_failed, 0, 4, stream));
+    hipLaunchKernelGGL(pack_kernel, dim3((n_nodes + 127u) / 128u), dim3(128), 0, stream, d_nodes, n_nodes, d_spheres, d_leafrec, d_packed, d_slotrec, d_failed);
+    BUILD_TRY(hipGetLastError());
+    BUILD_TRY(hipMemcpyAsync(&failed, d_failed, 4, hipMemcpyDeviceToHost, stream));
+    BUILD_TRY(hipStreamSynchronize(stream));
+    *ok_out = failed == 0;
+    *d_packed_out = d_packed, d_packed = nullptr;
+    *d_slotrec_out = d_slotrec, d_slotrec = nullptr;
+done:
+    (void)hipFree(d_packed);
+    (void)hipFree(d_slotrec);
+    (void)hipFree(d_failed);
     return rc;
 }
 

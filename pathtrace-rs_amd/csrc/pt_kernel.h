@@ -91,10 +91,10 @@ struct KArgs {
     const float4 *perlin_vec;    // 256 gradients (xyz, pad)
     const uint32_t *perlin_perm; // 768 entries: perm_x | perm_y | perm_z
     const DWideNode *wnodes;  // binary internal tree (variant bit 2048): children's AABBs inside the parent
-    const DNode4 *nodes4;     // 4-wide internal tree (default of the tree kernels), root = node 0
+    const DNode4Q *nodes4;    // 4-wide internal tree (default of the tree kernels) as packed 64-byte nodes, root = node 0
+    const float4 *slotrec;    // its leaves: [4 * (node * 4 + slot)] = sphere | gate min, chain count | gate max, chain offset | (rank bits, sphere index): ONE 64-byte fetch per exact test
     const uint32_t *rank_sphere;     // BVH worlds: sphere of each DFS leaf rank (inverse of leaf_rank; decodes the hit key)
     const float4 *shade_rank;        // BVH worlds, 4-wide tree: the shading records in DFS-rank order (the hit key carries the rank)
-    const float4 *leafrec;           // BVH worlds, 4-wide tree: [4*n] per sphere (sphere | gate min, chain count | gate max, chain offset | rank bits): ONE 64-byte fetch per exact test
     const uint32_t *leaf_rank;       // DFS (lhs before rhs) order of each sphere's leaf, for equal-t ties
     float root_min[3], root_max[3];
     uint32_t n_nodes, nodes_in_lds, bvh_stack_entries;
@@ -522,9 +522,17 @@ __device__ __forceinline__ bool aabb_hit_enter(const float mn[3], const float mx
 // BVH-world acceptance of a sphere hit (bvh.rs:37-62): the sphere only counts if every ancestor AABB of its leaf in
 // the CALLER's tree passes aabb.rs:46-58. Ancestor boxes nest, so the parent's box decides (plus the few ancestors
 // recorded in gate_chain above inverted boxes). A.gate == nullptr: list world, every hit counts.
+// where the MFMA list kernels read a BVH world's gate boxes and ranks: global memory, or the LDS copy of the wide kernels
+struct GateSrc {
+    const float4 *gate;
+    const uint32_t *rank;
+};
 __device__ __forceinline__ bool gate_pass_loaded(const KArgs &A, const float4 gmn, const float4 gmx, f3 o, f3 rcp);
 __device__ __forceinline__ bool gate_pass(const KArgs &A, int k, f3 o, f3 rcp) {
     return gate_pass_loaded(A, A.gate[2 * k], A.gate[2 * k + 1], o, rcp);
+}
+__device__ __forceinline__ bool gate_pass_from(const KArgs &A, const GateSrc &G, int k, f3 o, f3 rcp) {
+    return gate_pass_loaded(A, G.gate[2 * k], G.gate[2 * k + 1], o, rcp);
 }
 __device__ __forceinline__ bool gate_pass_loaded(const KArgs &A, const float4 gmn, const float4 gmx, f3 o, f3 rcp) {
     const float mn[3] = {gmn.x, gmn.y, gmn.z}, mx[3] = {gmx.x, gmx.y, gmx.z};
@@ -547,7 +555,7 @@ __device__ __forceinline__ bool gate_pass_loaded(const KArgs &A, const float4 gm
 // the earlier entry keeps an equal t).
 // GATED = false compiles the list-world rule alone (no rank register, no gate code in the hot list kernel).
 template <bool GATED>
-__device__ __forceinline__ void accept_hit(const KArgs &A, int k, float t, f3 o, f3 d, float &best, int &idx, uint32_t &best_rank) {
+__device__ __forceinline__ void accept_hit(const KArgs &A, const GateSrc &G, int k, float t, f3 o, f3 d, float &best, int &idx, uint32_t &best_rank) {
     if (!GATED) {
         if (idx < 0 || t < best || (t == best && k < idx)) {
             best = t;
@@ -555,9 +563,9 @@ __device__ __forceinline__ void accept_hit(const KArgs &A, int k, float t, f3 o,
         }
         return;
     }
-    const uint32_t rank = A.leaf_rank[k];
+    const uint32_t rank = G.rank[k];
     if (idx < 0 || t < best || (t == best && rank > best_rank)) {
-        if (gate_pass(A, k, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) {   // ray.rs:14 rcp_direction
+        if (gate_pass_from(A, G, k, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z))) {   // ray.rs:14 rcp_direction
             best = t;
             idx = k;
             best_rank = rank;
@@ -585,7 +593,7 @@ __device__ __forceinline__ float4 sphere_at(const KArgs &A, int k, float4 c, flo
 // return it for t_max = f32::MAX, winner = lexicographic (t, index) minimum == the sequential
 // closest_so_far scan of hitable_list.rs:40-56 (DESIGN.md "order-independent closest hit")
 template <bool GATED>
-__device__ __forceinline__ void exact_candidate(const KArgs &A, const float4 c, int k, f3 o, f3 d, float a, float &best, int &idx,
+__device__ __forceinline__ void exact_candidate(const KArgs &A, const GateSrc &G, const float4 c, int k, f3 o, f3 d, float a, float &best, int &idx,
                                                 uint32_t &best_rank) {
     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
@@ -593,7 +601,7 @@ __device__ __forceinline__ void exact_candidate(const KArgs &A, const float4 c, 
     const float disc = b * b - a * cc;
     if (disc > 0.0f) {
         float t = kMaxT;
-        if (sphere_roots(a, b, disc, t)) accept_hit<GATED>(A, k, t, o, d, best, idx, best_rank);
+        if (sphere_roots(a, b, disc, t)) accept_hit<GATED>(A, G, k, t, o, d, best, idx, best_rank);
     }
 }
 
@@ -641,7 +649,7 @@ __device__ __forceinline__ uint32_t lane_tile_mask(const float4 *P, const uint32
 }
 
 template <bool VERIFY, bool MOVING, bool GATED, int BLK>
-__device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 *P, const float4 *sph, const uint4 *s_afrag,
+__device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc &G, const float4 *P, const float4 *sph, const uint4 *s_afrag,
                                                    const uint16_t *s_tile_sphere, const uint32_t *s_cull, uint16_t *queue,
                                                    uint32_t *w_pairs, unsigned long long *w_keys,
                                                    f3 o, f3 d, float a, bool active, float time, float &t_out,
@@ -706,7 +714,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                     const uint32_t b = (uint32_t)__builtin_ctz(cur);
                     cur &= cur - 1u;
                     const int k = s_tile_sphere[slot_of(curT, b)];
-                    exact_candidate<GATED>(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+                    exact_candidate<GATED>(A, G, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
                 }
             }
         } else if (total != 0u) {
@@ -748,8 +756,8 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
                     if (disc > 0.0f) {
                         float t = kMaxT;
                         if (sphere_roots(pa, b, disc, t)) {
-                            const uint32_t rank = GATED ? A.leaf_rank[k] : 0u;
-                            if (!GATED || gate_pass(A, k, po, mk3(1.0f / pd.x, 1.0f / pd.y, 1.0f / pd.z)))   // ray.rs:14 rcp_direction
+                            const uint32_t rank = GATED ? G.rank[k] : 0u;
+                            if (!GATED || gate_pass_from(A, G, k, po, mk3(1.0f / pd.x, 1.0f / pd.y, 1.0f / pd.z)))   // ray.rs:14 rcp_direction
                                 atomicMin(&w_keys[owner], key_of(t, k, rank));
                         }
                     }
@@ -771,7 +779,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
     // the always-tested spheres first (wave-uniform): their nearest hit bounds the segment the tiles are culled against
     for (uint32_t j = 0; j < A.n_large; ++j) {
         const int k = (int)A.large[j];
-        if (active) exact_candidate<GATED>(A, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+        if (active) exact_candidate<GATED>(A, G, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
     }
     // wave-uniform set of tiles to run: the union of the lanes' tile masks (verify mode audits every tile)
     uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
@@ -853,7 +861,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const float4 
             // verify mode (and its queue overflows, where the masks of a ray were not all kept): brute force
             for (int k = 0; k < (int)A.n_spheres; ++k) {
                 const float4 c = sphere_at<MOVING>(A, k, sph[k], time);
-                exact_candidate<GATED>(A, c, k, o, d, a, vbest, vidx, vrank);
+                exact_candidate<GATED>(A, G, c, k, o, d, a, vbest, vidx, vrank);
                 if (VERIFY && active) {
                     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
                     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
@@ -1040,13 +1048,14 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
 }
 
 // ---- 4-wide internal tree ------------------------------------------------------------------------------------
-// The tree kernels' default traversal structure (DESIGN.md "tree kernel"). One 128-byte node holds the boxes of up
-// to four children as plane arrays (SoA), so a visit is eight 16-byte loads and FOUR box tests of identical, branch-free
-// code; a child is an inner node or ONE sphere (leaf). Per visit the lane
+// The tree kernels' default traversal structure (DESIGN.md "tree kernel"). One 64-byte node (pt_tree4.h DNode4Q) holds the
+// boxes of up to four children as plane arrays (SoA) of f16 offsets from the node's min corner, so a visit is FOUR 16-byte
+// loads (the vector L1 pays one tag lookup per lane and load: the visit is bound by their number) and four box tests of
+// identical, branch-free code; a child is an inner node or ONE sphere (leaf). Per visit the lane
 //   * pads all four boxes by ONE node-level bound of the reference's f32 discriminant error (same bound as
 //     accel_box_hit, taken over the node: every sphere below lies within |c_node - o| + |h_node| of the origin),
-//   * evaluates each plane with one FMA, t = plane * rcp_d + (-o * rcp_d -+ pad * |rcp_d|) -- the near / far plane
-//     arrays are picked by the ray's direction signs through the load ADDRESS, not by selects on the data,
+//   * evaluates each plane with one mixed-precision FMA, t = offset(f16) * rcp_d + ((origin - o) * rcp_d -+ pad * |rcp_d|) --
+//     the near / far plane arrays are picked by the ray's direction signs with two selects per axis and side,
 //   * pushes the inner children it hit far-to-near (4 sort keys = entry distance bits | slot, a 5-exchange network of
 //     v_min_u32 / v_max_u32), keeps the nearest in a register as the next node, and
 //   * appends the leaf children it hit to its queue of (sphere) candidates.
@@ -1059,7 +1068,7 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
 #define PT_LEAFQ 8
 #endif
 constexpr int kLeafQ = PT_LEAFQ;   // per-lane candidate slots; drained when a lane holds more than kLeafQ - 4
-constexpr uint32_t kPairLaneShift = 26u;   // pair = owner lane << 26 | sphere (scenes up to 2^26 spheres)
+constexpr uint32_t kPairLaneShift = 26u;   // pair = owner lane << 26 | leaf slot (node * 4 + slot; the tree has < 65536 nodes)
 __host__ __device__ constexpr uint32_t tree4_queue_bytes(uint32_t blk) { return (uint32_t)kLeafQ * blk * 4u + (blk / 64u) * kWavePairBytes; }
 
 struct Trav4 {
@@ -1078,15 +1087,17 @@ __device__ __forceinline__ unsigned long long key4_of(const KArgs &A, float t, i
     return ((unsigned long long)__float_as_uint(t) << 32) | low;
 }
 
-// exact reference test of one (ray, sphere) pair reduced into the owner's key (sphere.rs:29-66 with t_max = f32::MAX,
-// then the ancestor-AABB gate of a BVH world)
-// (BVH worlds fetch the sphere together with its gate box and rank: the accept rule then needs no dependent loads)
+// exact reference test of one (ray, leaf slot) pair reduced into the owner's key (sphere.rs:29-66 with t_max = f32::MAX,
+// then the ancestor-AABB gate of a BVH world). The slot record holds the sphere together with its gate box, rank and
+// index: the accept rule needs no dependent loads.
 template <bool MOVING>
-__device__ __forceinline__ void pair_test4(const KArgs &A, int k, float time, f3 o, f3 d, float a, unsigned long long *key) {
+__device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float time, f3 o, f3 d, float a, unsigned long long *key) {
     const bool gated = A.gate != nullptr;
-    const float4 *R = A.leafrec + 4 * k;
-    float4 c = gated ? R[0] : A.spheres[k], g0 = make_float4(0, 0, 0, 0), g1 = g0, g2 = g0;
-    if (gated) g0 = R[1], g1 = R[2], g2 = R[3];
+    const float4 *R = A.slotrec + 4 * (size_t)e;
+    float4 c = R[0], g0 = make_float4(0, 0, 0, 0), g1 = g0;
+    const float4 g2 = R[3];
+    if (gated) g0 = R[1], g1 = R[2];
+    const int k = (int)__float_as_uint(g2.y);
     c = sphere_at<MOVING>(A, k, c, time);
     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
@@ -1113,8 +1124,7 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
         // more pairs than the wave's list holds: every lane tests its own (rare: the queues drain at > 4 entries)
         for (uint32_t j = 0; __any(j < st.qn); ++j)
             if (j < st.qn) {
-                const int k = (int)leafq[j * BLK + tid];
-                pair_test4<MOVING>(A, k, time, o, d, a, &w_keys[lane]);
+                pair_test4<MOVING>(A, leafq[j * BLK + tid], time, o, d, a, &w_keys[lane]);
             }
     } else {
         uint32_t pos = incl - st.qn;
@@ -1125,12 +1135,12 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
             const bool valid = base + (uint32_t)lane < total;
             const uint32_t e = valid ? w_pairs[base + lane] : 0u;
             const uint32_t owner = e >> kPairLaneShift;
-            const int k = (int)(e & ((1u << kPairLaneShift) - 1u));
+            const uint32_t slot = e & ((1u << kPairLaneShift) - 1u);
             const f3 po = mk3(lane_fetch(owner, o.x), lane_fetch(owner, o.y), lane_fetch(owner, o.z));
             const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));
             const float pa = lane_fetch(owner, a);
             const float ptime = MOVING ? lane_fetch(owner, time) : 0.0f;
-            if (valid) pair_test4<MOVING>(A, k, ptime, po, pd, pa, &w_keys[owner]);
+            if (valid) pair_test4<MOVING>(A, slot, ptime, po, pd, pa, &w_keys[owner]);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1174,10 +1184,9 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
     const float Bx = -o.x * rcp.x, By = -o.y * rcp.y, Bz = -o.z * rcp.z;
     const float arx = __builtin_fabsf(rcp.x), ary = __builtin_fabsf(rcp.y), arz = __builtin_fabsf(rcp.z);
     const float pad_ray = 1.0e-6f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z));
-    // byte offsets of the near / far plane arrays of each axis inside a node (lo at 0/16/32, hi at 48/64/80)
-    const uint32_t nxo = d.x < 0.0f ? 48u : 0u, nyo = d.y < 0.0f ? 64u : 16u, nzo = d.z < 0.0f ? 80u : 32u;
-    const uint32_t fxo = 48u - nxo, fyo = 80u - nyo, fzo = 112u - nzo;
-    const char *base = reinterpret_cast<const char *>(A.nodes4);
+    const bool neg_x = d.x < 0.0f, neg_y = d.y < 0.0f, neg_z = d.z < 0.0f;   // near plane of an axis = the upper one when the ray runs down it
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const uint4 *base = reinterpret_cast<const uint4 *>(A.nodes4);
     for (;;) {
         if (st.active) {
             if (st.cur == kNoChild4) {
@@ -1185,50 +1194,53 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
                 else st.cur = (int32_t)s_stack[(--st.sp) * BLK + tid];
             }
             if (st.active) {
-                const uint32_t off = (uint32_t)st.cur << 7;
-                const float4 pnx = *reinterpret_cast<const float4 *>(base + (size_t)(off + nxo));
-                const float4 pny = *reinterpret_cast<const float4 *>(base + (size_t)(off + nyo));
-                const float4 pnz = *reinterpret_cast<const float4 *>(base + (size_t)(off + nzo));
-                const float4 pfx = *reinterpret_cast<const float4 *>(base + (size_t)(off + fxo));
-                const float4 pfy = *reinterpret_cast<const float4 *>(base + (size_t)(off + fyo));
-                const float4 pfz = *reinterpret_cast<const float4 *>(base + (size_t)(off + fzo));
-                const int4 ch = *reinterpret_cast<const int4 *>(base + (size_t)off + 96);
-                const float4 meta = *reinterpret_cast<const float4 *>(base + (size_t)off + 112);
+                // (keeping the top levels of the tree in LDS was measured: no gain, and the flat loads that serve both kinds of
+                // lanes cost 3 %)
+                const uint4 *np = base + (size_t)(uint32_t)st.cur * 4u;
+                const uint4 qx = np[0], qy = np[1], qz = np[2], qm = np[3];   // (lo[4], hi[4]) f16 offsets per axis | origin, meta
                 if (COUNT) st.visits += 1u;
-                // node-level pad: 6e-6 / r_min * (|c - o|^2 + |h|^2) + 1e-4 (+ the FMA form's own loss)
-                const uint32_t ph = __float_as_uint(meta.w);
-                const float pk = (float)__builtin_bit_cast(_Float16, (unsigned short)(ph & 0xffffu));
-                const float p0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(ph >> 16));
-                const float ex = meta.x - o.x, ey = meta.y - o.y, ez = meta.z - o.z;
+                const uint32_t meta = qm.w;
+                const uint32_t cbase = meta & 0xffffu, n_inner = (meta >> 16) & 7u, n_child = (meta >> 19) & 7u;
+                // node-level pad: k (|origin - o|^2 + |E|^2) + 1e-4 (+ rounding), k = 6e-6 / r_min and the constant term as powers of two
+                const float pk = __uint_as_float((((meta >> 22) & 31u) + 96u) << 23);
+                const float p0 = __uint_as_float(((meta >> 27) + 113u) << 23);
+                const float ox = __uint_as_float(qm.x), oy = __uint_as_float(qm.y), oz = __uint_as_float(qm.z);
+                const float ex = ox - o.x, ey = oy - o.y, ez = oz - o.z;
                 const float pad = __builtin_fmaf(pk, __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)), p0) + pad_ray;
-                const float Bnx = __builtin_fmaf(-pad, arx, Bx), Bny = __builtin_fmaf(-pad, ary, By), Bnz = __builtin_fmaf(-pad, arz, Bz);
-                const float Bfx = __builtin_fmaf(pad, arx, Bx), Bfy = __builtin_fmaf(pad, ary, By), Bfz = __builtin_fmaf(pad, arz, Bz);
+                // t = offset * rcp + (origin * rcp + (-o * rcp -+ pad |rcp|))
+                const float Bnx = __builtin_fmaf(ox, rcp.x, __builtin_fmaf(-pad, arx, Bx)), Bny = __builtin_fmaf(oy, rcp.y, __builtin_fmaf(-pad, ary, By)),
+                            Bnz = __builtin_fmaf(oz, rcp.z, __builtin_fmaf(-pad, arz, Bz));
+                const float Bfx = __builtin_fmaf(ox, rcp.x, __builtin_fmaf(pad, arx, Bx)), Bfy = __builtin_fmaf(oy, rcp.y, __builtin_fmaf(pad, ary, By)),
+                            Bfz = __builtin_fmaf(oz, rcp.z, __builtin_fmaf(pad, arz, Bz));
                 const float limit = st.best < kMaxT ? (st.best * kCullRel + kCullAbs) : kMaxT;
-                const float nx[4] = {pnx.x, pnx.y, pnx.z, pnx.w}, ny[4] = {pny.x, pny.y, pny.z, pny.w}, nz[4] = {pnz.x, pnz.y, pnz.z, pnz.w};
-                const float fx[4] = {pfx.x, pfx.y, pfx.z, pfx.w}, fy[4] = {pfy.x, pfy.y, pfy.z, pfy.w}, fz[4] = {pfz.x, pfz.y, pfz.z, pfz.w};
-                const int32_t cr[4] = {ch.x, ch.y, ch.z, ch.w};
-                // Inner children occupy the first slots and are consecutive nodes (child[j] = child[0] + j), leaves (~sphere)
-                // follow, empty slots last. Everything below is branch-free: a slot's queue / stack entry is written
-                // unconditionally and only COUNTED when the child was hit.
+                // near / far plane pairs of each axis: children 0,1 in [0], 2,3 in [1]
+                const uint32_t nxw[2] = {neg_x ? qx.z : qx.x, neg_x ? qx.w : qx.y}, fxw[2] = {neg_x ? qx.x : qx.z, neg_x ? qx.y : qx.w};
+                const uint32_t nyw[2] = {neg_y ? qy.z : qy.x, neg_y ? qy.w : qy.y}, fyw[2] = {neg_y ? qy.x : qy.z, neg_y ? qy.y : qy.w};
+                const uint32_t nzw[2] = {neg_z ? qz.z : qz.x, neg_z ? qz.w : qz.y}, fzw[2] = {neg_z ? qz.x : qz.z, neg_z ? qz.y : qz.w};
+                // Inner children occupy the first slots and are consecutive nodes (first + slot), leaves follow, empty slots
+                // last. Everything below is branch-free: a slot's queue / stack entry is written unconditionally and only
+                // COUNTED when the child was hit.
                 uint32_t key[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    const half2v hnx = __builtin_bit_cast(half2v, nxw[j >> 1]), hny = __builtin_bit_cast(half2v, nyw[j >> 1]), hnz = __builtin_bit_cast(half2v, nzw[j >> 1]);
+                    const half2v hfx = __builtin_bit_cast(half2v, fxw[j >> 1]), hfy = __builtin_bit_cast(half2v, fyw[j >> 1]), hfz = __builtin_bit_cast(half2v, fzw[j >> 1]);
                     // NaNs (0 * inf) drop out of max3 / min3: that axis then imposes nothing, i.e. they count as a hit
-                    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf(nx[j], rcp.x, Bnx), __builtin_fmaf(ny[j], rcp.y, Bny)),
-                                                                     __builtin_fmaf(nz[j], rcp.z, Bnz)), 0.0f);
-                    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf(fx[j], rcp.x, Bfx), __builtin_fmaf(fy[j], rcp.y, Bfy)),
-                                                     __builtin_fmaf(fz[j], rcp.z, Bfz));
-                    const bool hit = !(tf < tn) && !(tn > limit) && cr[j] != kNoChild4;
-                    leafq[st.qn * BLK + tid] = (uint32_t)~cr[j];
-                    st.qn += (hit && cr[j] < 0) ? 1u : 0u;       // leaf child: one more candidate for the exact test
-                    if (COUNT) st.leaves += (hit && cr[j] < 0) ? 1u : 0u;
-                    key[j] = (hit && cr[j] >= 0) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xffffffffu;
+                    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf((float)hnx[j & 1], rcp.x, Bnx), __builtin_fmaf((float)hny[j & 1], rcp.y, Bny)),
+                                                                     __builtin_fmaf((float)hnz[j & 1], rcp.z, Bnz)), 0.0f);
+                    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf((float)hfx[j & 1], rcp.x, Bfx), __builtin_fmaf((float)hfy[j & 1], rcp.y, Bfy)),
+                                                     __builtin_fmaf((float)hfz[j & 1], rcp.z, Bfz));
+                    const bool hit = !(tf < tn) && !(tn > limit) && (uint32_t)j < n_child;
+                    const bool leaf = (uint32_t)j >= n_inner;
+                    leafq[st.qn * BLK + tid] = ((uint32_t)st.cur << 2) | (uint32_t)j;
+                    st.qn += (hit && leaf) ? 1u : 0u;       // leaf child: one more candidate for the exact test
+                    if (COUNT) st.leaves += (hit && leaf) ? 1u : 0u;
+                    key[j] = (hit && !leaf) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xffffffffu;
                 }
                 // sort the inner children by entry distance (5 compare-exchanges), push far-to-near, continue with the nearest
 #define PT_CE(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
                 PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
 #undef PT_CE
-                const uint32_t cbase = (uint32_t)cr[0];
                 // (16-bit stack entries: the 4-wide tree is only used while it has fewer than 65536 nodes)
                 s_stack[st.sp * BLK + tid] = (uint16_t)(cbase + (key[3] & 3u));
                 st.sp += key[3] != 0xffffffffu ? 1 : 0;
@@ -1307,6 +1319,10 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     p += kLdsParamBytes;
     float4 *s_shade = reinterpret_cast<float4 *>(p);    // PAL: the per-sphere shading records (64 B each)
     p += PAL ? (A.n_spheres + 1u) * 64u : 0u;
+    float4 *s_gate = reinterpret_cast<float4 *>(p);     // PAL && GATE: gate boxes (2 float4 per sphere) and DFS ranks of a BVH world
+    p += (PAL && GATE) ? A.n_spheres * 32u : 0u;
+    uint32_t *s_rank = reinterpret_cast<uint32_t *>(p);
+    p += (PAL && GATE) ? ((A.n_spheres * 4u + 15u) & ~15u) : 0u;
     float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][BLK] attenuation stack (PAL: u16 [max_depth][BLK] palette codes)
     uint16_t *s_pal = reinterpret_cast<uint16_t *>(p);
 
@@ -1325,6 +1341,10 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     if (PAL) {
         for (uint32_t k = tid; k < A.n_spheres * 4u; k += BLK) s_shade[k] = A.shade[k];
         if (tid < 4) s_shade[A.n_spheres * 4u + tid] = make_float4(1.f, 1.f, 1.f, 0.f);   // the white entry (Dielectric, material.rs:117)
+        if (GATE) {
+            for (uint32_t k = tid; k < A.n_spheres * 2u; k += BLK) s_gate[k] = A.gate[k];
+            for (uint32_t k = tid; k < A.n_spheres; k += BLK) s_rank[k] = A.leaf_rank[k];
+        }
     }
     if (BVH && A.nodes_in_lds) {
         const uint4 *src = reinterpret_cast<const uint4 *>(A.wnodes);
@@ -1529,7 +1549,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             idx = trav.idx;
             t_hit = trav.best;
         } else if (MFMA)
-            idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, s_par, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_cull,
+            idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, (PAL && GATE) ? GateSrc{s_gate, s_rank} : GateSrc{A.gate, A.leaf_rank}, s_par, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_cull,
                                                       s_queue, w_pairs, w_keys, ro, rd, a, have, rtime, t_hit
 #ifdef PT_SECTIONS
                                                       , sec_t

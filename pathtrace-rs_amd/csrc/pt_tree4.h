@@ -117,4 +117,90 @@ PT_HD TreeBox tree_finish_node(DNode4 &w, const TreeBox ch[4], uint32_t c) {
     return out;
 }
 
+// ---- the node the tree kernels READ: 64 bytes -------------------------------------------------------------------
+// A divergent 16-byte load costs one tag lookup per lane in the vector L1 whatever it returns, and a visit of the 128-byte
+// DNode4 takes eight of them per lane: the tree kernel was bound by exactly that (profiles/r02_c5: TA / TD ~85 % busy; four
+// MORE loads per visit cost +38 % of the frame). The packed node holds the same four child boxes in FOUR loads:
+//   * planes as f16 OFFSETS from the node's own min corner (`origin`, f32), the lower planes rounded down and the upper
+//     ones up, so the decoded box contains the DNode4 box (at most extent / 1024 larger per side); the kernel feeds
+//     them to mixed-precision FMAs (v_fma_mix_f32: f16 plane x f32 1/d + f32 constant), no conversion instructions;
+//   * no child references: inner children come first and are consecutive nodes (base + slot), leaves follow, and a leaf's
+//     sphere is found through its (node, slot) number in the slot records built beside the nodes (PtSlotRec);
+//   * the two constants of the conservative pad as powers of two (rounded up), and the pad measured from `origin`
+//     with the node's full extent E: every sphere below lies within |origin - o| + |E| of the ray origin.
+// meta = first inner child (16 bits) | inner children (3) | children (3) | e_k (5): k = 2^(e_k - 31) | e_0 (5): p0 = 2^(e_0 - 14).
+struct DNode4Q {
+    uint16_t plane[3][2][4];   // [axis][0 = lower plane, 1 = upper plane][child]
+    float origin[3];
+    uint32_t meta;
+};
+static_assert(sizeof(DNode4Q) == 64, "packed node is one half cache line");
+
+// greatest f16 <= v (v >= 0; anything above the f16 range gives the largest finite f16)
+PT_HD uint16_t tree_f16_down(double v) {
+    if (!(v > 0.0)) return 0;
+    if (v >= 65504.0) return 0x7bffu;
+    uint16_t u = __builtin_bit_cast(uint16_t, (_Float16)(float)v);
+    if (u > 0x7bffu) u = 0x7bffu;
+    while (u > 0 && tree_f16_value(u) > v) --u;
+    while (u < 0x7bffu && tree_f16_value((uint16_t)(u + 1)) <= v) ++u;
+    return u;
+}
+// smallest f16 >= v including +inf (v >= 0)
+PT_HD uint16_t tree_f16_ceil(double v) {
+    if (!(v > 0.0)) return 0;
+    if (v > 65504.0) return 0x7c00u;
+    return tree_f16_up(v);
+}
+// smallest e with 2^(e - bias) >= v, or 32 when none in 0..31 does
+PT_HD uint32_t tree_pow2_up(double v, int bias) {
+    for (uint32_t e = 0; e < 32u; ++e) {
+        double p = 1.0;
+        for (int i = (int)e - bias; i > 0; --i) p *= 2.0;
+        for (int i = (int)e - bias; i < 0; ++i) p *= 0.5;
+        if (p >= v) return e;
+    }
+    return 32u;
+}
+
+// Packs one finished DNode4. Returns false when the node cannot be expressed (pad constants out of range, node numbers
+// beyond 16 bits): the scene then walks the binary tree instead.
+PT_HD bool tree_pack_node(const DNode4 &w, DNode4Q &q) {
+    uint32_t nc = 0, ni = 0;
+    for (int j = 0; j < 4; ++j) {
+        if (w.child[j] == kNoChild4) break;
+        ++nc;
+        if (w.child[j] >= 0) ++ni;
+    }
+    const uint32_t base = ni ? (uint32_t)w.child[0] : 0u;
+    bool ok = base + 3u < 65536u;
+    double e2 = 0.0, mag = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        float mn = 3.0e38f, mx = -3.0e38f;
+        for (uint32_t j = 0; j < nc; ++j) {
+            mn = w.lo[k][j] < mn ? w.lo[k][j] : mn;
+            mx = w.hi[k][j] > mx ? w.hi[k][j] : mx;
+        }
+        const bool sane = nc > 0 && mn <= mx && mn > -3.0e38f && mx < 3.0e38f;
+        // (a NaN origin makes every plane distance NaN, which the visit counts as a hit: conservative)
+        q.origin[k] = sane ? mn : __builtin_nanf("");
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const bool used = sane && j < nc;
+            q.plane[k][0][j] = used ? tree_f16_down((double)w.lo[k][j] - (double)mn) : (uint16_t)0;
+            q.plane[k][1][j] = used ? tree_f16_ceil((double)w.hi[k][j] - (double)mn) : (uint16_t)0;
+        }
+        const double ext = sane ? (double)mx - (double)mn : 0.0;
+        e2 += ext * ext, mag += ext + (sane ? (mn < 0.0f ? -(double)mn : (double)mn) : 0.0);
+    }
+    const double pk = tree_f16_value((uint16_t)(w.padh & 0xffffu));   // 6e-6 / r_min (rounded up by tree_finish_node)
+    const uint32_t ek = tree_pow2_up(pk, 31);
+    ok = ok && ek < 32u;
+    double pk2 = 1.0;
+    for (uint32_t i = ek; i < 31u; ++i) pk2 *= 0.5;
+    const uint32_t e0 = tree_pow2_up((pk2 * e2 + 1.0e-4 + 2.0e-6 * mag) * 1.001, 14);
+    ok = ok && e0 < 32u;
+    q.meta = (base & 0xffffu) | (ni << 16) | (nc << 19) | ((ek & 31u) << 22) | ((e0 & 31u) << 27);
+    return ok;
+}
+
 }  // namespace ptdev

@@ -84,6 +84,9 @@ struct pt_scene {
     DWideNode *d_wnodes = nullptr;
     DNode4 *d_nodes4 = nullptr;               // 4-wide internal tree (default of the tree kernels), built on the device
     uint32_t n_nodes4 = 0, depth4 = 0;
+    DNode4Q *d_nodes4q = nullptr;             // ... as the packed 64-byte nodes the kernels read (pt_tree4.h), and the leaves' slot records
+    float4 *d_slotrec = nullptr;
+    bool tree4_packed = false;                // false: some node could not be packed (the binary tree is walked instead)
     float tree_build_ms = 0.f;                // device time of that build (HIP events)
     bool tree_on_device = false;
     // the binary tree (variant bit 2048, scenes beyond the 4-wide tree's 65535 nodes) is built on the host when first needed
@@ -933,6 +936,14 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
         pt_scene_destroy(s);
         return rc;
     }
+    if (s->d_nodes4) {   // the nodes the kernels read + the leaves' slot records, from what is on the device now
+        const int prc = tree4_pack_device(s->d_nodes4, s->n_nodes4, s->d_spheres, desc->n_bvh_nodes ? s->d_leafrec : nullptr, nullptr, &s->d_nodes4q,
+                                          &s->d_slotrec, &s->tree4_packed);
+        if (prc != 0) {
+            pt_scene_destroy(s);
+            return fail(PT_ERR_HIP, "packing the internal tree failed (hipError %d)", prc);
+        }
+    }
     if (motion) {
         std::vector<float4> mot(2 * (size_t)desc->n_spheres, make_float4(0, 0, 0, 0));
         for (uint32_t i = 0; i < desc->n_spheres; ++i) {
@@ -1199,6 +1210,8 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_bvh_large);
     (void)hipFree(s->d_wnodes);
     (void)hipFree(s->d_nodes4);
+    (void)hipFree(s->d_nodes4q);
+    (void)hipFree(s->d_slotrec);
     (void)hipFree(s->d_rank_sphere);
     (void)hipFree(s->d_leafrec);
     (void)hipFree(s->d_shade_rank);
@@ -1439,9 +1452,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.gate_chain = s->d_gate_chain;
     A.bvh_large = s->d_bvh_large;
     A.n_bvh_large = s->n_bvh_large;
-    A.nodes4 = s->d_nodes4;
+    A.nodes4 = s->d_nodes4q;
+    A.slotrec = s->d_slotrec;
     A.rank_sphere = s->d_rank_sphere;
-    A.leafrec = s->d_leafrec;
     A.shade_rank = s->d_shade_rank;
     A.leaf_rank = s->d_leaf_rank;
     memcpy(A.root_min, s->root_min, 12);
@@ -1507,7 +1520,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (const char *e = getenv("PTGPU_DRAIN")) A.drain_at = std::min<uint32_t>((uint32_t)atoi(e), (uint32_t)(kLeafQ - 4));
     // 4-wide tree (default; variant bit 2048: the binary tree): a visit pushes at most three siblings per level
     // (its stack entries are 16-bit node indices; a bigger tree -- more than ~190 000 spheres -- walks the binary one)
-    const bool tree4 = bvh && (s->variant & 2048u) == 0 && s->n_nodes4 < 65536u && s->word_ok;
+    const bool tree4 = bvh && (s->variant & 2048u) == 0 && s->n_nodes4 < 65536u && s->word_ok && s->tree4_packed;
     if (bvh && !tree4)
         if (int rc = ensure_binary_tree(s)) return rc;
     A.wnodes = s->d_wnodes;
@@ -1530,7 +1543,10 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     const uint32_t stack_levels = params->max_depth > 1u ? params->max_depth - 1u : 1u;
     uint32_t blk = kBlock;
     // wide kernels: 16-bit palette codes on the attenuation stack + the shading records in LDS (pt_kernel.h PAL)
-    const auto wide_extra = [&](uint32_t b) { return ((uint64_t)s->n_spheres + 1ull) * 64ull + (((uint64_t)stack_levels * 2ull * b + 15ull) & ~15ull); };
+    const auto wide_extra = [&](uint32_t b) {
+        return ((uint64_t)s->n_spheres + 1ull) * 64ull + (((uint64_t)stack_levels * 2ull * b + 15ull) & ~15ull) +
+               (ref_bvh ? (uint64_t)s->n_spheres * 32ull + (((uint64_t)s->n_spheres * 4ull + 15ull) & ~15ull) : 0ull);   // BVH world: gates + ranks
+    };
     if (mfma && s->palette_ok && (s->variant & 2u) == 0 && (A.verify & 1u) == 0 && s->blocks_per_cu == 0) {
         const auto wide_lds = [&](uint32_t b) {
             return (uint64_t)lds + mfma_queue_bytes(b) + s->n_tiles * 2048u + ((s->n_tiles * 64u + 15u) & ~15u) + 8u * kCullCells + wide_extra(b);

@@ -1,10 +1,11 @@
 #!/bin/bash
 # One PMC pass (default WRITE_SIZE) of a bench.py workload; prints the per-launch average of the frame kernel.
+# (a counter set the hardware cannot collect aborts rocprofv3 and then hangs in its signal handler: hence the timeout)
 # usage: bash tools/pmc_one.sh TAG "COUNTERS" [bench.py args]
 TAG=$1; CNT=$2; shift 2
 OUT=gpurun_out/pmc_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT.log 2>&1
+timeout -k 5 240 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT.log 2>&1
 python3 - "$OUT" "$TAG" <<'PY'
 import csv, glob, sys, collections, re
 f = sorted(glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True))[0]
