@@ -119,7 +119,8 @@ __device__ __forceinline__ bool w_sphere(f3 centre, float radius, const WRay &r,
         h.point = add3(r.o, scale3(r.d, t));
         h.normal = divs3(sub3(h.point, centre), radius);
         h.t = t;
-        h.u = h.v = 0.0f;   // sphere.rs:47-48
+        h.u = 0.0f, h.v = 0.0f;   // sphere.rs:47-48 (u before v like every other shape: with the two stores in the other order the
+                                  //  compiler merges them across shapes into stores through a SELECTED pointer, which keeps u and v in scratch)
         return true;
     }
     return false;
@@ -261,7 +262,7 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
         h.point = add3(r.o, scale3(r.d, t));
         h.normal = mk3(1.0f, 0.0f, 0.0f);  // Vec3::X, arbitrary
         h.t = t;
-        h.u = h.v = 0.0f;
+        h.u = 0.0f, h.v = 0.0f;
         return H.medium_material;
     }
     return -1;
