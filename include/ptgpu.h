@@ -297,6 +297,11 @@ int pt_last_launch_info(pt_scene *scene, uint32_t *grid_out, uint32_t *block_out
  * builders byte for byte). */
 int pt_scene_build_info(pt_scene *scene, float *build_ms_out, uint32_t *n_nodes_out, uint32_t *depth_out, uint32_t *on_device_out);
 int pt_scene_debug_tree(pt_scene *scene, void *nodes_out, size_t capacity_bytes);
+/* The same tree as the kernels READ it: 64-byte nodes (csrc/pt_tree4.h DNode4Q: per axis the lower / upper planes of the four
+ * children as f16 offsets from the node's min corner -- lower rounded down, upper rounded up --, the corner as three f32, one
+ * word of child counts and pad constants). *usable_out = 0 when some node could not be packed (the kernels then walk the
+ * binary tree). Tests check that every packed box contains the 128-byte node's box. */
+int pt_scene_debug_tree_packed(pt_scene *scene, void *nodes_out, size_t capacity_bytes, uint32_t *usable_out);
 
 /* Tuning knobs (0 = library default): workgroups resident per CU for the persistent grid, and a
  * kernel-variant bit mask (DESIGN.md "kernel variants"): 1 = scan table from HBM/L2 instead of LDS,

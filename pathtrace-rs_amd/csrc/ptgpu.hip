@@ -1932,6 +1932,16 @@ extern "C" int pt_scene_debug_tree(pt_scene *s, void *nodes_out, size_t capacity
     return PT_OK;
 }
 
+extern "C" int pt_scene_debug_tree_packed(pt_scene *s, void *nodes_out, size_t capacity_bytes, uint32_t *usable_out) {
+    if (!s || !nodes_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    const size_t bytes = s->d_nodes4q ? (size_t)s->n_nodes4 * sizeof(DNode4Q) : 0;
+    if (capacity_bytes < bytes) return fail(PT_ERR_INVALID_ARG, "buffer holds %zu bytes, the packed tree has %zu", capacity_bytes, bytes);
+    HIP_TRY(hipSetDevice(s->device));
+    if (bytes) HIP_TRY(hipMemcpy(nodes_out, s->d_nodes4q, bytes, hipMemcpyDeviceToHost));
+    if (usable_out) *usable_out = s->tree4_packed ? 1u : 0u;
+    return PT_OK;
+}
+
 extern "C" int pt_last_launch_info(pt_scene *s, uint32_t *grid_out, uint32_t *block_out, uint32_t *lds_bytes_out) {
     if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
     if (grid_out) *grid_out = s->last_grid;

@@ -104,7 +104,7 @@ EXPORTS = [
     "pt_render_shard_device", "pt_shard_rows", "pt_scene_set_seed_base", "pt_last_kernel_ms",
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
-    "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree",
+    "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree", "pt_scene_debug_tree_packed",
     "pt_buffer_register", "pt_buffer_unregister",
 ]
 COMM_ID_BYTES = 128
@@ -159,6 +159,7 @@ def lib():
         L.pt_shard_unpack_all.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         L.pt_scene_build_info.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.pt_scene_debug_tree.argtypes = [vp, vp, C.c_size_t]
+        L.pt_scene_debug_tree_packed.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32)]
         L.pt_buffer_register.argtypes = [vp, C.c_size_t]
         L.pt_buffer_unregister.argtypes = [vp]
         L.pt_last_error.restype = C.c_char_p
@@ -360,6 +361,14 @@ class Scene:
         out = np.zeros((max(n, 1), 32), np.uint32)
         _check(lib().pt_scene_debug_tree(self._h, out.ctypes.data, out.nbytes))
         return out[:n]
+
+    def debug_tree_packed(self):
+        """The nodes as the kernels read them: ([n_nodes, 16] uint32 array of 64-byte records, usable flag)."""
+        n = self.build_info()["n_nodes"]
+        out = np.zeros((max(n, 1), 16), np.uint32)
+        ok = C.c_uint32(0)
+        _check(lib().pt_scene_debug_tree_packed(self._h, out.ctypes.data, out.nbytes, C.byref(ok)))
+        return out[:n], bool(ok.value)
 
     def last_launch_info(self):
         g, b, l = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)

@@ -883,6 +883,37 @@ def test_device_tree_build_equals_the_host_restatement(ptgpu, pthost, preset, bv
     assert len(set(leaves.tolist())) == len(leaves)
 
 
+@pytest.mark.parametrize("preset,bvh", [("perlin_spheres", True), ("random_spheres", True), ("random", True), ("small", False)])
+def test_packed_tree_nodes_contain_the_built_boxes(ptgpu, pthost, preset, bvh):
+    """The kernels read 64-byte nodes (pt_tree4.h DNode4Q): f16 plane offsets from the node's min corner. Packing may only
+    ENLARGE a child box (lower planes rounded down, upper ones up) and by no more than one f16 step of the offset; child
+    counts and the first inner child must survive it."""
+    hs = pthost.HostScene(preset, 64, 48, samples=1, use_bvh=bvh, device=0)
+    sc = hs.device_scene()
+    full = sc.debug_tree()
+    packed, usable = sc.debug_tree_packed()
+    assert usable and len(packed) == len(full) > 0
+    lo = full[:, 0:12].view(np.float32).reshape(-1, 3, 4).astype(np.float64)
+    hi = full[:, 12:24].view(np.float32).reshape(-1, 3, 4).astype(np.float64)
+    child = full[:, 24:28].view(np.int32)
+    used = child != 0x7fffffff
+    planes = np.ascontiguousarray(packed[:, 0:12]).view(np.float16).reshape(-1, 3, 2, 4).astype(np.float64)
+    origin = packed[:, 12:15].view(np.float32).astype(np.float64)
+    meta = packed[:, 15]
+    assert np.array_equal((meta >> 19) & 7, used.sum(axis=1))
+    assert np.array_equal((meta >> 16) & 7, ((child >= 0) & used).sum(axis=1))
+    has_inner = ((meta >> 16) & 7) > 0
+    assert np.array_equal((meta & 0xffff)[has_inner], child[has_inner, 0])
+    for k in range(3):
+        plo = origin[:, k, None] + planes[:, k, 0, :]
+        phi = origin[:, k, None] + planes[:, k, 1, :]
+        assert (plo[used] <= lo[:, k, :][used]).all() and (phi[used] >= hi[:, k, :][used]).all()
+        ext = (hi[:, k, :] - origin[:, k, None])[used]
+        step = np.maximum(np.abs(ext), 2.0 ** -14) * 2.0 ** -10   # one f16 step of the largest offset of the box
+        assert ((lo[:, k, :] - plo)[used] <= step).all() and ((phi - hi[:, k, :])[used] <= step).all()
+        assert np.allclose(origin[:, k], np.where(used, lo[:, k, :], np.inf).min(axis=1))
+
+
 def test_traversal_counters_report_internal_tree_work(ptgpu, pthost, oracle):
     """BVH-mode work is reported as node visits / sphere tests per ray. Verify mode on a tree kernel counts
     them for the device's internal tree; the oracle counts the reference's both-children traversal. The image must

@@ -161,6 +161,7 @@ def test_null_handles_are_errors_not_crashes(ptgpu):
     assert L.pt_buffer_unregister(buf.ctypes.data) == ptgpu.PT_ERR_INVALID_ARG      # never registered
     assert L.pt_scene_build_info(None, None, None, None, None) == ptgpu.PT_ERR_INVALID_ARG
     assert L.pt_scene_debug_tree(None, None, 0) == ptgpu.PT_ERR_INVALID_ARG
+    assert L.pt_scene_debug_tree_packed(None, None, 0, None) == ptgpu.PT_ERR_INVALID_ARG
 
 
 def test_comm_entry_points_validate_without_a_device(ptgpu):
