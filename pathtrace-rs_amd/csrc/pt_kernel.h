@@ -1076,9 +1076,10 @@ struct Trav4 {
     int sp;                    // stack entries of this lane
     int32_t cur;               // node to visit next (kNoChild4: pop)
     uint32_t qn;               // queued leaf candidates
-    float best;                // nearest accepted hit so far (register copy of the key's t)
+    float limit;               // culling limit of the node tests: nearest accepted hit so far * 1.02 + 0.02 (refreshed after every drain)
     bool active;
 };
+__device__ __forceinline__ float trav4_limit(float best) { return best < kMaxT ? (best * kCullRel + kCullAbs) : kMaxT; }
 
 // key of an accepted hit: smaller t wins; equal t goes to the lower list index (hitable_list.rs:48) or, in a BVH world,
 // to the DFS-later leaf (bvh.rs:47-53) -- the order-independent form of both scans (accept_hit / bvh_leaf)
@@ -1146,7 +1147,7 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     st.qn = 0;
-    st.best = __uint_as_float((uint32_t)(w_keys[lane] >> 32));
+    st.limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[lane] >> 32)));   // (an empty key's t field is a NaN pattern: not < kMaxT)
 }
 
 template <bool MOVING>
@@ -1160,7 +1161,7 @@ __device__ __forceinline__ void bvh4_start(const KArgs &A, unsigned long long *w
         bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, rcp, a, best, idx, rank);
     }
     w_keys[threadIdx.x & 63] = idx < 0 ? ~0ull : key4_of(A, best, idx);
-    st.best = idx < 0 ? kMaxT : best;
+    st.limit = trav4_limit(idx < 0 ? kMaxT : best);
     st.sp = 0;
     st.qn = 0;
     st.cur = A.bvh_root >= 0 ? 0 : kNoChild4;
@@ -1179,9 +1180,6 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
 #define PT_SUB4(i) do { } while (0)
 #endif
     const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    // per-ray constants of the plane test: t = plane * rcp + B; the FMA form loses ~eps * |o| of position against
-    // (plane - o) * rcp, which the pad below carries on top of the node's bound
-    const float Bx = -o.x * rcp.x, By = -o.y * rcp.y, Bz = -o.z * rcp.z;
     const float arx = __builtin_fabsf(rcp.x), ary = __builtin_fabsf(rcp.y), arz = __builtin_fabsf(rcp.z);
     const float pad_ray = 1.0e-6f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z));
     const bool neg_x = d.x < 0.0f, neg_y = d.y < 0.0f, neg_z = d.z < 0.0f;   // near plane of an axis = the upper one when the ray runs down it
@@ -1200,25 +1198,23 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
                 const uint4 qx = np[0], qy = np[1], qz = np[2], qm = np[3];   // (lo[4], hi[4]) f16 offsets per axis | origin, meta
                 if (COUNT) st.visits += 1u;
                 const uint32_t meta = qm.w;
-                const uint32_t cbase = meta & 0xffffu, n_inner = (meta >> 16) & 7u, n_child = (meta >> 19) & 7u;
+                const uint32_t cbase = meta & 0xffffu, n_inner = (meta >> 16) & 7u;
                 // node-level pad: k (|origin - o|^2 + |E|^2) + 1e-4 (+ rounding), k = 6e-6 / r_min and the constant term as powers of two
-                const float pk = __uint_as_float((((meta >> 22) & 31u) + 96u) << 23);
-                const float p0 = __uint_as_float(((meta >> 27) + 113u) << 23);
-                const float ox = __uint_as_float(qm.x), oy = __uint_as_float(qm.y), oz = __uint_as_float(qm.z);
-                const float ex = ox - o.x, ey = oy - o.y, ez = oz - o.z;
+                const float pk = __uint_as_float((__builtin_amdgcn_ubfe(meta, 22, 5) << 23) + (96u << 23));
+                const float p0 = __uint_as_float(((meta >> 27) << 23) + (113u << 23));
+                const float ex = __uint_as_float(qm.x) - o.x, ey = __uint_as_float(qm.y) - o.y, ez = __uint_as_float(qm.z) - o.z;
                 const float pad = __builtin_fmaf(pk, __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)), p0) + pad_ray;
-                // t = offset * rcp + (origin * rcp + (-o * rcp -+ pad |rcp|))
-                const float Bnx = __builtin_fmaf(ox, rcp.x, __builtin_fmaf(-pad, arx, Bx)), Bny = __builtin_fmaf(oy, rcp.y, __builtin_fmaf(-pad, ary, By)),
-                            Bnz = __builtin_fmaf(oz, rcp.z, __builtin_fmaf(-pad, arz, Bz));
-                const float Bfx = __builtin_fmaf(ox, rcp.x, __builtin_fmaf(pad, arx, Bx)), Bfy = __builtin_fmaf(oy, rcp.y, __builtin_fmaf(pad, ary, By)),
-                            Bfz = __builtin_fmaf(oz, rcp.z, __builtin_fmaf(pad, arz, Bz));
-                const float limit = st.best < kMaxT ? (st.best * kCullRel + kCullAbs) : kMaxT;
+                // t = offset * rcp + ((origin - o) * rcp -+ pad |rcp|)
+                const float px = pad * arx, py = pad * ary, pz = pad * arz;
+                const float Bnx = __builtin_fmaf(ex, rcp.x, -px), Bny = __builtin_fmaf(ey, rcp.y, -py), Bnz = __builtin_fmaf(ez, rcp.z, -pz);
+                const float Bfx = __builtin_fmaf(ex, rcp.x, px), Bfy = __builtin_fmaf(ey, rcp.y, py), Bfz = __builtin_fmaf(ez, rcp.z, pz);
+                const float limit = st.limit;
                 // near / far plane pairs of each axis: children 0,1 in [0], 2,3 in [1]
                 const uint32_t nxw[2] = {neg_x ? qx.z : qx.x, neg_x ? qx.w : qx.y}, fxw[2] = {neg_x ? qx.x : qx.z, neg_x ? qx.y : qx.w};
                 const uint32_t nyw[2] = {neg_y ? qy.z : qy.x, neg_y ? qy.w : qy.y}, fyw[2] = {neg_y ? qy.x : qy.z, neg_y ? qy.y : qy.w};
                 const uint32_t nzw[2] = {neg_z ? qz.z : qz.x, neg_z ? qz.w : qz.y}, fzw[2] = {neg_z ? qz.x : qz.z, neg_z ? qz.y : qz.w};
                 // Inner children occupy the first slots and are consecutive nodes (first + slot), leaves follow, empty slots
-                // last. Everything below is branch-free: a slot's queue / stack entry is written unconditionally and only
+                // last (their planes can never be hit: lower offsets at the f16 maximum, upper ones zero). Everything below is branch-free: a slot's queue / stack entry is written unconditionally and only
                 // COUNTED when the child was hit.
                 uint32_t key[4];
 #pragma unroll
@@ -1230,12 +1226,13 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
                                                                      __builtin_fmaf((float)hnz[j & 1], rcp.z, Bnz)), 0.0f);
                     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf((float)hfx[j & 1], rcp.x, Bfx), __builtin_fmaf((float)hfy[j & 1], rcp.y, Bfy)),
                                                      __builtin_fmaf((float)hfz[j & 1], rcp.z, Bfz));
-                    const bool hit = !(tf < tn) && !(tn > limit) && (uint32_t)j < n_child;
+                    // hit = !(tf < tn) && !(tn > limit); tn is never NaN (max with 0), so the limit folds into the far side
+                    const bool miss = __builtin_fminf(tf, limit) < tn;
                     const bool leaf = (uint32_t)j >= n_inner;
                     leafq[st.qn * BLK + tid] = ((uint32_t)st.cur << 2) | (uint32_t)j;
-                    st.qn += (hit && leaf) ? 1u : 0u;       // leaf child: one more candidate for the exact test
-                    if (COUNT) st.leaves += (hit && leaf) ? 1u : 0u;
-                    key[j] = (hit && !leaf) ? ((__float_as_uint(tn) & ~3u) | (uint32_t)j) : 0xffffffffu;
+                    st.qn += (miss || !leaf) ? 0u : 1u;     // leaf child: one more candidate for the exact test
+                    if (COUNT) st.leaves += (miss || !leaf) ? 0u : 1u;
+                    key[j] = (miss || leaf) ? 0xffffffffu : ((__float_as_uint(tn) & ~3u) | (uint32_t)j);
                 }
                 // sort the inner children by entry distance (5 compare-exchanges), push far-to-near, continue with the nearest
 #define PT_CE(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }

@@ -186,7 +186,9 @@ PT_HD bool tree_pack_node(const DNode4 &w, DNode4Q &q) {
         q.origin[k] = sane ? mn : __builtin_nanf("");
         for (uint32_t j = 0; j < 4u; ++j) {
             const bool used = sane && j < nc;
-            q.plane[k][0][j] = used ? tree_f16_down((double)w.lo[k][j] - (double)mn) : (uint16_t)0;
+            // (an empty slot -- or every slot of a node with a NaN corner would be "hit": such nodes have none -- must never be:
+            //  lower plane at the f16 maximum above an upper plane at zero makes far < near on every axis the ray moves along)
+            q.plane[k][0][j] = used ? tree_f16_down((double)w.lo[k][j] - (double)mn) : (uint16_t)(j < nc ? 0u : 0x7bffu);
             q.plane[k][1][j] = used ? tree_f16_ceil((double)w.hi[k][j] - (double)mn) : (uint16_t)0;
         }
         const double ext = sane ? (double)mx - (double)mn : 0.0;
