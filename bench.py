@@ -82,7 +82,8 @@ def cpu_baseline(preset, W, H, S, depth, use_bvh, target_secs=15.0):
 
 # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz, a wave64 VALU instruction issues over 2 cycles
 VALU_PEAK_TLANEOPS = 256 * 4 * 2.4e9 / 2 * 64 / 1e12      # 78.6 T lane-ops/s nominal
-VALU_PEAK_MEASURED = 67.0                                  # tools/valu_bench.hip on the GPU box (2.3 cycles / wave-instruction)
+VALU_PEAK_MEASURED = 67.0                                  # tools/valu_bench.hip on the GPU box: v_fma_f32 (2.3 cycles / wave-instruction)
+VALU_SIMPLE_MEASURED = 105.0                               # same tool, plain v_mul_f32 / v_add_f32 at 4 waves per SIMD (1.5 cycles)
 HBM_PEAK_GBS = 8000.0
 N_SIMD = 1024
 
@@ -126,6 +127,9 @@ def roofline_block(kernel_name, kms, rays_launch, n_hitables, use_bvh, counters)
         out["achieved"] = valu * 64.0 / ksec / 1e12
         out["frac"] = out["achieved"] / VALU_PEAK_TLANEOPS
         out["frac_of_measured_peak"] = out["achieved"] / VALU_PEAK_MEASURED
+        # tools/valu_bench.hip at 4 waves per SIMD: v_fma_f32 62 T lane-ops/s, plain v_mul / v_add 105 T (121 T at 8 waves). The
+        # path computes unfused (results must round like the reference), so most of its VALU work is of the second kind:
+        out["frac_of_simple_op_rate"] = out["achieved"] / VALU_SIMPLE_MEASURED
         out["valu_wave_insts_per_64_rays"] = per_ray.get("SQ_INSTS_VALU", 0.0) * 64.0
         if "hbm_bytes_per_launch" in per_ray:
             out["traffic"] = per_ray["hbm_bytes_per_launch"] * rays_launch

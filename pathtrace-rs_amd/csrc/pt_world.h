@@ -308,7 +308,9 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
     }
     __syncthreads();
     PerlinLds pn{s_pvec, s_perm, OCC < 4};
-    const bool want_uv = A.has_image != 0u;
+    // (u, v) of a hit only feed Image textures; the 4-waves-per-SIMD instantiations are launched for worlds without them and
+    // do not carry the two registers (nor their divisions) at all
+    const bool want_uv = OCC < 4 && A.has_image != 0u;
     const pt_hitable *hit = HIT_LDS ? s_hit : A.hit;
     const pt_affine *xf = HIT_LDS ? s_xf : A.xf;
     float *path = A.stack_in_lds ? (s_path + tid) : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * kBlock + tid);

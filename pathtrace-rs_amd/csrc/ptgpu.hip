@@ -1397,7 +1397,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
         W.stack_in_lds = (lds + path_bytes <= 60u * 1024u) ? 1u : 0u;
         if (W.stack_in_lds) lds += (uint32_t)path_bytes;
-        const bool occ4 = !s->has_noise && s->blocks_per_cu == 0 && 4u * lds <= kLdsBudget && !getenv("PTGPU_WORLD_OCC3");   // see pt_world_kernel's OCC
+        const bool occ4 = !s->has_noise && !s->has_image && s->blocks_per_cu == 0 && 4u * lds <= kLdsBudget && !getenv("PTGPU_WORLD_OCC3");   // see pt_world_kernel's OCC
         // one instantiation per (traversal, records in LDS, waves per SIMD, world has media); worlds whose records do not
         // fit LDS (more than ~600 hitables) share the MEDIA = true code
         const bool media = s->has_media || !hit_lds || s->has_motion;
