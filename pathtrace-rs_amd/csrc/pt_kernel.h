@@ -700,6 +700,9 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
         }
         const uint32_t incl = wave_inclusive_sum(mine_n);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#ifdef PT_WAVEDBG
+        if (sec) sec[1] += total, sec[3] += 1, sec[2] += total > (uint32_t)kPairCap ? 1 : 0;
+#endif
         if (total > (uint32_t)kPairCap) {
             // more pairs than the list holds (rays far outside the prefilter's accuracy range): every lane walks its own
             uint32_t tb = tbits, j = 0, cur = 0, curT = 0;
@@ -814,6 +817,9 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     while (rem != 0u) {
         const uint32_t T = (uint32_t)__builtin_ctz(rem);
         rem &= rem - 1u;
+#ifdef PT_WAVEDBG
+        if (sec) sec[0] += 1;
+#endif
         const uint32_t Tn = rem ? (uint32_t)__builtin_ctz(rem) : T;   // the next tile's fragments are fetched under this one
         float16v acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, rf.b0[0], zero, 0, 0, 0);
         float16v acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.h, rf.b1[0], zero, 0, 0, 0);
@@ -1424,6 +1430,14 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         return mk3(q.x, q.y, q.z);
     };
     float rtime = 0.f;  // ray.time (only MOVING kernels read it)
+#if defined(PT_SECTIONS) || defined(PT_WAVEDBG)
+#define PT_WAVE_DETAIL 1   // development builds: per-wave iteration counts, first / last pixel, moment the work list ran dry
+    uint32_t dbg_first_pxy = 0xffffffffu;
+#ifdef PT_WAVEDBG
+    unsigned long long dbgc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    unsigned long long dbg_exh_iter = 0, dbg_iters = 0, dbg_last_refill = 0, dbg_start = A.wave_end ? wall_clock64() : 0ull;   // (PTGPU_TIMING)
+#endif
 
     for (;;) {
         // ---- refill: one wave-aggregated atomic for all lanes that need a pixel. The refill code (a global atomic
@@ -1453,6 +1467,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             const uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (item >= A.n_items) {
                 exhausted = true;
+#ifdef PT_WAVE_DETAIL
+                if (A.wave_end && dbg_exh_iter == 0) dbg_exh_iter = dbg_iters, dbg_last_refill = wall_clock64();
+#endif
             } else {
                 const uint32_t in = item & (kTilePix - 1u);
                 const uint32_t tile = A.tile_order ? A.tile_order[item >> (2u * kTileLog2)] : (item >> (2u * kTileLog2));
@@ -1465,6 +1482,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 if (x < A.width && ly < A.local_rows && !(PILOT && !BVH && ((x | ly) & 1u))) {
                     have = true;
                     pxy = x | (ly << 16);
+#ifdef PT_WAVE_DETAIL
+                    if (dbg_first_pxy == 0xffffffffu) dbg_first_pxy = pxy;
+#endif
                     sd = 0;
                     const uint32_t px = x, py = ly * A.shard_count + A.shard_index;
                     need_cam = true;
@@ -1483,6 +1503,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             if (__ballot(!exhausted) == 0ull) break;
             continue;
         }
+#ifdef PT_WAVE_DETAIL
+        if (A.wave_end) dbg_iters += 1;
+#endif
         PT_SEC(0);
 
         // ---- camera.rs:56-68 + scene.rs:107-108: start the next sample
@@ -1550,6 +1573,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                                                       s_queue, w_pairs, w_keys, ro, rd, a, have, rtime, t_hit
 #ifdef PT_SECTIONS
                                                       , sec_t
+#elif defined(PT_WAVEDBG)
+                                                      , dbgc
 #endif
                                                       );
         else
@@ -1730,8 +1755,23 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     PT_SEC(4);
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&A.debug[16 + i], sec_t[i]);
+    if (A.wave_end && lane == 0)
+        for (int q = 0; q < 8; ++q) A.wave_end[(5 + q) * (gridDim.x * (BLK / 64)) + blockIdx.x * (BLK / 64) + (tid >> 6)] = sec_t[q];
 #endif
-    if (A.wave_end && lane == 0) A.wave_end[blockIdx.x * (BLK / 64) + (tid >> 6)] = wall_clock64();
+    if (A.wave_end && lane == 0) {
+        const uint32_t w = blockIdx.x * (BLK / 64) + (tid >> 6), nw = gridDim.x * (BLK / 64);
+        A.wave_end[w] = wall_clock64();
+        // (per-lane values of lane 0 would miss other lanes' exhaustion: take the wave's earliest)
+#ifdef PT_WAVE_DETAIL
+        A.wave_end[nw + w] = dbg_iters | (dbg_exh_iter << 32), A.wave_end[2 * nw + w] = dbg_last_refill, A.wave_end[3 * nw + w] = dbg_start;
+        A.wave_end[4 * nw + w] = dbg_first_pxy | ((unsigned long long)pxy << 32);
+#else
+        (void)nw;
+#endif
+#ifdef PT_WAVEDBG
+        for (int q = 0; q < 4; ++q) A.wave_end[(5 + q) * nw + w] = dbgc[q];
+#endif
+    }
     if (BVH && VERIFY) {   // traversal counters (accumulate over the lane's whole life: never reset per ray)
         atomicAdd(&A.debug[8], (unsigned long long)(TREE4 ? trav4.visits : trav.visits));
         atomicAdd(&A.debug[9], (unsigned long long)(TREE4 ? trav4.leaves : trav.leaves) + (lane == 0 ? wave_rays * A.n_bvh_large : 0ull));

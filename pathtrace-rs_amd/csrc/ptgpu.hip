@@ -1739,8 +1739,37 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (timing) {  // development aid: distribution of wave finish times
         (void)hipStreamSynchronize(stream);
         const uint32_t nw = grid * (blk / 64);
-        std::vector<unsigned long long> t(nw);
-        (void)hipMemcpy(t.data(), d_wave_end, nw * 8, hipMemcpyDeviceToHost);
+        std::vector<unsigned long long> t(nw), all(13 * (size_t)nw);
+        (void)hipMemcpy(all.data(), d_wave_end, std::min<size_t>(13 * (size_t)nw, 65536) * 8, hipMemcpyDeviceToHost);
+        std::copy(all.begin(), all.begin() + nw, t.begin());
+#if defined(PT_SECTIONS) || defined(PT_WAVEDBG)
+        if (13u * nw <= 65536u) {   // the last finishers: iterations, when they last fetched pixels, when they started
+            std::vector<uint32_t> idx(nw);
+            for (uint32_t i = 0; i < nw; ++i) idx[i] = i;
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return all[a] > all[b]; });
+            unsigned long long t_first = ~0ull;
+            for (uint32_t i = 0; i < nw; ++i) t_first = std::min(t_first, all[3 * (size_t)nw + i]);
+            double it_sum = 0;
+            for (uint32_t i = 0; i < nw; ++i) it_sum += (double)(all[nw + i] & 0xffffffffull);
+            fprintf(stderr, "[ptgpu timing] mean iterations per wave %.0f\n", it_sum / nw);
+            for (uint32_t r : {0u, 1u, 2u, 5u, 10u, 20u, 40u, 100u, 400u, 2000u, nw - 1u}) {
+                if (r >= nw) continue;
+                const uint32_t w = idx[r];
+                fprintf(stderr, "  lane 0: first pixel (%u, %u), last pixel (%u, %u);", (unsigned)(all[4 * (size_t)nw + w] & 0xffffu), (unsigned)((all[4 * (size_t)nw + w] >> 16) & 0xffffu),
+                        (unsigned)((all[4 * (size_t)nw + w] >> 32) & 0xffffu), (unsigned)(all[4 * (size_t)nw + w] >> 48));
+#ifdef PT_SECTIONS
+                fprintf(stderr, " kcycles: refill %.0f camera %.0f features %.0f tiles %.0f phase2 %.0f shade %.0f;", all[5 * (size_t)nw + w] * 1e-3, all[6 * (size_t)nw + w] * 1e-3,
+                        all[10 * (size_t)nw + w] * 1e-3, all[11 * (size_t)nw + w] * 1e-3, (all[7 * (size_t)nw + w] - all[10 * (size_t)nw + w] - all[11 * (size_t)nw + w]) * 1e-3, all[8 * (size_t)nw + w] * 1e-3);
+#endif
+#ifdef PT_WAVEDBG
+                fprintf(stderr, " tiles %llu pairs %llu overflows %llu drains %llu;", all[5 * (size_t)nw + w], all[6 * (size_t)nw + w], all[7 * (size_t)nw + w], all[8 * (size_t)nw + w]);
+#endif
+                fprintf(stderr, "  rank %4u wave %4u: end %.3f ms; first empty-handed fetch (lane 0) at %.3f ms after %llu of %llu iterations\n", r, w,
+                        (all[w] - t_first) * 1e-5, all[2 * (size_t)nw + w] ? (all[2 * (size_t)nw + w] - t_first) * 1e-5 : -1.0,
+                        all[nw + w] >> 32, all[nw + w] & 0xffffffffull);
+            }
+        }
+#endif
         std::sort(t.begin(), t.end());
         const double tick_ns = 10.0;  // wall_clock64: 100 MHz
         fprintf(stderr, "[ptgpu timing] waves %u: finish spread (ms after first finisher) p10 %.3f p50 %.3f p90 %.3f p99 %.3f last %.3f\n", nw,
