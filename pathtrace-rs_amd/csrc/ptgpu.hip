@@ -545,7 +545,8 @@ std::vector<AccelItem> accel_items(const pt_scene_desc *desc, const MotionIn *mo
         const pt_sphere &p = desc->spheres[i];
         const float r = radii[i];
         const bool finite = std::isfinite(p.cx) && std::isfinite(p.cy) && std::isfinite(p.cz) && std::isfinite(r);
-        if (!finite || r > 16.0f * median || !(r > 0.0f)) {
+        // (radii below 1e-5 stay out of the tree as well: its packed nodes hold the pad constant 6e-6 / r_min as a power of two <= 1)
+        if (!finite || r > 16.0f * median || !(r > 1.0e-5f)) {
             large.push_back(i);
             continue;
         }

@@ -692,6 +692,8 @@ def _random_sphere_world(oracle, seed, n, W, H, spread, rmax, extras=()):
     #                      around the whole scene (camera inside), one far outside the f16 feature range, one tiny
     (25, 100, 4.0, 0.5, ([0, 0, 0, 0.0], [1, 1, 1, 1e-20])),             # r = 0 and r^2 underflowing to 0
     (26, 900, 12.0, 0.4, ()),                                            # > 768 spheres: list mode walks the internal tree
+    (27, 900, 12.0, 0.4, ([0.5, 0.5, 2.0, 1e-7], [0.2, 0.1, 3.0, 2e-5], [-1, 0.3, 2.5, -3e-6])),   # the same with spheres too small
+    #                      for the packed tree nodes' pad constant (kept out of the tree, tested for every ray)
 ])
 @pytest.mark.parametrize("bvh", [False, True])
 def test_random_sphere_worlds_match_the_oracle(ptgpu, oracle, seed, n, spread, rmax, extras, bvh):
