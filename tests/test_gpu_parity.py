@@ -704,6 +704,25 @@ def test_random_sphere_worlds_match_the_oracle(ptgpu, oracle, seed, n, spread, r
     assert np.array_equal(ref, out, equal_nan=True), _report(ref, out)
 
 
+@pytest.mark.parametrize("bvh", [False, True])
+def test_unpackable_tree_falls_back_to_the_binary_tree(ptgpu, oracle, bvh):
+    """A node whose pad constants do not fit the packed format (radii of 2e-5 inside a scene 2000 units wide: 6e-6 / r_min x
+    |extent|^2 is beyond 2^17) makes pt_scene_create report the packed tree unusable; the kernels then walk the binary tree
+    and the result is still the oracle's."""
+    W, H, S = 96, 64, 2
+    w = _random_sphere_world(oracle, 28, 900, W, H, 1000.0, 40.0, extras=([3.0, 2.0, 5.0, 2e-5], [-400.0, 100.0, 30.0, 3e-5]))
+    osc = oracle.OracleScene.from_world(w["hitables"], w["transforms"], w["materials"], w["textures"], w["camera"], W, H, sky=w["sky"], use_bvh=bvh)
+    ex = osc.export()
+    sc = ptgpu.Scene(oracle.to_ptgpu_world_desc(ptgpu, ex), 0)
+    nodes, usable = sc.debug_tree_packed()
+    assert len(nodes) > 0 and not usable
+    out = np.zeros((H, W, 3), np.float32)
+    rays = sc.update(ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0), ptgpu.PtCamera.from_floats(ex["camera"]), 0, out)
+    sc.close()
+    ref, ref_rays = osc.update(S, max_depth=10, frame_num=0)
+    assert rays == ref_rays and np.array_equal(ref, out, equal_nan=True), _report(ref, out)
+
+
 @pytest.mark.parametrize("n,bvh", [(120, False), (120, True), (500, False)])
 def test_sphere_world_with_a_nested_checker_leaves_the_palette_kernels(ptgpu, oracle, n, bvh):
     """The wide MFMA kernels keep 16-bit palette codes on the attenuation stack, which needs every texture to be a Constant
