@@ -154,7 +154,8 @@ struct KArgs {
 // ---- perlin.rs:54-111 -------------------------------------------------------
 struct PerlinLds {
     const float4 *vec;       // 256 x float4
-    const uint32_t *perm;    // 768
+    const uint8_t *perm;     // 768 BYTES: perm_x | perm_y | perm_z (a 256-byte table spans each LDS bank exactly once, so two
+                             // lanes on one bank read the same word: the gathers have no bank conflicts)
     bool prefetch;           // fetch the eight gradients of an octave before its arithmetic (32 more live registers: kernels
                              // compiled for 128 VGPRs spill with it, the general-world kernel gains 10 % from it)
 };
@@ -1300,8 +1301,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     float4 *s_sph = reinterpret_cast<float4 *>(smem);  // list mode: n_spheres x (cx,cy,cz,r^2)
     unsigned char *p = smem + A.lds_sphere_bytes;
     float4 *s_pvec = reinterpret_cast<float4 *>(p);     // perlin gradients (4 KB) when has_noise
-    uint32_t *s_perm = reinterpret_cast<uint32_t *>(p + (A.has_noise ? 4096 : 0));
-    p += A.has_noise ? (4096 + 3072) : 0;
+    uint8_t *s_perm = p + (A.has_noise ? 4096 : 0);
+    p += A.has_noise ? (4096 + 768) : 0;
     uint32_t *s_bvh = reinterpret_cast<uint32_t *>(p);
     p += BVH ? (A.bvh_stack_entries * BLK * (TREE4 ? 2 : 4)) : 0;   // (4-wide tree: 16-bit entries, an even number of them)
     DWideNode *s_nodes = reinterpret_cast<DWideNode *>(p);
@@ -1372,7 +1373,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += BLK) s_pvec[k] = A.perlin_vec[k];
-        for (int k = tid; k < 768; k += BLK) s_perm[k] = A.perlin_perm[k];
+        for (int k = tid; k < 768; k += BLK) s_perm[k] = (uint8_t)A.perlin_perm[k];
     }
     __syncthreads();
 

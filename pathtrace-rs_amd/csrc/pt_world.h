@@ -280,8 +280,8 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *p = smem;
     float4 *s_pvec = reinterpret_cast<float4 *>(p);
-    uint32_t *s_perm = reinterpret_cast<uint32_t *>(p + (A.has_noise ? 4096 : 0));
-    p += A.has_noise ? (4096 + 3072) : 0;
+    uint8_t *s_perm = p + (A.has_noise ? 4096 : 0);
+    p += A.has_noise ? (4096 + 768) : 0;
     int32_t *s_stack = reinterpret_cast<int32_t *>(p);
     p += BVH ? (A.bvh_stack_entries * kBlock * 4) : 0;
     const pt_hitable *s_hit = reinterpret_cast<const pt_hitable *>(p);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
     }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += kBlock) s_pvec[k] = A.perlin_vec[k];
-        for (int k = tid; k < 768; k += kBlock) s_perm[k] = A.perlin_perm[k];
+        for (int k = tid; k < 768; k += kBlock) s_perm[k] = (uint8_t)A.perlin_perm[k];
     }
     __syncthreads();
     PerlinLds pn{s_pvec, s_perm, OCC < 4};

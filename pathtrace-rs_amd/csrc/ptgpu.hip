@@ -1389,7 +1389,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
         HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
         if (W.n_items == 0) return PT_OK;
-        uint32_t lds = s->has_noise ? (4096u + 3072u) : 0u;
+        uint32_t lds = s->has_noise ? (4096u + 768u) : 0u;
         if (ref_bvh) lds += W.bvh_stack_entries * kBlock * 4u;
         W.n_xf = s->n_world_xf;
         const bool hit_lds = s->n_hitables * 64u + s->n_world_xf * 96u <= 40960u;   // records + transforms staged in LDS
@@ -1515,7 +1515,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.verify = ((s->variant & 8u) ? 1u : 0u) | ((s->variant & 16u) ? 2u : 0u);  // bit 16: timing experiment, no stack
     A.debug = s->d_debug;
     uint32_t lds = sph_bytes + kLdsParamBytes;
-    if (s->has_noise) lds += 4096u + 3072u;
+    if (s->has_noise) lds += 4096u + 768u;
     A.ready_min = (uint32_t)kReadyMin, A.drain_at = (uint32_t)(kLeafQ - 4);
     if (const char *e = getenv("PTGPU_READY")) A.ready_min = (uint32_t)atoi(e);          // (development knobs)
     if (const char *e = getenv("PTGPU_DRAIN")) A.drain_at = std::min<uint32_t>((uint32_t)atoi(e), (uint32_t)(kLeafQ - 4));
