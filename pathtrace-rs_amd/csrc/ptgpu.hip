@@ -38,6 +38,26 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// Development knobs (environment), read ONCE per process: the launch path does not call getenv.
+struct DevKnobs {
+    int refill = -1, ready = -1, drain = -1, pilot_div = -1;
+    bool world_occ3 = false, debug = false, clamp_grid = false;
+};
+const DevKnobs &dev_knobs() {
+    static const DevKnobs k = [] {
+        DevKnobs d;
+        if (const char *e = getenv("PTGPU_REFILL")) d.refill = atoi(e);
+        if (const char *e = getenv("PTGPU_READY")) d.ready = atoi(e);
+        if (const char *e = getenv("PTGPU_DRAIN")) d.drain = atoi(e);
+        if (const char *e = getenv("PTGPU_PILOT_DIV")) d.pilot_div = std::max(1, atoi(e));
+        d.world_occ3 = getenv("PTGPU_WORLD_OCC3") != nullptr;
+        d.debug = getenv("PTGPU_DEBUG") != nullptr;
+        d.clamp_grid = getenv("PTGPU_CLAMP_GRID") != nullptr;
+        return d;
+    }();
+    return k;
+}
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -1307,7 +1327,7 @@ void fill_frame_args(Args &X, const pt_scene *s, const pt_params *params, const 
     X.random_seed = params->random_seed;
     // refills are batched: measured best at 4 waiting lanes for long pixels, 8 when pixels are short (< 32 spp)
     X.refill_min = params->samples < 32u ? 8u : 4u;
-    if (const char *e = getenv("PTGPU_REFILL")) X.refill_min = (uint32_t)atoi(e);   // (development knob)
+    if (dev_knobs().refill >= 0) X.refill_min = (uint32_t)dev_knobs().refill;   // (development knob PTGPU_REFILL)
     X.seed_base = s->seed_base;
     X.shard_index = shard_index;
     X.shard_count = shard_count;
@@ -1398,7 +1418,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         const uint64_t path_bytes = (uint64_t)params->max_depth * 3ull * kBlock * 4ull;
         W.stack_in_lds = (lds + path_bytes <= 60u * 1024u) ? 1u : 0u;
         if (W.stack_in_lds) lds += (uint32_t)path_bytes;
-        const bool occ4 = !s->has_noise && !s->has_image && s->blocks_per_cu == 0 && 4u * lds <= kLdsBudget && !getenv("PTGPU_WORLD_OCC3");   // see pt_world_kernel's OCC
+        const bool occ4 = !s->has_noise && !s->has_image && s->blocks_per_cu == 0 && 4u * lds <= kLdsBudget && !dev_knobs().world_occ3;   // see pt_world_kernel's OCC
         // one instantiation per (traversal, records in LDS, waves per SIMD, world has media); worlds whose records do not
         // fit LDS (more than ~600 hitables) share the MEDIA = true code
         const bool media = s->has_media || !hit_lds || s->has_motion;
@@ -1517,8 +1537,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     uint32_t lds = sph_bytes + kLdsParamBytes;
     if (s->has_noise) lds += 4096u + 768u;
     A.ready_min = (uint32_t)kReadyMin, A.drain_at = (uint32_t)(kLeafQ - 4);
-    if (const char *e = getenv("PTGPU_READY")) A.ready_min = (uint32_t)atoi(e);          // (development knobs)
-    if (const char *e = getenv("PTGPU_DRAIN")) A.drain_at = std::min<uint32_t>((uint32_t)atoi(e), (uint32_t)(kLeafQ - 4));
+    if (dev_knobs().ready >= 0) A.ready_min = (uint32_t)dev_knobs().ready;          // (development knobs PTGPU_READY / PTGPU_DRAIN)
+    if (dev_knobs().drain >= 0) A.drain_at = std::min<uint32_t>((uint32_t)dev_knobs().drain, (uint32_t)(kLeafQ - 4));
     // 4-wide tree (default; variant bit 2048: the binary tree): a visit pushes at most three siblings per level
     // (its stack entries are 16-bit node indices; a bigger tree -- more than ~190 000 spheres -- walks the binary one)
     const bool tree4 = bvh && (s->variant & 2048u) == 0 && s->n_nodes4 < 65536u && s->word_ok && s->tree4_packed;
@@ -1578,7 +1598,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         lds_levels = stack_levels;
     }
     A.stack_in_lds = lds_levels * slots;
-    if (getenv("PTGPU_DEBUG")) fprintf(stderr, "[ptgpu launch] bvh %d tree4 %d mfma %d blk %u slots %u stack_levels %u lds_levels %u lds %u\n", (int)bvh, (int)tree4, (int)mfma, blk, slots, stack_levels, lds_levels, lds);
+    if (dev_knobs().debug) fprintf(stderr, "[ptgpu launch] bvh %d tree4 %d mfma %d blk %u slots %u stack_levels %u lds_levels %u lds %u\n", (int)bvh, (int)tree4, (int)mfma, blk, slots, stack_levels, lds_levels, lds);
     lds += lds_levels * slots * blk * 4u;
     if (blk == kWideBlock || blk == 1024u) lds += (uint32_t)wide_extra(blk);
     A.lds_sphere_bytes = sph_bytes;
@@ -1627,7 +1647,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     // ---- persistent grid: CUs x resident blocks --------------------------------
     uint32_t bpc = s->blocks_per_cu;
     // 16-wave workgroups batch their refills harder (measured on configs 3 / 4 and `random`: 12 waiting lanes +1.5 % over 4)
-    if (blk == 1024u && params->samples >= 32u && !getenv("PTGPU_REFILL")) A.refill_min = 12u;
+    if (blk == 1024u && params->samples >= 32u && dev_knobs().refill < 0) A.refill_min = 12u;
     if (bpc == 0) bpc = (blk == kWideBlock || blk == 1024u) ? 1u : (bvh ? 4u : 3u);
     const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
     if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
@@ -1638,7 +1658,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     // work should be spread over ALL CUs -- two waves on a SIMD iterate faster than four -- so a one-workgroup-per-CU grid is
     // not cut down to the workgroups the pixels would fill (a wave that finds the queue empty leaves at once).
     const uint32_t need = (A.n_items + blk - 1) / blk;
-    if (grid > need && !((blk == kWideBlock || blk == 1024u) && need * 4u >= grid && !getenv("PTGPU_CLAMP_GRID"))) grid = need;
+    if (grid > need && !((blk == kWideBlock || blk == 1024u) && need * 4u >= grid && !dev_knobs().clamp_grid)) grid = need;
     if (grid == 0) grid = 1;
 
     if (blk == kBlock && lds_levels < stack_levels) {
@@ -1690,7 +1710,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         P.wave_end = nullptr;
         // a third of the frame's grid: the pilot has ~100x less work, and each workgroup stages the scene into LDS
         uint32_t pilot_div = 3u;
-        if (const char *e = getenv("PTGPU_PILOT_DIV")) pilot_div = std::max(1, atoi(e));   // (development knob)
+        if (dev_knobs().pilot_div > 0) pilot_div = (uint32_t)dev_knobs().pilot_div;   // (development knob PTGPU_PILOT_DIV)
         hipLaunchKernelGGL(pilot_kern, dim3((grid + pilot_div - 1u) / pilot_div), dim3(blk), lds, stream, P);
         hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, params->max_depth + 1u, order);
         HIP_TRY(hipGetLastError());
