@@ -145,7 +145,8 @@ struct KArgs {
     unsigned long long *ray_count;
     uint32_t *work_counter;
     const uint32_t *tile_order;  // optional permutation of the 8x8 work tiles (expensive tiles first)
-    uint32_t *tile_cost;         // optional: rays spent per work tile (accumulated when a pixel completes)
+    uint32_t *tile_cost;         // optional: rays spent per work tile (accumulated when a pixel completes): the pilot pass' result,
+                                 // or what a frame kernel measures for the next frame of the same view
     float *gstack;  // global path-stack fallback when max_depth*3*kBlock*4 exceeds the LDS budget
     uint32_t stack_in_lds;       // 256-thread kernels: number of attenuation-stack slots (3 per level; 1 on the 4-wide tree kernels, WST below) kept in LDS; the rest in gstack
     uint32_t lds_sphere_bytes;  // offsets of the dynamic LDS carve
@@ -1458,7 +1459,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     out[1] = out[1] * pf.y + col.y * pf.z;
                     out[2] = out[2] * pf.y + col.z * pf.z;
                 }
-                if (PILOT) atomicAdd(&A.tile_cost[lane_tile], pix_rays);
+                if (PILOT || A.tile_cost) atomicAdd(&A.tile_cost[lane_tile], pix_rays);   // (frame kernels: the NEXT frame's work order)
             }
             const unsigned long long m = __ballot(1);
             const int leader = __ffsll((long long)m) - 1;

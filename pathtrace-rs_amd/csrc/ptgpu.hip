@@ -130,7 +130,15 @@ struct pt_scene {
     uint32_t cull_axis = 3, cull_always = 0;
     float cull_u0 = 0.f, cull_inv_cell = 0.f, cull_rmin = 0.f, cull_rmax = 0.f, cull_cell = 0.f, rs_small = 0.f, clip_min[3] = {0, 0, 0}, clip_max[3] = {0, 0, 0};
     unsigned long long *d_debug = nullptr;    // 4 u64 counters (verify mode)
-    uint32_t *d_tile_buf = nullptr;           // [8 scratch words | n tile costs | n tile order]
+    uint32_t *d_tile_buf = nullptr;           // [8 scratch words | n tile costs | n tile order | n tile costs measured by the last frame]
+    // Work order of the NEXT frame of the same view: the rays each tile really took in the last frame (same scene, camera,
+    // size, samples, depth, shard). Only the order of the work depends on it, never a pixel.
+    struct ViewKey {
+        pt_params params;
+        pt_camera cam;
+        uint32_t shard_index, shard_count, variant, n_tiles;
+    } hint_key{};
+    bool hint_valid = false;
     float *d_pilot_rgb = nullptr;             // never-read frame buffer of the pilot pass
     size_t d_tile_cap = 0;
     uint32_t *d_work_counter = nullptr;       // 1 u32
@@ -1692,11 +1700,20 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
             s->d_tile_buf = nullptr;
             s->d_pilot_rgb = nullptr;
             s->d_tile_cap = 0;
-            HIP_TRY(hipMalloc((void **)&s->d_tile_buf, (8 + 2 * (size_t)n_work_tiles) * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void **)&s->d_tile_buf, (8 + 3 * (size_t)n_work_tiles) * sizeof(uint32_t)));
+            s->hint_valid = false;
             HIP_TRY(hipMalloc((void **)&s->d_pilot_rgb, px_floats * sizeof(float)));
             s->d_tile_cap = n_work_tiles;
         }
-        uint32_t *scratch = s->d_tile_buf, *cost = s->d_tile_buf + 8, *order = cost + s->d_tile_cap;
+        uint32_t *scratch = s->d_tile_buf, *cost = s->d_tile_buf + 8, *order = cost + s->d_tile_cap, *measured = order + s->d_tile_cap;
+        pt_scene::ViewKey key{};
+        key.params = *params, key.cam = *cam, key.shard_index = shard_index, key.shard_count = shard_count, key.variant = s->variant, key.n_tiles = n_work_tiles;
+        const bool reuse = s->hint_valid && (s->variant & 8192u) == 0 && memcmp(&key, &s->hint_key, sizeof key) == 0;
+        if (reuse) {
+            // the last frame of this view measured every tile: order by that (64 buckets over samples x (depth + 1) x 64 pixels)
+            hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, measured, params->samples * (params->max_depth + 1u), order);
+            HIP_TRY(hipGetLastError());
+        } else {
         HIP_TRY(hipMemsetAsync(scratch, 0, (8 + (size_t)s->d_tile_cap) * sizeof(uint32_t), stream));
         KArgs P = A;
         P.samples = 1;
@@ -1714,8 +1731,14 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         hipLaunchKernelGGL(pilot_kern, dim3((grid + pilot_div - 1u) / pilot_div), dim3(blk), lds, stream, P);
         hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, params->max_depth + 1u, order);
         HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
         A.tile_order = order;
+        if ((s->variant & 8192u) == 0) {   // this frame measures the tiles for the next one (after the order kernel has read the old values)
+            HIP_TRY(hipMemsetAsync(measured, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
+            A.tile_cost = measured;
+            s->hint_key = key, s->hint_valid = true;
+        }
     }
 
     HIP_TRY(hipEventRecord(s->ev_start, stream));

@@ -222,6 +222,33 @@ def test_progressive_frames_blend_like_scene_update(ptgpu, oracle):
     sc.close()
 
 
+@pytest.mark.parametrize("preset,bvh", [("random_spheres", False), ("random_spheres", True), ("perlin_spheres", True)])
+def test_work_order_from_the_previous_frame_never_changes_a_pixel(ptgpu, pthost, preset, bvh):
+    """A frame of the view the scene rendered last is ordered by the rays each tile took in that frame (measured by the frame
+    kernel) instead of by a 1-spp pilot pass. The order of the work must not change a pixel or the ray count: progressive
+    frames 0..3 (a camera change in between) equal the run that pilots every frame (variant 8192) and the run with no
+    ordering at all (variant 32)."""
+    W, H, S = 512, 320, 16          # 2 560 work tiles, 16 spp: large enough for the ordering to be used
+    runs = {}
+    for name, variant in (("reuse", 0), ("pilot", 8192), ("unordered", 32)):
+        hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=bvh, device=0)
+        sc = hs.device_scene()
+        sc.set_tuning(0, variant)
+        p = ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0)
+        camf = np.ctypeslib.as_array(C.cast(C.pointer(hs.camera), C.POINTER(C.c_float)), shape=(24,)).copy()
+        camf[0] += np.float32(0.25)                        # origin.x
+        other = ptgpu.PtCamera.from_floats(camf)
+        out, side, rays = np.zeros((H, W, 3), np.float32), np.zeros((H, W, 3), np.float32), []
+        for frame in range(4):
+            rays.append(sc.update(p, hs.camera, frame, out))
+            if frame == 1:
+                rays.append(sc.update(p, other, 0, side))    # another view in between: its key differs, the pilot runs
+        runs[name] = (out, side, rays)
+    for name in ("pilot", "unordered"):
+        assert runs["reuse"][2] == runs[name][2], (runs["reuse"][2], runs[name][2])
+        assert np.array_equal(runs["reuse"][0], runs[name][0]) and np.array_equal(runs["reuse"][1], runs[name][1])
+
+
 # ---- golden fixtures: HIP vs committed oracle output at BASELINE sizes (no oracle call needed) ------
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))))
 @pytest.mark.parametrize("mode", ["as_recorded", "other_world"])
