@@ -168,8 +168,8 @@ def roofline_block(kernel_name, kms, rays_launch, n_hitables, use_bvh, counters)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--preset", default="random_spheres")
     ap.add_argument("--width", type=int, default=1200)
     ap.add_argument("--height", type=int, default=800)
@@ -403,10 +403,10 @@ def main():
         scene.set_tuning(0, base_variant | 8192)
         assert torch.equal(pbuf["reuse"], pbuf["pilot"]) and res["reuse"][0] == res["pilot"][0], "work order changed a pixel"
         progressive = {"value": res["reuse"][0] / 1e6 / res["reuse"][1], "unit": "Mrays/s", "ms_per_frame": res["reuse"][1] / kf * 1e3,
-                       "frames": kf, "with_a_pilot_pass_every_frame": res["pilot"][0] / 1e6 / res["pilot"][1],
+                       "frames": kf, "measuring_every_frame_anew": res["pilot"][0] / 1e6 / res["pilot"][1],
                        "note": "Scene::update(frame_num = 1..%d) of one view accumulating into one buffer (the preview-window loop); "
-                               "work ordered by the previous frame's measured rays per tile instead of a 1-spp pilot pass; "
-                               "accumulated image bit-identical to the run that pilots every frame" % kf}
+                               "work ordered by the previous frame's measured rays per tile instead of a measuring launch of its own; "
+                               "accumulated image bit-identical to the run that measures every frame anew" % kf}
     if not multi and not args.no_extras:
         # Extra, never `value`: the reference's own contract -- Scene::update on a HOST buffer (offline.rs:27-34 times
         # exactly this call): pt_render = H2D of the previous frame + kernels + D2H, PCIe inclusive.

@@ -133,6 +133,11 @@ struct KArgs {
     uint32_t width, height, samples, max_depth, frame_num;
     float inv_nx, inv_ny, inv_ns, mix_prev, mix_new;  // scene.rs:82-87 (computed on the host in f32)
     uint32_t random_seed;
+    // A frame in two launches (phase 1: the first samples of every pixel, in natural order, MEASURING the tiles; phase 2: the
+    // rest, ordered by those costs). A pixel's samples are one serial RNG stream: phase 1 parks (xoshiro state, colour sum) in
+    // px_state (12 dwords per pixel) where phase 2 picks them up; 0 = the whole frame in one launch.
+    uint32_t phase;
+    uint4 *px_state;
     uint32_t refill_min;         // lanes that must be waiting before a wave fetches new pixels (4; 8 below 32 spp)
     uint32_t ready_min;          // 4-wide tree: lanes with a finished traversal before the wave leaves the traversal loop to shade
     uint32_t drain_at;           // 4-wide tree: a lane holding more than this many leaf candidates triggers the wave's drain
@@ -1271,7 +1276,9 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
 
 // SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
 // (staged once per workgroup); otherwise from HBM/L2 through wave-uniform loads.
-// PILOT: the 1-spp cost-estimation pass (own symbol so profiles keep it apart from the frame kernel)
+// PILOT: the measuring launch that precedes the frame kernel (own symbol so profiles keep the two apart). A.phase == 1: the
+// FIRST sample of every pixel, for real -- it parks each pixel's RNG stream and colour sum for the frame kernel (A.phase == 2)
+// and counts the rays per tile; A.phase == 0: the throw-away 1-spp pass over a quarter of the pixels (frames below 32 spp).
 // MOVING: the world also holds MovingSphere entries (moving_sphere.rs): rays keep their time (camera.rs:59) and
 // every exact sphere test / normal uses the centre at that time; prefilter fragments and internal-tree boxes
 // were built over the motion's whole sweep.
@@ -1452,6 +1459,12 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 // scene.rs:113-116
                 finished = false;
                 const float4 pf = s_par[10];   // inv_ns, mix_prev, mix_new
+                if (PILOT && A.phase == 1u) {   // to be continued: park the stream and the sum
+                    uint4 *st = A.px_state + 3u * (size_t)((pxy >> 16) * A.width + (pxy & 0xffffu));
+                    st[0] = make_uint4((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
+                    st[1] = make_uint4((uint32_t)rng.s2, (uint32_t)(rng.s2 >> 32), (uint32_t)rng.s3, (uint32_t)(rng.s3 >> 32));
+                    st[2] = make_uint4(__float_as_uint(col.x), __float_as_uint(col.y), __float_as_uint(col.z), 0u);
+                }
                 col = scale3(col, pf.x);
                 if (!PILOT) {
                     float *out = A.rgb + ((pxy >> 16) * A.width + (pxy & 0xffffu)) * 3u;
@@ -1481,7 +1494,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 const uint32_t ly = (tile / A.tiles_x) * kTileSide + (in >> kTileLog2);
                 // (the list kernels' cost-estimation pilot samples one pixel per 2x2 block: a quarter of the rays orders
                 //  the tiles as well as all of them did and costs 0.2 ms less; the tree kernels keep every pixel, measured)
-                if (x < A.width && ly < A.local_rows && !(PILOT && !BVH && ((x | ly) & 1u))) {
+                if (x < A.width && ly < A.local_rows && !(PILOT && A.phase == 0u && !BVH && ((x | ly) & 1u))) {
                     have = true;
                     pxy = x | (ly << 16);
 #ifdef PT_WAVE_DETAIL
@@ -1490,14 +1503,22 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     sd = 0;
                     const uint32_t px = x, py = ly * A.shard_count + A.shard_index;
                     need_cam = true;
-                    col = mk3(0.f, 0.f, 0.f);
-                    // scene.rs:96-102
-                    uint64_t seed = ((uint64_t)px * 1973ull + (uint64_t)py * 9277ull + (uint64_t)A.frame_num * 26699ull) | 1ull;
-                    if (A.random_seed) {
-                        uint64_t h = A.seed_base ^ (seed * 0x9e3779b97f4a7c15ULL);
-                        seed = splitmix64_next(h);
+                    if (!PILOT && A.phase == 2u) {   // continue the stream and the sum phase 1 parked
+                        const uint4 *st = A.px_state + 3u * (size_t)(ly * A.width + x);
+                        const uint4 a = st[0], b = st[1], c = st[2];
+                        rng.s0 = (uint64_t)a.x | ((uint64_t)a.y << 32), rng.s1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+                        rng.s2 = (uint64_t)b.x | ((uint64_t)b.y << 32), rng.s3 = (uint64_t)b.z | ((uint64_t)b.w << 32);
+                        col = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+                    } else {
+                        col = mk3(0.f, 0.f, 0.f);
+                        // scene.rs:96-102
+                        uint64_t seed = ((uint64_t)px * 1973ull + (uint64_t)py * 9277ull + (uint64_t)A.frame_num * 26699ull) | 1ull;
+                        if (A.random_seed) {
+                            uint64_t h = A.seed_base ^ (seed * 0x9e3779b97f4a7c15ULL);
+                            seed = splitmix64_next(h);
+                        }
+                        rng_seed_from_u64(rng, seed);
                     }
-                    rng_seed_from_u64(rng, seed);
                 }
             }
         }

@@ -65,6 +65,8 @@ const DevKnobs &dev_knobs() {
     } while (0)
 
 constexpr uint32_t kLdsBudget = 160u * 1024u;       // LDS per CU on gfx950
+constexpr uint32_t kTwoLaunchMinSamples = 32u;     // frames of a new view with at least this many samples measure their tiles with their own first sample
+constexpr uint32_t kPhase1Samples = 1u;            // two-launch frames: samples of the first, measuring launch
 constexpr uint32_t kPilotMinSamples = 16u;          // heavy-first tile ordering pays from 16 spp on (measured: +10 % at 16, -1 % at 8)
 constexpr uint32_t kWideBlock = 768u;              // MFMA list kernels: one workgroup of 12 waves per CU (see launch())
 constexpr uint32_t kLdsPerBlockMax = 96u * 1024u;   // leave room for >= 1 co-resident block's statics
@@ -139,6 +141,9 @@ struct pt_scene {
         uint32_t shard_index, shard_count, variant, n_tiles;
     } hint_key{};
     bool hint_valid = false;
+    uint32_t hint_scale = 1;                  // bucket width of the measured costs (samples the measuring launch traced x (depth + 1))
+    uint4 *d_px_state = nullptr;              // two-launch frames: parked (xoshiro state, colour sum) per pixel, 48 B each
+    size_t d_px_state_pixels = 0;
     float *d_pilot_rgb = nullptr;             // never-read frame buffer of the pilot pass
     size_t d_tile_cap = 0;
     uint32_t *d_work_counter = nullptr;       // 1 u32
@@ -1251,6 +1256,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_large);
     (void)hipFree(s->d_debug);
     (void)hipFree(s->d_tile_buf);
+    (void)hipFree(s->d_px_state);
     (void)hipFree(s->d_pilot_rgb);
     (void)hipFree(s->d_work_counter);
     (void)hipFree(s->d_ray_count);
@@ -1709,10 +1715,36 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         pt_scene::ViewKey key{};
         key.params = *params, key.cam = *cam, key.shard_index = shard_index, key.shard_count = shard_count, key.variant = s->variant, key.n_tiles = n_work_tiles;
         const bool reuse = s->hint_valid && (s->variant & 8192u) == 0 && memcmp(&key, &s->hint_key, sizeof key) == 0;
+        // A frame of a view not seen before, 32 samples or more: TWO launches instead of a pilot pass. The first traces the first
+        // kPhase1Samples samples of every pixel in natural order and measures the tiles while doing so (real work, 64 pixels x 4
+        // samples per tile instead of the pilot's 16 x 1 throw-away ones), the second the rest, ordered by those costs; a pixel's
+        // RNG stream and colour sum wait in d_px_state in between. Variant bit 16384 keeps the pilot pass.
+        uint32_t phase1 = kPhase1Samples;
+        if (const char *e = getenv("PTGPU_PHASE1")) phase1 = (uint32_t)atoi(e);   // (development knob)
+        const bool two_phase = !reuse && (s->variant & 16384u) == 0 && phase1 > 0 && params->samples >= kTwoLaunchMinSamples && params->samples > phase1 && (A.verify & 1u) == 0;
+        uint32_t measured_scale = params->samples * (params->max_depth + 1u);
         if (reuse) {
             // the last frame of this view measured every tile: order by that (64 buckets over samples x (depth + 1) x 64 pixels)
-            hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, measured, params->samples * (params->max_depth + 1u), order);
+            hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, measured, s->hint_scale, order);
             HIP_TRY(hipGetLastError());
+        } else if (two_phase) {
+            const size_t pixels = (size_t)A.width * A.local_rows;
+            if (pixels > s->d_px_state_pixels) {
+                (void)hipFree(s->d_px_state);
+                s->d_px_state = nullptr, s->d_px_state_pixels = 0;
+                HIP_TRY(hipMalloc((void **)&s->d_px_state, pixels * 48u));
+                s->d_px_state_pixels = pixels;
+            }
+            HIP_TRY(hipMemsetAsync(cost, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
+            KArgs A1 = A;
+            A1.samples = phase1, A1.phase = 1, A1.px_state = s->d_px_state, A1.tile_cost = cost, A1.wave_end = nullptr;
+            A1.refill_min = 48u;   // one sample per pixel: refills dominate, batch them hard (a plain 1-spp frame: 0.48 ms at 8, 0.34 at 32; frame: best at 48)
+            if (const char *e = getenv("PTGPU_PHASE1_REFILL")) A1.refill_min = (uint32_t)atoi(e);   // (development knob)
+            hipLaunchKernelGGL(pilot_kern, dim3(grid), dim3(blk), lds, stream, A1);
+            hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, phase1 * (params->max_depth + 1u), order);
+            HIP_TRY(hipGetLastError());
+            A.samples = params->samples - phase1, A.phase = 2, A.px_state = s->d_px_state;
+            measured_scale = A.samples * (params->max_depth + 1u);
         } else {
         HIP_TRY(hipMemsetAsync(scratch, 0, (8 + (size_t)s->d_tile_cap) * sizeof(uint32_t), stream));
         KArgs P = A;
@@ -1737,7 +1769,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         if ((s->variant & 8192u) == 0) {   // this frame measures the tiles for the next one (after the order kernel has read the old values)
             HIP_TRY(hipMemsetAsync(measured, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
             A.tile_cost = measured;
-            s->hint_key = key, s->hint_valid = true;
+            s->hint_key = key, s->hint_valid = true, s->hint_scale = measured_scale;
         }
     }
 
@@ -1864,9 +1896,10 @@ extern "C" int pt_scene_prepare(pt_scene *s, const pt_params *params) {
     if (int rc = ensure_frame_buffers(s, (size_t)params->width * params->height * 3u)) return rc;
     if (params->use_bvh && s->bvh_root < 0) return PT_OK;   // (pt_render will report the missing tree)
     // one throw-away frame with the caller's geometry of launch (samples only scale the work, except that the
-    // heavy-first pilot pass needs kPilotMinSamples of them to be scheduled at all): allocates every lazily sized buffer
+    // heavy-first pilot pass needs kPilotMinSamples of them to be scheduled at all, the two-launch frame kTwoLaunchMinSamples):
+    // allocates every lazily sized buffer
     pt_params p = *params;
-    p.samples = params->samples >= kPilotMinSamples ? kPilotMinSamples : 1u;
+    p.samples = params->samples >= kTwoLaunchMinSamples ? kTwoLaunchMinSamples : (params->samples >= kPilotMinSamples ? kPilotMinSamples : 1u);
     p.max_depth = params->max_depth;
     pt_camera cam;
     memset(&cam, 0, sizeof cam);

@@ -228,9 +228,10 @@ def test_work_order_from_the_previous_frame_never_changes_a_pixel(ptgpu, pthost,
     kernel) instead of by a 1-spp pilot pass. The order of the work must not change a pixel or the ray count: progressive
     frames 0..3 (a camera change in between) equal the run that pilots every frame (variant 8192) and the run with no
     ordering at all (variant 32)."""
-    W, H, S = 512, 320, 16          # 2 560 work tiles, 16 spp: large enough for the ordering to be used
+    W, H, S = 512, 320, 32          # 2 560 work tiles, 32 spp: large enough for every ordering scheme to be used
     runs = {}
-    for name, variant in (("reuse", 0), ("pilot", 8192), ("unordered", 32)):
+    # 8192: every frame measures its own order with its first sample (two launches); + 16384: with a throw-away pilot pass
+    for name, variant in (("reuse", 0), ("pilot", 8192), ("throwaway_pilot", 8192 | 16384), ("unordered", 32)):
         hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=bvh, device=0)
         sc = hs.device_scene()
         sc.set_tuning(0, variant)
@@ -244,7 +245,7 @@ def test_work_order_from_the_previous_frame_never_changes_a_pixel(ptgpu, pthost,
             if frame == 1:
                 rays.append(sc.update(p, other, 0, side))    # another view in between: its key differs, the pilot runs
         runs[name] = (out, side, rays)
-    for name in ("pilot", "unordered"):
+    for name in ("pilot", "throwaway_pilot", "unordered"):
         assert runs["reuse"][2] == runs[name][2], (runs["reuse"][2], runs[name][2])
         assert np.array_equal(runs["reuse"][0], runs[name][0]) and np.array_equal(runs["reuse"][1], runs[name][1])
 

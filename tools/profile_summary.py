@@ -64,16 +64,20 @@ for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
     f = find(d + "/**/*counter_collection.csv")
     if not f:
         continue
+    rows = [r for r in csv.DictReader(open(f)) if is_frame_kernel(r["Kernel_Name"])]
+    # the first dispatch of the frame kernel is pt_scene_prepare's throw-away frame (reduced samples, dummy camera): not a bench frame
+    first = min((int(r["Dispatch_Id"]) for r in rows), default=None)
+    if len({r["Dispatch_Id"] for r in rows}) > 1:
+        rows = [r for r in rows if int(r["Dispatch_Id"]) != first]
     agg, disp = collections.defaultdict(float), set()
-    for r in csv.DictReader(open(f)):
-        if is_frame_kernel(r["Kernel_Name"]):
-            agg[r["Counter_Name"]] += float(r["Counter_Value"])
-            disp.add(r["Dispatch_Id"])
+    for r in rows:
+        agg[r["Counter_Name"]] += float(r["Counter_Value"])
+        disp.add(r["Dispatch_Id"])
     n = max(1, len(disp))
     for k, v in agg.items():
         pmc[k] = v / n
 lines.append("")
-lines.append("# PMC counters, per launch of pt_trace_kernel (separate --pmc passes)")
+lines.append("# PMC counters, per bench launch of the frame kernel (separate --pmc passes; pt_scene_prepare's dispatch excluded)")
 for k in sorted(pmc):
     lines.append("%-32s %.6g" % (k, pmc[k]))
 out = {"tag": tag, "kernel_avg_ms": avg_ms, "pmc_per_launch": pmc}
