@@ -48,6 +48,13 @@ struct WArgs {
     uint32_t *work_counter;
     float *gstack;
     uint32_t stack_in_lds;
+    // heavy-first work order, as in pt_trace_kernel (pt_kernel.h KArgs): 8x8 tiles in the order of `tile_order` (nullptr: natural),
+    // rays per tile accumulated into `tile_cost` when a pixel completes, and a frame in two launches -- phase 1 traces the
+    // first sample of every pixel and parks (xoshiro state, colour sum) in px_state, phase 2 continues from there; 0 = one launch
+    const uint32_t *tile_order;
+    uint32_t *tile_cost;
+    uint32_t phase;
+    uint4 *px_state;
 };
 
 struct WRay {  // ray.rs:4-9
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
     float *path = A.stack_in_lds ? (s_path + tid) : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * kBlock + tid);
 
     bool have = false, exhausted = false, need_cam = true;
-    uint32_t px = 0, py = 0, boff = 0, sample = 0, depth = 0, nrays = 0;
+    uint32_t pxy = 0, pix_start = 0, sample = 0, depth = 0, nrays = 0;   // pxy = x | local row << 16; pix_start = nrays when the pixel began
     Rng rng{0, 0, 0, 0};
     f3 col = mk3(0.f, 0.f, 0.f);
     WRay ray = w_ray_new(mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 1.f), 0.f);
@@ -335,23 +342,32 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
             if (item >= A.n_items) {
                 exhausted = true;
             } else {
-                const uint32_t in = item & (kTilePix - 1u), tile = item >> (2u * kTileLog2);
+                const uint32_t in = item & (kTilePix - 1u);
+                const uint32_t tile = A.tile_order ? A.tile_order[item >> (2u * kTileLog2)] : (item >> (2u * kTileLog2));
                 const uint32_t x = (tile % A.tiles_x) * kTileSide + (in & (kTileSide - 1u));
                 const uint32_t ly = (tile / A.tiles_x) * kTileSide + (in >> kTileLog2);
                 if (x < A.width && ly < A.local_rows) {
                     have = true;
-                    px = x;
-                    py = ly * A.shard_count + A.shard_index;
-                    boff = (ly * A.width + x) * 3u;
+                    pxy = x | (ly << 16);
+                    pix_start = nrays;
                     sample = 0;
                     need_cam = true;
-                    col = mk3(0.f, 0.f, 0.f);
-                    uint64_t seed = ((uint64_t)px * 1973ull + (uint64_t)py * 9277ull + (uint64_t)A.frame_num * 26699ull) | 1ull;  // scene.rs:99-101
-                    if (A.random_seed) {
-                        uint64_t hsh = A.seed_base ^ (seed * 0x9e3779b97f4a7c15ULL);
-                        seed = splitmix64_next(hsh);
+                    if (A.phase == 2u) {   // continue the stream and the sum phase 1 parked
+                        const uint4 *st = A.px_state + 3u * (size_t)(ly * A.width + x);
+                        const uint4 a = st[0], b = st[1], c = st[2];
+                        rng.s0 = (uint64_t)a.x | ((uint64_t)a.y << 32), rng.s1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+                        rng.s2 = (uint64_t)b.x | ((uint64_t)b.y << 32), rng.s3 = (uint64_t)b.z | ((uint64_t)b.w << 32);
+                        col = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
+                    } else {
+                        col = mk3(0.f, 0.f, 0.f);
+                        const uint32_t px = x, py = ly * A.shard_count + A.shard_index;
+                        uint64_t seed = ((uint64_t)px * 1973ull + (uint64_t)py * 9277ull + (uint64_t)A.frame_num * 26699ull) | 1ull;  // scene.rs:99-101
+                        if (A.random_seed) {
+                            uint64_t hsh = A.seed_base ^ (seed * 0x9e3779b97f4a7c15ULL);
+                            seed = splitmix64_next(hsh);
+                        }
+                        rng_seed_from_u64(rng, seed);
                     }
-                    rng_seed_from_u64(rng, seed);
                 }
             }
         }
@@ -363,6 +379,7 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
         if (have) {
             // ---- camera.rs:56-68 + scene.rs:107-108
             if (need_cam) {
+                const uint32_t px = pxy & 0xffffu, py = (pxy >> 16) * A.shard_count + A.shard_index;
                 const float u = ((float)px + rng_f32(rng)) * A.inv_nx;
                 const float v = ((float)py + rng_f32(rng)) * A.inv_ny;
                 float dx, dy;
@@ -514,11 +531,20 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
                 sample += 1;
                 need_cam = true;
                 if (sample == A.samples) {  // scene.rs:113-116
-                    col = scale3(col, A.inv_ns);
-                    float *out = A.rgb + boff;
-                    out[0] = out[0] * A.mix_prev + col.x * A.mix_new;
-                    out[1] = out[1] * A.mix_prev + col.y * A.mix_new;
-                    out[2] = out[2] * A.mix_prev + col.z * A.mix_new;
+                    const uint32_t x = pxy & 0xffffu, ly = pxy >> 16;
+                    if (A.phase == 1u) {   // to be continued by the second launch
+                        uint4 *st = A.px_state + 3u * (size_t)(ly * A.width + x);
+                        st[0] = make_uint4((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
+                        st[1] = make_uint4((uint32_t)rng.s2, (uint32_t)(rng.s2 >> 32), (uint32_t)rng.s3, (uint32_t)(rng.s3 >> 32));
+                        st[2] = make_uint4(__float_as_uint(col.x), __float_as_uint(col.y), __float_as_uint(col.z), 0u);
+                    } else {
+                        col = scale3(col, A.inv_ns);
+                        float *out = A.rgb + (ly * A.width + x) * 3u;
+                        out[0] = out[0] * A.mix_prev + col.x * A.mix_new;
+                        out[1] = out[1] * A.mix_prev + col.y * A.mix_new;
+                        out[2] = out[2] * A.mix_prev + col.z * A.mix_new;
+                    }
+                    if (A.tile_cost) atomicAdd(&A.tile_cost[(ly >> kTileLog2) * A.tiles_x + (x >> kTileLog2)], nrays - pix_start);
                     have = false;
                 }
             }

@@ -145,7 +145,6 @@ struct pt_scene {
     uint32_t hint_scale = 1;                  // bucket width of the measured costs (samples the measuring launch traced x (depth + 1))
     uint4 *d_px_state = nullptr;              // two-launch frames: parked (xoshiro state, colour sum) per pixel, 48 B each
     size_t d_px_state_pixels = 0;
-    float *d_pilot_rgb = nullptr;             // never-read frame buffer of the pilot pass
     size_t d_tile_cap = 0;
     uint32_t *d_work_counter = nullptr;       // 1 u32
     unsigned long long *d_ray_count = nullptr; // internal counter for pt_render
@@ -1258,7 +1257,6 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
     (void)hipFree(s->d_debug);
     (void)hipFree(s->d_tile_buf);
     (void)hipFree(s->d_px_state);
-    (void)hipFree(s->d_pilot_rgb);
     (void)hipFree(s->d_work_counter);
     (void)hipFree(s->d_ray_count);
     (void)hipFree(s->d_frame);
@@ -1464,6 +1462,49 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         }
         if (int rc = set_lds_limit(s, 0, reinterpret_cast<const void *>(wk), lds)) return rc;
         HIP_TRY(hipEventRecord(s->ev_pass, stream));
+        // heavy-first work order, as for the sphere kernels below: a repeated view is ordered by the
+        // rays its last frame measured per tile; a new view runs as two launches of this kernel, the first tracing the first
+        // sample of every pixel while it counts
+        const uint32_t n_world_tiles = W.n_items / kTilePix;
+        if (n_world_tiles >= 256u && params->samples >= kPilotMinSamples && (s->variant & (32u | 16384u)) == 0 && params->width < 65536u && params->height < 65536u) {
+            if (n_world_tiles > s->d_tile_cap) {
+                (void)hipFree(s->d_tile_buf);
+                s->d_tile_buf = nullptr, s->d_tile_cap = 0, s->hint_valid = false;
+                HIP_TRY(hipMalloc((void **)&s->d_tile_buf, (8 + 3 * (size_t)n_world_tiles) * sizeof(uint32_t)));
+                s->d_tile_cap = n_world_tiles;
+            }
+            uint32_t *cost = s->d_tile_buf + 8, *order = cost + s->d_tile_cap, *measured = order + s->d_tile_cap;
+            pt_scene::ViewKey key{};
+            key.params = *params, key.cam = *cam, key.shard_index = shard_index, key.shard_count = shard_count, key.variant = s->variant, key.n_tiles = n_world_tiles;
+            const bool reuse = s->hint_valid && (s->variant & 8192u) == 0 && memcmp(&key, &s->hint_key, sizeof key) == 0;
+            uint32_t measured_scale = params->samples * (params->max_depth + 1u);
+            if (reuse) {
+                hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_world_tiles, measured, s->hint_scale, order);
+            } else {
+                const size_t pixels = (size_t)W.width * W.local_rows;
+                if (pixels > s->d_px_state_pixels) {
+                    (void)hipFree(s->d_px_state);
+                    s->d_px_state = nullptr, s->d_px_state_pixels = 0;
+                    HIP_TRY(hipMalloc((void **)&s->d_px_state, pixels * 48u));
+                    s->d_px_state_pixels = pixels;
+                }
+                HIP_TRY(hipMemsetAsync(cost, 0, (size_t)n_world_tiles * sizeof(uint32_t), stream));
+                WArgs W1 = W;
+                W1.samples = 1, W1.phase = 1, W1.px_state = s->d_px_state, W1.tile_cost = cost, W1.refill_min = 48u;
+                hipLaunchKernelGGL(wk, dim3(grid), dim3(kBlock), lds, stream, W1);
+                hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_world_tiles, cost, params->max_depth + 1u, order);
+                W.samples = params->samples - 1u, W.phase = 2, W.px_state = s->d_px_state;
+                measured_scale = W.samples * (params->max_depth + 1u);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+            W.tile_order = order;
+            if ((s->variant & 8192u) == 0) {
+                HIP_TRY(hipMemsetAsync(measured, 0, (size_t)n_world_tiles * sizeof(uint32_t), stream));
+                W.tile_cost = measured;
+                s->hint_key = key, s->hint_valid = true, s->hint_scale = measured_scale;
+            }
+        }
         HIP_TRY(hipEventRecord(s->ev_start, stream));
         hipLaunchKernelGGL(wk, dim3(grid), dim3(kBlock), lds, stream, W);
         HIP_TRY(hipGetLastError());
@@ -1700,16 +1741,12 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     // ---- heavy-first work order from a 1-spp pilot pass (variant bit 32 disables it) -------------------
     const uint32_t n_work_tiles = A.n_items / kTilePix;
     if (pilot_kern && n_work_tiles >= 256u && params->samples >= kPilotMinSamples && (s->variant & 32u) == 0) {  // the pilot costs ~0.3 ms
-        const size_t px_floats = (size_t)n_work_tiles * kTilePix * 3u;
         if (n_work_tiles > s->d_tile_cap) {
             (void)hipFree(s->d_tile_buf);
-            (void)hipFree(s->d_pilot_rgb);
             s->d_tile_buf = nullptr;
-            s->d_pilot_rgb = nullptr;
             s->d_tile_cap = 0;
             HIP_TRY(hipMalloc((void **)&s->d_tile_buf, (8 + 3 * (size_t)n_work_tiles) * sizeof(uint32_t)));
             s->hint_valid = false;
-            HIP_TRY(hipMalloc((void **)&s->d_pilot_rgb, px_floats * sizeof(float)));
             s->d_tile_cap = n_work_tiles;
         }
         uint32_t *scratch = s->d_tile_buf, *cost = s->d_tile_buf + 8, *order = cost + s->d_tile_cap, *measured = order + s->d_tile_cap;
@@ -1753,7 +1790,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         P.inv_ns = 1.0f;
         P.random_seed = 1;                       // throw-away seeds: the pilot must not look like frame data
         P.seed_base = 0x9e3779b97f4a7c15ull ^ frame_num;
-        P.rgb = s->d_pilot_rgb;
+        // (P.rgb stays the frame: PILOT kernels never write pixels)
         P.tile_cost = cost;
         P.ray_count = reinterpret_cast<unsigned long long *>(scratch);      // scratch[0..1]
         P.verify = 0;
