@@ -29,6 +29,24 @@ def find(pattern):
     return hits[0] if hits else None
 
 
+# bench frames under the profiler (steps + warm-up) -- the frame kernel is dispatched once per frame, or TWICE for general
+# worlds (their two launches of a new view share one symbol), plus pt_scene_prepare's throw-away frame before them
+n_frames = None
+_bl = os.path.join(src, "bench_line.json")
+if os.path.exists(_bl) and os.path.getsize(_bl):
+    _l = json.load(open(_bl))
+    n_frames = int(_l.get("steps", 0)) + int(_l.get("warmup", 0))
+
+
+def bench_groups(items):
+    """items: the frame kernel's dispatches in order. Returns them grouped per bench frame (prepare's dispatches dropped)."""
+    if not n_frames or len(items) < n_frames:
+        return [[x] for x in items[1:]] if len(items) > 1 else [[x] for x in items]
+    k = max(1, len(items) // (n_frames + 1)) if len(items) > n_frames else 1
+    tail = items[len(items) - n_frames * k:]
+    return [tail[i * k:(i + 1) * k] for i in range(n_frames)]
+
+
 # 1. kernel stats
 ks = find("stats/**/*kernel_stats.csv")
 kt = find("stats/**/*kernel_trace.csv")
@@ -45,11 +63,12 @@ if kt:
             if is_frame_kernel(r["Kernel_Name"])]
     lines.append("pt_trace_kernel dispatch durations (ms): " + ", ".join("%.3f" % d for d in durs))
     if len(durs) > 1:
-        # the first dispatch is pt_scene_prepare's throw-away frame at a reduced sample count (part of Scene::new),
-        # not a bench step: the per-step average is taken over the rest
-        avg_ms = sum(durs[1:]) / len(durs[1:])
-        lines.append("frame kernel, average over the %d bench dispatches (first = pt_scene_prepare excluded): %.3f ms" % (
-            len(durs) - 1, avg_ms))
+        # pt_scene_prepare's throw-away frame (part of Scene::new) comes first and is not a bench step; a bench frame of a
+        # general world is two dispatches of this symbol (first sample of every pixel, then the rest): summed per frame
+        groups = bench_groups(durs)
+        avg_ms = sum(sum(g) for g in groups) / len(groups)
+        lines.append("frame kernel, average over the %d bench frames (%d dispatch(es) each; pt_scene_prepare excluded): %.3f ms" % (
+            len(groups), len(groups[0]), avg_ms))
     rows = [r for r in csv.DictReader(open(kt)) if is_frame_kernel(r["Kernel_Name"])]
     if rows:
         r = rows[-1]
@@ -65,19 +84,19 @@ for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
     if not f:
         continue
     rows = [r for r in csv.DictReader(open(f)) if is_frame_kernel(r["Kernel_Name"])]
-    # the first dispatch of the frame kernel is pt_scene_prepare's throw-away frame (reduced samples, dummy camera): not a bench frame
-    first = min((int(r["Dispatch_Id"]) for r in rows), default=None)
-    if len({r["Dispatch_Id"] for r in rows}) > 1:
-        rows = [r for r in rows if int(r["Dispatch_Id"]) != first]
-    agg, disp = collections.defaultdict(float), set()
+    # per bench FRAME: pt_scene_prepare's throw-away frame dropped, the dispatches of one frame summed
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    groups = bench_groups(ids)
+    keep = {i for g in groups for i in g}
+    agg = collections.defaultdict(float)
     for r in rows:
-        agg[r["Counter_Name"]] += float(r["Counter_Value"])
-        disp.add(r["Dispatch_Id"])
-    n = max(1, len(disp))
+        if int(r["Dispatch_Id"]) in keep:
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+    n = max(1, len(groups))
     for k, v in agg.items():
         pmc[k] = v / n
 lines.append("")
-lines.append("# PMC counters, per bench launch of the frame kernel (separate --pmc passes; pt_scene_prepare's dispatch excluded)")
+lines.append("# PMC counters of the frame kernel per bench frame (separate --pmc passes; pt_scene_prepare's frame excluded)")
 for k in sorted(pmc):
     lines.append("%-32s %.6g" % (k, pmc[k]))
 out = {"tag": tag, "kernel_avg_ms": avg_ms, "pmc_per_launch": pmc}
