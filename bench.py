@@ -236,7 +236,7 @@ def main():
     cam = hs.camera
     # The headline is the offline.rs contract: ONE Scene::update of a view the library has not seen (offline.rs:27 "only ever
     # processing 1 frame"). The library orders the work of a repeated view by the rays its last frame measured per tile;
-    # every timed step here must instead pay for its own 1-spp pilot pass, so that reuse is switched off (variant bit
+    # every timed step here must instead pay for its own measuring launch, so that reuse is switched off (variant bit
     # 8192). The default behaviour for repeated frames of one view is reported beside it as `progressive_view`.
     base_variant = int(os.environ.get("PTGPU_VARIANT", "0"))
     scene.set_tuning(0, base_variant | 8192)
@@ -380,7 +380,7 @@ def main():
     if not multi and not args.no_extras and not hs.is_world:
         # Extra, never `value`: the preview-window pattern (glium_window.rs: Scene::update(frame_num = 0, 1, 2, ...) blending
         # into ONE buffer). From the second frame of a view on, the work order comes from the rays each tile took in the frame
-        # before (measured by the frame kernel itself), not from a pilot pass. Same pixels as with the pilot every frame.
+        # before (measured by the frame kernel itself), not from a measuring launch of its own. Same pixels either way.
         kf = max(4, args.steps)
         pbuf = {v: torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for v in ("reuse", "pilot")}
         prc = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -436,7 +436,7 @@ def main():
             ptgpu.buffer_unregister(hb)
     if not multi and not args.no_pipeline and not args.no_extras:
         # Extra figure, never `value`: independent frames back to back on two scene handles / two HIP streams, so the
-        # tail of frame k (its last, serial pixels) and the pilot pass of frame k + 1 overlap. A single frame cannot
+        # tail of frame k (its last, serial pixels) and the measuring launch of frame k + 1 overlap. A single frame cannot
         # use this; a renderer producing a sequence of independent frames (animation, tiles of a bigger image) can.
         hs2 = pthost.HostScene(args.preset, W, H, samples=S, use_bvh=args.bvh, device=local_rank)
         hs2.device_scene().set_tuning(0, base_variant | 8192)
@@ -471,7 +471,7 @@ def main():
         counters = committed_counters(args.preset, W, H, S, args.bvh)
         roof = roofline_block("pt_trace_kernel" if not hs.is_world else "pt_world_kernel", kms, float(rays_this_launch), n_spheres, args.bvh, counters)
         roof["pass_ms"] = pms
-        roof["note_pass"] = "kernel_ms = the frame kernel alone (what rocprofv3 reports); pass_ms adds the 1-spp pilot pass and the tile sort that precede it"
+        roof["note_pass"] = "kernel_ms = the frame kernel alone (what rocprofv3 reports; samples 2..S); pass_ms adds the measuring launch (first sample of every pixel) and the tile sort that precede it"
         is_headline = args.preset == "random_spheres" and (W, H) == (1200, 800) and not args.bvh and ((not multi and S == 64) or (tiles and S == 256))
         out = {
             "metric": ("Mrays/sec, random_spheres 1200x800 %dspp" % S) if is_headline else "Mrays/sec, %s %dx%d %dspp" % (args.preset, W, H, S),
