@@ -40,7 +40,7 @@ int fail(int code, const char *fmt, ...) {
 
 // Development knobs (environment), read ONCE per process: the launch path does not call getenv.
 struct DevKnobs {
-    int refill = -1, ready = -1, drain = -1, pilot_div = -1;
+    int refill = -1, ready = -1, drain = -1, pilot_div = -1, phase1 = -1, phase1_refill = -1;
     bool world_occ3 = false, debug = false, clamp_grid = false;
 };
 const DevKnobs &dev_knobs() {
@@ -50,6 +50,8 @@ const DevKnobs &dev_knobs() {
         if (const char *e = getenv("PTGPU_READY")) d.ready = atoi(e);
         if (const char *e = getenv("PTGPU_DRAIN")) d.drain = atoi(e);
         if (const char *e = getenv("PTGPU_PILOT_DIV")) d.pilot_div = std::max(1, atoi(e));
+        if (const char *e = getenv("PTGPU_PHASE1")) d.phase1 = std::max(0, atoi(e));
+        if (const char *e = getenv("PTGPU_PHASE1_REFILL")) d.phase1_refill = std::max(1, atoi(e));
         d.world_occ3 = getenv("PTGPU_WORLD_OCC3") != nullptr;
         d.debug = getenv("PTGPU_DEBUG") != nullptr;
         d.clamp_grid = getenv("PTGPU_CLAMP_GRID") != nullptr;
@@ -1758,7 +1760,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         // samples per tile instead of the pilot's 16 x 1 throw-away ones), the second the rest, ordered by those costs; a pixel's
         // RNG stream and colour sum wait in d_px_state in between. Variant bit 16384 keeps the pilot pass.
         uint32_t phase1 = kPhase1Samples;
-        if (const char *e = getenv("PTGPU_PHASE1")) phase1 = (uint32_t)atoi(e);   // (development knob)
+        if (dev_knobs().phase1 >= 0) phase1 = (uint32_t)dev_knobs().phase1;   // (development knob PTGPU_PHASE1)
         const bool two_phase = !reuse && (s->variant & 16384u) == 0 && phase1 > 0 && params->samples >= kTwoLaunchMinSamples && params->samples > phase1 && (A.verify & 1u) == 0;
         uint32_t measured_scale = params->samples * (params->max_depth + 1u);
         if (reuse) {
@@ -1777,7 +1779,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
             KArgs A1 = A;
             A1.samples = phase1, A1.phase = 1, A1.px_state = s->d_px_state, A1.tile_cost = cost, A1.wave_end = nullptr;
             A1.refill_min = 48u;   // one sample per pixel: refills dominate, batch them hard (a plain 1-spp frame: 0.48 ms at 8, 0.34 at 32; frame: best at 48)
-            if (const char *e = getenv("PTGPU_PHASE1_REFILL")) A1.refill_min = (uint32_t)atoi(e);   // (development knob)
+            if (dev_knobs().phase1_refill > 0) A1.refill_min = (uint32_t)dev_knobs().phase1_refill;   // (development knob PTGPU_PHASE1_REFILL)
             hipLaunchKernelGGL(pilot_kern, dim3(grid), dim3(blk), lds, stream, A1);
             hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, phase1 * (params->max_depth + 1u), order);
             HIP_TRY(hipGetLastError());
