@@ -222,7 +222,8 @@ def test_progressive_frames_blend_like_scene_update(ptgpu, oracle):
     sc.close()
 
 
-@pytest.mark.parametrize("preset,bvh", [("random_spheres", False), ("random_spheres", True), ("perlin_spheres", True)])
+@pytest.mark.parametrize("preset,bvh", [("random_spheres", False), ("random_spheres", True), ("perlin_spheres", True),
+                                        ("cornell_smoke", False), ("simple_light", True), ("random", False)])   # (general-world kernel too)
 def test_work_order_from_the_previous_frame_never_changes_a_pixel(ptgpu, pthost, preset, bvh):
     """A frame of the view the scene rendered last is ordered by the rays each tile took in that frame (measured by the frame
     kernel) instead of by a 1-spp pilot pass. The order of the work must not change a pixel or the ray count: progressive
