@@ -1054,8 +1054,8 @@ def test_bench_sharded_path_self_check():
     import json
     import subprocess
     env = dict(os.environ, PT_BENCH_FORCE_DIST="1", PT_BENCH_CHECK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
-    for extra in ([], ["--no-overlap"]):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--samples", "8",
+    for extra, spp in (([], "16"), (["--no-overlap"], "8")):   # (16 spp: the shard renders as two launches; 8: as one)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--samples", spp,
                               "--no-extras", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         assert "[bench check] tiles frame over 1 rank(s) == single-GPU frame" in out.stderr
@@ -1063,3 +1063,25 @@ def test_bench_sharded_path_self_check():
         d = json.loads(line)
         assert d["scaling"] == "strong" and d["unit"] == "Mrays/s" and d["value"] > 0 and "roofline" in d
         assert "split by rows" in d["config"]["workload"]
+
+
+def test_bench_default_line_keeps_the_contract():
+    """The one JSON line of `python bench.py` (N = 1): BASELINE's metric on BASELINE's workload, every fraction of the roofline
+    block <= 1, the extras present and self-consistent (bench.py asserts that each extra reproduces the headline frame)."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["metric"] == "Mrays/sec, random_spheres 1200x800 64spp" and d["unit"] == "Mrays/s" and d["n_gpus"] == 1
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["dtype"] == "f32"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["config"]["rays_per_step"] == 162554454
+    assert abs(d["value"] - d["config"]["rays_per_step"] / 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0 and 0.0 < r["hbm_frac"] <= 1.0 and 0.0 <= r["mfma_busy_frac"] <= 1.0
+    assert r["traffic"] > 0 and r["kernel_ms"] <= r["pass_ms"] <= d["ms_per_step"] * 1.05
+    for key in ("host_buffer", "pipelined_frames", "progressive_view"):
+        assert d[key]["value"] > 0 and d[key]["unit"] == "Mrays/s"
+    assert d["host_buffer"]["registered"]["value"] > 0
+
