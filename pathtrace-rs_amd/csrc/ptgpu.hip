@@ -1755,10 +1755,10 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         pt_scene::ViewKey key{};
         key.params = *params, key.cam = *cam, key.shard_index = shard_index, key.shard_count = shard_count, key.variant = s->variant, key.n_tiles = n_work_tiles;
         const bool reuse = s->hint_valid && (s->variant & 8192u) == 0 && memcmp(&key, &s->hint_key, sizeof key) == 0;
-        // A frame of a view not seen before, 32 samples or more: TWO launches instead of a pilot pass. The first traces the first
-        // kPhase1Samples samples of every pixel in natural order and measures the tiles while doing so (real work, 64 pixels x 4
-        // samples per tile instead of the pilot's 16 x 1 throw-away ones), the second the rest, ordered by those costs; a pixel's
-        // RNG stream and colour sum wait in d_px_state in between. Variant bit 16384 keeps the pilot pass.
+        // A frame of a view not seen before: TWO launches instead of a throw-away pilot pass. The first (the pilot symbol, phase 1)
+        // traces the first sample of every pixel in natural order and counts the rays per tile while doing so (real work, 64
+        // pixels per tile instead of the pilot's 16), the second the remaining samples, ordered by those costs; a pixel's RNG
+        // stream and colour sum wait in d_px_state in between. Variant bit 16384 keeps the pilot pass.
         uint32_t phase1 = kPhase1Samples;
         if (dev_knobs().phase1 >= 0) phase1 = (uint32_t)dev_knobs().phase1;   // (development knob PTGPU_PHASE1)
         const bool two_phase = !reuse && (s->variant & 16384u) == 0 && phase1 > 0 && params->samples >= kTwoLaunchMinSamples && params->samples > phase1 && (A.verify & 1u) == 0;
@@ -1786,23 +1786,23 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
             A.samples = params->samples - phase1, A.phase = 2, A.px_state = s->d_px_state;
             measured_scale = A.samples * (params->max_depth + 1u);
         } else {
-        HIP_TRY(hipMemsetAsync(scratch, 0, (8 + (size_t)s->d_tile_cap) * sizeof(uint32_t), stream));
-        KArgs P = A;
-        P.samples = 1;
-        P.inv_ns = 1.0f;
-        P.random_seed = 1;                       // throw-away seeds: the pilot must not look like frame data
-        P.seed_base = 0x9e3779b97f4a7c15ull ^ frame_num;
-        // (P.rgb stays the frame: PILOT kernels never write pixels)
-        P.tile_cost = cost;
-        P.ray_count = reinterpret_cast<unsigned long long *>(scratch);      // scratch[0..1]
-        P.verify = 0;
-        P.wave_end = nullptr;
-        // a third of the frame's grid: the pilot has ~100x less work, and each workgroup stages the scene into LDS
-        uint32_t pilot_div = 3u;
-        if (dev_knobs().pilot_div > 0) pilot_div = (uint32_t)dev_knobs().pilot_div;   // (development knob PTGPU_PILOT_DIV)
-        hipLaunchKernelGGL(pilot_kern, dim3((grid + pilot_div - 1u) / pilot_div), dim3(blk), lds, stream, P);
-        hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, params->max_depth + 1u, order);
-        HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemsetAsync(scratch, 0, (8 + (size_t)s->d_tile_cap) * sizeof(uint32_t), stream));
+            KArgs P = A;
+            P.samples = 1;
+            P.inv_ns = 1.0f;
+            P.random_seed = 1;                       // throw-away seeds: the pilot must not look like frame data
+            P.seed_base = 0x9e3779b97f4a7c15ull ^ frame_num;
+            // (P.rgb stays the frame: PILOT kernels never write pixels)
+            P.tile_cost = cost;
+            P.ray_count = reinterpret_cast<unsigned long long *>(scratch);      // scratch[0..1]
+            P.verify = 0;
+            P.wave_end = nullptr;
+            // a third of the frame's grid: the pilot has ~100x less work, and each workgroup stages the scene into LDS
+            uint32_t pilot_div = 3u;
+            if (dev_knobs().pilot_div > 0) pilot_div = (uint32_t)dev_knobs().pilot_div;   // (development knob PTGPU_PILOT_DIV)
+            hipLaunchKernelGGL(pilot_kern, dim3((grid + pilot_div - 1u) / pilot_div), dim3(blk), lds, stream, P);
+            hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, cost, params->max_depth + 1u, order);
+            HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
         A.tile_order = order;
