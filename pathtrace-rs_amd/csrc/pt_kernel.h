@@ -669,6 +669,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     (void)sec;
 #define PT_SUB(i) do { } while (0)
 #endif
+    const f3 rcp_own = GATED ? mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z) : mk3(0.f, 0.f, 0.f);   // ray.rs:14 (only the gate of a BVH world reads it)
     const RayFeat rf = make_ray_features(P, o, d, a, active, lane);
     PT_SUB(5);
     const float16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -757,6 +758,8 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                 const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));
                 const float pa = lane_fetch(owner, a);
                 const float ptime = MOVING ? lane_fetch(owner, time) : 0.0f;
+                // (BVH worlds: 1 / d of the owner's ray for the gate test, fetched instead of three IEEE divisions per round)
+                const f3 prcp = GATED ? mk3(lane_fetch(owner, rcp_own.x), lane_fetch(owner, rcp_own.y), lane_fetch(owner, rcp_own.z)) : mk3(0.f, 0.f, 0.f);
                 if (valid) {
                     const float4 c = sphere_at<MOVING>(A, k, sph[k], ptime);
                     const float ocx = po.x - c.x, ocy = po.y - c.y, ocz = po.z - c.z;
@@ -767,7 +770,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                         float t = kMaxT;
                         if (sphere_roots(pa, b, disc, t)) {
                             const uint32_t rank = GATED ? G.rank[k] : 0u;
-                            if (!GATED || gate_pass_from(A, G, k, po, mk3(1.0f / pd.x, 1.0f / pd.y, 1.0f / pd.z)))   // ray.rs:14 rcp_direction
+                            if (!GATED || gate_pass_from(A, G, k, po, prcp))   // ray.rs:14 rcp_direction
                                 atomicMin(&w_keys[owner], key_of(t, k, rank));
                         }
                     }
@@ -1105,7 +1108,7 @@ __device__ __forceinline__ unsigned long long key4_of(const KArgs &A, float t, i
 // then the ancestor-AABB gate of a BVH world). The slot record holds the sphere together with its gate box, rank and
 // index: the accept rule needs no dependent loads.
 template <bool MOVING>
-__device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float time, f3 o, f3 d, float a, unsigned long long *key) {
+__device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float time, f3 o, f3 d, f3 rcp, float a, unsigned long long *key) {
     const bool gated = A.gate != nullptr;
     const float4 *R = A.slotrec + 4 * (size_t)e;
     float4 c = R[0], g0 = make_float4(0, 0, 0, 0), g1 = g0;
@@ -1122,13 +1125,13 @@ __device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float tim
         if (sphere_roots(a, b, disc, t)) {
             const uint32_t low = gated ? (0xffffffffu - __float_as_uint(g2.x)) : (uint32_t)k;
             const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | low;
-            if (kk < *key && (!gated || gate_pass_loaded(A, g0, g1, o, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z)))) atomicMin(key, kk);
+            if (kk < *key && (!gated || gate_pass_loaded(A, g0, g1, o, rcp))) atomicMin(key, kk);   // rcp = ray.rs:14 rcp_direction of the OWNER's ray
         }
     }
 }
 
 template <bool MOVING, int BLK>
-__device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, f3 o, f3 d, float a,
+__device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, f3 o, f3 d, f3 rcp, float a,
                                        float time, Trav4 &st) {
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t incl = wave_inclusive_sum(st.qn);
@@ -1138,7 +1141,7 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
         // more pairs than the wave's list holds: every lane tests its own (rare: the queues drain at > 4 entries)
         for (uint32_t j = 0; __any(j < st.qn); ++j)
             if (j < st.qn) {
-                pair_test4<MOVING>(A, leafq[j * BLK + tid], time, o, d, a, &w_keys[lane]);
+                pair_test4<MOVING>(A, leafq[j * BLK + tid], time, o, d, rcp, a, &w_keys[lane]);
             }
     } else {
         uint32_t pos = incl - st.qn;
@@ -1154,7 +1157,9 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
             const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));
             const float pa = lane_fetch(owner, a);
             const float ptime = MOVING ? lane_fetch(owner, time) : 0.0f;
-            if (valid) pair_test4<MOVING>(A, slot, ptime, po, pd, pa, &w_keys[owner]);
+            // (a BVH world's gate test needs 1 / d of the owner's ray: three cross-lane fetches instead of three IEEE divisions per round)
+            const f3 prcp = A.gate ? mk3(lane_fetch(owner, rcp.x), lane_fetch(owner, rcp.y), lane_fetch(owner, rcp.z)) : rcp;
+            if (valid) pair_test4<MOVING>(A, slot, ptime, po, pd, prcp, pa, &w_keys[owner]);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1268,7 +1273,7 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
 #ifdef PT_SECTIONS
         sec[7] += 1ull;
 #endif
-        if (stop || __any(st.qn > A.drain_at)) drain4<MOVING, BLK>(A, leafq, w_pairs, w_keys, o, d, a, time, st);
+        if (stop || __any(st.qn > A.drain_at)) drain4<MOVING, BLK>(A, leafq, w_pairs, w_keys, o, d, rcp, a, time, st);
         PT_SUB4(6);
         if (stop) break;
     }
