@@ -583,9 +583,9 @@ __device__ __forceinline__ void accept_hit(const KArgs &A, const GateSrc &G, int
 // MovingSphere::centre (moving_sphere.rs:29-31): centre_start + ((time - time_start) * inv_time_delta) * centre_delta.
 // `c` carries the sphere as stored (centre_start in xyz; w untouched). Plain spheres are returned as they are.
 template <bool MOVING>
-__device__ __forceinline__ float4 sphere_at(const KArgs &A, int k, float4 c, float time) {
+__device__ __forceinline__ float4 sphere_at_m(const float4 *motion, int k, float4 c, float time) {
     if (MOVING) {
-        const float4 m0 = A.motion[2 * k], m1 = A.motion[2 * k + 1];
+        const float4 m0 = motion[2 * k], m1 = motion[2 * k + 1];
         if (m1.y != 0.0f) {
             const float s = (time - m1.x) * m0.w;
             c.x = c.x + s * m0.x;
@@ -594,6 +594,10 @@ __device__ __forceinline__ float4 sphere_at(const KArgs &A, int k, float4 c, flo
         }
     }
     return c;
+}
+template <bool MOVING>
+__device__ __forceinline__ float4 sphere_at(const KArgs &A, int k, float4 c, float time) {
+    return sphere_at_m<MOVING>(A.motion, k, c, time);
 }
 
 // exact reference test of one sphere, order independent: candidate t as sphere.rs:38-64 would
@@ -656,7 +660,7 @@ __device__ __forceinline__ uint32_t lane_tile_mask(const float4 *P, const uint32
 }
 
 template <bool VERIFY, bool MOVING, bool GATED, int BLK>
-__device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc &G, const float4 *P, const float4 *sph, const uint4 *s_afrag,
+__device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc &G, const float4 *mot, const float4 *P, const float4 *sph, const uint4 *s_afrag,
                                                    const uint16_t *s_tile_sphere, const uint32_t *s_cull, uint16_t *queue,
                                                    uint32_t *w_pairs, unsigned long long *w_keys,
                                                    f3 o, f3 d, float a, bool active, float time, float &t_out,
@@ -725,7 +729,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                     const uint32_t b = (uint32_t)__builtin_ctz(cur);
                     cur &= cur - 1u;
                     const int k = s_tile_sphere[slot_of(curT, b)];
-                    exact_candidate<GATED>(A, G, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+                    exact_candidate<GATED>(A, G, sphere_at_m<MOVING>(mot, k, sph[k], time), k, o, d, a, best, idx, best_rank);
                 }
             }
         } else if (total != 0u) {
@@ -761,7 +765,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                 // (BVH worlds: 1 / d of the owner's ray for the gate test, fetched instead of three IEEE divisions per round)
                 const f3 prcp = GATED ? mk3(lane_fetch(owner, rcp_own.x), lane_fetch(owner, rcp_own.y), lane_fetch(owner, rcp_own.z)) : mk3(0.f, 0.f, 0.f);
                 if (valid) {
-                    const float4 c = sphere_at<MOVING>(A, k, sph[k], ptime);
+                    const float4 c = sphere_at_m<MOVING>(mot, k, sph[k], ptime);
                     const float ocx = po.x - c.x, ocy = po.y - c.y, ocz = po.z - c.z;
                     const float b = (ocx * pd.x + ocy * pd.y) + ocz * pd.z;
                     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
@@ -792,7 +796,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     // the always-tested spheres first (wave-uniform): their nearest hit bounds the segment the tiles are culled against
     for (uint32_t j = 0; j < A.n_large; ++j) {
         const int k = (int)A.large[j];
-        if (active) exact_candidate<GATED>(A, G, sphere_at<MOVING>(A, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+        if (active) exact_candidate<GATED>(A, G, sphere_at_m<MOVING>(mot, k, sph[k], time), k, o, d, a, best, idx, best_rank);
     }
     // wave-uniform set of tiles to run: the union of the lanes' tile masks (verify mode audits every tile)
     uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
@@ -876,7 +880,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
         if (overflow || VERIFY) {
             // verify mode (and its queue overflows, where the masks of a ray were not all kept): brute force
             for (int k = 0; k < (int)A.n_spheres; ++k) {
-                const float4 c = sphere_at<MOVING>(A, k, sph[k], time);
+                const float4 c = sphere_at_m<MOVING>(mot, k, sph[k], time);
                 exact_candidate<GATED>(A, G, c, k, o, d, a, vbest, vidx, vrank);
                 if (VERIFY && active) {
                     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
@@ -1340,6 +1344,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     p += (PAL && GATE) ? A.n_spheres * 32u : 0u;
     uint32_t *s_rank = reinterpret_cast<uint32_t *>(p);
     p += (PAL && GATE) ? ((A.n_spheres * 4u + 15u) & ~15u) : 0u;
+    float4 *s_motion = reinterpret_cast<float4 *>(p);   // PAL && MOVING: the MovingSphere records (2 float4 per sphere)
+    p += (PAL && MOVING) ? A.n_spheres * 32u : 0u;
+    const float4 *const mot = (PAL && MOVING) ? (const float4 *)s_motion : A.motion;
     float *s_path = reinterpret_cast<float *>(p);       // [max_depth][3][BLK] attenuation stack (PAL: u16 [max_depth][BLK] palette codes)
     uint16_t *s_pal = reinterpret_cast<uint16_t *>(p);
 
@@ -1362,6 +1369,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             for (uint32_t k = tid; k < A.n_spheres * 2u; k += BLK) s_gate[k] = A.gate[k];
             for (uint32_t k = tid; k < A.n_spheres; k += BLK) s_rank[k] = A.leaf_rank[k];
         }
+        if (MOVING)
+            for (uint32_t k = tid; k < A.n_spheres * 2u; k += BLK) s_motion[k] = A.motion[k];
     }
     if (BVH && A.nodes_in_lds) {
         const uint4 *src = reinterpret_cast<const uint4 *>(A.wnodes);
@@ -1597,7 +1606,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             idx = trav.idx;
             t_hit = trav.best;
         } else if (MFMA)
-            idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, (PAL && GATE) ? GateSrc{s_gate, s_rank} : GateSrc{A.gate, A.leaf_rank}, s_par, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_cull,
+            idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, (PAL && GATE) ? GateSrc{s_gate, s_rank} : GateSrc{A.gate, A.leaf_rank}, mot, s_par, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_cull,
                                                       s_queue, w_pairs, w_keys, ro, rd, a, have, rtime, t_hit
 #ifdef PT_SECTIONS
                                                       , sec_t
@@ -1628,7 +1637,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     V = mk3(w1 + (t * 0.5f) * 0.3f, w1 + (t * 0.7f) * 0.3f, w1 + (t * 1.0f) * 0.3f);
                 }
             } else {
-                const float4 sp = sphere_at<MOVING>(A, idx, shade[4 * idx], rtime), q1 = shade[4 * idx + 1],
+                const float4 sp = sphere_at_m<MOVING>(mot, idx, shade[4 * idx], rtime), q1 = shade[4 * idx + 1],
                              qa = shade[4 * idx + 2], qb = shade[4 * idx + 3];
                 const f3 centre = mk3(sp.x, sp.y, sp.z);
                 const f3 point = add3(o, scale3(d, t_hit));            // ray.rs:24-26

@@ -1624,7 +1624,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     // wide kernels: 16-bit palette codes on the attenuation stack + the shading records in LDS (pt_kernel.h PAL)
     const auto wide_extra = [&](uint32_t b) {
         return ((uint64_t)s->n_spheres + 1ull) * 64ull + (((uint64_t)stack_levels * 2ull * b + 15ull) & ~15ull) +
-               (ref_bvh ? (uint64_t)s->n_spheres * 32ull + (((uint64_t)s->n_spheres * 4ull + 15ull) & ~15ull) : 0ull);   // BVH world: gates + ranks
+               (ref_bvh ? (uint64_t)s->n_spheres * 32ull + (((uint64_t)s->n_spheres * 4ull + 15ull) & ~15ull) : 0ull) +   // BVH world: gates + ranks
+               (moving ? (uint64_t)s->n_spheres * 32ull : 0ull);                                                          // MovingSphere records
     };
     if (mfma && s->palette_ok && (s->variant & 2u) == 0 && (A.verify & 1u) == 0 && s->blocks_per_cu == 0) {
         const auto wide_lds = [&](uint32_t b) {
