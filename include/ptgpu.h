@@ -203,8 +203,8 @@ int pt_scene_prepare(pt_scene *scene, const pt_params *params);
  * reference's contract: rgb_inout is width*height*3 floats (row 0 = bottom
  * row, offline.rs:44), READ (frame blend scene.rs:114-116) and written;
  * *ray_count_out receives the number of ray_trace invocations. Synchronous.
- * Limits of the sphere kernels (PT_ERR_UNSUPPORTED beyond them): width, height < 65536, max_depth < 4096,
- * samples < 2^20 (a lane keeps its pixel and its (depth, sample) counters in one register each). */
+ * Limits (PT_ERR_UNSUPPORTED beyond them): width, height < 65536 (a lane keeps its pixel in one register); sphere scenes also
+ * max_depth < 4096 and samples < 2^20 (their kernels pack the (depth, sample) counters into one register). */
 int pt_render(pt_scene *scene, const pt_params *params, const pt_camera *camera,
               uint32_t frame_num, float *rgb_inout, uint64_t *ray_count_out);
 

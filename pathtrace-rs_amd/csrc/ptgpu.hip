@@ -1377,9 +1377,10 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (params->width == 0 || params->height == 0 || params->samples == 0)
         return fail(PT_ERR_INVALID_ARG, "width/height/samples must be non-zero");
     if ((uint64_t)params->width * params->height > 0x3fffffffull) return fail(PT_ERR_INVALID_ARG, "frame too large");
-    // the sphere kernels pack a lane's pixel and its (depth, sample) counters into one register each
-    if (!s->is_world && (params->width > 0xffffu || params->height > 0xffffu || params->max_depth > 0xfffu || params->samples > 0xfffffu))
-        return fail(PT_ERR_UNSUPPORTED, "sphere kernels take width, height < 65536, max_depth < 4096, samples < 2^20");
+    // every kernel packs a lane's pixel into one register; the sphere kernels its (depth, sample) counters as well
+    if (params->width > 0xffffu || params->height > 0xffffu) return fail(PT_ERR_UNSUPPORTED, "width and height must be below 65536");
+    if (!s->is_world && (params->max_depth > 0xfffu || params->samples > 0xfffffu))
+        return fail(PT_ERR_UNSUPPORTED, "sphere kernels take max_depth < 4096, samples < 2^20");
     if (shard_count == 0 || shard_index >= shard_count) return fail(PT_ERR_INVALID_ARG, "bad shard %u/%u", shard_index, shard_count);
     const bool ref_bvh = params->use_bvh != 0;   // BVHNode::ray_hit semantics (needs the caller's tree for the gates)
     if (ref_bvh && s->bvh_root < 0) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the scene was created without BVH nodes");
@@ -1468,7 +1469,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         // rays its last frame measured per tile; a new view runs as two launches of this kernel, the first tracing the first
         // sample of every pixel while it counts
         const uint32_t n_world_tiles = W.n_items / kTilePix;
-        if (n_world_tiles >= 256u && params->samples >= kPilotMinSamples && (s->variant & (32u | 16384u)) == 0 && params->width < 65536u && params->height < 65536u) {
+        if (n_world_tiles >= 256u && params->samples >= kPilotMinSamples && (s->variant & (32u | 16384u)) == 0) {
             if (n_world_tiles > s->d_tile_cap) {
                 (void)hipFree(s->d_tile_buf);
                 s->d_tile_buf = nullptr, s->d_tile_cap = 0, s->hint_valid = false;

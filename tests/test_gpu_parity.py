@@ -529,6 +529,12 @@ def test_error_reporting_on_device(ptgpu, pthost):
             sc.update(bad, hs.camera, 0, buf)
         assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED
     assert sc.update(ptgpu.PtParams(32, 16, 1, 4095, 0, 0), hs.camera, 0, buf) > 0
+    # every kernel keeps a lane's pixel in one register: frames of 65536 pixels or more along an axis are refused
+    wide = np.zeros((1, 65536, 3), np.float32)
+    for scene in (sc, pthost.HostScene("cornell", 32, 16, device=0).device_scene()):
+        with pytest.raises(ptgpu.PtError) as e:
+            scene.update(ptgpu.PtParams(65536, 1, 1, 10, 0, 0), hs.camera, 0, wide)
+        assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED
 
 
 # ---- general worlds: MovingSphere, Rect, Cuboid, Instance, ConstantMedium ----------------
