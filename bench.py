@@ -490,7 +490,11 @@ def main():
                                         else "frame_num = rank on each of %d GPUs, no data-path collective, all_gather of the frames + "
                                              "blend in frame order (scene.rs:113-116)" % N)),
                        "overlap": ("collective of step k on a second HIP stream under the kernel of step k + 1" if overlap else "none"),
-                       "grid": grid, "block": block, "lds_bytes": lds},
+                       "grid": grid, "block": block, "lds_bytes": lds,
+                       "work_order": "every timed step measures its own tile costs (launch 1: first sample of every pixel; launch 2: the "
+                                     "rest, expensive tiles first); the library's reuse of the previous frame's measured costs for a "
+                                     "repeated view is switched off for `value` (pt_scene_set_tuning bit 8192) and reported as "
+                                     "`progressive_view`"},
             "roofline": roof,
         }
         if other is not None:
