@@ -318,7 +318,8 @@ int pt_scene_debug_tree_packed(pt_scene *scene, void *nodes_out, size_t capacity
  *        the order of the work never changes a pixel or the ray count,
  * 16384 = frames of a new view always use the throw-away 1-spp pilot pass (general worlds: natural order). Default (from 12
  *        samples on): the frame runs as two launches, the first tracing the first sample of every pixel for real while it
- *        counts the rays per tile. */
+ *        counts the rays per tile,
+ * 32768 = the 16-wave kernels' first fetches race for the work counter (default: handed out by wave age class, oldest waves first). */
 int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
 
 /* Verify-mode counters of the MFMA prefilter (variant bit 8): out4 = { exact-positive pairs the

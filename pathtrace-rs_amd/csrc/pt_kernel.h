@@ -138,6 +138,7 @@ struct KArgs {
     // px_state (12 dwords per pixel) where phase 2 picks them up; 0 = the whole frame in one launch.
     uint32_t phase;
     uint4 *px_state;
+    uint32_t first_static;       // 0, or the number of items handed out statically as the waves' first fetches (grid x 1024)
     uint32_t refill_min;         // lanes that must be waiting before a wave fetches new pixels (4; 8 below 32 spp)
     uint32_t ready_min;          // 4-wide tree: lanes with a finished traversal before the wave leaves the traversal loop to shade
     uint32_t drain_at;           // 4-wide tree: a lane holding more than this many leaf candidates triggers the wave's drain
@@ -1453,6 +1454,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         return mk3(q.x, q.y, q.z);
     };
     float rtime = 0.f;  // ray.time (only MOVING kernels read it)
+    bool first_claim = true;   // (wave-uniform: every lane of a wave takes part in its first fetch)
 #if defined(PT_SECTIONS) || defined(PT_WAVEDBG)
 #define PT_WAVE_DETAIL 1   // development builds: per-wave iteration counts, first / last pixel, moment the work list ran dry
     uint32_t dbg_first_pxy = 0xffffffffu;
@@ -1491,8 +1493,18 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             const unsigned long long m = __ballot(1);
             const int leader = __ffsll((long long)m) - 1;
             uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(A.work_counter, (uint32_t)__popcll(m));
-            base = __shfl(base, leader);
+            if (A.first_static != 0u && first_claim) {
+                // A SIMD's arbiter serves its OLDEST wave first: the first waves of a 16-wave workgroup advance up to twice as fast
+                // as the last ones ("The end of a frame"). The head of the heavy-first list -- the pixels whose
+                // serial sample chains decide when the frame ends -- therefore goes to them: a wave's first 64 items are fixed by
+                // its age class (wave >> 2) instead of by the race for the counter, which starts behind these items.
+                const uint32_t wv = (uint32_t)(tid >> 6), cls = wv >> 2, idx = blockIdx.x * 4u + (wv & 3u);
+                base = (cls * gridDim.x * 4u + idx) * 64u;
+            } else {
+                if (lane == leader) base = atomicAdd(A.work_counter, (uint32_t)__popcll(m));
+                base = __shfl(base, leader) + A.first_static;
+            }
+            first_claim = false;
             const uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (item >= A.n_items) {
                 exhausted = true;

@@ -1807,6 +1807,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+        // 16-wave workgroups: the waves' first fetches are handed out by age class (pt_kernel.h first_static; +1 % on configs 3 / 4);
+        // variant bit 32768 leaves them to the race for the counter
+        if (blk == 1024u && (uint64_t)grid * 1024ull <= A.n_items && (s->variant & 32768u) == 0) A.first_static = grid * 1024u;
         A.tile_order = order;
         if ((s->variant & 8192u) == 0) {   // this frame measures the tiles for the next one (after the order kernel has read the old values)
             HIP_TRY(hipMemsetAsync(measured, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
