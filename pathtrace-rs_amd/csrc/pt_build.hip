@@ -185,7 +185,11 @@ __global__ void pack_kernel(const DNode4 *nodes, uint32_t n_nodes, const float4 
     if (!tree_pack_node(w, q)) atomicOr(failed, 1u);
     packed[i] = q;
     for (uint32_t j = 0; j < 4u; ++j) {
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0, r3 = r0;
+        // A slot without a leaf must never produce a hit: its planes cannot be met while the node-level pad stays below half
+        // the f16 range, but a ray starting ~10^4 units away pads every box by more than that (pt_kernel.h bvh4_run), and the
+        // exact test then runs on this record. A NaN centre makes the reference discriminant NaN, which is not > 0.
+        const float qnan = __uint_as_float(0x7fc00000u);
+        float4 r0 = make_float4(qnan, qnan, qnan, 0.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r1, r3 = r1;
         if (w.child[j] != kNoChild4 && w.child[j] < 0) {
             const uint32_t k = (uint32_t)~w.child[j];
             if (leafrec) r0 = leafrec[4 * k], r1 = leafrec[4 * k + 1], r2 = leafrec[4 * k + 2], r3 = leafrec[4 * k + 3];

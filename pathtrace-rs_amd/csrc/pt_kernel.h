@@ -74,8 +74,8 @@ struct DCamera {  // camera.rs:8-19
 // loop and spills into VGPR lanes (v_readlane / v_writelane around every use).
 //   [0] clip_min.xyz, cull_u0   [1] clip_max.xyz, cull_inv_cell   [2] c0.xyz, rs2   [3] m0, gamma, inv_nx, inv_ny
 //   [4..9] DCamera (24 floats, camera.rs:8-19 order)   [10] inv_ns, mix_prev, mix_new, -   [11] sky.xyz, has_sky
-//   [12] as u32 bits: cull_axis, cull_always, max_depth, samples
-constexpr uint32_t kLdsParamBytes = 13u * 16u;
+//   [12] as u32 bits: cull_axis, cull_always, max_depth, samples   [13] tile culling's per-ray reach: 2 kappa, kappa (2 Rs^2 + r_max^2) + r_min^2, r_min, -
+constexpr uint32_t kLdsParamBytes = 14u * 16u;
 
 constexpr int kCullCells = 256;   // resolution of the tile-culling lookup along the sort axis
 
@@ -120,7 +120,8 @@ struct KArgs {
     uint32_t cull_axis;          // 0..2; 3 = culling off
     uint32_t cull_always;        // tiles that are always run (they hold spheres outside the sorted set)
     float cull_u0, cull_inv_cell;
-    float clip_min[3], clip_max[3];  // box of the sorted spheres, padded (launch() widens it by the reach of the reference's f32 rounding)
+    float clip_min[3], clip_max[3];  // box of the sorted spheres, padded by 2e-3 + 1e-5 |.| (lane_tile_mask adds each ray's own reach)
+    float cull_reach[3];             // 2 kappa, kappa (2 Rs^2 + r_max^2) + r_min^2, r_min (lane_tile_mask)
     uint32_t verify;             // debug: count exact-positive pairs the prefilter did not flag
     unsigned long long *debug;   // [4] misses, candidates, overflow fallbacks, exact positives
     unsigned long long *wave_end; // optional (PTGPU_TIMING=1): wall clock at which each wave left the main loop
@@ -411,10 +412,25 @@ __device__ __forceinline__ RayFeat make_ray_features(const float4 *P, f3 o, f3 d
     const f3 ot = mk3(o.x - pc.x, o.y - pc.y, o.z - pc.z);
     const float od0 = __builtin_fmaf(ot.z, d.z, __builtin_fmaf(ot.y, d.y, ot.x * d.x));
     const float s = active ? (-od0 / a) : 0.0f;
-    const f3 op = mk3(__builtin_fmaf(s, d.x, ot.x), __builtin_fmaf(s, d.y, ot.y), __builtin_fmaf(s, d.z, ot.z));
-    const float od = __builtin_fmaf(op.z, d.z, __builtin_fmaf(op.y, d.y, op.x * d.x));
+    f3 op = mk3(__builtin_fmaf(s, d.x, ot.x), __builtin_fmaf(s, d.y, ot.y), __builtin_fmaf(s, d.z, ot.z));
+    float od = __builtin_fmaf(op.z, d.z, __builtin_fmaf(op.y, d.y, op.x * d.x));
     const float oo = __builtin_fmaf(op.z, op.z, __builtin_fmaf(op.y, op.y, op.x * op.x));
     const float ot2 = __builtin_fmaf(ot.z, ot.z, __builtin_fmaf(ot.y, ot.y, ot.x * ot.x));
+    const float margin = a * __builtin_fmaf(pm.y, ot2 + pc.w, pm.x);
+    // candidate <=> S.R > thr. The tile GEMM evaluates thr - S.R directly (sphere fragments hold -S, and
+    // slots 30/31 hold 1 x thr_hi, 1 x thr_lo), so a candidate is simply a NEGATIVE accumulator.
+    float thr = __builtin_fmaf(a, oo, -(od * od)) - margin;
+    thr -= 1.0e-6f * __builtin_fabsf(thr);                         // covers the hi/lo f16 representation of thr
+    // Rays the f16 features cannot describe: an origin so far away that the margin alone exceeds the feature range
+    // (|o - c0| > ~86 000: the reference's own discriminant error is then of that size, and S.R of a reference-positive pair
+    // may lie below any threshold f16 can hold), a line passing farther from c0 than f16 can hold (|o'| > 30 000), or a NaN.
+    // Such a lane presents the null line through c0 (o' = 0: |S.R| <= 2 a Rs^2 <= 4608 a) with a threshold below that:
+    // EVERY prefiltered sphere becomes its candidate and the exact phase 2 decides, as for any other ray. (The floor stays
+    // above the -60000 a that a fragment's padding rows evaluate to; phase 2 skips padding rows anyway.)
+    const bool far = !(thr >= -50000.0f && oo < 9.0e8f);
+    if (far) op = mk3(0.f, 0.f, 0.f), od = 0.0f, thr = -50000.0f;
+    thr = __builtin_fminf(thr, 60000.0f);                          // (LOWERING a threshold only adds candidates)
+    if (!active) thr = 60000.0f;
     float R[10];
     R[0] = d.x * d.x; R[1] = d.y * d.y; R[2] = d.z * d.z;
     R[3] = 2.0f * d.x * d.y; R[4] = 2.0f * d.x * d.z; R[5] = 2.0f * d.y * d.z;
@@ -423,15 +439,6 @@ __device__ __forceinline__ RayFeat make_ray_features(const float4 *P, f3 o, f3 d
     R[7] = __builtin_fmaf(a2, op.y, -od2 * d.y);
     R[8] = __builtin_fmaf(a2, op.z, -od2 * d.z);
     R[9] = -a;
-    const float margin = a * __builtin_fmaf(pm.y, ot2 + pc.w, pm.x);
-    // a ray whose line passes farther than sqrt(oo) > Rs (+ margin) from c0 still gets the generic test
-    // candidate <=> S.R > thr. The tile GEMM evaluates thr - S.R directly (sphere fragments hold -S, and
-    // slots 30/31 hold 1 x thr_hi, 1 x thr_lo), so a candidate is simply a NEGATIVE accumulator.
-    float thr = __builtin_fmaf(a, oo, -(od * od)) - margin;
-    thr -= 1.0e-6f * __builtin_fabsf(thr);                         // covers the hi/lo f16 representation of thr
-    if (!(thr == thr)) thr = -60000.0f;                            // NaN -> everything is a candidate
-    thr = __builtin_fminf(__builtin_fmaxf(thr, -60000.0f), 60000.0f);  // |S.R| < 60000 always (features <= 2304)
-    if (!active) thr = 60000.0f;
     _Float16 slot[32];
 #pragma unroll
     for (int f = 0; f < 11; ++f) {
@@ -633,13 +640,26 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // the extent of the clipped segment along the sort axis selects the tiles whose own extent overlaps it (two table
 // lookups on a grid of kCullCells cells). Approximate reciprocals are fine: every bound is padded far beyond their error, and a
 // NaN anywhere yields "no tile", which is what the reference's `discriminant > 0` does with such a ray as well.
+//
+// How far the reference's f32 arithmetic can place a hit OUTSIDE a sorted sphere depends on where the RAY starts: its
+// discriminant (sphere.rs:33-37) carries an error of <= ~1.3e-6 a (|o - c|^2 + r^2), so from |o - c| = 2000
+// it accepts lines passing ~2 units outside a sphere of radius 0.2, and the accepted point o + t d then lies within
+// sqrt(r^2 + E) of the centre. The clip box and the segment's extent along the sort axis are therefore padded PER RAY by
+//     reach = sqrt(r_min^2 + 4 * 1.3e-6 * (D^2 + r_max^2)) - r_min,   D^2 = 2 |o - c0|^2 + 2 Rs^2 >= (|o - c0| + Rs)^2 >= |o - c|^2
+// (P[13] = 2 kappa, kappa (2 Rs^2 + r_max^2) + r_min^2, r_min; kappa = 5.2e-6, the same 4x safety as the tree kernels' box
+// pad). A bounce off a huge enclosing or ground sphere far from the cloud thus widens its own mask -- up to every tile --
+// whatever the camera's position.
 __device__ __forceinline__ uint32_t lane_tile_mask(const float4 *P, const uint32_t *s_cull, f3 o, f3 d, bool active, float t_end,
                                                    uint32_t cull_axis, uint32_t cull_always) {
     const float4 bmin = P[0], bmax = P[1];   // clip_min.xyz, cull_u0 | clip_max.xyz, cull_inv_cell
+    const float4 pc = P[2], pr = P[13];      // c0.xyz | reach constants
+    const float otx = o.x - pc.x, oty = o.y - pc.y, otz = o.z - pc.z;
+    const float ot2 = __builtin_fmaf(otz, otz, __builtin_fmaf(oty, oty, otx * otx));
+    const float reach = __builtin_amdgcn_sqrtf(__builtin_fmaf(pr.x, ot2, pr.y)) * 1.000001f - pr.z;
     float t0 = 0.0f, t1 = t_end * 1.00001f + 1.0e-5f;
     bool inside = active;
     const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-    const float mn[3] = {bmin.x, bmin.y, bmin.z}, mx[3] = {bmax.x, bmax.y, bmax.z};
+    const float mn[3] = {bmin.x - reach, bmin.y - reach, bmin.z - reach}, mx[3] = {bmax.x + reach, bmax.y + reach, bmax.z + reach};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {   // branch-free slabs: an axis the ray (nearly) does not move along only asks "inside?"
         const bool flat = !(__builtin_fabsf(dd[k]) > 1.0e-12f);
@@ -653,7 +673,8 @@ __device__ __forceinline__ uint32_t lane_tile_mask(const float4 *P, const uint32
     t0 = t0 - slack, t1 = t1 + slack;
     const float ou = cull_axis == 0u ? oo[0] : (cull_axis == 1u ? oo[1] : oo[2]), du = cull_axis == 0u ? dd[0] : (cull_axis == 1u ? dd[1] : dd[2]);
     const float ua = ou + t0 * du, ub = ou + t1 * du;
-    const float lo = __builtin_fminf(ua, ub) - 1.0e-3f, hi = __builtin_fmaxf(ua, ub) + 1.0e-3f;
+    const float pad = 1.0e-3f + reach;
+    const float lo = __builtin_fminf(ua, ub) - pad, hi = __builtin_fmaxf(ua, ub) + pad;
     const float cl = __builtin_fminf(__builtin_fmaxf((lo - bmin.w) * bmax.w, 0.0f), (float)(kCullCells - 1));
     const float ch = __builtin_fminf(__builtin_fmaxf((hi - bmin.w) * bmax.w, 0.0f), (float)(kCullCells - 1));
     const uint32_t tiles = s_cull[(int)cl] & s_cull[kCullCells + (int)ch];
@@ -730,7 +751,8 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                     const uint32_t b = (uint32_t)__builtin_ctz(cur);
                     cur &= cur - 1u;
                     const int k = s_tile_sphere[slot_of(curT, b)];
-                    exact_candidate<GATED>(A, G, sphere_at_m<MOVING>(mot, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+                    if (k != 0xffff)   // (a padding row of the fragment: flagged only by rays with a = d.d well below 1)
+                        exact_candidate<GATED>(A, G, sphere_at_m<MOVING>(mot, k, sph[k], time), k, o, d, a, best, idx, best_rank);
                 }
             }
         } else if (total != 0u) {
@@ -755,10 +777,10 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
             __builtin_amdgcn_wave_barrier();
             // 3. one pair per lane and round, with the owner's ray fetched across lanes
             for (uint32_t base = 0; base < total; base += 64u) {
-                const bool valid = base + (uint32_t)lane < total;
-                const uint32_t e = valid ? w_pairs[base + lane] : 0u;
+                const uint32_t e = base + (uint32_t)lane < total ? w_pairs[base + lane] : 0xffffu;
                 const uint32_t owner = e >> 16;
                 const int k = (int)(e & 0xffffu);
+                const bool valid = k != 0xffff;   // (beyond the list, or a padding row of a fragment)
                 const f3 po = mk3(lane_fetch(owner, o.x), lane_fetch(owner, o.y), lane_fetch(owner, o.z));
                 const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));
                 const float pa = lane_fetch(owner, a);
@@ -1393,6 +1415,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         w[10] = make_float4(A.inv_ns, A.mix_prev, A.mix_new, 0.0f);
         w[11] = make_float4(A.sky.x, A.sky.y, A.sky.z, A.has_sky ? 1.0f : 0.0f);
         w[12] = make_float4(__uint_as_float(A.cull_axis), __uint_as_float(A.cull_always), __uint_as_float(A.max_depth), __uint_as_float(A.samples));
+        w[13] = make_float4(A.cull_reach[0], A.cull_reach[1], A.cull_reach[2], 0.0f);
     }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += BLK) s_pvec[k] = A.perlin_vec[k];

@@ -1563,26 +1563,14 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.cull_u0 = s->cull_u0, A.cull_inv_cell = s->cull_inv_cell;
     memcpy(A.clip_min, s->clip_min, 12), memcpy(A.clip_max, s->clip_max, 12);
     if (A.cull_axis < 3u) {
-        // How far can the reference's f32 discriminant (sphere.rs:33-37) inflate a sorted sphere for THIS camera? Its error is
-        // <= ~1.3e-6 a (|o - c|^2 + r^2); every ray origin is the lens or a point of the scene, so
-        // |o - c| <= max(|camera - c0| + lens, Rs) + Rs. A hit then lies within sqrt(r^2 + E) - r of the true sphere: the
-        // clip box is widened by that reach (4x safety), and when it nears the one cell of slack the tables carry, the
-        // launch runs every tile instead.
-        const double dx = (double)cam->origin[0] - s->c0[0], dy = (double)cam->origin[1] - s->c0[1], dz = (double)cam->origin[2] - s->c0[2];
-        const double ulen = std::sqrt((double)cam->u[0] * cam->u[0] + (double)cam->u[1] * cam->u[1] + (double)cam->u[2] * cam->u[2]);
-        const double vlen = std::sqrt((double)cam->v[0] * cam->v[0] + (double)cam->v[1] * cam->v[1] + (double)cam->v[2] * cam->v[2]);
-        const double lens = std::fabs((double)cam->lens_radius) * (ulen + vlen);
-        const double dmax = std::max(std::sqrt(dx * dx + dy * dy + dz * dz) + lens, (double)s->rs_small) + (double)s->rs_small;
-        const double E = 4.0 * 1.3e-6 * (dmax * dmax + (double)s->cull_rmax * s->cull_rmax);
-        const double reach = std::sqrt((double)s->cull_rmin * s->cull_rmin + E) - (double)s->cull_rmin;
-        if (!(reach < 0.6 * (double)s->cull_cell)) {
-            A.cull_axis = 3u;
-        } else {
-            for (int k = 0; k < 3; ++k) {
-                A.clip_min[k] = std::nextafter((float)((double)A.clip_min[k] - reach), -3.0e38f);
-                A.clip_max[k] = std::nextafter((float)((double)A.clip_max[k] + reach), 3.0e38f);
-            }
-        }
+        // Per-RAY reach of the reference's f32 discriminant error (pt_kernel.h lane_tile_mask): the kernel pads the clip box and
+        // the segment's extent along the sort axis by sqrt(r_min^2 + kappa (2 |o - c0|^2 + 2 Rs^2 + r_max^2)) - r_min for the
+        // ray at hand, so nothing here depends on where the camera is. The constants are rounded up.
+        const double kappa = 4.0 * 1.3e-6;
+        const double k1 = kappa * (2.0 * (double)s->rs_small * s->rs_small + (double)s->cull_rmax * s->cull_rmax) + (double)s->cull_rmin * s->cull_rmin;
+        A.cull_reach[0] = std::nextafter((float)(2.0 * kappa), 3.0e38f);
+        A.cull_reach[1] = std::nextafter((float)k1, 3.0e38f);
+        A.cull_reach[2] = std::nextafter(s->cull_rmin, 0.0f);
     }
     A.large = s->d_large;
     A.n_tiles = mfma ? s->n_tiles : 0u;

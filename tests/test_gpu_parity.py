@@ -739,6 +739,116 @@ def test_random_sphere_worlds_match_the_oracle(ptgpu, oracle, seed, n, spread, r
     assert np.array_equal(ref, out, equal_nan=True), _report(ref, out)
 
 
+def _far_origin_world(oracle, seed, n, W, H, spread, rmax, kind, scale, moving=False):
+    """A cloud of small spheres plus huge ones that send BOUNCE rays back at it from far away: the reference's f32
+    discriminant (sphere.rs:33-38) has an error of ~1.3e-6 |o - c|^2, so from |o - c| = 2000 it accepts rays passing
+    2 units outside a sphere of radius 0.2 -- whatever it does there the kernels must do too.
+      kind 'enclosing': the camera and the cloud inside one sphere of radius -`scale`. NEGATIVE, so that its normals point
+                        inwards (sphere.rs:42 divides by the signed radius) and it works as a concave mirror: with outward normals
+                        a Metal absorbs every ray that reaches it from inside (material.rs:76) and a Lambertian scatters outwards.
+                        Metal without fuzz (most seeds: rays from near the centre come back through the cloud, from `scale` away),
+                        fuzzy metal or lambertian.
+      kind 'offcentre': the same mirror with its centre 0.3 `scale` away from the cloud (chords return after several bounces)
+      kind 'ground':    a ground sphere of radius `scale` under the cloud, camera 50 units up
+      kind 'mirrors':   two metal spheres of radius `scale` facing each other across the cloud, 3 radii apart"""
+    if moving:   # Sphere + MovingSphere entries within +-4 (the MOVING instantiations of the sphere kernels)
+        w = _random_world(oracle, seed, n, (0, 1, 1), W, H, media=False, instances=False)
+        metal, fuzzy, lambert, spread = 6, 7, seed % 5, 4.0   # rows of _random_world's material table
+    else:
+        w = _random_sphere_world(oracle, seed, n, W, H, spread, rmax)
+        metal, fuzzy, lambert = 5, 6, seed % 4            # rows of _random_sphere_world's material table
+    rec = w["hitables"]
+    look_from, look_at = [0.3 * spread, 0.4 * spread, 1.6 * spread], [0, 0, 0]
+    if kind == "enclosing":
+        extras, mats = [[0.1 * spread, 0.0, -0.1 * spread, -scale]], [[metal, metal, metal, fuzzy, lambert][seed % 5]]
+    elif kind == "offcentre":
+        extras, mats = [[0.3 * scale, 0.05 * scale, -0.1 * scale, -scale]], [metal]
+    elif kind == "ground":
+        extras, mats = [[0.0, -scale - spread - 1.0, 0.0, scale]], [lambert if seed & 1 else metal]
+        look_from = [0.8 * spread, 50.0, 2.0 * spread]
+    else:
+        extras = [[3.0 * scale, 0.0, 0.0, scale], [-3.0 * scale, 0.5 * spread, 0.0, scale]]
+        mats = [metal, metal]
+    more = np.zeros((len(extras), 16), np.uint32)
+    more[:, 1] = mats
+    more[:, 3] = more[:, 4] = 0xffffffff
+    more[:, 6:10] = np.asarray(extras, np.float32).view(np.uint32)
+    cam = np.zeros(24, np.float32)
+    lf, la, up = (np.asarray(v, np.float32) for v in (look_from, look_at, [0, 1, 0]))
+    oracle.lib().ora_camera_new(lf.ctypes.data, la.ctypes.data, up.ctypes.data, 50.0, W / H, 0.05, float(np.linalg.norm(lf - la)), 0.0, 1.0,
+                                cam.ctypes.data)
+    return dict(w, hitables=np.concatenate([rec, more]), camera=cam)
+
+
+def _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, depth=10):
+    """Default kernel, no tile culling (1024), exact VALU scan (4 | 64) and -- list worlds the prefilter takes -- verify mode
+    (8: dropped positives and culled winners must be 0), every one against the ORACLE."""
+    osc = oracle.OracleScene.from_world(w["hitables"], w["transforms"], w["materials"], w["textures"], w["camera"], W, H, sky=w["sky"], use_bvh=bvh)
+    ex = osc.export()
+    ref, ref_rays = osc.update(S, max_depth=depth, frame_num=0)
+    sc = ptgpu.Scene(oracle.to_ptgpu_world_desc(ptgpu, ex), 0)
+    p, cam = ptgpu.PtParams(W, H, S, depth, 0, 1 if bvh else 0), ptgpu.PtCamera.from_floats(ex["camera"])
+    bad = []
+    for variant in (0, 1024, 4 | 64) + ((256,) if bvh else (8,)):
+        sc.set_tuning(0, variant)
+        if variant == 8:
+            sc.debug_counters(reset=True)
+        out = np.zeros((H, W, 3), np.float32)
+        rays = sc.update(p, cam, 0, out)
+        if rays != ref_rays or not np.array_equal(ref, out, equal_nan=True):
+            bad.append("variant %d: rays %d vs %d, %s" % (variant, rays, ref_rays, _report(ref, out)))
+        if variant == 8:
+            c = sc.debug_counters()
+            if c["misses"] != 0 or (c["exact_positives"] == 0 and len(w["hitables"]) <= 700):   # (beyond 768 spheres: the tree kernel)
+                bad.append("verify mode: %r" % (c,))
+    sc.close()
+    return bad
+
+
+@pytest.mark.parametrize("kind,scale", [("enclosing", 2.0e2), ("enclosing", 2.0e3), ("enclosing", 2.0e4), ("enclosing", 2.0e5), ("enclosing", 3.0e6),
+                                        ("offcentre", 3.0e2), ("offcentre", 1.0e4), ("ground", 1.0e4), ("ground", 1.0e5), ("mirrors", 1.0e3), ("mirrors", 3.0e4)])
+@pytest.mark.parametrize("bvh", [False, True])
+def test_far_ray_origins_keep_prefilter_and_tile_culling_exact(ptgpu, oracle, kind, scale, bvh):
+    """Bounce origins far outside the cloud (off an enclosing sphere, a huge ground, two distant mirrors): the default MFMA
+    kernel with tile culling, the same without culling, the exact scan and verify mode all equal the ORACLE bit for bit.
+    The per-ray reach of lane_tile_mask and the far-ray path of make_ray_features are what this pins."""
+    W, H, S = 128, 96, 4
+    w = _far_origin_world(oracle, 31, 300, W, H, 6.0, 0.3, kind, scale)     # (seed 31: the enclosing sphere is a plain mirror)
+    bad = _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, depth=25 if kind == "offcentre" else 10)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("scale", [3.0e2, 3.0e4, 3.0e6])
+@pytest.mark.parametrize("bvh", [False, True])
+def test_far_ray_origins_with_moving_spheres(ptgpu, oracle, scale, bvh):
+    """The same concave mirror around a world of Sphere + MovingSphere entries: the MOVING instantiations' swept prefilter
+    bounds and swept tree boxes under far bounce origins."""
+    W, H, S = 96, 64, 3
+    w = _far_origin_world(oracle, 41, 200, W, H, 4.0, 0.7, "enclosing", scale, moving=True)
+    bad = _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("first", [90000, 90040])
+def test_fuzz_slice_of_far_origin_worlds(ptgpu, oracle, first):
+    """40 seeded worlds per slice of the far-origin kind (tools/fuzz_worlds.py kind 3): cloud size, spread, radius range,
+    the huge spheres' kind and scale (10^2.5 .. 10^6.5) all drawn from the seed; list and BVH, every kernel path vs the oracle."""
+    W, H, S = 64, 48, 2
+    bad = []
+    for seed in range(first, first + 40):
+        rng = np.random.default_rng(seed)
+        n = int(rng.choice([40, 150, 400, 700, 900]))
+        kind = ["enclosing", "enclosing", "offcentre", "ground", "mirrors"][int(rng.integers(0, 5))]
+        scale = float(10.0 ** rng.uniform(2.5, 6.5))
+        spread, rmax = float(rng.uniform(2, 15)), float(rng.uniform(0.1, 1.0))
+        depth = int(rng.choice([2, 10, 10, 25]))
+        w = _far_origin_world(oracle, seed, n, W, H, spread, rmax, kind, scale)
+        for bvh in (False, True):
+            for msg in _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, depth=depth):
+                bad.append((seed, kind, scale, bvh, msg))
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("bvh", [False, True])
 def test_unpackable_tree_falls_back_to_the_binary_tree(ptgpu, oracle, bvh):
     """A node whose pad constants do not fit the packed format (radii of 2e-5 inside a scene 2000 units wide: 6e-6 / r_min x
