@@ -147,6 +147,7 @@ struct KArgs {
     // sharding: rows y with y % shard_count == shard_index, compact buffer
     uint32_t shard_index, shard_count, local_rows;
     uint32_t tiles_x, n_items;  // 8x8 tiles over (width x local_rows); n_items = tiles * 64
+    uint32_t tiles_x_magic;     // floor(2^32 / tiles_x): tile / tiles_x = umulhi(tile, magic) (+ 1 after one correction step)
     // outputs / work queue
     float *rgb;
     unsigned long long *ray_count;
@@ -1375,6 +1376,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const uint32_t wave_id = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: lives in a scalar register
 
     if (!BVH && SPH_LDS) {
         for (uint32_t k = tid; k < A.n_spheres_pad; k += BLK) s_sph[k] = A.spheres_r2[k];
@@ -1448,7 +1450,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 #define PT_SEC(i) do { } while (0)
 #endif
     bool have = false, exhausted = false, need_cam = true, trav_new = false, finished = false;
-    uint32_t lane_tile = 0, pix_rays = 0;
+    uint32_t pix_rays = 0;
     BvhTrav trav{0u, 0u, 0, kMaxT, -1, 0u, false};
     Trav4 trav4{0u, 0u, 0, kNoChild4, 0u, kMaxT, false};
     // per-lane bookkeeping, packed (every register counts: the 4-waves-per-SIMD kernels are compiled for 128 VGPRs):
@@ -1511,7 +1513,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     out[1] = out[1] * pf.y + col.y * pf.z;
                     out[2] = out[2] * pf.y + col.z * pf.z;
                 }
-                if (PILOT || A.tile_cost) atomicAdd(&A.tile_cost[lane_tile], pix_rays);   // (frame kernels: the NEXT frame's work order)
+                // (frame kernels: the NEXT frame's work order; the pixel's work tile is recomputed from its coordinates)
+                if (PILOT || A.tile_cost) atomicAdd(&A.tile_cost[((pxy >> 16) >> kTileLog2) * A.tiles_x + ((pxy & 0xffffu) >> kTileLog2)], pix_rays);
             }
             const unsigned long long m = __ballot(1);
             const int leader = __ffsll((long long)m) - 1;
@@ -1521,14 +1524,14 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 // as the last ones ("The end of a frame"). The head of the heavy-first list -- the pixels whose
                 // serial sample chains decide when the frame ends -- therefore goes to them: a wave's first 64 items are fixed by
                 // its age class (wave >> 2) instead of by the race for the counter, which starts behind these items.
-                const uint32_t wv = (uint32_t)(tid >> 6), cls = wv >> 2, idx = blockIdx.x * 4u + (wv & 3u);
+                const uint32_t wv = wave_id, cls = wv >> 2, idx = blockIdx.x * 4u + (wv & 3u);
                 base = (cls * gridDim.x * 4u + idx) * 64u;
             } else {
                 if (lane == leader) base = atomicAdd(A.work_counter, (uint32_t)__popcll(m));
-                base = __shfl(base, leader) + A.first_static;
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader) + A.first_static;
             }
             first_claim = false;
-            const uint32_t item = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            const uint32_t item = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // lanes of m below this one
             if (item >= A.n_items) {
                 exhausted = true;
 #ifdef PT_WAVE_DETAIL
@@ -1537,10 +1540,13 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             } else {
                 const uint32_t in = item & (kTilePix - 1u);
                 const uint32_t tile = A.tile_order ? A.tile_order[item >> (2u * kTileLog2)] : (item >> (2u * kTileLog2));
-                lane_tile = tile;
                 pix_rays = 0;
-                const uint32_t x = (tile % A.tiles_x) * kTileSide + (in & (kTileSide - 1u));
-                const uint32_t ly = (tile / A.tiles_x) * kTileSide + (in >> kTileLog2);
+                // tile / tiles_x by the host's magic (a u32 division costs ~25 instructions and a hoisted reciprocal register):
+                // umulhi underestimates the quotient by at most one for any tile < 2^32
+                uint32_t trow = __umulhi(tile, A.tiles_x_magic), tcol = tile - trow * A.tiles_x;
+                if (tcol >= A.tiles_x) trow += 1u, tcol -= A.tiles_x;
+                const uint32_t x = tcol * kTileSide + (in & (kTileSide - 1u));
+                const uint32_t ly = trow * kTileSide + (in >> kTileLog2);
                 // (the list kernels' cost-estimation pilot samples one pixel per 2x2 block: a quarter of the rays orders
                 //  the tiles as well as all of them did and costs 0.2 ms less; the tree kernels keep every pixel, measured)
                 if (x < A.width && ly < A.local_rows && !(PILOT && A.phase == 0u && !BVH && ((x | ly) & 1u))) {
@@ -1759,7 +1765,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     // at slot d - 1
                     if (PAL) {
                         if (PT_DEPTH == 0u) att0c = attc;
-                        else s_pal[(PT_DEPTH - 1u) * BLK + tid] = (uint16_t)attc;
+                        else (s_pal + tid)[(PT_DEPTH - 1u) * BLK] = (uint16_t)attc;
                     } else if (WST) {
                         if (PT_DEPTH == 0u) att0c = attc;
                         else path_st(PT_DEPTH - 1u, __uint_as_float(attc));
@@ -1784,10 +1790,15 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 if (PAL) {
                     // three levels per trip: the codes, then the colours, are fetched together (two LDS round trips per
                     // trip instead of two per level); the products keep the innermost-first order
+                    // (the lane's column is re-derived here, behind an opaque copy: hoisted out of the main loop this address is one
+                    //  register too many for the 128 the kernel may use, and it was the last value the compiler spilled)
+                    uint32_t tid_here = (uint32_t)tid;
+                    asm volatile("" : "+v"(tid_here));
+                    const uint16_t *my_pal = s_pal + tid_here;
                     for (int k = (int)PT_DEPTH - 1; k >= 1; k -= 3) {
-                        const uint32_t ca = s_pal[(uint32_t)(k - 1) * BLK + tid];
-                        const uint32_t cb = s_pal[(uint32_t)(k >= 2 ? k - 2 : 0) * BLK + tid];
-                        const uint32_t cc = s_pal[(uint32_t)(k >= 3 ? k - 3 : 0) * BLK + tid];
+                        const uint32_t ca = my_pal[(uint32_t)(k - 1) * BLK];
+                        const uint32_t cb = my_pal[(uint32_t)(k >= 2 ? k - 2 : 0) * BLK];
+                        const uint32_t cc = my_pal[(uint32_t)(k >= 3 ? k - 3 : 0) * BLK];
                         const f3 qa3 = palette_colour(ca), qb3 = palette_colour(cb), qc3 = palette_colour(cc);
                         V = mk3(0.0f + qa3.x * V.x, 0.0f + qa3.y * V.y, 0.0f + qa3.z * V.z);
                         if (k >= 2) V = mk3(0.0f + qb3.x * V.x, 0.0f + qb3.y * V.y, 0.0f + qb3.z * V.z);
@@ -1828,10 +1839,10 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&A.debug[16 + i], sec_t[i]);
     if (A.wave_end && lane == 0)
-        for (int q = 0; q < 8; ++q) A.wave_end[(5 + q) * (gridDim.x * (BLK / 64)) + blockIdx.x * (BLK / 64) + (tid >> 6)] = sec_t[q];
+        for (int q = 0; q < 8; ++q) A.wave_end[(5 + q) * (gridDim.x * (BLK / 64)) + blockIdx.x * (BLK / 64) + wave_id] = sec_t[q];
 #endif
     if (A.wave_end && lane == 0) {
-        const uint32_t w = blockIdx.x * (BLK / 64) + (tid >> 6), nw = gridDim.x * (BLK / 64);
+        const uint32_t w = blockIdx.x * (BLK / 64) + wave_id, nw = gridDim.x * (BLK / 64);
         A.wave_end[w] = wall_clock64();
         // (per-lane values of lane 0 would miss other lanes' exhaustion: take the wave's earliest)
 #ifdef PT_WAVE_DETAIL

@@ -43,6 +43,7 @@ struct WArgs {
     uint64_t seed_base;
     uint32_t shard_index, shard_count, local_rows;
     uint32_t tiles_x, n_items;
+    uint32_t tiles_x_magic;
     float *rgb;
     unsigned long long *ray_count;
     uint32_t *work_counter;

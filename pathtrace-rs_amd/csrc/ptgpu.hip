@@ -1348,6 +1348,7 @@ void fill_frame_args(Args &X, const pt_scene *s, const pt_params *params, const 
     X.shard_count = shard_count;
     X.local_rows = pt_shard_rows(params->height, shard_index, shard_count);
     X.tiles_x = (params->width + kTileSide - 1u) / kTileSide;
+    X.tiles_x_magic = X.tiles_x > 1u ? (uint32_t)(0x100000000ull / X.tiles_x) : 0xffffffffu;   // (tiles_x == 1: umulhi gives tile - 1 for tile > 0, corrected by the kernel's one step)
     X.n_items = X.tiles_x * ((X.local_rows + kTileSide - 1u) / kTileSide) * kTilePix;
     X.rgb = d_rgb;
     X.ray_count = reinterpret_cast<unsigned long long *>(d_ray_count);
