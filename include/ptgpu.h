@@ -14,10 +14,13 @@
  * All functions return PT_OK (0) or a PT_ERR_* code and never throw or abort;
  * pt_last_error() returns a thread-local message for the last failure.
  *
- * Threading: thread-compatible. One in-flight render per pt_scene handle
- * (same contract as Scene::update(&self) being called from one thread,
- * offline.rs:29 / glium_window.rs:102). Distinct handles may be used from
- * distinct threads.
+ * Threading: thread-compatible. ONE frame in flight per pt_scene handle, on ONE
+ * stream at a time (same contract as Scene::update(&self) being called from one
+ * thread, offline.rs:29 / glium_window.rs:102): a handle owns per-frame device
+ * state (parked pixel streams of a two-launch frame, tile costs, the work
+ * counter), so frames of one handle enqueued on different streams must be
+ * ordered by the caller. Distinct handles may be used from distinct threads
+ * and streams (bench.py's pipelined frames use two).
  */
 #ifndef PTGPU_H
 #define PTGPU_H
@@ -250,6 +253,10 @@ int pt_comm_create(const uint8_t id[PT_COMM_ID_BYTES], uint32_t rank, uint32_t w
 /* ncclCommInitAll: `n` communicators of one process, comms_out[i] on devices[i] (rank i). */
 int pt_comm_create_all(const int *devices, uint32_t n, pt_comm **comms_out);
 void pt_comm_destroy(pt_comm *comm);
+/* The RCCL the pt_comm_* functions run on: it is resolved at run time, the first time one of them is called -- the copy the
+ * process has already loaded (a PyTorch process carries its own) or else the system's librccl.so.1; the render entry points
+ * never need it. version_code = ncclGetVersion (e.g. 22606), path = the shared object. PT_ERR_UNSUPPORTED when there is none. */
+int pt_comm_runtime(int *version_code_out, char *path_out, size_t path_capacity);
 int pt_comm_rank(const pt_comm *comm, uint32_t *rank_out, uint32_t *world_out);
 
 /* The exchange step alone, asynchronous on `hip_stream`: d_rgb_shard is this rank's compact shard as
@@ -312,15 +319,32 @@ int pt_scene_debug_tree_packed(pt_scene *scene, void *nodes_out, size_t capacity
  * 256 = use_bvh worlds always walk the internal tree (default: the MFMA list kernel + ancestor gate when it fits),
  * 1024 = the MFMA kernels run every sphere tile for every wave (no tile culling),
  * 2048 = the tree kernels walk the binary internal tree (host-built) instead of the 4-wide one,
- * 4096 = the wide MFMA kernels keep 768 threads per workgroup,
  * 8192 = every frame measures its own work order. Default: a frame of the SAME view as the scene's last one (equal pt_params,
  *        pt_camera and shard) is ordered by the rays each tile took in that last frame, measured by the frame kernel itself;
- *        the order of the work never changes a pixel or the ray count,
- * 16384 = frames of a new view always use the throw-away 1-spp pilot pass (general worlds: natural order). Default (from 12
- *        samples on): the frame runs as two launches, the first tracing the first sample of every pixel for real while it
- *        counts the rays per tile,
- * 32768 = the 16-wave kernels' first fetches race for the work counter (default: handed out by wave age class, oldest waves first). */
+ *        a frame of a new view (from 12 samples on) runs as two launches, the first tracing the first sample of every pixel for
+ *        real while it counts the rays per tile. The order of the work never changes a pixel or the ray count.
+ * (Bits 4096, 16384 and 32768 of earlier versions were A/B switches of settled questions and are ignored.) */
 int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
+
+/* Which kernel a frame runs on, and with what geometry (csrc/pt_select.h; DESIGN.md "kernel selection"). family: 0 general-world
+ * kernel, 1 binary-tree kernel, 2 4-wide tree kernel, 3 MFMA list kernel, 4 exact scan from LDS, 5 exact scan from HBM/L2. */
+typedef struct pt_kernel_choice {
+    uint32_t family, block, lds_bytes, blocks_per_cu; /* threads per workgroup, dynamic LDS per workgroup, resident workgroups per CU (before the register clamp) */
+    uint32_t moving, gate, verify, ref_bvh;           /* MOVING / GATE / VERIFY instantiation; BVHNode::ray_hit semantics */
+    uint32_t ordered;                                 /* heavy-first work order (two launches for a new view) */
+    uint32_t stack_in_lds, global_stack, n_tiles;     /* attenuation-stack slots in LDS, some levels in HBM, MFMA tiles */
+    uint32_t world_hit_lds, world_occ, world_media;   /* general-world kernel: <BVH = ref_bvh, HIT_LDS, OCC, MEDIA> */
+    uint32_t refill_min;
+    char name[96];
+} pt_kernel_choice;
+/* The choice the scene's most recent render made. */
+int pt_last_kernel_choice(pt_scene *scene, pt_kernel_choice *out);
+/* The choice pt_render* WOULD make for a description (exactly one of sphere_desc / world_desc), computed on the host alone:
+ * no device is touched, so the selection table can be checked on a machine without a GPU (tests/test_host_cpu.py).
+ * shard_count > 1 selects for one shard of a multi-GPU frame. */
+int pt_debug_select(const pt_scene_desc *sphere_desc, const pt_world_desc *world_desc, const pt_params *params,
+                    const pt_camera *camera, uint32_t shard_count, uint32_t blocks_per_cu, uint32_t variant,
+                    pt_kernel_choice *out);
 
 /* Verify-mode counters of the MFMA prefilter (variant bit 8): out4 = { exact-positive pairs the
  * prefilter failed to flag (must be 0), queued candidates, queue-overflow fallbacks, exact-positive

@@ -1,0 +1,278 @@
+// pt_api.hip -- the small entry points of the C ABI: errors, identification, tuning, timing and debug getters, the device
+// self-test probes, and pt_debug_select (kernel selection for a description, no GPU needed).
+#include "pt_device.h"
+#include "pt_host.h"
+#include "pt_world.h"   // logf_ref (the probe of constant_medium.rs:60's ln)
+
+using namespace pthostside;
+
+namespace pthostside {
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+const char *last_error_message() { return g_err; }
+
+const DevKnobs &dev_knobs() {
+    static const DevKnobs k = [] {
+        DevKnobs d;
+#ifdef PT_DEVKNOBS
+        if (const char *e = getenv("PTGPU_REFILL")) d.refill = atoi(e);
+        if (const char *e = getenv("PTGPU_READY")) d.ready = atoi(e);
+        if (const char *e = getenv("PTGPU_DRAIN")) d.drain = atoi(e);
+        if (const char *e = getenv("PTGPU_PHASE1_REFILL")) d.phase1_refill = std::max(1, atoi(e));
+        if (const char *e = getenv("PTGPU_CULL_AXIS")) d.cull_axis = atoi(e);
+        if (const char *e = getenv("PTGPU_HOST_THREADS")) d.host_threads = std::max(0, atoi(e));
+        if (const char *e = getenv("PTGPU_BLOCKS_PER_CU")) d.blocks_per_cu = (uint32_t)atoi(e);
+        if (const char *e = getenv("PTGPU_VARIANT")) d.variant = (uint32_t)atoi(e);
+        d.world_occ3 = getenv("PTGPU_WORLD_OCC3") != nullptr;
+        d.debug = getenv("PTGPU_DEBUG") != nullptr;
+        d.clamp_grid = getenv("PTGPU_CLAMP_GRID") != nullptr;
+        d.timing = getenv("PTGPU_TIMING") != nullptr;
+#endif
+        return d;
+    }();
+    return k;
+}
+
+}  // namespace pthostside
+
+extern "C" const char *pt_last_error(void) { return last_error_message(); }
+extern "C" const char *pt_version(void) { return "ptgpu 0.3 gfx950"; }
+
+extern "C" int pt_device_count(int *count_out) {
+    if (!count_out) return fail(PT_ERR_INVALID_ARG, "count_out is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count_out = 0;
+        return fail(PT_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count_out = n;
+    return PT_OK;
+}
+
+extern "C" uint32_t pt_shard_rows(uint32_t height, uint32_t shard_index, uint32_t shard_count) {
+    if (shard_count == 0 || shard_index >= shard_count || height <= shard_index) return 0;
+    return (height - shard_index + shard_count - 1) / shard_count;
+}
+
+extern "C" int pt_scene_set_seed_base(pt_scene *s, uint64_t seed_base) {
+    if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
+    s->seed_base = seed_base;
+    return PT_OK;
+}
+
+extern "C" int pt_scene_set_tuning(pt_scene *s, uint32_t blocks_per_cu, uint32_t variant) {
+    if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
+    s->blocks_per_cu = blocks_per_cu;
+    s->variant = variant;
+    return PT_OK;
+}
+
+extern "C" int pt_last_kernel_ms(pt_scene *s, float *ms_out) {
+    if (!s || !ms_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (!s->ev_valid) return fail(PT_ERR_INVALID_ARG, "no render has been launched on this scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms_out, s->ev_start, s->ev_stop));
+    return PT_OK;
+}
+
+extern "C" int pt_last_pass_ms(pt_scene *s, float *ms_out) {
+    if (!s || !ms_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (!s->ev_valid) return fail(PT_ERR_INVALID_ARG, "no render has been launched on this scene");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventSynchronize(s->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms_out, s->ev_pass, s->ev_stop));
+    return PT_OK;
+}
+
+extern "C" int pt_scene_build_info(pt_scene *s, float *build_ms_out, uint32_t *n_nodes_out, uint32_t *depth_out, uint32_t *on_device_out) {
+    if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
+    if (build_ms_out) *build_ms_out = s->tree_build_ms;
+    if (n_nodes_out) *n_nodes_out = s->tr.n_nodes4;
+    if (depth_out) *depth_out = s->tr.depth4;
+    if (on_device_out) *on_device_out = s->tree_on_device ? 1u : 0u;
+    return PT_OK;
+}
+
+extern "C" int pt_scene_debug_tree(pt_scene *s, void *nodes_out, size_t capacity_bytes) {
+    if (!s || !nodes_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    const size_t bytes = (size_t)s->tr.n_nodes4 * sizeof(DNode4);
+    if (capacity_bytes < bytes) return fail(PT_ERR_INVALID_ARG, "buffer holds %zu bytes, the tree has %zu", capacity_bytes, bytes);
+    HIP_TRY(hipSetDevice(s->device));
+    if (bytes) HIP_TRY(hipMemcpy(nodes_out, s->d_nodes4, bytes, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+extern "C" int pt_scene_debug_tree_packed(pt_scene *s, void *nodes_out, size_t capacity_bytes, uint32_t *usable_out) {
+    if (!s || !nodes_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    const size_t bytes = s->d_nodes4q ? (size_t)s->tr.n_nodes4 * sizeof(DNode4Q) : 0;
+    if (capacity_bytes < bytes) return fail(PT_ERR_INVALID_ARG, "buffer holds %zu bytes, the packed tree has %zu", capacity_bytes, bytes);
+    HIP_TRY(hipSetDevice(s->device));
+    if (bytes) HIP_TRY(hipMemcpy(nodes_out, s->d_nodes4q, bytes, hipMemcpyDeviceToHost));
+    if (usable_out) *usable_out = s->tr.tree4_packed ? 1u : 0u;
+    return PT_OK;
+}
+
+extern "C" int pt_last_launch_info(pt_scene *s, uint32_t *grid_out, uint32_t *block_out, uint32_t *lds_bytes_out) {
+    if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
+    if (grid_out) *grid_out = s->last_grid;
+    if (block_out) *block_out = s->last_block;
+    if (lds_bytes_out) *lds_bytes_out = s->last_lds;
+    return PT_OK;
+}
+
+namespace {
+void fill_choice(const ptsel::KernelChoice &c, pt_kernel_choice *out) {
+    memset(out, 0, sizeof *out);
+    out->family = (uint32_t)c.family;
+    out->block = c.block, out->lds_bytes = c.lds_bytes, out->blocks_per_cu = c.bpc;
+    out->moving = c.moving, out->gate = c.gate, out->verify = c.verify, out->ref_bvh = c.ref_bvh;
+    out->ordered = c.order == ptsel::Order::Measured;
+    out->stack_in_lds = c.stack_in_lds, out->global_stack = c.gstack, out->n_tiles = c.n_tiles;
+    out->world_hit_lds = c.world_hit_lds, out->world_occ = c.world_occ, out->world_media = c.world_media;
+    out->refill_min = c.refill_min;
+    kernel_name(c, out->name, sizeof out->name);
+}
+}  // namespace
+
+extern "C" int pt_last_kernel_choice(pt_scene *s, pt_kernel_choice *out) {
+    if (!s || !out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    fill_choice(s->last_choice, out);
+    return PT_OK;
+}
+
+// Kernel selection for a DESCRIPTION, without a device: the host half of pt_scene_create* (pt_prep.hip; the 4-wide tree's
+// size comes from the host restatement of the device build, which tests prove identical) followed by pt_select.h.
+extern "C" int pt_debug_select(const pt_scene_desc *sphere_desc, const pt_world_desc *world_desc, const pt_params *params, const pt_camera *camera,
+                               uint32_t shard_count, uint32_t blocks_per_cu, uint32_t variant, pt_kernel_choice *out) {
+    if ((!sphere_desc) == (!world_desc) || !params || !camera || !out) return fail(PT_ERR_INVALID_ARG, "exactly one description, params, camera and out are required");
+    if (shard_count == 0) shard_count = 1;
+    ptsel::SceneTraits tr;
+    WorldAsSpheres W;
+    const pt_scene_desc *sd = sphere_desc;
+    const MotionIn *motion = nullptr;
+    if (world_desc) {
+        if (int rc = analyze_world(world_desc, W)) return rc;
+        if (W.sphere_like) sd = &W.desc, motion = W.all_spheres ? nullptr : W.motion.data();
+    }
+    bool planned = false;
+    double plan_t_lo = 0.0, plan_t_hi = 0.0;
+    if (sd && sd->n_spheres) {
+        SpherePlan P;
+        const int rc = plan_sphere_scene(sd, motion, P);
+        if (rc == PT_OK) {
+            tr = P.tr, plan_t_lo = P.t_lo, plan_t_hi = P.t_hi;
+            if (!P.titems.empty()) {
+                const Tree4Host t4 = tree4_build_host(P.titems);
+                tr.n_nodes4 = (uint32_t)t4.nodes.size(), tr.depth4 = t4.depth;
+                tr.tree4_packed = true;
+                for (const DNode4 &w : t4.nodes) {
+                    DNode4Q q;
+                    if (!tree_pack_node(w, q)) tr.tree4_packed = false;
+                }
+            }
+            if (world_desc) tr.n_hitables = world_desc->n_hitables, tr.n_world_xf = world_desc->n_transforms, tr.ref_bvh_depth = W.ref_depth;
+            planned = true;
+        } else if (!(world_desc && rc == PT_ERR_UNSUPPORTED)) {
+            return rc;
+        }
+    }
+    if (!planned) {
+        if (!world_desc) {   // an empty sphere scene is an empty world
+            tr = ptsel::SceneTraits{};
+            tr.is_world = true;
+            tr.has_caller_bvh = sphere_desc->n_bvh_nodes != 0;
+        } else {
+            world_traits(world_desc, W, tr);
+        }
+    }
+    if (params->use_bvh && !tr.has_caller_bvh) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the description has no BVH nodes");
+    ptsel::Knobs knobs;
+    knobs.variant = variant, knobs.blocks_per_cu = blocks_per_cu;
+    const uint32_t local_rows = pt_shard_rows(params->height, 0, shard_count);
+    ptsel::KernelChoice c;
+    ptsel::select_kernel(tr, *params, camera->time0, camera->time1, local_rows, knobs, 4u, c);
+    if (c.needs_binary_tree && tr.bin_depth == 0 && sd) {
+        const AccelBuild acc = build_accel(sd, motion, plan_t_lo, plan_t_hi);
+        tr.bin_depth = acc.depth, tr.bin_nodes = (uint32_t)acc.nodes.size();
+        ptsel::select_kernel(tr, *params, camera->time0, camera->time1, local_rows, knobs, 4u, c);
+    }
+    fill_choice(c, out);
+    return PT_OK;
+}
+
+// ---- device self-test probes ---------------------------------------------------
+namespace {
+__global__ void probe_kernel(uint32_t probe, const float *in, float *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    float r = 0.f, s, c;
+    switch (probe) {
+    case PT_PROBE_POW5: r = pow5_ref(x); break;
+    case PT_PROBE_SIN: sinf_cosf_ref(x, s, c); r = s; break;
+    case PT_PROBE_COS: sinf_cosf_ref(x, s, c); r = c; break;
+    case PT_PROBE_LN: r = logf_ref(x); break;
+    default: {
+        Rng rng;
+        rng_seed_from_u64(rng, (uint64_t)__float_as_uint(x));
+        for (size_t k = 0; k <= (i & 15); ++k) r = rng_f32(rng);
+    }
+    }
+    out[i] = r;
+}
+}  // namespace
+
+extern "C" int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n) {
+    if (!in || !out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (probe > PT_PROBE_LN) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
+    if (n == 0) return PT_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
+    HIP_TRY(hipSetDevice(device));
+    float *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_in, n * sizeof(float)));
+    if (hipMalloc((void **)&d_out, n * sizeof(float)) != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(PT_ERR_HIP, "hipMalloc failed");
+    }
+    hipError_t e = hipMemcpy(d_in, in, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(probe_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, probe, d_in, d_out, n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(PT_ERR_HIP, "probe failed: %s", hipGetErrorString(e));
+    return PT_OK;
+}
+
+extern "C" int pt_scene_traversal_counters(pt_scene *s, uint64_t out2[2], int reset) {
+    if (!s || !out2) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out2, s->d_debug + 8, 16, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(s->d_debug + 8, 0, 16));
+    return PT_OK;
+}
+
+extern "C" int pt_scene_debug_counters(pt_scene *s, uint64_t out4[4], int reset) {
+    if (!s || !out4) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out4, s->d_debug, 32, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(s->d_debug, 0, 1024));
+    return PT_OK;
+}

@@ -12,15 +12,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "pt_args.h"
+
 namespace ptdev {
 
 constexpr float kMaxT = 3.40282346638528859812e+38f;  // scene.rs:15 f32::MAX
 constexpr float kMinT = 0.001f;                       // scene.rs:16
 constexpr float kPi = 3.14159274101257324f;           // f32::consts::PI
 
-struct f3 {
-    float x, y, z;
-};
 
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 __device__ __forceinline__ f3 add3(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }

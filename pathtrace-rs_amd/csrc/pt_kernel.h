@@ -16,149 +16,12 @@
 // accept/reject decision reproduced by a slab test on each sphere's parent AABB in the caller's tree.
 // DESIGN.md section 4 has the derivations and the error budget.
 #pragma once
+#include "pt_args.h"
 #include "pt_device.h"
 #include "pt_tree4.h"
 #include "ptgpu.h"
 
 namespace ptdev {
-
-#ifndef PT_BLOCK
-#define PT_BLOCK 256
-#endif
-#ifndef PT_MINWAVES
-#define PT_MINWAVES 2
-#endif
-#ifndef PT_TREE4_WAVES
-#define PT_TREE4_WAVES 4   // waves per SIMD the 4-wide tree kernels are compiled for (128 VGPRs)
-#endif
-#ifndef PT_TILE_LOG2
-#define PT_TILE_LOG2 3
-#endif
-constexpr uint32_t kTileLog2 = PT_TILE_LOG2;             // work tiles are (1 << kTileLog2)^2 pixels
-constexpr uint32_t kTileSide = 1u << kTileLog2, kTilePix = kTileSide * kTileSide;
-constexpr int kBlock = PT_BLOCK;  // threads per workgroup (the main loop never synchronises across waves)
-constexpr int kBvhStack = 32;    // per-lane traversal stack entries (LDS)
-
-struct DMat {  // 32 B
-    uint32_t kind;
-    float a0, a1, a2;
-    float param;
-    int32_t tex;
-    float pad0, pad1;
-};
-struct DTex {  // 32 B
-    uint32_t kind;
-    float c0, c1, c2;
-    int32_t odd, even;
-    float scale;
-    float pad;
-};
-struct DWideNode;
-
-// Per-sphere shading record: everything Material::scatter / emitted needs for the common cases, resolved at
-// scene creation so a hit costs one 64-byte fetch instead of the dependent chain
-// sphere -> material index -> material -> texture (-> checker children).
-//   q0 = (cx, cy, cz, radius)   q1 = (kind, flags, texture id, param as float bits)
-//   q2 = colour A (constant albedo / metal albedo / emitted constant / checker ODD)   q3 = checker EVEN colour
-constexpr uint32_t kShadeConst = 1u;    // texture is Constant: colour A
-constexpr uint32_t kShadeChecker2 = 2u; // texture is Checker of two Constants: odd = A, even = q3
-constexpr uint32_t kShadeNoise = 4u;    // texture is Noise: scale in A.x (texture.rs:86-89)
-
-struct DCamera {  // camera.rs:8-19
-    f3 origin, lower_left_corner, horizontal, vertical, u, v, w;
-    float time0, time1, lens_radius;
-};
-
-// Frame parameters the main loop needs in vector registers are staged in LDS once per workgroup (one ds_read_b128 per
-// group where they are used). Left as kernel arguments they are ~45 SGPRs that the compiler keeps live across the whole
-// loop and spills into VGPR lanes (v_readlane / v_writelane around every use).
-//   [0] clip_min.xyz, cull_u0   [1] clip_max.xyz, cull_inv_cell   [2] c0.xyz, rs2   [3] m0, gamma, inv_nx, inv_ny
-//   [4..9] DCamera (24 floats, camera.rs:8-19 order)   [10] inv_ns, mix_prev, mix_new, -   [11] sky.xyz, has_sky
-//   [12] as u32 bits: cull_axis, cull_always, max_depth, samples   [13] tile culling's per-ray reach: 2 kappa, kappa (2 Rs^2 + r_max^2) + r_min^2, r_min, -
-constexpr uint32_t kLdsParamBytes = 14u * 16u;
-
-constexpr int kCullCells = 256;   // resolution of the tile-culling lookup along the sort axis
-
-struct KArgs {
-    // scene (HBM resident)
-    const float4 *spheres;       // cx, cy, cz, radius
-    const float4 *shade;         // [4*n_spheres] per-sphere shading record (DShadeRec): ONE 64-byte fetch per hit
-    const float4 *spheres_r2;    // cx, cy, cz, radius*radius (sphere.rs:36), scan layout, padded to n_spheres_pad
-    const uint32_t *sphere_mat;  // material index per sphere
-    const float4 *motion;        // MOVING kernels: [2*n_spheres] (dx, dy, dz, inv_time_delta), (time_start, is_moving, -, -)
-    const DMat *mats;
-    const DTex *texs;
-    const float4 *perlin_vec;    // 256 gradients (xyz, pad)
-    const uint32_t *perlin_perm; // 768 entries: perm_x | perm_y | perm_z
-    const DWideNode *wnodes;  // binary internal tree (variant bit 2048): children's AABBs inside the parent
-    const DNode4Q *nodes4;    // 4-wide internal tree (default of the tree kernels) as packed 64-byte nodes, root = node 0
-    const float4 *slotrec;    // its leaves: [4 * (node * 4 + slot)] = sphere | gate min, chain count | gate max, chain offset | (rank bits, sphere index): ONE 64-byte fetch per exact test
-    const uint32_t *rank_sphere;     // BVH worlds: sphere of each DFS leaf rank (inverse of leaf_rank; decodes the hit key)
-    const float4 *shade_rank;        // BVH worlds, 4-wide tree: the shading records in DFS-rank order (the hit key carries the rank)
-    const uint32_t *leaf_rank;       // DFS (lhs before rhs) order of each sphere's leaf, for equal-t ties
-    float root_min[3], root_max[3];
-    uint32_t n_nodes, nodes_in_lds, bvh_stack_entries;
-    // BVH mode acceleration structure built by pt_scene_create (the caller's tree only defines the RESULT)
-    const float4 *gate;          // [2*n_spheres] AABB (min, max) of each sphere's parent node in the caller's tree;
-                                 // .w of the pair = count / offset of further ancestors in gate_chain (count ~0: never hit)
-    const float4 *gate_chain;    // ancestors whose test is not implied by the box below them (inverted boxes only)
-    const uint32_t *bvh_large;   // spheres kept out of the internal tree (huge radius): tested for every ray
-    uint32_t n_bvh_large;
-    uint32_t n_spheres;
-    uint32_t n_spheres_pad;      // multiple of kScanUnroll; padding entries can never be hit
-    // MFMA discriminant prefilter (list mode, see "MFMA prefilter" below); n_tiles == 0 disables it
-    const uint4 *afrag;          // [n_tiles][2 chunks][64 lanes] x 8 f16: sphere-feature A fragments
-    const uint16_t *tile_sphere; // [n_tiles*32] sphere index of each fragment row, 0xffff = padding
-    const uint32_t *large;       // spheres outside the prefilter's range: tested exactly for every ray
-    uint32_t n_tiles, n_large;
-    float c0[3];                 // feature-space origin (f32-exact), radius bound of the prefiltered set
-    float rs2;                   // Rs^2, Rs >= max(|c - c0| + |r|) over prefiltered spheres
-    float m0, gamma;             // margin = a * (m0 + gamma * (|o - c0|^2 + Rs^2))
-    // tile culling (DESIGN.md "tile culling"): tiles hold spheres sorted along cull_axis; a wave runs only the tiles
-    // some lane's ray segment (origin .. nearest exact hit so far, clipped to the sorted spheres' box) can overlap
-    const uint32_t *cull_tab;    // [kCullCells] tiles reaching up to cell c or beyond | [kCullCells] tiles starting at cell c or before
-    uint32_t cull_axis;          // 0..2; 3 = culling off
-    uint32_t cull_always;        // tiles that are always run (they hold spheres outside the sorted set)
-    float cull_u0, cull_inv_cell;
-    float clip_min[3], clip_max[3];  // box of the sorted spheres, padded by 2e-3 + 1e-5 |.| (lane_tile_mask adds each ray's own reach)
-    float cull_reach[3];             // 2 kappa, kappa (2 Rs^2 + r_max^2) + r_min^2, r_min (lane_tile_mask)
-    uint32_t verify;             // debug: count exact-positive pairs the prefilter did not flag
-    unsigned long long *debug;   // [4] misses, candidates, overflow fallbacks, exact positives
-    unsigned long long *wave_end; // optional (PTGPU_TIMING=1): wall clock at which each wave left the main loop
-    int32_t bvh_root;
-    uint32_t has_sky;
-    f3 sky;
-    uint32_t has_noise;
-    // frame
-    DCamera cam;
-    uint32_t width, height, samples, max_depth, frame_num;
-    float inv_nx, inv_ny, inv_ns, mix_prev, mix_new;  // scene.rs:82-87 (computed on the host in f32)
-    uint32_t random_seed;
-    // A frame in two launches (phase 1: the first samples of every pixel, in natural order, MEASURING the tiles; phase 2: the
-    // rest, ordered by those costs). A pixel's samples are one serial RNG stream: phase 1 parks (xoshiro state, colour sum) in
-    // px_state (12 dwords per pixel) where phase 2 picks them up; 0 = the whole frame in one launch.
-    uint32_t phase;
-    uint4 *px_state;
-    uint32_t first_static;       // 0, or the number of items handed out statically as the waves' first fetches (grid x 1024)
-    uint32_t refill_min;         // lanes that must be waiting before a wave fetches new pixels (4; 8 below 32 spp)
-    uint32_t ready_min;          // 4-wide tree: lanes with a finished traversal before the wave leaves the traversal loop to shade
-    uint32_t drain_at;           // 4-wide tree: a lane holding more than this many leaf candidates triggers the wave's drain
-    uint64_t seed_base;
-    // sharding: rows y with y % shard_count == shard_index, compact buffer
-    uint32_t shard_index, shard_count, local_rows;
-    uint32_t tiles_x, n_items;  // 8x8 tiles over (width x local_rows); n_items = tiles * 64
-    uint32_t tiles_x_magic;     // floor(2^32 / tiles_x): tile / tiles_x = umulhi(tile, magic) (+ 1 after one correction step)
-    // outputs / work queue
-    float *rgb;
-    unsigned long long *ray_count;
-    uint32_t *work_counter;
-    const uint32_t *tile_order;  // optional permutation of the 8x8 work tiles (expensive tiles first)
-    uint32_t *tile_cost;         // optional: rays spent per work tile (accumulated when a pixel completes): the pilot pass' result,
-                                 // or what a frame kernel measures for the next frame of the same view
-    float *gstack;  // global path-stack fallback when max_depth*3*kBlock*4 exceeds the LDS budget
-    uint32_t stack_in_lds;       // 256-thread kernels: number of attenuation-stack slots (3 per level; 1 on the 4-wide tree kernels, WST below) kept in LDS; the rest in gstack
-    uint32_t lds_sphere_bytes;  // offsets of the dynamic LDS carve
-};
 
 // ---- perlin.rs:54-111 -------------------------------------------------------
 struct PerlinLds {
@@ -315,8 +178,6 @@ __device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float
 // The sphere table is read 8 entries at a time (kScanUnroll) so the loads of a group are
 // in flight before its arithmetic starts; the table is padded to a multiple of 8 with
 // (3e38, 3e38, 3e38, 0) entries whose discriminant is NaN or -inf.
-constexpr int kScanUnroll = 8;
-constexpr int kQueueCap = 20;  // per-lane candidate slots (u16) of the exact scan, drained above kQueueCap - kScanUnroll
 
 __device__ __forceinline__ void drain_candidates(const float4 *sph, const uint16_t *q, uint32_t &cnt, f3 o, f3 d,
                                                  float a, float &closest, int &idx) {
@@ -495,16 +356,6 @@ __device__ __forceinline__ RayFeat make_ray_features(const float4 *P, f3 o, f3 d
 // accumulators into masks, swaps the partner ray's half with lane ^ 32, and appends the 32-bit mask of ITS OWN
 // ray when it is non-zero (~1 candidate per ray per bounce, so most tiles append nothing). Phase 2 walks the
 // set bits; bit -> fragment slot (tile*32 + row) -> sphere.
-constexpr int kEntCap = 4;      // u32 tile masks a lane can hold between two drains (a lane only queues tiles of its own mask)
-// Phase 2 is balanced over the wave: the lanes' candidates are expanded into one list of (ray, sphere) pairs per wave and
-// every lane takes one PAIR per round, whoever's ray it belongs to (a lane-owns-its-candidates loop ran 4.0 rounds per
-// bounce at 23 % lane utilisation: 59 candidates per wave, unevenly spread). Per wave: the pair list and one 64-bit
-// (t, tie-break) key per ray that the pairs' exact tests are reduced into with ds_min_u64.
-constexpr int kPairCap = 192;
-constexpr uint32_t kWavePairBytes = kPairCap * 4u + 64u * 8u;
-__host__ __device__ constexpr uint32_t mfma_queue_bytes(uint32_t blk) { return (uint32_t)kEntCap * blk * 4u + (blk / 64u) * kWavePairBytes; }
-__host__ __device__ constexpr uint32_t scan_queue_bytes(uint32_t blk) { return ((uint32_t)(kQueueCap + 1) * blk * 2u + 15u) / 16u * 16u; }
-
 // inclusive prefix sum over the 64 lanes of a wave (row_shr 1/2/4/8 inside each row of 16, then row_bcast 15 and 31)
 __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x) {
     x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
@@ -967,13 +818,6 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
 // inside has t >= entry distance (up to rounding, covered by the slack), and the
 // subtree's AABB test itself is the reference's, evaluated with the reference's arithmetic. Equal-t
 // ties are resolved by the precomputed DFS rank of the leaf instead of by visiting order.
-struct DWideNode {  // 64 B
-    float lmin[3], lmax[3];  // lhs inner node: box CENTRE, HALF extent; lhs leaf: the sphere (centre, lmax[0] = radius)
-    float rmin[3], rmax[3];  // same for rhs
-    int32_t lhs, rhs;        // >= 0 inner node, < 0 ~sphere
-    uint32_t pad0, pad1;     // 1 / smallest |radius| below lhs / rhs (float bits)
-};
-
 // relative / absolute slack of the distance cull (DESIGN.md "BVH culling slack")
 constexpr float kCullRel = 1.02f;
 constexpr float kCullAbs = 0.02f;
@@ -1036,7 +880,6 @@ struct BvhTrav {
     uint32_t rank;
     bool active;
 };
-constexpr int kReadyMin = 56;  // shade as soon as this many lanes of the wave have a finished traversal
 
 template <bool MOVING>
 __device__ __forceinline__ void bvh_start(const KArgs &A, uint32_t *s_stack, f3 o, f3 d, float a, float time, BvhTrav &st) {
@@ -1108,12 +951,6 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
 // accept rule, ds_min_u64 on the owner's (t, tie-break) key), so the exact tests run on full waves whatever the spread
 // of the lanes' traversals. A lane's nearest hit so far (`best`, the culling limit) is refreshed from its key after
 // every drain.
-#ifndef PT_LEAFQ
-#define PT_LEAFQ 8
-#endif
-constexpr int kLeafQ = PT_LEAFQ;   // per-lane candidate slots; drained when a lane holds more than kLeafQ - 4
-constexpr uint32_t kPairLaneShift = 26u;   // pair = owner lane << 26 | leaf slot (node * 4 + slot; the tree has < 65536 nodes)
-__host__ __device__ constexpr uint32_t tree4_queue_bytes(uint32_t blk) { return (uint32_t)kLeafQ * blk * 4u + (blk / 64u) * kWavePairBytes; }
 
 struct Trav4 {
     uint32_t visits, leaves;   // VERIFY kernels: nodes fetched / exact sphere tests (SURVEY 8d counters)
@@ -1309,9 +1146,9 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
 
 // SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
 // (staged once per workgroup); otherwise from HBM/L2 through wave-uniform loads.
-// PILOT: the measuring launch that precedes the frame kernel (own symbol so profiles keep the two apart). A.phase == 1: the
-// FIRST sample of every pixel, for real -- it parks each pixel's RNG stream and colour sum for the frame kernel (A.phase == 2)
-// and counts the rays per tile; A.phase == 0: the throw-away 1-spp pass over a quarter of the pixels (frames below 32 spp).
+// PILOT: the measuring launch that precedes the frame kernel of a new view (own symbol so profiles keep the two apart; A.phase == 1):
+// the FIRST sample of every pixel, for real -- it parks each pixel's RNG stream and colour sum for the frame kernel (A.phase == 2)
+// and counts the rays per tile.
 // MOVING: the world also holds MovingSphere entries (moving_sphere.rs): rays keep their time (camera.rs:59) and
 // every exact sphere test / normal uses the centre at that time; prefilter fragments and internal-tree boxes
 // were built over the motion's whole sweep.
@@ -1509,9 +1346,11 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 col = scale3(col, pf.x);
                 if (!PILOT) {
                     float *out = A.rgb + ((pxy >> 16) * A.width + (pxy & 0xffffu)) * 3u;
-                    out[0] = out[0] * pf.y + col.x * pf.z;
-                    out[1] = out[1] * pf.y + col.y * pf.z;
-                    out[2] = out[2] * pf.y + col.z * pf.z;
+                    // (prev_zero: pt_render found the host buffer all +0.0f and did not upload it -- same products, same sums)
+                    const float p0 = A.prev_zero ? 0.0f : out[0], p1 = A.prev_zero ? 0.0f : out[1], p2 = A.prev_zero ? 0.0f : out[2];
+                    out[0] = p0 * pf.y + col.x * pf.z;
+                    out[1] = p1 * pf.y + col.y * pf.z;
+                    out[2] = p2 * pf.y + col.z * pf.z;
                 }
                 // (frame kernels: the NEXT frame's work order; the pixel's work tile is recomputed from its coordinates)
                 if (PILOT || A.tile_cost) atomicAdd(&A.tile_cost[((pxy >> 16) >> kTileLog2) * A.tiles_x + ((pxy & 0xffffu) >> kTileLog2)], pix_rays);
@@ -1547,9 +1386,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 if (tcol >= A.tiles_x) trow += 1u, tcol -= A.tiles_x;
                 const uint32_t x = tcol * kTileSide + (in & (kTileSide - 1u));
                 const uint32_t ly = trow * kTileSide + (in >> kTileLog2);
-                // (the list kernels' cost-estimation pilot samples one pixel per 2x2 block: a quarter of the rays orders
-                //  the tiles as well as all of them did and costs 0.2 ms less; the tree kernels keep every pixel, measured)
-                if (x < A.width && ly < A.local_rows && !(PILOT && A.phase == 0u && !BVH && ((x | ly) & 1u))) {
+                if (x < A.width && ly < A.local_rows) {
                     have = true;
                     pxy = x | (ly << 16);
 #ifdef PT_WAVE_DETAIL
@@ -1862,37 +1699,6 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     // scene.rs:118 ray_count: wave reduce, one atomic per wave
     if (lane == 0) atomicAdd(A.ray_count, wave_rays);
 #undef PT_DEPTH
-}
-
-// ---- work ordering ------------------------------------------------------------------------------
-// The frame ends when the slowest lane finishes its last pixel, and a pixel's samples are inherently
-// serial (one RNG stream, scene.rs:96-111): a glass pixel needs ~700 dependent ray iterations, most of a
-// 15 ms frame. Handing out the expensive tiles FIRST keeps that tail short. Tile costs come from a PILOT
-// pass: the same kernel at 1 sample per pixel with throw-away seeds (random_seed path), writing nothing but
-// the rays spent per 8x8 tile (~1.5 % of the frame's work). The order only decides WHEN a pixel is rendered,
-// never its value.
-__global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile_cost, uint32_t cost_scale,
-                                     uint32_t *tile_order) {
-    __shared__ uint32_t count[64], cursor[64];
-    if (threadIdx.x < 64) count[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
-        const uint32_t b = tile_cost[t] / cost_scale;
-        atomicAdd(&count[b < 63u ? b : 63u], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {  // most expensive bucket first
-        uint32_t acc = 0;
-        for (int b = 63; b >= 0; --b) {
-            cursor[b] = acc;
-            acc += count[b];
-        }
-    }
-    __syncthreads();
-    for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
-        const uint32_t b = tile_cost[t] / cost_scale;
-        tile_order[atomicAdd(&cursor[b < 63u ? b : 63u], 1u)] = t;
-    }
 }
 
 }  // namespace ptdev

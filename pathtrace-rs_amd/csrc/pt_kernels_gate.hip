@@ -1,0 +1,23 @@
+// pt_kernels_gate.hip -- MFMA list kernels of BVH worlds (GATE = true: ancestor-AABB gate + DFS-rank ties at hit acceptance).
+#include "pt_kernel.h"
+#include "pt_kernels.h"
+
+namespace pthostside {
+
+void mfma_gate_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *frame, SphereKernel *measure) {
+    static const SphereKernel table[2][7] = {
+        {pt_trace_kernel<false, true, true, false, false, false, true>, pt_trace_kernel<false, true, true, false, true, false, true>,
+         pt_trace_kernel<false, true, true, true, false, false, true>,
+         pt_trace_kernel<false, true, true, false, false, false, true, 768>, pt_trace_kernel<false, true, true, false, true, false, true, 768>,
+         pt_trace_kernel<false, true, true, false, false, false, true, 1024>, pt_trace_kernel<false, true, true, false, true, false, true, 1024>},
+        {pt_trace_kernel<false, true, true, false, false, true, true>, pt_trace_kernel<false, true, true, false, true, true, true>,
+         pt_trace_kernel<false, true, true, true, false, true, true>,
+         pt_trace_kernel<false, true, true, false, false, true, true, 768>, pt_trace_kernel<false, true, true, false, true, true, true, 768>,
+         pt_trace_kernel<false, true, true, false, false, true, true, 1024>, pt_trace_kernel<false, true, true, false, true, true, true, 1024>}};
+    const SphereKernel *t = table[moving ? 1 : 0];
+    const int w = blk == 1024u ? 5 : (blk == 768u ? 3 : 0);
+    *frame = verify ? t[2] : t[w];
+    *measure = verify ? nullptr : t[w + 1];
+}
+
+}  // namespace pthostside

@@ -1,0 +1,63 @@
+// pt_kernels_list.hip -- MFMA list kernels of list worlds (GATE = false): the headline kernels.
+#include "pt_kernel.h"
+#include "pt_kernels.h"
+
+namespace ptdev {
+
+// ---- work ordering ------------------------------------------------------------------------------
+// The frame ends when the slowest lane finishes its last pixel, and a pixel's samples are inherently
+// serial (one RNG stream, scene.rs:96-111): a glass pixel needs ~700 dependent ray iterations, most of a
+// 15 ms frame. Handing out the expensive tiles FIRST keeps that tail short. Tile costs come from a PILOT
+// pass: the same kernel at 1 sample per pixel with throw-away seeds (random_seed path), writing nothing but
+// the rays spent per 8x8 tile (~1.5 % of the frame's work). The order only decides WHEN a pixel is rendered,
+// never its value.
+__global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile_cost, uint32_t cost_scale,
+                                     uint32_t *tile_order) {
+    __shared__ uint32_t count[64], cursor[64];
+    if (threadIdx.x < 64) count[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
+        const uint32_t b = tile_cost[t] / cost_scale;
+        atomicAdd(&count[b < 63u ? b : 63u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // most expensive bucket first
+        uint32_t acc = 0;
+        for (int b = 63; b >= 0; --b) {
+            cursor[b] = acc;
+            acc += count[b];
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
+        const uint32_t b = tile_cost[t] / cost_scale;
+        tile_order[atomicAdd(&cursor[b < 63u ? b : 63u], 1u)] = t;
+    }
+}
+
+}  // namespace ptdev
+
+namespace pthostside {
+
+void mfma_list_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *frame, SphereKernel *measure) {
+    // [moving][256 frame, 256 measure, verify, 768 frame, 768 measure, 1024 frame, 1024 measure]
+    static const SphereKernel table[2][7] = {
+        {pt_trace_kernel<false, true, true, false, false, false, false>, pt_trace_kernel<false, true, true, false, true, false, false>,
+         pt_trace_kernel<false, true, true, true, false, false, false>,
+         pt_trace_kernel<false, true, true, false, false, false, false, 768>, pt_trace_kernel<false, true, true, false, true, false, false, 768>,
+         pt_trace_kernel<false, true, true, false, false, false, false, 1024>, pt_trace_kernel<false, true, true, false, true, false, false, 1024>},
+        {pt_trace_kernel<false, true, true, false, false, true, false>, pt_trace_kernel<false, true, true, false, true, true, false>,
+         pt_trace_kernel<false, true, true, true, false, true, false>,
+         pt_trace_kernel<false, true, true, false, false, true, false, 768>, pt_trace_kernel<false, true, true, false, true, true, false, 768>,
+         pt_trace_kernel<false, true, true, false, false, true, false, 1024>, pt_trace_kernel<false, true, true, false, true, true, false, 1024>}};
+    const SphereKernel *t = table[moving ? 1 : 0];
+    const int w = blk == 1024u ? 5 : (blk == 768u ? 3 : 0);
+    *frame = verify ? t[2] : t[w];
+    *measure = verify ? nullptr : t[w + 1];
+}
+
+void launch_tile_order(uint32_t n_work_tiles, const uint32_t *tile_cost, uint32_t cost_scale, uint32_t *tile_order, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, tile_cost, cost_scale, tile_order);
+}
+
+}  // namespace pthostside

@@ -1,0 +1,16 @@
+// pt_kernels_world.hip -- the general-world kernel's instantiations: <BVH, HIT_LDS, OCC, MEDIA>.
+#include "pt_kernels.h"
+#include "pt_world.h"
+
+namespace pthostside {
+
+WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media) {
+    // worlds whose records do not fit LDS share the MEDIA = true code
+    if (occ == 4u)
+        return bvh ? (hit_lds ? (media ? pt_world_kernel<true, true, 4, true> : pt_world_kernel<true, true, 4, false>) : pt_world_kernel<true, false, 4, true>)
+                   : (hit_lds ? (media ? pt_world_kernel<false, true, 4, true> : pt_world_kernel<false, true, 4, false>) : pt_world_kernel<false, false, 4, true>);
+    return bvh ? (hit_lds ? (media ? pt_world_kernel<true, true, 3, true> : pt_world_kernel<true, true, 3, false>) : pt_world_kernel<true, false, 3, true>)
+               : (hit_lds ? (media ? pt_world_kernel<false, true, 3, true> : pt_world_kernel<false, true, 3, false>) : pt_world_kernel<false, false, 3, true>);
+}
+
+}  // namespace pthostside

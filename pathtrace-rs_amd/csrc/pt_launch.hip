@@ -1,0 +1,460 @@
+// pt_launch.hip -- one Scene::update (scene.rs:73-121) enqueued on a stream: validate the frame, ask pt_select.h which kernel
+// and geometry, fill the argument block, order the work (heavy tiles first), launch. Buffers that grow with the frame are
+// sized by the ensure_* helpers; nothing here decides WHICH code runs.
+#include "pt_kernels.h"
+
+#include <mutex>
+
+namespace pthostside {
+
+namespace {
+
+f3 to3(const float *p) { return f3{p[0], p[1], p[2]}; }
+
+// Workgroups of `blk` threads one CU can hold by registers: the unified VGPR file gives min(8, 512 / alloc) waves per SIMD,
+// alloc = the kernel's VGPR count rounded up to the granule of 8 (MI355X_MICROARCH.md "Register files"). A persistent grid
+// must not exceed it: a workgroup that does not fit only starts when another one retires.
+uint32_t blocks_per_cu_by_registers(const void *kern, uint32_t blk) {
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, kern) != hipSuccess || attr.numRegs <= 0) return 8u;
+    const uint32_t alloc = ((uint32_t)attr.numRegs + 7u) / 8u * 8u;
+    const uint32_t waves_per_simd = std::min<uint32_t>(8u, 512u / alloc);
+    return std::max<uint32_t>(1u, waves_per_simd * 4u / (blk / 64u));
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-function, PROCESS-wide attribute: the limit of a kernel is only ever
+// raised, and remembered per (device, kernel) for all scenes.
+int raise_lds_limit(int device, const void *kern, uint32_t lds) {
+    struct Entry { int device; const void *kern; uint32_t lds; };
+    static std::mutex mu;
+    static std::vector<Entry> seen;
+    std::lock_guard<std::mutex> lock(mu);
+    for (Entry &e : seen)
+        if (e.device == device && e.kern == kern) {
+            if (e.lds >= lds) return PT_OK;
+            HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            e.lds = lds;
+            return PT_OK;
+        }
+    HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    seen.push_back(Entry{device, kern, lds});
+    return PT_OK;
+}
+
+// The per-frame arguments both kernels share (KArgs and WArgs use the same member names).
+template <typename Args>
+void fill_frame_args(Args &X, const pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t frame_num, uint32_t shard_index, uint32_t shard_count,
+                     float *d_rgb, uint64_t *d_ray_count, const ptsel::KernelChoice &c) {
+    X.has_sky = s->has_sky;
+    X.sky = to3(s->sky);
+    X.has_noise = s->tr.has_noise ? 1u : 0u;
+    X.cam.origin = to3(cam->origin);
+    X.cam.lower_left_corner = to3(cam->lower_left_corner);
+    X.cam.horizontal = to3(cam->horizontal);
+    X.cam.vertical = to3(cam->vertical);
+    X.cam.u = to3(cam->u);
+    X.cam.v = to3(cam->v);
+    X.cam.w = to3(cam->w);
+    X.cam.time0 = cam->time0;
+    X.cam.time1 = cam->time1;
+    X.cam.lens_radius = cam->lens_radius;
+    X.width = params->width;
+    X.height = params->height;
+    X.samples = params->samples;
+    X.max_depth = params->max_depth;
+    X.frame_num = frame_num;
+    {   // scene.rs:82-87, evaluated in f32 exactly like the reference
+        const volatile float one = 1.0f;
+        X.inv_nx = one / (float)params->width;
+        X.inv_ny = one / (float)params->height;
+        X.inv_ns = one / (float)params->samples;
+        const volatile float mp = (float)frame_num / (float)(frame_num + 1u);
+        X.mix_prev = mp;
+        X.mix_new = one - mp;
+    }
+    X.random_seed = params->random_seed;
+    X.refill_min = c.refill_min;
+    X.seed_base = s->seed_base;
+    X.shard_index = shard_index;
+    X.shard_count = shard_count;
+    X.local_rows = pt_shard_rows(params->height, shard_index, shard_count);
+    X.tiles_x = (params->width + kTileSide - 1u) / kTileSide;
+    X.tiles_x_magic = X.tiles_x > 1u ? (uint32_t)(0x100000000ull / X.tiles_x) : 0xffffffffu;   // (tiles_x == 1: umulhi gives tile - 1, corrected by the kernel's one step)
+    X.n_items = X.tiles_x * ((X.local_rows + kTileSide - 1u) / kTileSide) * kTilePix;
+    X.rgb = d_rgb;
+    X.prev_zero = 0;
+    X.ray_count = reinterpret_cast<unsigned long long *>(d_ray_count);
+    X.work_counter = s->d_work_counter;
+}
+
+// The binary internal tree (variant bit 2048 for A/B runs, scenes whose attenuations do not fit the tree kernels' stack words,
+// trees the packed format cannot hold) is built on the host the first time a launch needs it.
+int ensure_binary_tree(pt_scene *s) {
+    if (s->binary_built) return PT_OK;
+    pt_scene_desc d{};
+    d.n_spheres = (uint32_t)s->h_spheres.size();
+    d.spheres = s->h_spheres.data();
+    AccelBuild acc = build_accel(&d, s->h_motion.empty() ? nullptr : s->h_motion.data(), s->h_t_lo, s->h_t_hi);
+    if (acc.depth + 2 > (uint32_t)kBvhStack) return fail(PT_ERR_UNSUPPORTED, "internal BVH depth %u exceeds the traversal stack", acc.depth);
+    if (int rc = upload(&s->d_wnodes, acc.nodes.data(), acc.nodes.size())) return rc;
+    s->bin_root = acc.root;
+    s->tr.bin_depth = acc.depth;
+    s->tr.bin_nodes = (uint32_t)acc.nodes.size();
+    s->binary_built = true;
+    return PT_OK;
+}
+
+int ensure_tile_buf(pt_scene *s, uint32_t n_work_tiles) {
+    if (n_work_tiles <= s->d_tile_cap) return PT_OK;
+    (void)hipFree(s->d_tile_buf);
+    s->d_tile_buf = nullptr, s->d_tile_cap = 0, s->hint_valid = false;
+    HIP_TRY(hipMalloc((void **)&s->d_tile_buf, (8 + 3 * (size_t)n_work_tiles) * sizeof(uint32_t)));
+    s->d_tile_cap = n_work_tiles;
+    return PT_OK;
+}
+
+int ensure_px_state(pt_scene *s, size_t pixels) {
+    if (pixels <= s->d_px_state_pixels) return PT_OK;
+    (void)hipFree(s->d_px_state);
+    s->d_px_state = nullptr, s->d_px_state_pixels = 0;
+    HIP_TRY(hipMalloc((void **)&s->d_px_state, pixels * 48u));
+    s->d_px_state_pixels = pixels;
+    return PT_OK;
+}
+
+int ensure_gstack(pt_scene *s, size_t need_floats) {
+    if (need_floats <= s->d_gstack_floats) return PT_OK;
+    (void)hipFree(s->d_gstack);
+    s->d_gstack = nullptr, s->d_gstack_floats = 0;
+    HIP_TRY(hipMalloc((void **)&s->d_gstack, need_floats * sizeof(float)));
+    s->d_gstack_floats = need_floats;
+    return PT_OK;
+}
+
+// Heavy-first work order, shared by both kernel families. A repeated view is ordered by the rays
+// each tile took in its last frame (measured by the frame kernel itself); a new view runs as TWO launches: the first (the
+// family's measuring twin, phase 1) traces the first sample of every pixel in natural order, counts the rays per tile and parks
+// each pixel's RNG stream and colour sum, the second continues, ordered by those costs. Only WHEN a pixel is rendered depends
+// on any of this, never its value. `A` is the frame kernel's argument block (updated in place), `measure` launches phase 1.
+template <typename Args, typename LaunchMeasure>
+int order_work(pt_scene *s, Args &A, const pt_params *params, const pt_camera *cam, uint32_t shard_index, uint32_t shard_count, hipStream_t stream,
+               LaunchMeasure measure) {
+    const uint32_t n_work_tiles = A.n_items / kTilePix;
+    if (int rc = ensure_tile_buf(s, n_work_tiles)) return rc;
+    uint32_t *cost = s->d_tile_buf + 8, *order = cost + s->d_tile_cap, *measured = order + s->d_tile_cap;
+    pt_scene::ViewKey key{};
+    key.params = *params, key.cam = *cam, key.shard_index = shard_index, key.shard_count = shard_count, key.variant = s->variant, key.n_tiles = n_work_tiles;
+    const bool reuse = s->hint_valid && (s->variant & ptsel::kVarMeasureEveryFrame) == 0 && memcmp(&key, &s->hint_key, sizeof key) == 0;
+    uint32_t measured_scale = params->samples * (params->max_depth + 1u);
+    if (reuse) {
+        // the last frame of this view measured every tile: order by that (64 buckets over samples x (depth + 1) x 64 pixels)
+        launch_tile_order(n_work_tiles, measured, s->hint_scale, order, stream);
+    } else {
+        if (int rc = ensure_px_state(s, (size_t)A.width * A.local_rows)) return rc;
+        HIP_TRY(hipMemsetAsync(cost, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
+        Args A1 = A;
+        A1.samples = 1, A1.phase = 1, A1.px_state = s->d_px_state, A1.tile_cost = cost;
+        // one sample per pixel: refills dominate, batch them hard (a plain 1-spp frame: 0.48 ms at 8, 0.34 at 32; frame: best at 48)
+        A1.refill_min = dev_knobs().phase1_refill > 0 ? (uint32_t)dev_knobs().phase1_refill : 48u;
+        measure(A1);
+        launch_tile_order(n_work_tiles, cost, params->max_depth + 1u, order, stream);
+        A.samples = params->samples - 1u, A.phase = 2, A.px_state = s->d_px_state;
+        measured_scale = A.samples * (params->max_depth + 1u);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+    A.tile_order = order;
+    if ((s->variant & ptsel::kVarMeasureEveryFrame) == 0) {   // this frame measures the tiles for the next one (after the order kernel has read the old values)
+        HIP_TRY(hipMemsetAsync(measured, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
+        A.tile_cost = measured;
+        s->hint_key = key, s->hint_valid = true, s->hint_scale = measured_scale;
+    }
+    return PT_OK;
+}
+
+int launch_world(pt_scene *s, const ptsel::KernelChoice &c, const pt_params *params, const pt_camera *cam, uint32_t frame_num, uint32_t shard_index,
+                 uint32_t shard_count, float *d_rgb, uint64_t *d_ray_count, hipStream_t stream, const BeforeFrame *before_frame) {
+    WArgs W;
+    memset(&W, 0, sizeof W);
+    W.hit = s->d_hitables;
+    W.xf = s->d_transforms;
+    W.nodes = s->d_ref_nodes;
+    W.mats = s->d_mats;
+    W.texs = s->d_texs;
+    W.perlin_vec = s->d_perlin_vec;
+    W.perlin_perm = s->d_perlin_perm;
+    W.image_table = s->d_image_table;
+    W.image_bytes = s->d_image_bytes;
+    W.has_image = s->tr.has_image ? 1u : 0u;
+    W.n_hit = s->tr.n_hitables;
+    W.n_xf = s->tr.n_world_xf;
+    W.bvh_root = c.ref_bvh ? s->bvh_root : -1;
+    W.bvh_stack_entries = c.bvh_stack_entries;
+    W.stack_in_lds = c.stack_in_lds;
+    fill_frame_args(W, s, params, cam, frame_num, shard_index, shard_count, d_rgb, d_ray_count, c);
+    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
+    if (W.n_items == 0) {
+        s->ev_valid = false;
+        return PT_OK;
+    }
+    const WorldKernel wk = world_kernel_for(c);
+    uint32_t bpc = c.bpc;
+    if (!c.bpc_forced) bpc = std::min(bpc, blocks_per_cu_by_registers(reinterpret_cast<const void *>(wk), c.block));
+    uint32_t grid = (uint32_t)s->num_cus * bpc;
+    const uint32_t need = (W.n_items + c.block - 1) / c.block;
+    if (grid > need) grid = need;
+    if (c.gstack) {
+        if (int rc = ensure_gstack(s, (size_t)grid * params->max_depth * 3ull * c.block)) return rc;
+        W.gstack = s->d_gstack;
+    }
+    if (int rc = raise_lds_limit(s->device, reinterpret_cast<const void *>(wk), c.lds_bytes)) return rc;
+    HIP_TRY(hipEventRecord(s->ev_pass, stream));
+    if (c.order == ptsel::Order::Measured)
+        if (int rc = order_work(s, W, params, cam, shard_index, shard_count, stream,
+                                [&](const WArgs &W1) { hipLaunchKernelGGL(wk, dim3(grid), dim3(c.block), c.lds_bytes, stream, W1); }))
+            return rc;
+    if (before_frame) {
+        bool zero = false;
+        if (int rc = (*before_frame)(&zero)) return rc;
+        W.prev_zero = zero ? 1u : 0u;
+    }
+    HIP_TRY(hipEventRecord(s->ev_start, stream));
+    hipLaunchKernelGGL(wk, dim3(grid), dim3(c.block), c.lds_bytes, stream, W);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev_stop, stream));
+    s->ev_valid = true;
+    s->last_grid = grid, s->last_block = c.block, s->last_lds = c.lds_bytes;
+    return PT_OK;
+}
+
+void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, hipStream_t stream);
+
+}  // namespace
+
+WorldKernel world_kernel_for(const ptsel::KernelChoice &c) { return world_kernel(c.ref_bvh, c.world_hit_lds, c.world_occ, c.world_media); }
+
+void sphere_kernels_for(const ptsel::KernelChoice &c, SphereKernel *frame, SphereKernel *measure) {
+    switch (c.family) {
+    case ptsel::Family::Tree4: tree_kernels(true, c.moving, c.verify, frame, measure); break;
+    case ptsel::Family::TreeBinary: tree_kernels(false, c.moving, c.verify, frame, measure); break;
+    case ptsel::Family::Mfma:
+        if (c.gate) mfma_gate_kernels(c.moving, c.block, c.verify, frame, measure);
+        else mfma_list_kernels(c.moving, c.block, c.verify, frame, measure);
+        break;
+    case ptsel::Family::ScanLds: scan_kernels(true, frame, measure); break;
+    default: scan_kernels(false, frame, measure); break;
+    }
+}
+
+const char *kernel_name(const ptsel::KernelChoice &c, char *buf, size_t cap) {
+    static const char *fam[] = {"world", "tree-binary", "tree4", "mfma", "scan-lds", "scan-hbm"};
+    if (c.family == ptsel::Family::World)
+        snprintf(buf, cap, "world<bvh=%d,hit_lds=%d,occ=%u,media=%d>", (int)c.ref_bvh, (int)c.world_hit_lds, c.world_occ, (int)c.world_media);
+    else
+        snprintf(buf, cap, "%s<blk=%u%s%s%s>", fam[(uint32_t)c.family], c.block, c.moving ? ",moving" : "", c.gate ? ",gate" : "", c.verify ? ",verify" : "");
+    return buf;
+}
+
+int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t frame_num, uint32_t shard_index, uint32_t shard_count, float *d_rgb,
+           uint64_t *d_ray_count, hipStream_t stream, const BeforeFrame *before_frame) {
+    if (!s || !params || !cam || !d_rgb || !d_ray_count) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (params->width == 0 || params->height == 0 || params->samples == 0) return fail(PT_ERR_INVALID_ARG, "width/height/samples must be non-zero");
+    if ((uint64_t)params->width * params->height > 0x3fffffffull) return fail(PT_ERR_INVALID_ARG, "frame too large");
+    // every kernel packs a lane's pixel into one register; the sphere kernels its (depth, sample) counters as well
+    if (params->width > 0xffffu || params->height > 0xffffu) return fail(PT_ERR_UNSUPPORTED, "width and height must be below 65536");
+    if (!s->tr.is_world && (params->max_depth > 0xfffu || params->samples > 0xfffffu))
+        return fail(PT_ERR_UNSUPPORTED, "sphere kernels take max_depth < 4096, samples < 2^20");
+    if (shard_count == 0 || shard_index >= shard_count) return fail(PT_ERR_INVALID_ARG, "bad shard %u/%u", shard_index, shard_count);
+    if (params->use_bvh && s->bvh_root < 0) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the scene was created without BVH nodes");
+    HIP_TRY(hipSetDevice(s->device));
+
+    // ---- which kernel, which geometry (pt_select.h) ----
+    ptsel::Knobs knobs;
+    knobs.variant = s->variant, knobs.blocks_per_cu = s->blocks_per_cu, knobs.refill = dev_knobs().refill, knobs.world_occ3 = dev_knobs().world_occ3;
+    const uint32_t local_rows = pt_shard_rows(params->height, shard_index, shard_count);
+    const auto tree4_regs = [&] {
+        return blocks_per_cu_by_registers(reinterpret_cast<const void *>(tree4_kernel_for_registers(s->tr.has_motion)), (uint32_t)kBlock);
+    };
+    ptsel::KernelChoice c;
+    ptsel::select_kernel(s->tr, *params, cam->time0, cam->time1, local_rows, knobs, s->tr.is_world ? 4u : tree4_regs(), c);
+    if (c.needs_binary_tree && !s->binary_built) {   // built on first use; its size enters the LDS carve
+        if (int rc = ensure_binary_tree(s)) return rc;
+        ptsel::select_kernel(s->tr, *params, cam->time0, cam->time1, local_rows, knobs, tree4_regs(), c);
+    }
+    s->last_choice = c;
+    if (dev_knobs().debug) {
+        char name[96];
+        fprintf(stderr, "[ptgpu launch] %s lds %u bpc %u stack_in_lds %u order %u\n", kernel_name(c, name, sizeof name), c.lds_bytes, c.bpc, c.stack_in_lds, (uint32_t)c.order);
+    }
+    if (c.family == ptsel::Family::World) return launch_world(s, c, params, cam, frame_num, shard_index, shard_count, d_rgb, d_ray_count, stream, before_frame);
+
+    // ---- argument block ----
+    const bool bvh = c.family == ptsel::Family::Tree4 || c.family == ptsel::Family::TreeBinary, tree4 = c.family == ptsel::Family::Tree4;
+    KArgs A;
+    memset(&A, 0, sizeof A);
+    A.spheres = s->d_spheres;
+    A.spheres_r2 = s->d_spheres_r2;
+    A.shade = s->d_shade;
+    A.sphere_mat = s->d_sphere_mat;
+    A.motion = s->d_motion;
+    A.mats = s->d_mats;
+    A.texs = s->d_texs;
+    A.perlin_vec = s->d_perlin_vec;
+    A.perlin_perm = s->d_perlin_perm;
+    A.gate = c.ref_bvh ? s->d_gate : nullptr;   // list semantics: no ancestor-AABB gate, ties to the lower index
+    A.gate_chain = s->d_gate_chain;
+    A.bvh_large = s->d_bvh_large;
+    A.n_bvh_large = s->n_bvh_large;
+    A.nodes4 = s->d_nodes4q;
+    A.slotrec = s->d_slotrec;
+    A.rank_sphere = s->d_rank_sphere;
+    A.shade_rank = s->d_shade_rank;
+    A.leaf_rank = s->d_leaf_rank;
+    A.n_spheres = s->tr.n_spheres;
+    A.n_spheres_pad = ptsel::scan_pad(s->tr.n_spheres);
+    fill_frame_args(A, s, params, cam, frame_num, shard_index, shard_count, d_rgb, d_ray_count, c);
+    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
+    if (A.n_items == 0) {
+        s->ev_valid = false;
+        return PT_OK;
+    }
+    A.afrag = s->d_afrag;
+    A.tile_sphere = s->d_tile_sphere;
+    A.cull_tab = s->d_cull_tab;
+    A.cull_axis = c.cull_off ? 3u : s->cull_axis;
+    A.cull_always = s->cull_always;
+    A.cull_u0 = s->cull_u0, A.cull_inv_cell = s->cull_inv_cell;
+    memcpy(A.clip_min, s->clip_min, 12), memcpy(A.clip_max, s->clip_max, 12);
+    if (A.cull_axis < 3u) {
+        // Per-RAY reach of the reference's f32 discriminant error (pt_kernel.h lane_tile_mask): the kernel pads the clip box and
+        // the segment's extent along the sort axis by sqrt(r_min^2 + kappa (2 |o - c0|^2 + 2 Rs^2 + r_max^2)) - r_min for the
+        // ray at hand, so nothing here depends on where the camera is. The constants are rounded up.
+        const double kappa = 4.0 * 1.3e-6;
+        const double k1 = kappa * (2.0 * (double)s->rs_small * s->rs_small + (double)s->cull_rmax * s->cull_rmax) + (double)s->cull_rmin * s->cull_rmin;
+        A.cull_reach[0] = std::nextafter((float)(2.0 * kappa), 3.0e38f);
+        A.cull_reach[1] = std::nextafter((float)k1, 3.0e38f);
+        A.cull_reach[2] = std::nextafter(s->cull_rmin, 0.0f);
+    }
+    A.large = s->d_large;
+    A.n_tiles = c.n_tiles;
+    A.n_large = s->n_large;
+    memcpy(A.c0, s->c0, sizeof A.c0);
+    A.rs2 = s->rs2;
+    A.m0 = s->m0;
+    A.gamma = s->gamma;
+    A.verify = (c.verify ? 1u : 0u) | ((s->variant & ptsel::kVarNoStack) ? 2u : 0u);
+    A.debug = s->d_debug;
+    A.ready_min = dev_knobs().ready >= 0 ? (uint32_t)dev_knobs().ready : (uint32_t)kReadyMin;
+    A.drain_at = dev_knobs().drain >= 0 ? std::min<uint32_t>((uint32_t)dev_knobs().drain, (uint32_t)(kLeafQ - 4)) : (uint32_t)(kLeafQ - 4);
+    A.wnodes = s->d_wnodes;
+    A.n_nodes = s->tr.bin_nodes;
+    A.bvh_root = tree4 ? (s->has_tree_items ? 0 : -1) : s->bin_root;   // (-1: every sphere is in bvh_large)
+    A.bvh_stack_entries = c.bvh_stack_entries;
+    A.nodes_in_lds = c.nodes_in_lds;
+    A.stack_in_lds = c.stack_in_lds;
+    A.lds_sphere_bytes = c.sph_bytes;
+    A.tile_order = nullptr;
+    A.tile_cost = nullptr;
+    (void)bvh;
+
+    SphereKernel kern = nullptr, measure_kern = nullptr;
+    sphere_kernels_for(c, &kern, &measure_kern);
+    const uint32_t blk = c.block, lds = c.lds_bytes;
+    // ---- persistent grid: CUs x resident workgroups ----
+    uint32_t bpc = c.bpc;
+    if (!c.bpc_forced) bpc = std::min(bpc, blocks_per_cu_by_registers(reinterpret_cast<const void *>(kern), blk));
+    uint32_t grid = (uint32_t)s->num_cus * bpc;
+    // Fewer pixels than lanes (a shard of an 8-GPU frame: 120 000 pixels for 262 144 lanes): the waves that win the race for
+    // work should be spread over ALL CUs -- two waves on a SIMD iterate faster than four -- so a one-workgroup-per-CU grid is
+    // not cut down to the workgroups the pixels would fill (a wave that finds the queue empty leaves at once).
+    const uint32_t need = (A.n_items + blk - 1) / blk;
+    const bool wide = blk != (uint32_t)kBlock;
+    if (grid > need && !(wide && need * 4u >= grid && !dev_knobs().clamp_grid)) grid = need;
+    if (grid == 0) grid = 1;
+    if (c.gstack) {
+        if (int rc = ensure_gstack(s, (size_t)grid * params->max_depth * 3ull * blk)) return rc;
+        A.gstack = s->d_gstack;
+    }
+    if (measure_kern)
+        if (int rc = raise_lds_limit(s->device, reinterpret_cast<const void *>(measure_kern), lds)) return rc;
+    if (int rc = raise_lds_limit(s->device, reinterpret_cast<const void *>(kern), lds)) return rc;
+    HIP_TRY(hipEventRecord(s->ev_pass, stream));
+    A.wave_end = s->d_wave_end;
+    if (s->d_wave_end) (void)hipMemsetAsync(s->d_wave_end, 0, 65536 * 8, stream);
+    if (c.order == ptsel::Order::Measured && measure_kern) {
+        if (int rc = order_work(s, A, params, cam, shard_index, shard_count, stream, [&](KArgs A1) {
+                A1.wave_end = nullptr;
+                hipLaunchKernelGGL(measure_kern, dim3(grid), dim3(blk), lds, stream, A1);
+            }))
+            return rc;
+        // 16-wave workgroups: the waves' first fetches are handed out by age class -- the oldest wave of every SIMD takes the head of
+        // the heavy-first list (pt_kernel.h first_static; +1 % on configs 3 / 4)
+        if (blk == 1024u && (uint64_t)grid * 1024ull <= A.n_items) A.first_static = grid * 1024u;
+    }
+    if (before_frame) {
+        bool zero = false;
+        if (int rc = (*before_frame)(&zero)) return rc;
+        A.prev_zero = zero ? 1u : 0u;
+    }
+    HIP_TRY(hipEventRecord(s->ev_start, stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(blk), lds, stream, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev_stop, stream));
+    s->ev_valid = true;
+    s->last_grid = grid, s->last_block = blk, s->last_lds = lds;
+    report_dev_aids(s, A, grid, blk, stream);
+    return PT_OK;
+}
+
+namespace {
+// Development aids of -DPT_CULLSTATS / -DPT_SECTIONS / -DPT_WAVEDBG builds and PTGPU_TIMING (none of it in the shipped library).
+void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, hipStream_t stream) {
+    (void)s, (void)A, (void)grid, (void)blk, (void)stream;
+#ifdef PT_CULLSTATS
+    {   // how many tiles the culling leaves
+        (void)hipStreamSynchronize(stream);
+        unsigned long long c[48];
+        (void)hipMemcpy(c, s->d_debug + 24, sizeof c, hipMemcpyDeviceToHost);
+        (void)hipMemset(s->d_debug + 24, 0, sizeof c);
+        if (c[0]) {
+            fprintf(stderr, "[ptgpu cull] wave-iterations %llu, tiles run per iteration %.2f of %u; lanes asked for %.2f tiles each\n  run histogram:", c[0],
+                    (double)c[1] / (double)c[0], A.n_tiles, (double)c[3] / (double)(c[2] ? c[2] : 1));
+            for (int i = 0; i < 18; ++i) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double)c[4 + i] / (double)c[0]);
+            fprintf(stderr, "\n  lane histogram:");
+            for (int i = 0; i < 18; ++i) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double)c[24 + i] / (double)(c[2] ? c[2] : 1));
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
+#ifdef PT_SECTIONS
+    {   // where the waves' cycles go
+        (void)hipStreamSynchronize(stream);
+        unsigned long long sec[8];
+        (void)hipMemcpy(sec, s->d_debug + 16, sizeof sec, hipMemcpyDeviceToHost);
+        (void)hipMemset(s->d_debug + 16, 0, sizeof sec);
+        double tot = 0;
+        for (int i = 0; i < 5; ++i) tot += (double)sec[i];
+        static const char *names[8] = {"refill", "camera", "intersect", "shade+terminal", "epilogue", "  features", "  tiles", "  phase2"};
+        fprintf(stderr, "[ptgpu sections]");
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)sec[i] / tot);
+        // (4-wide tree kernels: features = node visits, tiles = candidate drains, and the last slot COUNTS wave-trips)
+        fprintf(stderr, "  | raw: intersect %.3g cycles, slot7 %.3g, total %.3g\n", (double)sec[2], (double)sec[7], tot);
+    }
+#endif
+    if (s->d_wave_end) {  // distribution of wave finish times
+        (void)hipStreamSynchronize(stream);
+        const uint32_t nw = grid * (blk / 64);
+        std::vector<unsigned long long> t(nw);
+        (void)hipMemcpy(t.data(), s->d_wave_end, std::min<size_t>(nw, 65536) * 8, hipMemcpyDeviceToHost);
+        std::sort(t.begin(), t.end());
+        const double tick_ns = 10.0;  // wall_clock64: 100 MHz
+        fprintf(stderr, "[ptgpu timing] waves %u: finish spread (ms after first finisher) p10 %.3f p50 %.3f p90 %.3f p99 %.3f last %.3f\n", nw,
+                (t[nw / 10] - t[0]) * tick_ns * 1e-6, (t[nw / 2] - t[0]) * tick_ns * 1e-6, (t[nw * 9 / 10] - t[0]) * tick_ns * 1e-6,
+                (t[nw * 99 / 100] - t[0]) * tick_ns * 1e-6, (t[nw - 1] - t[0]) * tick_ns * 1e-6);
+    }
+}
+}  // namespace
+
+}  // namespace pthostside

@@ -1,0 +1,737 @@
+// pt_prep.hip -- host-side analysis of a scene description: validation, the flattened device layouts, the MFMA prefilter's
+// sphere fragments and tile-culling tables, and the host restatements of the internal traversal trees. No HIP call in this
+// file: pt_scene.hip uploads what it produces, pt_debug_select (pt_api.hip) runs it on machines without a GPU.
+#include "pt_host.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+
+namespace pthostside {
+
+// Depth of the supplied BVH (also validates child indices and acyclicity by
+// bounding the walk); returns 0 on a malformed tree.
+uint32_t bvh_depth_checked(const pt_bvh_node *nodes, uint32_t n_nodes, uint32_t n_spheres, int32_t root) {
+    struct Item { int32_t node; uint32_t depth; };
+    std::vector<Item> st;
+    st.push_back({root, 1});
+    uint32_t maxd = 0;
+    size_t visited = 0;
+    while (!st.empty()) {
+        Item it = st.back();
+        st.pop_back();
+        if (it.node < 0 || (uint32_t)it.node >= n_nodes) return 0;
+        if (++visited > (size_t)n_nodes * 2 + 2) return 0;  // a DAG/cycle would blow past this
+        if (it.depth > maxd) maxd = it.depth;
+        const int32_t ch[2] = {nodes[it.node].lhs, nodes[it.node].rhs};
+        for (int c = 0; c < 2; ++c) {
+            if (ch[c] >= 0) {
+                st.push_back({ch[c], it.depth + 1});
+            } else if ((uint32_t)(~ch[c]) >= n_spheres) {
+                return 0;
+            }
+        }
+    }
+    return maxd;
+}
+
+// Texture / material tables shared by both scene constructors.
+int validate_tables(uint32_t n_materials, const pt_material *materials, uint32_t n_textures, const pt_texture *textures,
+                    const pt_perlin *perlin, bool allow_isotropic, bool *has_noise_out, uint32_t n_images,
+                    const pt_image *images) {
+    bool has_noise = false;
+    for (uint32_t i = 0; i < n_images; ++i)
+        if (!images || !images[i].rgb || images[i].width == 0 || images[i].height == 0 ||
+            (uint64_t)images[i].width * images[i].height > (1ull << 28))
+            return fail(PT_ERR_INVALID_ARG, "image %u: empty, NULL or larger than 2^28 pixels", i);
+    for (uint32_t i = 0; i < n_textures; ++i) {
+        const pt_texture &t = textures[i];
+        if (t.kind > PT_TEX_IMAGE) return fail(PT_ERR_INVALID_ARG, "texture %u: unknown kind %u", i, t.kind);
+        if (t.kind == PT_TEX_IMAGE && (t.odd < 0 || (uint32_t)t.odd >= n_images))
+            return fail(PT_ERR_INVALID_ARG, "texture %u: image index %d out of range (images belong to pt_world_desc)", i, t.odd);
+        if (t.kind == PT_TEX_CHECKER) {
+            // arena order (storage.rs:45-48): sub-textures are allocated before the checker that
+            // references them; requiring odd/even < i also guarantees termination on device.
+            if (t.odd < 0 || t.even < 0 || (uint32_t)t.odd >= i || (uint32_t)t.even >= i)
+                return fail(PT_ERR_INVALID_ARG, "texture %u: checker children must be earlier textures", i);
+        }
+        if (t.kind == PT_TEX_NOISE) has_noise = true;
+    }
+    if (has_noise && !perlin) return fail(PT_ERR_INVALID_ARG, "noise texture without perlin tables");
+    for (uint32_t i = 0; i < n_materials; ++i) {
+        const pt_material &m = materials[i];
+        if (m.kind > (allow_isotropic ? (uint32_t)PT_MAT_ISOTROPIC : (uint32_t)PT_MAT_DIFFUSE_LIGHT))
+            return fail(PT_ERR_INVALID_ARG, "material %u: unknown kind %u", i, m.kind);
+        if (m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_DIFFUSE_LIGHT || m.kind == PT_MAT_ISOTROPIC) {
+            if (m.texture < 0 || (uint32_t)m.texture >= n_textures)
+                return fail(PT_ERR_INVALID_ARG, "material %u: texture index %d out of range", i, m.texture);
+        }
+    }
+    if (perlin)
+        for (int i = 0; i < 256; ++i)
+            if (perlin->perm_x[i] > 255 || perlin->perm_y[i] > 255 || perlin->perm_z[i] > 255)
+                return fail(PT_ERR_INVALID_ARG, "perlin permutation entry > 255");
+    *has_noise_out = has_noise;
+    return PT_OK;
+}
+
+Sweep sweep_of(const pt_sphere &p, const MotionIn *m, double t_lo, double t_hi) {
+    Sweep w{{p.cx, p.cy, p.cz}, 0.0};
+    if (!m || !m->moving) return w;
+    double s0 = (t_lo - (double)m->time_start) * (double)m->inv_time_delta, s1 = (t_hi - (double)m->time_start) * (double)m->inv_time_delta;
+    if (s0 > s1) std::swap(s0, s1);
+    const double padp = 1e-4 * (1.0 + std::fabs(s0) + std::fabs(s1));  // f32 rounding of time and of (time - t0) * inv
+    s0 -= padp, s1 += padp;
+    const double mid = 0.5 * (s0 + s1), len = std::sqrt((double)m->delta[0] * m->delta[0] + (double)m->delta[1] * m->delta[1] + (double)m->delta[2] * m->delta[2]);
+    for (int k = 0; k < 3; ++k) w.c[k] += mid * (double)m->delta[k];
+    w.half = 0.5 * (s1 - s0) * len * (1.0 + 1e-6) + 1e-6 * (std::fabs(w.c[0]) + std::fabs(w.c[1]) + std::fabs(w.c[2]));
+    return w;
+}
+
+// ---- MFMA prefilter preparation (DESIGN.md "MFMA prefilter") ------------------------------------
+// Spheres whose centre/radius stay within the f16 feature range relative to the set's centroid are
+// packed 32 per tile into A fragments of v_mfma_f32_32x32x16_f16; the rest ("large", e.g. the
+// r = 1000 ground sphere) are tested exactly for every ray. Features are computed in binary64 from
+// the exact f32 inputs and split into hi/lo f16.
+constexpr double kFeatRange = 48.0;   // |c - c0| + |r| bound for prefiltered spheres (features <= 2304 < 65504)
+constexpr double kRadiusMax = 8.0;
+constexpr uint32_t kMaxLarge = 8;
+
+uint16_t f16_bits(_Float16 h) {
+    uint16_t u;
+    memcpy(&u, &h, 2);
+    return u;
+}
+
+bool prepare_mfma(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi, MfmaPrep &out) {
+    const uint32_t n = desc->n_spheres;
+    if (n > 0xfff0u) return false;
+    // centroid of the moderate-radius spheres, rounded to f32 (c0 must be exactly what the device subtracts)
+    double cx = 0, cy = 0, cz = 0;
+    uint32_t m = 0;
+    std::vector<Sweep> sw(n);
+    for (uint32_t i = 0; i < n; ++i) sw[i] = sweep_of(desc->spheres[i], motion ? &motion[i] : nullptr, t_lo, t_hi);
+    for (uint32_t i = 0; i < n; ++i) {
+        const pt_sphere &p = desc->spheres[i];
+        if (std::fabs((double)p.radius) + sw[i].half <= kRadiusMax && std::isfinite(sw[i].c[0] + sw[i].c[1] + sw[i].c[2] + p.radius + sw[i].half)) {
+            cx += sw[i].c[0], cy += sw[i].c[1], cz += sw[i].c[2], ++m;
+        }
+    }
+    if (m == 0) return false;
+    out.c0[0] = (float)(cx / m), out.c0[1] = (float)(cy / m), out.c0[2] = (float)(cz / m);
+    std::vector<uint32_t> small;
+    for (uint32_t i = 0; i < n; ++i) {
+        const pt_sphere &p = desc->spheres[i];
+        const double dx = sw[i].c[0] - out.c0[0], dy = sw[i].c[1] - out.c0[1], dz = sw[i].c[2] - out.c0[2];
+        const double rad = std::fabs((double)p.radius) + sw[i].half;
+        const double reach = std::sqrt(dx * dx + dy * dy + dz * dz) + rad;
+        if (std::isfinite(reach) && rad <= kRadiusMax && reach <= kFeatRange && (sw[i].half == 0.0 || std::fabs((double)p.radius) > 0.0)) {
+            small.push_back(i);
+            if (reach > out.rs) out.rs = reach;
+            if (sw[i].half > 0.0) out.sweep_ratio = std::max(out.sweep_ratio, sw[i].half / std::fabs((double)p.radius));
+        } else {
+            out.large.push_back(i);
+        }
+    }
+    if (out.large.size() > kMaxLarge || small.size() < 32) return false;
+    out.n_tiles = (uint32_t)((small.size() + 31) / 32);
+    // ---- tile culling: give the tiles a spatial meaning -------------------------------------------------------
+    // Spheres of ordinary size are sorted along one axis, so a tile of 32 consecutive ones covers a short interval of
+    // that axis and a wave can skip the tiles no ray of it comes near (pt_kernel.h lane_tile_mask). Oversized spheres
+    // go last; a tile holding any of them is always run. The axis is the one on which the tiles come out narrowest.
+    // The order of the prefiltered spheres never affects the image (closest hit by (t, index)).
+    if (out.n_tiles >= 4 && out.n_tiles <= 32) {
+        auto radius_of = [&](uint32_t i) { return std::fabs((double)desc->spheres[i].radius) + sw[i].half; };
+        std::vector<double> rr;
+        for (uint32_t i : small) rr.push_back(radius_of(i));
+        std::nth_element(rr.begin(), rr.begin() + rr.size() / 2, rr.end());
+        const double r_med = rr[rr.size() / 2];
+        std::vector<uint32_t> regular, big;
+        for (uint32_t i : small) (radius_of(i) <= 3.0 * r_med ? regular : big).push_back(i);
+        const size_t full_tiles = regular.size() / 32;   // tiles made of sorted spheres only
+        int forced = -1;
+        forced = dev_knobs().cull_axis;   // (development knob: force the sort axis, 3 = culling off)
+        double best_score = 1e300;
+        int best_axis = 3;
+        for (int ax = 0; ax < 3 && full_tiles >= 3; ++ax) {
+            std::vector<uint32_t> ord = regular;
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return sw[a].c[ax] < sw[b].c[ax]; });
+            double lo_all = 1e300, hi_all = -1e300, sum = 0;
+            for (size_t T = 0; T < full_tiles; ++T) {
+                double lo = 1e300, hi = -1e300;
+                for (size_t j = T * 32; j < T * 32 + 32; ++j)
+                    lo = std::min(lo, sw[ord[j]].c[ax] - radius_of(ord[j])), hi = std::max(hi, sw[ord[j]].c[ax] + radius_of(ord[j]));
+                sum += hi - lo, lo_all = std::min(lo_all, lo), hi_all = std::max(hi_all, hi);
+            }
+            const double score = sum / ((double)full_tiles * std::max(hi_all - lo_all, 1e-30));   // mean tile extent / set extent
+            if ((forced < 0 && score < best_score) || forced == ax) best_score = score, best_axis = ax;
+        }
+        if (forced == 3) best_axis = 3;
+        if (best_axis < 3 && (best_score < 0.5 || forced >= 0)) {
+            const int ax = best_axis;
+            std::stable_sort(regular.begin(), regular.end(), [&](uint32_t a, uint32_t b) { return sw[a].c[ax] < sw[b].c[ax]; });
+            small = regular;
+            small.insert(small.end(), big.begin(), big.end());
+            std::vector<double> lo(out.n_tiles, 0.0), hi(out.n_tiles, 0.0);
+            double bmin[3] = {1e300, 1e300, 1e300}, bmax[3] = {-1e300, -1e300, -1e300};
+            for (uint32_t T = 0; T < out.n_tiles; ++T) {
+                if (T >= full_tiles) {
+                    out.cull_always |= 1u << T;
+                    continue;
+                }
+                lo[T] = 1e300, hi[T] = -1e300;
+                for (size_t j = (size_t)T * 32; j < (size_t)T * 32 + 32; ++j) {
+                    const uint32_t i = small[j];
+                    const double r = radius_of(i);
+                    lo[T] = std::min(lo[T], sw[i].c[ax] - r), hi[T] = std::max(hi[T], sw[i].c[ax] + r);
+                    for (int k = 0; k < 3; ++k) bmin[k] = std::min(bmin[k], sw[i].c[k] - r), bmax[k] = std::max(bmax[k], sw[i].c[k] + r);
+                }
+            }
+            // the box and the tile intervals are padded by 2e-3 + 1e-5 of their magnitude: the reference's f32 hit test
+            // sees a sphere inflated by ~1e-6 relative, and a moving sphere's sweep bound already carries its own slack
+            for (int k = 0; k < 3; ++k) {
+                const double pad = 2e-3 + 1e-5 * std::max(std::fabs(bmin[k]), std::fabs(bmax[k]));
+                out.clip_min[k] = std::nextafter((float)(bmin[k] - pad), -3.0e38f);
+                out.clip_max[k] = std::nextafter((float)(bmax[k] + pad), 3.0e38f);
+            }
+            out.cull_axis = (uint32_t)ax;
+            out.cull_u0 = out.clip_min[ax];
+            const double cell = std::max(((double)out.clip_max[ax] - (double)out.clip_min[ax]) / (double)kCullCells, 1e-30);
+            double rmin = 1e300, rmax = 0.0;
+            for (size_t j = 0; j < full_tiles * 32; ++j) {
+                const double r = std::fabs((double)desc->spheres[small[j]].radius);
+                rmin = std::min(rmin, r), rmax = std::max(rmax, r);
+            }
+            out.cull_rmin = (float)rmin, out.cull_rmax = (float)rmax;
+            out.cull_inv_cell = (float)(1.0 / cell);
+            out.cull_tab.assign(2 * kCullCells, 0u);
+            for (int c = 0; c < kCullCells; ++c) {
+                // cell c as the DEVICE sees it: a coordinate u lands in cell clamp(int((u - u0) * inv_cell)); one extra cell
+                // of slack on each side covers the f32 rounding of that expression
+                const double c_lo = (c == 0) ? -1e300 : (double)out.cull_u0 + (c - 1) * cell;
+                const double c_hi = (c == kCullCells - 1) ? 1e300 : (double)out.cull_u0 + (c + 2) * cell;
+                for (uint32_t T = 0; T < (uint32_t)full_tiles; ++T) {
+                    const double pad = 2e-3 + 1e-5 * std::max(std::fabs(lo[T]), std::fabs(hi[T]));
+                    if (hi[T] + pad >= c_lo) out.cull_tab[c] |= 1u << T;        // tiles reaching cell c or beyond
+                    if (lo[T] - pad <= c_hi) out.cull_tab[kCullCells + c] |= 1u << T;   // tiles starting at cell c or before
+                }
+            }
+        }
+    }
+    out.tile_sphere.assign((size_t)out.n_tiles * 32, 0xffffu);
+    out.afrag.assign((size_t)out.n_tiles * 2 * 64 * 8, 0);
+    for (uint32_t T = 0; T < out.n_tiles; ++T) {
+        for (uint32_t row = 0; row < 32; ++row) {
+            const size_t j = (size_t)T * 32 + row;
+            double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 60000.0};  // padding: S.R = -a * 60000 < thr, never a candidate
+            if (j < small.size()) {
+                const pt_sphere &p = desc->spheres[small[j]];
+                out.tile_sphere[j] = (uint16_t)small[j];
+                const Sweep &w = sw[small[j]];
+                const double x = w.c[0] - out.c0[0], y = w.c[1] - out.c0[1], z = w.c[2] - out.c0[2];
+                const volatile float r2s = p.radius * p.radius;  // sphere.rs:36 (the reference squares in f32)
+                // a moving sphere enters the prefilter as the sphere bounding its sweep: a line that meets the
+                // sphere at any covered time passes within |r| + half of the sweep's midpoint
+                const double rb = std::fabs((double)p.radius) + w.half;
+                const double r2f = w.half > 0.0 ? rb * rb : (double)r2s;
+                S[0] = x * x, S[1] = y * y, S[2] = z * z, S[3] = x * y, S[4] = x * z, S[5] = y * z;
+                S[6] = x, S[7] = y, S[8] = z, S[9] = x * x + y * y + z * z - (double)r2f;
+            }
+            _Float16 slot[32];
+            for (int f = 0; f < 10; ++f) {  // fragments hold -S: the GEMM yields thr - S.R (negative = candidate)
+                const _Float16 h = (_Float16)(-S[f]);
+                const _Float16 l = (_Float16)(-S[f] - (double)h);
+                slot[f] = h;        // x Rh
+                slot[10 + f] = h;   // x Rl
+                slot[20 + f] = l;   // x Rh
+            }
+            slot[30] = (_Float16)1.0, slot[31] = (_Float16)1.0;  // x thr_hi, x thr_lo
+            for (int c = 0; c < 2; ++c)
+                for (int half = 0; half < 2; ++half) {
+                    const uint32_t lane = row + 32 * half;
+                    for (int e = 0; e < 8; ++e)
+                        out.afrag[(((size_t)T * 2 + c) * 64 + lane) * 8 + e] = f16_bits(slot[c * 16 + half * 8 + e]);
+                }
+        }
+    }
+    return true;
+}
+
+// ---- internal BVH for BVH mode ------------------------------------------------------------------
+// The caller's tree (bvh.rs:64-94: random split axis, median split) defines the RESULT of BVHNode::ray_hit
+// but can be arbitrarily bad for traversal (random_spheres / perlin_spheres: every sphere has the same y, so
+// a third of the levels do not separate anything: ~1800 node visits per ray in the 10k-sphere scene).
+// pt_scene_create therefore builds its own tree (longest-axis median split over sphere centres; spheres
+// with a huge radius are kept out and tested for every ray) and keeps, per sphere, the AABB of its parent in
+// the CALLER's tree, which is all that is needed to reproduce the reference's accept/reject decision.
+struct AccelRef {
+    int32_t ref;
+    float mn[3], mx[3], rmin;
+    uint32_t depth;
+    float sph[4];  // leaves: the sphere as given (centre, signed radius)
+};
+
+AccelRef accel_build(std::vector<AccelItem> &items, size_t lo, size_t hi, std::vector<DWideNode> &nodes) {
+    if (hi - lo == 1) {
+        const AccelItem &it = items[lo];
+        AccelRef r{~(int32_t)it.sphere, {it.mn[0], it.mn[1], it.mn[2]}, {it.mx[0], it.mx[1], it.mx[2]}, it.r, 0,
+                   {it.c_start[0], it.c_start[1], it.c_start[2], it.signed_r}};
+        return r;
+    }
+    float cmin[3] = {3e38f, 3e38f, 3e38f}, cmax[3] = {-3e38f, -3e38f, -3e38f};
+    for (size_t i = lo; i < hi; ++i)
+        for (int k = 0; k < 3; ++k) cmin[k] = std::min(cmin[k], items[i].c[k]), cmax[k] = std::max(cmax[k], items[i].c[k]);
+    int axis = 0;
+    for (int k = 1; k < 3; ++k)
+        if (cmax[k] - cmin[k] > cmax[axis] - cmin[axis]) axis = k;
+    const size_t mid = lo + (hi - lo) / 2;
+    std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
+                     [axis](const AccelItem &a, const AccelItem &b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.sphere < b.sphere); });
+    const AccelRef l = accel_build(items, lo, mid, nodes), r = accel_build(items, mid, hi, nodes);
+    DWideNode w;
+    memset(&w, 0, sizeof w);
+    // inner children are stored as box centre / half extent (the slab test then needs no midpoint arithmetic);
+    // the half extent is rounded up until centre -+ half covers the box in exact arithmetic
+    auto centre_half = [](const float mn[3], const float mx[3], float c[3], float h[3]) {
+        for (int k = 0; k < 3; ++k) {
+            c[k] = (float)(0.5 * ((double)mn[k] + (double)mx[k]));
+            h[k] = (float)(0.5 * ((double)mx[k] - (double)mn[k]));
+            while ((double)c[k] - (double)h[k] > (double)mn[k] || (double)c[k] + (double)h[k] < (double)mx[k]) h[k] = std::nextafter(h[k], 3.0e38f);
+        }
+    };
+    centre_half(l.mn, l.mx, w.lmin, w.lmax);
+    centre_half(r.mn, r.mx, w.rmin, w.rmax);
+    w.lhs = l.ref, w.rhs = r.ref;
+    // a leaf child needs no box: its slot carries the sphere (centre, signed radius) so a leaf test costs no fetch
+    if (l.ref < 0) memcpy(w.lmin, l.sph, 12), w.lmax[0] = l.sph[3];
+    if (r.ref < 0) memcpy(w.rmin, r.sph, 12), w.rmax[0] = r.sph[3];
+    const float inv_l = 1.0f / l.rmin, inv_r = 1.0f / r.rmin;  // the pad of the conservative box test divides by the smallest radius below
+    memcpy(&w.pad0, &inv_l, 4), memcpy(&w.pad1, &inv_r, 4);
+    nodes.push_back(w);
+    AccelRef out{};
+    out.ref = (int32_t)nodes.size() - 1;
+    for (int k = 0; k < 3; ++k) out.mn[k] = std::min(l.mn[k], r.mn[k]), out.mx[k] = std::max(l.mx[k], r.mx[k]);
+    out.rmin = std::min(l.rmin, r.rmin);
+    out.depth = 1 + std::max(l.depth, r.depth);
+    return out;
+}
+
+// Spheres that go into the internal tree (with the box of their whole sweep when they move); the rest -- huge,
+// degenerate or non-finite ones -- are returned in `large` and tested for every ray.
+std::vector<AccelItem> accel_items(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi, std::vector<uint32_t> &large) {
+    std::vector<float> radii;
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) radii.push_back(std::fabs(desc->spheres[i].radius));
+    std::vector<float> sorted = radii;
+    std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
+    const float median = sorted[sorted.size() / 2];
+    std::vector<AccelItem> items;
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+        const pt_sphere &p = desc->spheres[i];
+        const float r = radii[i];
+        const bool finite = std::isfinite(p.cx) && std::isfinite(p.cy) && std::isfinite(p.cz) && std::isfinite(r);
+        // (radii below 1e-5 stay out of the tree as well: its packed nodes hold the pad constant 6e-6 / r_min as a power of two <= 1)
+        if (!finite || r > 16.0f * median || !(r > 1.0e-5f)) {
+            large.push_back(i);
+            continue;
+        }
+        AccelItem it{i, {p.cx, p.cy, p.cz}, {p.cx - r, p.cy - r, p.cz - r}, {p.cx + r, p.cy + r, p.cz + r}, r, p.radius, {p.cx, p.cy, p.cz}};
+        if (motion && motion[i].moving) {  // box the whole sweep; the leaf slot keeps centre_start (sphere_at moves it)
+            const Sweep w = sweep_of(p, &motion[i], t_lo, t_hi);
+            const double len = std::sqrt((double)motion[i].delta[0] * motion[i].delta[0] + (double)motion[i].delta[1] * motion[i].delta[1] +
+                                         (double)motion[i].delta[2] * motion[i].delta[2]);
+            for (int k = 0; k < 3; ++k) {
+                const double ext = len > 0.0 ? w.half * std::fabs((double)motion[i].delta[k]) / len : 0.0;
+                it.mn[k] = (float)(w.c[k] - ext - r - 1e-5 * (1.0 + std::fabs(w.c[k])));
+                it.mx[k] = (float)(w.c[k] + ext + r + 1e-5 * (1.0 + std::fabs(w.c[k])));
+                it.c[k] = (float)w.c[k];
+            }
+        }
+        items.push_back(it);
+    }
+    if (items.size() < 2) {  // degenerate: everything is tested directly
+        for (const AccelItem &it : items) large.push_back(it.sphere);
+        items.clear();
+    }
+    return items;
+}
+
+AccelBuild build_accel(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi) {
+    AccelBuild out;
+    std::vector<AccelItem> items = accel_items(desc, motion, t_lo, t_hi, out.large);
+    if (items.empty()) return out;
+    const AccelRef root = accel_build(items, 0, items.size(), out.nodes);
+    out.root = root.ref;
+    out.depth = root.depth;
+    return out;
+}
+
+// ---- 4-wide internal tree: host restatement of the DEVICE build (pt_build.hip; rules in pt_tree4.h) ----------------
+// Used as the reference the device build is tested against (PTGPU_HOST_BUILD=1 selects it) and when the device build
+// cannot run. Level by level like the device: order every segment along its longest centroid axis (stable, by the
+// orderable coordinate), cut, order the halves that are cut again, emit the children; boxes bottom-up at the end.
+void tree4_order_range(std::vector<TreeItem> &items, size_t lo, size_t hi) {
+    float cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0};
+    uint32_t umin[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, umax[3] = {0, 0, 0};
+    for (size_t i = lo; i < hi; ++i)
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t u = tree_orderable(items[i].c[k]);
+            if (u < umin[k]) umin[k] = u, cmin[k] = items[i].c[k];
+            if (u > umax[k]) umax[k] = u, cmax[k] = items[i].c[k];
+        }
+    const volatile float ex = cmax[0] - cmin[0], ey = cmax[1] - cmin[1], ez = cmax[2] - cmin[2];
+    const int axis = tree_axis_of_extents(ex, ey, ez);
+    std::stable_sort(items.begin() + lo, items.begin() + hi,
+                     [axis](const TreeItem &a, const TreeItem &b) { return tree_orderable(a.c[axis]) < tree_orderable(b.c[axis]); });
+}
+
+Tree4Host tree4_build_host(std::vector<TreeItem> items) {
+    Tree4Host out;
+    struct Seg { uint32_t lo, hi, node; };
+    std::vector<Seg> segs{{0u, (uint32_t)items.size(), 0u}};
+    std::vector<std::array<uint32_t, 4>> leaf_item(1);
+    std::vector<std::pair<uint32_t, uint32_t>> levels;   // (first node, count)
+    out.nodes.resize(1);
+    while (!segs.empty()) {
+        for (const Seg &sg : segs) tree4_order_range(items, sg.lo, sg.hi);
+        for (const Seg &sg : segs) {
+            const TreePlan pl = tree_plan(sg.hi - sg.lo);
+            if (pl.half == 2u) tree4_order_range(items, sg.lo, sg.lo + pl.cut[2]);
+            if (pl.c - pl.half == 2u) tree4_order_range(items, sg.lo + pl.cut[pl.half], sg.hi);
+        }
+        levels.push_back({(uint32_t)out.nodes.size() - (uint32_t)segs.size(), (uint32_t)segs.size()});
+        std::vector<Seg> next;
+        for (const Seg &sg : segs) {
+            const TreePlan pl = tree_plan(sg.hi - sg.lo);
+            uint32_t slot = 0;
+            int32_t child[4] = {kNoChild4, kNoChild4, kNoChild4, kNoChild4};
+            std::array<uint32_t, 4> li{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            for (int pass = 0; pass < 2; ++pass)
+                for (uint32_t j = 0; j < pl.c; ++j) {
+                    const uint32_t a = sg.lo + pl.cut[j], b = sg.lo + pl.cut[j + 1];
+                    if ((b - a > 1u) != (pass == 0)) continue;
+                    if (pass == 0) {
+                        const uint32_t node = (uint32_t)out.nodes.size();
+                        out.nodes.emplace_back();
+                        leaf_item.emplace_back();
+                        child[slot] = (int32_t)node;
+                        next.push_back({a, b, node});
+                    } else {
+                        child[slot] = ~(int32_t)items[a].sphere;
+                        li[slot] = a;
+                    }
+                    ++slot;
+                }
+            memcpy(out.nodes[sg.node].child, child, sizeof child);
+            leaf_item[sg.node] = li;
+        }
+        segs.swap(next);
+    }
+    std::vector<TreeBox> box(out.nodes.size());
+    for (size_t l = levels.size(); l-- > 0;)
+        for (uint32_t node = levels[l].first; node < levels[l].first + levels[l].second; ++node) {
+            DNode4 w = out.nodes[node];
+            TreeBox ch[4];
+            uint32_t c = 0;
+            for (uint32_t j = 0; j < 4u && w.child[j] != kNoChild4; ++j, ++c) {
+                if (w.child[j] >= 0) {
+                    ch[j] = box[w.child[j]];
+                } else {
+                    const TreeItem &it = items[leaf_item[node][j]];
+                    for (int k = 0; k < 3; ++k) ch[j].mn[k] = it.mn[k], ch[j].mx[k] = it.mx[k];
+                    ch[j].rmin = it.r;
+                }
+            }
+            box[node] = tree_finish_node(w, ch, c);
+            out.nodes[node] = w;
+        }
+    out.depth = (uint32_t)levels.size();
+    return out;
+}
+
+// ---- Scene::new, host half: everything pt_scene_create derives from the description before the device is touched ----
+int plan_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, SpherePlan &P) {
+    if (!desc) return fail(PT_ERR_INVALID_ARG, "desc is NULL");
+    if (desc->n_spheres == 0 || !desc->spheres || !desc->sphere_material) return fail(PT_ERR_INVALID_ARG, "scene has no spheres");
+    if (desc->n_materials == 0 || !desc->materials) return fail(PT_ERR_INVALID_ARG, "scene has no materials");
+    if (desc->n_textures && !desc->textures) return fail(PT_ERR_INVALID_ARG, "textures is NULL");
+    if (desc->n_spheres > 0x7fffffffu) return fail(PT_ERR_INVALID_ARG, "too many spheres");
+    bool has_noise = false;
+    if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, motion != nullptr, &has_noise)) return rc;
+    for (uint32_t i = 0; i < desc->n_spheres; ++i)
+        if (desc->sphere_material[i] >= desc->n_materials) return fail(PT_ERR_INVALID_ARG, "sphere %u: material index out of range", i);
+    if (desc->n_bvh_nodes) {
+        if (!desc->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "bvh_nodes is NULL");
+        // (the caller's depth is irrelevant for sphere scenes: traversal runs over the internal tree)
+        if (bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_spheres, desc->bvh_root) == 0)
+            return fail(PT_ERR_INVALID_ARG, "malformed BVH (bad child index or cycle)");
+    }
+    ptsel::SceneTraits &tr = P.tr;
+    tr = ptsel::SceneTraits{};
+    tr.n_spheres = desc->n_spheres;
+    tr.has_caller_bvh = desc->n_bvh_nodes != 0;
+    tr.has_noise = has_noise;
+    // the time interval the moving entries are defined over: the sweeps are bounded for ray times inside it
+    double t_lo = 0.0, t_hi = 0.0;
+    if (motion) {
+        bool first = true;
+        for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+            if (!motion[i].moving) continue;
+            const double a0 = motion[i].time_start, a1 = a0 + 1.0 / (double)motion[i].inv_time_delta;
+            if (!std::isfinite(a0) || !std::isfinite(a1)) return fail(PT_ERR_UNSUPPORTED, "moving sphere %u has a degenerate time interval", i);
+            t_lo = first ? std::min(a0, a1) : std::min(t_lo, std::min(a0, a1));
+            t_hi = first ? std::max(a0, a1) : std::max(t_hi, std::max(a0, a1));
+            first = false;
+        }
+        tr.has_motion = !first;
+        if (first) motion = nullptr;
+        tr.time_lo = (float)t_lo, tr.time_hi = (float)t_hi;
+    }
+    P.has_motion = motion != nullptr;
+    P.t_lo = t_lo, P.t_hi = t_hi;
+
+    // flatten to the device layouts
+    const uint32_t n_pad = ptsel::scan_pad(desc->n_spheres);
+    P.sph.assign(desc->n_spheres, make_float4(0, 0, 0, 0));
+    P.sph_r2.assign(n_pad, make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f));
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+        const pt_sphere &p = desc->spheres[i];
+        P.sph[i] = make_float4(p.cx, p.cy, p.cz, p.radius);
+        const volatile float r2 = p.radius * p.radius;  // sphere.rs:36, one f32 rounding
+        P.sph_r2[i] = make_float4(p.cx, p.cy, p.cz, r2);
+    }
+    // per-sphere shading records (one 64-byte fetch per hit)
+    P.shade.assign(4 * (size_t)desc->n_spheres, make_float4(0, 0, 0, 0));
+    bool palette_ok = true;   // every scattering material's attenuation is a per-sphere constant or one of two checker colours
+    bool word_ok = true;      // every attenuation fits one stack word: Noise -> its grey value; Constant / Checker2 / metal / glass -> a code
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+        const pt_sphere &p = desc->spheres[i];
+        const pt_material &m = desc->materials[desc->sphere_material[i]];
+        uint32_t flags = 0;
+        float4 qa = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], 0.f), qb = make_float4(0, 0, 0, 0);
+        if (m.kind == PT_MAT_LAMBERTIAN || m.kind == PT_MAT_DIFFUSE_LIGHT) {
+            const pt_texture &t = desc->textures[m.texture];
+            if (t.kind == PT_TEX_CONSTANT) {
+                flags = kShadeConst;
+                qa = make_float4(t.color[0], t.color[1], t.color[2], 0.f);
+            } else if (t.kind == PT_TEX_CHECKER && desc->textures[t.odd].kind == PT_TEX_CONSTANT && desc->textures[t.even].kind == PT_TEX_CONSTANT) {
+                flags = kShadeChecker2;
+                const pt_texture &o = desc->textures[t.odd], &e = desc->textures[t.even];
+                qa = make_float4(o.color[0], o.color[1], o.color[2], 0.f);
+                qb = make_float4(e.color[0], e.color[1], e.color[2], 0.f);
+            } else if (t.kind == PT_TEX_NOISE) {
+                flags = kShadeNoise;
+                qa = make_float4(t.scale, 0.f, 0.f, 0.f);
+            }
+        }
+        if (m.kind == PT_MAT_LAMBERTIAN && (flags & (kShadeConst | kShadeChecker2)) == 0) palette_ok = false;
+        if (m.kind == PT_MAT_LAMBERTIAN && flags == 0) word_ok = false;
+        if (m.kind > PT_MAT_DIFFUSE_LIGHT) palette_ok = false, word_ok = false;
+        union { uint32_t u; float f; } k{m.kind}, fl{flags}, tx{(uint32_t)m.texture};
+        P.shade[4 * i] = make_float4(p.cx, p.cy, p.cz, p.radius);
+        P.shade[4 * i + 1] = make_float4(k.f, fl.f, tx.f, m.param);
+        P.shade[4 * i + 2] = qa;
+        P.shade[4 * i + 3] = qb;
+    }
+    tr.palette_ok = palette_ok;
+    tr.word_ok = word_ok && desc->n_spheres < 0xFFFFFu;
+    P.mats.resize(desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        const pt_material &m = desc->materials[i];
+        P.mats[i] = DMat{m.kind, m.albedo[0], m.albedo[1], m.albedo[2], m.param, m.texture, 0.f, 0.f};
+    }
+    P.texs.resize(desc->n_textures ? desc->n_textures : 1);
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const pt_texture &t = desc->textures[i];
+        P.texs[i] = DTex{t.kind, t.color[0], t.color[1], t.color[2], t.odd, t.even, t.scale, 0.f};
+    }
+    // BVH mode: per-sphere parent AABB + DFS rank from the CALLER's tree (they define the result)
+    P.leaf_rank.assign(desc->n_spheres, 0);
+    P.gate.assign(2 * (size_t)desc->n_spheres, make_float4(0, 0, 0, 0));
+    if (desc->n_bvh_nodes) {
+        union FU { uint32_t u; float f; };
+        // a sphere that is not a leaf of the caller's tree can never be hit: chain count 0xffffffff = "never"
+        const FU never{0xffffffffu};
+        for (uint32_t i = 0; i < desc->n_spheres; ++i) P.gate[2 * i] = make_float4(0, 0, 0, never.f);
+        // The slab test (aabb.rs:46-58) takes min/max of the two plane distances, so a box acts as the interval
+        // [min(mn, mx), max(mn, mx)] per axis; when an ancestor's interval contains its child's on every axis,
+        // passing the child implies passing the ancestor (the arithmetic is monotone). Boxes built by
+        // AABB::add (aabb.rs:61-66) nest like that, EXCEPT above inverted boxes (a negative radius gives
+        // min > max, sphere.rs:69-75): there an ancestor can reject a ray its descendant accepts. Each leaf
+        // therefore gets its parent's box plus every ancestor that is not implied by the one below it.
+        auto implied_by = [&](const pt_bvh_node &up, const pt_bvh_node &low) {
+            for (int a = 0; a < 3; ++a) {
+                const float ul = std::min(up.min[a], up.max[a]), uh = std::max(up.min[a], up.max[a]);
+                const float ll = std::min(low.min[a], low.max[a]), lh = std::max(low.min[a], low.max[a]);
+                if (!(ul <= ll && uh >= lh)) return false;
+            }
+            return true;
+        };
+        // lhs-before-rhs DFS; a sphere referenced by several leaves keeps its LAST rank (bvh.rs:73-79 lhs == rhs)
+        struct Item { int32_t ref; int32_t parent; uint32_t depth; };
+        std::vector<Item> st{{desc->bvh_root, -1, 0}};
+        std::vector<int32_t> path;   // ancestors of the item being visited, root first
+        uint32_t rank = 0;
+        while (!st.empty()) {
+            const Item it = st.back();
+            st.pop_back();
+            path.resize(it.depth);
+            if (it.ref < 0) {
+                const uint32_t k = (uint32_t)~it.ref;
+                P.rank_sphere.push_back(k);
+                P.leaf_rank[k] = rank++;
+                const pt_bvh_node &pn = desc->bvh_nodes[it.parent];
+                FU cnt{0}, off{(uint32_t)(P.gate_chain.size() / 2)};
+                for (size_t j = path.size() - 1; j-- > 0;) {   // grandparent upwards
+                    const pt_bvh_node &up = desc->bvh_nodes[path[j]], &low = desc->bvh_nodes[path[j + 1]];
+                    if (!implied_by(up, low)) {
+                        P.gate_chain.push_back(make_float4(up.min[0], up.min[1], up.min[2], 0.f));
+                        P.gate_chain.push_back(make_float4(up.max[0], up.max[1], up.max[2], 0.f));
+                        ++cnt.u;
+                    }
+                }
+                P.gate[2 * k] = make_float4(pn.min[0], pn.min[1], pn.min[2], cnt.f);
+                P.gate[2 * k + 1] = make_float4(pn.max[0], pn.max[1], pn.max[2], off.f);
+            } else {
+                path.push_back(it.ref);
+                st.push_back({desc->bvh_nodes[it.ref].rhs, it.ref, it.depth + 1});
+                st.push_back({desc->bvh_nodes[it.ref].lhs, it.ref, it.depth + 1});
+            }
+        }
+    }
+    {   // the internal tree is built for every scene: BVH mode always may use it, list mode uses it for scenes too large for
+        // the scan (there it needs no gate: closest t, ties to the lower list index)
+        const std::vector<AccelItem> items = accel_items(desc, motion, t_lo, t_hi, P.bvh_large);
+        P.titems.resize(items.size());
+        for (size_t i = 0; i < items.size(); ++i) {
+            P.titems[i].sphere = items[i].sphere, P.titems[i].r = items[i].r;
+            memcpy(P.titems[i].c, items[i].c, 12), memcpy(P.titems[i].mn, items[i].mn, 12), memcpy(P.titems[i].mx, items[i].mx, 12);
+        }
+    }
+    P.pvec.assign(256, make_float4(0, 0, 0, 0));
+    P.pperm.assign(768, 0);
+    if (desc->perlin) {
+        for (int i = 0; i < 256; ++i) {
+            P.pvec[i] = make_float4(desc->perlin->randvec[i][0], desc->perlin->randvec[i][1], desc->perlin->randvec[i][2], 0.f);
+            P.pperm[i] = desc->perlin->perm_x[i];
+            P.pperm[256 + i] = desc->perlin->perm_y[i];
+            P.pperm[512 + i] = desc->perlin->perm_z[i];
+        }
+    }
+    if (desc->n_bvh_nodes) {
+        P.leafrec.resize(4 * (size_t)desc->n_spheres);
+        for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+            union { uint32_t u; float f; } rk{P.leaf_rank[i]};
+            P.leafrec[4 * i] = P.sph[i], P.leafrec[4 * i + 1] = P.gate[2 * i], P.leafrec[4 * i + 2] = P.gate[2 * i + 1];
+            P.leafrec[4 * i + 3] = make_float4(rk.f, 0.f, 0.f, 0.f);
+        }
+    }
+    P.shade_rank.resize(4 * P.rank_sphere.size());
+    for (size_t r = 0; r < P.rank_sphere.size(); ++r)
+        for (int q = 0; q < 4; ++q) P.shade_rank[4 * r + q] = P.shade[4 * (size_t)P.rank_sphere[r] + q];
+    if (motion) {
+        P.mot.assign(2 * (size_t)desc->n_spheres, make_float4(0, 0, 0, 0));
+        for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+            if (!motion[i].moving) continue;
+            P.mot[2 * i] = make_float4(motion[i].delta[0], motion[i].delta[1], motion[i].delta[2], motion[i].inv_time_delta);
+            P.mot[2 * i + 1] = make_float4(motion[i].time_start, 1.0f, 0.f, 0.f);
+        }
+    }
+    P.has_prep = prepare_mfma(desc, motion, t_lo, t_hi, P.prep);
+    tr.n_tiles = P.has_prep ? P.prep.n_tiles : 0u;
+    return PT_OK;
+}
+
+// A world description seen as a sphere scene when every entry is a Sphere or a MovingSphere (the specialised kernels then
+// apply); also the world-level facts the general kernel's selection needs.
+int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
+    if (!desc) return fail(PT_ERR_INVALID_ARG, "desc is NULL");
+    // an EMPTY list is a valid world (HitableList::ray_hit returns None for every ray: the `final` preset)
+    if (desc->n_hitables && !desc->hitables) return fail(PT_ERR_INVALID_ARG, "hitables is NULL");
+    if (desc->n_hitables > 0x3fffffffu) return fail(PT_ERR_INVALID_ARG, "too many hitables");
+    if (desc->n_hitables && (desc->n_materials == 0 || !desc->materials)) return fail(PT_ERR_INVALID_ARG, "world has no materials");
+    if (desc->n_materials && !desc->materials) return fail(PT_ERR_INVALID_ARG, "materials is NULL");
+    if (desc->n_hitables == 0 && desc->n_bvh_nodes) return fail(PT_ERR_INVALID_ARG, "BVH nodes over an empty list");
+    if (desc->n_textures && !desc->textures) return fail(PT_ERR_INVALID_ARG, "textures is NULL");
+    if (desc->n_transforms && !desc->transforms) return fail(PT_ERR_INVALID_ARG, "transforms is NULL");
+    bool has_noise = false;
+    if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, true, &has_noise, desc->n_images, desc->images))
+        return rc;
+    W.has_noise = has_noise;
+    W.has_image = false;
+    for (uint32_t i = 0; i < desc->n_textures; ++i) W.has_image = W.has_image || desc->textures[i].kind == PT_TEX_IMAGE;
+    W.all_spheres = true, W.sphere_like = true, W.has_media = false;
+    for (uint32_t i = 0; i < desc->n_hitables; ++i) {
+        const pt_hitable &h = desc->hitables[i];
+        if (h.kind > PT_HIT_CUBOID) return fail(PT_ERR_INVALID_ARG, "hitable %u: unknown kind %u", i, h.kind);
+        if (h.material >= desc->n_materials) return fail(PT_ERR_INVALID_ARG, "hitable %u: material index out of range", i);
+        if (desc->materials[h.material].kind == PT_MAT_ISOTROPIC)
+            return fail(PT_ERR_INVALID_ARG, "hitable %u: Isotropic is only valid as a medium's phase function", i);
+        if (h.transform >= 0 && (uint32_t)h.transform >= desc->n_transforms) return fail(PT_ERR_INVALID_ARG, "hitable %u: transform index out of range", i);
+        if (h.medium_material >= 0) {
+            if ((uint32_t)h.medium_material >= desc->n_materials || desc->materials[h.medium_material].kind != PT_MAT_ISOTROPIC)
+                return fail(PT_ERR_INVALID_ARG, "hitable %u: medium_material must index an Isotropic material", i);
+        }
+        W.has_media = W.has_media || h.medium_material >= 0;
+        if (h.kind != PT_HIT_SPHERE || h.transform >= 0 || h.medium_material >= 0) W.all_spheres = false;
+        if (h.kind > PT_HIT_MOVING_SPHERE || h.transform >= 0 || h.medium_material >= 0) W.sphere_like = false;
+    }
+    W.ref_depth = 0;
+    if (desc->n_bvh_nodes) {
+        if (!desc->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "bvh_nodes is NULL");
+        W.ref_depth = bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_hitables, desc->bvh_root);
+        if (W.ref_depth == 0) return fail(PT_ERR_INVALID_ARG, "malformed BVH (bad child index or cycle)");
+    }
+    if (!(W.sphere_like && desc->n_hitables)) {
+        W.sphere_like = false;
+        return PT_OK;
+    }
+    W.sph.resize(desc->n_hitables), W.mat.resize(desc->n_hitables), W.motion.resize(desc->n_hitables);
+    for (uint32_t i = 0; i < desc->n_hitables; ++i) {
+        const pt_hitable &h = desc->hitables[i];
+        W.mat[i] = h.material;
+        if (h.kind == PT_HIT_SPHERE) {
+            W.sph[i] = pt_sphere{h.p[0], h.p[1], h.p[2], h.p[3]};
+            W.motion[i] = MotionIn{{0, 0, 0}, 0.f, 0.f, 0u};
+        } else {
+            W.sph[i] = pt_sphere{h.p[0], h.p[1], h.p[2], h.p[6]};
+            W.motion[i] = MotionIn{{h.p[3], h.p[4], h.p[5]}, h.p[7], h.p[8], 1u};
+        }
+    }
+    // Sphere hits have u = v = 0 (sphere.rs:47-48), so an Image texture is one texel for them: i = 0,
+    // j = ((1 - 0) * height - 0.001) as i32 = height - 1 (texture.rs:28-33). Fold it into a Constant.
+    W.folded.assign(desc->textures, desc->textures + desc->n_textures);
+    for (pt_texture &t : W.folded) {
+        if (t.kind != PT_TEX_IMAGE) continue;
+        const pt_image &im = desc->images[t.odd];
+        const volatile float fj = (1.0f - 0.0f) * (float)im.height - 0.001f;
+        int64_t j = (int64_t)fj;
+        j = std::max<int64_t>(0, std::min<int64_t>(j, (int64_t)im.height - 1));
+        const uint8_t *px = im.rgb + 3ull * im.width * (uint64_t)j;
+        const volatile float k255 = 255.0f;
+        t.kind = PT_TEX_CONSTANT;
+        t.color[0] = (float)px[0] / k255, t.color[1] = (float)px[1] / k255, t.color[2] = (float)px[2] / k255;
+        t.odd = t.even = -1;
+    }
+    pt_scene_desc &d = W.desc;
+    d = pt_scene_desc{};
+    d.n_spheres = desc->n_hitables, d.spheres = W.sph.data(), d.sphere_material = W.mat.data();
+    d.n_materials = desc->n_materials, d.materials = desc->materials;
+    d.n_textures = desc->n_textures, d.textures = W.folded.data(), d.perlin = desc->perlin;
+    d.n_bvh_nodes = desc->n_bvh_nodes, d.bvh_nodes = desc->bvh_nodes, d.bvh_root = desc->bvh_root;
+    d.has_sky = desc->has_sky;
+    memcpy(d.sky, desc->sky, sizeof d.sky);
+    return PT_OK;
+}
+
+void world_traits(const pt_world_desc *desc, const WorldAsSpheres &w, ptsel::SceneTraits &tr) {
+    tr.is_world = true;
+    tr.has_media = w.has_media;
+    tr.has_image = w.has_image;
+    tr.has_noise = w.has_noise;
+    tr.n_hitables = desc->n_hitables;
+    tr.n_world_xf = desc->n_transforms;
+    tr.ref_bvh_depth = w.ref_depth;
+    tr.has_caller_bvh = desc->n_bvh_nodes != 0;
+}
+
+}  // namespace pthostside

@@ -18,45 +18,6 @@
 
 namespace ptdev {
 
-struct WArgs {
-    const pt_hitable *hit;   // [n_hit] HitableList order, the 64-byte C-ABI records
-    const pt_affine *xf;     // Instance transforms (Affine3A, inverse)
-    const pt_bvh_node *nodes;
-    const DMat *mats;
-    const DTex *texs;
-    const float4 *perlin_vec;
-    const uint32_t *perlin_perm;
-    const uint4 *image_table;   // Texture::Image sources: (byte offset, width, height, -) per image
-    const uint8_t *image_bytes;
-    uint32_t has_image;         // some texture is an Image: rect hits then compute (u, v) (rect.rs:97-98)
-    uint32_t n_hit, n_xf;
-    int32_t bvh_root;        // >= 0: BVHNode::ray_hit over `nodes`; < 0: HitableList::ray_hit
-    uint32_t bvh_stack_entries;
-    uint32_t has_sky;
-    f3 sky;
-    uint32_t has_noise;
-    DCamera cam;
-    uint32_t width, height, samples, max_depth, frame_num;
-    float inv_nx, inv_ny, inv_ns, mix_prev, mix_new;
-    uint32_t random_seed;
-    uint32_t refill_min;
-    uint64_t seed_base;
-    uint32_t shard_index, shard_count, local_rows;
-    uint32_t tiles_x, n_items;
-    uint32_t tiles_x_magic;
-    float *rgb;
-    unsigned long long *ray_count;
-    uint32_t *work_counter;
-    float *gstack;
-    uint32_t stack_in_lds;
-    // heavy-first work order, as in pt_trace_kernel (pt_kernel.h KArgs): 8x8 tiles in the order of `tile_order` (nullptr: natural),
-    // rays per tile accumulated into `tile_cost` when a pixel completes, and a frame in two launches -- phase 1 traces the
-    // first sample of every pixel and parks (xoshiro state, colour sum) in px_state, phase 2 continues from there; 0 = one launch
-    const uint32_t *tile_order;
-    uint32_t *tile_cost;
-    uint32_t phase;
-    uint4 *px_state;
-};
 
 struct WRay {  // ray.rs:4-9
     f3 o, d, rcp;
@@ -541,9 +502,10 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
                     } else {
                         col = scale3(col, A.inv_ns);
                         float *out = A.rgb + (ly * A.width + x) * 3u;
-                        out[0] = out[0] * A.mix_prev + col.x * A.mix_new;
-                        out[1] = out[1] * A.mix_prev + col.y * A.mix_new;
-                        out[2] = out[2] * A.mix_prev + col.z * A.mix_new;
+                        const float p0 = A.prev_zero ? 0.0f : out[0], p1 = A.prev_zero ? 0.0f : out[1], p2 = A.prev_zero ? 0.0f : out[2];
+                        out[0] = p0 * A.mix_prev + col.x * A.mix_new;
+                        out[1] = p1 * A.mix_prev + col.y * A.mix_new;
+                        out[2] = p2 * A.mix_prev + col.z * A.mix_new;
                     }
                     if (A.tile_cost) atomicAdd(&A.tile_cost[(ly >> kTileLog2) * A.tiles_x + (x >> kTileLog2)], nrays - pix_start);
                     have = false;

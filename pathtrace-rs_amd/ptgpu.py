@@ -99,13 +99,27 @@ class PtWorldDesc(C.Structure):
                 ("n_images", C.c_uint32), ("images", C.POINTER(PtImage))]
 
 
+class PtKernelChoice(C.Structure):
+    """pt_kernel_choice: which kernel a frame runs on (include/ptgpu.h)."""
+    _fields_ = [(n, C.c_uint32) for n in ("family", "block", "lds_bytes", "blocks_per_cu", "moving", "gate", "verify", "ref_bvh", "ordered",
+                                          "stack_in_lds", "global_stack", "n_tiles", "world_hit_lds", "world_occ", "world_media", "refill_min")] + \
+               [("name", C.c_char * 96)]
+
+    def as_dict(self):
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_[:-1]}
+        d["name"] = self.name.decode()
+        return d
+
+
+FAMILY_WORLD, FAMILY_TREE_BINARY, FAMILY_TREE4, FAMILY_MFMA, FAMILY_SCAN_LDS, FAMILY_SCAN_HBM = range(6)
+
 EXPORTS = [
     "pt_device_count", "pt_scene_create", "pt_scene_create_world", "pt_scene_prepare", "pt_scene_destroy", "pt_render", "pt_render_device",
     "pt_render_shard_device", "pt_shard_rows", "pt_scene_set_seed_base", "pt_last_kernel_ms",
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
     "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree", "pt_scene_debug_tree_packed",
-    "pt_buffer_register", "pt_buffer_unregister",
+    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_comm_runtime",
 ]
 COMM_ID_BYTES = 128
 
@@ -162,6 +176,10 @@ def lib():
         L.pt_scene_debug_tree_packed.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint32)]
         L.pt_buffer_register.argtypes = [vp, C.c_size_t]
         L.pt_buffer_unregister.argtypes = [vp]
+        L.pt_last_kernel_choice.argtypes = [vp, C.POINTER(PtKernelChoice)]
+        L.pt_debug_select.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtWorldDesc), C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, C.c_uint32,
+                                      C.c_uint32, C.POINTER(PtKernelChoice)]
+        L.pt_comm_runtime.argtypes = [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.pt_last_error.restype = C.c_char_p
         L.pt_version.restype = C.c_char_p
         _lib = L
@@ -370,10 +388,36 @@ class Scene:
         _check(lib().pt_scene_debug_tree_packed(self._h, out.ctypes.data, out.nbytes, C.byref(ok)))
         return out[:n], bool(ok.value)
 
+    def last_kernel_choice(self):
+        """The kernel and geometry the most recent render on this handle used (dict of pt_kernel_choice)."""
+        c = PtKernelChoice()
+        _check(lib().pt_last_kernel_choice(self._h, C.byref(c)))
+        return c.as_dict()
+
     def last_launch_info(self):
         g, b, l = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         _check(lib().pt_last_launch_info(self._h, C.byref(g), C.byref(b), C.byref(l)))
         return g.value, b.value, l.value
+
+
+def debug_select(desc, params, camera, shard_count=1, blocks_per_cu=0, variant=0):
+    """pt_debug_select: the kernel choice pt_render* would make for a description -- host only, no device needed."""
+    c = PtKernelChoice()
+    d = desc.struct()
+    if isinstance(desc, WorldDesc):
+        rc = lib().pt_debug_select(None, C.byref(d), C.byref(params), C.byref(camera), shard_count, blocks_per_cu, variant, C.byref(c))
+    else:
+        rc = lib().pt_debug_select(C.byref(d), None, C.byref(params), C.byref(camera), shard_count, blocks_per_cu, variant, C.byref(c))
+    _check(rc)
+    return c.as_dict()
+
+
+def comm_runtime():
+    """(version code, path) of the RCCL the pt_comm_* functions resolved at run time; raises PtError when there is none."""
+    v = C.c_int(0)
+    buf = C.create_string_buffer(256)
+    _check(lib().pt_comm_runtime(C.byref(v), buf, 256))
+    return v.value, buf.value.decode()
 
 
 class Comm:
@@ -395,6 +439,15 @@ class Comm:
         buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
         _check(lib().pt_comm_create(buf, rank, world, device, C.byref(h)))
         return cls(h, rank, world)
+
+    @classmethod
+    def create_all(cls, devices):
+        """ncclCommInitAll: one communicator per listed device, all in this process (rank i on devices[i])."""
+        n = len(devices)
+        devs = (C.c_int * n)(*devices)
+        hs = (C.c_void_p * n)()
+        _check(lib().pt_comm_create_all(devs, n, hs))
+        return [cls(C.c_void_p(hs[i]), i, n) for i in range(n)]
 
     def gather_frame(self, width, height, d_shard_ptr, d_full_ptr, d_ray_count_ptr, root=-1, stream=0):
         _check(lib().pt_comm_gather_frame(self._h, width, height, d_shard_ptr, d_full_ptr, d_ray_count_ptr, root, stream))

@@ -312,3 +312,103 @@ def test_product_never_references_the_oracle():
                 assert "ptref" not in text and "oracle_binding" not in text and "ora_" not in text, os.path.join(dirpath, f)
     ldd = subprocess.run(["ldd", os.path.join(pkg, "_build", "libptgpu.so")], capture_output=True, text=True).stdout
     assert "ptref" not in ldd
+
+
+# ---- kernel selection (csrc/pt_select.h) enumerated on the host: no device is touched ---------------------------------
+def _select(ptgpu, pthost, preset, W, H, S, bvh, depth=10, variant=0, shards=1, blocks_per_cu=0):
+    hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=bvh, device=None)
+    c = ptgpu.PtKernelChoice()
+    p = ptgpu.PtParams(W, H, S, depth, 0, 1 if bvh else 0)
+    wd = hs.world_desc
+    rc = ptgpu.lib().pt_debug_select(None, C.byref(wd), C.byref(p), C.byref(hs.camera), shards, blocks_per_cu, variant, C.byref(c))
+    assert rc == ptgpu.PT_OK, ptgpu.lib().pt_last_error()
+    return c.as_dict()
+
+
+# preset, use_bvh -> (kernel, dynamic LDS bytes per workgroup, workgroups per CU, attenuation-stack slots in LDS) at 1200x800, 64 spp, depth 10
+SELECTION_TABLE = {
+    ("small", False): ("scan-lds<blk=256>", 38752, 3, 27),                      # 5 spheres: too few for the prefilter
+    ("small", True): ("tree4<blk=256>", 24288, 4, 9),
+    ("aras", False): ("mfma<blk=1024>", 65568, 1, 0),                           # BASELINE config 2
+    ("aras", True): ("mfma<blk=1024,gate>", 67232, 1, 0),
+    ("random_spheres", False): ("mfma<blk=1024>", 130464, 1, 0),                # BASELINE config 3 / 4: the headline kernel
+    ("random_spheres", True): ("mfma<blk=1024,gate>", 148032, 1, 0),
+    ("perlin_spheres", False): ("tree4<blk=256>", 38368, 4, 9),                 # BASELINE config 5 as a list world: walks the tree
+    ("perlin_spheres", True): ("tree4<blk=256>", 38368, 4, 9),                  # BASELINE config 5
+    ("two_perlin_spheres", False): ("scan-lds<blk=256>", 43616, 3, 27),
+    ("two_perlin_spheres", True): ("tree4<blk=256>", 29152, 4, 9),
+    ("random", False): ("mfma<blk=1024,moving>", 146080, 1, 0),                 # Sphere + MovingSphere world on the fast kernels
+    ("random", True): ("mfma<blk=1024,moving,gate>", 163648, 1, 0),
+    ("simple_light", False): ("world<bvh=0,hit_lds=1,occ=3,media=0>", 44032, 3, 1),   # noise texture: the 3-wave build with (u, v)
+    ("simple_light", True): ("world<bvh=1,hit_lds=1,occ=3,media=0>", 48128, 3, 1),
+    ("cornell", False): ("world<bvh=0,hit_lds=1,occ=4,media=0>", 39616, 4, 1),
+    ("cornell", True): ("world<bvh=1,hit_lds=1,occ=3,media=0>", 44736, 3, 1),    # four workgroups no longer fit the LDS with the BVH stack
+    ("cornell_smoke", False): ("world<bvh=0,hit_lds=1,occ=4,media=1>", 39616, 4, 1),
+    ("cornell_smoke", True): ("world<bvh=1,hit_lds=1,occ=3,media=1>", 44736, 3, 1),
+    ("smallpt", False): ("scan-lds<blk=256>", 38752, 3, 27),                     # r = 1000 walls: nothing the f16 features can hold
+    ("smallpt", True): ("tree4<blk=256>", 25824, 4, 9),
+    ("final", False): ("world<bvh=0,hit_lds=1,occ=4,media=0>", 38912, 4, 1),     # presets.rs:40-71 returns an empty list
+}
+
+
+@pytest.mark.parametrize("preset,bvh", sorted(SELECTION_TABLE))
+def test_kernel_selection_table_for_every_preset(ptgpu, pthost, preset, bvh):
+    """Which kernel renders each of the reference's presets, list and BVH, at the BASELINE frame: the table the launch path
+    executes, computed on the host from the description alone (pt_debug_select = pt_prep.hip's analysis + pt_select.h)."""
+    d = _select(ptgpu, pthost, preset, 1200, 800, 64, bvh)
+    want = SELECTION_TABLE[(preset, bvh)]
+    assert (d["name"], d["lds_bytes"], d["blocks_per_cu"], d["stack_in_lds"]) == want, d
+    assert d["ordered"] == 1 and d["global_stack"] == 0 and d["lds_bytes"] * d["blocks_per_cu"] <= 160 * 1024
+    assert d["ref_bvh"] == int(bvh) and d["verify"] == 0
+
+
+def test_kernel_selection_follows_the_tuning_word_and_the_frame(ptgpu, pthost):
+    """The tuning bits and the frame parameters move the choice the documented way (include/ptgpu.h pt_scene_set_tuning)."""
+    sel = lambda **kw: _select(ptgpu, pthost, kw.pop("preset", "random_spheres"), kw.pop("W", 1200), kw.pop("H", 800), kw.pop("S", 64), kw.pop("bvh", False), **kw)
+    assert sel(variant=4)["name"] == "scan-lds<blk=256>"                                        # exact VALU scan
+    assert sel(variant=4 | 1)["name"] == "scan-hbm<blk=256>" and sel(variant=4 | 1)["ordered"] == 0   # ... from HBM/L2: no measuring twin
+    d = sel(variant=2)                                                                           # attenuation stack in HBM: three 256-thread workgroups
+    assert (d["name"], d["blocks_per_cu"], d["global_stack"]) == ("mfma<blk=256>", 3, 1)
+    assert sel(variant=8)["name"] == "mfma<blk=256,verify>" and sel(variant=8)["ordered"] == 0   # verify mode: one launch, no order
+    assert sel(bvh=True, variant=256)["name"] == "tree4<blk=256>"                                # BVH worlds on the internal tree
+    assert sel(bvh=True, variant=256 | 2048)["name"] == "tree-binary<blk=256>"                   # ... the binary one
+    assert sel(variant=32)["ordered"] == 0                                                       # natural order
+    assert sel(S=8)["ordered"] == 0 and sel(S=8)["refill_min"] == 8                              # below 12 spp: one launch, natural order
+    assert sel(S=12)["ordered"] == 1
+    assert sel(W=64, H=48)["ordered"] == 0                                                       # 48 work tiles: not worth two launches
+    assert sel(S=256, shards=8)["name"] == "mfma<blk=1024>" and sel(S=256, shards=8)["ordered"] == 1    # one shard of BASELINE config 4
+    assert sel(depth=26)["name"] == "mfma<blk=1024>" and sel(depth=27)["name"] == "mfma<blk=768>"   # 26 palette levels: 16 waves no longer fit the LDS
+    assert sel(depth=40)["name"] == "mfma<blk=768>"
+    assert sel(depth=41)["name"] == "mfma<blk=256>" and sel(depth=41)["global_stack"] == 1       # ... nor 12: float stacks in HBM
+    assert sel(blocks_per_cu=2)["name"] == "mfma<blk=256>" and sel(blocks_per_cu=2)["blocks_per_cu"] == 2
+    assert sel(preset="random", variant=128)["name"].startswith("world<")                        # moving spheres on the general kernel
+    # a camera shutter outside the interval the moving spheres are defined on leaves the MOVING kernels (their sweeps do not cover it)
+    hs = pthost.HostScene("random", 1200, 800, samples=64, device=None)
+    cam = type(hs.camera).from_buffer_copy(hs.camera)
+    cam.time0, cam.time1 = -1.0, 2.0
+    c = ptgpu.PtKernelChoice()
+    p = ptgpu.PtParams(1200, 800, 64, 10, 0, 0)
+    wd = hs.world_desc
+    assert ptgpu.lib().pt_debug_select(None, C.byref(wd), C.byref(p), C.byref(cam), 1, 0, 0, C.byref(c)) == ptgpu.PT_OK
+    assert c.as_dict()["name"].startswith("world<bvh=0,hit_lds=1"), c.as_dict()
+
+
+def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
+    """Sphere clouds of the sizes the fuzzers draw (tests/test_gpu_parity.py _random_scene): below 32 spheres the exact scan,
+    up to 768 the MFMA prefilter, beyond that the internal tree -- and use_bvh without BVH nodes is refused."""
+    rng = np.random.default_rng(5)
+
+    def cloud(n):
+        sph = np.concatenate([rng.uniform(-6, 6, (n, 3)), rng.uniform(0.05, 0.4, (n, 1))], axis=1).astype(np.float32)
+        tex = [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)]
+        mats = [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0), (ptgpu.MAT_METAL, (0.8, 0.8, 0.8), 0.1, -1), (ptgpu.MAT_DIELECTRIC, (0, 0, 0), 1.5, -1)]
+        return ptgpu.SceneDesc(sph, rng.integers(0, 3, n).astype(np.uint32), mats, tex)
+
+    cam = ptgpu.PtCamera.from_floats(np.zeros(24, np.float32))
+    p = ptgpu.PtParams(640, 480, 16, 10, 0, 0)
+    names = {n: ptgpu.debug_select(cloud(n), p, cam)["name"] for n in (12, 40, 300, 768, 800, 2500)}
+    assert {n: names[n] for n in (12, 40, 300, 800, 2500)} == {12: "scan-lds<blk=256>", 40: "mfma<blk=1024>", 300: "mfma<blk=1024>",
+                                                               800: "tree4<blk=256>", 2500: "tree4<blk=256>"}, names
+    assert names[768].startswith("mfma<")          # 24 tiles: the last size whose fragments fit beside the rest
+    with pytest.raises(ptgpu.PtError):
+        ptgpu.debug_select(cloud(40), ptgpu.PtParams(640, 480, 16, 10, 0, 1), cam)
