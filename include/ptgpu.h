@@ -126,7 +126,8 @@ typedef struct pt_scene_desc {
 /* ---- general worlds: the other Hitable arms of collision/hitable.rs:12-21 ------
  * One pt_hitable per HitableList entry: the innermost shape plus, optionally, the Instance
  * (instance.rs:9-13) and ConstantMedium (constant_medium.rs:11-15) wrapped around it in the order the
- * reference's presets nest them: ConstantMedium(Instance(shape)). Other nestings are rejected. */
+ * reference's presets nest them: ConstantMedium(Instance(shape)). Deeper nestings go through the scene graph
+ * of pt_world_desc (pt_node), which is flattened into this form. */
 enum {
     PT_HIT_SPHERE = 0,        /* sphere.rs:8-11          p = cx cy cz radius */
     PT_HIT_MOVING_SPHERE = 1, /* moving_sphere.rs:8-14   p = centre_start(3) centre_delta(3) radius time_start inv_time_delta */
@@ -139,7 +140,10 @@ typedef struct pt_hitable {
     uint32_t kind;
     uint32_t material;       /* the &Material paired with the shape */
     uint32_t flip_normals;   /* Rect */
-    int32_t transform;       /* Instance: index into transforms, -1 = none */
+    int32_t transform;       /* Instance: index into transforms, -1 = none. (Several nested Instances, as the scene-graph
+                              * flattener below writes them: first index | inner levels << 20 | outer levels << 24 -- `outer`
+                              * Instances around the ConstantMedium, then `inner` ones between it and the shape, outermost
+                              * first, consecutive in `transforms`; at most 15 each, n_transforms < 2^20.) */
     int32_t medium_material; /* ConstantMedium: index of its Isotropic phase-function material, -1 = none */
     float density;           /* ConstantMedium */
     float p[10];
@@ -157,6 +161,27 @@ typedef struct pt_image {
     uint32_t width, height;
     const uint8_t *rgb; /* width * height * 3 bytes */
 } pt_image;
+
+/* Optional scene graph: collision/hitable.rs:12-21 lets Hitables nest freely (List in List, Instance of Instance, an
+ * Instance around a ConstantMedium, ...). With n_nodes > 0 the world is the graph rooted at nodes[root_node] and
+ * `hitables` are its leaf shapes (their own transform / medium_material must be -1: wrappers are nodes here).
+ * pt_scene_create_world FLATTENS the graph into the list form above, which is exact for
+ *   - HitableList inside HitableList: the narrowing scan of hitable_list.rs:40-56 is the scan of the concatenation;
+ *   - Instance around a HitableList: Instance::ray_hit (instance.rs:32-47) builds the same local ray for every child
+ *     and t is shared between the two spaces, so Instance(List(a, b)) = List(Instance(a), Instance(b));
+ *   - any depth of Instance around a shape, and around or inside a ConstantMedium (transform chains, see pt_hitable).
+ * Not expressible in the list form, and rejected with PT_ERR_UNSUPPORTED and a message that names the node: a
+ * ConstantMedium whose boundary is a HitableList or another ConstantMedium, a graph deeper than 15 Instance levels on
+ * one side of a medium, a cycle. With bvh_nodes, leaves index the ROOT list's children, each of which must flatten to
+ * exactly one list entry. */
+enum { PT_NODE_HITABLE = 0, PT_NODE_LIST = 1, PT_NODE_INSTANCE = 2, PT_NODE_MEDIUM = 3 };
+typedef struct pt_node {
+    uint32_t kind;
+    uint32_t a;    /* HITABLE: index into hitables | LIST: first index into node_children | INSTANCE: index into transforms |
+                    * MEDIUM: index of its Isotropic phase-function material */
+    uint32_t b;    /* LIST: number of children | INSTANCE, MEDIUM: the child node */
+    float density; /* MEDIUM */
+} pt_node;
 
 /* bvh_nodes children: >= 0 node index, < 0 ~hitable_index. */
 typedef struct pt_world_desc {
@@ -176,6 +201,11 @@ typedef struct pt_world_desc {
     float sky[3];
     uint32_t n_images;          /* Texture::Image sources (0 / NULL when unused) */
     const pt_image *images;
+    uint32_t n_nodes;           /* scene graph (0: the world is the flat list `hitables`) */
+    const pt_node *nodes;
+    uint32_t n_node_children;
+    const uint32_t *node_children;
+    uint32_t root_node;
 } pt_world_desc;
 
 typedef struct pt_scene pt_scene;
@@ -295,6 +325,9 @@ int pt_last_kernel_ms(pt_scene *scene, float *ms_out);
 int pt_last_pass_ms(pt_scene *scene, float *ms_out);
 int pt_last_launch_info(pt_scene *scene, uint32_t *grid_out, uint32_t *block_out,
                         uint32_t *lds_bytes_out);
+/* Host-side breakdown (ms, wall clock) of the most recent pt_render on a PAGEABLE buffer: out4 = { all-zero scan or copy-in
+ * (runs under the measuring launch), wait for the GPU after the last enqueue, copy-out to the caller's pages, the whole call }. */
+int pt_last_host_ms(pt_scene *scene, float out4[4]);
 
 /* The traversal tree the library builds for itself in pt_scene_create (it never affects results): a
  * 4-wide tree over the sphere centres / sweeps, built ON THE DEVICE (level-synchronous: one global stable radix sort per

@@ -990,6 +990,8 @@ struct ora_scene {
     storage st;
     hitable world;          /* scene.rs:19 */
     hitable_list list;      /* storage.rs:86 alloc_hitables */
+    /* scene graphs (ora_scene_from_graph): the nested Hitables built over the leaves in `list` */
+    instance *g_instances; constant_medium *g_media; hitable_list *g_lists; hitable *g_children;
     int has_sky; v3 sky;    /* scene.rs:20 */
     camera cam;
     int use_bvh;
@@ -1613,10 +1615,94 @@ bad:
     return NULL;
 }
 
+/* A world given as a scene graph (collision/hitable.rs:12-21 lets Hitables nest freely): built LITERALLY -- HitableList inside
+ * HitableList, Instance of Instance, Instance around a ConstantMedium ... -- over the leaf shapes of `records16` (which carry no
+ * wrappers of their own). nodes4: n_nodes rows of (kind, a, b, density bits): kind 0 shape a = leaf index | 1 HitableList of
+ * children[a .. a+b) | 2 Instance transforms[a] around node b | 3 ConstantMedium, Isotropic material a, boundary node b.
+ * The product flattens the same graph (include/ptgpu.h pt_node); this is what it must agree with. List worlds only. */
+static int graph_build(ora_scene *sc, const uint32_t *nodes4, uint32_t n_nodes, const uint32_t *children, uint32_t n_children,
+                       const float *transforms24, uint32_t n_transforms, const float *materials6, uint32_t n_materials, uint32_t n_textures,
+                       uint32_t node, uint32_t depth, size_t *n_inst, size_t *n_med, size_t *n_lists, size_t *n_child, hitable *out) {
+    if (node >= n_nodes || depth > 64) return 0;
+    const uint32_t *w = nodes4 + 4 * node;
+    switch (w[0]) {
+    case 0:
+        if (w[1] >= sc->list.len) return 0;
+        *out = sc->list.hitables[w[1]];
+        return 1;
+    case 1: {
+        if ((uint64_t)w[1] + w[2] > n_children) return 0;
+        hitable_list *l = &sc->g_lists[(*n_lists)++];
+        l->hitables = sc->g_children + *n_child; l->len = w[2];
+        *n_child += w[2];
+        for (uint32_t j = 0; j < w[2]; ++j)
+            if (!graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, children[w[1] + j],
+                             depth + 1, n_inst, n_med, n_lists, n_child, &l->hitables[j])) return 0;
+        memset(out, 0, sizeof *out); out->kind = HIT_LIST; out->list = l;
+        return 1; }
+    case 2: {
+        if (w[1] >= n_transforms) return 0;
+        hitable child;
+        if (!graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, w[2], depth + 1, n_inst,
+                         n_med, n_lists, n_child, &child)) return 0;
+        const float *a = transforms24 + 24 * w[1];
+        instance *in = &sc->g_instances[(*n_inst)++];
+        in->child = child;   /* keeps the transform AND the inverse it was given (instance.rs:16-22 computes it once) */
+        in->transform.x_axis = V3(a[0], a[1], a[2]); in->transform.y_axis = V3(a[3], a[4], a[5]);
+        in->transform.z_axis = V3(a[6], a[7], a[8]); in->transform.translation = V3(a[9], a[10], a[11]);
+        a += 12;
+        in->inv_transform.x_axis = V3(a[0], a[1], a[2]); in->inv_transform.y_axis = V3(a[3], a[4], a[5]);
+        in->inv_transform.z_axis = V3(a[6], a[7], a[8]); in->inv_transform.translation = V3(a[9], a[10], a[11]);
+        memset(out, 0, sizeof *out); out->kind = HIT_INSTANCE; out->inst = in;
+        return 1; }
+    case 3: {
+        if (w[1] >= n_materials || (int)materials6[6 * w[1]] != MAT_ISOTROPIC) return 0;
+        const float ti = materials6[6 * w[1] + 5];
+        if (ti < 0 || (uint32_t)ti >= n_textures) return 0;
+        hitable child;
+        if (!graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, w[2], depth + 1, n_inst,
+                         n_med, n_lists, n_child, &child)) return 0;
+        constant_medium *cm = &sc->g_media[(*n_med)++];
+        cm->child = child; memcpy(&cm->density, &w[3], 4);
+        memset(&cm->phase_function, 0, sizeof cm->phase_function);
+        cm->phase_function.kind = MAT_ISOTROPIC; cm->phase_function.tex = &sc->st.textures[(uint32_t)ti];
+        memset(out, 0, sizeof *out); out->kind = HIT_CONSTANT_MEDIUM; out->med = cm;
+        return 1; }
+    default: return 0;
+    }
+}
+
+ora_scene *ora_scene_from_graph(const uint32_t *records16, uint32_t n_hitables, const float *transforms24, uint32_t n_transforms,
+                                const float *materials6, uint32_t n_materials, const float *textures7, uint32_t n_textures,
+                                const float *cam24, int has_sky, const float *sky3, const uint32_t *nodes4, uint32_t n_nodes,
+                                const uint32_t *children, uint32_t n_children, uint32_t root) {
+    if (!nodes4 || !n_nodes || root >= n_nodes) return NULL;
+    for (uint32_t i = 0; i < n_hitables; ++i)   /* leaves carry no wrappers: those are nodes */
+        if ((int32_t)records16[16 * i + 3] >= 0 || (int32_t)records16[16 * i + 4] >= 0) return NULL;
+    ora_scene *sc = ora_scene_from_world(records16, n_hitables, transforms24, n_transforms, materials6, n_materials, textures7, n_textures, cam24,
+                                         has_sky, sky3, 0, NULL, NULL, 0);
+    if (!sc) return NULL;
+    /* a node can be reached along several paths (a DAG): size the pools for the expanded tree, bounded */
+    const size_t cap = 1u << 16;
+    sc->g_instances = calloc(cap, sizeof(instance)); sc->g_media = calloc(cap, sizeof(constant_medium));
+    sc->g_lists = calloc(cap, sizeof(hitable_list)); sc->g_children = calloc(cap, sizeof(hitable));
+    size_t ni = 0, nm = 0, nl = 0, nc = 0;
+    hitable rooth;
+    /* (graph_build checks its indices; the pools hold 65536 entries each, far beyond what the tests build) */
+    if (!graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, root, 0, &ni, &nm, &nl, &nc,
+                     &rooth) || ni >= cap || nm >= cap || nl >= cap || nc >= cap) {
+        ora_scene_free(sc);
+        return NULL;
+    }
+    sc->world = rooth;   /* scene.rs:19: the world is whatever Hitable the graph's root is */
+    return sc;
+}
+
 void ora_scene_free(ora_scene *s) {
     if (!s) return;
     storage_free(&s->st);
     free(s->list.hitables);
+    free(s->g_instances); free(s->g_media); free(s->g_lists); free(s->g_children);
     free(s);
 }
 

@@ -50,6 +50,12 @@ ora_scene *ora_scene_from_world(const uint32_t *records16, uint32_t n_hitables,
                                 const float *textures7, uint32_t n_textures,
                                 const float *cam24, int has_sky, const float *sky3, int use_bvh,
                                 const uint32_t *image_wh, const uint8_t *image_bytes, uint32_t n_images);
+/* The same with the world given as a scene graph (nested Hitables built literally, list worlds): nodes4 = n_nodes rows of
+ * (kind, a, b, density bits) as include/ptgpu.h pt_node; records16 are the leaf shapes (no wrappers of their own). */
+ora_scene *ora_scene_from_graph(const uint32_t *records16, uint32_t n_hitables, const float *transforms24, uint32_t n_transforms,
+                                const float *materials6, uint32_t n_materials, const float *textures7, uint32_t n_textures,
+                                const float *cam24, int has_sky, const float *sky3, const uint32_t *nodes4, uint32_t n_nodes,
+                                const uint32_t *children, uint32_t n_children, uint32_t root);
 /* (Texture::Image rows: kind 3, odd_id = image index; images = (width, height) pairs + concatenated RGB8 rows) */
 
 /* ---- Scene::update (scene.rs:73-121) ------------------------------------

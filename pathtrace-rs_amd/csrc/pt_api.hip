@@ -96,6 +96,12 @@ extern "C" int pt_last_pass_ms(pt_scene *s, float *ms_out) {
     return PT_OK;
 }
 
+extern "C" int pt_last_host_ms(pt_scene *s, float out4[4]) {
+    if (!s || !out4) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    memcpy(out4, s->host_ms, sizeof s->host_ms);
+    return PT_OK;
+}
+
 extern "C" int pt_scene_build_info(pt_scene *s, float *build_ms_out, uint32_t *n_nodes_out, uint32_t *depth_out, uint32_t *on_device_out) {
     if (!s) return fail(PT_ERR_INVALID_ARG, "scene is NULL");
     if (build_ms_out) *build_ms_out = s->tree_build_ms;
@@ -154,9 +160,12 @@ extern "C" int pt_last_kernel_choice(pt_scene *s, pt_kernel_choice *out) {
 
 // Kernel selection for a DESCRIPTION, without a device: the host half of pt_scene_create* (pt_prep.hip; the 4-wide tree's
 // size comes from the host restatement of the device build, which tests prove identical) followed by pt_select.h.
-extern "C" int pt_debug_select(const pt_scene_desc *sphere_desc, const pt_world_desc *world_desc, const pt_params *params, const pt_camera *camera,
+extern "C" int pt_debug_select(const pt_scene_desc *sphere_desc, const pt_world_desc *world_given, const pt_params *params, const pt_camera *camera,
                                uint32_t shard_count, uint32_t blocks_per_cu, uint32_t variant, pt_kernel_choice *out) {
-    if ((!sphere_desc) == (!world_desc) || !params || !camera || !out) return fail(PT_ERR_INVALID_ARG, "exactly one description, params, camera and out are required");
+    if ((!sphere_desc) == (!world_given) || !params || !camera || !out) return fail(PT_ERR_INVALID_ARG, "exactly one description, params, camera and out are required");
+    FlatWorld flat;
+    const pt_world_desc *world_desc = world_given;
+    if (int rc = flatten_world_graph(world_given, flat, &world_desc)) return rc;
     if (shard_count == 0) shard_count = 1;
     ptsel::SceneTraits tr;
     WorldAsSpheres W;

@@ -146,6 +146,7 @@ struct pt_scene {
     bool ev_valid = false;
     uint32_t last_grid = 0, last_block = 0, last_lds = 0;
     ptsel::KernelChoice last_choice;
+    float host_ms[4] = {0, 0, 0, 0};                 // last pt_render on a pageable buffer: scan / copy-in, wait for the GPU, copy-out, whole call
     unsigned long long *d_wave_end = nullptr;        // -DPT_DEVKNOBS builds with PTGPU_TIMING=1: per-wave finish times of the last launch
 };
 
@@ -228,6 +229,15 @@ struct WorldAsSpheres {
     pt_scene_desc desc{};
 };
 int analyze_world(const pt_world_desc *desc, WorldAsSpheres &out);
+// A world given as a scene graph (pt_world_desc::nodes), flattened into the list form every kernel reads (include/ptgpu.h
+// states which nestings that is exact for). `flat` is a copy of the description whose hitables / transforms / BVH leaves
+// point into this object; descriptions without a graph are passed through untouched.
+struct FlatWorld {
+    std::vector<pt_hitable> hit;
+    std::vector<pt_affine> xf;
+    pt_world_desc flat{};
+};
+int flatten_world_graph(const pt_world_desc *desc, FlatWorld &out, const pt_world_desc **use);
 void world_traits(const pt_world_desc *desc, const WorldAsSpheres &w, ptsel::SceneTraits &tr);
 
 // ---- pt_kernels_*.hip: the instantiations behind a KernelChoice --------------------------------------------------------

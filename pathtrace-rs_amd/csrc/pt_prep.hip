@@ -456,9 +456,13 @@ int plan_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, SphereP
     if (desc->n_textures && !desc->textures) return fail(PT_ERR_INVALID_ARG, "textures is NULL");
     if (desc->n_spheres > 0x7fffffffu) return fail(PT_ERR_INVALID_ARG, "too many spheres");
     bool has_noise = false;
-    if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, motion != nullptr, &has_noise)) return rc;
-    for (uint32_t i = 0; i < desc->n_spheres; ++i)
+    // (an Isotropic row may sit in the table -- a world description shares it with its media -- but no sphere may use it)
+    if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, true, &has_noise, 0, nullptr)) return rc;
+    for (uint32_t i = 0; i < desc->n_spheres; ++i) {
         if (desc->sphere_material[i] >= desc->n_materials) return fail(PT_ERR_INVALID_ARG, "sphere %u: material index out of range", i);
+        if (desc->materials[desc->sphere_material[i]].kind == PT_MAT_ISOTROPIC)
+            return fail(PT_ERR_INVALID_ARG, "sphere %u: Isotropic is only valid as a medium's phase function", i);
+    }
     if (desc->n_bvh_nodes) {
         if (!desc->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "bvh_nodes is NULL");
         // (the caller's depth is irrelevant for sphere scenes: traversal runs over the internal tree)
@@ -666,7 +670,12 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
         if (h.material >= desc->n_materials) return fail(PT_ERR_INVALID_ARG, "hitable %u: material index out of range", i);
         if (desc->materials[h.material].kind == PT_MAT_ISOTROPIC)
             return fail(PT_ERR_INVALID_ARG, "hitable %u: Isotropic is only valid as a medium's phase function", i);
-        if (h.transform >= 0 && (uint32_t)h.transform >= desc->n_transforms) return fail(PT_ERR_INVALID_ARG, "hitable %u: transform index out of range", i);
+        if (h.transform >= 0) {   // a plain index, or first | inner levels << 20 | outer levels << 24 (include/ptgpu.h pt_hitable)
+            const uint32_t u = (uint32_t)h.transform, ext = u >> 20;
+            const uint64_t last = ext ? (uint64_t)(u & 0xfffffu) + ((u >> 20) & 15u) + ((u >> 24) & 15u) : (uint64_t)u + 1u;
+            if (last > desc->n_transforms || (ext && ((u >> 28) != 0u || (((u >> 24) & 15u) != 0u && h.medium_material < 0))))
+                return fail(PT_ERR_INVALID_ARG, "hitable %u: transform index / chain out of range", i);
+        }
         if (h.medium_material >= 0) {
             if ((uint32_t)h.medium_material >= desc->n_materials || desc->materials[h.medium_material].kind != PT_MAT_ISOTROPIC)
                 return fail(PT_ERR_INVALID_ARG, "hitable %u: medium_material must index an Isotropic material", i);
@@ -720,6 +729,135 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
     d.n_bvh_nodes = desc->n_bvh_nodes, d.bvh_nodes = desc->bvh_nodes, d.bvh_root = desc->bvh_root;
     d.has_sky = desc->has_sky;
     memcpy(d.sky, desc->sky, sizeof d.sky);
+    return PT_OK;
+}
+
+// ---- scene graph -> list form (include/ptgpu.h pt_node) ------------------------------------------------------------------
+namespace {
+const char *node_kind_name(uint32_t k) {
+    static const char *n[] = {"a shape", "a HitableList", "an Instance", "a ConstantMedium"};
+    return k < 4u ? n[k] : "an unknown node";
+}
+struct Flattener {
+    const pt_world_desc *d;
+    FlatWorld *out;
+    std::vector<uint32_t> path;    // nodes on the current descent (cycle check)
+    std::vector<uint32_t> chain;   // Instance transforms met on the way down, outermost first
+    int rc = PT_OK;
+
+    bool on_path(uint32_t n) const { return std::find(path.begin(), path.end(), n) != path.end(); }
+    int32_t encode_chain(const std::vector<uint32_t> &outer, const std::vector<uint32_t> &inner) {
+        if (outer.empty() && inner.empty()) return -1;
+        const size_t first = out->xf.size();
+        for (uint32_t t : outer) out->xf.push_back(d->transforms[t]);
+        for (uint32_t t : inner) out->xf.push_back(d->transforms[t]);
+        // (a single inner level is also written in the extended form: a plain index above 2^20 - 1 cannot occur either way)
+        return (int32_t)((uint32_t)first | ((uint32_t)inner.size() << 20) | ((uint32_t)outer.size() << 24));
+    }
+    // the boundary of a ConstantMedium: Instance* (shape); collects the Instances into `inner` and returns the leaf
+    int boundary(uint32_t medium_node, uint32_t n, std::vector<uint32_t> &inner, uint32_t *leaf) {
+        for (uint32_t guard = 0; guard <= d->n_nodes; ++guard) {
+            if (n >= d->n_nodes) return fail(PT_ERR_INVALID_ARG, "scene graph: node index %u out of range", n);
+            const pt_node &N = d->nodes[n];
+            if (N.kind == PT_NODE_HITABLE) {
+                *leaf = n;
+                return PT_OK;
+            }
+            if (N.kind != PT_NODE_INSTANCE)
+                return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u is a ConstantMedium whose boundary contains %s (node %u); only Instance levels around one shape can bound a medium",
+                            medium_node, node_kind_name(N.kind), n);
+            if (N.a >= d->n_transforms) return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: transform index %u out of range", n, N.a);
+            inner.push_back(N.a);
+            n = N.b;
+        }
+        return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u is a ConstantMedium whose boundary never reaches a shape (a cycle of Instances)", medium_node);
+    }
+    int emit(uint32_t leaf_node, const std::vector<uint32_t> &outer, const std::vector<uint32_t> &inner, int32_t medium_material, float density) {
+        const pt_node &L = d->nodes[leaf_node];
+        if (L.a >= d->n_hitables) return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: hitable index %u out of range", leaf_node, L.a);
+        pt_hitable h = d->hitables[L.a];
+        if (h.transform >= 0 || h.medium_material >= 0)
+            return fail(PT_ERR_INVALID_ARG, "scene graph: hitable %u carries its own transform / medium; in a graph these are Instance / ConstantMedium nodes", L.a);
+        if (outer.size() > 15 || inner.size() > 15)
+            return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u sits below %zu Instance levels on one side of a medium; at most 15 are supported", leaf_node,
+                        std::max(outer.size(), inner.size()));
+        if (out->hit.size() >= (1u << 22)) return fail(PT_ERR_UNSUPPORTED, "scene graph: flattening yields more than 2^22 list entries (an Instance around a HitableList is distributed over its children)");
+        h.transform = encode_chain(outer, inner);
+        if (out->xf.size() >= (1u << 20)) return fail(PT_ERR_UNSUPPORTED, "scene graph: flattening needs more than 2^20 transform slots");
+        h.medium_material = medium_material;
+        h.density = density;
+        out->hit.push_back(h);
+        return PT_OK;
+    }
+    int walk(uint32_t n) {
+        if (n >= d->n_nodes) return fail(PT_ERR_INVALID_ARG, "scene graph: node index %u out of range", n);
+        if (on_path(n)) return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u contains itself (a cycle)", n);
+        if (path.size() > 256) return fail(PT_ERR_UNSUPPORTED, "scene graph: deeper than 256 levels at node %u", n);
+        const pt_node &N = d->nodes[n];
+        path.push_back(n);
+        int r = PT_OK;
+        switch (N.kind) {
+        case PT_NODE_HITABLE: r = emit(n, {}, chain, -1, 0.f); break;
+        case PT_NODE_LIST:
+            if ((uint64_t)N.a + N.b > d->n_node_children) r = fail(PT_ERR_INVALID_ARG, "scene graph: node %u: children [%u, %u) exceed node_children", n, N.a, N.a + N.b);
+            for (uint32_t j = 0; j < N.b && r == PT_OK; ++j) r = walk(d->node_children[N.a + j]);
+            break;
+        case PT_NODE_INSTANCE:
+            if (N.a >= d->n_transforms) {
+                r = fail(PT_ERR_INVALID_ARG, "scene graph: node %u: transform index %u out of range", n, N.a);
+                break;
+            }
+            chain.push_back(N.a);
+            r = walk(N.b);
+            chain.pop_back();
+            break;
+        case PT_NODE_MEDIUM: {
+            std::vector<uint32_t> inner;
+            uint32_t leaf = 0;
+            if ((r = boundary(n, N.b, inner, &leaf)) == PT_OK) r = emit(leaf, chain, inner, (int32_t)N.a, N.density);
+            break;
+        }
+        default: r = fail(PT_ERR_INVALID_ARG, "scene graph: node %u: unknown kind %u", n, N.kind);
+        }
+        path.pop_back();
+        return r;
+    }
+};
+}  // namespace
+
+int flatten_world_graph(const pt_world_desc *desc, FlatWorld &out, const pt_world_desc **use) {
+    *use = desc;
+    if (!desc || desc->n_nodes == 0) return PT_OK;
+    if (!desc->nodes || (desc->n_node_children && !desc->node_children)) return fail(PT_ERR_INVALID_ARG, "scene graph: nodes / node_children is NULL");
+    if (desc->n_hitables && !desc->hitables) return fail(PT_ERR_INVALID_ARG, "hitables is NULL");
+    if (desc->n_transforms && !desc->transforms) return fail(PT_ERR_INVALID_ARG, "transforms is NULL");
+    if (desc->root_node >= desc->n_nodes) return fail(PT_ERR_INVALID_ARG, "scene graph: root node %u out of range", desc->root_node);
+    Flattener F{desc, &out, {}, {}};
+    std::vector<uint32_t> first_of_child;   // list entries each child of the root list starts at (BVH leaves index the root's children)
+    const pt_node &R = desc->nodes[desc->root_node];
+    if (R.kind == PT_NODE_LIST) {
+        if ((uint64_t)R.a + R.b > desc->n_node_children) return fail(PT_ERR_INVALID_ARG, "scene graph: root list exceeds node_children");
+        F.path.push_back(desc->root_node);
+        for (uint32_t j = 0; j < R.b; ++j) {
+            first_of_child.push_back((uint32_t)out.hit.size());
+            if (int rc = F.walk(desc->node_children[R.a + j])) return rc;
+        }
+    } else {
+        first_of_child.push_back(0u);
+        if (int rc = F.walk(desc->root_node)) return rc;
+    }
+    first_of_child.push_back((uint32_t)out.hit.size());
+    out.flat = *desc;
+    out.flat.n_nodes = 0, out.flat.nodes = nullptr, out.flat.n_node_children = 0, out.flat.node_children = nullptr, out.flat.root_node = 0;
+    out.flat.n_hitables = (uint32_t)out.hit.size(), out.flat.hitables = out.hit.data();
+    out.flat.n_transforms = (uint32_t)out.xf.size(), out.flat.transforms = out.xf.data();
+    if (desc->n_bvh_nodes) {
+        for (size_t c = 0; c + 1 < first_of_child.size(); ++c)
+            if (first_of_child[c + 1] - first_of_child[c] != 1u)
+                return fail(PT_ERR_UNSUPPORTED, "scene graph: BVH leaves index the root list's children, and child %zu flattens to %u list entries instead of one", c,
+                            first_of_child[c + 1] - first_of_child[c]);
+    }
+    *use = &out.flat;
     return PT_OK;
 }
 

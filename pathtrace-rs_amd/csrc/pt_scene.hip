@@ -131,9 +131,12 @@ extern "C" int pt_scene_create(const pt_scene_desc *desc, int device, pt_scene *
 }
 
 // ---- general worlds --------------------------------------------------------------------------------
-extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_scene **scene_out) {
-    if (!desc || !scene_out) return fail(PT_ERR_INVALID_ARG, "desc/scene_out is NULL");
+extern "C" int pt_scene_create_world(const pt_world_desc *given, int device, pt_scene **scene_out) {
+    if (!given || !scene_out) return fail(PT_ERR_INVALID_ARG, "desc/scene_out is NULL");
     *scene_out = nullptr;
+    FlatWorld flat;   // a scene graph is flattened into the list form first (pt_prep.hip); plain descriptions pass through
+    const pt_world_desc *desc = given;
+    if (int rc = flatten_world_graph(given, flat, &desc)) return rc;
     WorldAsSpheres W;
     if (int rc = analyze_world(desc, W)) return rc;
     if (W.sphere_like) {
@@ -144,6 +147,7 @@ extern "C" int pt_scene_create_world(const pt_world_desc *desc, int device, pt_s
         if (rc == PT_OK) {
             pt_scene *s = *scene_out;
             s->tr.n_hitables = desc->n_hitables;
+            s->tr.n_world_xf = desc->n_transforms;
             s->tr.ref_bvh_depth = W.ref_depth;
             if (W.ref_depth + 2 > 64u || (rc = upload(&s->d_hitables, desc->hitables, desc->n_hitables)) ||
                 (rc = upload(&s->d_transforms, desc->transforms, desc->n_transforms)) || (rc = upload(&s->d_ref_nodes, desc->bvh_nodes, desc->n_bvh_nodes))) {

@@ -183,16 +183,42 @@ __device__ __forceinline__ f3 w_xf_vector(const float m[12], f3 v) {
 }
 __device__ __forceinline__ f3 w_xf_point(const float m[12], f3 p) { return add3(w_xf_vector(m, p), mk3(m[9], m[10], m[11])); }
 
-// instance.rs:32-47 around the shape (ray.rs:28-40, 52-64)
-__device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine *xf, const WRay &r, float t_min, float t_max,
-                                            WHit &h, bool want_uv) {
-    if (H.transform < 0) return w_shape(H, r, t_min, t_max, h, want_uv);
-    const pt_affine &T = xf[H.transform];
-    const f3 lo = w_xf_point(T.inv, r.o), ld = w_xf_vector(T.inv, r.d);
-    const WRay local = w_ray_new(lo, ld, r.time);
+// pt_hitable.transform (include/ptgpu.h): -1 none; a plain index = ONE Instance around the shape; or, as the scene-graph
+// flattener writes it, first index | inner levels << 20 | outer levels << 24 -- `outer` Instances around the ConstantMedium
+// (if any), then `inner` ones between it and the shape, outermost first, consecutive in the transform table.
+struct WChain {
+    uint32_t first, n_in, n_out;
+};
+__device__ __forceinline__ WChain w_chain(int32_t tf) {
+    if (tf < 0) return WChain{0u, 0u, 0u};
+    const uint32_t u = (uint32_t)tf;
+    if ((u >> 20) == 0u) return WChain{u, 1u, 0u};
+    return WChain{u & 0xfffffu, (u >> 20) & 15u, (u >> 24) & 15u};
+}
+
+// instance.rs:32-47 (ray.rs:28-40, 52-64), `n` levels deep: each level builds a new Ray from the transformed origin and
+// direction (Ray::new recomputes the reciprocal), the innermost hit is carried back out level by level
+__device__ __forceinline__ WRay w_ray_into(const pt_affine *xf, uint32_t first, uint32_t n, const WRay &r) {
+    WRay local = r;
+    for (uint32_t j = 0; j < n; ++j) {
+        const pt_affine &T = xf[first + j];
+        local = w_ray_new(w_xf_point(T.inv, local.o), w_xf_vector(T.inv, local.d), r.time);
+    }
+    return local;
+}
+__device__ __forceinline__ void w_hit_out_of(const pt_affine *xf, uint32_t first, uint32_t n, WHit &h) {
+    for (uint32_t j = n; j-- > 0u;) {
+        const pt_affine &T = xf[first + j];
+        h.point = w_xf_point(T.m, h.point);
+        h.normal = w_xf_vector(T.m, h.normal);
+    }
+}
+__device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine *xf, const WChain &c, const WRay &r, float t_min, float t_max, WHit &h,
+                                            bool want_uv) {
+    if (c.n_in == 0u) return w_shape(H, r, t_min, t_max, h, want_uv);
+    const WRay local = w_ray_into(xf, c.first + c.n_out, c.n_in, r);
     if (!w_shape(H, local, t_min, t_max, h, want_uv)) return false;
-    h.point = w_xf_point(T.m, h.point);
-    h.normal = w_xf_vector(T.m, h.normal);
+    w_hit_out_of(xf, c.first + c.n_out, c.n_in, h);
     return true;
 }
 
@@ -200,22 +226,30 @@ __device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine
 // (constant_medium.rs:39-43): the shape code is reached through ONE call site in a two-trip loop so it exists once.
 // Returns the material index, or -1 for no hit.
 template <bool MEDIA>
-__device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *xf, const WRay &r, float t_min, float t_max,
+__device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *xf, const WRay &r_in, float t_min, float t_max,
                                          Rng &rng, WHit &h, bool want_uv) {
     const bool medium = MEDIA && H.medium_material >= 0;   // MEDIA = false: the world has no ConstantMedium (its code, and the RNG's liveness across the scan, drop out)
+    const WChain chain = w_chain(H.transform);
+    // Instances AROUND the medium (scene graphs only; MEDIA kernels): the medium then sees the transformed ray -- its
+    // length enters the distance it samples (constant_medium.rs:51) -- and the hit is carried back out at the end
+    const bool outer = MEDIA && chain.n_out != 0u;
+    const WRay r = outer ? w_ray_into(xf, chain.first, chain.n_out, r_in) : r_in;
     float lo = medium ? -kMaxT : t_min, hi = medium ? kMaxT : t_max;
     float t_first = 0.f;
     bool ok = true;
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < (medium ? 2 : 1); ++pass) {
         if (ok) {
-            ok = w_instanced(H, xf, r, lo, hi, h, want_uv);
+            ok = w_instanced(H, xf, chain, r, lo, hi, h, want_uv);
             if (pass == 0) t_first = h.t;
             lo = h.t + 0.0001f;   // constant_medium.rs:41
             hi = kMaxT;
         }
     }
-    if (!medium) return ok ? (int)H.material : -1;
+    if (!medium) {
+        if (ok && outer) w_hit_out_of(xf, chain.first, chain.n_out, h);
+        return ok ? (int)H.material : -1;
+    }
     if (!ok) return -1;
     // constant_medium.rs:44-76
     float t1 = t_first, t2 = h.t;
@@ -232,6 +266,7 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
         h.normal = mk3(1.0f, 0.0f, 0.0f);  // Vec3::X, arbitrary
         h.t = t;
         h.u = 0.0f, h.v = 0.0f;
+        if (outer) w_hit_out_of(xf, chain.first, chain.n_out, h);
         return H.medium_material;
     }
     return -1;

@@ -96,7 +96,9 @@ class PtWorldDesc(C.Structure):
                 ("perlin", C.POINTER(PtPerlin)),
                 ("n_bvh_nodes", C.c_uint32), ("bvh_nodes", C.POINTER(PtBvhNode)), ("bvh_root", C.c_int32),
                 ("has_sky", C.c_uint32), ("sky", C.c_float * 3),
-                ("n_images", C.c_uint32), ("images", C.POINTER(PtImage))]
+                ("n_images", C.c_uint32), ("images", C.POINTER(PtImage)),
+                ("n_nodes", C.c_uint32), ("nodes", C.c_void_p), ("n_node_children", C.c_uint32), ("node_children", C.POINTER(C.c_uint32)),
+                ("root_node", C.c_uint32)]
 
 
 class PtKernelChoice(C.Structure):
@@ -119,7 +121,7 @@ EXPORTS = [
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
     "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree", "pt_scene_debug_tree_packed",
-    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_comm_runtime",
+    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_comm_runtime", "pt_last_host_ms",
 ]
 COMM_ID_BYTES = 128
 
@@ -180,6 +182,7 @@ def lib():
         L.pt_debug_select.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtWorldDesc), C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.POINTER(PtKernelChoice)]
         L.pt_comm_runtime.argtypes = [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+        L.pt_last_host_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pt_last_error.restype = C.c_char_p
         L.pt_version.restype = C.c_char_p
         _lib = L
@@ -264,11 +267,15 @@ class WorldDesc(SceneDesc):
     `transforms` an [m, 24] float32 array of pt_affine (Affine3A, inverse); the tables are SceneDesc's."""
 
     def __init__(self, hitables, transforms, materials, textures, perlin=None, bvh_nodes=None, bvh_root=-1, sky=None,
-                 images=()):
+                 images=(), nodes=None, node_children=(), root_node=0):
         super().__init__(np.zeros((0, 4), np.float32), np.zeros(0, np.uint32), materials, textures, perlin=perlin,
                          bvh_nodes=bvh_nodes, bvh_root=bvh_root, sky=sky)
         self.hitables = np.ascontiguousarray(hitables, dtype=np.uint32).reshape(-1, 16)
         self.transforms = np.ascontiguousarray(transforms, dtype=np.float32).reshape(-1, 24)
+        # optional scene graph (include/ptgpu.h pt_node): [n, 4] uint32 rows (kind, a, b, density as float bits)
+        self.nodes = None if nodes is None else np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 4)
+        self.node_children = np.ascontiguousarray(node_children, dtype=np.uint32).reshape(-1)
+        self.root_node = int(root_node)
         self.image_arrays = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]   # [H, W, 3] each
         self.images = (PtImage * max(1, len(self.image_arrays)))()
         for i, im in enumerate(self.image_arrays):
@@ -294,6 +301,11 @@ class WorldDesc(SceneDesc):
             d.sky[:] = [float(c) for c in self.sky]
         d.n_images = len(self.image_arrays)
         d.images = C.cast(self.images, C.POINTER(PtImage)) if self.image_arrays else None
+        if self.nodes is not None:
+            d.n_nodes, d.nodes = len(self.nodes), self.nodes.ctypes.data
+            d.n_node_children = len(self.node_children)
+            d.node_children = C.cast(self.node_children.ctypes.data, C.POINTER(C.c_uint32)) if len(self.node_children) else None
+            d.root_node = self.root_node
         return d
 
 
@@ -387,6 +399,12 @@ class Scene:
         ok = C.c_uint32(0)
         _check(lib().pt_scene_debug_tree_packed(self._h, out.ctypes.data, out.nbytes, C.byref(ok)))
         return out[:n], bool(ok.value)
+
+    def last_host_ms(self):
+        """(scan / copy-in, GPU wait, copy-out, whole call) in ms of the last update() on a pageable buffer."""
+        out = (C.c_float * 4)()
+        _check(lib().pt_last_host_ms(self._h, out))
+        return tuple(float(x) for x in out)
 
     def last_kernel_choice(self):
         """The kernel and geometry the most recent render on this handle used (dict of pt_kernel_choice)."""

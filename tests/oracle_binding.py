@@ -43,6 +43,8 @@ def _bind(L):
     L.ora_scene_from_world.restype = vp
     L.ora_scene_from_world.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32, vp, C.c_int, vp, C.c_int, vp, vp, u32]
     L.ora_scene_free.restype = None
+    L.ora_scene_from_graph.restype = vp
+    L.ora_scene_from_graph.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32, vp, C.c_int, vp, vp, u32, vp, u32, u32]
     L.ora_scene_update.restype = u64
     L.ora_scene_update.argtypes = [vp, u32, u32, u32, u32, u32, vp, C.c_int]
     L.ora_scene_update_range.restype = u64
@@ -131,6 +133,30 @@ class OracleScene:
         if not self.h:
             raise ValueError("malformed world description")
         self.preset, self.width, self.height, self.use_bvh = "<world>", width, height, bool(use_bvh)
+        return self
+
+    @classmethod
+    def from_graph(cls, hitables, transforms, materials, textures, camera, width, height, nodes, node_children, root_node, sky=None, library=None):
+        """Scene whose world is a scene graph built literally (List in List, Instance of Instance, Instance around a medium ...)
+        over the leaf shapes `hitables`; `nodes` = [n, 4] uint32 rows as include/ptgpu.h pt_node. List worlds only."""
+        self = cls.__new__(cls)
+        self.L = library or lib()
+        rec = np.ascontiguousarray(hitables, dtype=np.uint32).reshape(-1, 16)
+        xf = np.ascontiguousarray(transforms, dtype=np.float32).reshape(-1, 24)
+        mats = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 6)
+        texs = np.ascontiguousarray(textures, dtype=np.float32).reshape(-1, 7)
+        cam = np.ascontiguousarray(camera, dtype=np.float32).reshape(24)
+        sk = np.ascontiguousarray(sky if sky is not None else [0, 0, 0], dtype=np.float32)
+        nd = np.ascontiguousarray(nodes, dtype=np.uint32).reshape(-1, 4)
+        ch = np.ascontiguousarray(node_children, dtype=np.uint32).reshape(-1)
+        if len(ch) == 0:
+            ch = np.zeros(1, np.uint32)
+        self.h = self.L.ora_scene_from_graph(rec.ctypes.data, len(rec), xf.ctypes.data, len(xf), mats.ctypes.data, len(mats), texs.ctypes.data, len(texs),
+                                             cam.ctypes.data, 1 if sky is not None else 0, sk.ctypes.data, nd.ctypes.data, len(nd), ch.ctypes.data,
+                                             len(node_children), int(root_node))
+        if not self.h:
+            raise ValueError("malformed scene graph")
+        self.preset, self.width, self.height, self.use_bvh = "<graph>", width, height, False
         return self
 
     def close(self):

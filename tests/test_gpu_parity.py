@@ -466,6 +466,67 @@ def test_registered_host_buffer_renders_in_place(ptgpu, pthost):
         ptgpu.buffer_unregister(big)                   # not registered any more
 
 
+@pytest.mark.parametrize("preset,W,H,S", [("random_spheres", 320, 200, 16), ("cornell_smoke", 160, 120, 16), ("small", 96, 64, 4)])
+def test_pageable_host_buffer_pipeline_against_the_oracle(ptgpu, pthost, oracle, preset, W, H, S):
+    """pt_render on a pageable buffer (the call offline.rs:27-34 times): the kernels render into a pinned + mapped copy, the
+    copy-in -- or the scan that finds the buffer all +0.0f and skips it -- runs under the measuring launch, helper threads copy
+    back. Frame 0 on zeros, progressive frames on what the last one left, and frame 0 on a buffer full of values whose product
+    with mix_prev = 0 is NOT +0 (-0.0, negatives, inf, NaN: scene.rs:114-116 multiplies whatever is there): all equal the oracle
+    given the same starting buffer. Sizes with and without the two-launch work order; sphere and general-world kernels."""
+    hs = pthost.HostScene(preset, W, H, samples=S, device=0)
+    sc, p = hs.device_scene(), ptgpu.PtParams(W, H, S, 10, 0, 0)
+    osc = oracle.OracleScene(preset, W, H)
+    got, ref = np.zeros((H, W, 3), np.float32), np.zeros((H, W, 3), np.float32)
+    for f in range(3):
+        rays = sc.update(p, hs.camera, f, got)
+        _, ref_rays = osc.update(S, frame_num=f, buffer=ref)
+        assert rays == ref_rays and np.array_equal(got, ref), "frame %d: %s" % (f, _report(ref, got))
+    assert sc.last_host_ms()[3] > 0.0                      # the pageable pipeline ran (and timed itself)
+    rng = np.random.default_rng(3)
+    start = np.zeros((H, W, 3), np.float32)
+    flat = start.reshape(-1)
+    for v in (-0.0, -3.5, np.inf, -np.inf, np.nan, 1e-45):
+        flat[rng.integers(0, flat.size, 40)] = v
+    for first in (start, np.full((H, W, 3), -0.0, np.float32)):
+        got, ref = first.copy(), first.copy()
+        rays = sc.update(p, hs.camera, 0, got)
+        _, ref_rays = osc.update(S, frame_num=0, buffer=ref)
+        assert rays == ref_rays and np.array_equal(got, ref, equal_nan=True), _report(ref, got)
+        zero = ~np.isnan(ref) & (ref == 0)                                                   # (+0 vs -0 where the blend yields a zero)
+        assert np.array_equal(np.signbit(got[zero]), np.signbit(ref[zero]))
+
+
+def test_communicators_from_a_device_list_and_side_by_side(ptgpu, pthost):
+    """pt_comm_create_all with one device (all a 1-GPU box can list), two communicators alive at once, the gather-to-root form
+    across two progressive frames, and the RCCL the library resolved at run time: the copy this process had already loaded
+    (torch's), never a second one."""
+    import torch
+    ver, path = ptgpu.comm_runtime()
+    assert ver >= 21000 and "librccl" in path
+    torch_rccl = [l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l]
+    assert len(set(torch_rccl)) == 1 and os.path.samefile(torch_rccl[0], path), (set(torch_rccl), path)    # ONE RCCL in the process
+    W, H, S = 200, 120, 4
+    hs = pthost.HostScene("aras", W, H, samples=S, device=0)
+    sc, p = hs.device_scene(), ptgpu.PtParams(W, H, S, 10, 0, 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    (a,) = ptgpu.Comm.create_all([0])
+    b = ptgpu.Comm.create(ptgpu.Comm.unique_id(), 0, 1, 0)
+    ref = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    rc_ref = torch.zeros(1, dtype=torch.int64, device="cuda")
+    outs = {id(c): torch.zeros((H, W, 3), dtype=torch.float32, device="cuda") for c in (a, b)}
+    rc = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for f in range(3):                                   # frames alternate between the two communicators' forms
+        sc.update_device(p, hs.camera, f, ref.data_ptr(), rc_ref.data_ptr(), stream)
+        for c, root in ((a, 0), (b, -1)):
+            sc.update_sharded(c, p, hs.camera, f, outs[id(c)].data_ptr(), rc.data_ptr(), root, stream)
+            torch.cuda.synchronize()
+            assert int(rc.item()) == int(rc_ref.item()) and torch.equal(outs[id(c)], ref), "frame %d root %d" % (f, root)
+    a.close()
+    b.close()
+    with pytest.raises(ptgpu.PtError):
+        ptgpu.Comm.create_all([7])                       # no such device
+
+
 def test_cli_offline_render_matches_reference_harness(pthost, oracle, tmp_path):
     """offline.rs:16-60 through the C++ host CLI: banner, `{:.2}secs {}rays {:.2}Mrays/s`, and an output.png whose
     pixels are the oracle's frame through linear_to_srgb + vertical flip (math.rs:36-48, offline.rs:43-51)."""
@@ -694,6 +755,82 @@ def test_random_general_worlds_match_the_oracle(ptgpu, oracle, seed, n, kinds, b
     out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh)
     assert rays == ref_rays, "ray_count %d vs oracle %d; %s" % (rays, ref_rays, _report(ref, out))
     assert np.array_equal(ref, out), _report(ref, out)
+
+
+def _random_graph_world(oracle, seed, W, H, n_top=7, max_depth=4, media=True):
+    """A world given as a SCENE GRAPH (include/ptgpu.h pt_node): leaf shapes of every arm under random nestings of HitableList,
+    Instance (also Instance of Instance, Instance around a List) and ConstantMedium (around Instance levels around a shape, and
+    itself inside Instances). Returned as the flat arrays both sides consume; the oracle nests them literally."""
+    rng = np.random.default_rng(seed)
+    w = _random_world(oracle, seed, 40, (0, 1, 2, 3, 4, 5), W, H, media=False, instances=False, sky=(0.4, 0.5, 0.7) if seed & 1 else None)
+    mats = [list(r) for r in w["materials"]]
+    xfs, nodes, children = [], [], []
+
+    def transform():
+        m = np.linalg.qr(rng.normal(size=(3, 3)))[0] * rng.uniform(0.8, 1.25, 3)
+        t = rng.uniform(-0.7, 0.7, 3)
+        m32, t32 = m.astype(np.float32), t.astype(np.float32)
+        inv = np.linalg.inv(m32.astype(np.float64))
+        it = -(inv @ t32.astype(np.float64))
+        xfs.append(np.concatenate([m32.T.reshape(-1), t32, inv.astype(np.float32).T.reshape(-1), it.astype(np.float32)]))
+        return len(xfs) - 1
+
+    def add(kind, a, b, density=0.0):
+        nodes.append([kind, a, b, int(np.float32(density).view(np.uint32))])
+        return len(nodes) - 1
+
+    leaves = list(rng.permutation(40))
+
+    def leaf():
+        return add(0, int(leaves.pop()), 0)
+
+    def subtree(depth):
+        r = rng.random()
+        if depth >= max_depth or len(leaves) < 6 or r < 0.3:
+            return leaf()
+        if r < 0.55:                                       # Instance around anything (a List, another Instance, a medium)
+            return add(2, transform(), subtree(depth + 1))
+        if r < 0.8:                                        # HitableList inside whatever we are in
+            kids = [subtree(depth + 1) for _ in range(int(rng.integers(2, 4)))]
+            first = len(children)
+            children.extend(kids)
+            return add(1, first, len(kids))
+        if not media:
+            return leaf()
+        b = leaf()                                          # ConstantMedium around Instance^k(shape), k = 0..2
+        for _ in range(int(rng.integers(0, 3))):
+            b = add(2, transform(), b)
+        mats.append([4, 0, 0, 0, 0, int(rng.integers(0, 5))])
+        return add(3, len(mats) - 1, b, float(rng.uniform(0.1, 0.8)))
+
+    kids = [subtree(1) for _ in range(n_top)]
+    first = len(children)
+    children.extend(kids)
+    root = add(1, first, len(kids))
+    return dict(w, materials=np.array(mats, np.float32), transforms=np.array(xfs, np.float32).reshape(-1, 24), nodes=np.array(nodes, np.uint32),
+                node_children=np.array(children, np.uint32), root_node=root)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_scene_graph_worlds_match_the_oracle(ptgpu, oracle, seed):
+    """collision/hitable.rs:12-21 nests Hitables freely. The product flattens a scene graph into its list form (Lists
+    concatenated, an Instance distributed over the List inside it, Instance levels around and inside a ConstantMedium as
+    transform chains); the oracle builds the nesting literally and recurses as the reference does. Same frame, bit for bit."""
+    W, H, S = 112, 80, 4
+    g = _random_graph_world(oracle, 500 + seed, W, H, media=seed % 4 != 0)
+    osc = oracle.OracleScene.from_graph(g["hitables"], g["transforms"], g["materials"], g["textures"], g["camera"], W, H, g["nodes"], g["node_children"],
+                                        g["root_node"], sky=g["sky"])
+    ref, ref_rays = osc.update(S, max_depth=10, frame_num=0)
+    materials = [(int(r[0]), r[1:4], r[4], int(r[5])) for r in g["materials"]]
+    textures = [(int(r[0]), r[1:4], int(r[4]), int(r[5]), r[6]) for r in g["textures"]]
+    desc = ptgpu.WorldDesc(g["hitables"], g["transforms"], materials, textures, sky=g["sky"], nodes=g["nodes"], node_children=g["node_children"],
+                           root_node=g["root_node"])
+    sc = ptgpu.Scene(desc, 0)
+    out = np.zeros((H, W, 3), np.float32)
+    rays = sc.update(ptgpu.PtParams(W, H, S, 10, 0, 0), ptgpu.PtCamera.from_floats(g["camera"]), 0, out)
+    sc.close()
+    assert rays == ref_rays, "ray_count %d vs oracle %d; %s" % (rays, ref_rays, _report(ref, out))
+    assert np.array_equal(ref, out, equal_nan=True), _report(ref, out)
 
 
 def _random_sphere_world(oracle, seed, n, W, H, spread, rmax, extras=()):
@@ -1197,7 +1334,7 @@ def test_bench_default_line_keeps_the_contract():
     r = d["roofline"]
     assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0 and 0.0 < r["hbm_frac"] <= 1.0 and 0.0 <= r["mfma_busy_frac"] <= 1.0
     assert r["traffic"] > 0 and r["kernel_ms"] <= r["pass_ms"] <= d["ms_per_step"] * 1.05
-    for key in ("host_buffer", "pipelined_frames", "progressive_view"):
+    for key in ("host_contract", "pipelined_frames", "progressive_view"):
         assert d[key]["value"] > 0 and d[key]["unit"] == "Mrays/s"
-    assert d["host_buffer"]["registered"]["value"] > 0
+    assert d["host_contract"]["reused_buffer"]["value"] > 0 and d["host_contract"]["registered"]["value"] > 0 and "value_note" in d
 

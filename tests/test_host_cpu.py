@@ -412,3 +412,37 @@ def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
     assert names[768].startswith("mfma<")          # 24 tiles: the last size whose fragments fit beside the rest
     with pytest.raises(ptgpu.PtError):
         ptgpu.debug_select(cloud(40), ptgpu.PtParams(640, 480, 16, 10, 0, 1), cam)
+
+
+def test_scene_graph_nestings_the_list_form_cannot_hold_are_named(ptgpu):
+    """include/ptgpu.h pt_node: a graph is flattened on the host; what the list form cannot express is refused with
+    PT_ERR_UNSUPPORTED and a message naming the node and the nesting (checked through pt_debug_select: no device needed)."""
+    tex = [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)]
+    mats = [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0), (ptgpu.MAT_ISOTROPIC, (0, 0, 0), 0.0, 0)]
+    rec = np.zeros((3, 16), np.uint32)
+    rec[:, 3] = rec[:, 4] = 0xffffffff
+    rec[:, 6:10] = np.array([[0, 0, 0, 1], [2, 0, 0, 1], [4, 0, 0, 1]], np.float32).view(np.uint32)
+    eye = np.array([[1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0] * 2], np.float32)
+    cam = ptgpu.PtCamera.from_floats(np.zeros(24, np.float32))
+    p = ptgpu.PtParams(64, 48, 4, 10, 0, 0)
+    dens = int(np.float32(0.5).view(np.uint32))
+
+    def select(nodes, children, root):
+        return ptgpu.debug_select(ptgpu.WorldDesc(rec, eye, mats, tex, nodes=np.array(nodes, np.uint32), node_children=children, root_node=root), p, cam)
+
+    # List(List(a, b), Instance(Instance(c))): flattens to three entries -> sphere-like? no: an Instance makes it a general world
+    ok = select([[0, 0, 0, 0], [0, 1, 0, 0], [0, 2, 0, 0], [1, 0, 2, 0], [2, 0, 2, 0], [2, 0, 4, 0], [1, 2, 2, 0]], [0, 1, 3, 5], 6)
+    assert ok["name"].startswith("world<")
+    # a List of plain spheres inside a List is still a sphere world (exact scan: three spheres)
+    assert select([[0, 0, 0, 0], [0, 1, 0, 0], [0, 2, 0, 0], [1, 0, 2, 0], [1, 2, 2, 0]], [0, 1, 3, 2], 4)["name"] == "scan-lds<blk=256>"
+    for nodes, children, root, needle in [
+        ([[0, 0, 0, 0], [0, 1, 0, 0], [1, 0, 2, 0], [3, 1, 2, dens], [1, 2, 1, 0]], [0, 1, 3], 4, "ConstantMedium whose boundary contains a HitableList"),
+        ([[0, 0, 0, 0], [3, 1, 0, dens], [3, 1, 1, dens], [1, 0, 1, 0]], [2], 3, "ConstantMedium whose boundary contains a ConstantMedium"),
+        ([[2, 0, 1, 0], [2, 0, 0, 0], [1, 0, 1, 0]], [0], 2, "contains itself"),
+    ]:
+        with pytest.raises(ptgpu.PtError) as e:
+            select(nodes, children, root)
+        assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and needle in str(e.value), str(e.value)
+    with pytest.raises(ptgpu.PtError) as e:     # sixteen Instance levels around one shape
+        select([[0, 0, 0, 0]] + [[2, 0, i, 0] for i in range(16)] + [[1, 0, 1, 0]], [16], 17)
+    assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and "at most 15" in str(e.value)
