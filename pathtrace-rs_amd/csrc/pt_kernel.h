@@ -23,6 +23,11 @@
 
 namespace ptdev {
 
+// value of `v` in lane `src_lane` (any lane may ask for any lane's)
+__device__ __forceinline__ float lane_fetch_any(uint32_t src_lane, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __float_as_int(v)));
+}
+
 // ---- perlin.rs:54-111 -------------------------------------------------------
 struct PerlinLds {
     const float4 *vec;       // 256 x float4
@@ -93,6 +98,51 @@ __device__ __forceinline__ float perlin_turb(const PerlinLds &pn, f3 p) {
         weight *= 0.5f;
         temp_p = scale3(temp_p, 2.0f);
     }
+    return fabsf(accum);
+}
+
+// perlin.rs:76-87 for the lanes of a wave that need it, BALANCED over the wave: the seven octaves of a point are independent
+// evaluations of perlin_noise (at p, 2p, 4p, ... -- doubling is exact), so the wave's 7 n (point, octave) tasks are spread
+// over all 64 lanes, ceil(7 n / 64) rounds instead of seven when only n of the 64 lanes hit a noise-textured surface (the
+// rest are sky misses or lanes still traversing). Each owner then adds its octaves up in the reference's order,
+// accum += weight * noise with weight = 1, 1/2, 1/4 ..., fetching them across lanes: bit-identical to perlin_turb.
+// `scratch`: 192 words of this wave's LDS (the pair list, idle between drains). Returns 0 for lanes that do not `need`.
+__device__ __forceinline__ float wave_balanced_turb(const PerlinLds &pn, uint32_t *scratch, bool need, f3 p) {
+    const unsigned long long mask = __ballot(need);
+    const uint32_t n = (uint32_t)__popcll(mask);
+    if (n == 0u) return 0.0f;
+#ifndef PT_BALANCE_MAX
+#define PT_BALANCE_MAX 4
+#endif
+    if (7u * n > (uint32_t)PT_BALANCE_MAX * 64u) return need ? perlin_turb(pn, p) : 0.0f;   // (measured on config 5: balancing pays up to four rounds -- 8.03 Grays/s against 7.73 without, 7.97 when always on)
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    float *sp = reinterpret_cast<float *>(scratch);
+    if (need) sp[3u * rank] = p.x, sp[3u * rank + 1u] = p.y, sp[3u * rank + 2u] = p.z;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float accum = 0.0f;
+    const uint32_t tasks = 7u * n;
+    for (uint32_t base = 0; base < tasks; base += 64u) {
+        const uint32_t t = base + lane;
+        float val = 0.0f;
+        if (t < tasks) {
+            const uint32_t k = t / 7u, oct = t - 7u * k;
+            const float sc = (float)(1u << oct);          // temp_p after `oct` doublings (perlin.rs:83)
+            val = perlin_noise(pn, mk3(sp[3u * k] * sc, sp[3u * k + 1u] * sc, sp[3u * k + 2u] * sc));
+        }
+        // octave j of the owner with rank r is task 7 r + j: computed in round (7 r + j) / 64 by lane (7 r + j) % 64
+        float weight = 1.0f;
+#pragma unroll
+        for (uint32_t j = 0; j < 7u; ++j) {
+            const uint32_t tj = 7u * rank + j;
+            const float v = lane_fetch_any(tj & 63u, val);
+            if (need && (tj & ~63u) == base) accum += weight * v;   // perlin.rs:82
+            weight *= 0.5f;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();   // (the scratch words are the pair list again from here on)
     return fabsf(accum);
 }
 
@@ -1068,11 +1118,15 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
     const bool neg_x = d.x < 0.0f, neg_y = d.y < 0.0f, neg_z = d.z < 0.0f;   // near plane of an axis = the upper one when the ray runs down it
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const uint4 *base = reinterpret_cast<const uint4 *>(A.nodes4);
+    // 16-bit stack entries [entry][lane]: lanes 2j and 2j + 1 share an LDS bank, a 2-way conflict whenever their depths differ.
+    // Measured and kept: the conflict-free layout (two levels of a lane per dword) needs three more address instructions per
+    // push / pop, and cost 3.5 % of config 5 for the conflicts it removed.
+    const auto slot_of_entry = [&](int e) -> uint32_t { return (uint32_t)e * (uint32_t)BLK + (uint32_t)tid; };
     for (;;) {
         if (st.active) {
             if (st.cur == kNoChild4) {
                 if (st.sp == 0) st.active = false;
-                else st.cur = (int32_t)s_stack[(--st.sp) * BLK + tid];
+                else st.cur = (int32_t)s_stack[slot_of_entry(--st.sp)];
             }
             if (st.active) {
                 // (keeping the top levels of the tree in LDS was measured: no gain, and the flat loads that serve both kinds of
@@ -1122,11 +1176,11 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
                 PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
 #undef PT_CE
                 // (16-bit stack entries: the 4-wide tree is only used while it has fewer than 65536 nodes)
-                s_stack[st.sp * BLK + tid] = (uint16_t)(cbase + (key[3] & 3u));
+                s_stack[slot_of_entry(st.sp)] = (uint16_t)(cbase + (key[3] & 3u));
                 st.sp += key[3] != 0xffffffffu ? 1 : 0;
-                s_stack[st.sp * BLK + tid] = (uint16_t)(cbase + (key[2] & 3u));
+                s_stack[slot_of_entry(st.sp)] = (uint16_t)(cbase + (key[2] & 3u));
                 st.sp += key[2] != 0xffffffffu ? 1 : 0;
-                s_stack[st.sp * BLK + tid] = (uint16_t)(cbase + (key[1] & 3u));
+                s_stack[slot_of_entry(st.sp)] = (uint16_t)(cbase + (key[1] & 3u));
                 st.sp += key[1] != 0xffffffffu ? 1 : 0;
                 st.cur = key[0] != 0xffffffffu ? (int32_t)(cbase + (key[0] & 3u)) : kNoChild4;
                 if (st.cur == kNoChild4 && st.sp == 0) st.active = false;
@@ -1500,6 +1554,22 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         // ---- scene.rs:49-71 one level of ray_trace (BVH mode: only lanes whose traversal has finished)
         const bool shading = have && !(BVH && (TREE4 ? trav4.active : trav.active));
         wave_rays += (unsigned long long)__popcll(__ballot(shading));   // scene.rs:57 `ray_count += 1` for every lane shaded below
+        // 4-wide tree kernels: Texture::Noise of the lanes that will scatter off a noise-textured Lambertian, evaluated for the
+        // whole wave at once (wave_balanced_turb): the shading below is divergent, and a third of its lanes (sky misses) idle
+        float turb_pre = 0.0f;
+        if (WST && A.has_noise) {
+            bool need = false;
+            f3 np = mk3(0.f, 0.f, 0.f);
+            if (shading && idx >= 0) {
+                const float4 q1n = shade[4 * idx + 1];
+                need = __float_as_uint(q1n.x) == (uint32_t)PT_MAT_LAMBERTIAN && (__float_as_uint(q1n.y) & kShadeNoise) != 0u &&
+                       PT_DEPTH < __float_as_uint(s_par[12].z);
+                np = add3(o, scale3(d, t_hit));   // ray.rs:24-26, the same point the shading computes
+            }
+            // (the eight gradients of an octave are fetched before its arithmetic here: outside the divergent shading block the
+            //  32 registers that takes are free -- 128 VGPRs, no spill; +0.8 %)
+            turb_pre = wave_balanced_turb(PerlinLds{s_pvec, s_perm, true}, w_pairs, need, np);
+        }
         if (shading) {
             pix_rays += 1;
             bool terminal = true;
@@ -1550,8 +1620,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                             const bool even = (m.flags & kShadeChecker2) && !checker_is_odd(10.0f * point.x, 10.0f * point.y, 10.0f * point.z);
                             attc = (uint32_t)idx | (even ? 0x8000u : 0u);
                         } else if (WST) {
-                            if (m.flags & kShadeNoise) {
-                                attc = __float_as_uint(surface_colour().x);
+                            if (m.flags & kShadeNoise) {   // texture.rs:86-89 with the turbulence evaluated above
+                                const float v1 = 1.0f + sinf(qa.x * point.z + 10.0f * turb_pre);
+                                attc = __float_as_uint(0.5f * v1);
                             } else {
                                 const bool even = (m.flags & kShadeChecker2) && !checker_is_odd(10.0f * point.x, 10.0f * point.y, 10.0f * point.z);
                                 attc = kWstCode | (uint32_t)idx | (even ? (1u << 20) : 0u);

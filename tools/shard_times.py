@@ -33,6 +33,7 @@ def main():
     W, H, S = args.width, args.height, args.samples
     hs = pthost.HostScene(args.preset, W, H, samples=S, device=0)
     sc = hs.device_scene()
+    sc.set_tuning(0, 8192)     # every repetition measures its own work order, as bench.py's timed steps do (no reuse of the last frame's costs)
     p = ptgpu.PtParams(W, H, S, 10, 0, 0)
     stream = torch.cuda.current_stream().cuda_stream
     rc = torch.zeros(1, dtype=torch.int64, device="cuda")
