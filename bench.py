@@ -104,7 +104,7 @@ def committed_counters(preset, W, H, S, use_bvh):
                 continue
             rays = float(line["config"]["rays_per_step"])
             per_launch = dict(prof["pmc_per_launch"])
-            for k in ("hbm_bytes_per_launch", "hbm_read_bytes_corrected", "hbm_write_bytes"):
+            for k in ("hbm_bytes_per_launch", "hbm_read_bytes_corrected", "hbm_write_bytes", "hbm_bytes_measuring_launch"):
                 if k in prof:
                     per_launch[k] = prof[k]
             per_launch["kernel_avg_ms_rocprof"] = prof.get("kernel_avg_ms")
@@ -135,6 +135,10 @@ def roofline_block(kernel_name, kms, rays_launch, n_hitables, use_bvh, counters)
             out["traffic"] = per_ray["hbm_bytes_per_launch"] * rays_launch
             out["hbm_gbs"] = out["traffic"] / ksec / 1e9
             out["hbm_frac"] = out["hbm_gbs"] / HBM_PEAK_GBS
+            out["traffic_note"] = "traffic = HBM bytes of the FRAME kernel alone (the dominant kernel, per launch)"
+            if "hbm_bytes_measuring_launch" in per_ray:
+                out["traffic_both_launches"] = (per_ray["hbm_bytes_per_launch"] + per_ray["hbm_bytes_measuring_launch"]) * rays_launch
+                out["traffic_note"] += "; traffic_both_launches adds the measuring launch that precedes it (it parks 48 B per pixel)"
         if "SQ_BUSY_CYCLES" in per_launch and per_launch.get("kernel_avg_ms_rocprof"):
             # SQ_BUSY_CYCLES sums the 32 shader engines; / 32 = cycles the kernel ran = the clock it really had
             cyc = per_launch["SQ_BUSY_CYCLES"] / 32.0

@@ -65,7 +65,7 @@ struct DCamera {  // camera.rs:8-19
 // group where they are used). Left as kernel arguments they are ~45 SGPRs that the compiler keeps live across the whole
 // loop and spills into VGPR lanes (v_readlane / v_writelane around every use).
 //   [0] clip_min.xyz, cull_u0   [1] clip_max.xyz, cull_inv_cell   [2] c0.xyz, rs2   [3] m0, gamma, inv_nx, inv_ny
-//   [4..9] DCamera (24 floats, camera.rs:8-19 order)   [10] inv_ns, mix_prev, mix_new, -   [11] sky.xyz, has_sky
+//   [4..9] DCamera (24 floats, camera.rs:8-19 order)   [10] inv_ns, mix_prev, mix_new, prev_zero (0 / 1)   [11] sky.xyz, has_sky
 //   [12] as u32 bits: cull_axis, cull_always, max_depth, samples   [13] tile culling's per-ray reach: 2 kappa, kappa (2 Rs^2 + r_max^2) + r_min^2, r_min, -
 constexpr uint32_t kLdsParamBytes = 14u * 16u;
 

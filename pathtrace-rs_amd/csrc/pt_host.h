@@ -220,7 +220,7 @@ int validate_tables(uint32_t n_materials, const pt_material *materials, uint32_t
 uint32_t bvh_depth_checked(const pt_bvh_node *nodes, uint32_t n_nodes, uint32_t n_leaves, int32_t root);
 // world description -> (is it a Sphere / MovingSphere world?) + the sphere-scene view of it
 struct WorldAsSpheres {
-    bool sphere_like = false, all_spheres = false, has_media = false, has_image = false, has_noise = false;
+    bool sphere_like = false, all_spheres = false, has_media = false, has_image = false, has_noise = false, has_chains = false;
     uint32_t ref_depth = 0;
     std::vector<pt_sphere> sph;
     std::vector<uint32_t> mat;

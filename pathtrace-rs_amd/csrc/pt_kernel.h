@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         w[7] = make_float4(A.cam.u.x, A.cam.u.y, A.cam.u.z, A.cam.v.x);
         w[8] = make_float4(A.cam.v.y, A.cam.v.z, A.cam.w.x, A.cam.w.y);
         w[9] = make_float4(A.cam.w.z, A.cam.time0, A.cam.time1, A.cam.lens_radius);
-        w[10] = make_float4(A.inv_ns, A.mix_prev, A.mix_new, 0.0f);
+        w[10] = make_float4(A.inv_ns, A.mix_prev, A.mix_new, A.prev_zero ? 1.0f : 0.0f);
         w[11] = make_float4(A.sky.x, A.sky.y, A.sky.z, A.has_sky ? 1.0f : 0.0f);
         w[12] = make_float4(__uint_as_float(A.cull_axis), __uint_as_float(A.cull_always), __uint_as_float(A.max_depth), __uint_as_float(A.samples));
         w[13] = make_float4(A.cull_reach[0], A.cull_reach[1], A.cull_reach[2], 0.0f);
@@ -1401,7 +1401,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 if (!PILOT) {
                     float *out = A.rgb + ((pxy >> 16) * A.width + (pxy & 0xffffu)) * 3u;
                     // (prev_zero: pt_render found the host buffer all +0.0f and did not upload it -- same products, same sums)
-                    const float p0 = A.prev_zero ? 0.0f : out[0], p1 = A.prev_zero ? 0.0f : out[1], p2 = A.prev_zero ? 0.0f : out[2];
+                    const bool pz = pf.w != 0.0f;   // (KArgs::prev_zero, through the LDS parameter block like its neighbours)
+                    const float p0 = pz ? 0.0f : out[0], p1 = pz ? 0.0f : out[1], p2 = pz ? 0.0f : out[2];
                     out[0] = p0 * pf.y + col.x * pf.z;
                     out[1] = p1 * pf.y + col.y * pf.z;
                     out[2] = p2 * pf.y + col.z * pf.z;

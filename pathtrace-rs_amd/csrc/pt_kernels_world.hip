@@ -4,7 +4,11 @@
 
 namespace pthostside {
 
-WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media) {
+WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media, bool chains) {
+    // worlds with Instance chains (scene graphs) take the most general build: three waves per SIMD, MEDIA code present
+    if (chains)
+        return bvh ? (hit_lds ? pt_world_kernel<true, true, 3, true, true> : pt_world_kernel<true, false, 3, true, true>)
+                   : (hit_lds ? pt_world_kernel<false, true, 3, true, true> : pt_world_kernel<false, false, 3, true, true>);
     // worlds whose records do not fit LDS share the MEDIA = true code
     if (occ == 4u)
         return bvh ? (hit_lds ? (media ? pt_world_kernel<true, true, 4, true> : pt_world_kernel<true, true, 4, false>) : pt_world_kernel<true, false, 4, true>)

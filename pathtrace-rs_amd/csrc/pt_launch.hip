@@ -232,7 +232,7 @@ void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, h
 
 }  // namespace
 
-WorldKernel world_kernel_for(const ptsel::KernelChoice &c) { return world_kernel(c.ref_bvh, c.world_hit_lds, c.world_occ, c.world_media); }
+WorldKernel world_kernel_for(const ptsel::KernelChoice &c) { return world_kernel(c.ref_bvh, c.world_hit_lds, c.world_occ, c.world_media, c.world_chains); }
 
 void sphere_kernels_for(const ptsel::KernelChoice &c, SphereKernel *frame, SphereKernel *measure) {
     switch (c.family) {
@@ -250,7 +250,7 @@ void sphere_kernels_for(const ptsel::KernelChoice &c, SphereKernel *frame, Spher
 const char *kernel_name(const ptsel::KernelChoice &c, char *buf, size_t cap) {
     static const char *fam[] = {"world", "tree-binary", "tree4", "mfma", "scan-lds", "scan-hbm"};
     if (c.family == ptsel::Family::World)
-        snprintf(buf, cap, "world<bvh=%d,hit_lds=%d,occ=%u,media=%d>", (int)c.ref_bvh, (int)c.world_hit_lds, c.world_occ, (int)c.world_media);
+        snprintf(buf, cap, "world<bvh=%d,hit_lds=%d,occ=%u,media=%d%s>", (int)c.ref_bvh, (int)c.world_hit_lds, c.world_occ, (int)c.world_media, c.world_chains ? ",chains" : "");
     else
         snprintf(buf, cap, "%s<blk=%u%s%s%s>", fam[(uint32_t)c.family], c.block, c.moving ? ",moving" : "", c.gate ? ",gate" : "", c.verify ? ",verify" : "");
     return buf;

@@ -681,6 +681,8 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
                 return fail(PT_ERR_INVALID_ARG, "hitable %u: medium_material must index an Isotropic material", i);
         }
         W.has_media = W.has_media || h.medium_material >= 0;
+        if (h.transform >= 0 && ((uint32_t)h.transform >> 20) != 0u && (((uint32_t)h.transform >> 20) & 15u) + (((uint32_t)h.transform >> 24) & 15u) != 1u) W.has_chains = true;
+        if (h.transform >= 0 && (((uint32_t)h.transform >> 24) & 15u) != 0u) W.has_chains = true;
         if (h.kind != PT_HIT_SPHERE || h.transform >= 0 || h.medium_material >= 0) W.all_spheres = false;
         if (h.kind > PT_HIT_MOVING_SPHERE || h.transform >= 0 || h.medium_material >= 0) W.sphere_like = false;
     }
@@ -865,6 +867,7 @@ void world_traits(const pt_world_desc *desc, const WorldAsSpheres &w, ptsel::Sce
     tr.is_world = true;
     tr.has_media = w.has_media;
     tr.has_image = w.has_image;
+    tr.has_chains = w.has_chains;
     tr.has_noise = w.has_noise;
     tr.n_hitables = desc->n_hitables;
     tr.n_world_xf = desc->n_transforms;

@@ -58,6 +58,7 @@ struct SceneTraits {
     // ---- general worlds
     uint32_t n_hitables = 0, n_world_xf = 0, ref_bvh_depth = 0;
     bool has_media = false, has_image = false;
+    bool has_chains = false;       // some entry sits below several Instance levels, or below Instances around its medium (scene graphs)
 };
 
 enum class Family : uint32_t { World = 0, TreeBinary = 1, Tree4 = 2, Mfma = 3, ScanLds = 4, ScanHbm = 5 };
@@ -70,7 +71,7 @@ struct KernelChoice {
     bool gate = false;          // GATE instantiation: a BVH world on the MFMA list kernel
     bool verify = false;
     // general-world kernel: <BVH, HIT_LDS, OCC, MEDIA>
-    bool world_hit_lds = false, world_media = false;
+    bool world_hit_lds = false, world_media = false, world_chains = false;
     uint32_t world_occ = 3;
     uint32_t block = 256;       // threads per workgroup
     uint32_t lds_bytes = 0;     // dynamic LDS per workgroup
@@ -124,10 +125,11 @@ inline void select_world(const SceneTraits &t, const pt_params &p, uint32_t loca
     if (c.stack_in_lds) lds += (uint32_t)path_bytes;
     c.gstack = !c.stack_in_lds;
     // four waves per SIMD (128 VGPRs, no (u, v) in the hit record) for worlds without noise / image textures
-    const bool occ4 = !t.has_noise && !t.has_image && k.blocks_per_cu == 0 && 4u * lds <= kLdsBudget && !k.world_occ3;
+    c.world_chains = t.has_chains;
+    const bool occ4 = !t.has_noise && !t.has_image && !t.has_chains && k.blocks_per_cu == 0 && 4u * lds <= kLdsBudget && !k.world_occ3;
     c.world_occ = occ4 ? 4u : 3u;
     // worlds whose records do not fit LDS (more than ~600 hitables) share the MEDIA = true code
-    c.world_media = t.has_media || !c.world_hit_lds || t.has_motion;
+    c.world_media = t.has_media || !c.world_hit_lds || t.has_motion || t.has_chains;
     c.lds_bytes = lds;
     uint32_t bpc = k.blocks_per_cu ? k.blocks_per_cu : c.world_occ;
     c.bpc_forced = k.blocks_per_cu != 0;

@@ -213,9 +213,20 @@ __device__ __forceinline__ void w_hit_out_of(const pt_affine *xf, uint32_t first
         h.normal = w_xf_vector(T.m, h.normal);
     }
 }
+// CHAINS = false: at most ONE Instance around the shape and none around a medium (every preset; the kernels selected for
+// such worlds do not carry the chain loops' registers)
+template <bool CHAINS>
 __device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine *xf, const WChain &c, const WRay &r, float t_min, float t_max, WHit &h,
                                             bool want_uv) {
     if (c.n_in == 0u) return w_shape(H, r, t_min, t_max, h, want_uv);
+    if (!CHAINS) {
+        const pt_affine &T = xf[c.first];
+        const WRay local = w_ray_new(w_xf_point(T.inv, r.o), w_xf_vector(T.inv, r.d), r.time);
+        if (!w_shape(H, local, t_min, t_max, h, want_uv)) return false;
+        h.point = w_xf_point(T.m, h.point);
+        h.normal = w_xf_vector(T.m, h.normal);
+        return true;
+    }
     const WRay local = w_ray_into(xf, c.first + c.n_out, c.n_in, r);
     if (!w_shape(H, local, t_min, t_max, h, want_uv)) return false;
     w_hit_out_of(xf, c.first + c.n_out, c.n_in, h);
@@ -225,14 +236,14 @@ __device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine
 // One HitableList entry. Returns the material to shade with in `mat`. A ConstantMedium asks its boundary twice
 // (constant_medium.rs:39-43): the shape code is reached through ONE call site in a two-trip loop so it exists once.
 // Returns the material index, or -1 for no hit.
-template <bool MEDIA>
+template <bool MEDIA, bool CHAINS>
 __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *xf, const WRay &r_in, float t_min, float t_max,
                                          Rng &rng, WHit &h, bool want_uv) {
     const bool medium = MEDIA && H.medium_material >= 0;   // MEDIA = false: the world has no ConstantMedium (its code, and the RNG's liveness across the scan, drop out)
     const WChain chain = w_chain(H.transform);
     // Instances AROUND the medium (scene graphs only; MEDIA kernels): the medium then sees the transformed ray -- its
     // length enters the distance it samples (constant_medium.rs:51) -- and the hit is carried back out at the end
-    const bool outer = MEDIA && chain.n_out != 0u;
+    const bool outer = MEDIA && CHAINS && chain.n_out != 0u;
     const WRay r = outer ? w_ray_into(xf, chain.first, chain.n_out, r_in) : r_in;
     float lo = medium ? -kMaxT : t_min, hi = medium ? kMaxT : t_max;
     float t_first = 0.f;
@@ -240,7 +251,7 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
 #pragma clang loop unroll(disable)
     for (int pass = 0; pass < (medium ? 2 : 1); ++pass) {
         if (ok) {
-            ok = w_instanced(H, xf, chain, r, lo, hi, h, want_uv);
+            ok = w_instanced<CHAINS>(H, xf, chain, r, lo, hi, h, want_uv);
             if (pass == 0) t_first = h.t;
             lo = h.t + 0.0001f;   // constant_medium.rs:41
             hi = kMaxT;
@@ -279,7 +290,8 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
 // whose LDS lets four workgroups share a CU (cornell +7 %, cornell_smoke +11 %); with Perlin noise inlined the spills
 // cost more than the fourth wave brings (simple_light -6 %), so those keep 2 (the compiler then uses ~160 VGPRs).
 // MEDIA: some hitable is a ConstantMedium (own instantiations: worlds without media do not carry that path's registers).
-template <bool BVH, bool HIT_LDS, int OCC = 3, bool MEDIA = true>
+// CHAINS: some entry sits below more than one Instance level, or below Instances around its medium (scene graphs only).
+template <bool BVH, bool HIT_LDS, int OCC = 3, bool MEDIA = true, bool CHAINS = false>
 __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *p = smem;
@@ -408,7 +420,7 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
                 float closest = kMaxT;
                 for (uint32_t k = 0; k < A.n_hit; ++k) {
                     WHit h;
-                    const int m = w_hitable<MEDIA>(hit[k], xf, ray, kMinT, closest, rng, h, want_uv);
+                    const int m = w_hitable<MEDIA, CHAINS>(hit[k], xf, ray, kMinT, closest, rng, h, want_uv);
                     if (m >= 0) {
                         keep(h), best_mat = (uint32_t)m, found = true;
                         closest = h.t;
@@ -421,7 +433,7 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
                     const int32_t ref = s_stack[--sp * kBlock + tid];
                     if (ref < 0) {
                         WHit h;
-                        const int m = w_hitable<MEDIA>(hit[~ref], xf, ray, kMinT, kMaxT, rng, h, want_uv);
+                        const int m = w_hitable<MEDIA, CHAINS>(hit[~ref], xf, ray, kMinT, kMaxT, rng, h, want_uv);
                         if (m >= 0) {
                             // bvh.rs:48-53: lhs only when lhs.t < rhs.t -> an equal t goes to the later leaf
                             if (!found || !(best_t < h.t)) keep(h), best_mat = (uint32_t)m;

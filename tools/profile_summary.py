@@ -19,6 +19,15 @@ def is_frame_kernel(name):
     flags = [f.strip() for f in m.group(1).split(",")]
     return len(flags) < 5 or flags[4] == "false"
 
+def is_measuring_kernel(name):
+    """The measuring launch of a sphere-kernel frame (5th template flag PILOT = true): first sample of every pixel."""
+    m = re.search(r"pt_trace_kernel<([^>]*)>", name)
+    if not m:
+        return False
+    flags = [f.strip() for f in m.group(1).split(",")]
+    return len(flags) >= 5 and flags[4] == "true"
+
+
 src = os.path.join("gpurun_out", "prof_" + tag)
 os.makedirs("profiles", exist_ok=True)
 lines = []
@@ -95,6 +104,22 @@ for d in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
     n = max(1, len(groups))
     for k, v in agg.items():
         pmc[k] = v / n
+# HBM traffic of the measuring launch (its own symbol for the sphere kernels), per bench frame
+pmc_m = {}
+for d in ("pmc_fetch", "pmc_write"):
+    f = find(d + "/**/*counter_collection.csv")
+    if not f:
+        continue
+    rows = [r for r in csv.DictReader(open(f)) if is_measuring_kernel(r["Kernel_Name"])]
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+    keep = set(bench_groups(ids)[g][0] for g in range(len(bench_groups(ids)))) if ids else set()
+    keep = {i for g in bench_groups(ids) for i in g} if ids else set()
+    agg = collections.defaultdict(float)
+    for r in rows:
+        if int(r["Dispatch_Id"]) in keep:
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+    for k, v in agg.items():
+        pmc_m[k] = v / max(1, len(bench_groups(ids)))
 lines.append("")
 lines.append("# PMC counters of the frame kernel per bench frame (separate --pmc passes; pt_scene_prepare's frame excluded)")
 for k in sorted(pmc):
@@ -110,6 +135,11 @@ if "FETCH_SIZE" in pmc or "WRITE_SIZE" in pmc:
     out["hbm_write_bytes"] = write
     lines.append("HBM traffic per launch: read %.3f MB (FETCH_SIZE KiB x 1024 x 2 gfx950 correction), write %.3f MB"
                  % (fetch / 1e6, write / 1e6))
+if pmc_m:
+    m_bytes = pmc_m.get("FETCH_SIZE", 0.0) * 1024 * 2 + pmc_m.get("WRITE_SIZE", 0.0) * 1024
+    out["hbm_bytes_measuring_launch"] = m_bytes
+    lines.append("HBM traffic of the measuring launch (first sample of every pixel; parks 48 B per pixel): %.3f MB; both launches of a frame: %.3f MB"
+                 % (m_bytes / 1e6, (m_bytes + out.get("hbm_bytes_per_launch", 0.0)) / 1e6))
 bl = os.path.join(src, "bench_line.json")
 if os.path.exists(bl) and os.path.getsize(bl):
     out["bench_line_under_profiler"] = json.load(open(bl))
