@@ -1432,7 +1432,6 @@ static bvhnode *bvh_new(storage *st, xoshiro *rng, hitable *v, size_t n) {
 /* ======================================================================== */
 /* offline.rs:16-24 + params.rs:21-46                                       */
 /* ======================================================================== */
-static uint64_t g_draw_probe; /* unused placeholder to keep the ledger explicit */
 
 ora_scene *ora_scene_from_preset(const char *name, uint32_t width, uint32_t height, int use_bvh) {
     int which;
@@ -1449,7 +1448,6 @@ ora_scene *ora_scene_from_preset(const char *name, uint32_t width, uint32_t heig
     else if (!strcmp(name, "final")) which = 10;
     else return NULL; /* presets.rs:36 (`earth` needs media/earthmap.jpg, absent upstream) */
     if (which == 10 && use_bvh) return NULL; /* BVHNode::new(&[]) is None and params.rs:37 unwraps it: the reference panics */
-    (void)g_draw_probe;
 
     ora_scene *sc = calloc(1, sizeof(*sc));
     xoshiro rng, rng0;
