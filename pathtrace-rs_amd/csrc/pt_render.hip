@@ -33,7 +33,8 @@ class HostPool {
     // fn(chunk) for chunk in [0, n): chunks are claimed from a shared counter by the helpers and the caller
     void run(size_t n, const std::function<void(size_t)> &fn) {
         if (n == 0) return;
-        std::unique_lock<std::mutex> lock(mu_);   // one job at a time
+        std::lock_guard<std::mutex> one_job(job_mu_);   // one job at a time (pt_render calls of different scenes may race here)
+        std::unique_lock<std::mutex> lock(mu_);
         start_helpers();
         fn_ = &fn, n_ = n, next_.store(0), done_.store(0);
         ++epoch_;
@@ -88,7 +89,7 @@ class HostPool {
             idle_.notify_all();
         }
     }
-    std::mutex mu_;
+    std::mutex job_mu_, mu_;
     std::condition_variable cv_, idle_;
     std::vector<std::thread> threads_;
     const std::function<void(size_t)> *fn_ = nullptr;

@@ -496,6 +496,37 @@ def test_pageable_host_buffer_pipeline_against_the_oracle(ptgpu, pthost, oracle,
         assert np.array_equal(np.signbit(got[zero]), np.signbit(ref[zero]))
 
 
+def test_two_threads_render_two_scenes_through_the_host_entry_point(ptgpu, pthost):
+    """include/ptgpu.h "Threading": distinct handles may be used from distinct threads. Two host threads call pt_render on
+    pageable buffers at the same time (ctypes releases the GIL): the helper threads of the host-buffer pipeline serve one copy
+    at a time, the frames are the ones each scene renders alone."""
+    import threading
+    jobs = [("random_spheres", 240, 160, 16), ("cornell_smoke", 160, 120, 16)]
+    scenes = [pthost.HostScene(pr, W, H, samples=S, device=0) for pr, W, H, S in jobs]
+    alone = []
+    for hs, (pr, W, H, S) in zip(scenes, jobs):
+        buf = np.zeros((H, W, 3), np.float32)
+        alone.append((hs.device_scene().update(ptgpu.PtParams(W, H, S, 10, 0, 0), hs.camera, 0, buf), buf))
+    results = [None, None]
+
+    def work(i):
+        hs, (pr, W, H, S) = scenes[i], jobs[i]
+        out = []
+        for _ in range(6):
+            buf = np.zeros((H, W, 3), np.float32)
+            out.append((hs.device_scene().update(ptgpu.PtParams(W, H, S, 10, 0, 0), hs.camera, 0, buf), buf))
+        results[i] = out
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for i in range(2):
+        for rays, buf in results[i]:
+            assert rays == alone[i][0] and np.array_equal(buf, alone[i][1])
+
+
 def test_communicators_from_a_device_list_and_side_by_side(ptgpu, pthost):
     """pt_comm_create_all with one device (all a 1-GPU box can list), two communicators alive at once, the gather-to-root form
     across two progressive frames, and the RCCL the library resolved at run time: the copy this process had already loaded

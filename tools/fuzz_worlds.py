@@ -1,5 +1,6 @@
 """Ad-hoc fuzzing of the GPU kernels against the oracle with seeded random worlds (development aid; the seeds that
-found bugs live on as cases in tests/test_gpu_parity.py). Usage: python tools/fuzz_worlds.py [first_seed] [count]"""
+found bugs live on as cases in tests/test_gpu_parity.py). Usage: python tools/fuzz_worlds.py [first_seed] [count] [all|classic]
+Kinds (seed % 5): 0 sphere worlds, 1 general worlds, 2 moving-sphere worlds, 3 far bounce origins, 4 scene graphs."""
 import importlib.util
 import os
 import sys
@@ -19,11 +20,40 @@ ptgpu = load_ptgpu()
 L = ob.lib(ob.build_native(os.path.join(ROOT, "gpurun_out", "ora_native")))
 
 first, count = int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 40
+MODE = sys.argv[3] if len(sys.argv) > 3 else "all"    # "all": five kinds (seed % 5); "classic": the three kinds of rounds 1-2 (seed % 3)
 W, H, S = 96, 64, 3
 bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
-    kind = seed % 3
+    kind = seed % 5 if MODE == "all" else seed % 3
+    if kind == 3:      # far bounce origins: concave mirrors / huge grounds / distant mirrors around a cloud (every list-kernel path)
+        n = int(rng.choice([40, 150, 400, 700, 900]))
+        fk = ["enclosing", "enclosing", "offcentre", "ground", "mirrors"][int(rng.integers(0, 5))]
+        scale = float(10.0 ** rng.uniform(2.5, 6.5))
+        w = tgp._far_origin_world(ob, seed, n, 64, 48, float(rng.uniform(2, 15)), float(rng.uniform(0.1, 1.0)), fk, scale, moving=bool(seed % 7 == 0 and n <= 400))
+        for bvh in (False, True):
+            msgs = tgp._check_all_list_paths_against_the_oracle(ptgpu, ob, w, 64, 48, 2, bvh, depth=int(rng.choice([2, 10, 10, 25])))
+            if msgs:
+                bad += 1
+                print("MISMATCH seed %d far %s scale %.3g bvh %s: %s" % (seed, fk, scale, bvh, msgs))
+        continue
+    if kind == 4:      # scene graphs: nested Lists / Instances / media, flattened by the product, nested literally by the oracle
+        g = tgp._random_graph_world(ob, seed, W, H, n_top=int(rng.integers(3, 9)), max_depth=int(rng.integers(2, 6)), media=bool(seed % 3))
+        osc = ob.OracleScene.from_graph(g["hitables"], g["transforms"], g["materials"], g["textures"], g["camera"], W, H, g["nodes"], g["node_children"],
+                                        g["root_node"], sky=g["sky"], library=L)
+        depth = int(rng.choice([1, 5, 10, 25]))
+        ref, ref_rays = osc.update(S, max_depth=depth, frame_num=0)
+        materials = [(int(r[0]), r[1:4], r[4], int(r[5])) for r in g["materials"]]
+        textures = [(int(r[0]), r[1:4], int(r[4]), int(r[5]), r[6]) for r in g["textures"]]
+        sc = ptgpu.Scene(ptgpu.WorldDesc(g["hitables"], g["transforms"], materials, textures, sky=g["sky"], nodes=g["nodes"],
+                                         node_children=g["node_children"], root_node=g["root_node"]), 0)
+        out = np.zeros((H, W, 3), np.float32)
+        rays = sc.update(ptgpu.PtParams(W, H, S, depth, 0, 0), ptgpu.PtCamera.from_floats(g["camera"]), 0, out)
+        sc.close()
+        if rays != ref_rays or not np.array_equal(ref, out, equal_nan=True):
+            bad += 1
+            print("MISMATCH seed %d graph: rays %d vs %d, %s" % (seed, rays, ref_rays, tgp._report(ref, out)))
+        continue
     if kind == 0:      # sphere worlds of assorted sizes and radius ranges, sometimes with extreme extras
         n = int(rng.choice([3, 20, 33, 64, 150, 400, 800]))
         extras = [(), ([0, -300, 0, 298],), ([0, 0, 0, 0.0], [2, 2, 2, -1e-3]), ([0, 0, 0, 25],)][int(rng.integers(0, 4))]
