@@ -215,7 +215,7 @@ extern "C" int pt_scene_prepare(pt_scene *s, const pt_params *params) {
     HIP_TRY(hipStreamSynchronize(nullptr));
     s->ev_valid = false;
     s->hint_valid = false;
-    (void)HostPool::get();
+    HostPool::get().run(16, [](size_t) {});   // starts the copy helpers now rather than inside the first pt_render
     return PT_OK;
 }
 
