@@ -21,6 +21,12 @@
 #include "pt_tree4.h"
 #include "ptgpu.h"
 
+// One rejection loop per wave-iteration for the camera's lens samples and a Metal scatter's sphere sample (see the main loop;
+// -DPT_NO_SHARED_REJECT restores the two separate loops for A/B runs)
+#ifndef PT_NO_SHARED_REJECT
+#define PT_SHARED_REJECT 1
+#endif
+
 namespace ptdev {
 
 // value of `v` in lane `src_lane` (any lane may ask for any lane's)
@@ -1341,6 +1347,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 #define PT_SEC(i) do { } while (0)
 #endif
     bool have = false, exhausted = false, need_cam = true, trav_new = false, finished = false;
+    bool pend_metal = false;    // PT_SHARED_REJECT: the lane's Metal scatter waits for its sphere sample (drawn with the next camera rays' lens samples)
+    float metal_fuzz = 0.0f;
     uint32_t pix_rays = 0;
     BvhTrav trav{0u, 0u, 0, kMaxT, -1, 0u, false};
     Trav4 trav4{0u, 0u, 0, kNoChild4, 0u, kMaxT, false};
@@ -1478,30 +1486,67 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 #endif
         PT_SEC(0);
 
-        // ---- camera.rs:56-68 + scene.rs:107-108: start the next sample
-        if (have && need_cam) {
+        // ---- camera.rs:56-68 + scene.rs:107-108: start the next sample -- and, in the same rejection loop, the
+        // random_in_unit_sphere a Metal scatter of the LAST iteration still owes (material.rs:77; PT_SHARED_REJECT).
+        // Both are "draw until the point lies inside the unit ball" loops (math.rs:6-13 in the plane, math.rs:15-26 in space), and
+        // a wave runs such a loop as often as its unluckiest lane needs: 2.8 trips for the lens, 3.1 for the metal lanes, one
+        // after the other. A lane is in at most one of the two roles here -- a path that scattered off metal continues, so it
+        // needs no camera ray -- and its draws keep their order (the sphere's three draws were the lane's next ones anyway), so
+        // both loops become ONE whose trips cost the maximum instead of the sum. Same arithmetic per role: x = 2a - 1 etc.,
+        // (x x + y y) + z z with z = 0 in the plane, which is the reference's (x x + y y) + 0.
+#ifdef PT_SHARED_REJECT
+        const bool cam_role = have && need_cam, met_role = have && pend_metal;
+#else
+        const bool cam_role = have && need_cam, met_role = false;
+#endif
+        if (cam_role || met_role) {
             const float4 c0 = s_par[4], c1 = s_par[5], c2 = s_par[6], c3 = s_par[7], c4 = s_par[8], c5 = s_par[9], pn2 = s_par[3];
             const f3 cam_origin = mk3(c0.x, c0.y, c0.z), cam_llc = mk3(c0.w, c1.x, c1.y), cam_horizontal = mk3(c1.z, c1.w, c2.x),
                      cam_vertical = mk3(c2.y, c2.z, c2.w), cam_u = mk3(c3.x, c3.y, c3.z), cam_v = mk3(c3.w, c4.x, c4.y);
             const float cam_time0 = c5.y, cam_time1 = c5.z, cam_lens_radius = c5.w;
             const uint32_t px = pxy & 0xffffu, py = (pxy >> 16) * A.shard_count + A.shard_index;
-            const float u = ((float)px + rng_f32(rng)) * pn2.z;
-            const float v = ((float)py + rng_f32(rng)) * pn2.w;
-            float dx, dy;
-            random_in_unit_disk(rng, dx, dy);
-            const float rdx = cam_lens_radius * dx, rdy = cam_lens_radius * dy;
-            const f3 offset = add3(scale3(cam_u, rdx), scale3(cam_v, rdy));
-            const float tdraw = rng_f32(rng);  // camera.rs:59 time draw (plain spheres ignore ray.time)
-            if (MOVING) rtime = cam_time0 + tdraw * (cam_time1 - cam_time0);
-            const f3 dir = sub3(sub3(add3(add3(cam_llc, scale3(cam_horizontal, u)), scale3(cam_vertical, v)), cam_origin), offset);
-            o = add3(cam_origin, offset);
-            d = normalize3(dir);
-            sd &= ~0xfffu;   // depth = 0
-            need_cam = false;
-            trav_new = true;
+            float u = 0.f, v = 0.f;
+            if (cam_role) {   // scene.rs:107-108: the jitter draws come before the lens draws
+                u = ((float)px + rng_f32(rng)) * pn2.z;
+                v = ((float)py + rng_f32(rng)) * pn2.w;
+            }
+            float sx = 0.f, sy = 0.f, sz = 0.f;
+            bool searching = true;
+            while (__any(searching)) {
+                if (searching) {
+                    const float ra = rng_f32(rng), rb = rng_f32(rng);
+                    const float x = ra * 2.0f - 1.0f, y = rb * 2.0f - 1.0f;   // math.rs:8 / math.rs:17-21
+                    float z = 0.0f;
+                    if (met_role) z = 2.0f * rng_f32(rng) - 1.0f;
+                    if (((x * x + y * y) + z * z) < 1.0f) sx = x, sy = y, sz = z, searching = false;
+                }
+            }
+            f3 vec;
+            if (cam_role) {
+                const float rdx = cam_lens_radius * sx, rdy = cam_lens_radius * sy;
+                const f3 offset = add3(scale3(cam_u, rdx), scale3(cam_v, rdy));
+                const float tdraw = rng_f32(rng);  // camera.rs:59 time draw (plain spheres ignore ray.time)
+                if (MOVING) rtime = cam_time0 + tdraw * (cam_time1 - cam_time0);
+                vec = sub3(sub3(add3(add3(cam_llc, scale3(cam_horizontal, u)), scale3(cam_vertical, v)), cam_origin), offset);
+                o = add3(cam_origin, offset);
+                sd &= ~0xfffu;   // depth = 0
+                need_cam = false;
+                trav_new = true;
+            } else {
+                // material.rs:82: reflected + fuzz * random_in_unit_sphere (the fuzz waited in the lane's idle candidate-queue slot)
+                const float fuzz = MFMA ? __uint_as_float(reinterpret_cast<const uint32_t *>(s_queue)[tid]) : metal_fuzz;
+                vec = add3(d, scale3(mk3(sx, sy, sz), fuzz));
+            }
+            d = normalize3(vec);   // camera.rs:66 / material.rs:84, once for both roles
+            pend_metal = false;
         }
 
         PT_SEC(1);
+#ifdef PT_VNOPS
+        // (experiment: how sensitive is the frame to VALU issue slots? PT_VNOPS idle VALU instructions per wave-iteration)
+#pragma unroll
+        for (int q = 0; q < PT_VNOPS; ++q) asm volatile("v_nop");
+#endif
         // ---- hitable.rs:39-65: closest hit (inactive lanes carry a null ray)
         const f3 ro = have ? o : mk3(0.f, 0.f, 0.f);
         const f3 rd = have ? d : mk3(0.f, 0.f, 0.f);
@@ -1638,8 +1683,14 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         if (dot3(reflected, normal) > 0.0f) {
                             att = mk3(qa.x, qa.y, qa.z);
                             attc = (WST ? kWstCode : 0u) | (uint32_t)idx;
+#ifdef PT_SHARED_REJECT
+                            raw = reflected, pend_metal = true;   // sampled at the top of the next iteration
+                            if (MFMA) reinterpret_cast<uint32_t *>(s_queue)[tid] = __float_as_uint(m.param);
+                            else metal_fuzz = m.param;
+#else
                             const f3 rs = random_in_unit_sphere(rng);
                             raw = add3(reflected, scale3(rs, m.param));
+#endif
                             scattered = true;
                         }
                     } else if (m.kind == PT_MAT_DIELECTRIC) {  // material.rs:91-124
@@ -1666,7 +1717,11 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         raw = use_refract ? refracted : reflect3(d, normal);
                         scattered = true;
                     }
+#ifdef PT_SHARED_REJECT
+                    if (scattered) nd = pend_metal ? raw : normalize3(raw);
+#else
                     if (scattered) nd = normalize3(raw);
+#endif
                 }
                 if (scattered) {
                     // the first scatter's attenuation stays in registers (measured best: 0 levels -1.5 %, 2 levels -2.3 %;
