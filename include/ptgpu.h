@@ -395,8 +395,12 @@ int pt_scene_traversal_counters(pt_scene *scene, uint64_t out2[2], int reset);
  *   PT_PROBE_SIN/COS out[i] = sinf_cosf(in[i]) (simd.rs:107-208)
  *   PT_PROBE_RNG     in[i] reinterpreted as a u32 seed s; out[i] = the (i%16+1)-th gen::<f32>() of
  *                    Xoshiro256Plus::seed_from_u64(s)
- *   PT_PROBE_LN      out[i] = device f32::ln used by ConstantMedium (constant_medium.rs:60; glibc logf) */
-enum { PT_PROBE_POW5 = 0, PT_PROBE_SIN = 1, PT_PROBE_COS = 2, PT_PROBE_RNG = 3, PT_PROBE_LN = 4 };
+ *   PT_PROBE_LN      out[i] = device f32::ln used by ConstantMedium (constant_medium.rs:60; glibc logf)
+ *   PT_PROBE_SWEEP_SQRT  (n >= 2, `in` is not read) the kernels' shortened f32::sqrt against the compiler's correctly rounded
+ *                    sqrtf on ALL 2^32 bit patterns: out[0] = number of mismatches, out[1] = bits of one mismatching input
+ *   PT_PROBE_SWEEP_DRAWS the same report for the single-rounding forms of `2 * draw - 1`, `draw * 2 * PI` and `n + draw` against
+ *                    the reference's expressions, for every draw k * 2^-24 beside 256 pixel coordinates n */
+enum { PT_PROBE_POW5 = 0, PT_PROBE_SIN = 1, PT_PROBE_COS = 2, PT_PROBE_RNG = 3, PT_PROBE_LN = 4, PT_PROBE_SWEEP_SQRT = 5, PT_PROBE_SWEEP_DRAWS = 6 };
 int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n);
 
 /* Thread-local message describing the last error returned on this thread. */

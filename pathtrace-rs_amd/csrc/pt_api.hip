@@ -241,15 +241,56 @@ __global__ void probe_kernel(uint32_t probe, const float *in, float *out, size_t
     }
     out[i] = r;
 }
+// Exhaustive checks of the device's own shortened math against the library lowering it replaces: every one of the 2^32 f32
+// bit patterns goes through both; out[0] = mismatches (saturating at 2^24), out[1] = bit pattern of one mismatching input.
+__global__ void sweep_kernel(uint32_t probe, uint32_t *result) {
+    uint32_t bad = 0, where = 0;
+    for (uint32_t k = 0; k < 16; ++k) {
+        const uint32_t bits = (blockIdx.x * 16u + k) * 256u + threadIdx.x;
+        const float x = __uint_as_float(bits);
+        uint32_t got = 0, want = 0;
+        if (probe == PT_PROBE_SWEEP_SQRT) got = __float_as_uint(sqrt_exact(x)), want = __float_as_uint(__builtin_sqrtf(x));
+        if (probe == PT_PROBE_SWEEP_DRAWS) {
+            // every draw k * 2^-24 (low 24 bits) beside a pixel coordinate n (high 8 bits, spread over 0..8160): the fused forms
+            // of pt_device.h against the reference's expressions
+            const float k = (float)(bits & 0xffffffu), draw = (1.0f / 16777216.0f) * k, n = (float)((bits >> 24) * 32u);
+            const uint32_t a = __float_as_uint(__builtin_fmaf(k, 1.0f / 8388608.0f, -1.0f)) ^ __float_as_uint(draw * 2.0f - 1.0f);
+            const uint32_t b = __float_as_uint(k * (kPi * (1.0f / 8388608.0f))) ^ __float_as_uint(draw * 2.0f * kPi);
+            const uint32_t c = __float_as_uint(__builtin_fmaf(k, 1.0f / 16777216.0f, n)) ^ __float_as_uint(n + draw);
+            got = a | b | c;
+        }
+        if (got != want && !(got << 1 > 0xff000000u && want << 1 > 0xff000000u)) bad += 1, where = bits;   // (any NaN matches any NaN)
+    }
+    if (bad) {
+        atomicAdd(&result[0], bad);
+        result[1] = where;
+    }
+}
 }  // namespace
 
 extern "C" int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n) {
     if (!in || !out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
-    if (probe > PT_PROBE_LN) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
+    if (probe > PT_PROBE_SWEEP_DRAWS) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
     if (n == 0) return PT_OK;
+    if (probe >= PT_PROBE_SWEEP_SQRT && n < 2) return fail(PT_ERR_INVALID_ARG, "a sweep probe reports into out[0..1]");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NO_DEVICE, "no HIP device available");
     HIP_TRY(hipSetDevice(device));
+    if (probe >= PT_PROBE_SWEEP_SQRT) {
+        uint32_t *d_res = nullptr, res[2] = {0, 0};
+        HIP_TRY(hipMalloc((void **)&d_res, sizeof res));
+        hipError_t e = hipMemset(d_res, 0, sizeof res);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(sweep_kernel, dim3(1u << 20), dim3(256), 0, 0, probe, d_res);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpy(res, d_res, sizeof res, hipMemcpyDeviceToHost);
+        (void)hipFree(d_res);
+        if (e != hipSuccess) return fail(PT_ERR_HIP, "sweep probe failed: %s", hipGetErrorString(e));
+        out[0] = (float)(res[0] < (1u << 24) ? res[0] : (1u << 24));
+        memcpy(&out[1], &res[1], 4);
+        return PT_OK;
+    }
     float *d_in = nullptr, *d_out = nullptr;
     HIP_TRY(hipMalloc((void **)&d_in, n * sizeof(float)));
     if (hipMalloc((void **)&d_out, n * sizeof(float)) != hipSuccess) {

@@ -30,7 +30,27 @@ __device__ __forceinline__ f3 divs3(f3 a, float s) { return f3{a.x / s, a.y / s,
 __device__ __forceinline__ f3 neg3(f3 a) { return f3{-a.x, -a.y, -a.z}; }
 // glam Vec3::dot: (x*x' + y*y') + z*z'
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-__device__ __forceinline__ float length3(f3 a) { return sqrtf(dot3(a, a)); }
+// Wave votes straight on the condition's lane mask. (hip's __any / __ballot first materialise the condition as 0 / 1 in a VGPR and
+// compare it again: two VALU instructions per vote, ~20 per wave-iteration of the list kernels.)
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
+// f32::sqrt, correctly rounded like sqrtf -- with the parts of clang's lowering that the callers here never need taken out of
+// the common path (16 -> 11 VALU instructions, five to seven square roots per wave-iteration). The lowering scales inputs below
+// 2^-96 up, takes v_sqrt_f32 (1 ulp), picks among {s - 1 ulp, s, s + 1 ulp} by the sign of two fused residuals, scales back and
+// patches +-0 / +inf. The residual selection alone already returns +-0, +inf and NaN unchanged, and without the scaling it is the
+// same arithmetic for every input of magnitude >= 2^-96; a wave in which some lane holds a smaller non-zero value takes the library path.
+// Checked against __builtin_sqrtf on ALL 2^32 bit patterns (pt_selftest_probe PT_PROBE_SWEEP_SQRT, tests/test_gpu_parity.py).
+__device__ __forceinline__ float sqrt_exact(float x) {
+    if (__builtin_expect(wave_any(__builtin_fabsf(x) < 0x1p-96f && x != 0.0f), 0)) return __builtin_sqrtf(x);
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+    s = (0.0f >= rm) ? sm : s;
+    s = (0.0f < rp) ? sp : s;
+    return s;
+}
+__device__ __forceinline__ float length3(f3 a) { return sqrt_exact(dot3(a, a)); }
 // glam 0.20 scalar Vec3::normalize: v * (1.0 / length)
 __device__ __forceinline__ f3 normalize3(f3 a) { return scale3(a, 1.0f / length3(a)); }
 
@@ -69,10 +89,24 @@ __device__ __forceinline__ uint64_t rng_next_u64(Rng &r) {
 }
 
 // rand 0.8 Standard f32: (next_u32 >> 8) * 2^-24, next_u32 = next_u64 >> 32
-__device__ __forceinline__ float rng_f32(Rng &r) {
-    const uint32_t v = (uint32_t)(rng_next_u64(r) >> 40);
-    return (1.0f / 16777216.0f) * (float)v;
+// (The high word is pinned in a 32-bit register before the shift: left to itself the compiler converts the 64-BIT value
+// `next >> 40` to f32, six VALU instructions where v_lshrrev + v_cvt_f32_u32 do.)
+__device__ __forceinline__ uint32_t rng_next_u24(Rng &r) {
+    uint32_t hi = (uint32_t)(rng_next_u64(r) >> 32);
+    asm volatile("" : "+v"(hi));
+    return hi >> 8;
 }
+__device__ __forceinline__ float rng_f32(Rng &r) { return (1.0f / 16777216.0f) * (float)rng_next_u24(r); }
+
+// rand's f32 draw is k * 2^-24 with an integer k < 2^24. The expressions the reference builds on a fresh draw are exact in their
+// first operations, so ONE correctly rounded operation on the integer yields the same bits:
+//   2 * draw - 1  (math.rs:8,17-21,29): 2k * 2^-24 - 1 is representable            -> fma(k, 2^-23, -1), no rounding at all
+//   draw * 2 * c  (math.rs:30):         draw * 2 is exact, c * 2^-23 is representable -> k * (c * 2^-23), the one rounding of the product
+//   n + draw      (scene.rs:107-108):   k * 2^-24 is exact                           -> fma(k, 2^-24, n), the one rounding of the sum
+__device__ __forceinline__ float rng_u24(Rng &r) { return (float)rng_next_u24(r); }
+__device__ __forceinline__ float rng_pm1(Rng &r) { return __builtin_fmaf(rng_u24(r), 1.0f / 8388608.0f, -1.0f); }
+__device__ __forceinline__ float rng_times_2c(Rng &r, float c) { return rng_u24(r) * (c * (1.0f / 8388608.0f)); }
+__device__ __forceinline__ float rng_plus(Rng &r, float n) { return __builtin_fmaf(rng_u24(r), 1.0f / 16777216.0f, n); }
 
 // ---- simd.rs:107-208 sinf_cosf (Cephes polynomial, lane 0 of the SSE2 code)
 __device__ __forceinline__ void sinf_cosf_ref(float xin, float &sin_out, float &cos_out) {
@@ -127,10 +161,8 @@ __device__ __forceinline__ void sinf_cosf_ref(float xin, float &sin_out, float &
 // math.rs:6-13 (runs even when lens_radius == 0; 2 draws per iteration)
 __device__ __forceinline__ void random_in_unit_disk(Rng &rng, float &px, float &py) {
     for (;;) {
-        const float a = rng_f32(rng);
-        const float b = rng_f32(rng);
-        const float x = a * 2.0f - 1.0f;
-        const float y = b * 2.0f - 1.0f;
+        const float x = rng_pm1(rng);   // a * 2 - 1
+        const float y = rng_pm1(rng);
         // p.dot(p) with z = 0*2 - 0 = 0: (x*x + y*y) + 0*0
         if (((x * x + y * y) + 0.0f) < 1.0f) {
             px = x;
@@ -143,9 +175,9 @@ __device__ __forceinline__ void random_in_unit_disk(Rng &rng, float &px, float &
 // math.rs:15-26
 __device__ __forceinline__ f3 random_in_unit_sphere(Rng &rng) {
     for (;;) {
-        const float a = 2.0f * rng_f32(rng) - 1.0f;
-        const float b = 2.0f * rng_f32(rng) - 1.0f;
-        const float c = 2.0f * rng_f32(rng) - 1.0f;
+        const float a = rng_pm1(rng);   // 2 * draw - 1
+        const float b = rng_pm1(rng);
+        const float c = rng_pm1(rng);
         const f3 p = mk3(a, b, c);
         if (dot3(p, p) < 1.0f) return p;
     }
@@ -153,9 +185,9 @@ __device__ __forceinline__ f3 random_in_unit_sphere(Rng &rng) {
 
 // math.rs:28-34
 __device__ __forceinline__ f3 random_unit_vector(Rng &rng) {
-    const float z = rng_f32(rng) * 2.0f - 1.0f;
-    const float a = rng_f32(rng) * 2.0f * kPi;
-    const float r = sqrtf(1.0f - z * z);
+    const float z = rng_pm1(rng);             // draw * 2 - 1
+    const float a = rng_times_2c(rng, kPi);   // draw * 2 * PI
+    const float r = sqrt_exact(1.0f - z * z);
     float sina, cosa;
     sinf_cosf_ref(a, sina, cosa);
     return mk3(r * cosa, r * sina, z);
@@ -169,7 +201,7 @@ __device__ __forceinline__ bool refract3(f3 v, f3 n, float ni_over_nt, f3 &out) 
     const float dt = dot3(v, n);
     const float discriminant = 1.0f - (ni_over_nt * ni_over_nt) * (1.0f - (dt * dt));
     if (discriminant > 0.0f) {
-        out = sub3(scale3(sub3(v, scale3(n, dt)), ni_over_nt), scale3(n, sqrtf(discriminant)));
+        out = sub3(scale3(sub3(v, scale3(n, dt)), ni_over_nt), scale3(n, sqrt_exact(discriminant)));
         return true;
     }
     return false;

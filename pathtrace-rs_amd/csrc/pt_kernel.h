@@ -114,7 +114,7 @@ __device__ __forceinline__ float perlin_turb(const PerlinLds &pn, f3 p) {
 // accum += weight * noise with weight = 1, 1/2, 1/4 ..., fetching them across lanes: bit-identical to perlin_turb.
 // `scratch`: 192 words of this wave's LDS (the pair list, idle between drains). Returns 0 for lanes that do not `need`.
 __device__ __forceinline__ float wave_balanced_turb(const PerlinLds &pn, uint32_t *scratch, bool need, f3 p) {
-    const unsigned long long mask = __ballot(need);
+    const unsigned long long mask = wave_ballot(need);
     const uint32_t n = (uint32_t)__popcll(mask);
     if (n == 0u) return 0.0f;
 #ifndef PT_BALANCE_MAX
@@ -206,7 +206,7 @@ __device__ __forceinline__ f3 texture_value(const DTex *texs, const PerlinLds &p
 // ---- sphere.rs:29-66 exact slow path for one sphere ---------------------------
 // Returns true and narrows `closest` when the sphere is hit in (kMinT, closest).
 __device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float &closest) {
-    const float sq = sqrtf(disc);
+    const float sq = sqrt_exact(disc);
     float t = (-b - sq) / a;
     if (t < closest && t > kMinT) {
         closest = t;
@@ -237,7 +237,7 @@ __device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float
 
 __device__ __forceinline__ void drain_candidates(const float4 *sph, const uint16_t *q, uint32_t &cnt, f3 o, f3 d,
                                                  float a, float &closest, int &idx) {
-    for (uint32_t j = 0; __any(j < cnt); ++j) {
+    for (uint32_t j = 0; wave_any(j < cnt); ++j) {
         if (j < cnt) {
             const int k = q[j * kBlock];
             const float4 c = sph[k];
@@ -278,7 +278,7 @@ __device__ __forceinline__ int intersect_list(const float4 *sph, int n_pad, uint
 #pragma unroll
         for (int u = 3; u + 1 < kScanUnroll; u += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, disc[u]), disc[u + 1]);
         if ((kScanUnroll & 1) == 0) m = __builtin_fmaxf(m, disc[kScanUnroll - 1]);
-        if (__any(m > 0.0f)) {
+        if (wave_any(m > 0.0f)) {
 #pragma unroll
             for (int u = 0; u < kScanUnroll; ++u) {
                 if (disc[u] > 0.0f) {
@@ -286,7 +286,7 @@ __device__ __forceinline__ int intersect_list(const float4 *sph, int n_pad, uint
                     cnt += 1;
                 }
             }
-            if (__any(cnt > (uint32_t)(kQueueCap - kScanUnroll))) drain_candidates(sph, q, cnt, o, d, a, closest, idx);
+            if (wave_any(cnt > (uint32_t)(kQueueCap - kScanUnroll))) drain_candidates(sph, q, cnt, o, d, a, closest, idx);
         }
     }
     drain_candidates(sph, q, cnt, o, d, a, closest, idx);
@@ -329,7 +329,7 @@ __device__ __forceinline__ RayFeat make_ray_features(const float4 *P, f3 o, f3 d
     // is valid; rounding here only needs to be covered by the margin)
     const f3 ot = mk3(o.x - pc.x, o.y - pc.y, o.z - pc.z);
     const float od0 = __builtin_fmaf(ot.z, d.z, __builtin_fmaf(ot.y, d.y, ot.x * d.x));
-    const float s = active ? (-od0 / a) : 0.0f;
+    const float s = active ? (-od0 * __builtin_amdgcn_rcpf(a)) : 0.0f;   // (1 ulp is plenty: s only picks the point on the line)
     f3 op = mk3(__builtin_fmaf(s, d.x, ot.x), __builtin_fmaf(s, d.y, ot.y), __builtin_fmaf(s, d.z, ot.z));
     float od = __builtin_fmaf(op.z, d.z, __builtin_fmaf(op.y, d.y, op.x * d.x));
     const float oo = __builtin_fmaf(op.z, op.z, __builtin_fmaf(op.y, op.y, op.x * op.x));
@@ -648,7 +648,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
         if (total > (uint32_t)kPairCap) {
             // more pairs than the list holds (rays far outside the prefilter's accuracy range): every lane walks its own
             uint32_t tb = tbits, j = 0, cur = 0, curT = 0;
-            while (__any((cur | tb) != 0u)) {
+            while (wave_any((cur | tb) != 0u)) {
                 if (cur == 0u && tb != 0u) {  // next non-empty tile of my ray
                     curT = (uint32_t)__builtin_ctz(tb);
                     tb &= tb - 1u;
@@ -799,7 +799,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
         }
         // a full queue is drained on the spot (exact phase 2 on what is queued so far); verify mode keeps
         // everything for its end-of-scan audit and treats an overflow as "every sphere is a candidate"
-        if (!VERIFY && __any(cnt >= (uint32_t)kEntCap)) drain();
+        if (!VERIFY && wave_any(cnt >= (uint32_t)kEntCap)) drain();
     }
     PT_SUB(6);
     // ---- phase 2: exact arithmetic on the candidates of this lane's own ray ----
@@ -807,7 +807,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     float vbest = kMaxT;   // verify mode: the brute-force winner
     int vidx = -1;
     uint32_t vrank = 0;
-    if (__any(overflow || (VERIFY && active))) {
+    if (wave_any(overflow || (VERIFY && active))) {
         if (overflow || VERIFY) {
             // verify mode (and its queue overflows, where the masks of a ray were not all kept): brute force
             for (int k = 0; k < (int)A.n_spheres; ++k) {
@@ -985,8 +985,8 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
                 }
             }
         }
-        if (__ballot(st.active) == 0ull) break;
-        if (__popcll(__ballot(have && !st.active)) >= kReadyMin) break;
+        if (wave_ballot(st.active) == 0ull) break;
+        if (__popcll(wave_ballot(have && !st.active)) >= kReadyMin) break;
     }
 }
 
@@ -1060,7 +1060,7 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
     if (total == 0u) return;
     if (total > (uint32_t)kPairCap) {
         // more pairs than the wave's list holds: every lane tests its own (rare: the queues drain at > 4 entries)
-        for (uint32_t j = 0; __any(j < st.qn); ++j)
+        for (uint32_t j = 0; wave_any(j < st.qn); ++j)
             if (j < st.qn) {
                 pair_test4<MOVING>(A, leafq[j * BLK + tid], time, o, d, rcp, a, &w_keys[lane]);
             }
@@ -1192,13 +1192,13 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
                 if (st.cur == kNoChild4 && st.sp == 0) st.active = false;
             }
         }
-        const unsigned long long act = __ballot(st.active);
-        const bool stop = act == 0ull || __popcll(__ballot(have && !st.active)) >= (int)A.ready_min;
+        const unsigned long long act = wave_ballot(st.active);
+        const bool stop = act == 0ull || __popcll(wave_ballot(have && !st.active)) >= (int)A.ready_min;
         PT_SUB4(5);
 #ifdef PT_SECTIONS
         sec[7] += 1ull;
 #endif
-        if (stop || __any(st.qn > A.drain_at)) drain4<MOVING, BLK>(A, leafq, w_pairs, w_keys, o, d, rcp, a, time, st);
+        if (stop || wave_any(st.qn > A.drain_at)) drain4<MOVING, BLK>(A, leafq, w_pairs, w_keys, o, d, rcp, a, time, st);
         PT_SUB4(6);
         if (stop) break;
     }
@@ -1216,8 +1216,13 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
 // BLK: threads per workgroup. 256 (three workgroups per CU) everywhere except the MFMA list kernels, which run ONE
 // 768-thread workgroup per CU when the scene allows: the sphere fragments are then staged once per CU instead of three
 // times, and the LDS that frees holds the per-lane attenuation stacks (no HBM traffic for them).
+#ifdef PT_BBPROF   // tools/bbprof.py: the instrumented assembly keeps its counter registers above the compiler's
+#define PT_BBPROF_ATTR __attribute__((amdgpu_num_sgpr(104)))
+#else
+#define PT_BBPROF_ATTR
+#endif
 template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false, bool GATE = false, int BLK = kBlock>
-__global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4_WAVES : PT_MINWAVES) : 1) void pt_trace_kernel(const KArgs A) {
+__global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4_WAVES : PT_MINWAVES) : 1) PT_BBPROF_ATTR void pt_trace_kernel(const KArgs A) {
     static_assert(BLK == kBlock || (MFMA && !BVH), "only the MFMA list kernels take another workgroup size");
     constexpr bool TREE4 = BVH && SPH_LDS;   // tree kernels: SPH_LDS selects the 4-wide tree (false: the binary one, variant bit 2048)
     // Wide (one workgroup per CU) MFMA kernels: every attenuation a path can pick up is one of a finite PALETTE -- a sphere's
@@ -1392,8 +1397,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         // ---- refill: one wave-aggregated atomic for all lanes that need a pixel. The refill code (a global atomic
         // round trip and four SplitMix64 steps of 64-bit multiplies) runs for the whole wave whenever ANY lane needs
         // it, so lanes wait until A.refill_min of them do (or nobody has work left): fewer, fuller refills.
-        const unsigned long long want = __ballot(!have && !exhausted);
-        const bool refill_now = __popcll(want) >= (int)A.refill_min || __ballot(have) == 0ull;
+        const unsigned long long want = wave_ballot(!have && !exhausted);
+        const bool refill_now = __popcll(want) >= (int)A.refill_min || wave_ballot(have) == 0ull;
         if (!have && !exhausted && refill_now) {
             if (finished) {
                 // scene.rs:113-116
@@ -1418,7 +1423,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 // (frame kernels: the NEXT frame's work order; the pixel's work tile is recomputed from its coordinates)
                 if (PILOT || A.tile_cost) atomicAdd(&A.tile_cost[((pxy >> 16) >> kTileLog2) * A.tiles_x + ((pxy & 0xffffu) >> kTileLog2)], pix_rays);
             }
-            const unsigned long long m = __ballot(1);
+            const unsigned long long m = wave_ballot(1);
             const int leader = __ffsll((long long)m) - 1;
             uint32_t base = 0;
             if (A.first_static != 0u && first_claim) {
@@ -1477,8 +1482,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 }
             }
         }
-        if (__ballot(have) == 0ull) {
-            if (__ballot(!exhausted) == 0ull) break;
+        if (wave_ballot(have) == 0ull) {
+            if (wave_ballot(!exhausted) == 0ull) break;
             continue;
         }
 #ifdef PT_WAVE_DETAIL
@@ -1507,19 +1512,15 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             const uint32_t px = pxy & 0xffffu, py = (pxy >> 16) * A.shard_count + A.shard_index;
             float u = 0.f, v = 0.f;
             if (cam_role) {   // scene.rs:107-108: the jitter draws come before the lens draws
-                u = ((float)px + rng_f32(rng)) * pn2.z;
-                v = ((float)py + rng_f32(rng)) * pn2.w;
+                u = rng_plus(rng, (float)px) * pn2.z;
+                v = rng_plus(rng, (float)py) * pn2.w;
             }
-            float sx = 0.f, sy = 0.f, sz = 0.f;
-            bool searching = true;
-            while (__any(searching)) {
-                if (searching) {
-                    const float ra = rng_f32(rng), rb = rng_f32(rng);
-                    const float x = ra * 2.0f - 1.0f, y = rb * 2.0f - 1.0f;   // math.rs:8 / math.rs:17-21
-                    float z = 0.0f;
-                    if (met_role) z = 2.0f * rng_f32(rng) - 1.0f;
-                    if (((x * x + y * y) + z * z) < 1.0f) sx = x, sy = y, sz = z, searching = false;
-                }
+            float sx, sy, sz;
+            for (;;) {   // (a plain divergent loop: a lane leaves when its point is inside, the wave when its last lane has)
+                sx = rng_pm1(rng), sy = rng_pm1(rng);   // math.rs:8 / math.rs:17-21: 2 * draw - 1
+                sz = 0.0f;
+                if (met_role) sz = rng_pm1(rng);
+                if (((sx * sx + sy * sy) + sz * sz) < 1.0f) break;
             }
             f3 vec;
             if (cam_role) {
@@ -1599,7 +1600,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         PT_SEC(2);
         // ---- scene.rs:49-71 one level of ray_trace (BVH mode: only lanes whose traversal has finished)
         const bool shading = have && !(BVH && (TREE4 ? trav4.active : trav.active));
-        wave_rays += (unsigned long long)__popcll(__ballot(shading));   // scene.rs:57 `ray_count += 1` for every lane shaded below
+        wave_rays += (unsigned long long)__popcll(wave_ballot(shading));   // scene.rs:57 `ray_count += 1` for every lane shaded below
         // 4-wide tree kernels: Texture::Noise of the lanes that will scatter off a noise-textured Lambertian, evaluated for the
         // whole wave at once (wave_balanced_turb): the shading below is divergent, and a third of its lanes (sky misses) idle
         float turb_pre = 0.0f;
@@ -1700,7 +1701,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         float ni_over_nt, cosine;
                         if (rdotn > 0.0f) {
                             cosine = rdotn / length3(d);
-                            cosine = sqrtf(1.0f - ref_idx * ref_idx * (1.0f - cosine * cosine));
+                            cosine = sqrt_exact(1.0f - ref_idx * ref_idx * (1.0f - cosine * cosine));
                             outward_normal = neg3(normal);
                             ni_over_nt = ref_idx;
                         } else {

@@ -79,7 +79,7 @@ __device__ __forceinline__ bool w_sphere(f3 centre, float radius, const WRay &r,
     const float c = dot3(oc, oc) - radius * radius;
     const float discriminant = b * b - a * c;
     if (discriminant > 0.0f) {
-        const float ds = sqrtf(discriminant);
+        const float ds = sqrt_exact(discriminant);
         float t = (-b - ds) / a;
         if (!(t < t_max && t > t_min)) {
             t = (-b + ds) / a;
@@ -340,9 +340,9 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
     for (;;) {
         // ---- refill (same scheme as pt_trace_kernel: one wave-aggregated atomic, 8x8 pixel tiles, batched until
         // A.refill_min lanes are waiting)
-        const bool refill_now = __popcll(__ballot(!have && !exhausted)) >= (int)A.refill_min || __ballot(have) == 0ull;
+        const bool refill_now = __popcll(wave_ballot(!have && !exhausted)) >= (int)A.refill_min || wave_ballot(have) == 0ull;
         if (!have && !exhausted && refill_now) {
-            const unsigned long long m = __ballot(1);
+            const unsigned long long m = wave_ballot(1);
             const int leader = __ffsll((long long)m) - 1;
             uint32_t base = 0;
             if (lane == leader) base = atomicAdd(A.work_counter, (uint32_t)__popcll(m));
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
                 }
             }
         }
-        if (__ballot(have) == 0ull) {
-            if (__ballot(!exhausted) == 0ull) break;
+        if (wave_ballot(have) == 0ull) {
+            if (wave_ballot(!exhausted) == 0ull) break;
             continue;
         }
 
@@ -389,8 +389,8 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
             // ---- camera.rs:56-68 + scene.rs:107-108
             if (need_cam) {
                 const uint32_t px = pxy & 0xffffu, py = (pxy >> 16) * A.shard_count + A.shard_index;
-                const float u = ((float)px + rng_f32(rng)) * A.inv_nx;
-                const float v = ((float)py + rng_f32(rng)) * A.inv_ny;
+                const float u = rng_plus(rng, (float)px) * A.inv_nx;
+                const float v = rng_plus(rng, (float)py) * A.inv_ny;
                 float dx, dy;
                 random_in_unit_disk(rng, dx, dy);
                 const float rdx = A.cam.lens_radius * dx, rdy = A.cam.lens_radius * dy;
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
                         float ni_over_nt, cosine;
                         if (rdotn > 0.0f) {
                             cosine = rdotn / length3(d);
-                            cosine = sqrtf(1.0f - ref_idx * ref_idx * (1.0f - cosine * cosine));
+                            cosine = sqrt_exact(1.0f - ref_idx * ref_idx * (1.0f - cosine * cosine));
                             outward_normal = neg3(normal);
                             ni_over_nt = ref_idx;
                         } else {

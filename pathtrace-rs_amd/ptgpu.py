@@ -503,7 +503,7 @@ def shard_rows(height, shard_index, shard_count):
     return lib().pt_shard_rows(height, shard_index, shard_count)
 
 
-PROBE_POW5, PROBE_SIN, PROBE_COS, PROBE_RNG, PROBE_LN = 0, 1, 2, 3, 4
+PROBE_POW5, PROBE_SIN, PROBE_COS, PROBE_RNG, PROBE_LN, PROBE_SWEEP_SQRT, PROBE_SWEEP_DRAWS = 0, 1, 2, 3, 4, 5, 6
 
 
 def selftest_probe(probe, values, device=0):

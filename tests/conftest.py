@@ -29,6 +29,14 @@ def load_ptgpu():
     name = "pathtrace_rs_amd_ptgpu"
     if name in sys.modules:
         return sys.modules[name]
+    # torch ships its own copy of the HIP runtime; libptgpu.so uses /opt/rocm's. Both live in one process as long as torch's
+    # initialises FIRST (the other way round torch reports "No HIP GPUs are available"), whatever order the tests run in.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
     spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "pathtrace-rs_amd", "ptgpu.py"))
     mod = importlib.util.module_from_spec(spec)
     sys.modules[name] = mod

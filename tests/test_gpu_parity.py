@@ -1286,6 +1286,15 @@ def test_device_ln_is_glibc_logf(ptgpu, oracle):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), int((got.view(np.uint32) != want.view(np.uint32)).sum())
 
 
+def test_shortened_device_math_is_exhaustively_equal_to_what_it_replaces(ptgpu):
+    """The kernels take f32::sqrt through a shortened form of the compiler's correctly rounded lowering and build `2 * draw - 1`,
+    `draw * 2 * PI`, `n + draw` with one rounding from the draw's integer (pt_device.h). Both are unary in 32 bits, so the device
+    simply tries every input: all 2^32 bit patterns for the square root, every draw beside 256 pixel coordinates for the rest."""
+    for probe in (ptgpu.PROBE_SWEEP_SQRT, ptgpu.PROBE_SWEEP_DRAWS):
+        out = ptgpu.selftest_probe(probe, np.zeros(2, dtype=np.float32))
+        assert out[0] == 0.0, (probe, float(out[0]), hex(int(out.view(np.uint32)[1])))
+
+
 # ---- device primitives vs oracle primitives ------------------------------------------------------
 def test_device_rng_matches_oracle(ptgpu, oracle):
     L = oracle.lib()

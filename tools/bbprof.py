@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Development aid: dynamic instruction profile of the MFMA list kernels by assembly instrumentation.
+
+No PC sampling or thread trace is available on the pool, and the kernels' time tracks their VALU instruction count
+(DESIGN.md section 4), so the question "where do the instructions go" is answered by counting basic-block executions:
+
+  python3 tools/bbprof.py build      # here (no GPU): pt_kernels_list.hip -> assembly -> one scalar atomic per basic
+                                     # block -> pathtrace-rs_amd/_build/bbprof/libptgpu.so + bbprof_map.json
+  gpurun -- python3 tools/bbprof.py run [--preset P ...]    # GPU box: renders frames, dumps gpurun_out/bbprof_counts.txt
+  python3 tools/bbprof.py report     # here: counts x static per-block instruction mix, by kernel and by source line
+
+The instrumented kernels reserve s[96:99] (the build caps the compiler at 96 SGPRs), so their register allocation differs a
+little from the shipped ones: use the result for proportions, not absolute counts.
+"""
+import collections, json, os, re, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "pathtrace-rs_amd")
+OUT = os.path.join(PKG, "_build", "bbprof")
+LLVM = "/opt/rocm/lib/llvm/bin"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-I../include", "-Icsrc",
+         "-I/opt/rocm/include", "-DPT_BBPROF"]
+UNIT = "pt_kernels_list"
+
+
+def sh(cmd, **kw):
+    r = subprocess.run(cmd, cwd=PKG, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, **kw)
+    if r.returncode:
+        sys.exit("FAILED: " + " ".join(cmd) + "\n" + r.stdout[-3000:])
+    return r.stdout
+
+
+def classify(op):
+    if op.startswith("v_mfma"): return "mfma"
+    if op.startswith("v_"): return "valu"
+    if op.startswith("s_"): return "salu"
+    if op.startswith("ds_"): return "lds"
+    if op.startswith(("global_", "buffer_", "scratch_", "flat_")): return "vmem"
+    return "other"
+
+
+def instrument(src_lines):
+    """One counter per basic block of every pt_trace_kernel instance; returns (patched lines, map)."""
+    files, out, blocks = {}, [], []
+    kernel, cur, loc = None, None, None
+
+    def open_block(name):
+        nonlocal cur
+        cur = {"kernel": kernel, "label": name, "valu": 0, "salu": 0, "lds": 0, "mfma": 0, "vmem": 0, "other": 0, "trans": 0, "lines": collections.Counter()}
+        blocks.append(cur)
+        out.append("\ts_atomic_add_x2 s[96:97], s[98:99], 0x%x" % (8 * (len(blocks) - 1)))
+
+    for l in src_lines:
+        m = re.match(r'\s*\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', l)
+        if m: files[int(m.group(1))] = m.group(2)
+        m = re.match(r"^(_ZN5ptdev15pt_trace_kernel\w+):", l)
+        if m:
+            kernel = m.group(1)
+            out.append(l)
+            out += ["\ts_mov_b64 s[96:97], 1", "\ts_getpc_b64 s[98:99]", "\ts_add_u32 s98, s98, pt_bbprof@gotpcrel32@lo+4", "\ts_addc_u32 s99, s99, pt_bbprof@gotpcrel32@hi+12",
+                    "\ts_load_dwordx2 s[98:99], s[98:99], 0x0", "\ts_waitcnt lgkmcnt(0)"]
+            open_block("entry")
+            continue
+        if kernel and re.match(r"^\.Lfunc_end", l):
+            kernel, cur = None, None
+        if kernel:
+            m = re.match(r"^(\.LBB[0-9_]+):", l) or re.match(r"^; (%bb\.\d+):", l)   # (fall-through blocks carry no label)
+            if m:
+                out.append(l)
+                open_block(m.group(1))
+                continue
+            if ".amdhsa_next_free_sgpr" in l:
+                l = "\t\t.amdhsa_next_free_sgpr 100"
+            m = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)", l)
+            if m: loc = (files.get(int(m.group(1)), "?"), int(m.group(2)))
+            m = re.match(r"^\s+([a-z_0-9]+)(\s|$)", l)
+            if m and cur is not None and not m.group(1).startswith("."):
+                op = m.group(1)
+                k = classify(op)
+                cur[k] += 1
+                if k == "valu":
+                    if re.match(r"v_(rcp|sqrt|rsq|div_|exp|log|sin|cos)", op): cur["trans"] += 1
+                    if loc: cur["lines"]["%s:%d" % loc] += 1
+        elif ".amdhsa_next_free_sgpr" in l and blocks and "pt_trace_kernel" in (blocks[-1]["kernel"] or ""):
+            l = "\t\t.amdhsa_next_free_sgpr 100"   # the descriptor follows the function body
+        out.append(l)
+    for b in blocks: b["lines"] = dict(b["lines"])
+    return out, blocks
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    s_file = os.path.join(OUT, UNIT + ".s")
+    sh(["/opt/rocm/bin/hipcc"] + FLAGS + ["--cuda-device-only", "-S", "-gline-tables-only", "csrc/%s.hip" % UNIT, "-o", s_file])
+    patched, blocks = instrument(open(s_file).read().split("\n"))
+    p_file = os.path.join(OUT, UNIT + "_bb.s")
+    open(p_file, "w").write("\n".join(patched))
+    json.dump(blocks, open(os.path.join(OUT, "bbprof_map.json"), "w"))
+    if len(blocks) > 16384: sys.exit("more blocks than counters")
+    sh([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", p_file, "-o", os.path.join(OUT, "dev.o")])
+    sh([LLVM + "/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", os.path.join(OUT, "dev.out"), os.path.join(OUT, "dev.o")])
+    sh([LLVM + "/clang-offload-bundler", "-type=o", "-bundle-align=4096", "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950",
+        "-input=/dev/null", "-input=" + os.path.join(OUT, "dev.out"), "-output=" + os.path.join(OUT, "dev.hipfb")])
+    sh(["/opt/rocm/bin/hipcc"] + FLAGS + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", os.path.join(OUT, "dev.hipfb"),
+                                         "-c", "csrc/%s.hip" % UNIT, "-o", os.path.join(OUT, UNIT + ".o")])
+    objs = []
+    for f in sorted(os.listdir(os.path.join(PKG, "_build"))):
+        if f.endswith(".o") and f != UNIT + ".o" and f.startswith("pt_"):
+            objs.append(os.path.join(PKG, "_build", f))
+    objs.append(os.path.join(OUT, UNIT + ".o"))
+    sh(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", os.path.join(OUT, "libptgpu.so"), "-Wl,-soname,libptgpu.so", "-ldl", "-lpthread"])
+    print("built", os.path.join(OUT, "libptgpu.so"), "with", len(blocks), "counted blocks")
+
+
+def run(argv):
+    """Renders frames of one workload (default: BASELINE config 3) on the instrumented library and dumps the counters."""
+    import argparse, ctypes, importlib.util
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", default="random_spheres")
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--bvh", action="store_true")
+    ap.add_argument("--frames", type=int, default=2)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "bbprof_counts.txt"))
+    a = ap.parse_args(argv)
+
+    def load(name, rel):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, rel))
+        m = importlib.util.module_from_spec(spec)
+        sys.modules[name] = m
+        spec.loader.exec_module(m)
+        return m
+    import torch
+    ptgpu = load("pathtrace_rs_amd_ptgpu", "pathtrace-rs_amd/ptgpu.py")
+    ptgpu.LIB_PATH = os.path.join(OUT, "libptgpu.so")   # its soname is libptgpu.so: libpthost's dependency resolves to this copy
+    ctypes.CDLL(ptgpu.LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    pthost = load("pathtrace_rs_amd_pthost", "pathtrace-rs_amd/pthost.py")
+    hs = pthost.HostScene(a.preset, a.width, a.height, samples=a.samples, use_bvh=a.bvh, device=0)
+    scene = hs.device_scene()
+    scene.set_tuning(0, 8192)   # every frame pays its own measuring launch, as the bench's headline does
+    frame = torch.zeros((a.height, a.width, 3), dtype=torch.float32, device="cuda:0")
+    rays = torch.zeros(1, dtype=torch.int64, device="cuda:0")
+    p = ptgpu.PtParams(a.width, a.height, a.samples, 10, 0, 1 if a.bvh else 0)
+    st = torch.cuda.current_stream()
+    total = 0
+    for _ in range(a.frames):
+        frame.zero_()
+        scene.update_device(p, hs.camera, 0, frame.data_ptr(), rays.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize()
+        total += int(rays.item())
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    rc = ptgpu.lib().pt_bbprof_dump(a.out.encode())
+    open(a.out, "a").write("rays %d\n" % total)
+    print("dump rc", rc, "rays", total, "kernel", scene.last_kernel_choice() if hasattr(scene, "last_kernel_choice") else "")
+
+
+def report(argv):
+    counts_file = argv[0] if argv else os.path.join(ROOT, "gpurun_out", "bbprof_counts.txt")
+    blocks = json.load(open(os.path.join(OUT, "bbprof_map.json")))
+    counts, rays = {}, 0
+    for l in open(counts_file):
+        a, b = l.split()
+        if a == "rays": rays = int(b)
+        else: counts[int(a)] = int(b)
+    per_kernel = collections.defaultdict(lambda: collections.Counter())
+    lines = collections.defaultdict(lambda: collections.Counter())
+    rows = collections.defaultdict(list)
+    for i, b in enumerate(blocks):
+        n = counts.get(i, 0)
+        if not n: continue
+        k = b["kernel"]
+        for c in ("valu", "salu", "lds", "mfma", "vmem", "trans"): per_kernel[k][c] += n * b[c]
+        per_kernel[k]["blocks"] += n
+        if b["label"] == "entry": per_kernel[k]["waves"] += n
+        for ln, c in b["lines"].items(): lines[k][ln] += n * c
+        rows[k].append((n * b["valu"], n, b))
+    for k, tot in sorted(per_kernel.items(), key=lambda kv: -kv[1]["valu"]):
+        print("==", k)
+        if rays: print("   VALU wave-instructions per 64 rays (all kernels' rays): %.1f" % (tot["valu"] / (rays / 64.0)))
+        print("   waves %d; dynamic wave-instructions: VALU %.4g (of them v_rcp/sqrt/div_* %.3g)  SALU %.4g  LDS %.4g  MFMA %.4g  VMEM %.4g" %
+              (tot["waves"], tot["valu"], tot["trans"], tot["salu"], tot["lds"], tot["mfma"], tot["vmem"]))
+        print("   -- blocks by dynamic VALU")
+        for dv, n, b in sorted(rows[k], key=lambda r: -r[0])[:45]:
+            top = sorted(b["lines"].items(), key=lambda kv: -kv[1])[:5]
+            print("   %5.2f%%  %-11s runs %.3g x (valu %d salu %d lds %d mfma %d)  %s" % (100.0 * dv / tot["valu"], b["label"], n, b["valu"], b["salu"], b["lds"], b["mfma"],
+                                                                                    " ".join("%s(%d)" % (a.replace("pt_kernel.h", "k").replace("pt_device.h", "d").replace("__clang_hip_math.h", "m"), c) for a, c in top)))
+        print("   -- source lines by dynamic VALU (innermost inlined location)")
+        for ln, c in lines[k].most_common(60):
+            print("   %5.2f%%  %s" % (100.0 * c / tot["valu"], ln))
+
+
+if __name__ == "__main__":
+    cmd = sys.argv[1] if len(sys.argv) > 1 else ""
+    if cmd == "build": build()
+    elif cmd == "run": run(sys.argv[2:])
+    elif cmd == "report": report(sys.argv[2:])
+    else: sys.exit(__doc__)
