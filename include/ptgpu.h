@@ -399,8 +399,11 @@ int pt_scene_traversal_counters(pt_scene *scene, uint64_t out2[2], int reset);
  *   PT_PROBE_SWEEP_SQRT  (n >= 2, `in` is not read) the kernels' shortened f32::sqrt against the compiler's correctly rounded
  *                    sqrtf on ALL 2^32 bit patterns: out[0] = number of mismatches, out[1] = bits of one mismatching input
  *   PT_PROBE_SWEEP_DRAWS the same report for the single-rounding forms of `2 * draw - 1`, `draw * 2 * PI` and `n + draw` against
- *                    the reference's expressions, for every draw k * 2^-24 beside 256 pixel coordinates n */
-enum { PT_PROBE_POW5 = 0, PT_PROBE_SIN = 1, PT_PROBE_COS = 2, PT_PROBE_RNG = 3, PT_PROBE_LN = 4, PT_PROBE_SWEEP_SQRT = 5, PT_PROBE_SWEEP_DRAWS = 6 };
+ *                    the reference's expressions, for every draw k * 2^-24 beside 256 pixel coordinates n
+ *   PT_PROBE_SWEEP_INVLEN the same report for the kernels' 1 / sqrt(t) of Vec3::normalize against `1.0f / sqrtf(t)`, all 2^32 t
+ *   PT_PROBE_SWEEP_DIV   the same report for the normal's division by a radius whose reciprocal the host supplies, against `/`, on
+ *                    2^32 seeded (numerator, radius) pairs including zeros, denormals, infinities and NaNs */
+enum { PT_PROBE_POW5 = 0, PT_PROBE_SIN = 1, PT_PROBE_COS = 2, PT_PROBE_RNG = 3, PT_PROBE_LN = 4, PT_PROBE_SWEEP_SQRT = 5, PT_PROBE_SWEEP_DRAWS = 6, PT_PROBE_SWEEP_INVLEN = 7, PT_PROBE_SWEEP_DIV = 8 };
 int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n);
 
 /* Thread-local message describing the last error returned on this thread. */

@@ -250,6 +250,35 @@ __global__ void sweep_kernel(uint32_t probe, uint32_t *result) {
         const float x = __uint_as_float(bits);
         uint32_t got = 0, want = 0;
         if (probe == PT_PROBE_SWEEP_SQRT) got = __float_as_uint(sqrt_exact(x)), want = __float_as_uint(__builtin_sqrtf(x));
+        if (probe == PT_PROBE_SWEEP_INVLEN) got = __float_as_uint(inv_sqrt_exact(x)), want = __float_as_uint(1.0f / __builtin_sqrtf(x));
+        if (probe == PT_PROBE_SWEEP_DIV) {
+            // 2^32 seeded (n, r) pairs: r from the divisor classes a radius can have (any sign, 2^-20 .. 2^20), n = r * a factor
+            // spread over 2^-95 .. 2^4 (a point on the sphere has |n| <= ~|r|; far-origin hits overshoot), every 16th n a special
+            // (0, -0, tiny, huge, inf, NaN). Lanes whose pair fails the guard take the full division on both sides.
+            uint64_t z = (uint64_t)bits * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull, z = (z ^ (z >> 27)) * 0x94D049BB133111EBull, z ^= z >> 31;
+            const uint32_t a = (uint32_t)z, b = (uint32_t)(z >> 32);
+            const float r = __uint_as_float((a & 0x807fffffu) | ((107u + (a >> 23) % 41u) << 23));
+            float f = __uint_as_float((b & 0x807fffffu) | ((32u + (b >> 23) % 100u) << 23));
+            float n = r * f;
+            if ((bits & 15u) == 0u) {
+                const uint32_t sel = (bits >> 4) & 7u;
+                n = sel == 0 ? 0.0f : sel == 1 ? -0.0f : sel == 2 ? 1.0e-40f : sel == 3 ? -3.0e38f : sel == 4 ? __uint_as_float(0x7f800000u)
+                  : sel == 5 ? __uint_as_float(0x7fc00000u) : sel == 6 ? 0x1p-91f : 0x1p100f;
+            }
+            const volatile float yv = 1.0f / r;
+            const f3 v = f3{n, n * 0.75f, f};
+            const f3 g = divs3_known(v, r, yv);
+            got = (__float_as_uint(g.x) ^ __float_as_uint(v.x / r)) | (__float_as_uint(g.y) ^ __float_as_uint(v.y / r)) | (__float_as_uint(g.z) ^ __float_as_uint(v.z / r));
+            const bool nan_both = (g.x != g.x) == ((v.x / r) != (v.x / r)) && (g.y != g.y) == ((v.y / r) != (v.y / r)) && (g.z != g.z) == ((v.z / r) != (v.z / r));
+            if ((g.x != g.x || g.y != g.y || g.z != g.z) && nan_both) {
+                // NaN payloads may differ: compare the non-NaN components only
+                got = 0;
+                if (g.x == g.x) got |= __float_as_uint(g.x) ^ __float_as_uint(v.x / r);
+                if (g.y == g.y) got |= __float_as_uint(g.y) ^ __float_as_uint(v.y / r);
+                if (g.z == g.z) got |= __float_as_uint(g.z) ^ __float_as_uint(v.z / r);
+            }
+        }
         if (probe == PT_PROBE_SWEEP_DRAWS) {
             // every draw k * 2^-24 (low 24 bits) beside a pixel coordinate n (high 8 bits, spread over 0..8160): the fused forms
             // of pt_device.h against the reference's expressions
@@ -270,7 +299,7 @@ __global__ void sweep_kernel(uint32_t probe, uint32_t *result) {
 
 extern "C" int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n) {
     if (!in || !out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
-    if (probe > PT_PROBE_SWEEP_DRAWS) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
+    if (probe > PT_PROBE_SWEEP_DIV) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
     if (n == 0) return PT_OK;
     if (probe >= PT_PROBE_SWEEP_SQRT && n < 2) return fail(PT_ERR_INVALID_ARG, "a sweep probe reports into out[0..1]");
     int ndev = 0;

@@ -21,6 +21,11 @@ constexpr float kMinT = 0.001f;                       // scene.rs:16
 constexpr float kPi = 3.14159274101257324f;           // f32::consts::PI
 
 
+// Wave votes straight on the condition's lane mask. (hip's __any / __ballot first materialise the condition as 0 / 1 in a VGPR and
+// compare it again: two VALU instructions per vote, ~20 per wave-iteration of the list kernels.)
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+
 __device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 __device__ __forceinline__ f3 add3(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ f3 sub3(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -28,13 +33,30 @@ __device__ __forceinline__ f3 mul3(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y,
 __device__ __forceinline__ f3 scale3(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ f3 divs3(f3 a, float s) { return f3{a.x / s, a.y / s, a.z / s}; }
 __device__ __forceinline__ f3 neg3(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+// v / r per component (sphere.rs:42 `(point - center) / radius`), correctly rounded, for a divisor whose f32 reciprocal `y` the
+// host already holds (pt_prep.hip: 1.0f / radius, NaN when |radius| is outside [2^-20, 2^20]). With no operand or quotient near
+// the ends of the exponent range the scaling steps of an IEEE division never apply and it reduces to what is left of clang's
+// lowering: q = n * y refined twice through the exact fused residual n - q r; v_div_fixup_f32 supplies signed zeros, infinities
+// and NaNs. A wave in which some lane falls outside that range (a component below 2^-90 -- zero included --, one above 2^100, no
+// reciprocal) takes the three full divisions. 23 VALU instructions instead of 34 per hit; checked against `/` on 2^32 seeded pairs
+// per divisor class (PT_PROBE_SWEEP_DIV).
+__device__ __forceinline__ float div_by_known(float n, float r, float y) {
+    float q = n * y;
+    q = __builtin_fmaf(__builtin_fmaf(-q, r, n), y, q);
+    q = __builtin_fmaf(__builtin_fmaf(-q, r, n), y, q);
+    return __builtin_amdgcn_div_fixupf(q, r, n);
+}
+__device__ __forceinline__ bool div_by_known_ok(f3 v, float y) {
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z));
+    return lo >= 0x1p-90f && hi < 0x1p100f && y == y;   // (a NaN component fails the first two)
+}
+__device__ __forceinline__ f3 divs3_known(f3 v, float r, float y) {
+    if (__builtin_expect(wave_any(!div_by_known_ok(v, y)), 0)) return f3{v.x / r, v.y / r, v.z / r};
+    return f3{div_by_known(v.x, r, y), div_by_known(v.y, r, y), div_by_known(v.z, r, y)};
+}
 // glam Vec3::dot: (x*x' + y*y') + z*z'
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-// Wave votes straight on the condition's lane mask. (hip's __any / __ballot first materialise the condition as 0 / 1 in a VGPR and
-// compare it again: two VALU instructions per vote, ~20 per wave-iteration of the list kernels.)
-__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
-
 // f32::sqrt, correctly rounded like sqrtf -- with the parts of clang's lowering that the callers here never need taken out of
 // the common path (16 -> 11 VALU instructions, five to seven square roots per wave-iteration). The lowering scales inputs below
 // 2^-96 up, takes v_sqrt_f32 (1 ulp), picks among {s - 1 ulp, s, s + 1 ulp} by the sign of two fused residuals, scales back and
@@ -51,8 +73,20 @@ __device__ __forceinline__ float sqrt_exact(float x) {
     return s;
 }
 __device__ __forceinline__ float length3(f3 a) { return sqrt_exact(dot3(a, a)); }
+// 1.0 / sqrt(t), both correctly rounded (glam 0.20's scalar `1.0 / length`). The divisor is a square root, so it is never
+// denormal, never above 2^64 and its reciprocal is a normal number: the scaling steps of a general IEEE division never apply, and
+// v_rcp_f32 refined by two fused Newton steps is already the correctly rounded quotient; v_div_fixup_f32 supplies the results for
+// 0, inf and NaN. 7 VALU instructions after the root instead of 11 -- and a function of ONE f32, so it is checked against the
+// compiler's `1.0f / sqrtf(t)` on all 2^32 inputs (PT_PROBE_SWEEP_INVLEN).
+__device__ __forceinline__ float inv_sqrt_exact(float t) {
+    const float s = sqrt_exact(t);
+    float y = __builtin_amdgcn_rcpf(s);
+    y = __builtin_fmaf(__builtin_fmaf(-s, y, 1.0f), y, y);
+    y = __builtin_fmaf(__builtin_fmaf(-s, y, 1.0f), y, y);
+    return __builtin_amdgcn_div_fixupf(y, s, 1.0f);
+}
 // glam 0.20 scalar Vec3::normalize: v * (1.0 / length)
-__device__ __forceinline__ f3 normalize3(f3 a) { return scale3(a, 1.0f / length3(a)); }
+__device__ __forceinline__ f3 normalize3(f3 a) { return scale3(a, inv_sqrt_exact(dot3(a, a))); }
 
 // ---- RNG: rand_xoshiro 0.6 Xoshiro256Plus seeded through SplitMix64 -------
 // call sites: scene.rs:96-102 (per-pixel seed), every rng.gen::<f32>()

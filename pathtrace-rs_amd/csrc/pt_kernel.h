@@ -1217,6 +1217,7 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
 // 768-thread workgroup per CU when the scene allows: the sphere fragments are then staged once per CU instead of three
 // times, and the LDS that frees holds the per-lane attenuation stacks (no HBM traffic for them).
 #ifdef PT_BBPROF   // tools/bbprof.py: the instrumented assembly keeps its counter registers above the compiler's
+#include "pt_bbprof.h"
 #define PT_BBPROF_ATTR __attribute__((amdgpu_num_sgpr(104)))
 #else
 #define PT_BBPROF_ATTR
@@ -1636,7 +1637,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                              qa = shade[4 * idx + 2], qb = shade[4 * idx + 3];
                 const f3 centre = mk3(sp.x, sp.y, sp.z);
                 const f3 point = add3(o, scale3(d, t_hit));            // ray.rs:24-26
-                const f3 normal = divs3(sub3(point, centre), sp.w);    // sphere.rs:42
+                const f3 normal = divs3_known(sub3(point, centre), sp.w, qa.w);    // sphere.rs:42 (qa.w: 1 / radius from the host)
                 struct { uint32_t kind, flags; int32_t tex; float param; } m = {
                     __float_as_uint(q1.x), __float_as_uint(q1.y), (int32_t)__float_as_uint(q1.z), q1.w};
                 // Texture::value for this sphere's texture (texture.rs:74-91), inlined for the resolved cases
@@ -1707,12 +1708,12 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         } else {
                             cosine = -rdotn / length3(d);
                             outward_normal = normal;
-                            ni_over_nt = 1.0f / ref_idx;
+                            ni_over_nt = qb.y;   // 1.0 / ref_idx (f32, from the host: pt_prep.hip)
                         }
                         f3 refracted;
                         bool use_refract = false;
                         if (refract3(d, outward_normal, ni_over_nt, refracted)) {
-                            const float reflect_prob = schlick_ref(cosine, ref_idx);
+                            const float reflect_prob = qb.x + (1.0f - qb.x) * pow5_ref(1.0f - cosine);   // math.rs:76-80, r0 from the host
                             if (rng_f32(rng) > reflect_prob) use_refract = true;
                         }
                         raw = use_refract ? refracted : reflect3(d, normal);

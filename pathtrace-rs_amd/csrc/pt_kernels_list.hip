@@ -2,24 +2,6 @@
 #include "pt_kernel.h"
 #include "pt_kernels.h"
 
-#ifdef PT_BBPROF
-// Development aid (tools/bbprof.py): execution counts of the kernels' basic blocks, bumped by scalar atomics that the tool
-// writes into this unit's ASSEMBLY; pt_bbprof_dump hands them to the tool.
-extern "C" {
-__device__ __attribute__((used, visibility("default"))) unsigned long long pt_bbprof[16384];
-}
-extern "C" __attribute__((visibility("default"))) int pt_bbprof_dump(const char *path) {
-    static unsigned long long host[16384];
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(host, HIP_SYMBOL(pt_bbprof), sizeof host) != hipSuccess) return -1;
-    FILE *f = fopen(path, "w");
-    if (!f) return -2;
-    for (int i = 0; i < 16384; ++i)
-        if (host[i]) fprintf(f, "%d %llu\n", i, host[i]);
-    fclose(f);
-    return 0;
-}
-#endif
-
 namespace ptdev {
 
 // ---- work ordering ------------------------------------------------------------------------------

@@ -2,6 +2,7 @@
 // sphere fragments and tile-culling tables, and the host restatements of the internal traversal trees. No HIP call in this
 // file: pt_scene.hip uploads what it produces, pt_debug_select (pt_api.hip) runs it on machines without a GPU.
 #include "pt_host.h"
+#include <limits>
 
 #include <algorithm>
 #include <array>
@@ -527,9 +528,25 @@ int plan_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, SphereP
                 qa = make_float4(t.scale, 0.f, 0.f, 0.f);
             }
         }
+        if (m.kind == PT_MAT_DIELECTRIC) {
+            // the two per-material constants of a Dielectric scatter, in the reference's f32 arithmetic (math.rs:77-78 r0 of schlick,
+            // material.rs:105 1.0 / ref_idx): two IEEE divisions the kernel would otherwise repeat at every glass hit
+            const volatile float one_minus = 1.0f - m.param, one_plus = 1.0f + m.param;
+            volatile float r0 = one_minus / one_plus;
+            r0 = r0 * r0;
+            const volatile float inv = 1.0f / m.param;
+            qb = make_float4(r0, inv, 0.f, 0.f);
+        }
         if (m.kind == PT_MAT_LAMBERTIAN && (flags & (kShadeConst | kShadeChecker2)) == 0) palette_ok = false;
         if (m.kind == PT_MAT_LAMBERTIAN && flags == 0) word_ok = false;
         if (m.kind > PT_MAT_DIFFUSE_LIGHT) palette_ok = false, word_ok = false;
+        // 1 / radius for the normal's division (pt_device.h divs3_known); NaN = "divide in full" for radii near the ends of the
+        // exponent range
+        {
+            const float ar = std::fabs(p.radius);
+            const volatile float inv_r = 1.0f / p.radius;
+            qa.w = (ar >= 0x1p-20f && ar <= 0x1p20f) ? (float)inv_r : std::numeric_limits<float>::quiet_NaN();
+        }
         union { uint32_t u; float f; } k{m.kind}, fl{flags}, tx{(uint32_t)m.texture};
         P.shade[4 * i] = make_float4(p.cx, p.cy, p.cz, p.radius);
         P.shade[4 * i + 1] = make_float4(k.f, fl.f, tx.f, m.param);

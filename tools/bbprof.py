@@ -20,7 +20,7 @@ OUT = os.path.join(PKG, "_build", "bbprof")
 LLVM = "/opt/rocm/lib/llvm/bin"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-I../include", "-Icsrc",
          "-I/opt/rocm/include", "-DPT_BBPROF"]
-UNIT = "pt_kernels_list"
+UNIT = os.environ.get("BBPROF_UNIT", "pt_kernels_list")   # pt_kernels_list | pt_kernels_gate | pt_kernels_tree
 
 
 def sh(cmd, **kw):
@@ -46,14 +46,14 @@ def instrument(src_lines):
 
     def open_block(name):
         nonlocal cur
-        cur = {"kernel": kernel, "label": name, "valu": 0, "salu": 0, "lds": 0, "mfma": 0, "vmem": 0, "other": 0, "trans": 0, "lines": collections.Counter()}
+        cur = {"kernel": kernel, "label": name, "valu": 0, "salu": 0, "lds": 0, "mfma": 0, "vmem": 0, "other": 0, "trans": 0, "lanes": 0, "movs": 0, "lines": collections.Counter()}
         blocks.append(cur)
         out.append("\ts_atomic_add_x2 s[96:97], s[98:99], 0x%x" % (8 * (len(blocks) - 1)))
 
     for l in src_lines:
         m = re.match(r'\s*\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', l)
         if m: files[int(m.group(1))] = m.group(2)
-        m = re.match(r"^(_ZN5ptdev15pt_trace_kernel\w+):", l)
+        m = re.match(r"^(_ZN5ptdev\d+pt_trace_kernel\w+):", l)
         if m:
             kernel = m.group(1)
             out.append(l)
@@ -80,6 +80,8 @@ def instrument(src_lines):
                 cur[k] += 1
                 if k == "valu":
                     if re.match(r"v_(rcp|sqrt|rsq|div_|exp|log|sin|cos)", op): cur["trans"] += 1
+                    if re.match(r"v_(readlane|writelane|readfirstlane)", op): cur["lanes"] += 1   # SGPR spill traffic and wave-uniform reads
+                    if re.match(r"v_(mov_b|accvgpr)", op): cur["movs"] += 1
                     if loc: cur["lines"]["%s:%d" % loc] += 1
         elif ".amdhsa_next_free_sgpr" in l and blocks and "pt_trace_kernel" in (blocks[-1]["kernel"] or ""):
             l = "\t\t.amdhsa_next_free_sgpr 100"   # the descriptor follows the function body
@@ -155,6 +157,12 @@ def run(argv):
     print("dump rc", rc, "rays", total, "kernel", scene.last_kernel_choice() if hasattr(scene, "last_kernel_choice") else "")
 
 
+def remap():
+    """Re-derives bbprof_map.json from the kept assembly (after a change to the classification above)."""
+    _, blocks = instrument(open(os.path.join(OUT, UNIT + ".s")).read().split("\n"))
+    json.dump(blocks, open(os.path.join(OUT, "bbprof_map.json"), "w"))
+
+
 def report(argv):
     counts_file = argv[0] if argv else os.path.join(ROOT, "gpurun_out", "bbprof_counts.txt")
     blocks = json.load(open(os.path.join(OUT, "bbprof_map.json")))
@@ -170,7 +178,7 @@ def report(argv):
         n = counts.get(i, 0)
         if not n: continue
         k = b["kernel"]
-        for c in ("valu", "salu", "lds", "mfma", "vmem", "trans"): per_kernel[k][c] += n * b[c]
+        for c in ("valu", "salu", "lds", "mfma", "vmem", "trans", "lanes", "movs"): per_kernel[k][c] += n * b.get(c, 0)
         per_kernel[k]["blocks"] += n
         if b["label"] == "entry": per_kernel[k]["waves"] += n
         for ln, c in b["lines"].items(): lines[k][ln] += n * c
@@ -180,6 +188,7 @@ def report(argv):
         if rays: print("   VALU wave-instructions per 64 rays (all kernels' rays): %.1f" % (tot["valu"] / (rays / 64.0)))
         print("   waves %d; dynamic wave-instructions: VALU %.4g (of them v_rcp/sqrt/div_* %.3g)  SALU %.4g  LDS %.4g  MFMA %.4g  VMEM %.4g" %
               (tot["waves"], tot["valu"], tot["trans"], tot["salu"], tot["lds"], tot["mfma"], tot["vmem"]))
+        print("   of the VALU instructions: v_readlane/v_writelane %.3g (%.1f%%), v_mov %.3g (%.1f%%)" % (tot["lanes"], 100.0 * tot["lanes"] / tot["valu"], tot["movs"], 100.0 * tot["movs"] / tot["valu"]))
         print("   -- blocks by dynamic VALU")
         for dv, n, b in sorted(rows[k], key=lambda r: -r[0])[:45]:
             top = sorted(b["lines"].items(), key=lambda kv: -kv[1])[:5]
@@ -195,4 +204,5 @@ if __name__ == "__main__":
     if cmd == "build": build()
     elif cmd == "run": run(sys.argv[2:])
     elif cmd == "report": report(sys.argv[2:])
+    elif cmd == "remap": remap()
     else: sys.exit(__doc__)
