@@ -69,6 +69,11 @@ struct DCamera {  // camera.rs:8-19
 //   [12] as u32 bits: cull_axis, cull_always, max_depth, samples   [13] tile culling's per-ray reach: 2 kappa, kappa (2 Rs^2 + r_max^2) + r_min^2, r_min, -
 constexpr uint32_t kLdsParamBytes = 14u * 16u;
 
+// Bit of a ray's 32-bit tile mask (pt_kernel.h, intersect_list_mfma) that fragment row `row` of a tile ends up in. A lane of
+// v_mfma_f32_32x32x16_f16 holds rows (r & 3) + 8 (r >> 2) + 4 * (lane >> 5) in accumulator registers r = 0..15; the kernel shifts
+// the signs in so that register r lands at bit 15 - r, the low half of the wave supplying bits 0..15 and the high half 16..31.
+// tile_sphere is stored in this BIT order, so a candidate bit indexes it directly.
+constexpr uint32_t tile_bit_of_row(uint32_t row) { return (15u - ((row & 3u) | ((row >> 3) << 2))) + 16u * ((row >> 2) & 1u); }
 constexpr int kCullCells = 256;   // resolution of the tile-culling lookup along the sort axis
 
 struct KArgs {
@@ -100,7 +105,7 @@ struct KArgs {
     uint32_t n_spheres_pad;      // multiple of kScanUnroll; padding entries can never be hit
     // MFMA discriminant prefilter (list mode, see "MFMA prefilter" below); n_tiles == 0 disables it
     const uint4 *afrag;          // [n_tiles][2 chunks][64 lanes] x 8 f16: sphere-feature A fragments
-    const uint16_t *tile_sphere; // [n_tiles*32] sphere index of each fragment row, 0xffff = padding
+    const uint16_t *tile_sphere; // [n_tiles*32] sphere index behind each bit of a tile mask (tile_bit_of_row), 0xffff = padding row
     const uint32_t *large;       // spheres outside the prefilter's range: tested exactly for every ray
     uint32_t n_tiles, n_large;
     float c0[3];                 // feature-space origin (f32-exact), radius bound of the prefiltered set

@@ -110,15 +110,25 @@ __device__ __forceinline__ void rng_seed_from_u64(Rng &r, uint64_t seed) {
     r.s3 = splitmix64_next(x);
 }
 
+// The state update is the reference's (rand_xoshiro 0.6: s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3; s2 ^= t; s3 = rotl(s3, 45)) written
+// on 32-bit halves with gfx950's three-input bit operation, so that no intermediate is materialised twice: s1' = s1 ^ s2 ^ s0 and
+// s2' = s2 ^ s0 ^ t are one v_bitop3_b32 (truth table 0x96) per half, the rotation two v_alignbit_b32 -- 13 VALU instructions per
+// step where the 64-bit form compiles to 15 (ten two-input xors, and a 64-bit shift + shift + or for the rotation).
 __device__ __forceinline__ uint64_t rng_next_u64(Rng &r) {
     const uint64_t result = r.s0 + r.s3;
     const uint64_t t = r.s1 << 17;
-    r.s2 ^= r.s0;
-    r.s3 ^= r.s1;
-    r.s1 ^= r.s2;
-    r.s0 ^= r.s3;
-    r.s2 ^= t;
-    r.s3 = (r.s3 << 45) | (r.s3 >> 19);
+    const uint32_t s0l = (uint32_t)r.s0, s0h = (uint32_t)(r.s0 >> 32), s1l = (uint32_t)r.s1, s1h = (uint32_t)(r.s1 >> 32);
+    const uint32_t s2l = (uint32_t)r.s2, s2h = (uint32_t)(r.s2 >> 32), s3l = (uint32_t)r.s3, s3h = (uint32_t)(r.s3 >> 32);
+    const uint32_t bl = s3l ^ s1l, bh = s3h ^ s1h;                                      // s3 ^= s1
+    const uint32_t n1l = __builtin_amdgcn_bitop3_b32(s1l, s2l, s0l, 0x96), n1h = __builtin_amdgcn_bitop3_b32(s1h, s2h, s0h, 0x96);   // s1 ^= (s2 ^ s0)
+    const uint32_t n2l = __builtin_amdgcn_bitop3_b32(s2l, s0l, (uint32_t)t, 0x96), n2h = __builtin_amdgcn_bitop3_b32(s2h, s0h, (uint32_t)(t >> 32), 0x96);   // s2 = (s2 ^ s0) ^ t
+    const uint32_t n0l = s0l ^ bl, n0h = s0h ^ bh;                                      // s0 ^= s3
+    // rotl(b, 45) = rotr(b, 19): low word = (bh : bl) >> 19, high word = (bl : bh) >> 19
+    const uint32_t n3l = __builtin_amdgcn_alignbit(bh, bl, 19), n3h = __builtin_amdgcn_alignbit(bl, bh, 19);
+    r.s0 = (uint64_t)n0l | ((uint64_t)n0h << 32);
+    r.s1 = (uint64_t)n1l | ((uint64_t)n1h << 32);
+    r.s2 = (uint64_t)n2l | ((uint64_t)n2h << 32);
+    r.s3 = (uint64_t)n3l | ((uint64_t)n3h << 32);
     return result;
 }
 

@@ -612,12 +612,10 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     // tile. Non-empty masks are appended to this lane's queue; `tbits` remembers which tiles they belong to.
     uint32_t tbits = 0, cnt = 0, ncand = 0;
     uint32_t *queue32 = reinterpret_cast<uint32_t *>(queue);
-    // slot of bit b of a tile mask: register r = 15 - (b & 15) is row (r & 3) + 8 (r >> 2) + 4 * (half of the wave
-    // that computed it); bits 0..15 come from the low half, 16..31 from the high half
-    auto slot_of = [&](uint32_t T, uint32_t b) -> uint32_t {
-        const uint32_t r = 15u - (b & 15u);
-        return T * 32u + (r & 3u) + 8u * (r >> 2) + ((b >> 4) << 2);
-    };
+    // slot of bit b of a tile mask. (Bit b comes from accumulator register r = 15 - (b & 15), i.e. fragment row (r & 3) + 8 (r >> 2)
+    // + 4 * (half of the wave that computed it), bits 0..15 from the low half, 16..31 from the high half; the host stores
+    // tile_sphere in BIT order -- pt_args.h tile_bit_of_row -- so the lookup in the per-bit loops below needs no arithmetic.)
+    auto slot_of = [&](uint32_t T, uint32_t b) -> uint32_t { return T * 32u + b; };
     float best = kMaxT;
     int idx = -1;
     uint32_t best_rank = 0;
@@ -1483,10 +1481,12 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 }
             }
         }
+#ifdef PT_SKIP_EDGE
         if (wave_ballot(have) == 0ull) {
             if (wave_ballot(!exhausted) == 0ull) break;
             continue;
         }
+#endif
 #ifdef PT_WAVE_DETAIL
         if (A.wave_end) dbg_iters += 1;
 #endif
@@ -1798,6 +1798,13 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             }
         }
         PT_SEC(3);
+#ifndef PT_SKIP_EDGE
+        // The loop's only exit, at its very end. (A wave whose refill brought no pixel -- beyond the frame's edge, or the list ran dry --
+        // used to skip the body with `continue` / leave with `break` from here up there. The compiler's structurizer turns such an edge
+        // into a flag tested after the body, which keeps every loop-carried register's start-of-iteration value alive THROUGH the body:
+        // a second home for ~28 registers and ~45 copies per wave-iteration. An idle trip through the body is harmless: no lane has a ray.)
+        if (wave_ballot(have) == 0ull && wave_ballot(!exhausted) == 0ull) break;
+#endif
     }
 
 #ifdef PT_SECTIONS

@@ -227,7 +227,7 @@ bool prepare_mfma(const pt_scene_desc *desc, const MotionIn *motion, double t_lo
             double S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 60000.0};  // padding: S.R = -a * 60000 < thr, never a candidate
             if (j < small.size()) {
                 const pt_sphere &p = desc->spheres[small[j]];
-                out.tile_sphere[j] = (uint16_t)small[j];
+                out.tile_sphere[(size_t)T * 32 + tile_bit_of_row(row)] = (uint16_t)small[j];
                 const Sweep &w = sw[small[j]];
                 const double x = w.c[0] - out.c0[0], y = w.c[1] - out.c0[1], z = w.c[2] - out.c0[2];
                 const volatile float r2s = p.radius * p.radius;  // sphere.rs:36 (the reference squares in f32)

@@ -380,11 +380,7 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
                 }
             }
         }
-        if (wave_ballot(have) == 0ull) {
-            if (wave_ballot(!exhausted) == 0ull) break;
-            continue;
-        }
-
+        // (no `continue` / `break` up here for a wave whose refill brought nothing: the loop's only exit is at its end -- see pt_kernel.h)
         if (have) {
             // ---- camera.rs:56-68 + scene.rs:107-108
             if (need_cam) {
@@ -559,6 +555,7 @@ __global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
                 }
             }
         }
+        if (wave_ballot(have) == 0ull && wave_ballot(!exhausted) == 0ull) break;
     }
 
     unsigned long long total = nrays;  // scene.rs:118

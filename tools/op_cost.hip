@@ -51,7 +51,23 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float s) {
         if (OP == 33) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(a##i) : "v"(b)); \
         if (OP == 34) asm volatile("v_cmp_lt_f32 s[22:23], %0, %1\n\tv_cndmask_b32 %0, %0, %1, s[22:23]" : "+v"(a##i) : "v"(b) : "s22", "s23"); \
         if (OP == 35) asm volatile("v_mul_f32 %0, %0, %1\n\tv_add_f32 %0, %0, %1" : "+v"(a##i) : "v"(b)); \
-        if (OP == 36) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n\tv_mul_f32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+        if (OP == 36) asm volatile("v_cndmask_b32 %0, %0, %1, vcc\n\tv_mul_f32 %0, %0, %1" : "+v"(a##i) : "v"(b)); \
+        if (OP == 50) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a##i) : "v"(b)); \
+        if (OP == 51) asm volatile("v_xor_b32 %0, %0, %1\n\tv_xor_b32 %0, %0, %1" : "+v"(a##i) : "v"(b)); \
+        if (OP == 52) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a##i), "+v"(b)); \
+        if (OP == 53) asm volatile("v_cvt_f16_f32 %0, %0" : "+v"(a##i)); \
+        if (OP == 54) asm volatile("v_cvt_f32_f16 %0, %0" : "+v"(a##i)); \
+        if (OP == 55) asm volatile("v_ffbl_b32 %0, %0" : "+v"(a##i)); \
+        if (OP == 56) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a##i) : "v"(b)); \
+        if (OP == 57) asm volatile("v_lshrrev_b32 %0, 8, %0" : "+v"(a##i)); \
+        if (OP == 58) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a##i) : "v"(b)); \
+        if (OP == 59) asm volatile("v_pack_b32_f16 %0, %0, %1" : "+v"(a##i) : "v"(b)); \
+        if (OP == 60) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(a##i) : "v"(b)); \
+        if (OP == 61) asm volatile("v_mul_f32 %0, %0, %1\n\ts_nop 0" : "+v"(a##i) : "v"(b)); \
+        if (OP == 63) asm volatile("v_fma_f32 %0, %0, %1, 1.0" : "+v"(a##i) : "v"(b)); \
+        if (OP == 64) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(a##i) : "v"(b)); \
+        if (OP == 65) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a##i) : "v"(b)); \
+        if (OP == 66) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(a##i) : "v"(b));
         REP8(ONE)
 #undef ONE
 #define DBL(i) \
@@ -61,7 +77,11 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float s) {
         if (OP == 23) asm volatile("v_fma_f64 %0, %0, %0, %0" : "+v"(d##i)); \
         if (OP == 40) asm volatile("v_pk_mul_f32 %0, %0, %0" : "+v"(d##i)); \
         if (OP == 41) asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(d##i)); \
-        if (OP == 42) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(d##i));
+        if (OP == 42) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(d##i)); \
+        if (OP == 43) asm volatile("v_lshl_add_u64 %0, %0, 0, %0" : "+v"(d##i)); \
+        if (OP == 44) asm volatile("v_lshlrev_b64 %0, 17, %0" : "+v"(d##i)); \
+        if (OP == 45) asm volatile("v_mov_b64 %0, %0" : "+v"(d##i)); \
+        if (OP == 46) asm volatile("v_lshrrev_b64 %0, 19, %0" : "+v"(d##i));
         DBL(0) DBL(1) DBL(2) DBL(3) DBL(0) DBL(1) DBL(2) DBL(3)
 #undef DBL
         if (OP == 30) {
@@ -99,10 +119,10 @@ int main() {
     hipMalloc(&d, 256 * 4096 * 4);
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
-    const int cus = prop.multiProcessorCount, bpc = 4, iters = 40000;
+    const int cus = prop.multiProcessorCount, bpc = 4, iters = 8000;
     struct Row { const char *name; float ms; int per_iter; };
     std::vector<Row> rows;
-#define RUN(op, name, n) rows.push_back(Row{name, run<op>(d, cus, bpc, iters), n});
+#define RUN(op, name, n) rows.push_back(Row{name, run<op>(d, cus, bpc, iters), n}); fprintf(stderr, "%s %.3f\n", name, rows.back().ms);
     RUN(2, "v_mul_f32", 8) RUN(0, "v_nop", 8) RUN(1, "v_mov_b32", 8) RUN(3, "v_add_f32", 8) RUN(19, "v_sub_f32", 8) RUN(4, "v_fma_f32", 8)
     RUN(5, "v_xor_b32", 8) RUN(6, "v_alignbit_b32", 8) RUN(7, "v_cndmask_b32 (vcc)", 8) RUN(8, "v_lshl_add_u32", 8) RUN(26, "v_and_or_b32", 8)
     RUN(18, "v_max3_f32", 8) RUN(27, "v_cvt_f32_u32", 8) RUN(9, "v_rcp_f32", 8) RUN(10, "v_sqrt_f32", 8) RUN(11, "v_mul_lo_u32", 8)
@@ -110,6 +130,11 @@ int main() {
     RUN(24, "v_add_co + v_addc (pair)", 8) RUN(25, "v_readlane_b32", 8) RUN(17, "ds_bpermute_b32 (+wait)", 8)
     RUN(28, "v_cndmask_b32 (sgpr pair)", 8) RUN(29, "s_nop 0", 8) RUN(32, "v_bfe_u32", 8) RUN(33, "v_perm_b32", 8)
     RUN(34, "v_cmp + v_cndmask (pair)", 8) RUN(35, "v_mul + v_add (pair)", 8) RUN(36, "v_cndmask(vcc) + v_mul (pair)", 8)
+    RUN(50, "v_bitop3_b32", 8) RUN(51, "v_xor + v_xor (pair)", 8) RUN(52, "v_permlane32_swap_b32", 8) RUN(53, "v_cvt_f16_f32", 8) RUN(54, "v_cvt_f32_f16", 8)
+    RUN(55, "v_ffbl_b32", 8) RUN(56, "v_add3_u32", 8) RUN(57, "v_lshrrev_b32", 8) RUN(58, "v_and_b32", 8) RUN(59, "v_pack_b32_f16", 8) RUN(60, "v_cvt_pkrtz_f16_f32", 8)
+    RUN(66, "v_cvt_pk_f16_f32", 8)
+    RUN(61, "v_mul + s_nop (pair)", 8) RUN(63, "v_fma_f32 (inline const)", 8) RUN(64, "v_fmac_f32 (VOP2)", 8) RUN(65, "v_min_f32", 8)
+    RUN(43, "v_lshl_add_u64", 8) RUN(44, "v_lshlrev_b64", 8) RUN(45, "v_mov_b64", 8) RUN(46, "v_lshrrev_b64", 8)
     RUN(40, "v_pk_mul_f32", 8) RUN(41, "v_pk_add_f32", 8) RUN(42, "v_pk_fma_f32", 8)
     RUN(20, "v_mul_f64", 8) RUN(23, "v_fma_f64", 8) RUN(22, "v_cvt_f64_f32", 8) RUN(21, "v_mad_u64_u32", 8) RUN(30, "v_mfma_f32_32x32x16_f16", 8)
     const double base = rows[0].ms / (double)(iters * rows[0].per_iter);
