@@ -279,6 +279,30 @@ __global__ void sweep_kernel(uint32_t probe, uint32_t *result) {
                 if (g.z == g.z) got |= __float_as_uint(g.z) ^ __float_as_uint(v.z / r);
             }
         }
+        if (probe == PT_PROBE_SWEEP_DIVA) {
+            // the sphere test's quotients n / a with a = d.d (pt_device.h DivA). Every thread checks (1) the reciprocal of one of the
+            // 2^24 + 1 values of [0.5, 2] against 1.0f / a, and (2) one seeded pair: a within 64 ulps of 1 (half of the pairs) or
+            // anywhere in [0.5, 2], n ANY bit pattern. Quotients of numerators below 2^-99 are only required to stay below 2^-97 (the
+            // kernels reject them against t_min), numerators above 2^100 never occur (a finite discriminant keeps them below 2^66).
+            const float ar = (bits & 0x1ffffffu) == 0x1000000u ? 2.0f : __uint_as_float(0x3f000000u + (bits & 0xffffffu));
+            got = __float_as_uint(recip_unit_range(ar)) ^ __float_as_uint(1.0f / ar);
+            uint64_t z = (uint64_t)bits * 0x9E3779B97F4A7C15ull + 0x2545F4914F6CDD1Dull;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull, z = (z ^ (z >> 27)) * 0x94D049BB133111EBull, z ^= z >> 31;
+            const uint32_t ha = (uint32_t)z, hn = (uint32_t)(z >> 32);
+            const float a = (ha & 1u) ? __uint_as_float(0x3f800000u - 64u + ((ha >> 1) & 127u))
+                                      : __uint_as_float(0x3f000000u + ((ha >> 1) & 0xffffffu));
+            float n = __uint_as_float(hn);
+            if ((bits & 31u) == 0u) {
+                const uint32_t sel = (bits >> 5) & 7u;
+                n = sel == 0 ? 0.0f : sel == 1 ? -0.0f : sel == 2 ? 1.0e-40f : sel == 3 ? -0x1p-99f : sel == 4 ? __uint_as_float(0x7f800000u)
+                  : sel == 5 ? __uint_as_float(0x7fc00000u) : sel == 6 ? 0x1p-100f : 0x1p66f;
+            }
+            const float q = div_by_unit_range(n, a, recip_unit_range(a)), w = n / a;
+            const float an = __builtin_fabsf(n);
+            if (an < 0x1p-99f && an > 0.0f) got |= (__builtin_fabsf(q) < 0x1p-97f) ? 0u : 1u;   // (tiny: magnitude only)
+            else if (an >= 0x1p100f && an < __uint_as_float(0x7f800000u)) got |= 0u;                    // (never a numerator)
+            else if (!(q != q && w != w)) got |= __float_as_uint(q) ^ __float_as_uint(w);
+        }
         if (probe == PT_PROBE_SWEEP_DRAWS) {
             // every draw k * 2^-24 (low 24 bits) beside a pixel coordinate n (high 8 bits, spread over 0..8160): the fused forms
             // of pt_device.h against the reference's expressions
@@ -299,7 +323,7 @@ __global__ void sweep_kernel(uint32_t probe, uint32_t *result) {
 
 extern "C" int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n) {
     if (!in || !out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
-    if (probe > PT_PROBE_SWEEP_DIV) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
+    if (probe > PT_PROBE_SWEEP_DIVA) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
     if (n == 0) return PT_OK;
     if (probe >= PT_PROBE_SWEEP_SQRT && n < 2) return fail(PT_ERR_INVALID_ARG, "a sweep probe reports into out[0..1]");
     int ndev = 0;

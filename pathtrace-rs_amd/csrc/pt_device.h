@@ -85,6 +85,36 @@ __device__ __forceinline__ float inv_sqrt_exact(float t) {
     y = __builtin_fmaf(__builtin_fmaf(-s, y, 1.0f), y, y);
     return __builtin_amdgcn_div_fixupf(y, s, 1.0f);
 }
+// n / a for the divisor of the sphere test, a = d.d of the ray (sphere.rs:34,40,51: `(-b -+ sqrt(disc)) / a`). Every ray direction
+// of the sphere kernels is a normalised vector, so a lies within a few ulps of 1; for ANY a in [0.5, 2] the scaling steps of an IEEE
+// division never apply to the divisor and its reciprocal is a normal number: y = v_rcp_f32(a) refined by two fused Newton steps is
+// the correctly rounded 1 / a (computed ONCE per ray), and q = n * y refined twice through the exact residual n - q a is the
+// correctly rounded n / a -- what is left of clang's lowering of `/` when nothing needs scaling -- with v_div_fixup_f32 supplying
+// zeros, infinities and NaNs. 6 VALU instructions per division instead of 11, on the longest dependent chain of the exact phase.
+// Numerators below 2^-99 (the lowering would scale; here the last bits may differ) give quotients far below t_min = 0.001, rejected
+// by sphere.rs:41,52 either way; the numerators -b -+ sqrt(disc) of a finite discriminant stay below 2^66, so nothing overflows.
+// A wave in which some ray's a is outside [0.5, 2] (never seen; a NaN direction) takes the full divisions: `fast` is wave-uniform.
+// Checked against `/` by pt_selftest_probe PT_PROBE_SWEEP_DIVA: every a in [0.5, 2] for the reciprocal, 2^32 seeded (n, a) pairs
+// (a within 64 ulps of 1, or anywhere in [0.5, 2]; n any bit pattern) for the quotient.
+struct DivA {
+    float a, y;   // d.d and its reciprocal
+    bool fast;    // wave-uniform: every ray the wave tests this iteration has a in [0.5, 2]
+};
+__device__ __forceinline__ float recip_unit_range(float a) {
+    float y = __builtin_amdgcn_rcpf(a);
+    y = __builtin_fmaf(__builtin_fmaf(-a, y, 1.0f), y, y);
+    y = __builtin_fmaf(__builtin_fmaf(-a, y, 1.0f), y, y);
+    return y;
+}
+__device__ __forceinline__ bool in_unit_range(float a) { return a >= 0.5f && a <= 2.0f; }
+__device__ __forceinline__ float div_by_unit_range(float n, float a, float y) {
+    float q = n * y;
+    q = __builtin_fmaf(__builtin_fmaf(-q, a, n), y, q);
+    q = __builtin_fmaf(__builtin_fmaf(-q, a, n), y, q);
+    return __builtin_amdgcn_div_fixupf(q, a, n);
+}
+__device__ __forceinline__ float div_a(float n, const DivA &v) { return v.fast ? div_by_unit_range(n, v.a, v.y) : n / v.a; }
+
 // glam 0.20 scalar Vec3::normalize: v * (1.0 / length)
 __device__ __forceinline__ f3 normalize3(f3 a) { return scale3(a, inv_sqrt_exact(dot3(a, a))); }
 

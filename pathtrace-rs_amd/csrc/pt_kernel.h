@@ -205,20 +205,22 @@ __device__ __forceinline__ f3 texture_value(const DTex *texs, const PerlinLds &p
 
 // ---- sphere.rs:29-66 exact slow path for one sphere ---------------------------
 // Returns true and narrows `closest` when the sphere is hit in (kMinT, closest).
-__device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float &closest) {
+__device__ __forceinline__ bool sphere_roots(const DivA &av, float b, float disc, float &closest) {
     const float sq = sqrt_exact(disc);
-    float t = (-b - sq) / a;
+    float t;
+    if (av.fast) t = div_by_unit_range(-b - sq, av.a, av.y); else t = (-b - sq) / av.a;   // (wave-uniform branch)
     if (t < closest && t > kMinT) {
         closest = t;
         return true;
     }
-    t = (-b + sq) / a;
+    if (av.fast) t = div_by_unit_range(-b + sq, av.a, av.y); else t = (-b + sq) / av.a;
     if (t < closest && t > kMinT) {
         closest = t;
         return true;
     }
     return false;
 }
+__device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float &closest) { return sphere_roots(DivA{a, 0.0f, false}, b, disc, closest); }
 
 // hitable_list.rs:40-56 over sphere.rs:29-66, restructured for the GPU in two phases that
 // together perform exactly the reference's sequence of accepted hits:
@@ -357,34 +359,42 @@ __device__ __forceinline__ RayFeat make_ray_features(const float4 *P, f3 o, f3 d
     R[7] = __builtin_fmaf(a2, op.y, -od2 * d.y);
     R[8] = __builtin_fmaf(a2, op.z, -od2 * d.z);
     R[9] = -a;
-    _Float16 slot[32];
+    // hi/lo split of the ten features and the threshold into the 32 f16 slots of a ray: slots 0..9 = hi (x -Sh), 10..19 = lo (x -Sh),
+    // 20..29 = hi again (x -Sl), 30 / 31 = thr hi / lo (x 1). The residual MUST be taken against the very f16 value that is stored.
+    // (hipcc was observed to round two uses of (_Float16)v differently at exact ties -- RNE for the stored half, RTZ inside a folded
+    // residual -- which loses one f16 ulp: each pair of features is therefore converted ONCE, by one v_cvt_pk_f16_f32 whose result is
+    // pinned behind an opaque register copy, and both the stored halves and the residuals come from that register.) Slots are
+    // consumed in pairs, so a packed pair is a finished dword of a fragment: no packing instructions.
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    uint32_t hi[5], lo[5];
 #pragma unroll
-    for (int f = 0; f < 11; ++f) {
-        const float v = (f < 10) ? R[f] : thr;
-        // hi/lo split: the residual MUST be taken against the very f16 value that is stored. hipcc was
-        // observed to round the two uses of (_Float16)v differently at exact ties (RNE for the stored
-        // half, RTZ inside the folded residual), which loses one f16 ulp; the opaque register copy pins
-        // one conversion result for both uses.
-        unsigned int hbits = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)v);
-        asm volatile("" : "+v"(hbits));
-        const _Float16 h = __builtin_bit_cast(_Float16, (unsigned short)hbits);
-        const _Float16 l = (_Float16)(v - (float)h);
-        if (f < 10) {
-            slot[f] = h;        // x (-Sh)
-            slot[10 + f] = l;   // x (-Sh)
-            slot[20 + f] = h;   // x (-Sl)
-        } else {
-            slot[30] = h;       // x 1
-            slot[31] = l;       // x 1
-        }
+    for (int q = 0; q < 5; ++q) {
+        const float2v v = {R[2 * q], R[2 * q + 1]};
+        uint32_t hb = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, half2v));
+        asm volatile("" : "+v"(hb));
+        const half2v h = __builtin_bit_cast(half2v, hb);
+        const float2v res = {v.x - (float)h.x, v.y - (float)h.y};
+        hi[q] = hb;
+        lo[q] = __builtin_bit_cast(uint32_t, __builtin_convertvector(res, half2v));
     }
+    uint32_t thr_pair;
+    {
+        unsigned int tb = (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)thr);
+        asm volatile("" : "+v"(tb));
+        const _Float16 th = __builtin_bit_cast(_Float16, (unsigned short)tb);
+        const _Float16 tl = (_Float16)(thr - (float)th);
+        thr_pair = tb | ((uint32_t)__builtin_bit_cast(unsigned short, tl) << 16);
+    }
+    // dwords of the four k-groups: own[chunk][k-half] = slots chunk * 16 + k-half * 8 + 0..7
+    union H8 { half8 h; uint32_t u[4]; };
+    H8 own00, own01, own10, own11;
+    own00.u[0] = hi[0], own00.u[1] = hi[1], own00.u[2] = hi[2], own00.u[3] = hi[3];   // slots 0..7
+    own01.u[0] = hi[4], own01.u[1] = lo[0], own01.u[2] = lo[1], own01.u[3] = lo[2];   // slots 8..15
+    own10.u[0] = lo[3], own10.u[1] = lo[4], own10.u[2] = hi[0], own10.u[3] = hi[1];   // slots 16..23
+    own11.u[0] = hi[2], own11.u[1] = hi[3], own11.u[2] = hi[4], own11.u[3] = thr_pair;   // slots 24..31
     half8 own[2][2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) own[c][h][e] = slot[c * 16 + h * 8 + e];
+    own[0][0] = own00.h, own[0][1] = own01.h, own[1][0] = own10.h, own[1][1] = own11.h;
     // B operand of v_mfma_f32_32x32x16_f16: lane l supplies column (ray) l & 31, k-half l >> 5. For the MFMA over rays
     // 0..31 the low lanes supply their own k-half 0 and the high lanes k-half 1 of ray l - 32; for rays 32..63 the
     // low lanes supply k-half 0 of ray l + 32 and the high lanes their own k-half 1. v_permlane32_swap(X = k-half 0,
@@ -520,15 +530,16 @@ __device__ __forceinline__ float4 sphere_at(const KArgs &A, int k, float4 c, flo
 // return it for t_max = f32::MAX, winner = lexicographic (t, index) minimum == the sequential
 // closest_so_far scan of hitable_list.rs:40-56 (DESIGN.md "order-independent closest hit")
 template <bool GATED>
-__device__ __forceinline__ void exact_candidate(const KArgs &A, const GateSrc &G, const float4 c, int k, f3 o, f3 d, float a, float &best, int &idx,
+__device__ __forceinline__ void exact_candidate(const KArgs &A, const GateSrc &G, const float4 c, int k, f3 o, f3 d, const DivA &av, float &best, int &idx,
                                                 uint32_t &best_rank) {
+    const float a = av.a;
     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
     const float disc = b * b - a * cc;
     if (disc > 0.0f) {
         float t = kMaxT;
-        if (sphere_roots(a, b, disc, t)) accept_hit<GATED>(A, G, k, t, o, d, best, idx, best_rank);
+        if (sphere_roots(av, b, disc, t)) accept_hit<GATED>(A, G, k, t, o, d, best, idx, best_rank);
     }
 }
 
@@ -593,8 +604,9 @@ template <bool VERIFY, bool MOVING, bool GATED, int BLK>
 __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc &G, const float4 *mot, const float4 *P, const float4 *sph, const uint4 *s_afrag,
                                                    const uint16_t *s_tile_sphere, const uint32_t *s_cull, uint16_t *queue,
                                                    uint32_t *w_pairs, unsigned long long *w_keys,
-                                                   f3 o, f3 d, float a, bool active, float time, float &t_out,
+                                                   f3 o, f3 d, const DivA &av, bool active, float time, float &t_out,
                                                    unsigned long long *sec = nullptr) {
+    const float a = av.a;
     const int tid = threadIdx.x, lane = tid & 63;
 #ifdef PT_SECTIONS
     unsigned long long sub_last = __builtin_readcyclecounter();
@@ -658,7 +670,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                     cur &= cur - 1u;
                     const int k = s_tile_sphere[slot_of(curT, b)];
                     if (k != 0xffff)   // (a padding row of the fragment: flagged only by rays with a = d.d well below 1)
-                        exact_candidate<GATED>(A, G, sphere_at_m<MOVING>(mot, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+                        exact_candidate<GATED>(A, G, sphere_at_m<MOVING>(mot, k, sph[k], time), k, o, d, av, best, idx, best_rank);
                 }
             }
         } else if (total != 0u) {
@@ -690,6 +702,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                 const f3 po = mk3(lane_fetch(owner, o.x), lane_fetch(owner, o.y), lane_fetch(owner, o.z));
                 const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));
                 const float pa = lane_fetch(owner, a);
+                const DivA pav{pa, lane_fetch(owner, av.y), av.fast};
                 const float ptime = MOVING ? lane_fetch(owner, time) : 0.0f;
                 // (BVH worlds: 1 / d of the owner's ray for the gate test, fetched instead of three IEEE divisions per round)
                 const f3 prcp = GATED ? mk3(lane_fetch(owner, rcp_own.x), lane_fetch(owner, rcp_own.y), lane_fetch(owner, rcp_own.z)) : mk3(0.f, 0.f, 0.f);
@@ -701,7 +714,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                     const float disc = b * b - pa * cc;
                     if (disc > 0.0f) {
                         float t = kMaxT;
-                        if (sphere_roots(pa, b, disc, t)) {
+                        if (sphere_roots(pav, b, disc, t)) {
                             const uint32_t rank = GATED ? G.rank[k] : 0u;
                             if (!GATED || gate_pass_from(A, G, k, po, prcp))   // ray.rs:14 rcp_direction
                                 atomicMin(&w_keys[owner], key_of(t, k, rank));
@@ -725,7 +738,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     // the always-tested spheres first (wave-uniform): their nearest hit bounds the segment the tiles are culled against
     for (uint32_t j = 0; j < A.n_large; ++j) {
         const int k = (int)A.large[j];
-        if (active) exact_candidate<GATED>(A, G, sphere_at_m<MOVING>(mot, k, sph[k], time), k, o, d, a, best, idx, best_rank);
+        if (active) exact_candidate<GATED>(A, G, sphere_at_m<MOVING>(mot, k, sph[k], time), k, o, d, av, best, idx, best_rank);
     }
     // wave-uniform set of tiles to run: the union of the lanes' tile masks (verify mode audits every tile)
     uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
@@ -810,7 +823,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
             // verify mode (and its queue overflows, where the masks of a ray were not all kept): brute force
             for (int k = 0; k < (int)A.n_spheres; ++k) {
                 const float4 c = sphere_at_m<MOVING>(mot, k, sph[k], time);
-                exact_candidate<GATED>(A, G, c, k, o, d, a, vbest, vidx, vrank);
+                exact_candidate<GATED>(A, G, c, k, o, d, av, vbest, vidx, vrank);
                 if (VERIFY && active) {
                     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
                     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
@@ -880,15 +893,16 @@ constexpr float kCullAbs = 0.02f;
 // counts if every ancestor AABB passed aabb.rs:46-58. Ancestor boxes nest (each is the union of its
 // children, aabb.rs:61-66, and the slab arithmetic is monotone in the box), so testing the sphere's PARENT
 // box with the reference's exact arithmetic decides all of them.
-__device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, const float4 c, f3 o, f3 d, f3 rcp, float a, float &best,
+__device__ __forceinline__ void bvh_leaf(const KArgs &A, int k, const float4 c, f3 o, f3 d, f3 rcp, const DivA &av, float &best,
                                          int &idx, uint32_t &best_rank) {
+    const float a = av.a;
     const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
     const float disc = b * b - a * cc;
     if (disc > 0.0f) {
         float t = kMaxT;
-        if (sphere_roots(a, b, disc, t)) {
+        if (sphere_roots(av, b, disc, t)) {
             // BVH world: DFS-last leaf wins equal t (bvh.rs:47-53); list world: the lower list index (hitable_list.rs:48)
             const uint32_t rank = A.gate ? A.leaf_rank[k] : ~(uint32_t)k;
             if (idx < 0 || t < best || (t == best && rank > best_rank)) {
@@ -945,7 +959,7 @@ __device__ __forceinline__ void bvh_start(const KArgs &A, uint32_t *s_stack, f3 
     st.active = true;
     for (uint32_t j = 0; j < A.n_bvh_large; ++j) {
         const int k = (int)A.bvh_large[j];
-        bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, rcp, a, st.best, st.idx, st.rank);
+        bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, rcp, DivA{a, 0.0f, false}, st.best, st.idx, st.rank);
     }
     if (A.bvh_root >= 0) s_stack[(st.sp++) * kBlock + threadIdx.x] = (uint32_t)A.bvh_root;
 }
@@ -965,8 +979,8 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
                 if (COUNT) st.visits += 1u, st.leaves += (uint32_t)(n.lhs < 0) + (uint32_t)(n.rhs < 0);
                 // leaves first: they can only shrink `best` before the inner children are considered
                 // a leaf child's box slot holds the sphere itself (centre, radius): no second fetch
-                if (n.lhs < 0) bvh_leaf(A, ~n.lhs, sphere_at<MOVING>(A, ~n.lhs, make_float4(n.lmin[0], n.lmin[1], n.lmin[2], n.lmax[0]), time), o, d, rcp, a, st.best, st.idx, st.rank);
-                if (n.rhs < 0) bvh_leaf(A, ~n.rhs, sphere_at<MOVING>(A, ~n.rhs, make_float4(n.rmin[0], n.rmin[1], n.rmin[2], n.rmax[0]), time), o, d, rcp, a, st.best, st.idx, st.rank);
+                if (n.lhs < 0) bvh_leaf(A, ~n.lhs, sphere_at<MOVING>(A, ~n.lhs, make_float4(n.lmin[0], n.lmin[1], n.lmin[2], n.lmax[0]), time), o, d, rcp, DivA{a, 0.0f, false}, st.best, st.idx, st.rank);
+                if (n.rhs < 0) bvh_leaf(A, ~n.rhs, sphere_at<MOVING>(A, ~n.rhs, make_float4(n.rmin[0], n.rmin[1], n.rmin[2], n.rmax[0]), time), o, d, rcp, DivA{a, 0.0f, false}, st.best, st.idx, st.rank);
                 const float limit = (st.idx >= 0) ? (st.best * kCullRel + kCullAbs) : kMaxT;
                 float tl = 0.f, tr = 0.f;
                 bool hl = false, hr = false;
@@ -1027,7 +1041,8 @@ __device__ __forceinline__ unsigned long long key4_of(const KArgs &A, float t, i
 // then the ancestor-AABB gate of a BVH world). The slot record holds the sphere together with its gate box, rank and
 // index: the accept rule needs no dependent loads.
 template <bool MOVING>
-__device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float time, f3 o, f3 d, f3 rcp, float a, unsigned long long *key) {
+__device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float time, f3 o, f3 d, f3 rcp, const DivA &av, unsigned long long *key) {
+    const float a = av.a;
     const bool gated = A.gate != nullptr;
     const float4 *R = A.slotrec + 4 * (size_t)e;
     float4 c = R[0], g0 = make_float4(0, 0, 0, 0), g1 = g0;
@@ -1041,7 +1056,7 @@ __device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float tim
     const float disc = b * b - a * cc;
     if (disc > 0.0f) {
         float t = kMaxT;
-        if (sphere_roots(a, b, disc, t)) {
+        if (sphere_roots(av, b, disc, t)) {
             const uint32_t low = gated ? (0xffffffffu - __float_as_uint(g2.x)) : (uint32_t)k;
             const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | low;
             if (kk < *key && (!gated || gate_pass_loaded(A, g0, g1, o, rcp))) atomicMin(key, kk);   // rcp = ray.rs:14 rcp_direction of the OWNER's ray
@@ -1050,8 +1065,9 @@ __device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float tim
 }
 
 template <bool MOVING, int BLK>
-__device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, f3 o, f3 d, f3 rcp, float a,
+__device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, f3 o, f3 d, f3 rcp, const DivA &av,
                                        float time, Trav4 &st) {
+    const float a = av.a;
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t incl = wave_inclusive_sum(st.qn);
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -1060,7 +1076,7 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
         // more pairs than the wave's list holds: every lane tests its own (rare: the queues drain at > 4 entries)
         for (uint32_t j = 0; wave_any(j < st.qn); ++j)
             if (j < st.qn) {
-                pair_test4<MOVING>(A, leafq[j * BLK + tid], time, o, d, rcp, a, &w_keys[lane]);
+                pair_test4<MOVING>(A, leafq[j * BLK + tid], time, o, d, rcp, av, &w_keys[lane]);
             }
     } else {
         uint32_t pos = incl - st.qn;
@@ -1074,11 +1090,11 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
             const uint32_t slot = e & ((1u << kPairLaneShift) - 1u);
             const f3 po = mk3(lane_fetch(owner, o.x), lane_fetch(owner, o.y), lane_fetch(owner, o.z));
             const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));
-            const float pa = lane_fetch(owner, a);
+            const DivA pav{lane_fetch(owner, a), lane_fetch(owner, av.y), av.fast};
             const float ptime = MOVING ? lane_fetch(owner, time) : 0.0f;
             // (a BVH world's gate test needs 1 / d of the owner's ray: three cross-lane fetches instead of three IEEE divisions per round)
             const f3 prcp = A.gate ? mk3(lane_fetch(owner, rcp.x), lane_fetch(owner, rcp.y), lane_fetch(owner, rcp.z)) : rcp;
-            if (valid) pair_test4<MOVING>(A, slot, ptime, po, pd, prcp, pa, &w_keys[owner]);
+            if (valid) pair_test4<MOVING>(A, slot, ptime, po, pd, prcp, pav, &w_keys[owner]);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1088,14 +1104,14 @@ __device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t
 }
 
 template <bool MOVING>
-__device__ __forceinline__ void bvh4_start(const KArgs &A, unsigned long long *w_keys, f3 o, f3 d, float a, float time, Trav4 &st) {
+__device__ __forceinline__ void bvh4_start(const KArgs &A, unsigned long long *w_keys, f3 o, f3 d, const DivA &av, float time, Trav4 &st) {
     const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // ray.rs:14
     float best = kMaxT;
     int idx = -1;
     uint32_t rank = 0;
     for (uint32_t j = 0; j < A.n_bvh_large; ++j) {   // spheres kept out of the tree: tested for every ray
         const int k = (int)A.bvh_large[j];
-        bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, rcp, a, best, idx, rank);
+        bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, rcp, av, best, idx, rank);
     }
     w_keys[threadIdx.x & 63] = idx < 0 ? ~0ull : key4_of(A, best, idx);
     st.limit = trav4_limit(idx < 0 ? kMaxT : best);
@@ -1107,7 +1123,7 @@ __device__ __forceinline__ void bvh4_start(const KArgs &A, unsigned long long *w
 
 template <bool MOVING, bool COUNT, int BLK>
 __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys,
-                                         f3 o, f3 d, float a, float time, bool have, Trav4 &st, unsigned long long *sec = nullptr) {
+                                         f3 o, f3 d, const DivA &av, float time, bool have, Trav4 &st, unsigned long long *sec = nullptr) {
     const int tid = threadIdx.x;
 #ifdef PT_SECTIONS
     unsigned long long sub_last = __builtin_readcyclecounter();   // sec[5] node visits, sec[6] drains, sec[7] trips (count)
@@ -1196,7 +1212,7 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
 #ifdef PT_SECTIONS
         sec[7] += 1ull;
 #endif
-        if (stop || wave_any(st.qn > A.drain_at)) drain4<MOVING, BLK>(A, leafq, w_pairs, w_keys, o, d, rcp, a, time, st);
+        if (stop || wave_any(st.qn > A.drain_at)) drain4<MOVING, BLK>(A, leafq, w_pairs, w_keys, o, d, rcp, av, time, st);
         PT_SUB4(6);
         if (stop) break;
     }
@@ -1553,14 +1569,17 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         const f3 ro = have ? o : mk3(0.f, 0.f, 0.f);
         const f3 rd = have ? d : mk3(0.f, 0.f, 0.f);
         const float a = dot3(rd, rd);  // sphere.rs:34
+        // its reciprocal, once per ray, for the quotients of the exact sphere tests (pt_device.h DivA; the exact-scan and binary-tree kernels divide in full)
+        const bool short_div = (MFMA && !BVH) || TREE4;
+        const DivA av{a, short_div ? recip_unit_range(a) : 0.0f, short_div && wave_ballot(have && !in_unit_range(a)) == 0ull};
         float t_hit;
         int idx;
         if (TREE4) {
             if (have && trav_new) {
-                bvh4_start<MOVING>(A, w_keys, o, d, dot3(d, d), rtime, trav4);
+                bvh4_start<MOVING>(A, w_keys, o, d, av, rtime, trav4);
                 trav_new = false;
             }
-            bvh4_run<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint16_t *>(s_bvh), reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, ro, rd, a, rtime, have, trav4
+            bvh4_run<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint16_t *>(s_bvh), reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, ro, rd, av, rtime, have, trav4
 #ifdef PT_SECTIONS
                                           , sec_t
 #endif
@@ -1587,7 +1606,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             t_hit = trav.best;
         } else if (MFMA)
             idx = intersect_list_mfma<VERIFY, MOVING, GATE, BLK>(A, (PAL && GATE) ? GateSrc{s_gate, s_rank} : GateSrc{A.gate, A.leaf_rank}, mot, s_par, SPH_LDS ? (const float4 *)s_sph : A.spheres_r2, s_afrag, s_tile_sphere, s_cull,
-                                                      s_queue, w_pairs, w_keys, ro, rd, a, have, rtime, t_hit
+                                                      s_queue, w_pairs, w_keys, ro, rd, av, have, rtime, t_hit
 #ifdef PT_SECTIONS
                                                       , sec_t
 #elif defined(PT_WAVEDBG)
