@@ -107,6 +107,7 @@ struct KArgs {
     const uint4 *afrag;          // [n_tiles][2 chunks][64 lanes] x 8 f16: sphere-feature A fragments
     const uint16_t *tile_sphere; // [n_tiles*32] sphere index behind each bit of a tile mask (tile_bit_of_row), 0xffff = padding row
     const uint32_t *large;       // spheres outside the prefilter's range: tested exactly for every ray
+    uint32_t large0;             // large[0] (0xffffffff: there is none): the first of them is tested without a load of the list or a branch
     uint32_t n_tiles, n_large;
     float c0[3];                 // feature-space origin (f32-exact), radius bound of the prefiltered set
     float rs2;                   // Rs^2, Rs >= max(|c - c0| + |r|) over prefiltered spheres

@@ -101,7 +101,7 @@ struct pt_scene {
     uint4 *d_afrag = nullptr;
     uint16_t *d_tile_sphere = nullptr;
     uint32_t *d_large = nullptr;
-    uint32_t n_large = 0;
+    uint32_t n_large = 0, large0 = 0xffffffffu;
     float c0[3] = {0, 0, 0};
     float rs2 = 0.f, m0 = 0.f, gamma = 0.f;
     uint32_t *d_cull_tab = nullptr;                  // tile-culling tables (cull_axis == 3: off)

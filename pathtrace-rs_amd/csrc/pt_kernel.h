@@ -222,6 +222,31 @@ __device__ __forceinline__ bool sphere_roots(const DivA &av, float b, float disc
 }
 __device__ __forceinline__ bool sphere_roots(float a, float b, float disc, float &closest) { return sphere_roots(DivA{a, 0.0f, false}, b, disc, closest); }
 
+// sphere.rs:38-64 for t_max = f32::MAX WITHOUT a branch: the root the reference accepts, or kMaxT when there is none (`tested`
+// false, discriminant <= 0 or NaN, both roots outside (t_min, f32::MAX)). Both quotients are always formed -- the second one is
+// needed whenever a ray starts on the sphere it tests, i.e. in nearly every wave -- so that the square root's refinement and the two
+// divisions are ONE basic block of independent chains; the inputs the short forms do not cover (pt_device.h: a discriminant below
+// 2^-96, a divisor outside [0.5, 2]) are recomputed in full behind one wave-uniform test. Same arithmetic, same result as
+// sphere_roots with closest = kMaxT.
+__device__ __forceinline__ float sphere_hit_t(const DivA &av, float b, float disc, bool tested) {
+    float sq = __builtin_amdgcn_sqrtf(disc);   // sqrt_exact's common path
+    {
+        const float sm = __uint_as_float(__float_as_uint(sq) - 1u), sp = __uint_as_float(__float_as_uint(sq) + 1u);
+        const float rm = __builtin_fmaf(-sm, sq, disc), rp = __builtin_fmaf(-sp, sq, disc);
+        sq = (0.0f >= rm) ? sm : sq;
+        sq = (0.0f < rp) ? sp : sq;
+    }
+    float t1 = div_by_unit_range(-b - sq, av.a, av.y), t2 = div_by_unit_range(-b + sq, av.a, av.y);
+    const bool ok = tested && disc > 0.0f;
+    if (__builtin_expect(!av.fast || wave_any(ok && disc < 0x1p-96f), 0)) {
+        const float s2 = __builtin_sqrtf(disc);
+        t1 = (-b - s2) / av.a, t2 = (-b + s2) / av.a;
+    }
+    const bool h1 = ok && t1 < kMaxT && t1 > kMinT;          // sphere.rs:40-49
+    const bool h2 = ok && !h1 && t2 < kMaxT && t2 > kMinT;   // sphere.rs:51-60
+    return h1 ? t1 : (h2 ? t2 : kMaxT);
+}
+
 // hitable_list.rs:40-56 over sphere.rs:29-66, restructured for the GPU in two phases that
 // together perform exactly the reference's sequence of accepted hits:
 //
@@ -568,14 +593,20 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 // (P[13] = 2 kappa, kappa (2 Rs^2 + r_max^2) + r_min^2, r_min; kappa = 5.2e-6, the same 4x safety as the tree kernels' box
 // pad). A bounce off a huge enclosing or ground sphere far from the cloud thus widens its own mask -- up to every tile --
 // whatever the camera's position.
-__device__ __forceinline__ uint32_t lane_tile_mask(const float4 *P, const uint32_t *s_cull, f3 o, f3 d, bool active, float t_end,
-                                                   uint32_t cull_axis, uint32_t cull_always) {
+// (in two parts: the ray against the padded box depends on nothing but the ray, and is computed next to the ray's features and the
+//  first always-tested sphere -- three independent chains in one basic block; only the few instructions of the second part wait
+//  for t_end, the nearest hit on the always-tested spheres)
+struct TileClip {
+    float t0, t1, reach;
+    bool inside;
+};
+__device__ __forceinline__ TileClip lane_tile_clip(const float4 *P, f3 o, f3 d, bool active) {
     const float4 bmin = P[0], bmax = P[1];   // clip_min.xyz, cull_u0 | clip_max.xyz, cull_inv_cell
     const float4 pc = P[2], pr = P[13];      // c0.xyz | reach constants
     const float otx = o.x - pc.x, oty = o.y - pc.y, otz = o.z - pc.z;
     const float ot2 = __builtin_fmaf(otz, otz, __builtin_fmaf(oty, oty, otx * otx));
     const float reach = __builtin_amdgcn_sqrtf(__builtin_fmaf(pr.x, ot2, pr.y)) * 1.000001f - pr.z;
-    float t0 = 0.0f, t1 = t_end * 1.00001f + 1.0e-5f;
+    float t0 = 0.0f, t1 = kMaxT;
     bool inside = active;
     const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
     const float mn[3] = {bmin.x - reach, bmin.y - reach, bmin.z - reach}, mx[3] = {bmax.x + reach, bmax.y + reach, bmax.z + reach};
@@ -588,16 +619,26 @@ __device__ __forceinline__ uint32_t lane_tile_mask(const float4 *P, const uint32
         t1 = __builtin_fminf(t1, flat ? kMaxT : __builtin_fmaxf(ta, tb));
         inside = inside && (!flat || (oo[k] >= mn[k] && oo[k] <= mx[k]));
     }
+    return TileClip{t0, t1, reach, inside};
+}
+__device__ __forceinline__ uint32_t lane_tile_mask_of(const float4 *P, const uint32_t *s_cull, const TileClip &c, f3 o, f3 d, float t_end, uint32_t cull_axis,
+                                                      uint32_t cull_always) {
+    const float4 bmin = P[0], bmax = P[1];
+    float t0 = c.t0, t1 = __builtin_fminf(c.t1, t_end * 1.00001f + 1.0e-5f);
     const float slack = 1.0e-3f * (1.0f + t1);     // relative to the distance travelled: covers rcp and f32 rounding
     t0 = t0 - slack, t1 = t1 + slack;
-    const float ou = cull_axis == 0u ? oo[0] : (cull_axis == 1u ? oo[1] : oo[2]), du = cull_axis == 0u ? dd[0] : (cull_axis == 1u ? dd[1] : dd[2]);
+    const float ou = cull_axis == 0u ? o.x : (cull_axis == 1u ? o.y : o.z), du = cull_axis == 0u ? d.x : (cull_axis == 1u ? d.y : d.z);
     const float ua = ou + t0 * du, ub = ou + t1 * du;
-    const float pad = 1.0e-3f + reach;
+    const float pad = 1.0e-3f + c.reach;
     const float lo = __builtin_fminf(ua, ub) - pad, hi = __builtin_fmaxf(ua, ub) + pad;
     const float cl = __builtin_fminf(__builtin_fmaxf((lo - bmin.w) * bmax.w, 0.0f), (float)(kCullCells - 1));
     const float ch = __builtin_fminf(__builtin_fmaxf((hi - bmin.w) * bmax.w, 0.0f), (float)(kCullCells - 1));
     const uint32_t tiles = s_cull[(int)cl] & s_cull[kCullCells + (int)ch];
-    return ((inside && t0 <= t1 && lo <= hi) ? tiles : 0u) | cull_always;
+    return ((c.inside && t0 <= t1 && lo <= hi) ? tiles : 0u) | cull_always;
+}
+__device__ __forceinline__ uint32_t lane_tile_mask(const float4 *P, const uint32_t *s_cull, f3 o, f3 d, bool active, float t_end,
+                                                   uint32_t cull_axis, uint32_t cull_always) {
+    return lane_tile_mask_of(P, s_cull, lane_tile_clip(P, o, d, active), o, d, t_end, cull_axis, cull_always);
 }
 
 template <bool VERIFY, bool MOVING, bool GATED, int BLK>
@@ -712,6 +753,14 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                     const float b = (ocx * pd.x + ocy * pd.y) + ocz * pd.z;
                     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
                     const float disc = b * b - pa * cc;
+#ifndef PT_NO_HEAD_ILP
+                    const float t = sphere_hit_t(pav, b, disc, true);
+                    if (t < kMaxT) {
+                        const uint32_t rank = GATED ? G.rank[k] : 0u;
+                        if (!GATED || gate_pass_from(A, G, k, po, prcp))   // ray.rs:14 rcp_direction
+                            atomicMin(&w_keys[owner], key_of(t, k, rank));
+                    }
+#else
                     if (disc > 0.0f) {
                         float t = kMaxT;
                         if (sphere_roots(pav, b, disc, t)) {
@@ -720,6 +769,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                                 atomicMin(&w_keys[owner], key_of(t, k, rank));
                         }
                     }
+#endif
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -736,17 +786,46 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
         cnt = 0;
     };
     // the always-tested spheres first (wave-uniform): their nearest hit bounds the segment the tiles are culled against
-    for (uint32_t j = 0; j < A.n_large; ++j) {
+    const float4 pcull = P[12];
+    const uint32_t cull_axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(pcull.x)), cull_always = __float_as_uint(pcull.y);
+    const bool culling = !VERIFY && cull_axis < 3u;
+    uint32_t j_first = 0;
+    TileClip clip{0.0f, 0.0f, 0.0f, false};
+#ifndef PT_NO_HEAD_ILP
+    if (!GATED) {
+        // List worlds: the FIRST always-tested sphere (the ground of most scenes) without a branch, so that its chain -- load,
+        // discriminant, square root, two quotients -- shares one basic block with the ray's features above and the box clip of the
+        // tile culling: three independent chains for the scheduler instead of one after the other (this stretch was 16 % of the
+        // wave-cycles for 10 % of the instructions). The arithmetic is sphere.rs:33-64 as everywhere else; the rare inputs the
+        // short square root / quotients do not cover are recomputed in full behind ONE wave-uniform test at the end.
+        if (culling) clip = lane_tile_clip(P, o, d, active);
+        const bool has0 = A.large0 != 0xffffffffu;
+        const int k0 = has0 ? (int)A.large0 : 0;
+        const float4 c = sphere_at_m<MOVING>(mot, k0, sph[k0], time);
+        const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
+        const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+        const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
+        const float disc = b * b - a * cc;
+        const float t = sphere_hit_t(av, b, disc, has0 && active);
+        best = t;
+        idx = t < kMaxT ? k0 : -1;
+        j_first = 1;
+    }
+#endif
+    for (uint32_t j = j_first; j < A.n_large; ++j) {
         const int k = (int)A.large[j];
         if (active) exact_candidate<GATED>(A, G, sphere_at_m<MOVING>(mot, k, sph[k], time), k, o, d, av, best, idx, best_rank);
     }
     // wave-uniform set of tiles to run: the union of the lanes' tile masks (verify mode audits every tile)
     uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
     uint32_t mine = rem;   // tiles THIS lane's ray can find its winner in; the wave runs the union
-    const float4 pcull = P[12];
-    const uint32_t cull_axis = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(pcull.x)), cull_always = __float_as_uint(pcull.y);
-    if (!VERIFY && cull_axis < 3u) {
-        mine = lane_tile_mask(P, s_cull, o, d, active, best, cull_axis, cull_always);
+    if (culling) {
+#ifndef PT_NO_HEAD_ILP
+        if (GATED) clip = lane_tile_clip(P, o, d, active);
+#else
+        clip = lane_tile_clip(P, o, d, active);
+#endif
+        mine = lane_tile_mask_of(P, s_cull, clip, o, d, best, cull_axis, cull_always);
         rem = wave_or(mine);
 #ifdef PT_CULLSTATS
         // development aid: debug[24] wave-iterations, [25] tiles run, [26] active lanes, [27] tiles the lanes asked for,
@@ -1054,6 +1133,14 @@ __device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float tim
     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
     const float disc = b * b - a * cc;
+#ifndef PT_NO_HEAD_ILP
+    const float t = sphere_hit_t(av, b, disc, true);
+    if (t < kMaxT) {
+        const uint32_t low = gated ? (0xffffffffu - __float_as_uint(g2.x)) : (uint32_t)k;
+        const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | low;
+        if (kk < *key && (!gated || gate_pass_loaded(A, g0, g1, o, rcp))) atomicMin(key, kk);   // rcp = ray.rs:14 rcp_direction of the OWNER's ray
+    }
+#else
     if (disc > 0.0f) {
         float t = kMaxT;
         if (sphere_roots(av, b, disc, t)) {
@@ -1062,6 +1149,7 @@ __device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float tim
             if (kk < *key && (!gated || gate_pass_loaded(A, g0, g1, o, rcp))) atomicMin(key, kk);   // rcp = ray.rs:14 rcp_direction of the OWNER's ray
         }
     }
+#endif
 }
 
 template <bool MOVING, int BLK>

@@ -340,6 +340,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.large = s->d_large;
     A.n_tiles = c.n_tiles;
     A.n_large = s->n_large;
+    A.large0 = s->large0;
     memcpy(A.c0, s->c0, sizeof A.c0);
     A.rs2 = s->rs2;
     A.m0 = s->m0;

@@ -102,6 +102,7 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
             memcpy(s->clip_min, prep.clip_min, 12), memcpy(s->clip_max, prep.clip_max, 12);
         }
         s->n_large = (uint32_t)prep.large.size();
+        s->large0 = prep.large.empty() ? 0xffffffffu : prep.large[0];
         memcpy(s->c0, prep.c0, sizeof s->c0);
         s->rs2 = (float)(prep.rs * prep.rs * 1.0001);
         // margin = a * (m0 + gamma * (|o - c0|^2 + Rs^2)); see DESIGN.md for the derivation. A swept bound of half-length h moves
