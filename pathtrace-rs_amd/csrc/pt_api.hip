@@ -30,6 +30,7 @@ const DevKnobs &dev_knobs() {
         if (const char *e = getenv("PTGPU_DRAIN")) d.drain = atoi(e);
         if (const char *e = getenv("PTGPU_PHASE1_REFILL")) d.phase1_refill = std::max(1, atoi(e));
         if (const char *e = getenv("PTGPU_CULL_AXIS")) d.cull_axis = atoi(e);
+        if (const char *e = getenv("PTGPU_CULL_STRIPS")) d.cull_strips = atoi(e);
         if (const char *e = getenv("PTGPU_HOST_THREADS")) d.host_threads = std::max(0, atoi(e));
         if (const char *e = getenv("PTGPU_BLOCKS_PER_CU")) d.blocks_per_cu = (uint32_t)atoi(e);
         if (const char *e = getenv("PTGPU_VARIANT")) d.variant = (uint32_t)atoi(e);

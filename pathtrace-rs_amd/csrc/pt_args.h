@@ -67,14 +67,15 @@ struct DCamera {  // camera.rs:8-19
 //   [0] clip_min.xyz, cull_u0   [1] clip_max.xyz, cull_inv_cell   [2] c0.xyz, rs2   [3] m0, gamma, inv_nx, inv_ny
 //   [4..9] DCamera (24 floats, camera.rs:8-19 order)   [10] inv_ns, mix_prev, mix_new, prev_zero (0 / 1)   [11] sky.xyz, has_sky
 //   [12] as u32 bits: cull_axis, cull_always, max_depth, samples   [13] tile culling's per-ray reach: 2 kappa, kappa (2 Rs^2 + r_max^2) + r_min^2, r_min, -
-constexpr uint32_t kLdsParamBytes = 14u * 16u;
+//   [14] tile culling's second axis: cull_u0_2, cull_inv_cell_2, cull_axis2 (u32 bits), -
+constexpr uint32_t kLdsParamBytes = 15u * 16u;
 
 // Bit of a ray's 32-bit tile mask (pt_kernel.h, intersect_list_mfma) that fragment row `row` of a tile ends up in. A lane of
 // v_mfma_f32_32x32x16_f16 holds rows (r & 3) + 8 (r >> 2) + 4 * (lane >> 5) in accumulator registers r = 0..15; the kernel shifts
 // the signs in so that register r lands at bit 15 - r, the low half of the wave supplying bits 0..15 and the high half 16..31.
 // tile_sphere is stored in this BIT order, so a candidate bit indexes it directly.
 constexpr uint32_t tile_bit_of_row(uint32_t row) { return (15u - ((row & 3u) | ((row >> 3) << 2))) + 16u * ((row >> 2) & 1u); }
-constexpr int kCullCells = 256;   // resolution of the tile-culling lookup along the sort axis
+constexpr int kCullCells = 128;   // resolution of the tile-culling lookups along each of the two axes (two pairs of tables: 2 KB of LDS)
 
 struct KArgs {
     // scene (HBM resident)
@@ -114,10 +115,13 @@ struct KArgs {
     float m0, gamma;             // margin = a * (m0 + gamma * (|o - c0|^2 + Rs^2))
     // tile culling (DESIGN.md "tile culling"): tiles hold spheres sorted along cull_axis; a wave runs only the tiles
     // some lane's ray segment (origin .. nearest exact hit so far, clipped to the sorted spheres' box) can overlap
-    const uint32_t *cull_tab;    // [kCullCells] tiles reaching up to cell c or beyond | [kCullCells] tiles starting at cell c or before
+    const uint32_t *cull_tab;    // per axis: [kCullCells] tiles reaching up to cell c or beyond | [kCullCells] tiles starting at cell c or before
+                                 // (first the sort axis, then the second axis: 4 x kCullCells words)
     uint32_t cull_axis;          // 0..2; 3 = culling off
     uint32_t cull_always;        // tiles that are always run (they hold spheres outside the sorted set)
     float cull_u0, cull_inv_cell;
+    uint32_t cull_axis2;         // the axis the strips of the sort axis are sorted along (tiles are boxes in two axes); tables of all ones when unused
+    float cull_u0_2, cull_inv_cell_2;
     float clip_min[3], clip_max[3];  // box of the sorted spheres, padded by 2e-3 + 1e-5 |.| (lane_tile_mask adds each ray's own reach)
     float cull_reach[3];             // 2 kappa, kappa (2 Rs^2 + r_max^2) + r_min^2, r_min (lane_tile_mask)
     uint32_t verify;             // debug: count exact-positive pairs the prefilter did not flag

@@ -41,7 +41,7 @@ const char *last_error_message();
 // Development knobs (environment), read ONCE per process and only in builds made with -DPT_DEVKNOBS (the shipped library
 // has none: every knob below then keeps its default).
 struct DevKnobs {
-    int refill = -1, ready = -1, drain = -1, phase1_refill = -1, cull_axis = -1;
+    int refill = -1, ready = -1, drain = -1, phase1_refill = -1, cull_axis = -1, cull_strips = -1;
     bool world_occ3 = false, debug = false, clamp_grid = false, timing = false;
     int host_threads = -1;
     uint32_t variant = 0, blocks_per_cu = 0;
@@ -105,7 +105,8 @@ struct pt_scene {
     float c0[3] = {0, 0, 0};
     float rs2 = 0.f, m0 = 0.f, gamma = 0.f;
     uint32_t *d_cull_tab = nullptr;                  // tile-culling tables (cull_axis == 3: off)
-    uint32_t cull_axis = 3, cull_always = 0;
+    uint32_t cull_axis = 3, cull_always = 0, cull_axis2 = 0;
+    float cull_u0_2 = 0.f, cull_inv_cell_2 = 0.f;
     float cull_u0 = 0.f, cull_inv_cell = 0.f, cull_rmin = 0.f, cull_rmax = 0.f, rs_small = 0.f, clip_min[3] = {0, 0, 0}, clip_max[3] = {0, 0, 0};
     float4 *d_motion = nullptr;                      // MovingSphere records of a Sphere + MovingSphere world
     // device memory: general worlds (also the fallback data of a Sphere + MovingSphere world)
@@ -172,8 +173,9 @@ struct MfmaPrep {
     double sweep_ratio = 0.0;  // max over prefiltered spheres of (swept half-length / |radius|)
     uint32_t n_tiles = 0;
     // tile culling: sort axis (3 = off), tiles that are always run, lookup tables (kCullCells cells), padded box of the sorted spheres
-    uint32_t cull_axis = 3, cull_always = 0;
+    uint32_t cull_axis = 3, cull_always = 0, cull_axis2 = 0, cull_strips = 1;
     std::vector<uint32_t> cull_tab;
+    float cull_u0_2 = 0.f, cull_inv_cell_2 = 0.f;
     float cull_u0 = 0.f, cull_inv_cell = 0.f, cull_rmin = 0.f, cull_rmax = 0.f, clip_min[3] = {0, 0, 0}, clip_max[3] = {0, 0, 0};
 };
 bool prepare_mfma(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi, MfmaPrep &out);

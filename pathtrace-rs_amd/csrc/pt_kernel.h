@@ -633,8 +633,16 @@ __device__ __forceinline__ uint32_t lane_tile_mask_of(const float4 *P, const uin
     const float lo = __builtin_fminf(ua, ub) - pad, hi = __builtin_fmaxf(ua, ub) + pad;
     const float cl = __builtin_fminf(__builtin_fmaxf((lo - bmin.w) * bmax.w, 0.0f), (float)(kCullCells - 1));
     const float ch = __builtin_fminf(__builtin_fmaxf((hi - bmin.w) * bmax.w, 0.0f), (float)(kCullCells - 1));
-    const uint32_t tiles = s_cull[(int)cl] & s_cull[kCullCells + (int)ch];
-    return ((c.inside && t0 <= t1 && lo <= hi) ? tiles : 0u) | cull_always;
+    // the same along the second axis of the tiles' boxes (tables of all ones when the scene has a single strip)
+    const float4 p2 = P[14];   // cull_u0_2, cull_inv_cell_2, cull_axis2
+    const uint32_t axis2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p2.z));
+    const float ov = axis2 == 0u ? o.x : (axis2 == 1u ? o.y : o.z), dv = axis2 == 0u ? d.x : (axis2 == 1u ? d.y : d.z);
+    const float va = ov + t0 * dv, vb = ov + t1 * dv;
+    const float lo2 = __builtin_fminf(va, vb) - pad, hi2 = __builtin_fmaxf(va, vb) + pad;
+    const float cl2 = __builtin_fminf(__builtin_fmaxf((lo2 - p2.x) * p2.y, 0.0f), (float)(kCullCells - 1));
+    const float ch2 = __builtin_fminf(__builtin_fmaxf((hi2 - p2.x) * p2.y, 0.0f), (float)(kCullCells - 1));
+    const uint32_t tiles = (s_cull[(int)cl] & s_cull[kCullCells + (int)ch]) & (s_cull[2 * kCullCells + (int)cl2] & s_cull[3 * kCullCells + (int)ch2]);
+    return ((c.inside && t0 <= t1 && lo <= hi && lo2 <= hi2) ? tiles : 0u) | cull_always;
 }
 __device__ __forceinline__ uint32_t lane_tile_mask(const float4 *P, const uint32_t *s_cull, f3 o, f3 d, bool active, float t_end,
                                                    uint32_t cull_axis, uint32_t cull_always) {
@@ -1362,8 +1370,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     p += MFMA ? A.n_tiles * 2048u : 0u;
     uint16_t *s_tile_sphere = reinterpret_cast<uint16_t *>(p);
     p += MFMA ? ((A.n_tiles * 64u + 15u) & ~15u) : 0u;
-    uint32_t *s_cull = reinterpret_cast<uint32_t *>(p);   // MFMA: tile-culling tables, 2 x kCullCells words
-    p += MFMA ? 8u * kCullCells : 0u;
+    uint32_t *s_cull = reinterpret_cast<uint32_t *>(p);   // MFMA: tile-culling tables, 2 axes x 2 x kCullCells words
+    p += MFMA ? 16u * kCullCells : 0u;
 
     const float4 *s_par = reinterpret_cast<const float4 *>(p);   // frame parameters (kLdsParamBytes)
     p += kLdsParamBytes;
@@ -1390,7 +1398,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         for (uint32_t k = tid; k < A.n_tiles * 128u; k += BLK) s_afrag[k] = A.afrag[k];
         for (uint32_t k = tid; k < A.n_tiles * 32u; k += BLK) s_tile_sphere[k] = A.tile_sphere[k];
         if (A.cull_axis < 3u)
-            for (uint32_t k = tid; k < 2u * kCullCells; k += BLK) s_cull[k] = A.cull_tab[k];
+            for (uint32_t k = tid; k < 4u * kCullCells; k += BLK) s_cull[k] = A.cull_tab[k];
     }
     if (PAL) {
         for (uint32_t k = tid; k < A.n_spheres * 4u; k += BLK) s_shade[k] = A.shade[k];
@@ -1423,6 +1431,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         w[11] = make_float4(A.sky.x, A.sky.y, A.sky.z, A.has_sky ? 1.0f : 0.0f);
         w[12] = make_float4(__uint_as_float(A.cull_axis), __uint_as_float(A.cull_always), __uint_as_float(A.max_depth), __uint_as_float(A.samples));
         w[13] = make_float4(A.cull_reach[0], A.cull_reach[1], A.cull_reach[2], 0.0f);
+        w[14] = make_float4(A.cull_u0_2, A.cull_inv_cell_2, __uint_as_float(A.cull_axis2), 0.0f);
     }
     if (A.has_noise) {
         for (int k = tid; k < 256; k += BLK) s_pvec[k] = A.perlin_vec[k];

@@ -326,6 +326,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.cull_axis = c.cull_off ? 3u : s->cull_axis;
     A.cull_always = s->cull_always;
     A.cull_u0 = s->cull_u0, A.cull_inv_cell = s->cull_inv_cell;
+    A.cull_axis2 = s->cull_axis2, A.cull_u0_2 = s->cull_u0_2, A.cull_inv_cell_2 = s->cull_inv_cell_2;
     memcpy(A.clip_min, s->clip_min, 12), memcpy(A.clip_max, s->clip_max, 12);
     if (A.cull_axis < 3u) {
         // Per-RAY reach of the reference's f32 discriminant error (pt_kernel.h lane_tile_mask): the kernel pads the clip box and

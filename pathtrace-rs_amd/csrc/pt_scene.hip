@@ -98,6 +98,7 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
             if ((rc = upload(&s->d_cull_tab, prep.cull_tab.data(), prep.cull_tab.size()))) return bail(rc);
             s->cull_axis = prep.cull_axis, s->cull_always = prep.cull_always;
             s->cull_u0 = prep.cull_u0, s->cull_inv_cell = prep.cull_inv_cell;
+            s->cull_axis2 = prep.cull_axis2, s->cull_u0_2 = prep.cull_u0_2, s->cull_inv_cell_2 = prep.cull_inv_cell_2;
             s->cull_rmin = prep.cull_rmin, s->cull_rmax = prep.cull_rmax, s->rs_small = (float)prep.rs;
             memcpy(s->clip_min, prep.clip_min, 12), memcpy(s->clip_max, prep.clip_max, 12);
         }

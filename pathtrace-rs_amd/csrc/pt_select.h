@@ -196,7 +196,7 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
                (ref_bvh ? (uint64_t)t.n_spheres * 32ull + (((uint64_t)t.n_spheres * 4ull + 15ull) & ~15ull) : 0ull) +
                (moving ? (uint64_t)t.n_spheres * 32ull : 0ull);
     };
-    const uint32_t mfma_tables = t.n_tiles * 2048u + ((t.n_tiles * 64u + 15u) & ~15u) + 8u * (uint32_t)kCullCells;
+    const uint32_t mfma_tables = t.n_tiles * 2048u + ((t.n_tiles * 64u + 15u) & ~15u) + 16u * (uint32_t)kCullCells;
     if (mfma && t.palette_ok && (v & kVarStackInHbm) == 0 && !c.verify && k.blocks_per_cu == 0) {
         const auto wide_lds = [&](uint32_t b) { return (uint64_t)lds + mfma_queue_bytes(b) + mfma_tables + wide_extra(b); };
         if (wide_lds(1024u) <= kLdsBudget) blk = 1024u;

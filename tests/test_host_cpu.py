@@ -327,26 +327,26 @@ def _select(ptgpu, pthost, preset, W, H, S, bvh, depth=10, variant=0, shards=1, 
 
 # preset, use_bvh -> (kernel, dynamic LDS bytes per workgroup, workgroups per CU, attenuation-stack slots in LDS) at 1200x800, 64 spp, depth 10
 SELECTION_TABLE = {
-    ("small", False): ("scan-lds<blk=256>", 38752, 3, 27),                      # 5 spheres: too few for the prefilter
-    ("small", True): ("tree4<blk=256>", 24288, 4, 9),
-    ("aras", False): ("mfma<blk=1024>", 65568, 1, 0),                           # BASELINE config 2
-    ("aras", True): ("mfma<blk=1024,gate>", 67232, 1, 0),
-    ("random_spheres", False): ("mfma<blk=1024>", 130464, 1, 0),                # BASELINE config 3 / 4: the headline kernel
-    ("random_spheres", True): ("mfma<blk=1024,gate>", 148032, 1, 0),
-    ("perlin_spheres", False): ("tree4<blk=256>", 38368, 4, 9),                 # BASELINE config 5 as a list world: walks the tree
-    ("perlin_spheres", True): ("tree4<blk=256>", 38368, 4, 9),                  # BASELINE config 5
-    ("two_perlin_spheres", False): ("scan-lds<blk=256>", 43616, 3, 27),
-    ("two_perlin_spheres", True): ("tree4<blk=256>", 29152, 4, 9),
-    ("random", False): ("mfma<blk=1024,moving>", 146080, 1, 0),                 # Sphere + MovingSphere world on the fast kernels
-    ("random", True): ("mfma<blk=1024,moving,gate>", 163648, 1, 0),
+    ("small", False): ("scan-lds<blk=256>", 38768, 3, 27),                      # 5 spheres: too few for the prefilter
+    ("small", True): ("tree4<blk=256>", 24304, 4, 9),
+    ("aras", False): ("mfma<blk=1024>", 65584, 1, 0),                           # BASELINE config 2
+    ("aras", True): ("mfma<blk=1024,gate>", 67248, 1, 0),
+    ("random_spheres", False): ("mfma<blk=1024>", 130480, 1, 0),                # BASELINE config 3 / 4: the headline kernel
+    ("random_spheres", True): ("mfma<blk=1024,gate>", 148048, 1, 0),
+    ("perlin_spheres", False): ("tree4<blk=256>", 38384, 4, 9),                 # BASELINE config 5 as a list world: walks the tree
+    ("perlin_spheres", True): ("tree4<blk=256>", 38384, 4, 9),                  # BASELINE config 5
+    ("two_perlin_spheres", False): ("scan-lds<blk=256>", 43632, 3, 27),
+    ("two_perlin_spheres", True): ("tree4<blk=256>", 29168, 4, 9),
+    ("random", False): ("mfma<blk=1024,moving>", 146096, 1, 0),                 # Sphere + MovingSphere world on the fast kernels
+    ("random", True): ("mfma<blk=1024,moving,gate>", 163664, 1, 0),
     ("simple_light", False): ("world<bvh=0,hit_lds=1,occ=3,media=0>", 44032, 3, 1),   # noise texture: the 3-wave build with (u, v)
     ("simple_light", True): ("world<bvh=1,hit_lds=1,occ=3,media=0>", 48128, 3, 1),
     ("cornell", False): ("world<bvh=0,hit_lds=1,occ=4,media=0>", 39616, 4, 1),
     ("cornell", True): ("world<bvh=1,hit_lds=1,occ=3,media=0>", 44736, 3, 1),    # four workgroups no longer fit the LDS with the BVH stack
     ("cornell_smoke", False): ("world<bvh=0,hit_lds=1,occ=4,media=1>", 39616, 4, 1),
     ("cornell_smoke", True): ("world<bvh=1,hit_lds=1,occ=3,media=1>", 44736, 3, 1),
-    ("smallpt", False): ("scan-lds<blk=256>", 38752, 3, 27),                     # r = 1000 walls: nothing the f16 features can hold
-    ("smallpt", True): ("tree4<blk=256>", 25824, 4, 9),
+    ("smallpt", False): ("scan-lds<blk=256>", 38768, 3, 27),                     # r = 1000 walls: nothing the f16 features can hold
+    ("smallpt", True): ("tree4<blk=256>", 25840, 4, 9),
     ("final", False): ("world<bvh=0,hit_lds=1,occ=4,media=0>", 38912, 4, 1),     # presets.rs:40-71 returns an empty list
 }
 
