@@ -138,7 +138,7 @@ int ensure_gstack(pt_scene *s, size_t need_floats) {
 // on any of this, never its value. `A` is the frame kernel's argument block (updated in place), `measure` launches phase 1.
 template <typename Args, typename LaunchMeasure>
 int order_work(pt_scene *s, Args &A, const pt_params *params, const pt_camera *cam, uint32_t shard_index, uint32_t shard_count, hipStream_t stream,
-               LaunchMeasure measure) {
+               uint32_t measure_refill, LaunchMeasure measure) {
     const uint32_t n_work_tiles = A.n_items / kTilePix;
     if (int rc = ensure_tile_buf(s, n_work_tiles)) return rc;
     uint32_t *cost = s->d_tile_buf + 8, *order = cost + s->d_tile_cap, *measured = order + s->d_tile_cap;
@@ -154,8 +154,8 @@ int order_work(pt_scene *s, Args &A, const pt_params *params, const pt_camera *c
         HIP_TRY(hipMemsetAsync(cost, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
         Args A1 = A;
         A1.samples = 1, A1.phase = 1, A1.px_state = s->d_px_state, A1.tile_cost = cost;
-        // one sample per pixel: refills dominate, batch them hard (a plain 1-spp frame: 0.48 ms at 8, 0.34 at 32; frame: best at 48)
-        A1.refill_min = dev_knobs().phase1_refill > 0 ? (uint32_t)dev_knobs().phase1_refill : 48u;
+        // one sample per pixel: refills dominate, batch them hard (`measure_refill` lanes must be waiting: the caller's choice)
+        A1.refill_min = dev_knobs().phase1_refill > 0 ? (uint32_t)dev_knobs().phase1_refill : measure_refill;
         measure(A1);
         launch_tile_order(n_work_tiles, cost, params->max_depth + 1u, order, stream);
         A.samples = params->samples - 1u, A.phase = 2, A.px_state = s->d_px_state;
@@ -211,7 +211,7 @@ int launch_world(pt_scene *s, const ptsel::KernelChoice &c, const pt_params *par
     if (int rc = raise_lds_limit(s->device, reinterpret_cast<const void *>(wk), c.lds_bytes)) return rc;
     HIP_TRY(hipEventRecord(s->ev_pass, stream));
     if (c.order == ptsel::Order::Measured)
-        if (int rc = order_work(s, W, params, cam, shard_index, shard_count, stream,
+        if (int rc = order_work(s, W, params, cam, shard_index, shard_count, stream, 48u,
                                 [&](const WArgs &W1) { hipLaunchKernelGGL(wk, dim3(grid), dim3(c.block), c.lds_bytes, stream, W1); }))
             return rc;
     if (before_frame) {
@@ -386,7 +386,11 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.wave_end = s->d_wave_end;
     if (s->d_wave_end) (void)hipMemsetAsync(s->d_wave_end, 0, 65536 * 8, stream);
     if (c.order == ptsel::Order::Measured && measure_kern) {
-        if (int rc = order_work(s, A, params, cam, shard_index, shard_count, stream, [&](KArgs A1) {
+        // The measuring launch of the prefilter kernels refills ALL lanes of a wave at once: the wave then always holds one whole
+        // 8x8 tile, and the rays of one sample differ little in length (measuring launch + order kernel on config 3: 0.44 ms at 16
+        // waiting lanes, 0.35 at 48, 0.31 at 60, 0.28 at 64; tools/sweep_phase1.sh). Tree traversals differ a lot: 48 stays better there.
+        const uint32_t measure_refill = c.family == ptsel::Family::Mfma ? 64u : 48u;
+        if (int rc = order_work(s, A, params, cam, shard_index, shard_count, stream, measure_refill, [&](KArgs A1) {
                 A1.wave_end = nullptr;
                 hipLaunchKernelGGL(measure_kern, dim3(grid), dim3(blk), lds, stream, A1);
             }))

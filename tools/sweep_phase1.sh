@@ -1,0 +1,5 @@
+P='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print(sys.argv[1], round(d["value"],1), round(d["ms_per_step"],3), round(d["roofline"]["kernel_ms"],3), round(d["roofline"]["pass_ms"]-d["roofline"]["kernel_ms"],3))'
+cp pathtrace-rs_amd/_build/libptgpu.so /tmp/cur.so
+cp _ab/libptgpu_dk.so pathtrace-rs_amd/_build/libptgpu.so
+for r in 16 32 40 48 56 60 64; do for rep in 1 2; do PTGPU_PHASE1_REFILL=$r python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python -c "$P" p1_refill_$r; done; done
+cp /tmp/cur.so pathtrace-rs_amd/_build/libptgpu.so
