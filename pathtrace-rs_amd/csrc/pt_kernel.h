@@ -1752,7 +1752,10 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 const float4 sp = sphere_at_m<MOVING>(mot, idx, shade[4 * idx], rtime), q1 = shade[4 * idx + 1],
                              qa = shade[4 * idx + 2], qb = shade[4 * idx + 3];
                 const f3 centre = mk3(sp.x, sp.y, sp.z);
-                const f3 point = add3(o, scale3(d, t_hit));            // ray.rs:24-26
+                // ray.rs:24-26. The hit point IS the next ray's origin when the path scatters, and a path that ends here gets a new
+                // origin from the camera: the lane's origin is advanced in place (no second copy of the point kept alive)
+                o = add3(o, scale3(d, t_hit));
+                const f3 point = o;
                 const f3 normal = divs3_known(sub3(point, centre), sp.w, qa.w);    // sphere.rs:42 (qa.w: 1 / radius from the host)
                 struct { uint32_t kind, flags; int32_t tex; float param; } m = {
                     __float_as_uint(q1.x), __float_as_uint(q1.y), (int32_t)__float_as_uint(q1.z), q1.w};
@@ -1772,7 +1775,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 f3 emitted = mk3(0.f, 0.f, 0.f);                        // material.rs:161-167
                 if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = surface_colour();
                 bool scattered = false;
-                f3 att = mk3(1.f, 1.f, 1.f), nd = d;
+                f3 att = mk3(1.f, 1.f, 1.f);
                 uint32_t attc = WST ? kWstWhite : kWhite;    // PAL / WST: code of `att` (white unless a branch says otherwise)
                 if (PT_DEPTH < __float_as_uint(s_par[12].z)) {   // max_depth
                     // every scatter ends in `.normalize()` of some vector (material.rs:63,84,112,119): the branches
@@ -1835,10 +1838,11 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         raw = use_refract ? refracted : reflect3(d, normal);
                         scattered = true;
                     }
+                    // (the direction is replaced in place as well: a path that does not scatter ends, and its lane's next ray is a camera ray)
 #ifdef PT_SHARED_REJECT
-                    if (scattered) nd = pend_metal ? raw : normalize3(raw);
+                    if (scattered) d = pend_metal ? raw : normalize3(raw);
 #else
-                    if (scattered) nd = normalize3(raw);
+                    if (scattered) d = normalize3(raw);
 #endif
                 }
                 if (scattered) {
@@ -1859,8 +1863,6 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         path_st((PT_DEPTH - 1u) * 3u + 2u, att.z);
                     }
                     sd += 1u;   // depth += 1
-                    o = point;
-                    d = nd;
                     terminal = false;
                     trav_new = true;
                 } else {
