@@ -52,8 +52,10 @@ __device__ __forceinline__ bool div_by_known_ok(f3 v, float y) {
     return lo >= 0x1p-90f && hi < 0x1p100f && y == y;   // (a NaN component fails the first two)
 }
 __device__ __forceinline__ f3 divs3_known(f3 v, float r, float y) {
-    if (__builtin_expect(wave_any(!div_by_known_ok(v, y)), 0)) return f3{v.x / r, v.y / r, v.z / r};
-    return f3{div_by_known(v.x, r, y), div_by_known(v.y, r, y), div_by_known(v.z, r, y)};
+    // (the short form first, the rare full divisions behind it: the common path then has no branch in front of its arithmetic)
+    f3 q = f3{div_by_known(v.x, r, y), div_by_known(v.y, r, y), div_by_known(v.z, r, y)};
+    if (__builtin_expect(wave_any(!div_by_known_ok(v, y)), 0)) q = f3{v.x / r, v.y / r, v.z / r};
+    return q;
 }
 // glam Vec3::dot: (x*x' + y*y') + z*z'
 __device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
@@ -64,12 +66,13 @@ __device__ __forceinline__ float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.
 // same arithmetic for every input of magnitude >= 2^-96; a wave in which some lane holds a smaller non-zero value takes the library path.
 // Checked against __builtin_sqrtf on ALL 2^32 bit patterns (pt_selftest_probe PT_PROBE_SWEEP_SQRT, tests/test_gpu_parity.py).
 __device__ __forceinline__ float sqrt_exact(float x) {
-    if (__builtin_expect(wave_any(__builtin_fabsf(x) < 0x1p-96f && x != 0.0f), 0)) return __builtin_sqrtf(x);
     float s = __builtin_amdgcn_sqrtf(x);
     const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
     const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
     s = (0.0f >= rm) ? sm : s;
     s = (0.0f < rp) ? sp : s;
+    // (the library path for the rare wave BEHIND the common arithmetic: v_sqrt_f32 issues without waiting for the vote)
+    if (__builtin_expect(wave_any(__builtin_fabsf(x) < 0x1p-96f && x != 0.0f), 0)) s = __builtin_sqrtf(x);
     return s;
 }
 __device__ __forceinline__ float length3(f3 a) { return sqrt_exact(dot3(a, a)); }
