@@ -672,6 +672,8 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     // rows of the tile), bits 16..31 from lane ^ 32's (the other 16 rows), exchanged with one cross-half swap per
     // tile. Non-empty masks are appended to this lane's queue; `tbits` remembers which tiles they belong to.
     uint32_t tbits = 0, cnt = 0, ncand = 0;
+    uint32_t queued = 0;   // candidates behind the masks this lane has queued since the last drain (counted as they are queued: the
+                           // drain's prefix sum needs no pass over the queue)
     uint32_t *queue32 = reinterpret_cast<uint32_t *>(queue);
     // slot of bit b of a tile mask. (Bit b comes from accumulator register r = 15 - (b & 15), i.e. fragment row (r & 3) + 8 (r >> 2)
     // + 4 * (half of the wave that computed it), bits 0..15 from the low half, 16..31 from the high half; the host stores
@@ -690,15 +692,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     };
     auto drain = [&]() {
         // 1. how many candidates does the wave hold, and where do mine go in its list
-        uint32_t mine_n = 0;
-        {
-            uint32_t tb = tbits, j = 0;
-            while (tb != 0u) {
-                tb &= tb - 1u;
-                mine_n += (uint32_t)__popc(queue32[j * BLK + tid]);
-                j += 1;
-            }
-        }
+        const uint32_t mine_n = queued;
         const uint32_t incl = wave_inclusive_sum(mine_n);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
 #ifdef PT_WAVEDBG
@@ -792,6 +786,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
         }
         tbits = 0;
         cnt = 0;
+        queued = 0;
     };
     // the always-tested spheres first (wave-uniform): their nearest hit bounds the segment the tiles are culled against
     const float4 pcull = P[12];
@@ -891,6 +886,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
             if (cnt < (uint32_t)kEntCap) {   // (only verify mode can get past the capacity: everyone else drains when full)
                 queue32[cnt * BLK + tid] = full;
                 tbits |= 1u << T;
+                queued += (uint32_t)__popc(full);
             }
             cnt += 1;
             if (VERIFY) ncand += (uint32_t)__popc(full);
