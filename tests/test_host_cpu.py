@@ -446,3 +446,20 @@ def test_scene_graph_nestings_the_list_form_cannot_hold_are_named(ptgpu):
     with pytest.raises(ptgpu.PtError) as e:     # sixteen Instance levels around one shape
         select([[0, 0, 0, 0]] + [[2, 0, i, 0] for i in range(16)] + [[1, 0, 1, 0]], [16], 17)
     assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and "at most 15" in str(e.value)
+
+
+def test_committed_kernel_resource_table_shows_no_spill():
+    """profiles/r03_kernel_resources.txt (`make -C pathtrace-rs_amd resources`: hipcc -Rpass-analysis=kernel-resource-usage on the
+    four kernel translation units) is the evidence behind DESIGN.md's "no kernel of the library spills": every one of the 43
+    pt_trace_kernel and 16 pt_world_kernel instantiations is listed, none uses scratch or spills a VGPR, and the 1024-thread
+    prefilter kernels (one workgroup per CU, four waves per SIMD) stay within the 128 registers that occupancy allows."""
+    rows = [l for l in open(os.path.join(ROOT, "profiles", "r03_kernel_resources.txt")).read().splitlines()[1:] if l.strip()]
+    parsed = []
+    for l in rows:
+        name, rest = l[:100].strip(), l[100:].split()
+        vgprs, scratch, _sgpr_spills, vgpr_spills, occ = (int(x) for x in rest)
+        parsed.append((name, vgprs, scratch, vgpr_spills, occ))
+    assert sum(n.startswith("pt_trace_kernel<") for n, *_ in parsed) == 43 and sum(n.startswith("pt_world_kernel<") for n, *_ in parsed) == 16
+    assert all(scratch == 0 and spills == 0 for _, _, scratch, spills, _ in parsed), [p for p in parsed if p[2] or p[3]]
+    wide = [p for p in parsed if re.search(r", 1024>", p[0])]
+    assert len(wide) == 8 and all(v <= 128 and occ == 4 for _, v, _, _, occ in wide), wide
