@@ -191,7 +191,7 @@ bool prepare_mfma(const pt_scene_desc *desc, const MotionIn *motion, double t_lo
                 if (dev_knobs().cull_strips > 0) strips = (uint32_t)dev_knobs().cull_strips;
                 strips = std::max(1u, std::min(strips, (uint32_t)full_tiles));
                 const size_t tps = (full_tiles + strips - 1) / strips;   // tiles per strip
-                for (size_t t0 = 0; t0 < full_tiles; t0 += tps) {
+                for (size_t t0 = 0; t0 < full_tiles && strips > 1; t0 += tps) {   // (one strip: the tiles stay slabs of the sort axis)
                     const size_t q0 = t0 * 32, q1 = std::min(t0 + tps, full_tiles) * 32;
                     std::stable_sort(regular.begin() + q0, regular.begin() + q1, [&](uint32_t a, uint32_t b) { return sw[a].c[bx] < sw[b].c[bx]; });
                 }
