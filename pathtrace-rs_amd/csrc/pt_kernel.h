@@ -795,8 +795,8 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     uint32_t j_first = 0;
     TileClip clip{0.0f, 0.0f, 0.0f, false};
 #ifndef PT_NO_HEAD_ILP
-    if (!GATED) {
-        // List worlds: the FIRST always-tested sphere (the ground of most scenes) without a branch, so that its chain -- load,
+    {
+        // The FIRST always-tested sphere (the ground of most scenes) without a branch, so that its chain -- load,
         // discriminant, square root, two quotients -- shares one basic block with the ray's features above and the box clip of the
         // tile culling: three independent chains for the scheduler instead of one after the other (this stretch was 16 % of the
         // wave-cycles for 10 % of the instructions). The arithmetic is sphere.rs:33-64 as everywhere else; the rare inputs the
@@ -810,8 +810,12 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
         const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
         const float disc = b * b - a * cc;
         const float t = sphere_hit_t(av, b, disc, has0 && active);
-        best = t;
-        idx = t < kMaxT ? k0 : -1;
+        if (!GATED) {
+            best = t;
+            idx = t < kMaxT ? k0 : -1;
+        } else if (t < kMaxT) {
+            accept_hit<GATED>(A, G, k0, t, o, d, best, idx, best_rank);   // BVH world: the ancestor-AABB gate decides (bvh.rs:37-62)
+        }
         j_first = 1;
     }
 #endif
@@ -823,9 +827,7 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
     uint32_t mine = rem;   // tiles THIS lane's ray can find its winner in; the wave runs the union
     if (culling) {
-#ifndef PT_NO_HEAD_ILP
-        if (GATED) clip = lane_tile_clip(P, o, d, active);
-#else
+#ifdef PT_NO_HEAD_ILP
         clip = lane_tile_clip(P, o, d, active);
 #endif
         mine = lane_tile_mask_of(P, s_cull, clip, o, d, best, cull_axis, cull_always);

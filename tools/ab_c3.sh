@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development aid: config 3 (the metric) on each library variant in _ab/ (A/B of list-kernel changes), two rounds.
-B="python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-extras"
+B="python bench.py $AB_ARGS --steps 12 --warmup 3 --no-cpu-baseline --no-extras"
 P='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print(sys.argv[1], round(d["value"],1), round(d["ms_per_step"],3), round(d["roofline"]["kernel_ms"],3))'
 cp pathtrace-rs_amd/_build/libptgpu.so /tmp/cur.so
 for rep in 1 2 3; do

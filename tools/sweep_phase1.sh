@@ -1,3 +1,6 @@
+#!/bin/bash
+# Development aid: config 3 over PTGPU_PHASE1_REFILL (lanes that must be waiting before a wave of the MEASURING launch refills) on a
+# -DPT_DEVKNOBS build kept as _ab/libptgpu_dk.so; last column: pass_ms - kernel_ms = measuring launch + order kernel.
 P='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print(sys.argv[1], round(d["value"],1), round(d["ms_per_step"],3), round(d["roofline"]["kernel_ms"],3), round(d["roofline"]["pass_ms"]-d["roofline"]["kernel_ms"],3))'
 cp pathtrace-rs_amd/_build/libptgpu.so /tmp/cur.so
 cp _ab/libptgpu_dk.so pathtrace-rs_amd/_build/libptgpu.so
