@@ -234,7 +234,7 @@ __device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine
 }
 
 // One HitableList entry. Returns the material to shade with in `mat`. A ConstantMedium asks its boundary twice
-// (constant_medium.rs:39-43): the shape code is reached through ONE call site in a two-trip loop so it exists once.
+// (constant_medium.rs:39-43): two call sites of the shape code (see below).
 // Returns the material index, or -1 for no hit.
 template <bool MEDIA, bool CHAINS>
 __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *xf, const WRay &r_in, float t_min, float t_max,
@@ -245,23 +245,21 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
     // length enters the distance it samples (constant_medium.rs:51) -- and the hit is carried back out at the end
     const bool outer = MEDIA && CHAINS && chain.n_out != 0u;
     const WRay r = outer ? w_ray_into(xf, chain.first, chain.n_out, r_in) : r_in;
-    float lo = medium ? -kMaxT : t_min, hi = medium ? kMaxT : t_max;
-    float t_first = 0.f;
-    bool ok = true;
-#pragma clang loop unroll(disable)
-    for (int pass = 0; pass < (medium ? 2 : 1); ++pass) {
-        if (ok) {
-            ok = w_instanced<CHAINS>(H, xf, chain, r, lo, hi, h, want_uv);
-            if (pass == 0) t_first = h.t;
-            lo = h.t + 0.0001f;   // constant_medium.rs:41
-            hi = kMaxT;
-        }
-    }
+    // (A ConstantMedium asks its boundary twice, constant_medium.rs:39-43. The two questions are two call sites: a two-trip loop
+    //  around one call site carried the whole hit record -- nine registers -- around its back edge for EVERY entry of the list,
+    //  eight register copies per entry; the second question only needs the distance, the rest of its record is dead code.)
+    bool ok = w_instanced<CHAINS>(H, xf, chain, r, medium ? -kMaxT : t_min, medium ? kMaxT : t_max, h, want_uv);
     if (!medium) {
         if (ok && outer) w_hit_out_of(xf, chain.first, chain.n_out, h);
         return ok ? (int)H.material : -1;
     }
     if (!ok) return -1;
+    const float t_first = h.t;
+    {
+        WHit h2;
+        if (!w_instanced<CHAINS>(H, xf, chain, r, t_first + 0.0001f, kMaxT, h2, false)) return -1;   // constant_medium.rs:41
+        h.t = h2.t;
+    }
     // constant_medium.rs:44-76
     float t1 = t_first, t2 = h.t;
     if (t1 < t_min) t1 = t_min;
@@ -291,8 +289,14 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
 // cost more than the fourth wave brings (simple_light -6 %), so those keep 2 (the compiler then uses ~160 VGPRs).
 // MEDIA: some hitable is a ConstantMedium (own instantiations: worlds without media do not carry that path's registers).
 // CHAINS: some entry sits below more than one Instance level, or below Instances around its medium (scene graphs only).
+#ifdef PT_BBPROF   // tools/bbprof.py (BBPROF_UNIT=pt_kernels_world): the instrumented assembly keeps its counter registers above the compiler's
+#include "pt_bbprof.h"
+#define PT_WBBPROF_ATTR __attribute__((amdgpu_num_sgpr(104)))
+#else
+#define PT_WBBPROF_ATTR
+#endif
 template <bool BVH, bool HIT_LDS, int OCC = 3, bool MEDIA = true, bool CHAINS = false>
-__global__ __launch_bounds__(kBlock, OCC) void pt_world_kernel(const WArgs A) {
+__global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(const WArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *p = smem;
     float4 *s_pvec = reinterpret_cast<float4 *>(p);

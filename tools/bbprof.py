@@ -20,7 +20,7 @@ OUT = os.path.join(PKG, "_build", "bbprof")
 LLVM = "/opt/rocm/lib/llvm/bin"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-I../include", "-Icsrc",
          "-I/opt/rocm/include", "-DPT_BBPROF"]
-UNIT = os.environ.get("BBPROF_UNIT", "pt_kernels_list")   # pt_kernels_list | pt_kernels_gate | pt_kernels_tree
+UNIT = os.environ.get("BBPROF_UNIT", "pt_kernels_list")   # pt_kernels_list | pt_kernels_gate | pt_kernels_tree | pt_kernels_world
 
 
 def sh(cmd, **kw):
@@ -53,7 +53,7 @@ def instrument(src_lines):
     for l in src_lines:
         m = re.match(r'\s*\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', l)
         if m: files[int(m.group(1))] = m.group(2)
-        m = re.match(r"^(_ZN5ptdev\d+pt_trace_kernel\w+):", l)
+        m = re.match(r"^(_ZN5ptdev\d+pt_(?:trace|world)_kernel\w+):", l)
         if m:
             kernel = m.group(1)
             out.append(l)
@@ -83,7 +83,7 @@ def instrument(src_lines):
                     if re.match(r"v_(readlane|writelane|readfirstlane)", op): cur["lanes"] += 1   # SGPR spill traffic and wave-uniform reads
                     if re.match(r"v_(mov_b|accvgpr)", op): cur["movs"] += 1
                     if loc: cur["lines"]["%s:%d" % loc] += 1
-        elif ".amdhsa_next_free_sgpr" in l and blocks and "pt_trace_kernel" in (blocks[-1]["kernel"] or ""):
+        elif ".amdhsa_next_free_sgpr" in l and blocks and ("pt_trace_kernel" in (blocks[-1]["kernel"] or "") or "pt_world_kernel" in (blocks[-1]["kernel"] or "")):
             l = "\t\t.amdhsa_next_free_sgpr 100"   # the descriptor follows the function body
         out.append(l)
     for b in blocks: b["lines"] = dict(b["lines"])
