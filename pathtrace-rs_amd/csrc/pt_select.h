@@ -119,7 +119,6 @@ inline void select_world(const SceneTraits &t, const pt_params &p, uint32_t loca
     if (c.ref_bvh) lds += c.bvh_stack_entries * (uint32_t)kBlock * 4u;
     c.world_hit_lds = t.n_hitables * 64u + t.n_world_xf * 96u <= 40960u;   // records + transforms staged in LDS
     if (c.world_hit_lds) lds += t.n_hitables * 64u + t.n_world_xf * 96u;
-    lds += 8u * (uint32_t)kBlock * 4u;                                       // the running closest-hit record
     const uint64_t path_bytes = (uint64_t)p.max_depth * 3ull * (uint32_t)kBlock * 4ull;
     c.stack_in_lds = (lds + path_bytes <= 60u * 1024u) ? 1u : 0u;
     if (c.stack_in_lds) lds += (uint32_t)path_bytes;

@@ -71,8 +71,14 @@ __device__ __forceinline__ float logf_ref(float x) {
     return (float)y;
 }
 
+// The hit tests answer in two steps. While the world is scanned they only return the accepted PARAMETER t (and, for a cuboid, the
+// face): `*_t`. The record of the one hit that wins (point, normal, u, v: ray.rs:43-50) is built afterwards from (entry, t, face) by
+// `*_rec`, with the expressions the reference uses at the hit -- same inputs, same operations, same bits. (Filling a nine-register
+// record inside every test and merging it across the tests' exits cost the general-world kernel 22 % of its VALU instructions in
+// register copies, and an LDS record of the running best hit.)
+
 // sphere.rs:29-66 with the caller's t_max (the list scan narrows it)
-__device__ __forceinline__ bool w_sphere(f3 centre, float radius, const WRay &r, float t_min, float t_max, WHit &h) {
+__device__ __forceinline__ bool w_sphere_t(f3 centre, float radius, const WRay &r, float t_min, float t_max, float &t_out) {
     const f3 oc = sub3(r.o, centre);
     const float a = dot3(r.d, r.d);
     const float b = dot3(oc, r.d);
@@ -85,21 +91,20 @@ __device__ __forceinline__ bool w_sphere(f3 centre, float radius, const WRay &r,
             t = (-b + ds) / a;
             if (!(t < t_max && t > t_min)) return false;
         }
-        h.point = add3(r.o, scale3(r.d, t));
-        h.normal = divs3(sub3(h.point, centre), radius);
-        h.t = t;
-        h.u = 0.0f, h.v = 0.0f;   // sphere.rs:47-48 (u before v like every other shape: with the two stores in the other order the
-                                  //  compiler merges them across shapes into stores through a SELECTED pointer, which keeps u and v in scratch)
+        t_out = t;
         return true;
     }
     return false;
 }
+__device__ __forceinline__ void w_sphere_rec(f3 centre, float radius, const WRay &r, float t, WHit &h) {
+    h.point = add3(r.o, scale3(r.d, t));
+    h.normal = divs3(sub3(h.point, centre), radius);
+    h.u = 0.0f, h.v = 0.0f;   // sphere.rs:47-48
+}
 
 // rect.rs:73-190. `axis` 0/1/2 = XY/XZ/YZ. The comparisons keep the reference's form: a NaN t or
 // coordinate falls through every test exactly as it does there.
-__device__ __forceinline__ bool w_rect(uint32_t axis, float a0, float a1, float b0, float b1, float k, bool flip,
-                                       const WRay &r, float t_min, float t_max, WHit &h, bool want_uv) {
-    float ok, rk, oa, da, ob, db;
+__device__ __forceinline__ void w_rect_axes(uint32_t axis, const WRay &r, float &ok, float &rk, float &oa, float &da, float &ob, float &db) {
     if (axis == 0u) {
         ok = r.o.z, rk = r.rcp.z, oa = r.o.x, da = r.d.x, ob = r.o.y, db = r.d.y;
     } else if (axis == 1u) {
@@ -107,18 +112,29 @@ __device__ __forceinline__ bool w_rect(uint32_t axis, float a0, float a1, float 
     } else {
         ok = r.o.x, rk = r.rcp.x, oa = r.o.y, da = r.d.y, ob = r.o.z, db = r.d.z;
     }
+}
+__device__ __forceinline__ bool w_rect_t(uint32_t axis, float a0, float a1, float b0, float b1, float k, const WRay &r, float t_min, float t_max,
+                                         float &t_out) {
+    float ok, rk, oa, da, ob, db;
+    w_rect_axes(axis, r, ok, rk, oa, da, ob, db);
     const float t = (k - ok) * rk;
     if (t < t_min || t > t_max) return false;
     const float a = oa + t * da;
     const float b = ob + t * db;
     if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+    t_out = t;
+    return true;
+}
+__device__ __forceinline__ void w_rect_rec(uint32_t axis, float a0, float a1, float b0, float b1, bool flip, const WRay &r, float t, WHit &h, bool want_uv) {
+    float ok, rk, oa, da, ob, db;
+    w_rect_axes(axis, r, ok, rk, oa, da, ob, db);
+    const float a = oa + t * da;
+    const float b = ob + t * db;
     const float sgn = flip ? -1.0f : 1.0f;  // rect.rs:33 FLIP_SIGN
     h.normal = axis == 0u ? mk3(0.0f, 0.0f, sgn) : (axis == 1u ? mk3(0.0f, sgn, 0.0f) : mk3(sgn, 0.0f, 0.0f));
     h.point = add3(r.o, scale3(r.d, t));
-    h.t = t;
     h.u = want_uv ? (a - a0) / (a1 - a0) : 0.0f;   // rect.rs:97-98
     h.v = want_uv ? (b - b0) / (b1 - b0) : 0.0f;
-    return true;
 }
 
 // aabb.rs:46-58 (Vec3A min/max = _mm_min_ps/_mm_max_ps: the SECOND operand wins on NaN), one axis
@@ -136,44 +152,67 @@ __device__ __forceinline__ bool w_aabb_hit(f3 mn, f3 mx, const WRay &r, float tm
 
 // cuboid.rs:11-37: AABB test, then the six faces in construction order with narrowing. The faces are written out (axis
 // and side are compile-time constants of each call): a loop over a face index made the compiler keep p0 / p1 in scratch
-// memory and index them dynamically.
+// memory and index them dynamically. Face id = 2 * axis + (1 for the face at p0, which looks the other way).
 template <int AXIS, bool FLIP>
-__device__ __forceinline__ void w_cuboid_face(f3 p0, f3 p1, const WRay &r, float t_min, float &closest, WHit &h, bool &found, bool want_uv) {
-    float a0, a1, b0, b1, k;
+__device__ __forceinline__ void w_cuboid_face_bounds(f3 p0, f3 p1, float &a0, float &a1, float &b0, float &b1, float &k) {
     if (AXIS == 0) a0 = p0.x, a1 = p1.x, b0 = p0.y, b1 = p1.y, k = FLIP ? p0.z : p1.z;        // XY
     else if (AXIS == 1) a0 = p0.x, a1 = p1.x, b0 = p0.z, b1 = p1.z, k = FLIP ? p0.y : p1.y;   // XZ
     else a0 = p0.y, a1 = p1.y, b0 = p0.z, b1 = p1.z, k = FLIP ? p0.x : p1.x;                   // YZ
-    WHit f;
-    if (w_rect((uint32_t)AXIS, a0, a1, b0, b1, k, FLIP, r, t_min, closest, f, want_uv)) h = f, closest = f.t, found = true;
 }
-__device__ __forceinline__ bool w_cuboid(f3 p0, f3 p1, const WRay &r, float t_min, float t_max, WHit &h, bool want_uv) {
+template <int AXIS, bool FLIP>
+__device__ __forceinline__ void w_cuboid_face_t(f3 p0, f3 p1, const WRay &r, float t_min, float &closest, uint32_t &face, bool &found) {
+    float a0, a1, b0, b1, k, t;
+    w_cuboid_face_bounds<AXIS, FLIP>(p0, p1, a0, a1, b0, b1, k);
+    if (w_rect_t((uint32_t)AXIS, a0, a1, b0, b1, k, r, t_min, closest, t)) closest = t, face = 2u * (uint32_t)AXIS + (FLIP ? 1u : 0u), found = true;
+}
+__device__ __forceinline__ bool w_cuboid_t(f3 p0, f3 p1, const WRay &r, float t_min, float t_max, float &t_out, uint32_t &face) {
     if (!w_aabb_hit(p0, p1, r, t_min, t_max)) return false;
     bool found = false;
     float closest = t_max;
-    w_cuboid_face<0, false>(p0, p1, r, t_min, closest, h, found, want_uv);   // odd faces sit at p0 and face the other way
-    w_cuboid_face<0, true>(p0, p1, r, t_min, closest, h, found, want_uv);
-    w_cuboid_face<1, false>(p0, p1, r, t_min, closest, h, found, want_uv);
-    w_cuboid_face<1, true>(p0, p1, r, t_min, closest, h, found, want_uv);
-    w_cuboid_face<2, false>(p0, p1, r, t_min, closest, h, found, want_uv);
-    w_cuboid_face<2, true>(p0, p1, r, t_min, closest, h, found, want_uv);
+    w_cuboid_face_t<0, false>(p0, p1, r, t_min, closest, face, found);   // odd faces sit at p0 and face the other way
+    w_cuboid_face_t<0, true>(p0, p1, r, t_min, closest, face, found);
+    w_cuboid_face_t<1, false>(p0, p1, r, t_min, closest, face, found);
+    w_cuboid_face_t<1, true>(p0, p1, r, t_min, closest, face, found);
+    w_cuboid_face_t<2, false>(p0, p1, r, t_min, closest, face, found);
+    w_cuboid_face_t<2, true>(p0, p1, r, t_min, closest, face, found);
+    t_out = closest;
     return found;
+}
+__device__ __forceinline__ void w_cuboid_rec(f3 p0, f3 p1, uint32_t face, const WRay &r, float t, WHit &h, bool want_uv) {
+    const uint32_t axis = face >> 1;
+    const bool flip = (face & 1u) != 0u;
+    float a0, a1, b0, b1;
+    if (axis == 0u) a0 = p0.x, a1 = p1.x, b0 = p0.y, b1 = p1.y;
+    else if (axis == 1u) a0 = p0.x, a1 = p1.x, b0 = p0.z, b1 = p1.z;
+    else a0 = p0.y, a1 = p1.y, b0 = p0.z, b1 = p1.z;
+    w_rect_rec(axis, a0, a1, b0, b1, flip, r, t, h, want_uv);
 }
 
 // The innermost shape (hitable.rs:50-56)
-__device__ __forceinline__ bool w_shape(const pt_hitable &H, const WRay &r, float t_min, float t_max, WHit &h, bool want_uv) {
+__device__ __forceinline__ f3 w_moving_centre(const pt_hitable &H, const WRay &r) {   // moving_sphere.rs:29-31
+    const float s = (r.time - H.p[7]) * H.p[8];
+    return add3(mk3(H.p[0], H.p[1], H.p[2]), scale3(mk3(H.p[3], H.p[4], H.p[5]), s));
+}
+__device__ __forceinline__ bool w_shape_t(const pt_hitable &H, const WRay &r, float t_min, float t_max, float &t, uint32_t &face) {
     switch (H.kind) {
-    case PT_HIT_SPHERE: return w_sphere(mk3(H.p[0], H.p[1], H.p[2]), H.p[3], r, t_min, t_max, h);
-    case PT_HIT_MOVING_SPHERE: {  // moving_sphere.rs:29-31,38-73
-        const float s = (r.time - H.p[7]) * H.p[8];
-        const f3 centre = add3(mk3(H.p[0], H.p[1], H.p[2]), scale3(mk3(H.p[3], H.p[4], H.p[5]), s));
-        return w_sphere(centre, H.p[6], r, t_min, t_max, h);
-    }
-    case PT_HIT_CUBOID: return w_cuboid(mk3(H.p[0], H.p[1], H.p[2]), mk3(H.p[3], H.p[4], H.p[5]), r, t_min, t_max, h, want_uv);
+    case PT_HIT_SPHERE: return w_sphere_t(mk3(H.p[0], H.p[1], H.p[2]), H.p[3], r, t_min, t_max, t);
+    case PT_HIT_MOVING_SPHERE: return w_sphere_t(w_moving_centre(H, r), H.p[6], r, t_min, t_max, t);   // moving_sphere.rs:38-73
+    case PT_HIT_CUBOID: return w_cuboid_t(mk3(H.p[0], H.p[1], H.p[2]), mk3(H.p[3], H.p[4], H.p[5]), r, t_min, t_max, t, face);
     // (one call per plane orientation, each with a constant axis: a run-time axis made the compiler index the ray's
     //  components through scratch memory)
-    case PT_HIT_RECT_XY: return w_rect(0u, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], H.flip_normals != 0u, r, t_min, t_max, h, want_uv);
-    case PT_HIT_RECT_XZ: return w_rect(1u, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], H.flip_normals != 0u, r, t_min, t_max, h, want_uv);
-    default: return w_rect(2u, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], H.flip_normals != 0u, r, t_min, t_max, h, want_uv);
+    case PT_HIT_RECT_XY: return w_rect_t(0u, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], r, t_min, t_max, t);
+    case PT_HIT_RECT_XZ: return w_rect_t(1u, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], r, t_min, t_max, t);
+    default: return w_rect_t(2u, H.p[0], H.p[1], H.p[2], H.p[3], H.p[4], r, t_min, t_max, t);
+    }
+}
+__device__ __forceinline__ void w_shape_rec(const pt_hitable &H, const WRay &r, float t, uint32_t face, WHit &h, bool want_uv) {
+    switch (H.kind) {
+    case PT_HIT_SPHERE: w_sphere_rec(mk3(H.p[0], H.p[1], H.p[2]), H.p[3], r, t, h); break;
+    case PT_HIT_MOVING_SPHERE: w_sphere_rec(w_moving_centre(H, r), H.p[6], r, t, h); break;
+    case PT_HIT_CUBOID: w_cuboid_rec(mk3(H.p[0], H.p[1], H.p[2]), mk3(H.p[3], H.p[4], H.p[5]), face, r, t, h, want_uv); break;
+    case PT_HIT_RECT_XY: w_rect_rec(0u, H.p[0], H.p[1], H.p[2], H.p[3], H.flip_normals != 0u, r, t, h, want_uv); break;
+    case PT_HIT_RECT_XZ: w_rect_rec(1u, H.p[0], H.p[1], H.p[2], H.p[3], H.flip_normals != 0u, r, t, h, want_uv); break;
+    default: w_rect_rec(2u, H.p[0], H.p[1], H.p[2], H.p[3], H.flip_normals != 0u, r, t, h, want_uv); break;
     }
 }
 
@@ -214,54 +253,60 @@ __device__ __forceinline__ void w_hit_out_of(const pt_affine *xf, uint32_t first
     }
 }
 // CHAINS = false: at most ONE Instance around the shape and none around a medium (every preset; the kernels selected for
-// such worlds do not carry the chain loops' registers)
+// such worlds do not carry the chain loops' registers). An Instance keeps the ray's parameter: the local ray is the transformed
+// origin and the transformed, NOT re-normalised direction (instance.rs:32-47).
 template <bool CHAINS>
-__device__ __forceinline__ bool w_instanced(const pt_hitable &H, const pt_affine *xf, const WChain &c, const WRay &r, float t_min, float t_max, WHit &h,
-                                            bool want_uv) {
-    if (c.n_in == 0u) return w_shape(H, r, t_min, t_max, h, want_uv);
+__device__ __forceinline__ WRay w_local_ray(const pt_affine *xf, const WChain &c, const WRay &r) {
+    if (c.n_in == 0u) return r;
     if (!CHAINS) {
         const pt_affine &T = xf[c.first];
-        const WRay local = w_ray_new(w_xf_point(T.inv, r.o), w_xf_vector(T.inv, r.d), r.time);
-        if (!w_shape(H, local, t_min, t_max, h, want_uv)) return false;
+        return w_ray_new(w_xf_point(T.inv, r.o), w_xf_vector(T.inv, r.d), r.time);
+    }
+    return w_ray_into(xf, c.first + c.n_out, c.n_in, r);
+}
+template <bool CHAINS>
+__device__ __forceinline__ bool w_instanced_t(const pt_hitable &H, const pt_affine *xf, const WChain &c, const WRay &r, float t_min, float t_max, float &t,
+                                              uint32_t &face) {
+    return w_shape_t(H, w_local_ray<CHAINS>(xf, c, r), t_min, t_max, t, face);
+}
+template <bool CHAINS>
+__device__ __forceinline__ void w_instanced_rec(const pt_hitable &H, const pt_affine *xf, const WChain &c, const WRay &r, float t, uint32_t face, WHit &h,
+                                                bool want_uv) {
+    w_shape_rec(H, w_local_ray<CHAINS>(xf, c, r), t, face, h, want_uv);
+    if (c.n_in == 0u) return;
+    if (!CHAINS) {
+        const pt_affine &T = xf[c.first];
         h.point = w_xf_point(T.m, h.point);
         h.normal = w_xf_vector(T.m, h.normal);
-        return true;
+        return;
     }
-    const WRay local = w_ray_into(xf, c.first + c.n_out, c.n_in, r);
-    if (!w_shape(H, local, t_min, t_max, h, want_uv)) return false;
     w_hit_out_of(xf, c.first + c.n_out, c.n_in, h);
-    return true;
 }
 
-// One HitableList entry. Returns the material to shade with in `mat`. A ConstantMedium asks its boundary twice
-// (constant_medium.rs:39-43): two call sites of the shape code (see below).
-// Returns the material index, or -1 for no hit.
+constexpr uint32_t kFaceMedium = 0xffu;   // `face` of a hit INSIDE a ConstantMedium (its record is the scatter point, not the boundary's)
+
+// One HitableList entry, first step: the accepted parameter. Returns the material index to shade with, or -1 for no hit.
+// A ConstantMedium asks its boundary twice (constant_medium.rs:39-43) -- two call sites of the shape code: a two-trip loop around
+// one call site carried its state around the back edge for EVERY entry of the list.
 template <bool MEDIA, bool CHAINS>
-__device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *xf, const WRay &r_in, float t_min, float t_max,
-                                         Rng &rng, WHit &h, bool want_uv) {
+__device__ __forceinline__ int w_hitable_t(const pt_hitable &H, const pt_affine *xf, const WRay &r_in, float t_min, float t_max, Rng &rng, float &t,
+                                           uint32_t &face) {
     const bool medium = MEDIA && H.medium_material >= 0;   // MEDIA = false: the world has no ConstantMedium (its code, and the RNG's liveness across the scan, drop out)
     const WChain chain = w_chain(H.transform);
     // Instances AROUND the medium (scene graphs only; MEDIA kernels): the medium then sees the transformed ray -- its
     // length enters the distance it samples (constant_medium.rs:51) -- and the hit is carried back out at the end
     const bool outer = MEDIA && CHAINS && chain.n_out != 0u;
     const WRay r = outer ? w_ray_into(xf, chain.first, chain.n_out, r_in) : r_in;
-    // (A ConstantMedium asks its boundary twice, constant_medium.rs:39-43. The two questions are two call sites: a two-trip loop
-    //  around one call site carried the whole hit record -- nine registers -- around its back edge for EVERY entry of the list,
-    //  eight register copies per entry; the second question only needs the distance, the rest of its record is dead code.)
-    bool ok = w_instanced<CHAINS>(H, xf, chain, r, medium ? -kMaxT : t_min, medium ? kMaxT : t_max, h, want_uv);
-    if (!medium) {
-        if (ok && outer) w_hit_out_of(xf, chain.first, chain.n_out, h);
-        return ok ? (int)H.material : -1;
-    }
+    face = 0u;
+    const bool ok = w_instanced_t<CHAINS>(H, xf, chain, r, medium ? -kMaxT : t_min, medium ? kMaxT : t_max, t, face);
+    if (!medium) return ok ? (int)H.material : -1;
     if (!ok) return -1;
-    const float t_first = h.t;
-    {
-        WHit h2;
-        if (!w_instanced<CHAINS>(H, xf, chain, r, t_first + 0.0001f, kMaxT, h2, false)) return -1;   // constant_medium.rs:41
-        h.t = h2.t;
-    }
+    const float t_first = t;
+    float t_second;
+    uint32_t face2 = 0u;
+    if (!w_instanced_t<CHAINS>(H, xf, chain, r, t_first + 0.0001f, kMaxT, t_second, face2)) return -1;   // constant_medium.rs:41
     // constant_medium.rs:44-76
-    float t1 = t_first, t2 = h.t;
+    float t1 = t_first, t2 = t_second;
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
     if (t1 >= t2) return -1;
@@ -270,15 +315,27 @@ __device__ __forceinline__ int w_hitable(const pt_hitable &H, const pt_affine *x
     const float distance_inside_boundary = (t2 - t1) * ray_length;
     const float hit_distance = -(1.0f / H.density) * logf_ref(rng_f32(rng));
     if (hit_distance < distance_inside_boundary) {
-        const float t = t1 + hit_distance / ray_length;
-        h.point = add3(r.o, scale3(r.d, t));
-        h.normal = mk3(1.0f, 0.0f, 0.0f);  // Vec3::X, arbitrary
-        h.t = t;
-        h.u = 0.0f, h.v = 0.0f;
-        if (outer) w_hit_out_of(xf, chain.first, chain.n_out, h);
+        t = t1 + hit_distance / ray_length;
+        face = kFaceMedium;
         return H.medium_material;
     }
     return -1;
+}
+// ... second step, for the entry whose hit won: its record at parameter t
+template <bool MEDIA, bool CHAINS>
+__device__ __forceinline__ void w_hitable_rec(const pt_hitable &H, const pt_affine *xf, const WRay &r_in, float t, uint32_t face, WHit &h, bool want_uv) {
+    const WChain chain = w_chain(H.transform);
+    const bool outer = MEDIA && CHAINS && chain.n_out != 0u;
+    const WRay r = outer ? w_ray_into(xf, chain.first, chain.n_out, r_in) : r_in;
+    if (MEDIA && face == kFaceMedium) {
+        h.point = add3(r.o, scale3(r.d, t));
+        h.normal = mk3(1.0f, 0.0f, 0.0f);  // Vec3::X, arbitrary (constant_medium.rs:67)
+        h.u = 0.0f, h.v = 0.0f;
+    } else {
+        w_instanced_rec<CHAINS>(H, xf, chain, r, t, face, h, want_uv);
+    }
+    if (outer) w_hit_out_of(xf, chain.first, chain.n_out, h);
+    h.t = t;
 }
 
 // HIT_LDS: the hitable records and transforms are staged in LDS (worlds up to 16 KB: every preset); the list scan
@@ -308,8 +365,6 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
     p += HIT_LDS ? A.n_hit * 64u : 0u;
     const pt_affine *s_xf = reinterpret_cast<const pt_affine *>(p);
     p += HIT_LDS ? A.n_xf * 96u : 0u;
-    float *s_best = reinterpret_cast<float *>(p) + threadIdx.x;   // [8][kBlock]: the closest hit record of the running scan (point, normal, u, v)
-    p += 8 * kBlock * 4;
     float *s_path = reinterpret_cast<float *>(p);
 
     const int tid = threadIdx.x;
@@ -405,25 +460,20 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
             }
 
             // ---- Hitable::ray_hit(ray, MIN_T, MAX_T) on the world (scene.rs:58)
-            // The running closest-hit record lives in LDS: it is written when a closer hit is accepted and read once after
-            // the scan, instead of holding nine registers across the whole intersection code.
+            // The scan keeps (entry, t, face) of the running closest hit -- three registers; the winner's record is built once, after
+            // the scan (w_hitable_rec).
             bool found = false;
-            uint32_t best_mat = 0;
+            uint32_t best_mat = 0, best_k = 0, best_face = 0;
             float best_t = kMaxT;
-            auto keep = [&](const WHit &h) {
-                s_best[0 * kBlock] = h.point.x, s_best[1 * kBlock] = h.point.y, s_best[2 * kBlock] = h.point.z;
-                s_best[3 * kBlock] = h.normal.x, s_best[4 * kBlock] = h.normal.y, s_best[5 * kBlock] = h.normal.z;
-                s_best[6 * kBlock] = h.u, s_best[7 * kBlock] = h.v;
-                best_t = h.t;
-            };
             if (!BVH) {  // hitable_list.rs:40-56
                 float closest = kMaxT;
                 for (uint32_t k = 0; k < A.n_hit; ++k) {
-                    WHit h;
-                    const int m = w_hitable<MEDIA, CHAINS>(hit[k], xf, ray, kMinT, closest, rng, h, want_uv);
+                    float t;
+                    uint32_t face;
+                    const int m = w_hitable_t<MEDIA, CHAINS>(hit[k], xf, ray, kMinT, closest, rng, t, face);
                     if (m >= 0) {
-                        keep(h), best_mat = (uint32_t)m, found = true;
-                        closest = h.t;
+                        best_k = k, best_face = face, best_t = t, best_mat = (uint32_t)m, found = true;
+                        closest = t;
                     }
                 }
             } else {  // bvh.rs:37-62, iterative: lhs subtree, then rhs, both with the original t_max
@@ -432,11 +482,12 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                 while (sp > 0) {
                     const int32_t ref = s_stack[--sp * kBlock + tid];
                     if (ref < 0) {
-                        WHit h;
-                        const int m = w_hitable<MEDIA, CHAINS>(hit[~ref], xf, ray, kMinT, kMaxT, rng, h, want_uv);
+                        float t;
+                        uint32_t face;
+                        const int m = w_hitable_t<MEDIA, CHAINS>(hit[~ref], xf, ray, kMinT, kMaxT, rng, t, face);
                         if (m >= 0) {
                             // bvh.rs:48-53: lhs only when lhs.t < rhs.t -> an equal t goes to the later leaf
-                            if (!found || !(best_t < h.t)) keep(h), best_mat = (uint32_t)m;
+                            if (!found || !(best_t < t)) best_k = (uint32_t)~ref, best_face = face, best_t = t, best_mat = (uint32_t)m;
                             found = true;
                         }
                     } else {
@@ -463,9 +514,10 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                 }
             } else {
                 const DMat m = A.mats[best_mat];
-                const f3 point = mk3(s_best[0 * kBlock], s_best[1 * kBlock], s_best[2 * kBlock]);
-                const f3 normal = mk3(s_best[3 * kBlock], s_best[4 * kBlock], s_best[5 * kBlock]), d = ray.d;
-                const float best_u = want_uv ? s_best[6 * kBlock] : 0.0f, best_v = want_uv ? s_best[7 * kBlock] : 0.0f;
+                WHit bh;
+                w_hitable_rec<MEDIA, CHAINS>(hit[best_k], xf, ray, best_t, best_face, bh, want_uv);
+                const f3 point = bh.point, normal = bh.normal, d = ray.d;
+                const float best_u = want_uv ? bh.u : 0.0f, best_v = want_uv ? bh.v : 0.0f;
                 // Texture::value (texture.rs:74-91); Constant textures were folded into the material record
                 auto colour = [&]() -> f3 {
                     return m.pad0 != 0.0f ? mk3(m.a0, m.a1, m.a2) : texture_value(A.texs, pn, m.tex, point, best_u, best_v, DImages{A.image_table, A.image_bytes});

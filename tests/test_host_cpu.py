@@ -339,15 +339,15 @@ SELECTION_TABLE = {
     ("two_perlin_spheres", True): ("tree4<blk=256>", 29168, 4, 9),
     ("random", False): ("mfma<blk=1024,moving>", 146096, 1, 0),                 # Sphere + MovingSphere world on the fast kernels
     ("random", True): ("mfma<blk=1024,moving,gate>", 163664, 1, 0),
-    ("simple_light", False): ("world<bvh=0,hit_lds=1,occ=3,media=0>", 44032, 3, 1),   # noise texture: the 3-wave build with (u, v)
-    ("simple_light", True): ("world<bvh=1,hit_lds=1,occ=3,media=0>", 48128, 3, 1),
-    ("cornell", False): ("world<bvh=0,hit_lds=1,occ=4,media=0>", 39616, 4, 1),
-    ("cornell", True): ("world<bvh=1,hit_lds=1,occ=3,media=0>", 44736, 3, 1),    # four workgroups no longer fit the LDS with the BVH stack
-    ("cornell_smoke", False): ("world<bvh=0,hit_lds=1,occ=4,media=1>", 39616, 4, 1),
-    ("cornell_smoke", True): ("world<bvh=1,hit_lds=1,occ=3,media=1>", 44736, 3, 1),
+    ("simple_light", False): ("world<bvh=0,hit_lds=1,occ=3,media=0>", 35840, 3, 1),   # noise texture: the 3-wave build with (u, v)
+    ("simple_light", True): ("world<bvh=1,hit_lds=1,occ=3,media=0>", 39936, 3, 1),
+    ("cornell", False): ("world<bvh=0,hit_lds=1,occ=4,media=0>", 31424, 4, 1),
+    ("cornell", True): ("world<bvh=1,hit_lds=1,occ=4,media=0>", 36544, 4, 1),    # (four workgroups fit the LDS with the BVH stack since the running hit record left it)
+    ("cornell_smoke", False): ("world<bvh=0,hit_lds=1,occ=4,media=1>", 31424, 4, 1),
+    ("cornell_smoke", True): ("world<bvh=1,hit_lds=1,occ=4,media=1>", 36544, 4, 1),
     ("smallpt", False): ("scan-lds<blk=256>", 38768, 3, 27),                     # r = 1000 walls: nothing the f16 features can hold
     ("smallpt", True): ("tree4<blk=256>", 25840, 4, 9),
-    ("final", False): ("world<bvh=0,hit_lds=1,occ=4,media=0>", 38912, 4, 1),     # presets.rs:40-71 returns an empty list
+    ("final", False): ("world<bvh=0,hit_lds=1,occ=4,media=0>", 30720, 4, 1),     # presets.rs:40-71 returns an empty list
 }
 
 
