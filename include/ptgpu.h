@@ -405,9 +405,10 @@ int pt_scene_traversal_counters(pt_scene *scene, uint64_t out2[2], int reset);
  *                    2^32 seeded (numerator, radius) pairs including zeros, denormals, infinities and NaNs
  *   PT_PROBE_SWEEP_DIVA  the same report for the sphere test's quotients n / (d.d): the once-per-ray reciprocal of every a in [0.5, 2]
  *                    against `1.0f / a`, and the short division against `/` on 2^32 seeded (n, a) pairs (a within 64 ulps of 1 or
- *                    anywhere in [0.5, 2], n any bit pattern) */
+ *                    anywhere in [0.5, 2], n any bit pattern)
+ *   PT_PROBE_SWEEP_RECIP the same report for the ray's reciprocal direction (ray.rs:14) against `1.0f / x`, all 2^32 x */
 enum { PT_PROBE_POW5 = 0, PT_PROBE_SIN = 1, PT_PROBE_COS = 2, PT_PROBE_RNG = 3, PT_PROBE_LN = 4, PT_PROBE_SWEEP_SQRT = 5, PT_PROBE_SWEEP_DRAWS = 6, PT_PROBE_SWEEP_INVLEN = 7, PT_PROBE_SWEEP_DIV = 8,
-       PT_PROBE_SWEEP_DIVA = 9 };
+       PT_PROBE_SWEEP_DIVA = 9, PT_PROBE_SWEEP_RECIP = 10 };
 int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n);
 
 /* Thread-local message describing the last error returned on this thread. */

@@ -304,6 +304,7 @@ __global__ void sweep_kernel(uint32_t probe, uint32_t *result) {
             else if (an >= 0x1p100f && an < __uint_as_float(0x7f800000u)) got |= 0u;                    // (never a numerator)
             else if (!(q != q && w != w)) got |= __float_as_uint(q) ^ __float_as_uint(w);
         }
+        if (probe == PT_PROBE_SWEEP_RECIP) got = __float_as_uint(recip_exact(x)), want = __float_as_uint(1.0f / x);
         if (probe == PT_PROBE_SWEEP_DRAWS) {
             // every draw k * 2^-24 (low 24 bits) beside a pixel coordinate n (high 8 bits, spread over 0..8160): the fused forms
             // of pt_device.h against the reference's expressions
@@ -324,7 +325,7 @@ __global__ void sweep_kernel(uint32_t probe, uint32_t *result) {
 
 extern "C" int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, size_t n) {
     if (!in || !out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
-    if (probe > PT_PROBE_SWEEP_DIVA) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
+    if (probe > PT_PROBE_SWEEP_RECIP) return fail(PT_ERR_INVALID_ARG, "unknown probe %u", probe);
     if (n == 0) return PT_OK;
     if (probe >= PT_PROBE_SWEEP_SQRT && n < 2) return fail(PT_ERR_INVALID_ARG, "a sweep probe reports into out[0..1]");
     int ndev = 0;

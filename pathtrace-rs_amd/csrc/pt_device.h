@@ -116,6 +116,16 @@ __device__ __forceinline__ float div_by_unit_range(float n, float a, float y) {
     q = __builtin_fmaf(__builtin_fmaf(-q, a, n), y, q);
     return __builtin_amdgcn_div_fixupf(q, a, n);
 }
+// 1.0f / x, correctly rounded, for the ray's reciprocal direction (ray.rs:14). The short form of recip_unit_range holds for every x
+// whose magnitude lies in [2^-60, 2^60]: all of its operations scale by exact powers of two there, so it rounds like the same
+// mantissa in [1, 2) does (checked exhaustively); a wave in which some lane's x lies outside that range -- an axis-parallel ray's
+// 0, a denormal, an infinity, a NaN -- divides in full. Checked against `1.0f / x` on ALL 2^32 inputs (PT_PROBE_SWEEP_RECIP).
+__device__ __forceinline__ float recip_exact(float x) {
+    float y = recip_unit_range(x);
+    const float ax = __builtin_fabsf(x);
+    if (__builtin_expect(wave_any(!(ax >= 0x1p-60f && ax <= 0x1p60f)), 0)) y = 1.0f / x;
+    return y;
+}
 __device__ __forceinline__ float div_a(float n, const DivA &v) { return v.fast ? div_by_unit_range(n, v.a, v.y) : n / v.a; }
 
 // glam 0.20 scalar Vec3::normalize: v * (1.0 / length)

@@ -30,7 +30,7 @@ struct WHit {  // ray.rs:43-50; (u, v) are only computed when the world has an I
 
 // ray.rs:13-21
 __device__ __forceinline__ WRay w_ray_new(f3 o, f3 d, float time) {
-    return WRay{o, d, mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), time};
+    return WRay{o, d, mk3(recip_exact(d.x), recip_exact(d.y), recip_exact(d.z)), time};
 }
 
 // f32::ln as glibc's logf computes it (constant_medium.rs:60; sysdeps/ieee754/flt-32/e_logf.c, the
@@ -265,11 +265,6 @@ __device__ __forceinline__ WRay w_local_ray(const pt_affine *xf, const WChain &c
     return w_ray_into(xf, c.first + c.n_out, c.n_in, r);
 }
 template <bool CHAINS>
-__device__ __forceinline__ bool w_instanced_t(const pt_hitable &H, const pt_affine *xf, const WChain &c, const WRay &r, float t_min, float t_max, float &t,
-                                              uint32_t &face) {
-    return w_shape_t(H, w_local_ray<CHAINS>(xf, c, r), t_min, t_max, t, face);
-}
-template <bool CHAINS>
 __device__ __forceinline__ void w_instanced_rec(const pt_hitable &H, const pt_affine *xf, const WChain &c, const WRay &r, float t, uint32_t face, WHit &h,
                                                 bool want_uv) {
     w_shape_rec(H, w_local_ray<CHAINS>(xf, c, r), t, face, h, want_uv);
@@ -298,13 +293,14 @@ __device__ __forceinline__ int w_hitable_t(const pt_hitable &H, const pt_affine 
     const bool outer = MEDIA && CHAINS && chain.n_out != 0u;
     const WRay r = outer ? w_ray_into(xf, chain.first, chain.n_out, r_in) : r_in;
     face = 0u;
-    const bool ok = w_instanced_t<CHAINS>(H, xf, chain, r, medium ? -kMaxT : t_min, medium ? kMaxT : t_max, t, face);
+    const WRay local = w_local_ray<CHAINS>(xf, chain, r);   // (once for both questions of a medium)
+    const bool ok = w_shape_t(H, local, medium ? -kMaxT : t_min, medium ? kMaxT : t_max, t, face);
     if (!medium) return ok ? (int)H.material : -1;
     if (!ok) return -1;
     const float t_first = t;
     float t_second;
     uint32_t face2 = 0u;
-    if (!w_instanced_t<CHAINS>(H, xf, chain, r, t_first + 0.0001f, kMaxT, t_second, face2)) return -1;   // constant_medium.rs:41
+    if (!w_shape_t(H, local, t_first + 0.0001f, kMaxT, t_second, face2)) return -1;   // constant_medium.rs:41
     // constant_medium.rs:44-76
     float t1 = t_first, t2 = t_second;
     if (t1 < t_min) t1 = t_min;

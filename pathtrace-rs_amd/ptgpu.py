@@ -503,7 +503,7 @@ def shard_rows(height, shard_index, shard_count):
     return lib().pt_shard_rows(height, shard_index, shard_count)
 
 
-PROBE_POW5, PROBE_SIN, PROBE_COS, PROBE_RNG, PROBE_LN, PROBE_SWEEP_SQRT, PROBE_SWEEP_DRAWS, PROBE_SWEEP_INVLEN, PROBE_SWEEP_DIV, PROBE_SWEEP_DIVA = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+PROBE_POW5, PROBE_SIN, PROBE_COS, PROBE_RNG, PROBE_LN, PROBE_SWEEP_SQRT, PROBE_SWEEP_DRAWS, PROBE_SWEEP_INVLEN, PROBE_SWEEP_DIV, PROBE_SWEEP_DIVA, PROBE_SWEEP_RECIP = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
 def selftest_probe(probe, values, device=0):

@@ -1292,8 +1292,9 @@ def test_shortened_device_math_is_exhaustively_equal_to_what_it_replaces(ptgpu):
     steps of a general division (pt_device.h). All are unary in 32 bits, so the device simply tries every input: all 2^32 bit
     patterns for the square root and the reciprocal length, every draw beside 256 pixel coordinates for the rest. The normal's
     division by the radius (two operands) goes through 2^32 seeded pairs that include every special value, and so do the sphere
-    test's quotients by d.d (every divisor in [0.5, 2] for the once-per-ray reciprocal)."""
-    for probe in (ptgpu.PROBE_SWEEP_SQRT, ptgpu.PROBE_SWEEP_DRAWS, ptgpu.PROBE_SWEEP_INVLEN, ptgpu.PROBE_SWEEP_DIV, ptgpu.PROBE_SWEEP_DIVA):
+    test's quotients by d.d (every divisor in [0.5, 2] for the once-per-ray reciprocal); the general worlds' reciprocal ray direction
+    is checked on all 2^32 inputs."""
+    for probe in (ptgpu.PROBE_SWEEP_SQRT, ptgpu.PROBE_SWEEP_DRAWS, ptgpu.PROBE_SWEEP_INVLEN, ptgpu.PROBE_SWEEP_DIV, ptgpu.PROBE_SWEEP_DIVA, ptgpu.PROBE_SWEEP_RECIP):
         out = ptgpu.selftest_probe(probe, np.zeros(2, dtype=np.float32))
         assert out[0] == 0.0, (probe, float(out[0]), hex(int(out.view(np.uint32)[1])))
 
