@@ -244,6 +244,19 @@ __device__ __forceinline__ void sinf_cosf_ref(float xin, float &sin_out, float &
     cos_out = __uint_as_float(__float_as_uint(c) ^ sign_bit_cos);
 }
 
+// f32::sin of a Noise texture's argument (texture.rs:86-89). The value only colours (it never feeds control flow), and the tests
+// hold it to 2e-6 against the CPU's libm -- which differs from ANY other libm in the last ulp anyway. The device library's sinf
+// carries its large-argument (Payne-Hanek) reduction branch-free in some kernels: 380 VALU instructions per call in the
+// general-world kernel, 16 % of a `simple_light` frame. Arguments below 8192 -- `scale * z + 10 * turbulence` of any sensible
+// scene -- take the Cephes evaluation the path already has for its own sin / cos (sinf_cosf_ref: three-part pi/4 reduction, < 2
+// ulp there); a wave in which some lane's argument is larger, infinite or NaN calls the library.
+__device__ __forceinline__ float sin_colour(float x) {
+    float s, c;
+    sinf_cosf_ref(x, s, c);
+    if (__builtin_expect(wave_any(!(__builtin_fabsf(x) < 8192.0f)), 0)) s = sinf(x);
+    return s;
+}
+
 // ---- math.rs:6-34 sampling -------------------------------------------------
 // math.rs:6-13 (runs even when lens_radius == 0; 2 draws per iteration)
 __device__ __forceinline__ void random_in_unit_disk(Rng &rng, float &px, float &py) {

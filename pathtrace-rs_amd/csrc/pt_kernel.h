@@ -196,7 +196,7 @@ __device__ __forceinline__ f3 texture_value(const DTex *texs, const PerlinLds &p
         t = texs[checker_is_odd(s.x, s.y, s.z) ? t.odd : t.even];
     }
     if (t.kind == PT_TEX_NOISE) {
-        const float v1 = 1.0f + sinf(t.scale * p.z + 10.0f * perlin_turb(pn, p));
+        const float v1 = 1.0f + sin_colour(t.scale * p.z + 10.0f * perlin_turb(pn, p));
         return mk3(0.5f * v1, 0.5f * v1, 0.5f * v1);  // vec3(1,1,1) * 0.5 * (1 + sin(..))
     }
     if (t.kind == PT_TEX_IMAGE) return image_value(images, t.odd, u, v);
@@ -1765,7 +1765,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         return odd ? mk3(qa.x, qa.y, qa.z) : mk3(qb.x, qb.y, qb.z);
                     }
                     if (m.flags & kShadeNoise) {   // texture.rs:86-89, resolved here: no dependent fetch of the texture record
-                        const float v1 = 1.0f + sinf(qa.x * point.z + 10.0f * perlin_turb(pn, point));
+                        const float v1 = 1.0f + sin_colour(qa.x * point.z + 10.0f * perlin_turb(pn, point));
                         return mk3(0.5f * v1, 0.5f * v1, 0.5f * v1);
                     }
                     return texture_value(A.texs, pn, m.tex, point);
@@ -1786,7 +1786,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                             attc = (uint32_t)idx | (even ? 0x8000u : 0u);
                         } else if (WST) {
                             if (m.flags & kShadeNoise) {   // texture.rs:86-89 with the turbulence evaluated above
-                                const float v1 = 1.0f + sinf(qa.x * point.z + 10.0f * turb_pre);
+                                const float v1 = 1.0f + sin_colour(qa.x * point.z + 10.0f * turb_pre);
                                 attc = __float_as_uint(0.5f * v1);
                             } else {
                                 const bool even = (m.flags & kShadeChecker2) && !checker_is_odd(10.0f * point.x, 10.0f * point.y, 10.0f * point.z);
