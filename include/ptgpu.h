@@ -356,6 +356,10 @@ int pt_scene_debug_tree_packed(pt_scene *scene, void *nodes_out, size_t capacity
  *        pt_camera and shard) is ordered by the rays each tile took in that last frame, measured by the frame kernel itself;
  *        a frame of a new view (from 12 samples on) runs as two launches, the first tracing the first sample of every pixel for
  *        real while it counts the rays per tile. The order of the work never changes a pixel or the ray count.
+ * 65536 = no cooperative hand-over. Default on the wide (one workgroup per CU) MFMA list kernels: once the work list is dry, a wave
+ *        that has run out of pixels finishes pixels handed over by waves that still have some, all 64 lanes on each ray
+ *        (csrc/pt_coop.h; scene.rs:96-111 makes a pixel one serial chain, and this shortens the chain). A pixel's RNG stream
+ *        travels with it: who traces a pixel never changes it.
  * (Bits 4096, 16384 and 32768 of earlier versions were A/B switches of settled questions and are ignored.) */
 int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
 
@@ -368,6 +372,7 @@ typedef struct pt_kernel_choice {
     uint32_t stack_in_lds, global_stack, n_tiles;     /* attenuation-stack slots in LDS, some levels in HBM, MFMA tiles */
     uint32_t world_hit_lds, world_occ, world_media;   /* general-world kernel: <BVH = ref_bvh, HIT_LDS, OCC, MEDIA> */
     uint32_t refill_min;
+    uint32_t coop;                                    /* wide MFMA list kernels: waves that run out of work finish pixels handed over by busy ones, 64 lanes per ray (tuning bit 65536 switches it off) */
     char name[96];
 } pt_kernel_choice;
 /* The choice the scene's most recent render made. */
@@ -388,6 +393,10 @@ int pt_scene_debug_counters(pt_scene *scene, uint64_t out4[4], int reset);
  * to walk the internal tree): out2 = { nodes of the internal tree fetched, spheres tested exactly } summed over
  * all rays since the last reset (reported next to the oracle's counts for the caller's tree). */
 int pt_scene_traversal_counters(pt_scene *scene, uint64_t out2[2], int reset);
+
+/* Cooperative hand-over (csrc/pt_coop.h): out2 = { pixels handed over to idle waves, rays those waves traced } since the last
+ * reset. Synchronises the device. */
+int pt_scene_coop_counters(pt_scene *scene, uint64_t out2[2], int reset);
 
 /* Device self-test probes (diagnostics for the parity tests; not part of the reference's
  * interface): evaluate one device primitive on n host inputs.

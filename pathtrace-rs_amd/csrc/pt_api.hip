@@ -31,6 +31,8 @@ const DevKnobs &dev_knobs() {
         if (const char *e = getenv("PTGPU_PHASE1_REFILL")) d.phase1_refill = std::max(1, atoi(e));
         if (const char *e = getenv("PTGPU_CULL_AXIS")) d.cull_axis = atoi(e);
         if (const char *e = getenv("PTGPU_CULL_STRIPS")) d.cull_strips = atoi(e);
+        if (const char *e = getenv("PTGPU_COOP_LIVE")) d.coop_live = atoi(e);
+        if (const char *e = getenv("PTGPU_COOP_STREAK")) d.coop_streak = atoi(e);
         if (const char *e = getenv("PTGPU_HOST_THREADS")) d.host_threads = std::max(0, atoi(e));
         if (const char *e = getenv("PTGPU_BLOCKS_PER_CU")) d.blocks_per_cu = (uint32_t)atoi(e);
         if (const char *e = getenv("PTGPU_VARIANT")) d.variant = (uint32_t)atoi(e);
@@ -149,6 +151,7 @@ void fill_choice(const ptsel::KernelChoice &c, pt_kernel_choice *out) {
     out->stack_in_lds = c.stack_in_lds, out->global_stack = c.gstack, out->n_tiles = c.n_tiles;
     out->world_hit_lds = c.world_hit_lds, out->world_occ = c.world_occ, out->world_media = c.world_media;
     out->refill_min = c.refill_min;
+    out->coop = c.coop ? 1u : 0u;
     kernel_name(c, out->name, sizeof out->name);
 }
 }  // namespace
@@ -370,6 +373,15 @@ extern "C" int pt_scene_traversal_counters(pt_scene *s, uint64_t out2[2], int re
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out2, s->d_debug + 8, 16, hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(s->d_debug + 8, 0, 16));
+    return PT_OK;
+}
+
+extern "C" int pt_scene_coop_counters(pt_scene *s, uint64_t out2[2], int reset) {
+    if (!s || !out2) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out2, s->d_debug + 88, 16, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(s->d_debug + 88, 0, 16));
     return PT_OK;
 }
 

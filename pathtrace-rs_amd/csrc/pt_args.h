@@ -154,7 +154,15 @@ struct KArgs {
     float *rgb;
     uint32_t prev_zero;          // the caller vouches that the buffer holds +0.0f everywhere: the blend uses 0.0f instead of loading it
     unsigned long long *ray_count;
-    uint32_t *work_counter;
+    uint32_t *work_counter;      // [0] next work item; the other words of its 64-byte block: hand-over protocol of the cooperative mode (pt_coop.h)
+    // wave-cooperative mode of the wide list kernels (pt_coop.h): pixels handed from waves still in their main loop to waves that have left it
+    uint64_t *tail_box;          // [tail_cap][16] one mailbox per wave of the grid: a handed-over pixel (64 B), its state word, the exit word
+    uint32_t tail_cap;           // waves of the grid; 0: the mode is off for this launch
+    uint32_t tail_dry0;          // the frame has no more work items than the grid has lanes: the list is dry once every wave has fetched
+    uint32_t tail_gen;           // this launch's stamp in the mailboxes' words (never 0, below 2^30)
+    uint32_t tail_live_max;      // a wave with at most this many live pixels hands over to any idle worker it finds ...
+    uint32_t tail_streak;        // ... any wave does after this many probes in a row that found an idle worker
+    uint32_t tail_dbg;           // -DPT_DEVKNOBS builds (PTGPU_COOP_DBG): 1 no workers, 2 no probes, 4 no started / done counting
     const uint32_t *tile_order;  // optional permutation of the 8x8 work tiles (expensive tiles first)
     uint32_t *tile_cost;         // optional: rays spent per work tile (accumulated when a pixel completes): the pilot pass' result,
                                  // or what a frame kernel measures for the next frame of the same view

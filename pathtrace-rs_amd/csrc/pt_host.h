@@ -44,6 +44,7 @@ struct DevKnobs {
     int refill = -1, ready = -1, drain = -1, phase1_refill = -1, cull_axis = -1, cull_strips = -1;
     bool world_occ3 = false, debug = false, clamp_grid = false, timing = false;
     int host_threads = -1;
+    int coop_live = -1, coop_streak = -1;   // cooperative hand-over policy (pt_coop.h)
     uint32_t variant = 0, blocks_per_cu = 0;
 };
 const DevKnobs &dev_knobs();
@@ -122,7 +123,9 @@ struct pt_scene {
     size_t d_tile_cap = 0;
     uint4 *d_px_state = nullptr;                     // two-launch frames: parked (xoshiro state, colour sum) per pixel, 48 B each
     size_t d_px_state_pixels = 0;
-    uint32_t *d_work_counter = nullptr;
+    uint32_t *d_work_counter = nullptr;              // 64 bytes: [0] next work item, the rest the hand-over protocol of the cooperative mode (pt_coop.h)
+    uint64_t *d_tail_box = nullptr;                  // cooperative mode: one mailbox (128 B) per wave of the largest grid so far, stamped with the launch's generation
+    uint32_t tail_cap = 0, tail_gen = 0;
     unsigned long long *d_ray_count = nullptr;       // internal counter of the host-buffer entry point
     float *d_frame = nullptr;                        // internal frame (pt_scene_prepare's throw-away frame, unpinned fallback of pt_render)
     float *h_stage = nullptr;                        // pinned + mapped copy of the caller's pageable buffer: the kernels render into it over PCIe

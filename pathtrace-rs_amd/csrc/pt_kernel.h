@@ -1312,6 +1312,10 @@ __device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint
     }
 }
 
+}  // namespace ptdev
+#include "pt_coop.h"   // the wave-cooperative mode of the wide list kernels (one pixel per wave), built from the pieces above
+namespace ptdev {
+
 // SPH_LDS: list-mode sphere scan reads the (cx,cy,cz,r^2) table from LDS
 // (staged once per workgroup); otherwise from HBM/L2 through wave-uniform loads.
 // PILOT: the measuring launch that precedes the frame kernel of a new view (own symbol so profiles keep the two apart; A.phase == 1):
@@ -1340,6 +1344,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     // colours back from the per-sphere shading records, which live in LDS here. 18 instead of 108 bytes of LDS per lane.
     // (launch() only picks a wide kernel for scenes whose textures are all Constant or Checker-of-two-Constants.)
     constexpr bool PAL = (BLK != kBlock);
+    // The wide frame kernels hand pixels over to waves that have run out of work (pt_coop.h); A.tail_cap == 0 switches it off.
+    constexpr bool TAIL = PAL && !PILOT && !VERIFY;
     // 4-wide tree kernels: ONE 32-bit word per attenuation-stack level -- the grey value of a Noise texture as its float bits
     // (texture.rs:86-89 yields (v, v, v)), or a palette code like PAL's for everything else: 0xFFE00000 | even-checker bit << 20 |
     // record index (0xFFFFF = white). No arithmetic produces such a NaN pattern (canonical NaNs are 0x7FC00000 / 0xFFC00000).
@@ -1436,6 +1442,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         for (int k = tid; k < 768; k += BLK) s_perm[k] = (uint8_t)A.perlin_perm[k];
     }
     __syncthreads();
+    if (TAIL && A.tail_cap != 0u && tid == 0 && PT_COOP_DBG(4u)) atomicAdd(&A.work_counter[kCtlStarted], 1u);   // (counted per workgroup: pt_coop.h "end")
 
     PerlinLds pn{s_pvec, s_perm, false};
     // attenuation stack of this lane: the 768-thread kernels always have it in LDS; the 256-thread ones keep the first
@@ -1494,6 +1501,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     };
     float rtime = 0.f;  // ray.time (only MOVING kernels read it)
     bool first_claim = true;   // (wave-uniform: every lane of a wave takes part in its first fetch)
+    bool tail_dry = TAIL && A.tail_dry0 != 0u;     // TAIL, wave-uniform: the work list has run dry (from then on pixels may be handed over)
+    uint32_t tail_it = 0, tail_streak = 0, tail_rand = (blockIdx.x * (BLK / 64) + wave_id) * 2654435761u + 12345u;   // (wave-uniform)
 #if defined(PT_SECTIONS) || defined(PT_WAVEDBG)
 #define PT_WAVE_DETAIL 1   // development builds: per-wave iteration counts, first / last pixel, moment the work list ran dry
     uint32_t dbg_first_pxy = 0xffffffffu;
@@ -1592,12 +1601,21 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 }
             }
         }
-#ifdef PT_SKIP_EDGE
-        if (wave_ballot(have) == 0ull) {
-            if (wave_ballot(!exhausted) == 0ull) break;
-            continue;
+        // TAIL: once the list is dry, every few iterations a look into ONE other wave's mailbox (pt_coop.h): a load of a line nobody
+        // else polls, issued here and read at the end of the iteration, so its latency hides behind the iteration's work
+        uint64_t tail_probe = 0;
+        uint32_t tail_target = 0;
+        bool tail_polled = false;   // (wave-uniform)
+        if (TAIL && A.tail_cap != 0u) {
+            tail_dry = tail_dry || wave_any(exhausted);
+            tail_polled = tail_dry && PT_COOP_DBG(2u) && ((tail_it & 3u) == 0u || (uint32_t)__popcll(wave_ballot(have)) <= A.tail_live_max);
+            if (tail_polled) {
+                tail_rand = tail_rand * 1664525u + 1013904223u;
+                tail_target = __umulhi(tail_rand, A.tail_cap);
+                tail_probe = wt_load(A.tail_box + 16u * (size_t)tail_target + 8);
+            }
+            tail_it += 1u;
         }
-#endif
 #ifdef PT_WAVE_DETAIL
         if (A.wave_end) dbg_iters += 1;
 #endif
@@ -1914,6 +1932,25 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             }
         }
         PT_SEC(3);
+        if (TAIL && tail_polled) {
+            // Hand-over (pt_coop.h): the list is dry and the probed wave is an idle worker -- the lane at a sample boundary with the
+            // most estimated work left parks its pixel (RNG stream, colour sum, counters: the pixel's whole state between two samples)
+            // in that worker's mailbox, to be finished with all 64 lanes on each of its rays. At most one pixel per wave and iteration.
+            const bool idle = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tail_probe) == ((A.tail_gen << 2) | kBoxIdle) &&
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tail_probe >> 32)) == (A.tail_gen >> 30);
+            tail_streak = idle ? tail_streak + 1u : 0u;
+            const uint32_t live = (uint32_t)__popcll(wave_ballot(have));
+            if (idle && (live <= A.tail_live_max || tail_streak >= A.tail_streak)) {
+                const bool cand = have && need_cam;   // between two samples
+                const uint32_t done_s = sd >> 12;
+                const float est = (float)pix_rays * (float)(__float_as_uint(s_par[12].w) - done_s) * __builtin_amdgcn_rcpf((float)done_s);   // rays per sample so far x samples left
+                const uint32_t eb = (cand && est >= kCoopMinEst) ? __float_as_uint(est) : 0u;   // (NaN before the first sample: not >=)
+                const uint32_t mx = wave_max_u32(eb);
+                if (mx != 0u && eb == mx && lane == __builtin_ctzll(wave_ballot(eb == mx))) {
+                    if (coop_hand_over(A, tail_target, rng, col, pxy, done_s, pix_rays)) have = false;   // (not `finished`: nothing is written, the lane simply holds no pixel any more)
+                }
+            }
+        }
 #ifndef PT_SKIP_EDGE
         // The loop's only exit, at its very end. (A wave whose refill brought no pixel -- beyond the frame's edge, or the list ran dry --
         // used to skip the body with `continue` / leave with `break` from here up there. The compiler's structurizer turns such an edge
@@ -1923,6 +1960,21 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 #endif
     }
 
+    if (TAIL && A.tail_cap != 0u) {
+        // this wave hands nothing over any more (its mailbox stores were drained before their flags): count it, and become a worker --
+        // unless it is the last one out of a main loop: then nobody can hand anything over, and every worker is told so
+        uint32_t last = 0u;
+        if (lane == 0 && PT_COOP_DBG(4u)) {
+            // (the waves of a workgroup count in LDS -- the one spare word of the parameter block, zero since it was staged -- and only
+            // the last of them touches the global counters: 4 096 waves counting on one word cost a 2 ms frame 0.2 ms)
+            uint32_t *wg_done = reinterpret_cast<uint32_t *>(const_cast<float4 *>(s_par) + 13) + 3;
+            if (atomicAdd(wg_done, 1u) + 1u == (uint32_t)(BLK / 64))
+                last = (atomicAdd(&A.work_counter[kCtlDone], 1u) + 1u == ctl_load(A.work_counter + kCtlStarted)) ? 1u : 0u;
+        }
+        if (__builtin_amdgcn_readfirstlane((int)last) != 0) coop_broadcast_exit(A, A.tail_cap);
+        else if (PT_COOP_DBG(1u))
+            coop_worker<MOVING, GATE>(A, GATE ? GateSrc{s_gate, s_rank} : GateSrc{nullptr, nullptr}, mot, s_par, s_sph, s_shade, pn, blockIdx.x * (BLK / 64) + wave_id, wave_rays);
+    }
 #ifdef PT_SECTIONS
     PT_SEC(4);
     if (lane == 0)

@@ -122,6 +122,18 @@ int ensure_px_state(pt_scene *s, size_t pixels) {
     return PT_OK;
 }
 
+// cooperative mode (pt_coop.h): one mailbox per wave of the grid; its words are stamped with the launch's generation, so they are
+// cleared only here
+int ensure_tail(pt_scene *s, uint32_t waves) {
+    if (waves <= s->tail_cap) return PT_OK;
+    (void)hipFree(s->d_tail_box);
+    s->d_tail_box = nullptr, s->tail_cap = 0;
+    HIP_TRY(hipMalloc((void **)&s->d_tail_box, (size_t)waves * 128u));
+    HIP_TRY(hipMemset(s->d_tail_box, 0, (size_t)waves * 128u));
+    s->tail_cap = waves;
+    return PT_OK;
+}
+
 int ensure_gstack(pt_scene *s, size_t need_floats) {
     if (need_floats <= s->d_gstack_floats) return PT_OK;
     (void)hipFree(s->d_gstack);
@@ -162,7 +174,7 @@ int order_work(pt_scene *s, Args &A, const pt_params *params, const pt_camera *c
         measured_scale = A.samples * (params->max_depth + 1u);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
     A.tile_order = order;
     if ((s->variant & ptsel::kVarMeasureEveryFrame) == 0) {   // this frame measures the tiles for the next one (after the order kernel has read the old values)
         HIP_TRY(hipMemsetAsync(measured, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
@@ -192,7 +204,7 @@ int launch_world(pt_scene *s, const ptsel::KernelChoice &c, const pt_params *par
     W.bvh_stack_entries = c.bvh_stack_entries;
     W.stack_in_lds = c.stack_in_lds;
     fill_frame_args(W, s, params, cam, frame_num, shard_index, shard_count, d_rgb, d_ray_count, c);
-    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
     HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
     if (W.n_items == 0) {
         s->ev_valid = false;
@@ -314,7 +326,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.n_spheres = s->tr.n_spheres;
     A.n_spheres_pad = ptsel::scan_pad(s->tr.n_spheres);
     fill_frame_args(A, s, params, cam, frame_num, shard_index, shard_count, d_rgb, d_ray_count, c);
-    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
     HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
     if (A.n_items == 0) {
         s->ev_valid = false;
@@ -373,8 +385,20 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     // not cut down to the workgroups the pixels would fill (a wave that finds the queue empty leaves at once).
     const uint32_t need = (A.n_items + blk - 1) / blk;
     const bool wide = blk != (uint32_t)kBlock;
-    if (grid > need && !(wide && need * 4u >= grid && !dev_knobs().clamp_grid)) grid = need;
+    // (with the cooperative mode on, the waves that find no work of their own finish pixels handed over by the others: the full grid stays)
+    if (grid > need && !(wide && (c.coop || need * 4u >= grid) && !dev_knobs().clamp_grid)) grid = need;
     if (grid == 0) grid = 1;
+    if (c.coop) {
+        if (int rc = ensure_tail(s, grid * (blk / 64u))) return rc;
+        s->tail_gen = s->tail_gen >= 0x3fffffffu ? 1u : s->tail_gen + 1u;   // (a mailbox word keeps two bits below it)
+        A.tail_box = s->d_tail_box, A.tail_cap = grid * (blk / 64u), A.tail_gen = s->tail_gen;
+        A.tail_dry0 = A.n_items <= grid * blk ? 1u : 0u;
+#ifdef PT_DEVKNOBS
+        A.tail_dbg = getenv("PTGPU_COOP_DBG") ? (uint32_t)atoi(getenv("PTGPU_COOP_DBG")) : 0u;
+#endif
+        A.tail_live_max = dev_knobs().coop_live >= 0 ? (uint32_t)dev_knobs().coop_live : 4u;
+        A.tail_streak = dev_knobs().coop_streak >= 0 ? (uint32_t)dev_knobs().coop_streak : 2u;
+    }
     if (c.gstack) {
         if (int rc = ensure_gstack(s, (size_t)grid * params->max_depth * 3ull * blk)) return rc;
         A.gstack = s->d_gstack;
@@ -431,6 +455,19 @@ void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, h
             fprintf(stderr, "\n  lane histogram:");
             for (int i = 0; i < 18; ++i) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double)c[24 + i] / (double)(c[2] ? c[2] : 1));
             fprintf(stderr, "\n");
+        }
+    }
+#endif
+#ifdef PT_COOPSEC
+    {   // the cooperative workers' cycles (pt_coop.h)
+        (void)hipStreamSynchronize(stream);
+        unsigned long long c[8];
+        (void)hipMemcpy(c, s->d_debug + 80, sizeof c, hipMemcpyDeviceToHost);
+        (void)hipMemset(s->d_debug + 80, 0, sizeof c);
+        if (c[7]) {
+            const double rays = (double)(c[6] ? c[6] : 1);
+            fprintf(stderr, "[ptgpu coop] %llu pixels handed over, %llu rays traced by workers; cycles per ray: camera %.0f scan %.0f reduce %.0f shade %.0f fold %.0f\n", c[7], c[6],
+                    c[0] / rays, c[1] / rays, c[2] / rays, c[3] / rays, c[4] / rays);
         }
     }
 #endif

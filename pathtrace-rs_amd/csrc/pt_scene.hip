@@ -21,7 +21,7 @@ int device_for(int device, hipDeviceProp_t *prop) {
 // counters, events and the tuning defaults every scene has
 int finish_scene(pt_scene *s) {
     if (hipMalloc((void **)&s->d_debug, 1024) != hipSuccess || hipMemset(s->d_debug, 0, 1024) != hipSuccess ||
-        hipMalloc((void **)&s->d_work_counter, 64) != hipSuccess || hipMalloc((void **)&s->d_ray_count, 64) != hipSuccess ||
+        hipMalloc((void **)&s->d_work_counter, 64) != hipSuccess || hipMemset(s->d_work_counter, 0, 64) != hipSuccess || hipMalloc((void **)&s->d_ray_count, 64) != hipSuccess ||
         hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess || hipEventCreate(&s->ev_pass) != hipSuccess)
         return fail(PT_ERR_HIP, "allocating counters / events failed");
     s->blocks_per_cu = dev_knobs().blocks_per_cu;
@@ -234,7 +234,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
                          s->d_shade, s->d_sphere_mat, s->d_mats, s->d_texs, s->d_perlin_vec, s->d_perlin_perm, s->d_gate, s->d_gate_chain, s->d_bvh_large,
                          s->d_wnodes, s->d_nodes4, s->d_nodes4q, s->d_slotrec, s->d_rank_sphere, s->d_leafrec, s->d_shade_rank, s->d_leaf_rank, s->d_afrag,
                          s->d_tile_sphere, s->d_cull_tab, s->d_large, s->d_debug, s->d_tile_buf, s->d_px_state, s->d_work_counter, s->d_ray_count,
-                         s->d_frame, s->d_gstack, s->d_wave_end};
+                         s->d_frame, s->d_gstack, s->d_wave_end, s->d_tail_box};
     for (void *p : dev) (void)hipFree(p);
     (void)hipHostFree(s->h_stage);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);

@@ -37,6 +37,7 @@ enum : uint32_t {
     kVarNoCulling = 1024u,       // MFMA kernels run every tile
     kVarBinaryTree = 2048u,      // tree kernels walk the binary tree
     kVarMeasureEveryFrame = 8192u,   // no reuse of the previous frame's measured tile costs
+    kVarNoCoop = 65536u,         // wide list kernels: no hand-over of pixels to idle waves (pt_coop.h)
 };
 
 // Facts about a scene that kernel selection may look at. Filled by pt_scene_create*; never changes afterwards
@@ -83,6 +84,7 @@ struct KernelChoice {
     // values the kernels' LDS carve is driven by (copied into KArgs / WArgs)
     uint32_t sph_bytes = 0, n_tiles = 0, stack_in_lds = 0, nodes_in_lds = 0, bvh_stack_entries = 0, cull_off = 0;
     uint32_t refill_min = 4;
+    bool coop = false;          // wide list kernels: idle waves finish pixels handed over by busy ones, 64 lanes per ray (pt_coop.h)
 };
 
 struct Knobs {                  // tuning word + the development overrides (-1 / 0: library default)
@@ -227,6 +229,8 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     c.block = blk;
     c.family = bvh ? (tree4 ? Family::Tree4 : Family::TreeBinary) : (mfma ? Family::Mfma : (sph_lds ? Family::ScanLds : Family::ScanHbm));
     c.gate = mfma && ref_bvh;
+    // cooperative hand-over: the wide frame kernels; a path's attenuations live one level per lane there (depth <= 64), a lane's spheres in 8 register sets (<= 512 spheres)
+    c.coop = wide && !c.verify && p.max_depth <= 64u && t.n_spheres <= 512u && (v & kVarNoCoop) == 0;
     // refills are batched: 4 waiting lanes for long pixels, 8 when pixels are short (< 32 spp); 16-wave workgroups batch harder
     c.refill_min = p.samples < 32u ? 8u : 4u;
     if (blk == 1024u && p.samples >= 32u) c.refill_min = 12u;

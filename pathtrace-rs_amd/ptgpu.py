@@ -104,7 +104,7 @@ class PtWorldDesc(C.Structure):
 class PtKernelChoice(C.Structure):
     """pt_kernel_choice: which kernel a frame runs on (include/ptgpu.h)."""
     _fields_ = [(n, C.c_uint32) for n in ("family", "block", "lds_bytes", "blocks_per_cu", "moving", "gate", "verify", "ref_bvh", "ordered",
-                                          "stack_in_lds", "global_stack", "n_tiles", "world_hit_lds", "world_occ", "world_media", "refill_min")] + \
+                                          "stack_in_lds", "global_stack", "n_tiles", "world_hit_lds", "world_occ", "world_media", "refill_min", "coop")] + \
                [("name", C.c_char * 96)]
 
     def as_dict(self):
@@ -121,7 +121,7 @@ EXPORTS = [
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
     "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree", "pt_scene_debug_tree_packed",
-    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_comm_runtime", "pt_last_host_ms",
+    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters",
 ]
 COMM_ID_BYTES = 128
 
@@ -162,6 +162,7 @@ def lib():
         L.pt_selftest_probe.argtypes = [C.c_int, C.c_uint32, vp, vp, C.c_size_t]
         L.pt_scene_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.pt_scene_traversal_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+        L.pt_scene_coop_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.pt_last_pass_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pt_comm_unique_id.argtypes = [vp]
         L.pt_comm_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
@@ -357,6 +358,12 @@ class Scene:
         out = (C.c_uint64 * 4)()
         _check(lib().pt_scene_debug_counters(self._h, out, 1 if reset else 0))
         return dict(misses=out[0], candidates=out[1], overflows=out[2], exact_positives=out[3])
+
+    def coop_counters(self, reset=True):
+        """(pixels handed over to idle waves, rays those waves traced) since the last reset (csrc/pt_coop.h)."""
+        out = (C.c_uint64 * 2)()
+        _check(lib().pt_scene_coop_counters(self._h, out, 1 if reset else 0))
+        return dict(pixels=out[0], rays=out[1])
 
     def traversal_counters(self, reset=True):
         out = (C.c_uint64 * 2)()

@@ -360,6 +360,8 @@ def test_kernel_selection_table_for_every_preset(ptgpu, pthost, preset, bvh):
     assert (d["name"], d["lds_bytes"], d["blocks_per_cu"], d["stack_in_lds"]) == want, d
     assert d["ordered"] == 1 and d["global_stack"] == 0 and d["lds_bytes"] * d["blocks_per_cu"] <= 160 * 1024
     assert d["ref_bvh"] == int(bvh) and d["verify"] == 0
+    # the cooperative hand-over (csrc/pt_coop.h) rides on the wide MFMA list kernels and on nothing else
+    assert d["coop"] == int(d["name"].startswith("mfma<blk=1024") or d["name"].startswith("mfma<blk=768")), d
 
 
 def test_kernel_selection_follows_the_tuning_word_and_the_frame(ptgpu, pthost):
@@ -382,6 +384,8 @@ def test_kernel_selection_follows_the_tuning_word_and_the_frame(ptgpu, pthost):
     assert sel(depth=41)["name"] == "mfma<blk=256>" and sel(depth=41)["global_stack"] == 1       # ... nor 12: float stacks in HBM
     assert sel(blocks_per_cu=2)["name"] == "mfma<blk=256>" and sel(blocks_per_cu=2)["blocks_per_cu"] == 2
     assert sel(preset="random", variant=128)["name"].startswith("world<")                        # moving spheres on the general kernel
+    assert sel()["coop"] == 1 and sel(variant=65536)["coop"] == 0 and sel(variant=65536)["name"] == "mfma<blk=1024>"   # no hand-over to idle waves: same kernel
+    assert sel(depth=40)["coop"] == 1 and sel(depth=41)["coop"] == 0 and sel(variant=8)["coop"] == 0 and sel(variant=2)["coop"] == 0
     # a camera shutter outside the interval the moving spheres are defined on leaves the MOVING kernels (their sweeps do not cover it)
     hs = pthost.HostScene("random", 1200, 800, samples=64, device=None)
     cam = type(hs.camera).from_buffer_copy(hs.camera)
@@ -410,6 +414,8 @@ def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
     assert {n: names[n] for n in (12, 40, 300, 800, 2500)} == {12: "scan-lds<blk=256>", 40: "mfma<blk=1024>", 300: "mfma<blk=1024>",
                                                                800: "tree4<blk=256>", 2500: "tree4<blk=256>"}, names
     assert names[768].startswith("mfma<")          # 24 tiles: the last size whose fragments fit beside the rest
+    # the hand-over's workers keep a lane's spheres in eight register sets: up to 512 spheres
+    assert ptgpu.debug_select(cloud(512), p, cam)["coop"] == 1 and ptgpu.debug_select(cloud(513), p, cam)["coop"] == 0
     with pytest.raises(ptgpu.PtError):
         ptgpu.debug_select(cloud(40), ptgpu.PtParams(640, 480, 16, 10, 0, 1), cam)
 
