@@ -272,7 +272,11 @@ uint32_t pt_shard_rows(uint32_t height, uint32_t shard_index, uint32_t shard_cou
  * y % world == r (disjoint pixels, scene.rs:90-93), the float3 shards are collected with ONE ncclAllGather (or
  * ncclGather to `root`) over xGMI and the per-rank ray counts are summed with an 8-byte ncclAllReduce
  * (scene.rs:118-120). No collective happens while rendering. One process per GPU (pt_comm_create, the unique id
- * travels over any host channel) or one process driving several GPUs (pt_comm_create_all with a device list). */
+ * travels over any host channel) or one process driving several GPUs (pt_comm_create_all with a device list).
+ * Threading of the second form: RCCL requires that collectives which ONE thread issues for several communicators sit inside
+ * one group, otherwise the first rank's call waits for peers the thread has not reached yet. pt_comm_gather_frame and
+ * pt_render_sharded issue ONE rank's collectives (their own group): call them from one thread PER communicator -- or use the
+ * *_all forms below, which take every rank of the clique and put all their collectives into a single group. */
 typedef struct pt_comm pt_comm;
 #define PT_COMM_ID_BYTES 128 /* sizeof(ncclUniqueId) */
 
@@ -303,6 +307,18 @@ int pt_comm_gather_frame(pt_comm *comm, uint32_t width, uint32_t height, const f
 int pt_render_sharded(pt_scene *scene, pt_comm *comm, const pt_params *params, const pt_camera *camera,
                       uint32_t frame_num, float *d_rgb_full_inout, uint64_t *d_ray_count, int root,
                       void *hip_stream);
+
+/* The same for ALL ranks of a pt_comm_create_all clique from one thread: comms[i] must be rank i of n. Per rank i: scenes[i]
+ * (a scene on comms[i]'s device), d_rgb_full_inout[i] / d_rgb_shards[i] / d_rgb_fulls[i], d_ray_counts[i] (8 bytes on that
+ * device) and hip_streams[i] (NULL array: the default streams). Every rank's pack and render is enqueued first, then all ranks'
+ * collectives inside ONE ncclGroupStart / ncclGroupEnd, then the unpack kernels. Buffers a rank does not need (the full frame
+ * on ranks that do not receive it, root >= 0) may be NULL exactly as in the one-rank forms. */
+int pt_render_sharded_all(pt_scene *const *scenes, pt_comm *const *comms, uint32_t n, const pt_params *params,
+                          const pt_camera *camera, uint32_t frame_num, float *const *d_rgb_full_inout,
+                          uint64_t *const *d_ray_counts, int root, void *const *hip_streams);
+int pt_comm_gather_frame_all(pt_comm *const *comms, uint32_t n, uint32_t width, uint32_t height,
+                             const float *const *d_rgb_shards, float *const *d_rgb_fulls, uint64_t *const *d_ray_counts,
+                             int root, void *const *hip_streams);
 
 /* The two layout kernels of the sharded path, exposed so that a single GPU can check them (and so that a caller
  * with its own transport can reuse them): full frame -> one rank's compact shard, and the gathered

@@ -372,7 +372,10 @@ extern "C" int pt_scene_traversal_counters(pt_scene *s, uint64_t out2[2], int re
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out2, s->d_debug + 8, 16, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(s->d_debug + 8, 0, 16));
+    if (reset) {
+        HIP_TRY(hipMemset(s->d_debug + 8, 0, 16));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
     return PT_OK;
 }
 
@@ -381,7 +384,10 @@ extern "C" int pt_scene_coop_counters(pt_scene *s, uint64_t out2[2], int reset) 
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out2, s->d_debug + 88, 16, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(s->d_debug + 88, 0, 16));
+    if (reset) {
+        HIP_TRY(hipMemset(s->d_debug + 88, 0, 16));
+        HIP_TRY(hipStreamSynchronize(nullptr));   // (later launches may use non-blocking streams, which do not wait for the NULL stream)
+    }
     return PT_OK;
 }
 
@@ -390,6 +396,9 @@ extern "C" int pt_scene_debug_counters(pt_scene *s, uint64_t out4[4], int reset)
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out4, s->d_debug, 32, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(hipMemset(s->d_debug, 0, 1024));
+    if (reset) {
+        HIP_TRY(hipMemset(s->d_debug, 0, 1024));
+        HIP_TRY(hipStreamSynchronize(nullptr));
+    }
     return PT_OK;
 }

@@ -144,7 +144,9 @@ __global__ void shard_unpack_kernel(const float *gathered, float *full, uint32_t
 
 uint32_t copy_grid(size_t n) { return (uint32_t)std::min<size_t>((n + 255) / 256, 4096); }
 
-int comm_ensure(pt_comm *c, uint32_t width, uint32_t height) {
+// (the clearing memset runs on the CALLER's stream: a NULL-stream hipMemset is not ordered against a non-blocking stream, and what is
+// enqueued next on `stream` writes this rank's rows into the buffer -- found by tests/mock_rccl: whole shards arrived as zeros)
+int comm_ensure(pt_comm *c, uint32_t width, uint32_t height, hipStream_t stream) {
     const uint32_t prow = (height + c->world - 1) / c->world;
     const size_t need = (size_t)c->world * prow * width * 3u;
     if (need <= c->gather_floats) return PT_OK;
@@ -153,31 +155,84 @@ int comm_ensure(pt_comm *c, uint32_t width, uint32_t height) {
     c->gather_floats = 0;
     c->slot_valid = false;
     HIP_TRY(hipMalloc((void **)&c->d_gather, need * sizeof(float)));
-    HIP_TRY(hipMemset(c->d_gather, 0, need * sizeof(float)));   // ranks with one row less send a zero row
+    HIP_TRY(hipMemsetAsync(c->d_gather, 0, need * sizeof(float), stream));   // ranks with one row less send a zero row
     c->gather_floats = need;
     return PT_OK;
 }
 
-// shard already sits in slot `rank` of c->d_gather
-int comm_exchange(pt_comm *c, uint32_t width, uint32_t height, float *d_rgb_full, uint64_t *d_ray_count, int root, hipStream_t stream) {
+// The exchange of one rank, in two halves so that several ranks driven by ONE thread can share a group (RCCL: collectives of
+// different communicators issued by one thread must sit inside one ncclGroupStart / ncclGroupEnd, or the first rank's call
+// waits for peers that this thread has not reached yet). The shard already sits in slot `rank` of c->d_gather.
+int comm_post(pt_comm *c, uint32_t width, uint32_t height, uint64_t *d_ray_count, int root, hipStream_t stream) {
     const uint32_t prow = (height + c->world - 1) / c->world;
     const size_t slot = (size_t)prow * width * 3u;
+    const Rccl *R = c->R;
+    if (root < 0)
+        NCCL_TRY(R, R->AllGather(c->d_gather + (size_t)c->rank * slot, c->d_gather, slot, ncclFloat, c->comm, stream));
+    else
+        NCCL_TRY(R, R->Gather(c->d_gather + (size_t)c->rank * slot, c->d_gather, slot, ncclFloat, root, c->comm, stream));
+    NCCL_TRY(R, R->AllReduce(d_ray_count, d_ray_count, 1, ncclUint64, ncclSum, c->comm, stream));
+    return PT_OK;
+}
+int comm_unpack(pt_comm *c, uint32_t width, uint32_t height, float *d_rgb_full, int root, hipStream_t stream) {
+    if (root >= 0 && (uint32_t)root != c->rank) return PT_OK;   // this rank does not receive the frame
+    const uint32_t prow = (height + c->world - 1) / c->world;
+    const size_t n = (size_t)height * width * 3u;
+    hipLaunchKernelGGL(shard_unpack_kernel, dim3(copy_grid(n)), dim3(256), 0, stream, c->d_gather, d_rgb_full, width * 3u, height, c->world, prow);
+    HIP_TRY(hipGetLastError());
+    return PT_OK;
+}
+// one group around the posts of `n` ranks; the group is closed on EVERY path (an open group would swallow the thread's later calls)
+template <typename Post>
+int comm_grouped(const Rccl *R, uint32_t n, Post post) {
+    NCCL_TRY(R, R->GroupStart());
+    int rc = PT_OK;
+    for (uint32_t i = 0; i < n && rc == PT_OK; ++i) rc = post(i);
+    const ncclResult_t e = R->GroupEnd();
+    if (rc != PT_OK) return rc;   // (pt_last_error holds the post's message)
+    if (e != ncclSuccess) return fail(PT_ERR_HIP, "ncclGroupEnd failed: %s", R->GetErrorString(e));
+    return PT_OK;
+}
+int comm_exchange(pt_comm *c, uint32_t width, uint32_t height, float *d_rgb_full, uint64_t *d_ray_count, int root, hipStream_t stream) {
     const bool have_frame = root < 0 || (uint32_t)root == c->rank;
     if (have_frame && !d_rgb_full) return fail(PT_ERR_INVALID_ARG, "d_rgb_full is NULL on a rank that receives the frame");
-    const Rccl *R = c->R;
-    {   // (a one-rank communicator goes through the same calls: that is what a 1-GPU box can test)
-        NCCL_TRY(R, R->GroupStart());
-        if (root < 0)
-            NCCL_TRY(R, R->AllGather(c->d_gather + (size_t)c->rank * slot, c->d_gather, slot, ncclFloat, c->comm, stream));
-        else
-            NCCL_TRY(R, R->Gather(c->d_gather + (size_t)c->rank * slot, c->d_gather, slot, ncclFloat, root, c->comm, stream));
-        NCCL_TRY(R, R->AllReduce(d_ray_count, d_ray_count, 1, ncclUint64, ncclSum, c->comm, stream));
-        NCCL_TRY(R, R->GroupEnd());
+    // (a one-rank communicator goes through the same calls: that is what a 1-GPU box can test with the real RCCL)
+    if (int rc = comm_grouped(c->R, 1u, [&](uint32_t) { return comm_post(c, width, height, d_ray_count, root, stream); })) return rc;
+    return comm_unpack(c, width, height, d_rgb_full, root, stream);
+}
+
+// checks shared by the one-rank and the all-ranks forms of pt_render_sharded; prepares the rank's slot and enqueues its render
+int sharded_render_one(pt_scene *s, pt_comm *c, const pt_params *params, const pt_camera *cam, uint32_t frame_num, float *d_rgb_full_inout, uint64_t *d_ray_count,
+                       int root, hipStream_t stream) {
+    if (!s || !c || !d_ray_count) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (s->device != c->device) return fail(PT_ERR_INVALID_ARG, "scene lives on device %d, communicator on %d", s->device, c->device);
+    if (root >= (int)c->world) return fail(PT_ERR_INVALID_ARG, "root %d out of range (%u ranks)", root, c->world);
+    HIP_TRY(hipSetDevice(c->device));
+    if (int rc = comm_ensure(c, params->width, params->height, stream)) return rc;
+    const uint32_t prow = (params->height + c->world - 1) / c->world;
+    float *slot = c->d_gather + (size_t)c->rank * prow * params->width * 3u;
+    // The blend reads the previous frame (scene.rs:114-116): this rank's rows. After an all-gather every rank's full buffer is
+    // current, and they are packed out of it. A rank that does NOT receive the frame (root >= 0, another rank) has a stale
+    // buffer; its gather slot still holds exactly the rows it rendered for the frame before, so those are kept instead.
+    const bool receives = root < 0 || (uint32_t)root == c->rank;
+    if (receives && !d_rgb_full_inout) return fail(PT_ERR_INVALID_ARG, "d_rgb_full_inout is NULL on a rank that receives the frame");
+    const bool slot_is_previous = c->slot_valid && frame_num > 0 && c->slot_frame + 1u == frame_num && c->slot_w == params->width && c->slot_h == params->height;
+    if (!(slot_is_previous && !receives)) {
+        if (!d_rgb_full_inout) return fail(PT_ERR_INVALID_ARG, "d_rgb_full_inout is NULL and the communicator does not hold this rank's previous rows");
+        if (int rc = pt_shard_pack(d_rgb_full_inout, slot, params->width, params->height, c->rank, c->world, stream)) return rc;
     }
-    if (have_frame) {
-        const size_t n = (size_t)height * width * 3u;
-        hipLaunchKernelGGL(shard_unpack_kernel, dim3(copy_grid(n)), dim3(256), 0, stream, c->d_gather, d_rgb_full, width * 3u, height, c->world, prow);
-        HIP_TRY(hipGetLastError());
+    c->slot_valid = false;
+    if (int rc = launch(s, params, cam, frame_num, c->rank, c->world, slot, d_ray_count, stream)) return rc;
+    c->slot_valid = true, c->slot_frame = frame_num, c->slot_w = params->width, c->slot_h = params->height;
+    return PT_OK;
+}
+
+// the communicators of a pt_*_all call: one clique, one process, in rank order
+int check_clique(pt_comm *const *comms, uint32_t n) {
+    if (!comms || n == 0) return fail(PT_ERR_INVALID_ARG, "no communicators");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!comms[i]) return fail(PT_ERR_INVALID_ARG, "comms[%u] is NULL", i);
+        if (comms[i]->world != n || comms[i]->rank != i) return fail(PT_ERR_INVALID_ARG, "comms[%u] is rank %u of %u: pass all %u communicators of pt_comm_create_all in rank order", i, comms[i]->rank, comms[i]->world, comms[i]->world);
     }
     return PT_OK;
 }
@@ -290,43 +345,77 @@ extern "C" int pt_shard_unpack_all(const float *d_gathered, float *d_rgb_full, u
     return PT_OK;
 }
 
-extern "C" int pt_comm_gather_frame(pt_comm *c, uint32_t width, uint32_t height, const float *d_rgb_shard, float *d_rgb_full, uint64_t *d_ray_count, int root,
-                                    void *hip_stream) {
-    if (!c || !d_rgb_shard || !d_ray_count || width == 0 || height == 0) return fail(PT_ERR_INVALID_ARG, "NULL argument / empty frame");
-    if (root >= (int)c->world) return fail(PT_ERR_INVALID_ARG, "root %d out of range (%u ranks)", root, c->world);
+// copy a rank's compact shard into its gather slot
+static int stage_shard(pt_comm *c, uint32_t width, uint32_t height, const float *d_rgb_shard, hipStream_t stream) {
     HIP_TRY(hipSetDevice(c->device));
-    if (int rc = comm_ensure(c, width, height)) return rc;
-    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (int rc = comm_ensure(c, width, height, stream)) return rc;
     const uint32_t prow = (height + c->world - 1) / c->world, rows = pt_shard_rows(height, c->rank, c->world);
     c->slot_valid = false;   // (the slot now holds whatever the caller rendered: only pt_render_sharded knows which frame that is)
     if (rows)
         HIP_TRY(hipMemcpyAsync(c->d_gather + (size_t)c->rank * prow * width * 3u, d_rgb_shard, (size_t)rows * width * 3u * sizeof(float), hipMemcpyDeviceToDevice,
                                stream));
+    return PT_OK;
+}
+
+extern "C" int pt_comm_gather_frame(pt_comm *c, uint32_t width, uint32_t height, const float *d_rgb_shard, float *d_rgb_full, uint64_t *d_ray_count, int root,
+                                    void *hip_stream) {
+    if (!c || !d_rgb_shard || !d_ray_count || width == 0 || height == 0) return fail(PT_ERR_INVALID_ARG, "NULL argument / empty frame");
+    if (root >= (int)c->world) return fail(PT_ERR_INVALID_ARG, "root %d out of range (%u ranks)", root, c->world);
+    hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
+    if (int rc = stage_shard(c, width, height, d_rgb_shard, stream)) return rc;
     return comm_exchange(c, width, height, d_rgb_full, d_ray_count, root, stream);
+}
+
+extern "C" int pt_comm_gather_frame_all(pt_comm *const *comms, uint32_t n, uint32_t width, uint32_t height, const float *const *d_rgb_shards, float *const *d_rgb_fulls,
+                                        uint64_t *const *d_ray_counts, int root, void *const *hip_streams) {
+    if (int rc = check_clique(comms, n)) return rc;
+    if (!d_rgb_shards || !d_rgb_fulls || !d_ray_counts || width == 0 || height == 0) return fail(PT_ERR_INVALID_ARG, "NULL argument / empty frame");
+    if (root >= (int)n) return fail(PT_ERR_INVALID_ARG, "root %d out of range (%u ranks)", root, n);
+    const auto stream_of = [&](uint32_t i) { return reinterpret_cast<hipStream_t>(hip_streams ? hip_streams[i] : nullptr); };
+    for (uint32_t i = 0; i < n; ++i) {
+        const bool receives = root < 0 || (uint32_t)root == i;
+        if (!d_rgb_shards[i] || !d_ray_counts[i] || (receives && !d_rgb_fulls[i])) return fail(PT_ERR_INVALID_ARG, "NULL buffer for rank %u", i);
+        if (int rc = stage_shard(comms[i], width, height, d_rgb_shards[i], stream_of(i))) return rc;
+    }
+    if (int rc = comm_grouped(comms[0]->R, n, [&](uint32_t i) {
+            (void)hipSetDevice(comms[i]->device);
+            return comm_post(comms[i], width, height, d_ray_counts[i], root, stream_of(i));
+        }))
+        return rc;
+    for (uint32_t i = 0; i < n; ++i) {
+        HIP_TRY(hipSetDevice(comms[i]->device));
+        if (int rc = comm_unpack(comms[i], width, height, d_rgb_fulls[i], root, stream_of(i))) return rc;
+    }
+    return PT_OK;
 }
 
 extern "C" int pt_render_sharded(pt_scene *s, pt_comm *c, const pt_params *params, const pt_camera *cam, uint32_t frame_num, float *d_rgb_full_inout,
                                  uint64_t *d_ray_count, int root, void *hip_stream) {
     if (!s || !c || !params || !cam || !d_ray_count) return fail(PT_ERR_INVALID_ARG, "NULL argument");
     if (params->width == 0 || params->height == 0 || params->samples == 0) return fail(PT_ERR_INVALID_ARG, "width/height/samples must be non-zero");
-    if (s->device != c->device) return fail(PT_ERR_INVALID_ARG, "scene lives on device %d, communicator on %d", s->device, c->device);
-    if (root >= (int)c->world) return fail(PT_ERR_INVALID_ARG, "root %d out of range (%u ranks)", root, c->world);
-    HIP_TRY(hipSetDevice(c->device));
-    if (int rc = comm_ensure(c, params->width, params->height)) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(hip_stream);
-    const uint32_t prow = (params->height + c->world - 1) / c->world;
-    float *slot = c->d_gather + (size_t)c->rank * prow * params->width * 3u;
-    // The blend reads the previous frame (scene.rs:114-116): this rank's rows. After an all-gather every rank's full buffer is
-    // current, and they are packed out of it. A rank that does NOT receive the frame (root >= 0, another rank) has a stale
-    // buffer; its gather slot still holds exactly the rows it rendered for the frame before, so those are kept instead.
-    const bool receives = root < 0 || (uint32_t)root == c->rank;
-    const bool slot_is_previous = c->slot_valid && frame_num > 0 && c->slot_frame + 1u == frame_num && c->slot_w == params->width && c->slot_h == params->height;
-    if (!(slot_is_previous && !receives)) {
-        if (!d_rgb_full_inout) return fail(PT_ERR_INVALID_ARG, "d_rgb_full_inout is NULL and the communicator does not hold this rank's previous rows");
-        if (int rc = pt_shard_pack(d_rgb_full_inout, slot, params->width, params->height, c->rank, c->world, hip_stream)) return rc;
-    }
-    c->slot_valid = false;
-    if (int rc = launch(s, params, cam, frame_num, c->rank, c->world, slot, d_ray_count, stream)) return rc;
-    c->slot_valid = true, c->slot_frame = frame_num, c->slot_w = params->width, c->slot_h = params->height;
+    if (int rc = sharded_render_one(s, c, params, cam, frame_num, d_rgb_full_inout, d_ray_count, root, stream)) return rc;
     return comm_exchange(c, params->width, params->height, d_rgb_full_inout, d_ray_count, root, stream);
+}
+
+extern "C" int pt_render_sharded_all(pt_scene *const *scenes, pt_comm *const *comms, uint32_t n, const pt_params *params, const pt_camera *cam, uint32_t frame_num,
+                                     float *const *d_rgb_full_inout, uint64_t *const *d_ray_counts, int root, void *const *hip_streams) {
+    if (int rc = check_clique(comms, n)) return rc;
+    if (!scenes || !params || !cam || !d_rgb_full_inout || !d_ray_counts) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (params->width == 0 || params->height == 0 || params->samples == 0) return fail(PT_ERR_INVALID_ARG, "width/height/samples must be non-zero");
+    if (root >= (int)n) return fail(PT_ERR_INVALID_ARG, "root %d out of range (%u ranks)", root, n);
+    const auto stream_of = [&](uint32_t i) { return reinterpret_cast<hipStream_t>(hip_streams ? hip_streams[i] : nullptr); };
+    // every rank's pack + render first (nothing here waits for a peer), then ALL ranks' collectives inside one group, then the unpacks
+    for (uint32_t i = 0; i < n; ++i)
+        if (int rc = sharded_render_one(scenes[i], comms[i], params, cam, frame_num, d_rgb_full_inout[i], d_ray_counts[i], root, stream_of(i))) return rc;
+    if (int rc = comm_grouped(comms[0]->R, n, [&](uint32_t i) {
+            (void)hipSetDevice(comms[i]->device);
+            return comm_post(comms[i], params->width, params->height, d_ray_counts[i], root, stream_of(i));
+        }))
+        return rc;
+    for (uint32_t i = 0; i < n; ++i) {
+        HIP_TRY(hipSetDevice(comms[i]->device));
+        if (int rc = comm_unpack(comms[i], params->width, params->height, d_rgb_full_inout[i], root, stream_of(i))) return rc;
+    }
+    return PT_OK;
 }

@@ -124,12 +124,12 @@ int ensure_px_state(pt_scene *s, size_t pixels) {
 
 // cooperative mode (pt_coop.h): one mailbox per wave of the grid; its words are stamped with the launch's generation, so they are
 // cleared only here
-int ensure_tail(pt_scene *s, uint32_t waves) {
+int ensure_tail(pt_scene *s, uint32_t waves, hipStream_t stream) {
     if (waves <= s->tail_cap) return PT_OK;
     (void)hipFree(s->d_tail_box);
     s->d_tail_box = nullptr, s->tail_cap = 0;
     HIP_TRY(hipMalloc((void **)&s->d_tail_box, (size_t)waves * 128u));
-    HIP_TRY(hipMemset(s->d_tail_box, 0, (size_t)waves * 128u));
+    HIP_TRY(hipMemsetAsync(s->d_tail_box, 0, (size_t)waves * 128u, stream));   // (on the launch's stream: a NULL-stream memset is not ordered against a non-blocking one)
     s->tail_cap = waves;
     return PT_OK;
 }
@@ -389,7 +389,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (grid > need && !(wide && (c.coop || need * 4u >= grid) && !dev_knobs().clamp_grid)) grid = need;
     if (grid == 0) grid = 1;
     if (c.coop) {
-        if (int rc = ensure_tail(s, grid * (blk / 64u))) return rc;
+        if (int rc = ensure_tail(s, grid * (blk / 64u), stream)) return rc;
         s->tail_gen = s->tail_gen >= 0x3fffffffu ? 1u : s->tail_gen + 1u;   // (a mailbox word keeps two bits below it)
         A.tail_box = s->d_tail_box, A.tail_cap = grid * (blk / 64u), A.tail_gen = s->tail_gen;
         A.tail_dry0 = A.n_items <= grid * blk ? 1u : 0u;

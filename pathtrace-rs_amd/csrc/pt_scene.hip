@@ -24,6 +24,8 @@ int finish_scene(pt_scene *s) {
         hipMalloc((void **)&s->d_work_counter, 64) != hipSuccess || hipMemset(s->d_work_counter, 0, 64) != hipSuccess || hipMalloc((void **)&s->d_ray_count, 64) != hipSuccess ||
         hipEventCreate(&s->ev_start) != hipSuccess || hipEventCreate(&s->ev_stop) != hipSuccess || hipEventCreate(&s->ev_pass) != hipSuccess)
         return fail(PT_ERR_HIP, "allocating counters / events failed");
+    // (the uploads and clears above ran on the NULL stream, which a caller's non-blocking stream does not wait for)
+    if (hipDeviceSynchronize() != hipSuccess) return fail(PT_ERR_HIP, "hipDeviceSynchronize failed");
     s->blocks_per_cu = dev_knobs().blocks_per_cu;
     s->variant = dev_knobs().variant;
     if (dev_knobs().timing && hipMalloc((void **)&s->d_wave_end, 65536 * 8) != hipSuccess) s->d_wave_end = nullptr;

@@ -121,7 +121,7 @@ EXPORTS = [
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
     "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree", "pt_scene_debug_tree_packed",
-    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters",
+    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters", "pt_render_sharded_all", "pt_comm_gather_frame_all",
 ]
 COMM_ID_BYTES = 128
 
@@ -173,6 +173,8 @@ def lib():
         L.pt_comm_gather_frame.argtypes = [vp, C.c_uint32, C.c_uint32, vp, vp, vp, C.c_int, vp]
         L.pt_render_sharded.argtypes = [vp, vp, C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, vp, vp, C.c_int, vp]
         L.pt_shard_pack.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+        L.pt_render_sharded_all.argtypes = [C.POINTER(vp), C.POINTER(vp), C.c_uint32, C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.c_int, C.POINTER(vp)]
+        L.pt_comm_gather_frame_all.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, C.POINTER(vp)]
         L.pt_shard_unpack_all.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
         L.pt_scene_build_info.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.pt_scene_debug_tree.argtypes = [vp, vp, C.c_size_t]
@@ -487,6 +489,24 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def _ptr_array(values):
+    return (C.c_void_p * len(values))(*[v if isinstance(v, (int, type(None))) else v.value for v in values])
+
+
+def render_sharded_all(scenes, comms, params, camera, frame_num, d_full_ptrs, d_ray_count_ptrs, root=-1, streams=None):
+    """pt_render_sharded_all: every rank of a Comm.create_all clique from ONE thread -- all ranks' collectives inside one RCCL group."""
+    n = len(comms)
+    _check(lib().pt_render_sharded_all(_ptr_array([s._h for s in scenes]), _ptr_array([c._h for c in comms]), n, C.byref(params), C.byref(camera), frame_num,
+                                       _ptr_array(d_full_ptrs), _ptr_array(d_ray_count_ptrs), root, _ptr_array(streams) if streams else None))
+
+
+def gather_frame_all(comms, width, height, d_shard_ptrs, d_full_ptrs, d_ray_count_ptrs, root=-1, streams=None):
+    """pt_comm_gather_frame_all: the exchange step alone for every rank of the clique, one RCCL group."""
+    n = len(comms)
+    _check(lib().pt_comm_gather_frame_all(_ptr_array([c._h for c in comms]), n, width, height, _ptr_array(d_shard_ptrs), _ptr_array(d_full_ptrs),
+                                          _ptr_array(d_ray_count_ptrs), root, _ptr_array(streams) if streams else None))
 
 
 def buffer_register(array):

@@ -8,6 +8,8 @@ sinf() (noise textures); see DESIGN.md "Parity".
 """
 import ctypes as C
 import glob
+import json
+import subprocess
 import importlib.util
 import os
 import sys
@@ -598,6 +600,49 @@ def test_communicators_from_a_device_list_and_side_by_side(ptgpu, pthost):
     b.close()
     with pytest.raises(ptgpu.PtError):
         ptgpu.Comm.create_all([7])                       # no such device
+
+
+MOCK_RCCL = os.path.join(ROOT, "tests", "mock_rccl")
+
+
+def _mock_rccl_dir():
+    """tests/mock_rccl/_build/librccl.so.1, (re)built with hipcc when the source is newer."""
+    src, out = os.path.join(MOCK_RCCL, "mock_rccl.hip"), os.path.join(MOCK_RCCL, "_build", "librccl.so.1")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-I/opt/rocm/include", src, "-o", out])
+    return os.path.dirname(out)
+
+
+@pytest.mark.parametrize("ranks,root,height,mode,extra", [
+    (2, -1, 51, "sharded_all", []),                  # all-gather, H not divisible by N, all ranks from one thread in ONE group
+    (2, 1, 50, "sharded_all", ["--null-stale"]),     # gather to the last rank; the other passes NULL from frame 1 on (its slot keeps its rows)
+    (3, 0, 50, "sharded", ["--null-stale"]),         # one rank per call, issue order alternating between frames
+    (3, -1, 50, "gather", []),                       # caller-owned shards + pt_comm_gather_frame per rank
+    (8, -1, 50, "sharded_all", []),                  # the 8-GPU node's geometry: ranks 2..7 own one row less than ranks 0, 1
+    (8, 7, 50, "gather_all", []),
+    (8, 0, 20, "sharded", []),
+])
+def test_sharded_frames_on_an_rccl_test_double(ptgpu, ranks, root, height, mode, extra):
+    """The N > 1 paths of the C ABI (include/ptgpu.h "multi-GPU frames") EXECUTED on a 1-GPU box: a child process that never loads
+    torch resolves tests/mock_rccl (a test double of the eleven RCCL entry points: N ranks on one device, collectives performed as
+    stream-ordered device copies once every rank has posted them) and renders progressive frames over N communicators of
+    pt_comm_create_all([0] * N). Every receiving rank's frame equals the unsharded pt_render_device frame bit for bit, every rank's
+    ray count equals the unsharded count (scene.rs:90-93, 118-120), and no RCCL group is left open. This exercises OUR offsets,
+    slots, root handling and grouping -- not RCCL itself: the real library at N > 1 is still unexecuted."""
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = _mock_rccl_dir() + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    # every rank's stream gets a hardware queue of its own: all ranks share ONE device here, and a stream parked inside a collective
+    # must not hold back another rank's render behind it in the same queue (on a real node every rank has its own device)
+    env["GPU_MAX_HW_QUEUES"] = "16"
+    cmd = [sys.executable, os.path.join(MOCK_RCCL, "run_sharded.py"), "--ranks", str(ranks), "--root", str(root), "--height", str(height), "--mode", mode,
+           "--frames", "3"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["ok"] and "mock_rccl" in res["rccl_path"] and res["rccl_version"] % 10000 == 9900, res   # the double, not the real RCCL
+    receiving = ranks if root < 0 else 1
+    assert res["checks"] == 3 * (ranks + receiving), res
 
 
 def test_cli_offline_render_matches_reference_harness(pthost, oracle, tmp_path):
