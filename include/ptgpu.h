@@ -414,6 +414,20 @@ int pt_scene_traversal_counters(pt_scene *scene, uint64_t out2[2], int reset);
  * reset. Synchronises the device. */
 int pt_scene_coop_counters(pt_scene *scene, uint64_t out2[2], int reset);
 
+/* Closest-hit QUERIES on explicit rays, asynchronous on `hip_stream` -- the unit of the reference's own #[bench] functions (one
+ * `ray_hit` on the centre ray of a preset: bench.rs:8-26, hitable_list.rs:68-75, spheres_soa.rs:464-485, bvh.rs:361-379) and the home of
+ * SpheresSoA (collision/spheres_soa.rs:12-392), which only those benches call. Sphere / MovingSphere worlds. Not on the render
+ * path; every mode is the reference's algorithm as written, one ray per lane (csrc/pt_query.hip):
+ *   PT_QUERY_LIST        HitableList::ray_hit (hitable_list.rs:40-56; sphere.rs:29-66, moving_sphere.rs:38-73)
+ *   PT_QUERY_BVH         BVHNode::ray_hit over the tree the scene was created with (bvh.rs:37-62, aabb.rs:46-58)
+ *   PT_QUERY_SOA_SCALAR / _SSE4_1 / _AVX2   SpheresSoA::hit_scalar / hit_sse4_1 / hit_avx2 (:105-155 / :161-268 / :274-391). Their
+ *                        arithmetic differs from Sphere::ray_hit's (no `a`, no division, normal * (1 / r), ties to the lowest LANE).
+ * d_rays7: n_rays x (origin3, direction3, time) floats on the device. d_hits8: n_rays x (t, entry, point3, normal3); entry = the list
+ * index as u32 bits, 0xffffffff for a miss (t = t_max then), 0xfffffffe when a BVH deeper than the walk's 48-entry stack was met. */
+enum { PT_QUERY_LIST = 0, PT_QUERY_BVH = 1, PT_QUERY_SOA_SCALAR = 2, PT_QUERY_SOA_SSE4_1 = 3, PT_QUERY_SOA_AVX2 = 4 };
+int pt_closest_hit(pt_scene *scene, uint32_t mode, uint32_t n_rays, const float *d_rays7, float t_min, float t_max,
+                   float *d_hits8, void *hip_stream);
+
 /* Device self-test probes (diagnostics for the parity tests; not part of the reference's
  * interface): evaluate one device primitive on n host inputs.
  *   PT_PROBE_POW5    out[i] = device x^5 used by schlick (math.rs:79 powf(x, 5.0))

@@ -2078,6 +2078,164 @@ void ora_ray_trace(const ora_scene *s, const float o[3], const float d[3], float
     rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
 }
 
+/* ======================================================================== */
+/* collision/spheres_soa.rs:12-392 -- SpheresSoA (bench-only in the reference:  */
+/* nothing but its own #[bench] functions calls it).           */
+/* The arithmetic DIFFERS from Sphere::ray_hit (sphere.rs:29-66): co = centre -  */
+/* origin, discriminant = nb*nb - c WITHOUT `a` (it assumes |direction| = 1),    */
+/* t = nb -+ sqrt WITHOUT the division, normal = (p - c) * (1/r) instead of / r. */
+/* ======================================================================== */
+typedef struct { size_t len, num; float *cx, *cy, *cz, *rsq, *rinv; const material **mat; } spheres_soa;
+
+/* spheres_soa.rs:26-74 (chunk = TargetFeature::get_bits() / 32: 8 AVX2, 4 SSE4.1, 1 FallBack; simd.rs:35-41) */
+static int soa_new(spheres_soa *o, const hitable_list *l, size_t chunk) {
+    memset(o, 0, sizeof *o);
+    o->num = l->len;
+    o->len = (l->len + chunk - 1) / chunk * chunk;   /* math.rs align_to */
+    o->cx = malloc(5 * (o->len + 1) * sizeof(float));
+    o->cy = o->cx + o->len; o->cz = o->cy + o->len; o->rsq = o->cz + o->len; o->rinv = o->rsq + o->len;
+    o->mat = calloc(o->len + 1, sizeof *o->mat);
+    if (!o->cx || !o->mat) return 0;
+    for (size_t i = 0; i < l->len; ++i) {
+        const hitable *h = &l->hitables[i];
+        if (h->kind != HIT_SPHERE) return 0;   /* spheres_soa.rs:52: panics on anything else */
+        o->cx[i] = h->sph->centre.x; o->cy[i] = h->sph->centre.y; o->cz[i] = h->sph->centre.z;
+        o->rsq[i] = h->sph->radius * h->sph->radius;
+        o->rinv[i] = 1.0f / h->sph->radius;
+        o->mat[i] = h->mat;
+    }
+    for (size_t i = l->len; i < o->len; ++i) {   /* spheres_soa.rs:55-62 padding */
+        o->cx[i] = o->cy[i] = o->cz[i] = 3.40282346638528859812e+38f;
+        o->rsq[i] = 0.0f; o->rinv[i] = 0.0f; o->mat[i] = NULL;
+    }
+    return 1;
+}
+static void soa_free(spheres_soa *o) { free(o->cx); free(o->mat); }
+
+/* material.rs:41-49, 169-180: (u, v) only for Image-textured Lambertian / DiffuseLight */
+static void soa_sphere_uv(const material *m, v3 normal, float *u, float *v) {
+    *u = 0.0f; *v = 0.0f;
+    if ((m->kind == MAT_LAMBERTIAN || m->kind == MAT_DIFFUSE_LIGHT) && m->tex && m->tex->kind == TEX_IMAGE) {
+        const float pi = 3.14159274101257324f, frac_1_2pi = 1.0f / (2.0f * pi);
+        float phi = atan2f(normal.x, normal.y), theta = asinf(normal.y);
+        *u = 1.0f - (phi + pi) * frac_1_2pi;
+        *v = (theta + 1.57079637050628662f) * 0.318309873342514038f;
+    }
+}
+/* the common tail of all three variants (spheres_soa.rs:135-155, 235-265, 358-388) */
+static int soa_finish(const spheres_soa *o, const ray *r, size_t hit_index, float hit_t, ray_hit *out, size_t *index_out) {
+    out->point = point_at_parameter(r, hit_t);
+    v3 centre = V3(o->cx[hit_index], o->cy[hit_index], o->cz[hit_index]);
+    out->normal = v3_scale(v3_sub(out->point, centre), o->rinv[hit_index]);
+    out->t = hit_t;
+    soa_sphere_uv(o->mat[hit_index], out->normal, &out->u, &out->v);
+    *index_out = hit_index;
+    return 1;
+}
+/* spheres_soa.rs:105-155 hit_scalar */
+static int soa_hit_scalar(const spheres_soa *o, const ray *r, float t_min, float t_max, ray_hit *out, size_t *index_out) {
+    float hit_t = t_max;
+    size_t hit_index = o->len;
+    for (size_t index = 0; index < o->len; ++index) {
+        v3 co = v3_sub(V3(o->cx[index], o->cy[index], o->cz[index]), r->origin);
+        float nb = v3_dot(co, r->direction);
+        float c = v3_dot(co, co) - o->rsq[index];
+        float discriminant = nb * nb - c;
+        if (discriminant > 0.0f) {
+            float discriminant_sqrt = sqrtf(discriminant);
+            float t = nb - discriminant_sqrt;
+            if (t < t_min) t = nb + discriminant_sqrt;
+            if (t > t_min && t < hit_t) { hit_t = t; hit_index = index; }
+        }
+    }
+    if (hit_index < o->len) return soa_finish(o, r, hit_index, hit_t, out, index_out);
+    return 0;
+}
+/* spheres_soa.rs:161-268 hit_sse4_1 (lanes = 4) / :274-391 hit_avx2 (lanes = 8): `lanes` running minima, one per SIMD lane,
+ * then the horizontal minimum and the LOWEST LANE holding it (:232-236, :355-359) -- not the lowest sphere index. */
+static int soa_hit_lanes(const spheres_soa *o, size_t lanes, const ray *r, float t_min, float t_max, ray_hit *out, size_t *index_out) {
+    float hit_t[8]; int32_t hit_index[8];
+    for (size_t l = 0; l < lanes; ++l) { hit_t[l] = t_max; hit_index[l] = -1; }
+    for (size_t chunk = 0; chunk + lanes <= o->len; chunk += lanes) {
+        for (size_t l = 0; l < lanes; ++l) {   /* (the lanes are independent: the movemask test around :209 / :323 only skips work) */
+            size_t i = chunk + l;
+            float co_x = o->cx[i] - r->origin.x, co_y = o->cy[i] - r->origin.y, co_z = o->cz[i] - r->origin.z;
+            float nb = (co_x * r->direction.x + co_y * r->direction.y) + co_z * r->direction.z;   /* simd.rs:253-265 dot3 */
+            float c = ((co_x * co_x + co_y * co_y) + co_z * co_z) - o->rsq[i];
+            float discr = nb * nb - c;
+            if (discr > 0.0f) {
+                float discr_sqrt = sqrtf(discr);
+                float t0 = nb - discr_sqrt, t1 = nb + discr_sqrt;
+                float t = t0 > t_min ? t0 : t1;             /* blendv(t1, t0, t0 > t_min) */
+                if (t > t_min && t < hit_t[l]) { hit_index[l] = (int32_t)i; hit_t[l] = t; }
+            }
+        }
+    }
+    float min_hit_t = hit_t[0];
+    for (size_t l = 1; l < lanes; ++l) min_hit_t = hit_t[l] < min_hit_t ? hit_t[l] : min_hit_t;   /* hmin (no NaNs can be stored) */
+    if (min_hit_t < t_max)
+        for (size_t l = 0; l < lanes; ++l)
+            if (hit_t[l] == min_hit_t) return soa_finish(o, r, (size_t)hit_index[l], hit_t[l], out, index_out);
+    return 0;
+}
+
+static void put_hit9(const ray_hit *h, float out9[9]) {
+    out9[0] = h->point.x; out9[1] = h->point.y; out9[2] = h->point.z;
+    out9[3] = h->normal.x; out9[4] = h->normal.y; out9[5] = h->normal.z; out9[6] = h->t; out9[7] = h->u; out9[8] = h->v;
+}
+/* SpheresSoA::new over the scene's list + one ray_hit; lanes: 1 hit_scalar, 4 hit_sse4_1, 8 hit_avx2. -1: the list holds a non-sphere. */
+int ora_soa_ray_hit(const ora_scene *s, int lanes, const float o[3], const float d[3], float t_min, float t_max, float out9[9], uint32_t *index_out) {
+    if (lanes != 1 && lanes != 4 && lanes != 8) return -1;
+    spheres_soa soa;
+    if (!soa_new(&soa, &s->list, (size_t)lanes)) { soa_free(&soa); return -1; }
+    ray ry = ray_new(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), 0.0f);
+    ray_hit h; size_t idx = 0;
+    int hit = lanes == 1 ? soa_hit_scalar(&soa, &ry, t_min, t_max, &h, &idx) : soa_hit_lanes(&soa, (size_t)lanes, &ry, t_min, t_max, &h, &idx);
+    if (hit) { put_hit9(&h, out9); *index_out = (uint32_t)idx; }
+    soa_free(&soa);
+    return hit;
+}
+/* Hitable::ray_hit on the scene's WORLD (scene.rs:58: the HitableList, or the BVH root when the scene was built with one) for one
+ * explicit ray; out9 as above, *index_out = the list entry that was hit (sphere worlds: the entry owning the returned material). */
+int ora_world_ray_hit(const ora_scene *s, const float o[3], const float d[3], float time, float t_min, float t_max, uint64_t state[4],
+                      float out9[9], uint32_t *index_out) {
+    xoshiro r; memcpy(r.s, state, 32);
+    ray ry = ray_new(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), time);
+    ray_hit h; const material *m = NULL;
+    int hit = hitable_ray_hit(&s->world, &ry, t_min, t_max, &r, &h, &m);
+    memcpy(state, r.s, 32);
+    if (hit) {
+        put_hit9(&h, out9);
+        *index_out = 0xffffffffu;
+        for (size_t i = 0; i < s->list.len; ++i)
+            if (s->list.hitables[i].mat == m) { *index_out = (uint32_t)i; break; }
+    }
+    return hit;
+}
+/* The reference's six #[bench] units (bench.rs:8-26; hitable_list.rs:68-75, spheres_soa.rs:464-485, bvh.rs:361-379): `reps` calls of
+ * one closest-hit query on one fixed ray, nanoseconds per call (what `b.iter` reports). which: 0 world (list or BVH as built),
+ * 1 / 4 / 8 SpheresSoA scalar / 4 lanes / 8 lanes. */
+double ora_bench_ray_hit(const ora_scene *s, int which, const float o[3], const float d[3], float time, uint64_t reps) {
+    ray ry = ray_new(V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]), time);
+    xoshiro rng; xoshiro_seed_from_u64(&rng, 0);
+    spheres_soa soa; memset(&soa, 0, sizeof soa);
+    if (which != 0 && !soa_new(&soa, &s->list, (size_t)which)) { soa_free(&soa); return -1.0; }
+    volatile float sink = 0.0f;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint64_t i = 0; i < reps; ++i) {
+        ray_hit h; const material *m; size_t idx;
+        __asm__ volatile("" : "+m"(ry) : : "memory");   /* (the query is re-evaluated every time, as under test::black_box) */
+        int hit = which == 0 ? hitable_ray_hit(&s->world, &ry, MIN_T, MAX_T, &rng, &h, &m)
+                : which == 1 ? soa_hit_scalar(&soa, &ry, MIN_T, MAX_T, &h, &idx) : soa_hit_lanes(&soa, (size_t)which, &ry, MIN_T, MAX_T, &h, &idx);
+        if (hit) sink = sink + h.t;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (which != 0) soa_free(&soa);
+    (void)sink;
+    return ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / (double)(reps ? reps : 1);
+}
+
 /* math.rs:36-48 */
 static inline float fmax0(float a) { return a > 0.0f ? a : 0.0f; } /* f32::max(0.0): NaN -> 0.0 */
 static inline uint8_t f32_as_u8(float f) { if (!(f > 0.0f)) return 0; if (f >= 255.0f) return 255; return (uint8_t)f; }

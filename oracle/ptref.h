@@ -172,6 +172,18 @@ void ora_texture_value(const ora_scene *s, uint32_t texture_id,
 void ora_ray_trace(const ora_scene *s, const float origin[3],
                    const float direction[3], float time, uint32_t max_depth,
                    uint64_t state[4], float rgb[3], uint64_t *ray_count);
+/* ---- collision/spheres_soa.rs (bench-only in the reference) and whole-world closest-hit queries ----
+ * ora_soa_ray_hit: SpheresSoA::new over the scene's list, then hit_scalar (lanes = 1, spheres_soa.rs:105-155), hit_sse4_1
+ * (4, :161-268) or hit_avx2 (8, :274-391). out9 = point3, normal3, t, u, v; *index_out = sphere index. Returns 1 hit, 0 miss,
+ * -1 when the list holds anything but spheres (the reference panics). Note the arithmetic differs from Sphere::ray_hit.
+ * ora_world_ray_hit: Hitable::ray_hit on the scene's world (list or BVH as built) for one explicit ray.
+ * ora_bench_ray_hit: ns per call of one such query repeated `reps` times (which: 0 world, 1 / 4 / 8 SpheresSoA variants) -- the
+ * unit of the reference's own #[bench] functions (bench.rs:8-26). */
+int ora_soa_ray_hit(const ora_scene *s, int lanes, const float origin[3], const float direction[3], float t_min, float t_max,
+                    float out9[9], uint32_t *index_out);
+int ora_world_ray_hit(const ora_scene *s, const float origin[3], const float direction[3], float time, float t_min, float t_max,
+                      uint64_t state[4], float out9[9], uint32_t *index_out);
+double ora_bench_ray_hit(const ora_scene *s, int which, const float origin[3], const float direction[3], float time, uint64_t reps);
 /* math.rs:36-48 */
 void ora_linear_to_srgb(const float rgb[3], uint8_t out[3]);
 /* offline.rs:43-51: full frame -> top-down RGB8 */

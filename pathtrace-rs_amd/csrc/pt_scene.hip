@@ -91,6 +91,8 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
         if (prc != 0) return bail(fail(PT_ERR_HIP, "packing the internal tree failed (hipError %d)", prc));
     }
     if (P.has_motion && (rc = upload(&s->d_motion, P.mot.data(), P.mot.size()))) return bail(rc);
+    // the caller's tree as given: only pt_closest_hit(PT_QUERY_BVH) walks it (the frame kernels use the gates and ranks derived from it)
+    if (desc->n_bvh_nodes && (rc = upload(&s->d_ref_nodes, desc->bvh_nodes, desc->n_bvh_nodes))) return bail(rc);
     if (P.has_prep) {
         const MfmaPrep &prep = P.prep;
         if ((rc = upload(&s->d_afrag, prep.afrag.data(), prep.afrag.size() / 8)) || (rc = upload(&s->d_tile_sphere, prep.tile_sphere.data(), prep.tile_sphere.size())) ||
@@ -154,7 +156,7 @@ extern "C" int pt_scene_create_world(const pt_world_desc *given, int device, pt_
             s->tr.n_world_xf = desc->n_transforms;
             s->tr.ref_bvh_depth = W.ref_depth;
             if (W.ref_depth + 2 > 64u || (rc = upload(&s->d_hitables, desc->hitables, desc->n_hitables)) ||
-                (rc = upload(&s->d_transforms, desc->transforms, desc->n_transforms)) || (rc = upload(&s->d_ref_nodes, desc->bvh_nodes, desc->n_bvh_nodes))) {
+                (rc = upload(&s->d_transforms, desc->transforms, desc->n_transforms)) || (!s->d_ref_nodes && (rc = upload(&s->d_ref_nodes, desc->bvh_nodes, desc->n_bvh_nodes)))) {
                 pt_scene_destroy(s);
                 *scene_out = nullptr;
                 return rc ? rc : fail(PT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack", W.ref_depth);

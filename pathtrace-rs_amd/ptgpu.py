@@ -113,6 +113,7 @@ class PtKernelChoice(C.Structure):
         return d
 
 
+QUERY_LIST, QUERY_BVH, QUERY_SOA_SCALAR, QUERY_SOA_SSE4_1, QUERY_SOA_AVX2 = range(5)
 FAMILY_WORLD, FAMILY_TREE_BINARY, FAMILY_TREE4, FAMILY_MFMA, FAMILY_SCAN_LDS, FAMILY_SCAN_HBM = range(6)
 
 EXPORTS = [
@@ -121,7 +122,7 @@ EXPORTS = [
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
     "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree", "pt_scene_debug_tree_packed",
-    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters", "pt_render_sharded_all", "pt_comm_gather_frame_all",
+    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters", "pt_render_sharded_all", "pt_comm_gather_frame_all", "pt_closest_hit",
 ]
 COMM_ID_BYTES = 128
 
@@ -163,6 +164,7 @@ def lib():
         L.pt_scene_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.pt_scene_traversal_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.pt_scene_coop_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+        L.pt_closest_hit.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_float, C.c_float, vp, vp]
         L.pt_last_pass_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pt_comm_unique_id.argtypes = [vp]
         L.pt_comm_create.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
@@ -366,6 +368,10 @@ class Scene:
         out = (C.c_uint64 * 2)()
         _check(lib().pt_scene_coop_counters(self._h, out, 1 if reset else 0))
         return dict(pixels=out[0], rays=out[1])
+
+    def closest_hit(self, mode, n_rays, d_rays7_ptr, d_hits8_ptr, t_min=0.001, t_max=3.4028234663852886e38, stream=0):
+        """pt_closest_hit: the reference's closest-hit query (QUERY_* mode) for n_rays explicit rays on the device."""
+        _check(lib().pt_closest_hit(self._h, mode, n_rays, d_rays7_ptr, t_min, t_max, d_hits8_ptr, stream))
 
     def traversal_counters(self, reset=True):
         out = (C.c_uint64 * 2)()

@@ -88,6 +88,9 @@ def _bind(L):
     L.ora_perlin_turb.restype, L.ora_perlin_turb.argtypes = f32, [vp, vp]
     L.ora_texture_value.argtypes = [vp, u32, vp, vp]
     L.ora_ray_trace.argtypes = [vp, vp, vp, f32, u32, vp, vp, vp]
+    L.ora_soa_ray_hit.restype, L.ora_soa_ray_hit.argtypes = C.c_int, [vp, C.c_int, vp, vp, f32, f32, vp, vp]
+    L.ora_world_ray_hit.restype, L.ora_world_ray_hit.argtypes = C.c_int, [vp, vp, vp, f32, f32, f32, vp, vp, vp]
+    L.ora_bench_ray_hit.restype, L.ora_bench_ray_hit.argtypes = C.c_double, [vp, C.c_int, vp, vp, f32, u64]
     L.ora_linear_to_srgb.argtypes = [vp, vp]
     L.ora_frame_to_srgb8.argtypes = [vp, u32, u32, vp]
     return L
@@ -186,6 +189,29 @@ class OracleScene:
         else:
             rc = self.L.ora_scene_update(self.h, W, H, samples, max_depth, frame_num, buffer.ctypes.data, nthreads)
         return buffer, rc
+
+    # closest-hit queries on explicit rays --------------------------------
+    def soa_ray_hit(self, lanes, origin, direction, t_min=0.001, t_max=3.4028234663852886e38):
+        """SpheresSoA::hit_scalar / hit_sse4_1 / hit_avx2 (lanes 1 / 4 / 8; spheres_soa.rs). None for a miss, else
+        (t, index, point3, normal3, u, v); raises when the list holds anything but spheres."""
+        o, d = np.asarray(origin, np.float32), np.asarray(direction, np.float32)
+        out, idx = np.zeros(9, np.float32), C.c_uint32(0)
+        rc = self.L.ora_soa_ray_hit(self.h, lanes, o.ctypes.data, d.ctypes.data, t_min, t_max, out.ctypes.data, C.byref(idx))
+        if rc < 0:
+            raise ValueError("SpheresSoA takes Hitable::Sphere entries only")
+        return None if rc == 0 else (out[6], idx.value, out[0:3].copy(), out[3:6].copy(), out[7], out[8])
+
+    def world_ray_hit(self, origin, direction, time=0.0, t_min=0.001, t_max=3.4028234663852886e38):
+        """Hitable::ray_hit on the scene's world (list, or BVH when built with one). None or (t, index, point3, normal3)."""
+        o, d = np.asarray(origin, np.float32), np.asarray(direction, np.float32)
+        out, idx, st = np.zeros(9, np.float32), C.c_uint32(0), np.zeros(4, np.uint64)
+        rc = self.L.ora_world_ray_hit(self.h, o.ctypes.data, d.ctypes.data, time, t_min, t_max, st.ctypes.data, out.ctypes.data, C.byref(idx))
+        return None if rc == 0 else (out[6], idx.value, out[0:3].copy(), out[3:6].copy())
+
+    def bench_ray_hit(self, which, origin, direction, time=0.0, reps=100000):
+        """ns per closest-hit query (bench.rs:8-26's unit): which 0 = the world, 1 / 4 / 8 = SpheresSoA variants."""
+        o, d = np.asarray(origin, np.float32), np.asarray(direction, np.float32)
+        return float(self.L.ora_bench_ray_hit(self.h, which, o.ctypes.data, d.ctypes.data, time, reps))
 
     # flat export ---------------------------------------------------------
     def export(self):

@@ -602,6 +602,58 @@ def test_communicators_from_a_device_list_and_side_by_side(ptgpu, pthost):
         ptgpu.Comm.create_all([7])                       # no such device
 
 
+@pytest.mark.parametrize("preset", ["random_spheres", "random", "aras"])
+def test_closest_hit_queries_match_the_oracle(ptgpu, pthost, oracle, preset):
+    """pt_closest_hit (csrc/pt_query.hip): the reference's closest-hit functions on explicit rays, device vs oracle, BIT for bit in
+    t, entry, point and normal -- HitableList::ray_hit (hitable_list.rs:40-56), BVHNode::ray_hit over the scene's own tree
+    (bvh.rs:37-62) and the three SpheresSoA variants (spheres_soa.rs:105-155 / 161-268 / 274-391), whose arithmetic
+    differs from Sphere::ray_hit's (no `a`, no division, normal * (1 / r)): hence their own oracle functions and no render mode.
+    Rays: camera-like unit rays, bounce-like rays from inside the cloud, and non-unit directions (the SoA forms assume |d| = 1 and
+    are wrong for those -- but wrong the SAME way on both sides)."""
+    import torch
+    W, H = 200, 100
+    rng = np.random.default_rng(11)
+    n = 4096
+    rays = np.zeros((n, 7), np.float32)
+    rays[:, 0:3] = np.array([13, 2, 3], np.float32) + rng.normal(0, 0.05, (n, 3))
+    target = rng.uniform(-6, 6, (n, 3)).astype(np.float32)
+    target[:, 1] = rng.uniform(-0.5, 1.5, n)
+    rays[n // 2:, 0:3] = rng.uniform(-5, 5, (n - n // 2, 3)) * np.array([1, 0.1, 1]) + np.array([0, 0.6, 0])   # from inside the cloud
+    d = target - rays[:, 0:3]
+    d /= np.sqrt((d * d).sum(axis=1, keepdims=True))
+    d[::7] *= rng.uniform(0.3, 3.0, (len(d[::7]), 1))       # some non-unit directions
+    rays[:, 3:6] = d
+    rays[:, 6] = rng.uniform(0, 1, n)
+    rays = rays.astype(np.float32)
+    d_rays = torch.from_numpy(rays).cuda()
+    d_hits = torch.zeros((n, 8), dtype=torch.float32, device="cuda")
+    moving = preset == "random"
+    modes = [("list", ptgpu.QUERY_LIST, False), ("bvh", ptgpu.QUERY_BVH, True)]
+    if not moving:
+        modes += [("soa1", ptgpu.QUERY_SOA_SCALAR, False), ("soa4", ptgpu.QUERY_SOA_SSE4_1, False), ("soa8", ptgpu.QUERY_SOA_AVX2, False)]
+    for name, mode, bvh in modes:
+        hs = pthost.HostScene(preset, W, H, samples=1, use_bvh=bvh, device=0)
+        osc = oracle.OracleScene(preset, W, H, use_bvh=bvh)
+        hs.device_scene().closest_hit(mode, n, d_rays.data_ptr(), d_hits.data_ptr())
+        torch.cuda.synchronize()
+        got = d_hits.cpu().numpy()
+        entry = got[:, 1].view(np.uint32)
+        n_hit = 0
+        for i in range(n):
+            o, dd, tm = rays[i, 0:3], rays[i, 3:6], float(rays[i, 6])
+            ref = osc.world_ray_hit(o, dd, tm) if name in ("list", "bvh") else osc.soa_ray_hit({"soa1": 1, "soa4": 4, "soa8": 8}[name], o, dd)
+            if ref is None:
+                assert entry[i] == 0xffffffff, (preset, name, i, entry[i], got[i])
+                continue
+            n_hit += 1
+            assert entry[i] == ref[1] and got[i, 0] == ref[0], (preset, name, i, entry[i], got[i, 0], ref[:2])
+            assert np.array_equal(got[i, 2:5], ref[2]) and np.array_equal(got[i, 5:8], ref[3]), (preset, name, i, got[i], ref)
+        assert n_hit > n // 2, (preset, name, n_hit)
+    if moving:
+        with pytest.raises(ptgpu.PtError):     # SpheresSoA::new panics on a MovingSphere (spheres_soa.rs:52)
+            pthost.HostScene(preset, W, H, samples=1, device=0).device_scene().closest_hit(ptgpu.QUERY_SOA_SCALAR, n, d_rays.data_ptr(), d_hits.data_ptr())
+
+
 MOCK_RCCL = os.path.join(ROOT, "tests", "mock_rccl")
 
 

@@ -453,3 +453,44 @@ def test_image_texture_sampling(oracle):
     np.testing.assert_array_equal(trace([3.99, 0.01, 5], [0, 0, -1]), img[2, 3].astype(np.float32) / np.float32(255))
     # the sphere: u = v = 0 (sphere.rs:47-48) -> texel (0, h - 1)
     np.testing.assert_array_equal(trace([10, 10, 5], [0, 0, -1]), img[2, 0].astype(np.float32) / np.float32(255))
+
+
+# ---- collision/spheres_soa.rs (bench-only in the reference) -------------------------------------------------
+def test_spheres_soa_known_answer_and_padding(oracle):
+    """hit_scalar on `small` (presets.rs:217-269: sphere 0 = centre (0, 0, -1), r = 0.5) for the ray from the origin along -z, by hand:
+    co = (0, 0, -1), nb = 1, c = 1 - 0.25, discriminant = 0.25, t = 1 - 0.5; normal = (p - c) * (1 / r). The 4- and 8-lane variants
+    pad the five spheres with (MAX, MAX, MAX), r^2 = 0 entries (spheres_soa.rs:55-62) that must never be hit."""
+    sc = oracle.OracleScene("small", 200, 100)
+    for lanes in (1, 4, 8):
+        t, idx, p, n, u, v = sc.soa_ray_hit(lanes, (0, 0, 0), (0, 0, -1))
+        assert (t, idx, u, v) == (0.5, 0, 0.0, 0.0) and np.array_equal(p, [0, 0, -0.5]) and np.array_equal(n, [0, 0, 1])
+        assert sc.soa_ray_hit(lanes, (0, 50, 0), (0, 1, 0)) is None               # away from everything: the padding stays silent
+    # t_max narrows like hitable_list.rs:48-54; t0 < t_min falls through to the far root
+    assert sc.soa_ray_hit(1, (0, 0, 0), (0, 0, -1), t_max=0.4) is None
+    t, idx, *_ = sc.soa_ray_hit(1, (0, 0, -1), (0, 0, -1))                        # from the centre: near root -0.5 < t_min, far root 0.5
+    assert (t, idx) == (0.5, 0)
+    with pytest.raises(ValueError):
+        oracle.OracleScene("cornell", 64, 64).soa_ray_hit(1, (0, 0, 0), (0, 0, 1))   # spheres_soa.rs:52 panics on a non-sphere
+
+
+def test_spheres_soa_agrees_with_the_list_up_to_its_own_arithmetic(oracle):
+    """For unit directions SpheresSoA answers the HitableList's question with other arithmetic (no `a`, no division): the same entry and
+    a t within 2e-5 relative (the roots cancel differently) on random_spheres camera-like rays; the lane variants agree with hit_scalar except where two entries tie
+    (lowest lane, spheres_soa.rs:232-236, instead of lowest index) -- none of these rays does."""
+    sc = oracle.OracleScene("random_spheres", 200, 100)
+    rng = np.random.default_rng(3)
+    hits = 0
+    for _ in range(400):
+        o = np.array([13, 2, 3], np.float32) + rng.normal(0, 0.05, 3).astype(np.float32)
+        d = (np.array(rng.uniform(-4, 4, 3), np.float32) - o)
+        d = (d / np.float32(np.sqrt((d * d).sum(dtype=np.float32)))).astype(np.float32)
+        ref = sc.world_ray_hit(o, d)
+        got = [sc.soa_ray_hit(l, o, d) for l in (1, 4, 8)]
+        assert all((g is None) == (ref is None) for g in got)
+        if ref is None:
+            continue
+        hits += 1
+        for g in got:
+            assert g[1] == ref[1] and abs(g[0] - ref[0]) <= 2e-5 * max(1.0, ref[0]), (g[:2], ref[:2])
+        assert got[1][:2] == got[0][:2] and got[2][:2] == got[0][:2]
+    assert hits > 250
