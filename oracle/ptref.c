@@ -1618,11 +1618,13 @@ bad:
  * wrappers of their own). nodes4: n_nodes rows of (kind, a, b, density bits): kind 0 shape a = leaf index | 1 HitableList of
  * children[a .. a+b) | 2 Instance transforms[a] around node b | 3 ConstantMedium, Isotropic material a, boundary node b.
  * The product flattens the same graph (include/ptgpu.h pt_node); this is what it must agree with. List worlds only. */
+#define GRAPH_POOL ((size_t)1 << 16)   /* entries per pool of ora_scene_from_graph */
 static int graph_build(ora_scene *sc, const uint32_t *nodes4, uint32_t n_nodes, const uint32_t *children, uint32_t n_children,
                        const float *transforms24, uint32_t n_transforms, const float *materials6, uint32_t n_materials, uint32_t n_textures,
                        uint32_t node, uint32_t depth, size_t *n_inst, size_t *n_med, size_t *n_lists, size_t *n_child, hitable *out) {
     if (node >= n_nodes || depth > 64) return 0;
     const uint32_t *w = nodes4 + 4 * node;
+    const size_t pool = GRAPH_POOL;   /* every pool is checked BEFORE it is written: a DAG expands per path */
     switch (w[0]) {
     case 0:
         if (w[1] >= sc->list.len) return 0;
@@ -1630,6 +1632,7 @@ static int graph_build(ora_scene *sc, const uint32_t *nodes4, uint32_t n_nodes, 
         return 1;
     case 1: {
         if ((uint64_t)w[1] + w[2] > n_children) return 0;
+        if (*n_lists >= pool || *n_child + (size_t)w[2] > pool) return 0;
         hitable_list *l = &sc->g_lists[(*n_lists)++];
         l->hitables = sc->g_children + *n_child; l->len = w[2];
         *n_child += w[2];
@@ -1644,6 +1647,7 @@ static int graph_build(ora_scene *sc, const uint32_t *nodes4, uint32_t n_nodes, 
         if (!graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, w[2], depth + 1, n_inst,
                          n_med, n_lists, n_child, &child)) return 0;
         const float *a = transforms24 + 24 * w[1];
+        if (*n_inst >= pool) return 0;
         instance *in = &sc->g_instances[(*n_inst)++];
         in->child = child;   /* keeps the transform AND the inverse it was given (instance.rs:16-22 computes it once) */
         in->transform.x_axis = V3(a[0], a[1], a[2]); in->transform.y_axis = V3(a[3], a[4], a[5]);
@@ -1660,6 +1664,7 @@ static int graph_build(ora_scene *sc, const uint32_t *nodes4, uint32_t n_nodes, 
         hitable child;
         if (!graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, w[2], depth + 1, n_inst,
                          n_med, n_lists, n_child, &child)) return 0;
+        if (*n_med >= pool) return 0;
         constant_medium *cm = &sc->g_media[(*n_med)++];
         cm->child = child; memcpy(&cm->density, &w[3], 4);
         memset(&cm->phase_function, 0, sizeof cm->phase_function);
@@ -1681,14 +1686,15 @@ ora_scene *ora_scene_from_graph(const uint32_t *records16, uint32_t n_hitables, 
                                          has_sky, sky3, 0, NULL, NULL, 0);
     if (!sc) return NULL;
     /* a node can be reached along several paths (a DAG): size the pools for the expanded tree, bounded */
-    const size_t cap = 1u << 16;
+    const size_t cap = GRAPH_POOL;
     sc->g_instances = calloc(cap, sizeof(instance)); sc->g_media = calloc(cap, sizeof(constant_medium));
     sc->g_lists = calloc(cap, sizeof(hitable_list)); sc->g_children = calloc(cap, sizeof(hitable));
     size_t ni = 0, nm = 0, nl = 0, nc = 0;
     hitable rooth;
-    /* (graph_build checks its indices; the pools hold 65536 entries each, far beyond what the tests build) */
-    if (!graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, root, 0, &ni, &nm, &nl, &nc,
-                     &rooth) || ni >= cap || nm >= cap || nl >= cap || nc >= cap) {
+    /* (graph_build checks its indices and the pools' capacity before every write) */
+    if (!sc->g_instances || !sc->g_media || !sc->g_lists || !sc->g_children ||
+        !graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, root, 0, &ni, &nm, &nl, &nc,
+                     &rooth)) {
         ora_scene_free(sc);
         return NULL;
     }

@@ -249,11 +249,17 @@ __device__ __forceinline__ void sinf_cosf_ref(float xin, float &sin_out, float &
 // carries its large-argument (Payne-Hanek) reduction branch-free in some kernels: 380 VALU instructions per call in the
 // general-world kernel, 16 % of a `simple_light` frame. Arguments below 8192 -- `scale * z + 10 * turbulence` of any sensible
 // scene -- take the Cephes evaluation the path already has for its own sin / cos (sinf_cosf_ref: three-part pi/4 reduction, < 2
-// ulp there); a wave in which some lane's argument is larger, infinite or NaN calls the library.
+// ulp there); a lane whose argument is larger, infinite or NaN takes the library's value.
 __device__ __forceinline__ float sin_colour(float x) {
     float s, c;
     sinf_cosf_ref(x, s, c);
-    if (__builtin_expect(wave_any(!(__builtin_fabsf(x) < 8192.0f)), 0)) s = sinf(x);
+    // (the library call is wave-uniform for its cost, its RESULT is taken per lane: a lane's colour must not depend on which other
+    // pixels happen to share its wave -- the work order, and with it a wave's composition, varies from run to run)
+    const bool big = !(__builtin_fabsf(x) < 8192.0f);
+    if (__builtin_expect(wave_any(big), 0)) {
+        const float l = sinf(x);
+        s = big ? l : s;
+    }
     return s;
 }
 

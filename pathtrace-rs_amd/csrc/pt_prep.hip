@@ -707,6 +707,8 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
     if (desc->n_hitables == 0 && desc->n_bvh_nodes) return fail(PT_ERR_INVALID_ARG, "BVH nodes over an empty list");
     if (desc->n_textures && !desc->textures) return fail(PT_ERR_INVALID_ARG, "textures is NULL");
     if (desc->n_transforms && !desc->transforms) return fail(PT_ERR_INVALID_ARG, "transforms is NULL");
+    // pt_hitable.transform keeps a chain's level counts in bits 20..27: a plain index up there would be read as a chain
+    if (desc->n_transforms > (1u << 20)) return fail(PT_ERR_UNSUPPORTED, "more than 2^20 transforms");
     bool has_noise = false;
     if (int rc = validate_tables(desc->n_materials, desc->materials, desc->n_textures, desc->textures, desc->perlin, true, &has_noise, desc->n_images, desc->images))
         return rc;
@@ -796,6 +798,7 @@ struct Flattener {
     std::vector<uint32_t> path;    // nodes on the current descent (cycle check)
     std::vector<uint32_t> chain;   // Instance transforms met on the way down, outermost first
     int rc = PT_OK;
+    unsigned long long visits = 0;   // nodes walked so far (budget against exponential expansion of shared children)
 
     bool on_path(uint32_t n) const { return std::find(path.begin(), path.end(), n) != path.end(); }
     int32_t encode_chain(const std::vector<uint32_t> &outer, const std::vector<uint32_t> &inner) {
@@ -845,6 +848,8 @@ struct Flattener {
         if (n >= d->n_nodes) return fail(PT_ERR_INVALID_ARG, "scene graph: node index %u out of range", n);
         if (on_path(n)) return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u contains itself (a cycle)", n);
         if (path.size() > 256) return fail(PT_ERR_UNSUPPORTED, "scene graph: deeper than 256 levels at node %u", n);
+        // shared children are expanded once per path: a DAG of nested lists can cost exponential time on caller-supplied input
+        if (++visits > (1ull << 24)) return fail(PT_ERR_UNSUPPORTED, "scene graph: flattening visits more than 2^24 nodes (shared children are expanded per path)");
         const pt_node &N = d->nodes[n];
         path.push_back(n);
         int r = PT_OK;
@@ -866,6 +871,11 @@ struct Flattener {
         case PT_NODE_MEDIUM: {
             std::vector<uint32_t> inner;
             uint32_t leaf = 0;
+            // (checked here, not after flattening: as int32 an index >= 2^31 would read as "no medium" and render the boundary solid)
+            if (N.a >= d->n_materials || d->materials[N.a].kind != PT_MAT_ISOTROPIC) {
+                r = fail(PT_ERR_INVALID_ARG, "scene graph: node %u: a ConstantMedium's material %u must index an Isotropic material", n, N.a);
+                break;
+            }
             if ((r = boundary(n, N.b, inner, &leaf)) == PT_OK) r = emit(leaf, chain, inner, (int32_t)N.a, N.density);
             break;
         }

@@ -6,6 +6,7 @@ checked against include/ptgpu.h, and its argument validation / error reporting e
 import ctypes as C
 import importlib.util
 import os
+import time
 import re
 import struct
 import subprocess
@@ -452,6 +453,24 @@ def test_scene_graph_nestings_the_list_form_cannot_hold_are_named(ptgpu):
     with pytest.raises(ptgpu.PtError) as e:     # sixteen Instance levels around one shape
         select([[0, 0, 0, 0]] + [[2, 0, i, 0] for i in range(16)] + [[1, 0, 1, 0]], [16], 17)
     assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and "at most 15" in str(e.value)
+    # a ConstantMedium's material must be Isotropic -- also when the index does not fit an int32 (it used to read as "no medium",
+    # and the boundary was rendered as a solid)
+    for bad in (0, 5, 0xffffffff):
+        with pytest.raises(ptgpu.PtError) as e:
+            select([[0, 0, 0, 0], [3, bad, 0, dens], [1, 0, 1, 0]], [1], 2)
+        assert e.value.code == ptgpu.PT_ERR_INVALID_ARG and "Isotropic" in str(e.value), str(e.value)
+    # shared children are expanded once per path: a chain of lists that each hold the next one TWICE is 2^40 visits -- refused in
+    # bounded time instead of walked
+    depth = 40
+    nodes = [[0, 0, 0, 0]] + [[1, 2 * i, 2, 0] for i in range(depth)]
+    children = []
+    for i in range(depth):
+        children += [i, i]          # list node i + 1 holds node i twice
+    t0 = time.time()
+    with pytest.raises(ptgpu.PtError) as e:
+        select(nodes, children, depth)
+    assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and ("2^24" in str(e.value) or "2^22" in str(e.value)), str(e.value)
+    assert time.time() - t0 < 20.0
 
 
 def test_committed_kernel_resource_table_shows_no_spill():
