@@ -21,11 +21,6 @@
 #include "pt_tree4.h"
 #include "ptgpu.h"
 
-// One rejection loop per wave-iteration for the camera's lens samples and a Metal scatter's sphere sample (see the main loop;
-// -DPT_NO_SHARED_REJECT restores the two separate loops for A/B runs)
-#ifndef PT_NO_SHARED_REJECT
-#define PT_SHARED_REJECT 1
-#endif
 
 namespace ptdev {
 
@@ -755,23 +750,12 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                     const float b = (ocx * pd.x + ocy * pd.y) + ocz * pd.z;
                     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
                     const float disc = b * b - pa * cc;
-#ifndef PT_NO_HEAD_ILP
                     const float t = sphere_hit_t(pav, b, disc, true);
                     if (t < kMaxT) {
                         const uint32_t rank = GATED ? G.rank[k] : 0u;
                         if (!GATED || gate_pass_from(A, G, k, po, prcp))   // ray.rs:14 rcp_direction
                             atomicMin(&w_keys[owner], key_of(t, k, rank));
                     }
-#else
-                    if (disc > 0.0f) {
-                        float t = kMaxT;
-                        if (sphere_roots(pav, b, disc, t)) {
-                            const uint32_t rank = GATED ? G.rank[k] : 0u;
-                            if (!GATED || gate_pass_from(A, G, k, po, prcp))   // ray.rs:14 rcp_direction
-                                atomicMin(&w_keys[owner], key_of(t, k, rank));
-                        }
-                    }
-#endif
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -794,7 +778,6 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     const bool culling = !VERIFY && cull_axis < 3u;
     uint32_t j_first = 0;
     TileClip clip{0.0f, 0.0f, 0.0f, false};
-#ifndef PT_NO_HEAD_ILP
     {
         // The FIRST always-tested sphere (the ground of most scenes) without a branch, so that its chain -- load,
         // discriminant, square root, two quotients -- shares one basic block with the ray's features above and the box clip of the
@@ -818,7 +801,6 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
         }
         j_first = 1;
     }
-#endif
     for (uint32_t j = j_first; j < A.n_large; ++j) {
         const int k = (int)A.large[j];
         if (active) exact_candidate<GATED>(A, G, sphere_at_m<MOVING>(mot, k, sph[k], time), k, o, d, av, best, idx, best_rank);
@@ -827,9 +809,6 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
     uint32_t rem = A.n_tiles >= 32u ? 0xffffffffu : ((1u << A.n_tiles) - 1u);
     uint32_t mine = rem;   // tiles THIS lane's ray can find its winner in; the wave runs the union
     if (culling) {
-#ifdef PT_NO_HEAD_ILP
-        clip = lane_tile_clip(P, o, d, active);
-#endif
         mine = lane_tile_mask_of(P, s_cull, clip, o, d, best, cull_axis, cull_always);
         rem = wave_or(mine);
 #ifdef PT_CULLSTATS
@@ -1139,23 +1118,12 @@ __device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float tim
     const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
     const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
     const float disc = b * b - a * cc;
-#ifndef PT_NO_HEAD_ILP
     const float t = sphere_hit_t(av, b, disc, true);
     if (t < kMaxT) {
         const uint32_t low = gated ? (0xffffffffu - __float_as_uint(g2.x)) : (uint32_t)k;
         const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | low;
         if (kk < *key && (!gated || gate_pass_loaded(A, g0, g1, o, rcp))) atomicMin(key, kk);   // rcp = ray.rs:14 rcp_direction of the OWNER's ray
     }
-#else
-    if (disc > 0.0f) {
-        float t = kMaxT;
-        if (sphere_roots(av, b, disc, t)) {
-            const uint32_t low = gated ? (0xffffffffu - __float_as_uint(g2.x)) : (uint32_t)k;
-            const unsigned long long kk = ((unsigned long long)__float_as_uint(t) << 32) | low;
-            if (kk < *key && (!gated || gate_pass_loaded(A, g0, g1, o, rcp))) atomicMin(key, kk);   // rcp = ray.rs:14 rcp_direction of the OWNER's ray
-        }
-    }
-#endif
 }
 
 template <bool MOVING, int BLK>
@@ -1469,7 +1437,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 #define PT_SEC(i) do { } while (0)
 #endif
     bool have = false, exhausted = false, need_cam = true, trav_new = false, finished = false;
-    bool pend_metal = false;    // PT_SHARED_REJECT: the lane's Metal scatter waits for its sphere sample (drawn with the next camera rays' lens samples)
+    bool pend_metal = false;    // the lane's Metal scatter waits for its sphere sample (drawn with the next camera rays' lens samples)
     float metal_fuzz = 0.0f;
     uint32_t pix_rays = 0;
     BvhTrav trav{0u, 0u, 0, kMaxT, -1, 0u, false};
@@ -1622,18 +1590,14 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         PT_SEC(0);
 
         // ---- camera.rs:56-68 + scene.rs:107-108: start the next sample -- and, in the same rejection loop, the
-        // random_in_unit_sphere a Metal scatter of the LAST iteration still owes (material.rs:77; PT_SHARED_REJECT).
+        // random_in_unit_sphere a Metal scatter of the LAST iteration still owes (material.rs:77).
         // Both are "draw until the point lies inside the unit ball" loops (math.rs:6-13 in the plane, math.rs:15-26 in space), and
         // a wave runs such a loop as often as its unluckiest lane needs: 2.8 trips for the lens, 3.1 for the metal lanes, one
         // after the other. A lane is in at most one of the two roles here -- a path that scattered off metal continues, so it
         // needs no camera ray -- and its draws keep their order (the sphere's three draws were the lane's next ones anyway), so
         // both loops become ONE whose trips cost the maximum instead of the sum. Same arithmetic per role: x = 2a - 1 etc.,
         // (x x + y y) + z z with z = 0 in the plane, which is the reference's (x x + y y) + 0.
-#ifdef PT_SHARED_REJECT
         const bool cam_role = have && need_cam, met_role = have && pend_metal;
-#else
-        const bool cam_role = have && need_cam, met_role = false;
-#endif
         if (cam_role || met_role) {
             const float4 c0 = s_par[4], c1 = s_par[5], c2 = s_par[6], c3 = s_par[7], c4 = s_par[8], c5 = s_par[9], pn2 = s_par[3];
             const f3 cam_origin = mk3(c0.x, c0.y, c0.z), cam_llc = mk3(c0.w, c1.x, c1.y), cam_horizontal = mk3(c1.z, c1.w, c2.x),
@@ -1673,11 +1637,6 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         }
 
         PT_SEC(1);
-#ifdef PT_VNOPS
-        // (experiment: how sensitive is the frame to VALU issue slots? PT_VNOPS idle VALU instructions per wave-iteration)
-#pragma unroll
-        for (int q = 0; q < PT_VNOPS; ++q) asm volatile("v_nop");
-#endif
         // ---- hitable.rs:39-65: closest hit (inactive lanes carry a null ray)
         const f3 ro = have ? o : mk3(0.f, 0.f, 0.f);
         const f3 rd = have ? d : mk3(0.f, 0.f, 0.f);
@@ -1820,14 +1779,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         if (dot3(reflected, normal) > 0.0f) {
                             att = mk3(qa.x, qa.y, qa.z);
                             attc = (WST ? kWstCode : 0u) | (uint32_t)idx;
-#ifdef PT_SHARED_REJECT
                             raw = reflected, pend_metal = true;   // sampled at the top of the next iteration
                             if (MFMA) reinterpret_cast<uint32_t *>(s_queue)[tid] = __float_as_uint(m.param);
                             else metal_fuzz = m.param;
-#else
-                            const f3 rs = random_in_unit_sphere(rng);
-                            raw = add3(reflected, scale3(rs, m.param));
-#endif
                             scattered = true;
                         }
                     } else if (m.kind == PT_MAT_DIELECTRIC) {  // material.rs:91-124
@@ -1855,11 +1809,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         scattered = true;
                     }
                     // (the direction is replaced in place as well: a path that does not scatter ends, and its lane's next ray is a camera ray)
-#ifdef PT_SHARED_REJECT
                     if (scattered) d = pend_metal ? raw : normalize3(raw);
-#else
-                    if (scattered) d = normalize3(raw);
-#endif
                 }
                 if (scattered) {
                     // the first scatter's attenuation stays in registers (measured best: 0 levels -1.5 %, 2 levels -2.3 %;
@@ -1951,13 +1901,11 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 }
             }
         }
-#ifndef PT_SKIP_EDGE
         // The loop's only exit, at its very end. (A wave whose refill brought no pixel -- beyond the frame's edge, or the list ran dry --
         // used to skip the body with `continue` / leave with `break` from here up there. The compiler's structurizer turns such an edge
         // into a flag tested after the body, which keeps every loop-carried register's start-of-iteration value alive THROUGH the body:
         // a second home for ~28 registers and ~45 copies per wave-iteration. An idle trip through the body is harmless: no lane has a ray.)
         if (wave_ballot(have) == 0ull && wave_ballot(!exhausted) == 0ull) break;
-#endif
     }
 
     if (TAIL && A.tail_cap != 0u) {
