@@ -145,9 +145,20 @@ def roofline_block(kernel_name, kms, rays_launch, n_hitables, use_bvh, counters)
             out["shader_clock_ghz"] = cyc / (per_launch["kernel_avg_ms_rocprof"] * 1e-3) / 1e9
             if "SQ_VALU_MFMA_BUSY_CYCLES" in per_launch:
                 out["mfma_busy_frac"] = per_launch["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * N_SIMD)
+            # the nominal peak assumes 2.4 GHz; the same fraction against the clock the kernel really ran at
+            out["peak_at_measured_clock"] = VALU_PEAK_TLANEOPS * out["shader_clock_ghz"] / 2.4
+            out["frac_at_measured_clock"] = out["achieved"] / out["peak_at_measured_clock"]
             if "SQ_WAIT_INST_ANY" in per_launch and "SQ_WAVE_CYCLES" in per_launch:
                 out["issue_stall_frac_of_wave_cycles"] = per_launch["SQ_WAIT_INST_ANY"] / per_launch["SQ_WAVE_CYCLES"]
                 out["parked_frac_of_wave_cycles"] = per_launch.get("SQ_WAIT_ANY", 0.0) / per_launch["SQ_WAVE_CYCLES"]
+        if per_launch.get("SQ_ACTIVE_INST_VALU") and "SQ_THREAD_CYCLES_VALU" in per_launch:
+            # `frac` counts every issued wave-instruction as 64 lanes: it is ISSUE-SLOT occupancy. How many of those lanes were
+            # switched on is rocprof's VALUUtilization = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64) (calibrated with
+            # tools/valu_bench.hip at 64 / 32 / 16 active lanes: profiles/r04_valu_lane_calibration.txt); their product is the
+            # fraction of the peak spent on lanes that compute something
+            out["valu_lane_utilisation"] = per_launch["SQ_THREAD_CYCLES_VALU"] / (per_launch["SQ_ACTIVE_INST_VALU"] * 64.0)
+            out["frac_useful"] = out["frac"] * out["valu_lane_utilisation"]
+            out["achieved_useful"] = out["achieved"] * out["valu_lane_utilisation"]
         if "SQ_INSTS_LDS" in per_ray:
             out["lds_wave_insts"] = per_ray["SQ_INSTS_LDS"] * rays_launch
             out["lds_bank_conflict_cycles_per_inst"] = per_launch.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(per_launch["SQ_INSTS_LDS"], 1.0)
@@ -164,7 +175,8 @@ def roofline_block(kernel_name, kms, rays_launch, n_hitables, use_bvh, counters)
         out["algorithmic_equiv"] = {"scan_bytes_per_ray": 16.0 * n_hitables, "scan_equiv_gbs": eq,
                                     "note": "reference-scan equivalent rate (SURVEY 8d), LDS/matrix-core served; not a roofline fraction"}
     out["note"] = ("the path is bound by VALU issue + dependency/divergence stalls, not by HBM or MFMA (SURVEY 8d): frac = "
-                   "SQ_INSTS_VALU x 64 lanes / kernel time against 78.6 T lane-ops/s (256 CU x 4 SIMD x 2.4 GHz / 2 cycles); "
+                   "SQ_INSTS_VALU x 64 lanes / kernel time against 78.6 T lane-ops/s (256 CU x 4 SIMD x 2.4 GHz / 2 cycles) is issue-slot "
+                   "occupancy; frac_useful = frac x valu_lane_utilisation counts only the lanes that were switched on; "
                    "hbm_frac = measured FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE bytes / kernel time against 8 TB/s")
     return out
 

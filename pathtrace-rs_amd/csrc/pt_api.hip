@@ -33,6 +33,8 @@ const DevKnobs &dev_knobs() {
         if (const char *e = getenv("PTGPU_CULL_STRIPS")) d.cull_strips = atoi(e);
         if (const char *e = getenv("PTGPU_COOP_LIVE")) d.coop_live = atoi(e);
         if (const char *e = getenv("PTGPU_COOP_STREAK")) d.coop_streak = atoi(e);
+        if (const char *e = getenv("PTGPU_COOP_PERIOD")) d.coop_period = atoi(e);
+        if (const char *e = getenv("PTGPU_COOP_EST")) d.coop_est = atoi(e);
         if (const char *e = getenv("PTGPU_HOST_THREADS")) d.host_threads = std::max(0, atoi(e));
         if (const char *e = getenv("PTGPU_BLOCKS_PER_CU")) d.blocks_per_cu = (uint32_t)atoi(e);
         if (const char *e = getenv("PTGPU_VARIANT")) d.variant = (uint32_t)atoi(e);

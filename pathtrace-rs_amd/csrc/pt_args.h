@@ -162,6 +162,8 @@ struct KArgs {
     uint32_t tail_gen;           // this launch's stamp in the mailboxes' words (never 0, below 2^30)
     uint32_t tail_live_max;      // a wave with at most this many live pixels hands over to any idle worker it finds ...
     uint32_t tail_streak;        // ... any wave does after this many probes in a row that found an idle worker
+    uint32_t tail_period_mask;   // a wave with more live pixels probes when (iteration & mask) == 0 (3: every fourth)
+    float tail_min_est;          // a pixel with fewer estimated rays left is not worth the hand-over's global round trips
     uint32_t tail_dbg;           // -DPT_DEVKNOBS builds (PTGPU_COOP_DBG): 1 no workers, 2 no probes, 4 no started / done counting
     const uint32_t *tile_order;  // optional permutation of the 8x8 work tiles (expensive tiles first)
     uint32_t *tile_cost;         // optional: rays spent per work tile (accumulated when a pixel completes): the pilot pass' result,

@@ -4,14 +4,14 @@
 #include <cstdio>
 #include <hip/hip_runtime.h>
 extern "C" {
-__device__ __attribute__((used, visibility("default"))) unsigned long long pt_bbprof[16384];
+__device__ __attribute__((used, visibility("default"))) unsigned long long pt_bbprof[32768];   // [0, 16384) executions of block i; [16384, 32768) lanes that were switched on, summed over them
 }
 extern "C" __attribute__((visibility("default"), used)) inline int pt_bbprof_dump(const char *path) {
-    static unsigned long long host[16384];
+    static unsigned long long host[32768];
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(host, HIP_SYMBOL(pt_bbprof), sizeof host) != hipSuccess) return -1;
     FILE *f = fopen(path, "w");
     if (!f) return -2;
-    for (int i = 0; i < 16384; ++i)
+    for (int i = 0; i < 32768; ++i)
         if (host[i]) fprintf(f, "%d %llu\n", i, host[i]);
     fclose(f);
     return 0;

@@ -51,7 +51,6 @@ namespace ptdev {
 
 enum : uint32_t { kCtlWork = 0, kCtlDone = 1, kCtlStarted = 6 };
 constexpr uint32_t kBoxIdle = 1u, kBoxClaimed = 2u, kBoxPixel = 3u;
-constexpr float kCoopMinEst = 24.0f;   // a pixel with fewer estimated rays left is not worth the hand-over's global round trips
 
 __device__ __forceinline__ uint32_t ctl_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint64_t wt_load(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -364,7 +363,10 @@ __device__ __forceinline__ void coop_worker(const KArgs &A, const GateSrc &G, co
             }
             kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
             if (kind != 0u) break;
-            for (uint32_t i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(16);
+            // (4 096 ... 16 384 cycles between two looks: an idle worker's polls are instructions its SIMD's busy waves do not get --
+            // with 1 024-cycle naps they were 8 % of ALL VALU instructions of a config-3 frame, each with one lane switched on:
+            // tools/bbprof.py, profiles/r04_bbprof_lanes.txt)
+            for (uint32_t i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(64);
             nap = nap < 4u ? nap * 2u : 4u;
         }
         if (kind == 2u) return;

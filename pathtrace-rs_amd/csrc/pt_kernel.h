@@ -1298,7 +1298,7 @@ namespace ptdev {
 // times, and the LDS that frees holds the per-lane attenuation stacks (no HBM traffic for them).
 #ifdef PT_BBPROF   // tools/bbprof.py: the instrumented assembly keeps its counter registers above the compiler's
 #include "pt_bbprof.h"
-#define PT_BBPROF_ATTR __attribute__((amdgpu_num_sgpr(104)))
+#define PT_BBPROF_ATTR __attribute__((amdgpu_num_sgpr(100)))
 #else
 #define PT_BBPROF_ATTR
 #endif
@@ -1576,7 +1576,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         bool tail_polled = false;   // (wave-uniform)
         if (TAIL && A.tail_cap != 0u) {
             tail_dry = tail_dry || wave_any(exhausted);
-            tail_polled = tail_dry && PT_COOP_DBG(2u) && ((tail_it & 3u) == 0u || (uint32_t)__popcll(wave_ballot(have)) <= A.tail_live_max);
+            tail_polled = tail_dry && PT_COOP_DBG(2u) && ((tail_it & A.tail_period_mask) == 0u || (uint32_t)__popcll(wave_ballot(have)) <= A.tail_live_max);
             if (tail_polled) {
                 tail_rand = tail_rand * 1664525u + 1013904223u;
                 tail_target = __umulhi(tail_rand, A.tail_cap);
@@ -1894,7 +1894,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 const bool cand = have && need_cam;   // between two samples
                 const uint32_t done_s = sd >> 12;
                 const float est = (float)pix_rays * (float)(__float_as_uint(s_par[12].w) - done_s) * __builtin_amdgcn_rcpf((float)done_s);   // rays per sample so far x samples left
-                const uint32_t eb = (cand && est >= kCoopMinEst) ? __float_as_uint(est) : 0u;   // (NaN before the first sample: not >=)
+                const uint32_t eb = (cand && est >= A.tail_min_est) ? __float_as_uint(est) : 0u;   // (NaN before the first sample: not >=)
                 const uint32_t mx = wave_max_u32(eb);
                 if (mx != 0u && eb == mx && lane == __builtin_ctzll(wave_ballot(eb == mx))) {
                     if (coop_hand_over(A, tail_target, rng, col, pxy, done_s, pix_rays)) have = false;   // (not `finished`: nothing is written, the lane simply holds no pixel any more)

@@ -398,6 +398,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
 #endif
         A.tail_live_max = dev_knobs().coop_live >= 0 ? (uint32_t)dev_knobs().coop_live : 4u;
         A.tail_streak = dev_knobs().coop_streak >= 0 ? (uint32_t)dev_knobs().coop_streak : 2u;
+        A.tail_period_mask = dev_knobs().coop_period >= 0 ? (uint32_t)dev_knobs().coop_period : 3u;
+        A.tail_min_est = dev_knobs().coop_est >= 0 ? (float)dev_knobs().coop_est : 24.0f;
     }
     if (c.gstack) {
         if (int rc = ensure_gstack(s, (size_t)grid * params->max_depth * 3ull * blk)) return rc;

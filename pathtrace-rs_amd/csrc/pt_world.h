@@ -344,7 +344,7 @@ __device__ __forceinline__ void w_hitable_rec(const pt_hitable &H, const pt_affi
 // CHAINS: some entry sits below more than one Instance level, or below Instances around its medium (scene graphs only).
 #ifdef PT_BBPROF   // tools/bbprof.py (BBPROF_UNIT=pt_kernels_world): the instrumented assembly keeps its counter registers above the compiler's
 #include "pt_bbprof.h"
-#define PT_WBBPROF_ATTR __attribute__((amdgpu_num_sgpr(104)))
+#define PT_WBBPROF_ATTR __attribute__((amdgpu_num_sgpr(100)))
 #else
 #define PT_WBBPROF_ATTR
 #endif

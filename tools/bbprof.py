@@ -9,7 +9,11 @@ No PC sampling or thread trace is available on the pool, and the kernels' time t
   gpurun -- python3 tools/bbprof.py run [--preset P ...]    # GPU box: renders frames, dumps gpurun_out/bbprof_counts.txt
   python3 tools/bbprof.py report     # here: counts x static per-block instruction mix, by kernel and by source line
 
-The instrumented kernels reserve s[96:99] (the build caps the compiler at 96 SGPRs), so their register allocation differs a
+Every block also adds popcount(exec) to a second counter, so the report knows how many of the 64 lanes were switched on when the
+block ran: blocks are ranked by MASKED lane-instructions (VALU instructions x lanes that were off) as well, and the kernel's lane
+utilisation comes out as rocprof's VALUUtilization does (sum of active lanes over sum of issued lanes).
+
+The instrumented kernels reserve s[92:99] (the build caps the compiler at 92 SGPRs), so their register allocation differs a
 little from the shipped ones: use the result for proportions, not absolute counts.
 """
 import collections, json, os, re, subprocess, sys
@@ -49,6 +53,10 @@ def instrument(src_lines):
         cur = {"kernel": kernel, "label": name, "valu": 0, "salu": 0, "lds": 0, "mfma": 0, "vmem": 0, "other": 0, "trans": 0, "lanes": 0, "movs": 0, "lines": collections.Counter()}
         blocks.append(cur)
         out.append("\ts_atomic_add_x2 s[96:97], s[98:99], 0x%x" % (8 * (len(blocks) - 1)))
+        # active lanes of this execution into the second half of the counter array. s_bcnt1 writes SCC, which may be live across
+        # the block's entry (a compare in the block above): saved and restored. The wait keeps the data pair stable under the atomic.
+        out.extend(["\ts_cselect_b32 s94, 1, 0", "\ts_bcnt1_i32_b64 s92, exec", "\ts_mov_b32 s93, 0",
+                    "\ts_atomic_add_x2 s[92:93], s[98:99], 0x%x" % (8 * (len(blocks) - 1) + 8 * 16384), "\ts_waitcnt lgkmcnt(0)", "\ts_cmp_lg_u32 s94, 0"])
 
     for l in src_lines:
         m = re.match(r'\s*\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', l)
@@ -73,6 +81,13 @@ def instrument(src_lines):
                 l = "\t\t.amdhsa_next_free_sgpr 100"
             m = re.match(r"\s*\.loc\s+(\d+)\s+(\d+)", l)
             if m: loc = (files.get(int(m.group(1)), "?"), int(m.group(2)))
+            # an instruction that writes exec (the restore at a join, a saveexec whose region was too short for a skip branch) changes
+            # how many lanes the REST of the block runs with: a new counted segment starts behind it
+            if cur is not None and re.match(r"^\s+s_\w+\s+exec\b", l) or (cur is not None and re.match(r"^\s+s_\w*saveexec_b64\s", l)):
+                cur["salu"] += 1
+                out.append(l)
+                open_block(cur["label"].rstrip("+") + "+")
+                continue
             m = re.match(r"^\s+([a-z_0-9]+)(\s|$)", l)
             if m and cur is not None and not m.group(1).startswith("."):
                 op = m.group(1)
@@ -166,10 +181,11 @@ def remap():
 def report(argv):
     counts_file = argv[0] if argv else os.path.join(ROOT, "gpurun_out", "bbprof_counts.txt")
     blocks = json.load(open(os.path.join(OUT, "bbprof_map.json")))
-    counts, rays = {}, 0
+    counts, lanes_on, rays = {}, {}, 0
     for l in open(counts_file):
         a, b = l.split()
         if a == "rays": rays = int(b)
+        elif int(a) >= 16384: lanes_on[int(a) - 16384] = int(b)
         else: counts[int(a)] = int(b)
     per_kernel = collections.defaultdict(lambda: collections.Counter())
     lines = collections.defaultdict(lambda: collections.Counter())
@@ -182,15 +198,27 @@ def report(argv):
         per_kernel[k]["blocks"] += n
         if b["label"] == "entry": per_kernel[k]["waves"] += n
         for ln, c in b["lines"].items(): lines[k][ln] += n * c
-        rows[k].append((n * b["valu"], n, b))
+        on = lanes_on.get(i, 64 * n)
+        per_kernel[k]["lane_issued"] += 64 * n * b["valu"]
+        per_kernel[k]["lane_on"] += on * b["valu"]
+        rows[k].append((n * b["valu"], n, b, on))
     for k, tot in sorted(per_kernel.items(), key=lambda kv: -kv[1]["valu"]):
         print("==", k)
         if rays: print("   VALU wave-instructions per 64 rays (all kernels' rays): %.1f" % (tot["valu"] / (rays / 64.0)))
         print("   waves %d; dynamic wave-instructions: VALU %.4g (of them v_rcp/sqrt/div_* %.3g)  SALU %.4g  LDS %.4g  MFMA %.4g  VMEM %.4g" %
               (tot["waves"], tot["valu"], tot["trans"], tot["salu"], tot["lds"], tot["mfma"], tot["vmem"]))
         print("   of the VALU instructions: v_readlane/v_writelane %.3g (%.1f%%), v_mov %.3g (%.1f%%)" % (tot["lanes"], 100.0 * tot["lanes"] / tot["valu"], tot["movs"], 100.0 * tot["movs"] / tot["valu"]))
+        if tot["lane_issued"]:
+            print("   VALU lane utilisation (active lanes / issued lanes, as rocprof's VALUUtilization): %.1f%%" % (100.0 * tot["lane_on"] / tot["lane_issued"]))
+            print("   -- blocks by MASKED lane-instructions (VALU instructions x lanes switched off): share of all masked, lanes on of 64, share of all VALU")
+            masked_total = tot["lane_issued"] - tot["lane_on"]
+            for dv, n, b, on in sorted(rows[k], key=lambda r: -(64 * r[1] - r[3]) * r[2]["valu"])[:40]:
+                top = sorted(b["lines"].items(), key=lambda kv: -kv[1])[:4]
+                print("   %5.2f%%  %-11s lanes on %4.1f  valu share %5.2f%%  runs %.3g x valu %d  %s" % (
+                    100.0 * (64 * n - on) * b["valu"] / max(masked_total, 1), b["label"], on / max(n, 1), 100.0 * dv / tot["valu"], n, b["valu"],
+                    " ".join("%s(%d)" % (a.replace("pt_kernel.h", "k").replace("pt_device.h", "d").replace("pt_coop.h", "c").replace("__clang_hip_math.h", "m"), c) for a, c in top)))
         print("   -- blocks by dynamic VALU")
-        for dv, n, b in sorted(rows[k], key=lambda r: -r[0])[:45]:
+        for dv, n, b, _on in sorted(rows[k], key=lambda r: -r[0])[:45]:
             top = sorted(b["lines"].items(), key=lambda kv: -kv[1])[:5]
             print("   %5.2f%%  %-11s runs %.3g x (valu %d salu %d lds %d mfma %d)  %s" % (100.0 * dv / tot["valu"], b["label"], n, b["valu"], b["salu"], b["lds"], b["mfma"],
                                                                                     " ".join("%s(%d)" % (a.replace("pt_kernel.h", "k").replace("pt_device.h", "d").replace("__clang_hip_math.h", "m"), c) for a, c in top)))
