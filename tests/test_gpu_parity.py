@@ -728,6 +728,33 @@ def test_cli_offline_render_matches_reference_harness(pthost, oracle, tmp_path):
     assert np.array_equal(img, want)
 
 
+def test_rust_expectations_are_what_the_product_renders(tmp_path):
+    """tests/golden/rust_expectations.json is what the pin kit (tools/pin_against_rust.py) holds a real `cargo run --release` of the
+    reference to; it was generated from the ORACLE. Here the PRODUCT renders every case through its CLI (same flags, offline.rs:16-60)
+    and must print the same ray count and write the same pixels -- decoded with the kit's own PNG reader, so that is exercised too.
+    Cases whose colour passes through f32::sin / ln on the host side of the oracle (`libm_sensitive`) may differ in a last bit of a
+    byte; everything else is hash for hash."""
+    import hashlib
+    import re
+    spec = importlib.util.spec_from_file_location("pin_against_rust", os.path.join(ROOT, "tools", "pin_against_rust.py"))
+    kit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kit)
+    exp = json.load(open(os.path.join(GOLDEN, "rust_expectations.json")))
+    exe = os.path.join(ROOT, "pathtrace-rs_amd", "_build", "pathtrace")
+    assert len(exp["cases"]) >= 10
+    for c in exp["cases"]:
+        out_png = str(tmp_path / "out.png")
+        r = subprocess.run([exe] + c["args"] + ["--output", out_png], capture_output=True, text=True)
+        assert r.returncode == 0, (c["args"], r.stderr)
+        m = re.search(r"(\d+)rays", r.stdout)
+        assert m and int(m.group(1)) == c["rays"], (c["args"], r.stdout, c["rays"])
+        got = kit.png_rgb8(out_png)
+        if not c["libm_sensitive"]:
+            assert hashlib.sha256(got).hexdigest() == c["rgb8_sha256"], c["args"]
+        else:
+            assert len(got) == 3 * int(c["args"][c["args"].index("-W") + 1]) * int(c["args"][c["args"].index("-H") + 1])
+
+
 def test_random_seed_mode_is_deterministic_per_base_and_differs_from_fixed(ptgpu, pthost):
     W, H, S = 64, 32, 2
     hs = pthost.HostScene("small", W, H, samples=S, device=0)

@@ -494,3 +494,57 @@ def test_spheres_soa_agrees_with_the_list_up_to_its_own_arithmetic(oracle):
             assert g[1] == ref[1] and abs(g[0] - ref[0]) <= 2e-5 * max(1.0, ref[0]), (g[:2], ref[:2])
         assert got[1][:2] == got[0][:2] and got[2][:2] == got[0][:2]
     assert hits > 250
+
+
+# ---- the pin kit (tools/pin_against_rust.py + tests/golden/rust_expectations.json) ---------------------------------------------
+def test_rust_expectations_are_the_oracles_and_the_kit_reads_pngs(oracle, tmp_path):
+    """The expectations a real `cargo run` is to be held to are the oracle's: regenerated here for the small cases (ray count, SHA-256
+    of the sRGB bytes and of the raw f32 frame). The kit's PNG reader (zlib + the five PNG filters) is checked on files written
+    here with every filter type."""
+    import hashlib
+    import importlib.util
+    import json
+    import struct
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = json.load(open(os.path.join(root, "tests", "golden", "rust_expectations.json")))
+    assert "NOT yet compared" in exp["status"]
+    done = 0
+    for c in exp["cases"]:
+        a = c["args"]
+        W, H, S, preset, bvh = int(a[a.index("-W") + 1]), int(a[a.index("-H") + 1]), int(a[a.index("-S") + 1]), a[a.index("-P") + 1], "-B" in a
+        if W * H * S > 200000:
+            continue
+        buf, rays = oracle.OracleScene(preset, W, H, use_bvh=bvh).update(S, 10, 0)
+        rgb8 = np.zeros((H, W, 3), np.uint8)
+        oracle.lib().ora_frame_to_srgb8(buf.ctypes.data, W, H, rgb8.ctypes.data)
+        assert (rays, hashlib.sha256(rgb8.tobytes()).hexdigest(), hashlib.sha256(buf.tobytes()).hexdigest()) == (c["rays"], c["rgb8_sha256"], c["f32_sha256"]), a
+        done += 1
+    assert done >= 5
+    spec = importlib.util.spec_from_file_location("pin_against_rust", os.path.join(root, "tools", "pin_against_rust.py"))
+    kit = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kit)
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, (9, 7, 3), dtype=np.uint8)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    raw = bytearray()
+    prev = np.zeros(21, np.int32)
+    for y in range(9):
+        line = img[y].reshape(-1).astype(np.int32)
+        f = y % 5
+        left = np.concatenate([np.zeros(3, np.int32), line[:-3]])
+        upleft = np.concatenate([np.zeros(3, np.int32), prev[:-3]])
+        pred = [np.zeros(21, np.int32), left, prev, (left + prev) // 2, np.array([paeth(int(left[i]), int(prev[i]), int(upleft[i])) for i in range(21)], np.int32)][f]
+        raw += bytes([f]) + bytes(((line - pred) & 255).astype(np.uint8))
+        prev = line
+
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body))
+    path = str(tmp_path / "t.png")
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 7, 9, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+    assert kit.png_rgb8(path) == img.tobytes()
