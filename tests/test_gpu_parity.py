@@ -253,14 +253,16 @@ def test_work_order_from_the_previous_frame_never_changes_a_pixel(ptgpu, pthost,
         assert np.array_equal(runs["reuse"][0], runs[name][0]) and np.array_equal(runs["reuse"][1], runs[name][1])
 
 
-@pytest.mark.parametrize("preset,bvh,W,H,S,frames", [
-    ("random_spheres", False, 96, 64, 48, 2),     # 6 144 pixels for 262 144 lanes: nearly every pixel is finished by a worker
-    ("random_spheres", True, 96, 64, 48, 1),      # BVH world on the list kernel: the ancestor-AABB gate + DFS-rank ties inside the workers' scan
-    ("random", False, 96, 64, 32, 1),             # Sphere + MovingSphere world: rays keep their time in the workers as well
-    ("aras", False, 160, 90, 32, 2),              # diffuse lights, 46 spheres (one register set per lane)
-    ("random_spheres", False, 600, 400, 24, 1),   # more pixels than lanes for a while: the hand-over only starts once the list is dry
+@pytest.mark.parametrize("preset,bvh,W,H,S,frames,depth", [
+    ("random_spheres", False, 96, 64, 48, 2, 10),     # 6 144 pixels for 262 144 lanes: nearly every pixel is finished by a worker
+    ("random_spheres", True, 96, 64, 48, 1, 10),      # BVH world on the list kernel: the ancestor-AABB gate + DFS-rank ties inside the workers' scan
+    ("random", False, 96, 64, 32, 1, 10),             # Sphere + MovingSphere world: rays keep their time in the workers as well
+    ("aras", False, 160, 90, 32, 2, 10),              # diffuse lights, 46 spheres (one register set per lane)
+    ("random_spheres", False, 600, 400, 24, 1, 10),   # more pixels than lanes for a while: the hand-over only starts once the list is dry
+    ("random_spheres", False, 96, 64, 32, 1, 33),     # depth 33: the 768-thread kernel (12 waves per workgroup), 33 attenuation levels in the workers' lanes
+    ("random_spheres", True, 96, 64, 32, 1, 0),       # depth 0: every path ends at its first hit
 ])
-def test_cooperative_handover_never_changes_a_pixel(ptgpu, pthost, oracle, preset, bvh, W, H, S, frames):
+def test_cooperative_handover_never_changes_a_pixel(ptgpu, pthost, oracle, preset, bvh, W, H, S, frames, depth):
     """csrc/pt_coop.h: once the work list is dry, waves that have run out of pixels finish pixels handed over by busy waves, all 64
     lanes on each ray (scene.rs:96-111 makes a pixel ONE serial chain of samples; this shortens the chain). The pixel's RNG stream,
     colour sum and counters travel with it, so neither a pixel nor the ray count may depend on who traced it: the frame with the
@@ -272,7 +274,7 @@ def test_cooperative_handover_never_changes_a_pixel(ptgpu, pthost, oracle, prese
         sc = hs.device_scene()
         sc.set_tuning(0, variant)
         sc.coop_counters(reset=True)
-        p = ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0)
+        p = ptgpu.PtParams(W, H, S, depth, 0, 1 if bvh else 0)
         out, rays = np.zeros((H, W, 3), np.float32), []
         for frame in range(frames):
             rays.append(sc.update(p, hs.camera, frame, out))
@@ -281,15 +283,18 @@ def test_cooperative_handover_never_changes_a_pixel(ptgpu, pthost, oracle, prese
     assert runs["coop"][3]["coop"] == 1 and runs["plain"][3]["coop"] == 0, (runs["coop"][3], runs["plain"][3])
     assert runs["plain"][2]["pixels"] == 0
     handed = runs["coop"][2]
-    assert handed["pixels"] > 0 and handed["rays"] > 0, handed
-    if preset == "random_spheres" and W * H <= 16384:
+    if depth > 0:   # (at depth 0 a sample is one ray: no pixel ever has the two dozen estimated rays left that a hand-over asks for)
+        assert handed["pixels"] > 0 and handed["rays"] > 0, handed
+    if depth == 33:
+        assert runs["coop"][3]["block"] == 768, runs["coop"][3]
+    if preset == "random_spheres" and W * H <= 16384 and depth == 10:
         assert handed["pixels"] > W * H // 4, "a frame this small should be finished mostly by workers: %r" % (handed,)
     assert runs["coop"][1] == runs["plain"][1], (runs["coop"][1], runs["plain"][1])
     assert np.array_equal(runs["coop"][0], runs["plain"][0]), _report(runs["plain"][0], runs["coop"][0])
     osc = oracle.OracleScene(preset, W, H, use_bvh=bvh)
     ref, ref_rays = np.zeros((H, W, 3), np.float32), []
     for frame in range(frames):
-        ref, r = osc.update(S, 10, frame, buffer=ref)
+        ref, r = osc.update(S, depth, frame, buffer=ref)
         ref_rays.append(r)
     assert runs["coop"][1] == ref_rays, (runs["coop"][1], ref_rays)
     assert np.array_equal(runs["coop"][0], ref), _report(ref, runs["coop"][0])
