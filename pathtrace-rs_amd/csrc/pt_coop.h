@@ -116,6 +116,10 @@ __device__ __forceinline__ void coop_trace_pixel(const KArgs &A, const GateSrc &
     const uint32_t pxy = (uint32_t)(w5 >> 32);
     uint32_t sample = (uint32_t)w6, rays = (uint32_t)(w6 >> 32);
     const uint32_t rays_before = rays;
+#ifdef PT_DEVKNOBS   // (PTGPU_TIMING=1: one log entry per handed-over pixel, pt_launch.hip prints the timeline)
+    const unsigned long long log_t0 = A.wave_end ? wall_clock64() : 0ull;
+    const uint32_t log_sample0 = sample;
+#endif
     const float4 pcnt = s_par[12];
     const uint32_t max_depth = __float_as_uint(pcnt.z), n_samples = __float_as_uint(pcnt.w);
     const float fpx = (float)(pxy & 0xffffu), fpy = (float)((pxy >> 16) * A.shard_count + A.shard_index);
@@ -323,6 +327,15 @@ __device__ __forceinline__ void coop_trace_pixel(const KArgs &A, const GateSrc &
         out[2] = p2 * pf.y + col.z * pf.z;
         if (A.tile_cost) atomicAdd(&A.tile_cost[((pxy >> 16) >> kTileLog2) * A.tiles_x + ((pxy & 0xffffu) >> kTileLog2)], rays);
         atomicAdd(&A.debug[88], 1ull), atomicAdd(&A.debug[89], (unsigned long long)(rays - rays_before));   // pt_scene_coop_counters
+#ifdef PT_DEVKNOBS
+        if (A.wave_end) {
+            const unsigned long long slot = atomicAdd(&A.debug[91], 1ull);
+            if (slot < 130000ull) {
+                unsigned long long *e = A.wave_end + 65536 + 4 * slot;
+                e[0] = log_t0, e[1] = wall_clock64(), e[2] = (unsigned long long)(rays - rays_before) | ((unsigned long long)log_sample0 << 32), e[3] = pxy | ((unsigned long long)rays_before << 32);
+            }
+        }
+#endif
     }
     wave_rays += (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(rays - rays_before));   // scene.rs:57 (the rays before the hand-over were counted by the wave that traced them)
 }

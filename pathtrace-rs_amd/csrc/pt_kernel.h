@@ -1471,6 +1471,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     bool first_claim = true;   // (wave-uniform: every lane of a wave takes part in its first fetch)
     bool tail_dry = TAIL && A.tail_dry0 != 0u;     // TAIL, wave-uniform: the work list has run dry (from then on pixels may be handed over)
     uint32_t tail_it = 0, tail_streak = 0, tail_rand = (blockIdx.x * (BLK / 64) + wave_id) * 2654435761u + 12345u;   // (wave-uniform)
+#ifdef PT_DEVKNOBS
+    if (A.wave_end && lane == 0) atomicMin(&A.wave_end[65535], (unsigned long long)wall_clock64());   // (the launch's first wave: origin of the hand-over log's timeline)
+#endif
 #if defined(PT_SECTIONS) || defined(PT_WAVEDBG)
 #define PT_WAVE_DETAIL 1   // development builds: per-wave iteration counts, first / last pixel, moment the work list ran dry
     uint32_t dbg_first_pxy = 0xffffffffu;

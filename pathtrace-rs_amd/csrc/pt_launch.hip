@@ -410,7 +410,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     if (int rc = raise_lds_limit(s->device, reinterpret_cast<const void *>(kern), lds)) return rc;
     HIP_TRY(hipEventRecord(s->ev_pass, stream));
     A.wave_end = s->d_wave_end;
-    if (s->d_wave_end) (void)hipMemsetAsync(s->d_wave_end, 0, 65536 * 8, stream);
+    if (s->d_wave_end) (void)hipMemsetAsync(s->d_wave_end, 0, 65535 * 8, stream), (void)hipMemsetAsync(s->d_wave_end + 65535, 0xff, 8, stream), (void)hipMemsetAsync(s->d_debug + 91, 0, 8, stream);
     if (c.order == ptsel::Order::Measured && measure_kern) {
         // The measuring launch of the prefilter kernels refills ALL lanes of a wave at once: the wave then always holds one whole
         // 8x8 tile, and the rays of one sample differ little in length (measuring launch + order kernel on config 3: 0.44 ms at 16
@@ -498,6 +498,28 @@ void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, h
         fprintf(stderr, "[ptgpu timing] waves %u: finish spread (ms after first finisher) p10 %.3f p50 %.3f p90 %.3f p99 %.3f last %.3f\n", nw,
                 (t[nw / 10] - t[0]) * tick_ns * 1e-6, (t[nw / 2] - t[0]) * tick_ns * 1e-6, (t[nw * 9 / 10] - t[0]) * tick_ns * 1e-6,
                 (t[nw * 99 / 100] - t[0]) * tick_ns * 1e-6, (t[nw - 1] - t[0]) * tick_ns * 1e-6);
+        // the cooperative workers' pixels (pt_coop.h): when each was received and finished, on the launch's own timeline
+        unsigned long long n_log = 0, t0 = 0;
+        (void)hipMemcpy(&n_log, s->d_debug + 91, 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&t0, s->d_wave_end + 65535, 8, hipMemcpyDeviceToHost);
+        n_log = std::min<unsigned long long>(n_log, 130000ull);
+        if (n_log) {
+            std::vector<unsigned long long> e(4 * n_log);
+            (void)hipMemcpy(e.data(), s->d_wave_end + 65536, e.size() * 8, hipMemcpyDeviceToHost);
+            std::vector<size_t> idx(n_log);
+            for (size_t i = 0; i < n_log; ++i) idx[i] = i;
+            auto ms = [&](unsigned long long x) { return (double)(x - t0) * tick_ns * 1e-6; };
+            std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return e[4 * a] < e[4 * b]; });
+            fprintf(stderr, "[ptgpu coop log] %llu pixels; main loops ended %.3f .. %.3f ms; received at p0 %.3f p10 %.3f p50 %.3f p90 %.3f last %.3f ms\n", n_log, ms(t[0]), ms(t[nw - 1]),
+                    ms(e[4 * idx[0]]), ms(e[4 * idx[n_log / 10]]), ms(e[4 * idx[n_log / 2]]), ms(e[4 * idx[n_log * 9 / 10]]), ms(e[4 * idx[n_log - 1]]));
+            std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return e[4 * a + 1] > e[4 * b + 1]; });
+            for (size_t i = 0; i < std::min<size_t>(n_log, 12); ++i) {
+                const unsigned long long *q = &e[4 * idx[i]];
+                const double dur = (double)(q[1] - q[0]) * tick_ns * 1e-3;
+                fprintf(stderr, "   finished %.3f ms: received %.3f ms at sample %u with %u rays behind it, then %u rays in %.0f us (%.2f us per ray), pixel (%u, %u)\n", ms(q[1]), ms(q[0]),
+                        (unsigned)(q[2] >> 32), (unsigned)(q[3] >> 32), (unsigned)q[2], dur, dur / std::max(1u, (unsigned)q[2]), (unsigned)(q[3] & 0xffff), (unsigned)((q[3] >> 16) & 0xffff));
+            }
+        }
     }
 }
 }  // namespace

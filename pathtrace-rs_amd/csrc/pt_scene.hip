@@ -28,7 +28,7 @@ int finish_scene(pt_scene *s) {
     if (hipDeviceSynchronize() != hipSuccess) return fail(PT_ERR_HIP, "hipDeviceSynchronize failed");
     s->blocks_per_cu = dev_knobs().blocks_per_cu;
     s->variant = dev_knobs().variant;
-    if (dev_knobs().timing && hipMalloc((void **)&s->d_wave_end, 65536 * 8) != hipSuccess) s->d_wave_end = nullptr;
+    if (dev_knobs().timing && hipMalloc((void **)&s->d_wave_end, 65536 * 8 + 130000 * 32) != hipSuccess) s->d_wave_end = nullptr;   // (+ the hand-over log, pt_coop.h)
     return PT_OK;
 }
 
