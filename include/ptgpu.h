@@ -376,6 +376,10 @@ int pt_scene_debug_tree_packed(pt_scene *scene, void *nodes_out, size_t capacity
  *        that has run out of pixels finishes pixels handed over by waves that still have some, all 64 lanes on each ray
  *        (csrc/pt_coop.h; scene.rs:96-111 makes a pixel one serial chain, and this shortens the chain). A pixel's RNG stream
  *        travels with it: who traces a pixel never changes it.
+ * 131072 = general-world kernel: the colour of a Noise texture (texture.rs:86-88) is evaluated where the surface is hit, by every lane
+ *        for itself. Default for worlds with Noise textures: a Lambertian / Isotropic scatter keeps the hit POINT, and the colour is formed
+ *        only when the path ends on something that is not black, by the whole wave for all such lanes (csrc/pt_world.h LAZY). A path
+ *        that ends in black multiplies each of its (finite) attenuations by zero (scene.rs:62-64): 0 + a * 0 = 0, the same bits.
  * (Bits 4096, 16384 and 32768 of earlier versions were A/B switches of settled questions and are ignored.) */
 int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
 
@@ -389,6 +393,7 @@ typedef struct pt_kernel_choice {
     uint32_t world_hit_lds, world_occ, world_media;   /* general-world kernel: <BVH = ref_bvh, HIT_LDS, OCC, MEDIA> */
     uint32_t refill_min;
     uint32_t coop;                                    /* wide MFMA list kernels: waves that run out of work finish pixels handed over by busy ones, 64 lanes per ray (tuning bit 65536 switches it off) */
+    uint32_t world_lazy;                              /* general-world kernel, worlds with Noise textures: a scatter's Noise colour is formed when its path ends lit, by the whole wave (tuning bit 131072 switches it off) */
     char name[96];
 } pt_kernel_choice;
 /* The choice the scene's most recent render made. */

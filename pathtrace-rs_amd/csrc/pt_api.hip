@@ -154,6 +154,7 @@ void fill_choice(const ptsel::KernelChoice &c, pt_kernel_choice *out) {
     out->world_hit_lds = c.world_hit_lds, out->world_occ = c.world_occ, out->world_media = c.world_media;
     out->refill_min = c.refill_min;
     out->coop = c.coop ? 1u : 0u;
+    out->world_lazy = c.world_lazy ? 1u : 0u;
     kernel_name(c, out->name, sizeof out->name);
 }
 }  // namespace

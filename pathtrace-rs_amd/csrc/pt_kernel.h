@@ -108,14 +108,15 @@ __device__ __forceinline__ float perlin_turb(const PerlinLds &pn, f3 p) {
 // rest are sky misses or lanes still traversing). Each owner then adds its octaves up in the reference's order,
 // accum += weight * noise with weight = 1, 1/2, 1/4 ..., fetching them across lanes: bit-identical to perlin_turb.
 // `scratch`: 192 words of this wave's LDS (the pair list, idle between drains). Returns 0 for lanes that do not `need`.
+#ifndef PT_BALANCE_MAX
+#define PT_BALANCE_MAX 4
+#endif
+template <int MAX_ROUNDS = PT_BALANCE_MAX>
 __device__ __forceinline__ float wave_balanced_turb(const PerlinLds &pn, uint32_t *scratch, bool need, f3 p) {
     const unsigned long long mask = wave_ballot(need);
     const uint32_t n = (uint32_t)__popcll(mask);
     if (n == 0u) return 0.0f;
-#ifndef PT_BALANCE_MAX
-#define PT_BALANCE_MAX 4
-#endif
-    if (7u * n > (uint32_t)PT_BALANCE_MAX * 64u) return need ? perlin_turb(pn, p) : 0.0f;   // (measured on config 5: balancing pays up to four rounds -- 8.03 Grays/s against 7.73 without, 7.97 when always on)
+    if (7u * n > (uint32_t)MAX_ROUNDS * 64u) return need ? perlin_turb(pn, p) : 0.0f;   // (measured on config 5: balancing pays up to four rounds -- 8.03 Grays/s against 7.73 without, 7.97 when always on)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     float *sp = reinterpret_cast<float *>(scratch);
@@ -182,20 +183,28 @@ __device__ __forceinline__ f3 image_value(const DImages &im, int32_t index, floa
     return mk3((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
 }
 
-// texture.rs:74-91 (Constant / Checker / Noise / Image; Checker may nest). (u, v, images) only matter for Image.
-__device__ __forceinline__ f3 texture_value(const DTex *texs, const PerlinLds &pn, int32_t tex, f3 p, float u = 0.0f, float v = 0.0f,
-                                         DImages images = DImages{nullptr, nullptr}) {
+// texture.rs:74-91 in two steps: which leaf texture colours the point (Checker may nest, texture.rs:78-85) ...
+__device__ __forceinline__ DTex texture_leaf(const DTex *texs, int32_t tex, f3 p) {
     DTex t = texs[tex];
     while (t.kind == PT_TEX_CHECKER) {
         const f3 s = mk3(10.0f * p.x, 10.0f * p.y, 10.0f * p.z);
         t = texs[checker_is_odd(s.x, s.y, s.z) ? t.odd : t.even];
     }
+    return t;
+}
+// ... and its value (Constant / Noise / Image); `turb` = perlin.rs:76-87 at p, wherever it was evaluated. (u, v, images) only matter for Image.
+__device__ __forceinline__ f3 texture_leaf_value(const DTex &t, float turb, f3 p, float u, float v, DImages images) {
     if (t.kind == PT_TEX_NOISE) {
-        const float v1 = 1.0f + sin_colour(t.scale * p.z + 10.0f * perlin_turb(pn, p));
+        const float v1 = 1.0f + sin_colour(t.scale * p.z + 10.0f * turb);
         return mk3(0.5f * v1, 0.5f * v1, 0.5f * v1);  // vec3(1,1,1) * 0.5 * (1 + sin(..))
     }
     if (t.kind == PT_TEX_IMAGE) return image_value(images, t.odd, u, v);
     return mk3(t.c0, t.c1, t.c2);
+}
+__device__ __forceinline__ f3 texture_value(const DTex *texs, const PerlinLds &pn, int32_t tex, f3 p, float u = 0.0f, float v = 0.0f,
+                                         DImages images = DImages{nullptr, nullptr}) {
+    const DTex t = texture_leaf(texs, tex, p);
+    return texture_leaf_value(t, t.kind == PT_TEX_NOISE ? perlin_turb(pn, p) : 0.0f, p, u, v, images);
 }
 
 // ---- sphere.rs:29-66 exact slow path for one sphere ---------------------------

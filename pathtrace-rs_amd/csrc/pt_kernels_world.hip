@@ -1,10 +1,14 @@
-// pt_kernels_world.hip -- the general-world kernel's instantiations: <BVH, HIT_LDS, OCC, MEDIA>.
+// pt_kernels_world.hip -- the general-world kernel's instantiations: <BVH, HIT_LDS, OCC, MEDIA, CHAINS, LAZY>.
 #include "pt_kernels.h"
 #include "pt_world.h"
 
 namespace pthostside {
 
-WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media, bool chains) {
+WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media, bool chains, bool lazy) {
+    // worlds with Noise textures (pt_select.h: records in LDS, three waves per SIMD, no chains)
+    if (lazy)
+        return bvh ? (media ? pt_world_kernel<true, true, 3, true, false, true> : pt_world_kernel<true, true, 3, false, false, true>)
+                   : (media ? pt_world_kernel<false, true, 3, true, false, true> : pt_world_kernel<false, true, 3, false, false, true>);
     // worlds with Instance chains (scene graphs) take the most general build: three waves per SIMD, MEDIA code present
     if (chains)
         return bvh ? (hit_lds ? pt_world_kernel<true, true, 3, true, true> : pt_world_kernel<true, false, 3, true, true>)

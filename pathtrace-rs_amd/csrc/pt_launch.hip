@@ -198,6 +198,7 @@ int launch_world(pt_scene *s, const ptsel::KernelChoice &c, const pt_params *par
     W.image_table = s->d_image_table;
     W.image_bytes = s->d_image_bytes;
     W.has_image = s->tr.has_image ? 1u : 0u;
+    W.atts_finite = s->tr.atts_finite ? 1u : 0u;
     W.n_hit = s->tr.n_hitables;
     W.n_xf = s->tr.n_world_xf;
     W.bvh_root = c.ref_bvh ? s->bvh_root : -1;
@@ -217,7 +218,7 @@ int launch_world(pt_scene *s, const ptsel::KernelChoice &c, const pt_params *par
     const uint32_t need = (W.n_items + c.block - 1) / c.block;
     if (grid > need) grid = need;
     if (c.gstack) {
-        if (int rc = ensure_gstack(s, (size_t)grid * params->max_depth * 3ull * c.block)) return rc;
+        if (int rc = ensure_gstack(s, (size_t)grid * params->max_depth * (c.world_lazy ? 4ull : 3ull) * c.block)) return rc;
         W.gstack = s->d_gstack;
     }
     if (int rc = raise_lds_limit(s->device, reinterpret_cast<const void *>(wk), c.lds_bytes)) return rc;
@@ -244,7 +245,7 @@ void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, h
 
 }  // namespace
 
-WorldKernel world_kernel_for(const ptsel::KernelChoice &c) { return world_kernel(c.ref_bvh, c.world_hit_lds, c.world_occ, c.world_media, c.world_chains); }
+WorldKernel world_kernel_for(const ptsel::KernelChoice &c) { return world_kernel(c.ref_bvh, c.world_hit_lds, c.world_occ, c.world_media, c.world_chains, c.world_lazy); }
 
 void sphere_kernels_for(const ptsel::KernelChoice &c, SphereKernel *frame, SphereKernel *measure) {
     switch (c.family) {
@@ -262,7 +263,7 @@ void sphere_kernels_for(const ptsel::KernelChoice &c, SphereKernel *frame, Spher
 const char *kernel_name(const ptsel::KernelChoice &c, char *buf, size_t cap) {
     static const char *fam[] = {"world", "tree-binary", "tree4", "mfma", "scan-lds", "scan-hbm"};
     if (c.family == ptsel::Family::World)
-        snprintf(buf, cap, "world<bvh=%d,hit_lds=%d,occ=%u,media=%d%s>", (int)c.ref_bvh, (int)c.world_hit_lds, c.world_occ, (int)c.world_media, c.world_chains ? ",chains" : "");
+        snprintf(buf, cap, "world<bvh=%d,hit_lds=%d,occ=%u,media=%d%s>", (int)c.ref_bvh, (int)c.world_hit_lds, c.world_occ, (int)c.world_media, c.world_chains ? ",chains" : (c.world_lazy ? ",lazy" : ""));
     else
         snprintf(buf, cap, "%s<blk=%u%s%s%s>", fam[(uint32_t)c.family], c.block, c.moving ? ",moving" : "", c.gate ? ",gate" : "", c.verify ? ",verify" : "");
     return buf;

@@ -37,6 +37,7 @@ enum : uint32_t {
     kVarNoCulling = 1024u,       // MFMA kernels run every tile
     kVarBinaryTree = 2048u,      // tree kernels walk the binary tree
     kVarMeasureEveryFrame = 8192u,   // no reuse of the previous frame's measured tile costs
+    kVarWorldEager = 131072u,    // general-world kernel: Noise colours where the surface is hit, every lane its own (no LAZY instantiation)
     kVarNoCoop = 65536u,         // wide list kernels: no hand-over of pixels to idle waves (pt_coop.h)
 };
 
@@ -59,6 +60,8 @@ struct SceneTraits {
     // ---- general worlds
     uint32_t n_hitables = 0, n_world_xf = 0, ref_bvh_depth = 0;
     bool has_media = false, has_image = false;
+    bool atts_finite = false;      // every material colour is finite: a path that ends in black needs no fold (pt_world.h)
+    bool noise_finite = false;     // ... and every Noise texture's scale and the Perlin gradients are such that its colour is finite wherever |p| < 1e30
     bool has_chains = false;       // some entry sits below several Instance levels, or below Instances around its medium (scene graphs)
 };
 
@@ -73,6 +76,7 @@ struct KernelChoice {
     bool verify = false;
     // general-world kernel: <BVH, HIT_LDS, OCC, MEDIA>
     bool world_hit_lds = false, world_media = false, world_chains = false;
+    bool world_lazy = false;    // Noise colours of scatters are formed when a lit path ends, wave-balanced (pt_world.h LAZY)
     uint32_t world_occ = 3;
     uint32_t block = 256;       // threads per workgroup
     uint32_t lds_bytes = 0;     // dynamic LDS per workgroup
@@ -117,16 +121,17 @@ inline void select_world(const SceneTraits &t, const pt_params &p, uint32_t loca
     c.ref_bvh = p.use_bvh != 0;
     c.block = (uint32_t)kBlock;
     c.bvh_stack_entries = t.ref_bvh_depth + 2u;
-    uint32_t lds = t.has_noise ? (4096u + 768u) : 0u;
+    uint32_t lds = t.has_noise ? kWorldNoiseLds : 0u;
     if (c.ref_bvh) lds += c.bvh_stack_entries * (uint32_t)kBlock * 4u;
     c.world_hit_lds = t.n_hitables * 64u + t.n_world_xf * 96u <= 40960u;   // records + transforms staged in LDS
     if (c.world_hit_lds) lds += t.n_hitables * 64u + t.n_world_xf * 96u;
-    const uint64_t path_bytes = (uint64_t)p.max_depth * 3ull * (uint32_t)kBlock * 4ull;
+    c.world_chains = t.has_chains;
+    c.world_lazy = t.has_noise && t.noise_finite && c.world_hit_lds && !t.has_chains && p.max_depth <= 64u && !(k.variant & kVarWorldEager);
+    const uint64_t path_bytes = (uint64_t)p.max_depth * (c.world_lazy ? 4ull : 3ull) * (uint32_t)kBlock * 4ull;
     c.stack_in_lds = (lds + path_bytes <= 60u * 1024u) ? 1u : 0u;
     if (c.stack_in_lds) lds += (uint32_t)path_bytes;
     c.gstack = !c.stack_in_lds;
     // four waves per SIMD (128 VGPRs, no (u, v) in the hit record) for worlds without noise / image textures
-    c.world_chains = t.has_chains;
     const bool occ4 = !t.has_noise && !t.has_image && !t.has_chains && k.blocks_per_cu == 0 && 4u * lds <= kLdsBudget && !k.world_occ3;
     c.world_occ = occ4 ? 4u : 3u;
     // worlds whose records do not fit LDS (more than ~600 hitables) share the MEDIA = true code

@@ -348,13 +348,22 @@ __device__ __forceinline__ void w_hitable_rec(const pt_hitable &H, const pt_affi
 #else
 #define PT_WBBPROF_ATTR
 #endif
-template <bool BVH, bool HIT_LDS, int OCC = 3, bool MEDIA = true, bool CHAINS = false>
+// LAZY (worlds with Noise textures): what a Lambertian / Isotropic scatter off a Noise texture pushes on the attenuation stack is the
+// hit POINT, not the colour -- the colour (seven octaves of perlin.rs:54-111, 58 % of simple_light's VALU instructions when every hit
+// evaluates it) is only formed when the path ends on something that is not black, and then for all such lanes of the wave together,
+// spread over its 64 lanes (wave_balanced_turb). A path that ends in black (a dark sky, the depth limit) multiplies every one of its
+// attenuations by zero: scene.rs:62-64 gives 0 + a * (+-0) = +0 per level for any finite a, so those colours are never needed.
+#ifndef PT_WORLD_TURB_ROUNDS
+#define PT_WORLD_TURB_ROUNDS 6
+#endif
+template <bool BVH, bool HIT_LDS, int OCC = 3, bool MEDIA = true, bool CHAINS = false, bool LAZY = false>
 __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(const WArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *p = smem;
     float4 *s_pvec = reinterpret_cast<float4 *>(p);
     uint8_t *s_perm = p + (A.has_noise ? 4096 : 0);
-    p += A.has_noise ? (4096 + 768) : 0;
+    uint32_t *s_turb = reinterpret_cast<uint32_t *>(p + 4096 + 768) + 192u * (threadIdx.x >> 6);   // wave_balanced_turb's words of this wave (LAZY)
+    p += A.has_noise ? kWorldNoiseLds : 0;
     int32_t *s_stack = reinterpret_cast<int32_t *>(p);
     p += BVH ? (A.bvh_stack_entries * kBlock * 4) : 0;
     const pt_hitable *s_hit = reinterpret_cast<const pt_hitable *>(p);
@@ -384,13 +393,16 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
     const bool want_uv = OCC < 4 && A.has_image != 0u;
     const pt_hitable *hit = HIT_LDS ? s_hit : A.hit;
     const pt_affine *xf = HIT_LDS ? s_xf : A.xf;
-    float *path = A.stack_in_lds ? (s_path + tid) : (A.gstack + (size_t)blockIdx.x * A.max_depth * 3 * kBlock + tid);
+    constexpr uint32_t PS = LAZY ? 4u : 3u;   // words per level of the attenuation stack: colour -- or hit point + the Noise texture's scale
+    float *path = A.stack_in_lds ? (s_path + tid) : (A.gstack + (size_t)blockIdx.x * A.max_depth * PS * kBlock + tid);
 
     bool have = false, exhausted = false, need_cam = true;
     uint32_t pxy = 0, pix_start = 0, sample = 0, depth = 0, nrays = 0;   // pxy = x | local row << 16; pix_start = nrays when the pixel began
     Rng rng{0, 0, 0, 0};
     f3 col = mk3(0.f, 0.f, 0.f);
     WRay ray = w_ray_new(mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 1.f), 0.f);
+    unsigned long long lazy_mask = 0ull;   // LAZY: bit k = level k of this path holds a point whose Noise colour has not been formed
+    bool path_odd = false;                 // some attenuation of this path is not finite (inf / NaN colours): its product with zero is not zero
 
     for (;;) {
         // ---- refill (same scheme as pt_trace_kernel: one wave-aggregated atomic, 8x8 pixel tiles, batched until
@@ -436,6 +448,8 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
             }
         }
         // (no `continue` / `break` up here for a wave whose refill brought nothing: the loop's only exit is at its end -- see pt_kernel.h)
+        bool terminal = false;
+        f3 V = mk3(0.f, 0.f, 0.f);
         if (have) {
             // ---- camera.rs:56-68 + scene.rs:107-108
             if (need_cam) {
@@ -453,6 +467,7 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                 ray = w_ray_new(add3(A.cam.origin, offset), normalize3(dir), time);
                 depth = 0;
                 need_cam = false;
+                lazy_mask = 0ull, path_odd = false;
             }
 
             // ---- Hitable::ray_hit(ray, MIN_T, MAX_T) on the world (scene.rs:58)
@@ -498,8 +513,7 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
 
             // ---- scene.rs:49-71 one level of ray_trace
             nrays += 1;
-            bool terminal = true;
-            f3 V;
+            terminal = true;
             if (!found) {
                 if (A.has_sky) {
                     V = A.sky;
@@ -515,8 +529,25 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                 const f3 point = bh.point, normal = bh.normal, d = ray.d;
                 const float best_u = want_uv ? bh.u : 0.0f, best_v = want_uv ? bh.v : 0.0f;
                 // Texture::value (texture.rs:74-91); Constant textures were folded into the material record
-                auto colour = [&]() -> f3 {
-                    return m.pad0 != 0.0f ? mk3(m.a0, m.a1, m.a2) : texture_value(A.texs, pn, m.tex, point, best_u, best_v, DImages{A.image_table, A.image_bytes});
+                auto colour = [&]() __attribute__((always_inline)) -> f3 {   // (always_inline: a closure that is CALLED holds the kernel's argument block by address, which puts all of it into scratch)
+                    if (m.pad0 != 0.0f) return mk3(m.a0, m.a1, m.a2);
+                    const f3 c = texture_value(A.texs, pn, m.tex, point, best_u, best_v, DImages{A.image_table, A.image_bytes});
+                    path_odd = path_odd || !(__builtin_isfinite(c.x) && __builtin_isfinite(c.y) && __builtin_isfinite(c.z));
+                    return c;
+                };
+                // the attenuation of a Lambertian / Isotropic scatter: the colour -- or, LAZY, the point of a Noise texture (WArgs::lazy_ok:
+                // the host checked that a Noise colour of a point below 1e30 is finite)
+                bool lazy = false;
+                float lazy_scale = 0.0f;
+                auto surface = [&]() __attribute__((always_inline)) -> f3 {
+                    if (LAZY && m.pad0 == 0.0f) {
+                        const DTex leaf = texture_leaf(A.texs, m.tex, point);
+                        if (leaf.kind == PT_TEX_NOISE && __builtin_fabsf(point.x) < 1.0e30f && __builtin_fabsf(point.y) < 1.0e30f && __builtin_fabsf(point.z) < 1.0e30f) {
+                            lazy = true, lazy_scale = leaf.scale;
+                            return point;
+                        }
+                    }
+                    return colour();
                 };
                 f3 emitted = mk3(0.f, 0.f, 0.f);  // material.rs:161-167
                 if (m.kind == PT_MAT_DIFFUSE_LIGHT) emitted = colour();
@@ -525,7 +556,7 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                 if (depth < A.max_depth) {
                     if (m.kind == PT_MAT_LAMBERTIAN) {  // material.rs:52-67
                         const f3 target = add3(add3(point, normal), random_unit_vector(rng));
-                        att = colour();
+                        att = surface();
                         nd = normalize3(sub3(target, point));
                         scattered = true;
                     } else if (m.kind == PT_MAT_METAL) {  // material.rs:69-89
@@ -560,15 +591,16 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                         nd = use_refract ? normalize3(refracted) : normalize3(reflect3(d, normal));
                         scattered = true;
                     } else if (m.kind == PT_MAT_ISOTROPIC) {  // material.rs:126-136: direction NOT normalised
-                        att = colour();
+                        att = surface();
                         nd = random_in_unit_sphere(rng);
                         scattered = true;
                     }
                 }
                 if (scattered) {
-                    path[(depth * 3 + 0) * kBlock] = att.x;
-                    path[(depth * 3 + 1) * kBlock] = att.y;
-                    path[(depth * 3 + 2) * kBlock] = att.z;
+                    path[(depth * PS + 0) * kBlock] = att.x;
+                    path[(depth * PS + 1) * kBlock] = att.y;
+                    path[(depth * PS + 2) * kBlock] = att.z;
+                    if (LAZY && lazy) path[(depth * PS + 3) * kBlock] = lazy_scale, lazy_mask |= 1ull << depth;   // (launch(): LAZY only with max_depth <= 64)
                     // scene.rs:62-64: emitted + attenuation * deeper. Only DiffuseLight emits and it never scatters
                     // (material.rs:157), so `emitted` is zero on this branch and the fold below adds 0.0f for it.
                     depth += 1;
@@ -578,11 +610,37 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                     V = emitted;
                 }
             }
+        }
+        // ---- scene.rs:62-64 unwound: emitted (= 0) + attenuation * deeper, innermost level first. A path that ended in black keeps
+        // nothing of its attenuations: 0 + a * (+-0) = +0 at every level for finite a -- no loop, and (LAZY) no Noise colours.
+        const bool dark = have && terminal && depth != 0u && A.atts_finite != 0u && !path_odd && V.x == 0.0f && V.y == 0.0f && V.z == 0.0f;
+        if (LAZY) {
+            // the Noise colours the fold below will read, for all lanes of the wave that end a lit path in this iteration, one level per trip
+            bool pend = have && terminal && !dark && lazy_mask != 0ull;
+            while (wave_any(pend)) {
+                const uint32_t k = pend ? 63u - (uint32_t)__builtin_clzll(lazy_mask) : 0u;
+                const f3 q = pend ? mk3(path[(k * PS + 0) * kBlock], path[(k * PS + 1) * kBlock], path[(k * PS + 2) * kBlock]) : mk3(0.f, 0.f, 0.f);
+                const float turb = wave_balanced_turb<PT_WORLD_TURB_ROUNDS>(pn, s_turb, pend, q);
+                if (pend) {
+                    DTex leaf{};
+                    leaf.kind = PT_TEX_NOISE, leaf.scale = path[(k * PS + 3) * kBlock];
+                    const f3 c = texture_leaf_value(leaf, turb, q, 0.0f, 0.0f, DImages{nullptr, nullptr});   // texture.rs:86-88
+                    path[(k * PS + 0) * kBlock] = c.x, path[(k * PS + 1) * kBlock] = c.y, path[(k * PS + 2) * kBlock] = c.z;
+                    lazy_mask &= ~(1ull << k);
+                    pend = lazy_mask != 0ull;
+                }
+            }
+        }
+        if (have) {
             if (terminal) {
-                for (int k = (int)depth - 1; k >= 0; --k) {
-                    V.x = 0.0f + path[(k * 3 + 0) * kBlock] * V.x;
-                    V.y = 0.0f + path[(k * 3 + 1) * kBlock] * V.y;
-                    V.z = 0.0f + path[(k * 3 + 2) * kBlock] * V.z;
+                if (dark) {
+                    V = mk3(0.f, 0.f, 0.f);
+                } else {
+                    for (int k = (int)depth - 1; k >= 0; --k) {
+                        V.x = 0.0f + path[(k * PS + 0) * kBlock] * V.x;
+                        V.y = 0.0f + path[(k * PS + 1) * kBlock] * V.y;
+                        V.z = 0.0f + path[(k * PS + 2) * kBlock] * V.z;
+                    }
                 }
                 col = add3(col, V);  // scene.rs:110
                 sample += 1;

@@ -959,6 +959,63 @@ def test_random_general_worlds_match_the_oracle(ptgpu, oracle, seed, n, kinds, b
     assert np.array_equal(ref, out), _report(ref, out)
 
 
+@pytest.mark.parametrize("seed,n,kinds,bvh,sky,depth,noisy_light", [
+    (11, 16, (0, 2, 3, 4, 5), False, None, 10, False),             # gradient sky: every path ends lit -> every parked point gets its colour
+    (12, 16, (0, 2, 3, 4, 5), True, (0.0, 0.0, 0.0), 10, False),   # black sky: nearly every path ends dark -> no colours, no fold
+    (13, 24, (0, 1, 2, 3, 4, 5), False, (0.5, 0.6, 0.8), 10, True),   # + a DiffuseLight with a Noise texture (emitted: evaluated where it is hit)
+    (14, 12, (0, 5), True, (0.0, 0.0, 0.0), 64, True),             # the deepest stack the parked form takes (one bit per level)
+    (15, 12, (0, 5), False, None, 65, False),                      # one level more: the kernel without it
+])
+def test_noise_colours_formed_at_the_end_of_a_path_equal_those_formed_at_the_hit(ptgpu, oracle, seed, n, kinds, bvh, sky, depth, noisy_light):
+    """General worlds with Noise textures (texture.rs:86-88 over perlin.rs:54-111) on Lambertian surfaces, behind a Checker, in
+    Isotropic media and on a light: by default a scatter parks the hit point and the colour is formed when the path ends lit
+    (csrc/pt_world.h LAZY); tuning bit 131072 forms it at the hit. Both must give the same bits and the oracle's ray count; the
+    colours agree with the oracle within the sinf tolerance."""
+    W, H, S = 120, 80, 6
+    w = _random_world(oracle, seed, n, kinds, W, H, sky=sky)
+    tex = w["textures"].copy()
+    tex[1] = [2, 0, 0, 0, -1, -1, 4.0]       # Noise, two scales
+    tex[3] = [2, 0, 0, 0, -1, -1, 0.7]
+    tex[5] = [1, 0, 0, 0, 0, 1, 0]           # Checker(Constant, Noise)
+    if noisy_light:
+        tex[6] = [2, 0, 0, 0, -1, -1, 2.0]
+    w = dict(w, textures=tex)
+    osc = oracle.OracleScene.from_world(w["hitables"], w["transforms"], w["materials"], w["textures"], w["camera"], W, H, sky=w["sky"], use_bvh=bvh)
+    ex = osc.export()
+    ref, ref_rays = osc.update(S, max_depth=depth)
+    frames = {}
+    for variant in (0, 131072):
+        sc = ptgpu.Scene(oracle.to_ptgpu_world_desc(ptgpu, ex), 0)
+        sc.set_tuning(0, variant)
+        out = np.zeros((H, W, 3), np.float32)
+        rays = sc.update(ptgpu.PtParams(W, H, S, depth, 0, 1 if bvh else 0), ptgpu.PtCamera.from_floats(ex["camera"]), 0, out)
+        choice = sc.last_kernel_choice()
+        sc.close()
+        assert choice["family"] == 0 and choice["world_lazy"] == (1 if variant == 0 and depth <= 64 else 0), choice
+        assert ("lazy" in choice["name"]) == bool(choice["world_lazy"])
+        assert rays == ref_rays, "variant %d: ray_count %d vs oracle %d" % (variant, rays, ref_rays)
+        np.testing.assert_allclose(out, ref, rtol=0, atol=NOISE_ATOL)
+        frames[variant] = out
+    assert np.array_equal(frames[0], frames[131072]), _report(frames[131072], frames[0])
+
+
+@pytest.mark.parametrize("bvh", [False, True])
+def test_a_non_finite_colour_keeps_the_fold_of_a_dark_path(ptgpu, oracle, bvh):
+    """scene.rs:62-64 multiplies a path that ended in black by each of its attenuations: zero for finite colours (the general-world
+    kernel then skips the loop), NaN as soon as one of them is infinite -- the kernel must notice (WArgs::atts_finite)."""
+    W, H, S = 96, 64, 4
+    w = _random_world(oracle, 21, 14, (0, 2, 3, 4, 5), W, H, sky=(0.0, 0.0, 0.0))
+    mats = w["materials"].copy()
+    mats[6, 1] = np.inf                       # the first Metal's red albedo
+    tex = w["textures"].copy()
+    tex[2, 2] = np.inf                        # a Constant texture's green, under a Lambertian
+    w = dict(w, materials=mats, textures=tex)
+    out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh)
+    assert rays == ref_rays
+    assert np.isnan(ref).any(), "the fixture no longer sends a dark path over the infinite colours"
+    assert np.array_equal(np.isnan(ref), np.isnan(out)) and np.array_equal(np.nan_to_num(ref, nan=-1.0), np.nan_to_num(out, nan=-1.0)), _report(ref, out)
+
+
 def _random_graph_world(oracle, seed, W, H, n_top=7, max_depth=4, media=True):
     """A world given as a SCENE GRAPH (include/ptgpu.h pt_node): leaf shapes of every arm under random nestings of HitableList,
     Instance (also Instance of Instance, Instance around a List) and ConstantMedium (around Instance levels around a shape, and

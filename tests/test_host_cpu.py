@@ -340,8 +340,8 @@ SELECTION_TABLE = {
     ("two_perlin_spheres", True): ("tree4<blk=256>", 29168, 4, 9),
     ("random", False): ("mfma<blk=1024,moving>", 146096, 1, 0),                 # Sphere + MovingSphere world on the fast kernels
     ("random", True): ("mfma<blk=1024,moving,gate>", 163664, 1, 0),
-    ("simple_light", False): ("world<bvh=0,hit_lds=1,occ=3,media=0>", 35840, 3, 1),   # noise texture: the 3-wave build with (u, v)
-    ("simple_light", True): ("world<bvh=1,hit_lds=1,occ=3,media=0>", 39936, 3, 1),
+    ("simple_light", False): ("world<bvh=0,hit_lds=1,occ=3,media=0,lazy>", 49152, 3, 1),   # noise texture: the 3-wave build with (u, v); Noise colours when a lit path ends (4-word stack levels)
+    ("simple_light", True): ("world<bvh=1,hit_lds=1,occ=3,media=0,lazy>", 53248, 3, 1),
     ("cornell", False): ("world<bvh=0,hit_lds=1,occ=4,media=0>", 31424, 4, 1),
     ("cornell", True): ("world<bvh=1,hit_lds=1,occ=4,media=0>", 36544, 4, 1),    # (four workgroups fit the LDS with the BVH stack since the running hit record left it)
     ("cornell_smoke", False): ("world<bvh=0,hit_lds=1,occ=4,media=1>", 31424, 4, 1),
@@ -385,6 +385,10 @@ def test_kernel_selection_follows_the_tuning_word_and_the_frame(ptgpu, pthost):
     assert sel(depth=41)["name"] == "mfma<blk=256>" and sel(depth=41)["global_stack"] == 1       # ... nor 12: float stacks in HBM
     assert sel(blocks_per_cu=2)["name"] == "mfma<blk=256>" and sel(blocks_per_cu=2)["blocks_per_cu"] == 2
     assert sel(preset="random", variant=128)["name"].startswith("world<")                        # moving spheres on the general kernel
+    lazy, eager, deep = sel(preset="simple_light"), sel(preset="simple_light", variant=131072), sel(preset="simple_light", depth=65)
+    assert lazy["world_lazy"] == 1 and eager["world_lazy"] == 0 and eager["name"] == "world<bvh=0,hit_lds=1,occ=3,media=0>" and eager["lds_bytes"] < lazy["lds_bytes"]
+    assert deep["world_lazy"] == 0                                                               # one stack level per bit of a 64-bit word
+    assert sel(preset="cornell_smoke")["world_lazy"] == 0                                        # no Noise texture
     assert sel()["coop"] == 1 and sel(variant=65536)["coop"] == 0 and sel(variant=65536)["name"] == "mfma<blk=1024>"   # no hand-over to idle waves: same kernel
     assert sel(depth=40)["coop"] == 1 and sel(depth=41)["coop"] == 0 and sel(variant=8)["coop"] == 0 and sel(variant=2)["coop"] == 0
     # a camera shutter outside the interval the moving spheres are defined on leaves the MOVING kernels (their sweeps do not cover it)
