@@ -1,6 +1,9 @@
 """Ad-hoc fuzzing of the GPU kernels against the oracle with seeded random worlds (development aid; the seeds that
 found bugs live on as cases in tests/test_gpu_parity.py). Usage: python tools/fuzz_worlds.py [first_seed] [count] [all|classic]
-Kinds (seed % 5): 0 sphere worlds, 1 general worlds, 2 moving-sphere worlds, 3 far bounce origins, 4 scene graphs."""
+Kinds (seed % 5): 0 sphere worlds, 1 general worlds, 2 moving-sphere worlds, 3 far bounce origins, 4 scene graphs.
+Mode "noise": general worlds with Noise textures (on Lambertians, behind a Checker, in media, sometimes on the light) under a gradient /
+black / coloured sky: ray counts against the oracle, colours within the sinf tolerance, and the general-world kernel's two ways of forming
+a Noise colour -- when a lit path ends (default) / where the surface is hit (tuning bit 131072) -- against each other bit for bit."""
 import importlib.util
 import os
 import sys
@@ -26,6 +29,24 @@ bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     kind = seed % 5 if MODE == "all" else seed % 3
+    if MODE == "noise":
+        sky = [None, (0.0, 0.0, 0.0), tuple(rng.uniform(0.0, 1.0, 3))][int(rng.integers(0, 3))]
+        w = tgp._random_world(ob, seed, int(rng.integers(1, 30)), (0, 1, 2, 3, 4, 5), W, H, sky=sky)
+        tex = w["textures"].copy()
+        tex[1] = [2, 0, 0, 0, -1, -1, float(rng.uniform(0.2, 8.0))]
+        tex[3] = [2, 0, 0, 0, -1, -1, float(rng.uniform(0.2, 8.0))]
+        tex[5] = [1, 0, 0, 0, 0, 1, 0]
+        if seed % 3 == 0:
+            tex[6] = [2, 0, 0, 0, -1, -1, 2.0]
+        w = dict(w, textures=tex)
+        depth, frame = int(rng.choice([1, 2, 5, 10, 10, 25, 64, 65])), int(rng.choice([0, 0, 3]))
+        for bvh in (False, True):
+            out, rays, ref, ref_rays = tgp._render_world_both(ptgpu, ob, w, W, H, S, bvh, depth=depth, frame=frame)
+            out2, rays2, _, _ = tgp._render_world_both(ptgpu, ob, w, W, H, S, bvh, variant=131072, depth=depth, frame=frame)
+            if rays != ref_rays or rays2 != ref_rays or not np.array_equal(out, out2, equal_nan=True) or not np.allclose(out, ref, rtol=0, atol=2e-6, equal_nan=True):
+                bad += 1
+                print("MISMATCH seed %d noise bvh %s depth %d: rays %d / %d vs %d, lazy vs eager %s, vs oracle %s" % (seed, bvh, depth, rays, rays2, ref_rays, tgp._report(out2, out), tgp._report(ref, out)))
+        continue
     if kind == 3:      # far bounce origins: concave mirrors / huge grounds / distant mirrors around a cloud (every list-kernel path)
         n = int(rng.choice([40, 150, 400, 700, 900]))
         fk = ["enclosing", "enclosing", "offcentre", "ground", "mirrors"][int(rng.integers(0, 5))]
