@@ -170,16 +170,22 @@ typedef struct pt_image {
  *   - Instance around a HitableList: Instance::ray_hit (instance.rs:32-47) builds the same local ray for every child
  *     and t is shared between the two spaces, so Instance(List(a, b)) = List(Instance(a), Instance(b));
  *   - any depth of Instance around a shape, and around or inside a ConstantMedium (transform chains, see pt_hitable).
- * Not expressible in the list form, and rejected with PT_ERR_UNSUPPORTED and a message that names the node: a
- * ConstantMedium whose boundary is a HitableList or another ConstantMedium, a graph deeper than 15 Instance levels on
- * one side of a medium, a cycle. With bvh_nodes, leaves index the ROOT list's children, each of which must flatten to
- * exactly one list entry. */
-enum { PT_NODE_HITABLE = 0, PT_NODE_LIST = 1, PT_NODE_INSTANCE = 2, PT_NODE_MEDIUM = 3 };
+ * Not expressible in the list form: a ConstantMedium whose boundary is a HitableList or another ConstantMedium
+ * (constant_medium.rs:32-43 asks its boundary twice, and a medium in there draws from the pixel's RNG both times), and a
+ * BVHNode below the root (PT_NODE_BVH: bvh.rs:37-62 as a Hitable anywhere, hitable.rs:12-21). A graph with either is not
+ * flattened but INTERPRETED on the device (csrc/pt_graph.h: Hitable::ray_hit as the reference recurses, one stack of frames
+ * per lane; correct for every nesting, several times slower than the list form; at most 24 nested ray_hit calls;
+ * pt_params.use_bvh is refused for it -- its BVHNodes are part of the graph). Rejected with PT_ERR_UNSUPPORTED and a message
+ * that names the node: a flattened graph deeper than 15 Instance levels on one side of a medium, an interpreted one deeper
+ * than 24 levels, a cycle. With bvh_nodes and a graph that flattens, leaves index the ROOT list's children, each of which
+ * must flatten to exactly one list entry. */
+enum { PT_NODE_HITABLE = 0, PT_NODE_LIST = 1, PT_NODE_INSTANCE = 2, PT_NODE_MEDIUM = 3, PT_NODE_BVH = 4 };
 typedef struct pt_node {
     uint32_t kind;
     uint32_t a;    /* HITABLE: index into hitables | LIST: first index into node_children | INSTANCE: index into transforms |
-                    * MEDIUM: index of its Isotropic phase-function material */
-    uint32_t b;    /* LIST: number of children | INSTANCE, MEDIUM: the child node */
+                    * MEDIUM: index of its Isotropic phase-function material | BVH: index into bvh_nodes -- that row's box, and its
+                    * lhs / rhs read as NODE indices (>= 0) */
+    uint32_t b;    /* LIST: number of children | INSTANCE, MEDIUM: the child node | BVH: 0 */
     float density; /* MEDIUM */
 } pt_node;
 
@@ -393,6 +399,7 @@ typedef struct pt_kernel_choice {
     uint32_t world_hit_lds, world_occ, world_media;   /* general-world kernel: <BVH = ref_bvh, HIT_LDS, OCC, MEDIA> */
     uint32_t refill_min;
     uint32_t coop;                                    /* wide MFMA list kernels: waves that run out of work finish pixels handed over by busy ones, 64 lanes per ray (tuning bit 65536 switches it off) */
+    uint32_t world_graph;                             /* general-world kernel: the world is a scene graph that does not flatten and is interpreted (csrc/pt_graph.h) */
     uint32_t world_lazy;                              /* general-world kernel, worlds with Noise textures: a scatter's Noise colour is formed when its path ends lit, by the whole wave (tuning bit 131072 switches it off) */
     char name[96];
 } pt_kernel_choice;

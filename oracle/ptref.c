@@ -991,7 +991,7 @@ struct ora_scene {
     hitable world;          /* scene.rs:19 */
     hitable_list list;      /* storage.rs:86 alloc_hitables */
     /* scene graphs (ora_scene_from_graph): the nested Hitables built over the leaves in `list` */
-    instance *g_instances; constant_medium *g_media; hitable_list *g_lists; hitable *g_children;
+    instance *g_instances; constant_medium *g_media; hitable_list *g_lists; hitable *g_children; bvhnode *g_bvh;
     int has_sky; v3 sky;    /* scene.rs:20 */
     camera cam;
     int use_bvh;
@@ -1616,9 +1616,12 @@ bad:
 /* A world given as a scene graph (collision/hitable.rs:12-21 lets Hitables nest freely): built LITERALLY -- HitableList inside
  * HitableList, Instance of Instance, Instance around a ConstantMedium ... -- over the leaf shapes of `records16` (which carry no
  * wrappers of their own). nodes4: n_nodes rows of (kind, a, b, density bits): kind 0 shape a = leaf index | 1 HitableList of
- * children[a .. a+b) | 2 Instance transforms[a] around node b | 3 ConstantMedium, Isotropic material a, boundary node b.
- * The product flattens the same graph (include/ptgpu.h pt_node); this is what it must agree with. List worlds only. */
+ * children[a .. a+b) | 2 Instance transforms[a] around node b | 3 ConstantMedium, Isotropic material a, boundary node b |
+ * 4 BVHNode (bvh.rs:19-35 as a Hitable anywhere in the graph, hitable.rs:12-21): box bvh_minmax6[a], children = the NODES bvh_lr2[a].
+ * The product flattens the same graph where the list form can express it and interprets it otherwise (include/ptgpu.h pt_node);
+ * this is what it must agree with. List worlds only. */
 #define GRAPH_POOL ((size_t)1 << 16)   /* entries per pool of ora_scene_from_graph */
+static const float *g_bvh_minmax6; static const int32_t *g_bvh_lr2; static uint32_t g_n_bvh; static size_t g_n_bvh_used;   /* (build-time only; the tests build scenes from one thread) */
 static int graph_build(ora_scene *sc, const uint32_t *nodes4, uint32_t n_nodes, const uint32_t *children, uint32_t n_children,
                        const float *transforms24, uint32_t n_transforms, const float *materials6, uint32_t n_materials, uint32_t n_textures,
                        uint32_t node, uint32_t depth, size_t *n_inst, size_t *n_med, size_t *n_lists, size_t *n_child, hitable *out) {
@@ -1671,8 +1674,35 @@ static int graph_build(ora_scene *sc, const uint32_t *nodes4, uint32_t n_nodes, 
         cm->phase_function.kind = MAT_ISOTROPIC; cm->phase_function.tex = &sc->st.textures[(uint32_t)ti];
         memset(out, 0, sizeof *out); out->kind = HIT_CONSTANT_MEDIUM; out->med = cm;
         return 1; }
+    case 4: {
+        if (w[1] >= g_n_bvh || !g_bvh_minmax6 || !g_bvh_lr2) return 0;
+        const int32_t l = g_bvh_lr2[2 * w[1]], r = g_bvh_lr2[2 * w[1] + 1];
+        if (l < 0 || r < 0) return 0;
+        hitable lhs, rhs;
+        if (!graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, (uint32_t)l, depth + 1, n_inst,
+                         n_med, n_lists, n_child, &lhs) ||
+            !graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, (uint32_t)r, depth + 1, n_inst,
+                         n_med, n_lists, n_child, &rhs)) return 0;
+        if (g_n_bvh_used >= pool) return 0;
+        bvhnode *bn = &sc->g_bvh[g_n_bvh_used++];
+        const float *m = g_bvh_minmax6 + 6 * w[1];
+        bn->bb.min = V3(m[0], m[1], m[2]); bn->bb.max = V3(m[3], m[4], m[5]);
+        bn->lhs = lhs; bn->rhs = rhs;
+        *out = mk_node_hitable(bn);
+        return 1; }
     default: return 0;
     }
+}
+
+ora_scene *ora_scene_from_graph_bvh(const uint32_t *records16, uint32_t n_hitables, const float *transforms24, uint32_t n_transforms,
+                                    const float *materials6, uint32_t n_materials, const float *textures7, uint32_t n_textures,
+                                    const float *cam24, int has_sky, const float *sky3, const uint32_t *nodes4, uint32_t n_nodes,
+                                    const uint32_t *children, uint32_t n_children, uint32_t root, const float *bvh_minmax6, const int32_t *bvh_lr2, uint32_t n_bvh) {
+    g_bvh_minmax6 = bvh_minmax6, g_bvh_lr2 = bvh_lr2, g_n_bvh = n_bvh, g_n_bvh_used = 0;
+    ora_scene *sc = ora_scene_from_graph(records16, n_hitables, transforms24, n_transforms, materials6, n_materials, textures7, n_textures, cam24, has_sky, sky3,
+                                         nodes4, n_nodes, children, n_children, root);
+    g_bvh_minmax6 = NULL, g_bvh_lr2 = NULL, g_n_bvh = 0;
+    return sc;
 }
 
 ora_scene *ora_scene_from_graph(const uint32_t *records16, uint32_t n_hitables, const float *transforms24, uint32_t n_transforms,
@@ -1688,11 +1718,11 @@ ora_scene *ora_scene_from_graph(const uint32_t *records16, uint32_t n_hitables, 
     /* a node can be reached along several paths (a DAG): size the pools for the expanded tree, bounded */
     const size_t cap = GRAPH_POOL;
     sc->g_instances = calloc(cap, sizeof(instance)); sc->g_media = calloc(cap, sizeof(constant_medium));
-    sc->g_lists = calloc(cap, sizeof(hitable_list)); sc->g_children = calloc(cap, sizeof(hitable));
+    sc->g_lists = calloc(cap, sizeof(hitable_list)); sc->g_children = calloc(cap, sizeof(hitable)); sc->g_bvh = calloc(cap, sizeof(bvhnode));
     size_t ni = 0, nm = 0, nl = 0, nc = 0;
     hitable rooth;
     /* (graph_build checks its indices and the pools' capacity before every write) */
-    if (!sc->g_instances || !sc->g_media || !sc->g_lists || !sc->g_children ||
+    if (!sc->g_instances || !sc->g_media || !sc->g_lists || !sc->g_children || !sc->g_bvh ||
         !graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, root, 0, &ni, &nm, &nl, &nc,
                      &rooth)) {
         ora_scene_free(sc);
@@ -1706,7 +1736,7 @@ void ora_scene_free(ora_scene *s) {
     if (!s) return;
     storage_free(&s->st);
     free(s->list.hitables);
-    free(s->g_instances); free(s->g_media); free(s->g_lists); free(s->g_children);
+    free(s->g_instances); free(s->g_media); free(s->g_lists); free(s->g_children); free(s->g_bvh);
     free(s);
 }
 

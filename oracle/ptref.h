@@ -56,6 +56,11 @@ ora_scene *ora_scene_from_graph(const uint32_t *records16, uint32_t n_hitables, 
                                 const float *materials6, uint32_t n_materials, const float *textures7, uint32_t n_textures,
                                 const float *cam24, int has_sky, const float *sky3, const uint32_t *nodes4, uint32_t n_nodes,
                                 const uint32_t *children, uint32_t n_children, uint32_t root);
+/* ... and with BVHNodes inside the graph (node kind 4: a = row of bvh_minmax6 / bvh_lr2, whose two children are NODE indices) */
+ora_scene *ora_scene_from_graph_bvh(const uint32_t *records16, uint32_t n_hitables, const float *transforms24, uint32_t n_transforms,
+                                    const float *materials6, uint32_t n_materials, const float *textures7, uint32_t n_textures,
+                                    const float *cam24, int has_sky, const float *sky3, const uint32_t *nodes4, uint32_t n_nodes,
+                                    const uint32_t *children, uint32_t n_children, uint32_t root, const float *bvh_minmax6, const int32_t *bvh_lr2, uint32_t n_bvh);
 /* (Texture::Image rows: kind 3, odd_id = image index; images = (width, height) pairs + concatenated RGB8 rows) */
 
 /* ---- Scene::update (scene.rs:73-121) ------------------------------------

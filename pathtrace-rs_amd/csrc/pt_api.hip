@@ -155,6 +155,7 @@ void fill_choice(const ptsel::KernelChoice &c, pt_kernel_choice *out) {
     out->refill_min = c.refill_min;
     out->coop = c.coop ? 1u : 0u;
     out->world_lazy = c.world_lazy ? 1u : 0u;
+    out->world_graph = c.world_graph ? 1u : 0u;
     kernel_name(c, out->name, sizeof out->name);
 }
 }  // namespace

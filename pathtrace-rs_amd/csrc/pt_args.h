@@ -29,6 +29,7 @@ struct f3 {
 constexpr uint32_t kTileLog2 = PT_TILE_LOG2;             // work tiles are (1 << kTileLog2)^2 pixels
 constexpr uint32_t kTileSide = 1u << kTileLog2, kTilePix = kTileSide * kTileSide;
 constexpr int kBlock = PT_BLOCK;  // threads per workgroup (the main loop never synchronises across waves)
+constexpr uint32_t kGraphDepth = 24u, kGraphFrame = 24u;   // interpreted scene graphs (pt_graph.h): nested Hitable::ray_hit calls per lane, words per call
 constexpr uint32_t kWorldNoiseLds = 4096u + 768u + (uint32_t)(kBlock / 64) * 768u;   // general-world kernel, worlds with Noise textures: gradients, permutations, wave_balanced_turb's 192 words per wave
 constexpr int kBvhStack = 32;    // per-lane traversal stack entries (LDS)
 
@@ -218,6 +219,11 @@ struct WArgs {
     const uint8_t *image_bytes;
     uint32_t has_image;         // some texture is an Image: rect hits then compute (u, v) (rect.rs:97-98)
     uint32_t atts_finite;       // every material colour is finite (a path that ends in black then needs no fold)
+    // scene graphs that do not flatten (pt_graph.h): pt_node rows, HitableList children, the root; `nodes` then holds the graph's BVHNode rows
+    const uint4 *gnodes;
+    const uint32_t *gchildren;
+    uint32_t groot;
+    float *gframes;             // kGraphDepth x kGraphFrame words per lane of the grid
     uint32_t n_hit, n_xf;
     int32_t bvh_root;        // >= 0: BVHNode::ray_hit over `nodes`; < 0: HitableList::ray_hit
     uint32_t bvh_stack_entries;

@@ -132,6 +132,11 @@ struct pt_scene {
     float *h_stage_dev = nullptr;                    // ... as the device addresses it
     size_t frame_floats = 0;
     float *d_gstack = nullptr;                       // attenuation-stack levels that do not fit the LDS
+    uint4 *d_gnodes = nullptr;                       // interpreted scene graphs (pt_graph.h): pt_node rows, HitableList children, frames of the walk
+    uint32_t *d_gchildren = nullptr;
+    uint32_t groot = 0;
+    float *d_gframes = nullptr;
+    size_t d_gframes_floats = 0;
     size_t d_gstack_floats = 0;
     // Work order of the NEXT frame of the same view: the rays each tile really took in the last frame (same scene, camera,
     // size, samples, depth, shard). Only the order of the work depends on it, never a pixel.
@@ -226,6 +231,7 @@ uint32_t bvh_depth_checked(const pt_bvh_node *nodes, uint32_t n_nodes, uint32_t 
 // world description -> (is it a Sphere / MovingSphere world?) + the sphere-scene view of it
 struct WorldAsSpheres {
     bool sphere_like = false, all_spheres = false, has_media = false, has_image = false, has_noise = false, has_chains = false;
+    bool is_graph = false;   // an interpreted scene graph (pt_graph.h): `hitables` are its leaves
     uint32_t ref_depth = 0;
     std::vector<pt_sphere> sph;
     std::vector<uint32_t> mat;
@@ -241,6 +247,7 @@ struct FlatWorld {
     std::vector<pt_hitable> hit;
     std::vector<pt_affine> xf;
     pt_world_desc flat{};
+    bool interpreted = false;   // the graph does not flatten (pt_graph.h): `flat` is the caller's description, nodes and all
 };
 int flatten_world_graph(const pt_world_desc *desc, FlatWorld &out, const pt_world_desc **use);
 void world_traits(const pt_world_desc *desc, const WorldAsSpheres &w, ptsel::SceneTraits &tr);

@@ -12,6 +12,6 @@ void mfma_gate_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *fra
 void tree_kernels(bool tree4, bool moving, bool verify, SphereKernel *frame, SphereKernel *measure);
 void scan_kernels(bool sph_lds, SphereKernel *frame, SphereKernel *measure);
 // pt_world_kernel<BVH, HIT_LDS, OCC, MEDIA, CHAINS> (pt_kernels_world.hip)
-WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media, bool chains, bool lazy);
+WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media, bool chains, bool lazy, bool graph);
 
 }  // namespace pthostside

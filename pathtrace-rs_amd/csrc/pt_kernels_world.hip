@@ -4,7 +4,8 @@
 
 namespace pthostside {
 
-WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media, bool chains, bool lazy) {
+WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media, bool chains, bool lazy, bool graph) {
+    if (graph) return pt_world_kernel<false, false, 3, true, true, false, true>;   // an interpreted scene graph (pt_graph.h)
     // worlds with Noise textures (pt_select.h: records in LDS, three waves per SIMD, no chains)
     if (lazy)
         return bvh ? (media ? pt_world_kernel<true, true, 3, true, false, true> : pt_world_kernel<true, true, 3, false, false, true>)

@@ -221,6 +221,16 @@ int launch_world(pt_scene *s, const ptsel::KernelChoice &c, const pt_params *par
         if (int rc = ensure_gstack(s, (size_t)grid * params->max_depth * (c.world_lazy ? 4ull : 3ull) * c.block)) return rc;
         W.gstack = s->d_gstack;
     }
+    if (c.world_graph) {   // the interpreted walk's frames: kGraphDepth x kGraphFrame words per lane (pt_graph.h)
+        const size_t need_floats = (size_t)grid * ptdev::kGraphDepth * ptdev::kGraphFrame * c.block;
+        if (need_floats > s->d_gframes_floats) {
+            (void)hipFree(s->d_gframes);
+            s->d_gframes = nullptr, s->d_gframes_floats = 0;
+            HIP_TRY(hipMalloc((void **)&s->d_gframes, need_floats * sizeof(float)));
+            s->d_gframes_floats = need_floats;
+        }
+        W.gnodes = s->d_gnodes, W.gchildren = s->d_gchildren, W.groot = s->groot, W.gframes = s->d_gframes;
+    }
     if (int rc = raise_lds_limit(s->device, reinterpret_cast<const void *>(wk), c.lds_bytes)) return rc;
     HIP_TRY(hipEventRecord(s->ev_pass, stream));
     if (c.order == ptsel::Order::Measured)
@@ -245,7 +255,7 @@ void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, h
 
 }  // namespace
 
-WorldKernel world_kernel_for(const ptsel::KernelChoice &c) { return world_kernel(c.ref_bvh, c.world_hit_lds, c.world_occ, c.world_media, c.world_chains, c.world_lazy); }
+WorldKernel world_kernel_for(const ptsel::KernelChoice &c) { return world_kernel(c.ref_bvh, c.world_hit_lds, c.world_occ, c.world_media, c.world_chains, c.world_lazy, c.world_graph); }
 
 void sphere_kernels_for(const ptsel::KernelChoice &c, SphereKernel *frame, SphereKernel *measure) {
     switch (c.family) {
@@ -263,7 +273,7 @@ void sphere_kernels_for(const ptsel::KernelChoice &c, SphereKernel *frame, Spher
 const char *kernel_name(const ptsel::KernelChoice &c, char *buf, size_t cap) {
     static const char *fam[] = {"world", "tree-binary", "tree4", "mfma", "scan-lds", "scan-hbm"};
     if (c.family == ptsel::Family::World)
-        snprintf(buf, cap, "world<bvh=%d,hit_lds=%d,occ=%u,media=%d%s>", (int)c.ref_bvh, (int)c.world_hit_lds, c.world_occ, (int)c.world_media, c.world_chains ? ",chains" : (c.world_lazy ? ",lazy" : ""));
+        snprintf(buf, cap, "world<bvh=%d,hit_lds=%d,occ=%u,media=%d%s>", (int)c.ref_bvh, (int)c.world_hit_lds, c.world_occ, (int)c.world_media, c.world_graph ? ",graph" : (c.world_chains ? ",chains" : (c.world_lazy ? ",lazy" : "")));
     else
         snprintf(buf, cap, "%s<blk=%u%s%s%s>", fam[(uint32_t)c.family], c.block, c.moving ? ",moving" : "", c.gate ? ",gate" : "", c.verify ? ",verify" : "");
     return buf;

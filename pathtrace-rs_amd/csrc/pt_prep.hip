@@ -716,6 +716,7 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
     W.has_image = false;
     for (uint32_t i = 0; i < desc->n_textures; ++i) W.has_image = W.has_image || desc->textures[i].kind == PT_TEX_IMAGE;
     W.all_spheres = true, W.sphere_like = true, W.has_media = false;
+    W.is_graph = desc->n_nodes != 0;   // (a graph that flattens arrives here without nodes: flatten_world_graph)
     for (uint32_t i = 0; i < desc->n_hitables; ++i) {
         const pt_hitable &h = desc->hitables[i];
         if (h.kind > PT_HIT_CUBOID) return fail(PT_ERR_INVALID_ARG, "hitable %u: unknown kind %u", i, h.kind);
@@ -739,6 +740,11 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
         if (h.kind > PT_HIT_MOVING_SPHERE || h.transform >= 0 || h.medium_material >= 0) W.sphere_like = false;
     }
     W.ref_depth = 0;
+    if (W.is_graph) {   // interpreted (pt_graph.h): the leaves were checked above, the nodes by flatten_world_graph; media and BVHNodes live in the graph
+        W.sphere_like = W.all_spheres = false;
+        W.has_media = W.has_chains = true;
+        return PT_OK;
+    }
     if (desc->n_bvh_nodes) {
         if (!desc->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "bvh_nodes is NULL");
         W.ref_depth = bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_hitables, desc->bvh_root);
@@ -789,8 +795,78 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
 // ---- scene graph -> list form (include/ptgpu.h pt_node) ------------------------------------------------------------------
 namespace {
 const char *node_kind_name(uint32_t k) {
-    static const char *n[] = {"a shape", "a HitableList", "an Instance", "a ConstantMedium"};
-    return k < 4u ? n[k] : "an unknown node";
+    static const char *n[] = {"a shape", "a HitableList", "an Instance", "a ConstantMedium", "a BVHNode"};
+    return k < 5u ? n[k] : "an unknown node";
+}
+
+// A graph that does not flatten is interpreted on the device (pt_graph.h), which trusts every index: all nodes reachable from the
+// root are checked here, once each (shared children are NOT expanded: the walk visits a node as often as the reference would, but
+// validity is per node), cycles are refused, and so is a nesting deeper than the walk's frames.
+int validate_interpreted_graph(const pt_world_desc *d) {
+    std::vector<uint8_t> colour(d->n_nodes, 0);     // 0 unseen, 1 on the current path, 2 done
+    std::vector<uint32_t> height(d->n_nodes, 0);    // frames the walk needs at and below a node
+    struct Item { uint32_t node; size_t next; std::vector<uint32_t> kids; };
+    std::vector<Item> stack;
+    auto children_of = [&](uint32_t n, std::vector<uint32_t> &out) -> int {
+        const pt_node &N = d->nodes[n];
+        out.clear();
+        switch (N.kind) {
+        case PT_NODE_HITABLE: {
+            if (N.a >= d->n_hitables) return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: hitable index %u out of range", n, N.a);
+            const pt_hitable &h = d->hitables[N.a];
+            if (h.transform >= 0 || h.medium_material >= 0)
+                return fail(PT_ERR_INVALID_ARG, "scene graph: hitable %u carries its own transform / medium; in a graph these are Instance / ConstantMedium nodes", N.a);
+            return PT_OK;
+        }
+        case PT_NODE_LIST:
+            if ((uint64_t)N.a + N.b > d->n_node_children) return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: children [%u, %u) exceed node_children", n, N.a, N.a + N.b);
+            for (uint32_t j = 0; j < N.b; ++j) out.push_back(d->node_children[N.a + j]);
+            return PT_OK;
+        case PT_NODE_INSTANCE:
+            if (N.a >= d->n_transforms) return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: transform index %u out of range", n, N.a);
+            out.push_back(N.b);
+            return PT_OK;
+        case PT_NODE_MEDIUM:
+            if (N.a >= d->n_materials || d->materials[N.a].kind != PT_MAT_ISOTROPIC)
+                return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: a ConstantMedium's material %u must index an Isotropic material", n, N.a);
+            out.push_back(N.b);
+            return PT_OK;
+        case PT_NODE_BVH:
+            if (N.a >= d->n_bvh_nodes || !d->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: BVHNode row %u out of range", n, N.a);
+            if (d->bvh_nodes[N.a].lhs < 0 || d->bvh_nodes[N.a].rhs < 0)
+                return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: the children of a BVHNode in a graph are node indices (>= 0)", n);
+            out.push_back((uint32_t)d->bvh_nodes[N.a].lhs), out.push_back((uint32_t)d->bvh_nodes[N.a].rhs);
+            return PT_OK;
+        default: return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: unknown kind %u", n, N.kind);
+        }
+    };
+    const auto push = [&](uint32_t n) -> int {
+        stack.push_back(Item{n, 0, {}});
+        colour[n] = 1;
+        return children_of(n, stack.back().kids);
+    };
+    if (int rc = push(d->root_node)) return rc;
+    while (!stack.empty()) {
+        Item &top = stack.back();
+        const uint32_t n = top.node;
+        if (top.next < top.kids.size()) {
+            const uint32_t c = top.kids[top.next++];
+            if (c >= d->n_nodes) return fail(PT_ERR_INVALID_ARG, "scene graph: node index %u out of range (child of node %u)", c, n);
+            if (colour[c] == 1) return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u contains itself (a cycle)", c);
+            if (colour[c] == 0)
+                if (int rc = push(c)) return rc;   // (`top` is stale from here on)
+            continue;
+        }
+        uint32_t h = 0;
+        for (uint32_t c : top.kids) h = std::max(h, height[c]);
+        height[n] = h + 1u;
+        colour[n] = 2;
+        stack.pop_back();
+    }
+    if (height[d->root_node] > ptdev::kGraphDepth)
+        return fail(PT_ERR_UNSUPPORTED, "scene graph: %u nested ray_hit calls below the root; the interpreted walk takes %u (a graph that flattens has no such limit)",
+                    height[d->root_node], ptdev::kGraphDepth);
+    return PT_OK;
 }
 struct Flattener {
     const pt_world_desc *d;
@@ -799,6 +875,7 @@ struct Flattener {
     std::vector<uint32_t> chain;   // Instance transforms met on the way down, outermost first
     int rc = PT_OK;
     unsigned long long visits = 0;   // nodes walked so far (budget against exponential expansion of shared children)
+    bool needs_interpreter = false;  // refused because of a nesting the list form cannot express (not because the graph is malformed)
 
     bool on_path(uint32_t n) const { return std::find(path.begin(), path.end(), n) != path.end(); }
     int32_t encode_chain(const std::vector<uint32_t> &outer, const std::vector<uint32_t> &inner) {
@@ -818,6 +895,7 @@ struct Flattener {
                 *leaf = n;
                 return PT_OK;
             }
+            if (N.kind == PT_NODE_LIST || N.kind == PT_NODE_MEDIUM || N.kind == PT_NODE_BVH) needs_interpreter = true;
             if (N.kind != PT_NODE_INSTANCE)
                 return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u is a ConstantMedium whose boundary contains %s (node %u); only Instance levels around one shape can bound a medium",
                             medium_node, node_kind_name(N.kind), n);
@@ -879,6 +957,10 @@ struct Flattener {
             if ((r = boundary(n, N.b, inner, &leaf)) == PT_OK) r = emit(leaf, chain, inner, (int32_t)N.a, N.density);
             break;
         }
+        case PT_NODE_BVH:
+            needs_interpreter = true;
+            r = fail(PT_ERR_UNSUPPORTED, "scene graph: node %u is a BVHNode below the root", n);
+            break;
         default: r = fail(PT_ERR_INVALID_ARG, "scene graph: node %u: unknown kind %u", n, N.kind);
         }
         path.pop_back();
@@ -895,6 +977,16 @@ int flatten_world_graph(const pt_world_desc *desc, FlatWorld &out, const pt_worl
     if (desc->n_transforms && !desc->transforms) return fail(PT_ERR_INVALID_ARG, "transforms is NULL");
     if (desc->root_node >= desc->n_nodes) return fail(PT_ERR_INVALID_ARG, "scene graph: root node %u out of range", desc->root_node);
     Flattener F{desc, &out, {}, {}};
+    // a nesting the list form cannot express: the graph is validated and handed on as it is, to be interpreted (pt_graph.h)
+    const auto interpret_instead = [&](int rc) -> int {
+        if (rc != PT_ERR_UNSUPPORTED || !F.needs_interpreter) return rc;
+        if (int v = validate_interpreted_graph(desc)) return v;
+        out.hit.clear(), out.xf.clear();
+        out.flat = *desc;
+        out.interpreted = true;
+        *use = &out.flat;
+        return PT_OK;
+    };
     std::vector<uint32_t> first_of_child;   // list entries each child of the root list starts at (BVH leaves index the root's children)
     const pt_node &R = desc->nodes[desc->root_node];
     if (R.kind == PT_NODE_LIST) {
@@ -902,11 +994,11 @@ int flatten_world_graph(const pt_world_desc *desc, FlatWorld &out, const pt_worl
         F.path.push_back(desc->root_node);
         for (uint32_t j = 0; j < R.b; ++j) {
             first_of_child.push_back((uint32_t)out.hit.size());
-            if (int rc = F.walk(desc->node_children[R.a + j])) return rc;
+            if (int rc = F.walk(desc->node_children[R.a + j])) return interpret_instead(rc);
         }
     } else {
         first_of_child.push_back(0u);
-        if (int rc = F.walk(desc->root_node)) return rc;
+        if (int rc = F.walk(desc->root_node)) return interpret_instead(rc);
     }
     first_of_child.push_back((uint32_t)out.hit.size());
     out.flat = *desc;
@@ -932,7 +1024,8 @@ void world_traits(const pt_world_desc *desc, const WorldAsSpheres &w, ptsel::Sce
     tr.n_hitables = desc->n_hitables;
     tr.n_world_xf = desc->n_transforms;
     tr.ref_bvh_depth = w.ref_depth;
-    tr.has_caller_bvh = desc->n_bvh_nodes != 0;
+    tr.has_caller_bvh = desc->n_bvh_nodes != 0 && !w.is_graph;   // (an interpreted graph's BVHNode rows are part of the graph: no `-B` over it)
+    tr.is_graph = w.is_graph;
     tr.atts_finite = true;
     for (uint32_t i = 0; i < desc->n_materials; ++i)
         for (int c = 0; c < 3; ++c) tr.atts_finite = tr.atts_finite && std::isfinite(desc->materials[i].albedo[c]);

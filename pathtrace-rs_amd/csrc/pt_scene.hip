@@ -226,6 +226,13 @@ extern "C" int pt_scene_create_world(const pt_world_desc *given, int device, pt_
         (rc = upload(&s->d_texs, texs.data(), texs.size())) || (rc = upload(&s->d_perlin_vec, pvec.data(), pvec.size())) ||
         (rc = upload(&s->d_perlin_perm, pperm.data(), pperm.size())))
         return bail(rc);
+    if (W.is_graph) {   // interpreted: the graph itself goes to the device (pt_graph.h); pt_node is four 32-bit words
+        static_assert(sizeof(pt_node) == sizeof(uint4), "pt_node rows are read as uint4");
+        s->groot = desc->root_node;
+        if ((rc = upload(&s->d_gnodes, reinterpret_cast<const uint4 *>(desc->nodes), desc->n_nodes)) ||
+            (rc = upload(&s->d_gchildren, desc->node_children, desc->n_node_children)))
+            return bail(rc);
+    }
     if ((rc = finish_scene(s))) return bail(rc);
     *scene_out = s;
     return PT_OK;
@@ -238,7 +245,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
                          s->d_shade, s->d_sphere_mat, s->d_mats, s->d_texs, s->d_perlin_vec, s->d_perlin_perm, s->d_gate, s->d_gate_chain, s->d_bvh_large,
                          s->d_wnodes, s->d_nodes4, s->d_nodes4q, s->d_slotrec, s->d_rank_sphere, s->d_leafrec, s->d_shade_rank, s->d_leaf_rank, s->d_afrag,
                          s->d_tile_sphere, s->d_cull_tab, s->d_large, s->d_debug, s->d_tile_buf, s->d_px_state, s->d_work_counter, s->d_ray_count,
-                         s->d_frame, s->d_gstack, s->d_wave_end, s->d_tail_box};
+                         s->d_frame, s->d_gstack, s->d_wave_end, s->d_tail_box, s->d_gnodes, s->d_gchildren, s->d_gframes};
     for (void *p : dev) (void)hipFree(p);
     (void)hipHostFree(s->h_stage);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);

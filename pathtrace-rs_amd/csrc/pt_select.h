@@ -63,6 +63,7 @@ struct SceneTraits {
     bool atts_finite = false;      // every material colour is finite: a path that ends in black needs no fold (pt_world.h)
     bool noise_finite = false;     // ... and every Noise texture's scale and the Perlin gradients are such that its colour is finite wherever |p| < 1e30
     bool has_chains = false;       // some entry sits below several Instance levels, or below Instances around its medium (scene graphs)
+    bool is_graph = false;         // a scene graph that does not flatten: interpreted (pt_graph.h)
 };
 
 enum class Family : uint32_t { World = 0, TreeBinary = 1, Tree4 = 2, Mfma = 3, ScanLds = 4, ScanHbm = 5 };
@@ -76,6 +77,7 @@ struct KernelChoice {
     bool verify = false;
     // general-world kernel: <BVH, HIT_LDS, OCC, MEDIA>
     bool world_hit_lds = false, world_media = false, world_chains = false;
+    bool world_graph = false;   // the scan is the interpreted walk of a scene graph (pt_graph.h)
     bool world_lazy = false;    // Noise colours of scatters are formed when a lit path ends, wave-balanced (pt_world.h LAZY)
     uint32_t world_occ = 3;
     uint32_t block = 256;       // threads per workgroup
@@ -123,7 +125,8 @@ inline void select_world(const SceneTraits &t, const pt_params &p, uint32_t loca
     c.bvh_stack_entries = t.ref_bvh_depth + 2u;
     uint32_t lds = t.has_noise ? kWorldNoiseLds : 0u;
     if (c.ref_bvh) lds += c.bvh_stack_entries * (uint32_t)kBlock * 4u;
-    c.world_hit_lds = t.n_hitables * 64u + t.n_world_xf * 96u <= 40960u;   // records + transforms staged in LDS
+    c.world_graph = t.is_graph;
+    c.world_hit_lds = !t.is_graph && t.n_hitables * 64u + t.n_world_xf * 96u <= 40960u;   // records + transforms staged in LDS
     if (c.world_hit_lds) lds += t.n_hitables * 64u + t.n_world_xf * 96u;
     c.world_chains = t.has_chains;
     c.world_lazy = t.has_noise && t.noise_finite && c.world_hit_lds && !t.has_chains && p.max_depth <= 64u && !(k.variant & kVarWorldEager);

@@ -334,6 +334,10 @@ __device__ __forceinline__ void w_hitable_rec(const pt_hitable &H, const pt_affi
     h.t = t;
 }
 
+}  // namespace ptdev
+#include "pt_graph.h"
+namespace ptdev {
+
 // HIT_LDS: the hitable records and transforms are staged in LDS (worlds up to 16 KB: every preset); the list scan
 // then reads them at LDS latency instead of waiting on the scalar cache for each entry (58 % of the wave-cycles of
 // cornell_smoke were such waits), and BVH mode gathers them per lane from LDS instead of L2.
@@ -356,7 +360,8 @@ __device__ __forceinline__ void w_hitable_rec(const pt_hitable &H, const pt_affi
 #ifndef PT_WORLD_TURB_ROUNDS
 #define PT_WORLD_TURB_ROUNDS 6
 #endif
-template <bool BVH, bool HIT_LDS, int OCC = 3, bool MEDIA = true, bool CHAINS = false, bool LAZY = false>
+// GRAPH: the world is a scene graph that does not flatten (pt_graph.h): the scan is the interpreted Hitable::ray_hit of its root.
+template <bool BVH, bool HIT_LDS, int OCC = 3, bool MEDIA = true, bool CHAINS = false, bool LAZY = false, bool GRAPH = false>
 __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(const WArgs A) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *p = smem;
@@ -476,7 +481,13 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
             bool found = false;
             uint32_t best_mat = 0, best_k = 0, best_face = 0;
             float best_t = kMaxT;
-            if (!BVH) {  // hitable_list.rs:40-56
+            GHit gh;
+            gh.found = false;
+            if (GRAPH) {   // scene.rs:58 on the graph's root (pt_graph.h)
+                gh = graph_ray_hit(GraphSrc{A.gnodes, A.gchildren, A.nodes, A.groot}, hit, xf, ray, kMinT, kMaxT, rng,
+                                   A.gframes + (size_t)blockIdx.x * kGraphDepth * kGraphFrame * kBlock + tid, want_uv);
+                found = gh.found, best_mat = gh.mat;
+            } else if (!BVH) {  // hitable_list.rs:40-56
                 float closest = kMaxT;
                 for (uint32_t k = 0; k < A.n_hit; ++k) {
                     float t;
@@ -525,7 +536,8 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
             } else {
                 const DMat m = A.mats[best_mat];
                 WHit bh;
-                w_hitable_rec<MEDIA, CHAINS>(hit[best_k], xf, ray, best_t, best_face, bh, want_uv);
+                if (GRAPH) bh = gh.h;
+                else w_hitable_rec<MEDIA, CHAINS>(hit[best_k], xf, ray, best_t, best_face, bh, want_uv);
                 const f3 point = bh.point, normal = bh.normal, d = ray.d;
                 const float best_u = want_uv ? bh.u : 0.0f, best_v = want_uv ? bh.v : 0.0f;
                 // Texture::value (texture.rs:74-91); Constant textures were folded into the material record

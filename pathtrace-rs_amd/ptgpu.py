@@ -104,7 +104,7 @@ class PtWorldDesc(C.Structure):
 class PtKernelChoice(C.Structure):
     """pt_kernel_choice: which kernel a frame runs on (include/ptgpu.h)."""
     _fields_ = [(n, C.c_uint32) for n in ("family", "block", "lds_bytes", "blocks_per_cu", "moving", "gate", "verify", "ref_bvh", "ordered",
-                                          "stack_in_lds", "global_stack", "n_tiles", "world_hit_lds", "world_occ", "world_media", "refill_min", "coop", "world_lazy")] + \
+                                          "stack_in_lds", "global_stack", "n_tiles", "world_hit_lds", "world_occ", "world_media", "refill_min", "coop", "world_graph", "world_lazy")] + \
                [("name", C.c_char * 96)]
 
     def as_dict(self):

@@ -45,6 +45,8 @@ def _bind(L):
     L.ora_scene_free.restype = None
     L.ora_scene_from_graph.restype = vp
     L.ora_scene_from_graph.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32, vp, C.c_int, vp, vp, u32, vp, u32, u32]
+    L.ora_scene_from_graph_bvh.restype = vp
+    L.ora_scene_from_graph_bvh.argtypes = [vp, u32, vp, u32, vp, u32, vp, u32, vp, C.c_int, vp, vp, u32, vp, u32, u32, vp, vp, u32]
     L.ora_scene_update.restype = u64
     L.ora_scene_update.argtypes = [vp, u32, u32, u32, u32, u32, vp, C.c_int]
     L.ora_scene_update_range.restype = u64
@@ -139,8 +141,10 @@ class OracleScene:
         return self
 
     @classmethod
-    def from_graph(cls, hitables, transforms, materials, textures, camera, width, height, nodes, node_children, root_node, sky=None, library=None):
-        """Scene whose world is a scene graph built literally (List in List, Instance of Instance, Instance around a medium ...)
+    def from_graph(cls, hitables, transforms, materials, textures, camera, width, height, nodes, node_children, root_node, sky=None, library=None,
+                   bvh_minmax=None, bvh_children=None):
+        """Scene whose world is a scene graph built literally (List in List, Instance of Instance, Instance around a medium, a medium
+        around a List or another medium, BVHNodes anywhere: node kind 4 = row of bvh_minmax [n, 6] / bvh_children [n, 2] NODE indices)
         over the leaf shapes `hitables`; `nodes` = [n, 4] uint32 rows as include/ptgpu.h pt_node. List worlds only."""
         self = cls.__new__(cls)
         self.L = library or lib()
@@ -154,9 +158,11 @@ class OracleScene:
         ch = np.ascontiguousarray(node_children, dtype=np.uint32).reshape(-1)
         if len(ch) == 0:
             ch = np.zeros(1, np.uint32)
-        self.h = self.L.ora_scene_from_graph(rec.ctypes.data, len(rec), xf.ctypes.data, len(xf), mats.ctypes.data, len(mats), texs.ctypes.data, len(texs),
-                                             cam.ctypes.data, 1 if sky is not None else 0, sk.ctypes.data, nd.ctypes.data, len(nd), ch.ctypes.data,
-                                             len(node_children), int(root_node))
+        mm = np.ascontiguousarray(bvh_minmax if bvh_minmax is not None else np.zeros((0, 6)), dtype=np.float32).reshape(-1, 6)
+        lr = np.ascontiguousarray(bvh_children if bvh_children is not None else np.zeros((0, 2)), dtype=np.int32).reshape(-1, 2)
+        self.h = self.L.ora_scene_from_graph_bvh(rec.ctypes.data, len(rec), xf.ctypes.data, len(xf), mats.ctypes.data, len(mats), texs.ctypes.data, len(texs),
+                                                 cam.ctypes.data, 1 if sky is not None else 0, sk.ctypes.data, nd.ctypes.data, len(nd), ch.ctypes.data,
+                                                 len(node_children), int(root_node), mm.ctypes.data if len(mm) else None, lr.ctypes.data if len(lr) else None, len(mm))
         if not self.h:
             raise ValueError("malformed scene graph")
         self.preset, self.width, self.height, self.use_bvh = "<graph>", width, height, False

@@ -1016,7 +1016,7 @@ def test_a_non_finite_colour_keeps_the_fold_of_a_dark_path(ptgpu, oracle, bvh):
     assert np.array_equal(np.isnan(ref), np.isnan(out)) and np.array_equal(np.nan_to_num(ref, nan=-1.0), np.nan_to_num(out, nan=-1.0)), _report(ref, out)
 
 
-def _random_graph_world(oracle, seed, W, H, n_top=7, max_depth=4, media=True):
+def _random_graph_world(oracle, seed, W, H, n_top=7, max_depth=4, media=True, wild=False):
     """A world given as a SCENE GRAPH (include/ptgpu.h pt_node): leaf shapes of every arm under random nestings of HitableList,
     Instance (also Instance of Instance, Instance around a List) and ConstantMedium (around Instance levels around a shape, and
     itself inside Instances). Returned as the flat arrays both sides consume; the oracle nests them literally."""
@@ -1039,6 +1039,7 @@ def _random_graph_world(oracle, seed, W, H, n_top=7, max_depth=4, media=True):
         return len(nodes) - 1
 
     leaves = list(rng.permutation(40))
+    bvh_minmax, bvh_lr = [], []
 
     def leaf():
         return add(0, int(leaves.pop()), 0)
@@ -1047,6 +1048,15 @@ def _random_graph_world(oracle, seed, W, H, n_top=7, max_depth=4, media=True):
         r = rng.random()
         if depth >= max_depth or len(leaves) < 6 or r < 0.3:
             return leaf()
+        q = rng.random() if wild else 1.0
+        if q < 0.2:                                        # ConstantMedium around ANYTHING: a List, an Instance of a List, another medium, a BVHNode
+            mats.append([4, 0, 0, 0, 0, int(rng.integers(0, 5))])
+            return add(3, len(mats) - 1, subtree(depth + 1), float(rng.uniform(0.05, 0.6)))
+        if q < 0.35:                                       # BVHNode below the root: any box (both sides take it as given), children = two subtrees
+            c, h = rng.uniform(-3, 3, 3), rng.uniform(1.0, 7.0, 3) * (1 if rng.random() < 0.8 else 50)
+            bvh_minmax.append([*(c - h), *(c + h)])
+            bvh_lr.append([subtree(depth + 1), subtree(depth + 1)])
+            return add(4, len(bvh_lr) - 1, 0)
         if r < 0.55:                                       # Instance around anything (a List, another Instance, a medium)
             return add(2, transform(), subtree(depth + 1))
         if r < 0.8:                                        # HitableList inside whatever we are in
@@ -1067,7 +1077,54 @@ def _random_graph_world(oracle, seed, W, H, n_top=7, max_depth=4, media=True):
     children.extend(kids)
     root = add(1, first, len(kids))
     return dict(w, materials=np.array(mats, np.float32), transforms=np.array(xfs, np.float32).reshape(-1, 24), nodes=np.array(nodes, np.uint32),
-                node_children=np.array(children, np.uint32), root_node=root)
+                node_children=np.array(children, np.uint32), root_node=root, bvh_minmax=np.array(bvh_minmax, np.float32).reshape(-1, 6),
+                bvh_children=np.array(bvh_lr, np.int32).reshape(-1, 2))
+
+
+def _render_graph_both(ptgpu, oracle, g, W, H, S, depth=10, frame=0):
+    osc = oracle.OracleScene.from_graph(g["hitables"], g["transforms"], g["materials"], g["textures"], g["camera"], W, H, g["nodes"], g["node_children"],
+                                        g["root_node"], sky=g["sky"], bvh_minmax=g["bvh_minmax"], bvh_children=g["bvh_children"])
+    ref, ref_rays = osc.update(S, max_depth=depth, frame_num=frame)
+    materials = [(int(r[0]), r[1:4], r[4], int(r[5])) for r in g["materials"]]
+    textures = [(int(r[0]), r[1:4], int(r[4]), int(r[5]), r[6]) for r in g["textures"]]
+    desc = ptgpu.WorldDesc(g["hitables"], g["transforms"], materials, textures, sky=g["sky"], nodes=g["nodes"], node_children=g["node_children"],
+                           root_node=g["root_node"], bvh_nodes=(g["bvh_minmax"], g["bvh_children"]) if len(g["bvh_minmax"]) else None)
+    sc = ptgpu.Scene(desc, 0)
+    out = np.zeros((H, W, 3), np.float32)
+    rays = sc.update(ptgpu.PtParams(W, H, S, depth, 0, 0), ptgpu.PtCamera.from_floats(g["camera"]), frame, out)
+    choice = sc.last_kernel_choice()
+    sc.close()
+    return out, rays, ref, ref_rays, choice
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
+def test_scene_graphs_that_do_not_flatten_are_interpreted(ptgpu, oracle, seed):
+    """A ConstantMedium whose boundary is a HitableList or another medium (constant_medium.rs:32-43 asks the boundary twice; a medium
+    in there draws from the pixel's RNG both times) and BVHNodes below the root (bvh.rs:37-62, hitable.rs:12-21) have no list form:
+    the device walks such a graph as the reference recurses (csrc/pt_graph.h). Same ray count, same frame, bit for bit."""
+    W, H, S = 96, 64, 3
+    g = _random_graph_world(oracle, 900 + seed, W, H, n_top=int(3 + seed % 5), max_depth=int(3 + seed % 3), wild=True)
+    kinds = set(int(k) for k in g["nodes"][:, 0])
+    out, rays, ref, ref_rays, choice = _render_graph_both(ptgpu, oracle, g, W, H, S, depth=[10, 3, 25][seed % 3], frame=seed % 2)
+    assert choice["family"] == 0 and ("graph" in choice["name"]) == bool(choice["world_graph"])
+    assert rays == ref_rays, "ray_count %d vs oracle %d (node kinds %s, %s); %s" % (rays, ref_rays, kinds, choice["name"], _report(ref, out))
+    assert np.array_equal(ref, out, equal_nan=True), _report(ref, out)
+
+
+def test_the_interpreted_graphs_of_the_test_above_cover_every_nesting(ptgpu, oracle):
+    """(what the seeds above contain: a medium around a List, around another medium, around a BVHNode; a BVHNode under an Instance)"""
+    seen = set()
+    for seed in range(1, 11):
+        g = _random_graph_world(oracle, 900 + seed, 96, 64, n_top=int(3 + seed % 5), max_depth=int(3 + seed % 3), wild=True)
+        nd, lr = g["nodes"], g["bvh_children"]
+        for k, a, b, _ in nd:
+            if k == 3:
+                seen.add(("medium around", int(nd[b][0])))
+            if k == 2:
+                seen.add(("instance around", int(nd[b][0])))
+            if k == 4:
+                seen.update(("bvh over", int(nd[c][0])) for c in lr[a])
+    assert {("medium around", 1), ("medium around", 3), ("medium around", 4), ("instance around", 4), ("instance around", 3), ("bvh over", 3)} <= seen, seen
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8])

@@ -425,9 +425,9 @@ def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
         ptgpu.debug_select(cloud(40), ptgpu.PtParams(640, 480, 16, 10, 0, 1), cam)
 
 
-def test_scene_graph_nestings_the_list_form_cannot_hold_are_named(ptgpu):
-    """include/ptgpu.h pt_node: a graph is flattened on the host; what the list form cannot express is refused with
-    PT_ERR_UNSUPPORTED and a message naming the node and the nesting (checked through pt_debug_select: no device needed)."""
+def test_scene_graph_nestings_the_list_form_cannot_hold_are_interpreted_and_malformed_graphs_are_named(ptgpu):
+    """include/ptgpu.h pt_node: a graph is flattened on the host; what the list form cannot express is interpreted on the device, and
+    what neither can take is refused with a message naming the node (checked through pt_debug_select: no device needed)."""
     tex = [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)]
     mats = [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0), (ptgpu.MAT_ISOTROPIC, (0, 0, 0), 0.0, 0)]
     rec = np.zeros((3, 16), np.uint32)
@@ -446,10 +446,41 @@ def test_scene_graph_nestings_the_list_form_cannot_hold_are_named(ptgpu):
     assert ok["name"].startswith("world<")
     # a List of plain spheres inside a List is still a sphere world (exact scan: three spheres)
     assert select([[0, 0, 0, 0], [0, 1, 0, 0], [0, 2, 0, 0], [1, 0, 2, 0], [1, 2, 2, 0]], [0, 1, 3, 2], 4)["name"] == "scan-lds<blk=256>"
+    # what the list form cannot express is INTERPRETED (csrc/pt_graph.h): a ConstantMedium around a HitableList, around another medium,
+    # a BVHNode below the root (its row of bvh_nodes holds the box and two NODE indices)
+    med_list = ([[0, 0, 0, 0], [0, 1, 0, 0], [1, 0, 2, 0], [3, 1, 2, dens], [1, 2, 1, 0]], [0, 1, 3], 4)
+    med_med = ([[0, 0, 0, 0], [3, 1, 0, dens], [3, 1, 1, dens], [1, 0, 1, 0]], [2], 3)
+    for nodes, children, root in (med_list, med_med):
+        d = select(nodes, children, root)
+        assert d["world_graph"] == 1 and d["name"] == "world<bvh=0,hit_lds=0,occ=3,media=1,graph>" and d["world_lazy"] == 0, d
+    box = (np.array([[-1, -1, -1, 5, 1, 1]], np.float32), np.array([[0, 1]], np.int32))
+
+    def select_bvh(nodes, children, root, bvh, use_bvh=0):
+        return ptgpu.debug_select(ptgpu.WorldDesc(rec, eye, mats, tex, nodes=np.array(nodes, np.uint32), node_children=children, root_node=root, bvh_nodes=bvh),
+                                  ptgpu.PtParams(64, 48, 4, 10, 0, use_bvh), cam)
+
+    under_instance = ([[0, 0, 0, 0], [0, 1, 0, 0], [4, 0, 0, 0], [2, 0, 2, 0], [0, 2, 0, 0], [1, 0, 2, 0]], [3, 4], 5)   # List(Instance(BVHNode(a, b)), c)
+    assert select_bvh(*under_instance, box)["world_graph"] == 1
+    with pytest.raises(ptgpu.PtError):                       # `-B` over an interpreted graph: its BVHNodes are part of the graph
+        select_bvh(*under_instance, box, use_bvh=1)
+    for bvh, code, needle in [((box[0], np.array([[0, -1]], np.int32)), ptgpu.PT_ERR_INVALID_ARG, "node indices"),
+                              ((box[0], np.array([[0, 9]], np.int32)), ptgpu.PT_ERR_INVALID_ARG, "out of range"),
+                              ((box[0], np.array([[0, 3]], np.int32)), ptgpu.PT_ERR_UNSUPPORTED, "contains itself")]:
+        with pytest.raises(ptgpu.PtError) as e:
+            select_bvh(*under_instance, bvh)
+        assert e.value.code == code and needle in str(e.value), str(e.value)
+    with pytest.raises(ptgpu.PtError) as e:                  # BVHNode row out of range
+        select_bvh([[0, 0, 0, 0], [4, 3, 0, 0], [1, 0, 1, 0]], [1], 2, box)
+    assert e.value.code == ptgpu.PT_ERR_INVALID_ARG and "BVHNode row" in str(e.value)
+    # the interpreted walk keeps one frame per nested ray_hit call: 24. List(Instance^k(Medium(List(a, b)))) needs k + 4
+    deep = lambda k: ([[0, 0, 0, 0], [0, 1, 0, 0], [1, 0, 2, 0], [3, 1, 2, dens]] + [[2, 0, 3 + i, 0] for i in range(k)] + [[1, 2, 1, 0]], [0, 1, 3 + k], 4 + k)
+    assert select(*deep(20))["world_graph"] == 1
+    with pytest.raises(ptgpu.PtError) as e:
+        select(*deep(21))
+    assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and "nested ray_hit calls" in str(e.value), str(e.value)
     for nodes, children, root, needle in [
-        ([[0, 0, 0, 0], [0, 1, 0, 0], [1, 0, 2, 0], [3, 1, 2, dens], [1, 2, 1, 0]], [0, 1, 3], 4, "ConstantMedium whose boundary contains a HitableList"),
-        ([[0, 0, 0, 0], [3, 1, 0, dens], [3, 1, 1, dens], [1, 0, 1, 0]], [2], 3, "ConstantMedium whose boundary contains a ConstantMedium"),
         ([[2, 0, 1, 0], [2, 0, 0, 0], [1, 0, 1, 0]], [0], 2, "contains itself"),
+        ([[0, 0, 0, 0], [3, 1, 2, dens], [1, 0, 1, 0], [1, 1, 1, 0]], [1, 2], 3, "contains itself"),   # List(Medium(List(that Medium)))
     ]:
         with pytest.raises(ptgpu.PtError) as e:
             select(nodes, children, root)

@@ -1,6 +1,7 @@
 """Ad-hoc fuzzing of the GPU kernels against the oracle with seeded random worlds (development aid; the seeds that
 found bugs live on as cases in tests/test_gpu_parity.py). Usage: python tools/fuzz_worlds.py [first_seed] [count] [all|classic]
 Kinds (seed % 5): 0 sphere worlds, 1 general worlds, 2 moving-sphere worlds, 3 far bounce origins, 4 scene graphs.
+Mode "graphs": scene graphs with every nesting, flattened or interpreted (csrc/pt_graph.h) as the product decides.
 Mode "noise": general worlds with Noise textures (on Lambertians, behind a Checker, in media, sometimes on the light) under a gradient /
 black / coloured sky: ray counts against the oracle, colours within the sinf tolerance, and the general-world kernel's two ways of forming
 a Noise colour -- when a lit path ends (default) / where the surface is hit (tuning bit 131072) -- against each other bit for bit."""
@@ -29,6 +30,16 @@ bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     kind = seed % 5 if MODE == "all" else seed % 3
+    if MODE == "graphs":   # scene graphs with every nesting (a medium around a List / a medium / a BVHNode, BVHNodes anywhere): flattened where possible, interpreted otherwise
+        g = tgp._random_graph_world(ob, seed, W, H, n_top=int(rng.integers(1, 9)), max_depth=int(rng.integers(2, 7)), media=bool(seed % 3), wild=bool(seed % 4))
+        depth = int(rng.choice([0, 1, 5, 10, 25]))
+        out, rays, ref, ref_rays, choice = tgp._render_graph_both(ptgpu, ob, g, W, H, S, depth=depth, frame=int(rng.choice([0, 2])))
+        n_interp = globals().get("n_interp", 0) + int(choice["world_graph"])
+        globals()["n_interp"] = n_interp
+        if rays != ref_rays or not np.array_equal(ref, out, equal_nan=True):
+            bad += 1
+            print("MISMATCH seed %d graph (%s): rays %d vs %d, %s" % (seed, choice["name"], rays, ref_rays, tgp._report(ref, out)))
+        continue
     if MODE == "noise":
         sky = [None, (0.0, 0.0, 0.0), tuple(rng.uniform(0.0, 1.0, 3))][int(rng.integers(0, 3))]
         w = tgp._random_world(ob, seed, int(rng.integers(1, 30)), (0, 1, 2, 3, 4, 5), W, H, sky=sky)
@@ -96,4 +107,4 @@ for seed in range(first, first + count):
         if not ok:
             bad += 1
             print("MISMATCH seed %d kind %d bvh %s: rays %d vs %d, %s" % (seed, kind, bvh, rays, ref_rays, tgp._report(ref, out)))
-print("fuzz: %d worlds x list/BVH, %d mismatches" % (count, bad))
+print("fuzz: %d worlds x list/BVH, %d mismatches%s" % (count, bad, (" (%d graphs interpreted)" % globals().get("n_interp", 0)) if MODE == "graphs" else ""))
