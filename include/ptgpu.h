@@ -382,6 +382,9 @@ int pt_scene_debug_tree_packed(pt_scene *scene, void *nodes_out, size_t capacity
  *        that has run out of pixels finishes pixels handed over by waves that still have some, all 64 lanes on each ray
  *        (csrc/pt_coop.h; scene.rs:96-111 makes a pixel one serial chain, and this shortens the chain). A pixel's RNG stream
  *        travels with it: who traces a pixel never changes it.
+ * 262144 = the measuring launch of a new view traces every tile. Default on the MFMA list kernels: it traces one colour of a checkerboard
+ *        of 8x8 tiles; a tile of the other colour takes the mean of its measured neighbours as its cost and starts at its first sample
+ *        in the second launch (measuring launch + order of config 3: 0.30 -> 0.23 ms).
  * 131072 = general-world kernel: the colour of a Noise texture (texture.rs:86-88) is evaluated where the surface is hit, by every lane
  *        for itself. Default for worlds with Noise textures: a Lambertian / Isotropic scatter keeps the hit POINT, and the colour is formed
  *        only when the path ends on something that is not black, by the whole wave for all such lanes (csrc/pt_world.h LAZY). A path

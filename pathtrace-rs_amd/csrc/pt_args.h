@@ -142,6 +142,7 @@ struct KArgs {
     // rest, ordered by those costs). A pixel's samples are one serial RNG stream: phase 1 parks (xoshiro state, colour sum) in
     // px_state (12 dwords per pixel) where phase 2 picks them up; 0 = the whole frame in one launch.
     uint32_t phase;
+    uint32_t checker;            // phase 2: only the tiles with an even tcol + trow were measured (their pixels continue at sample 1); the others start here
     uint4 *px_state;
     uint32_t first_static;       // 0, or the number of items handed out statically as the waves' first fetches (grid x 1024)
     uint32_t refill_min;         // lanes that must be waiting before a wave fetches new pixels (4; 8 below 32 spp)

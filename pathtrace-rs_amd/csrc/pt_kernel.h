@@ -1559,10 +1559,14 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 #ifdef PT_WAVE_DETAIL
                     if (dbg_first_pxy == 0xffffffffu) dbg_first_pxy = pxy;
 #endif
-                    sd = 0;
                     const uint32_t px = x, py = ly * A.shard_count + A.shard_index;
                     need_cam = true;
-                    if (!PILOT && A.phase == 2u) {   // continue the stream and the sum phase 1 parked
+                    // phase 2 of a frame whose measuring launch traced every OTHER tile (KArgs::checker): a pixel of an unmeasured tile
+                    // starts here, one sample behind the others -- its sample number starts at -1 (20 bits), so that it too is done
+                    // when the number reaches s_par[12].w = samples - 1
+                    const bool parked = !PILOT && A.phase == 2u && (A.checker == 0u || ((tcol + trow) & 1u) == 0u);
+                    sd = (!PILOT && A.phase == 2u && !parked) ? 0xfffff000u : 0u;
+                    if (parked) {   // continue the stream and the sum phase 1 parked
                         const uint4 *st = A.px_state + 3u * (size_t)(ly * A.width + x);
                         const uint4 a = st[0], b = st[1], c = st[2];
                         rng.s0 = (uint64_t)a.x | ((uint64_t)a.y << 32), rng.s1 = (uint64_t)a.z | ((uint64_t)a.w << 32);

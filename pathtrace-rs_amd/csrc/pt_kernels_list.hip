@@ -35,9 +35,43 @@ __global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile
     }
 }
 
+// ---- measuring every OTHER tile -----------------------------------------------------------------
+// The measuring launch of a new view traces one sample of the tiles of one colour of a checkerboard (tcol + trow even); a tile of the
+// other colour takes the mean of its measured neighbours as its cost and is traced from its first sample by the frame kernel
+// (KArgs::checker). Config 3: measuring launch + order 0.30 -> 0.23 ms, frame 6.75 -> 6.70 ms; 16 spp 2.23 -> 2.15 ms. (One tile of every
+// 2 x 2 block was measured too: 7.1 ms -- the order gets too coarse. tools/checker_ab.sh)
+__global__ void pt_checker_list_kernel(uint32_t tiles_x, uint32_t tiles_y, uint32_t *list) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles_x * tiles_y) return;
+    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+    if (((tx + ty) & 1u) != 0u) return;
+    // two rows hold tiles_x measured tiles: ceil(tiles_x / 2) in the even row, the rest in the odd one
+    list[(ty >> 1) * tiles_x + ((ty & 1u) ? (tiles_x + 1u) / 2u : 0u) + (tx >> 1)] = t;
+}
+__global__ void pt_checker_fill_kernel(uint32_t tiles_x, uint32_t tiles_y, uint32_t *cost) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles_x * tiles_y) return;
+    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+    if (((tx + ty) & 1u) == 0u) return;
+    uint32_t sum = 0, n = 0;   // (its four neighbours are all of the measured colour, and nobody writes those)
+    if (tx > 0u) sum += cost[t - 1u], n += 1u;
+    if (tx + 1u < tiles_x) sum += cost[t + 1u], n += 1u;
+    if (ty > 0u) sum += cost[t - tiles_x], n += 1u;
+    if (ty + 1u < tiles_y) sum += cost[t + tiles_x], n += 1u;
+    cost[t] = n ? sum / n : 0u;
+}
+
 }  // namespace ptdev
 
 namespace pthostside {
+
+void launch_checker_list(uint32_t tiles_x, uint32_t tiles_y, uint32_t *list, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_checker_list_kernel, dim3((tiles_x * tiles_y + 255u) / 256u), dim3(256), 0, stream, tiles_x, tiles_y, list);
+}
+void launch_checker_fill(uint32_t tiles_x, uint32_t tiles_y, uint32_t *cost, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_checker_fill_kernel, dim3((tiles_x * tiles_y + 255u) / 256u), dim3(256), 0, stream, tiles_x, tiles_y, cost);
+}
+
 
 void mfma_list_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *frame, SphereKernel *measure) {
     // [moving][256 frame, 256 measure, verify, 768 frame, 768 measure, 1024 frame, 1024 measure]

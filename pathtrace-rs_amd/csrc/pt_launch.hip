@@ -148,9 +148,11 @@ int ensure_gstack(pt_scene *s, size_t need_floats) {
 // family's measuring twin, phase 1) traces the first sample of every pixel in natural order, counts the rays per tile and parks
 // each pixel's RNG stream and colour sum, the second continues, ordered by those costs. Only WHEN a pixel is rendered depends
 // on any of this, never its value. `A` is the frame kernel's argument block (updated in place), `measure` launches phase 1.
+inline void set_checker(KArgs &A, bool on) { A.checker = on ? 1u : 0u; }
+inline void set_checker(WArgs &, bool) {}   // (the general-world kernel measures every tile)
 template <typename Args, typename LaunchMeasure>
 int order_work(pt_scene *s, Args &A, const pt_params *params, const pt_camera *cam, uint32_t shard_index, uint32_t shard_count, hipStream_t stream,
-               uint32_t measure_refill, LaunchMeasure measure) {
+               uint32_t measure_refill, LaunchMeasure measure, bool checker = false) {
     const uint32_t n_work_tiles = A.n_items / kTilePix;
     if (int rc = ensure_tile_buf(s, n_work_tiles)) return rc;
     uint32_t *cost = s->d_tile_buf + 8, *order = cost + s->d_tile_cap, *measured = order + s->d_tile_cap;
@@ -166,11 +168,19 @@ int order_work(pt_scene *s, Args &A, const pt_params *params, const pt_camera *c
         HIP_TRY(hipMemsetAsync(cost, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
         Args A1 = A;
         A1.samples = 1, A1.phase = 1, A1.px_state = s->d_px_state, A1.tile_cost = cost;
+        const uint32_t tiles_y = n_work_tiles / A.tiles_x;
+        if (checker) {   // every other tile (pt_kernels_list.hip): the list of the measured colour lives where the frame's order will be written
+            launch_checker_list(A.tiles_x, tiles_y, order, stream);
+            A1.tile_order = order;
+            A1.n_items = ((tiles_y >> 1) * A.tiles_x + ((tiles_y & 1u) ? (A.tiles_x + 1u) / 2u : 0u)) * kTilePix;
+        }
         // one sample per pixel: refills dominate, batch them hard (`measure_refill` lanes must be waiting: the caller's choice)
         A1.refill_min = dev_knobs().phase1_refill > 0 ? (uint32_t)dev_knobs().phase1_refill : measure_refill;
         measure(A1);
+        if (checker) launch_checker_fill(A.tiles_x, tiles_y, cost, stream);
         launch_tile_order(n_work_tiles, cost, params->max_depth + 1u, order, stream);
         A.samples = params->samples - 1u, A.phase = 2, A.px_state = s->d_px_state;
+        set_checker(A, checker);
         measured_scale = A.samples * (params->max_depth + 1u);
     }
     HIP_TRY(hipGetLastError());
@@ -430,7 +440,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         if (int rc = order_work(s, A, params, cam, shard_index, shard_count, stream, measure_refill, [&](KArgs A1) {
                 A1.wave_end = nullptr;
                 hipLaunchKernelGGL(measure_kern, dim3(grid), dim3(blk), lds, stream, A1);
-            }))
+            }, c.family == ptsel::Family::Mfma && !(s->variant & ptsel::kVarMeasureAllTiles) && A.n_items / kTilePix >= 4u * A.tiles_x))
             return rc;
         // 16-wave workgroups: the waves' first fetches are handed out by age class -- the oldest wave of every SIMD takes the head of
         // the heavy-first list (pt_kernel.h first_static; +1 % on configs 3 / 4)

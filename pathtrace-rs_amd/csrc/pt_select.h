@@ -37,6 +37,7 @@ enum : uint32_t {
     kVarNoCulling = 1024u,       // MFMA kernels run every tile
     kVarBinaryTree = 2048u,      // tree kernels walk the binary tree
     kVarMeasureEveryFrame = 8192u,   // no reuse of the previous frame's measured tile costs
+    kVarMeasureAllTiles = 262144u,   // MFMA list kernels: the measuring launch of a new view traces EVERY tile (default: one colour of a checkerboard)
     kVarWorldEager = 131072u,    // general-world kernel: Noise colours where the surface is hit, every lane its own (no LAZY instantiation)
     kVarNoCoop = 65536u,         // wide list kernels: no hand-over of pixels to idle waves (pt_coop.h)
 };

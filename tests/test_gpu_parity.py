@@ -234,7 +234,8 @@ def test_work_order_from_the_previous_frame_never_changes_a_pixel(ptgpu, pthost,
     W, H, S = 512, 320, 32          # 2 560 work tiles, 32 spp: large enough for every ordering scheme to be used
     runs = {}
     # 8192: every frame measures its own order with its first sample (two launches)
-    for name, variant in (("reuse", 0), ("pilot", 8192), ("unordered", 32)):
+    # 262144: ... over every tile (default on the MFMA list kernels: one colour of a checkerboard, the other tiles start in the second launch)
+    for name, variant in (("reuse", 0), ("pilot", 8192), ("pilot_all", 8192 | 262144), ("unordered", 32)):
         hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=bvh, device=0)
         sc = hs.device_scene()
         sc.set_tuning(0, variant)
@@ -248,7 +249,7 @@ def test_work_order_from_the_previous_frame_never_changes_a_pixel(ptgpu, pthost,
             if frame == 1:
                 rays.append(sc.update(p, other, 0, side))    # another view in between: its key differs, the pilot runs
         runs[name] = (out, side, rays)
-    for name in ("pilot", "unordered"):
+    for name in ("pilot", "pilot_all", "unordered"):
         assert runs["reuse"][2] == runs[name][2], (runs["reuse"][2], runs[name][2])
         assert np.array_equal(runs["reuse"][0], runs[name][0]) and np.array_equal(runs["reuse"][1], runs[name][1])
 
