@@ -30,7 +30,7 @@ struct GraphSrc {
 };
 
 // Hitable::ray_hit of the graph's root for `ray` in (t_min, t_max). `fr`: this lane's frames (word w of level l at fr[(l * kGraphFrame + w) * kBlock]).
-__device__ __noinline__ GHit graph_ray_hit(const GraphSrc G, const pt_hitable *hit, const pt_affine *xf, WRay ray, float t_min, float t_max, Rng &rng, float *fr,
+static __device__ __noinline__ GHit graph_ray_hit(const GraphSrc G, const pt_hitable *hit, const pt_affine *xf, WRay ray, float t_min, float t_max, Rng &rng, float *fr,
                                            bool want_uv) {
     auto W = [&](uint32_t level, uint32_t word) -> float & { return fr[((size_t)level * kGraphFrame + word) * (size_t)kBlock]; };
     auto Wu = [&](uint32_t level, uint32_t word) -> uint32_t & { return reinterpret_cast<uint32_t *>(fr)[((size_t)level * kGraphFrame + word) * (size_t)kBlock]; };
