@@ -20,7 +20,7 @@ def is_frame_kernel(name):
     return len(flags) < 5 or flags[4] == "false"
 
 def is_measuring_kernel(name):
-    """The measuring launch of a sphere-kernel frame (5th template flag PILOT = true): first sample of every pixel."""
+    """The measuring launch of a sphere-kernel frame (5th template flag PILOT = true): the first sample of every pixel (MFMA list kernels: of every other tile)."""
     m = re.search(r"pt_trace_kernel<([^>]*)>", name)
     if not m:
         return False
@@ -138,7 +138,7 @@ if "FETCH_SIZE" in pmc or "WRITE_SIZE" in pmc:
 if pmc_m:
     m_bytes = pmc_m.get("FETCH_SIZE", 0.0) * 1024 * 2 + pmc_m.get("WRITE_SIZE", 0.0) * 1024
     out["hbm_bytes_measuring_launch"] = m_bytes
-    lines.append("HBM traffic of the measuring launch (first sample of every pixel; parks 48 B per pixel): %.3f MB; both launches of a frame: %.3f MB"
+    lines.append("HBM traffic of the measuring launch (first sample of the measured pixels; parks 48 B per pixel): %.3f MB; both launches of a frame: %.3f MB"
                  % (m_bytes / 1e6, (m_bytes + out.get("hbm_bytes_per_launch", 0.0)) / 1e6))
 bl = os.path.join(src, "bench_line.json")
 if os.path.exists(bl) and os.path.getsize(bl):
