@@ -29,6 +29,12 @@ struct f3 {
 constexpr uint32_t kTileLog2 = PT_TILE_LOG2;             // work tiles are (1 << kTileLog2)^2 pixels
 constexpr uint32_t kTileSide = 1u << kTileLog2, kTilePix = kTileSide * kTileSide;
 constexpr int kBlock = PT_BLOCK;  // threads per workgroup (the main loop never synchronises across waves)
+// LAZY Noise colours (pt_world.h): 0.5 (1 + sin(scale p.z + 10 turb(p))) (texture.rs:86-88) is formed later -- or never, when the path ends
+// in black -- only where it is certainly finite, i.e. where the sine's argument is (f32::sin of a finite number is): |p| < kLazyNoiseReach
+// per axis on the device, |scale| <= kLazyNoiseScale and Perlin gradients of at most kLazyNoiseGradient per component on the host. The
+// trilinear weights of perlin.rs:66-69 sum to one, so |noise| <= 3 x 4 and |turb| <= 24: the argument stays below 1.1e6. (Far tighter than
+// finiteness needs; a point, a scale or a gradient table outside is coloured where it is hit, and `path_odd` sees what comes out.)
+constexpr float kLazyNoiseReach = 1.0e4f, kLazyNoiseScale = 1.0e2f, kLazyNoiseGradient = 4.0f;
 constexpr uint32_t kGraphDepth = 24u, kGraphFrame = 24u;   // interpreted scene graphs (pt_graph.h): nested Hitable::ray_hit calls per lane, words per call
 constexpr uint32_t kWorldNoiseLds = 4096u + 768u + (uint32_t)(kBlock / 64) * 768u;   // general-world kernel, worlds with Noise textures: gradients, permutations, wave_balanced_turb's 192 words per wave
 constexpr int kBvhStack = 32;    // per-lane traversal stack entries (LDS)

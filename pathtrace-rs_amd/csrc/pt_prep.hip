@@ -1029,14 +1029,14 @@ void world_traits(const pt_world_desc *desc, const WorldAsSpheres &w, ptsel::Sce
     tr.atts_finite = true;
     for (uint32_t i = 0; i < desc->n_materials; ++i)
         for (int c = 0; c < 3; ++c) tr.atts_finite = tr.atts_finite && std::isfinite(desc->materials[i].albedo[c]);
-    // texture.rs:86-88: 0.5 (1 + sin(scale p.z + 10 turb(p))) is finite when its argument is; turb (perlin.rs:76-87) is a sum of products of
-    // finite gradients with weights in [0, 1] at points up to 64 p
+    // texture.rs:86-88: 0.5 (1 + sin(scale p.z + 10 turb(p))) is finite where its argument is (pt_args.h kLazyNoise*: bounds on the scale
+    // and on the Perlin gradients here, on the point in the kernel)
     tr.noise_finite = tr.atts_finite && (!w.has_noise || desc->perlin != nullptr);
     for (uint32_t i = 0; i < desc->n_textures; ++i)
-        if (desc->textures[i].kind == PT_TEX_NOISE) tr.noise_finite = tr.noise_finite && std::fabs(desc->textures[i].scale) <= 1.0e6f;
+        if (desc->textures[i].kind == PT_TEX_NOISE) tr.noise_finite = tr.noise_finite && std::fabs(desc->textures[i].scale) <= ptdev::kLazyNoiseScale;
     if (desc->perlin)
         for (int i = 0; i < 256; ++i)
-            for (int c = 0; c < 3; ++c) tr.noise_finite = tr.noise_finite && std::fabs(desc->perlin->randvec[i][c]) <= 1.0e6f;
+            for (int c = 0; c < 3; ++c) tr.noise_finite = tr.noise_finite && std::fabs(desc->perlin->randvec[i][c]) <= ptdev::kLazyNoiseGradient;
 }
 
 }  // namespace pthostside

@@ -62,7 +62,7 @@ struct SceneTraits {
     uint32_t n_hitables = 0, n_world_xf = 0, ref_bvh_depth = 0;
     bool has_media = false, has_image = false;
     bool atts_finite = false;      // every material colour is finite: a path that ends in black needs no fold (pt_world.h)
-    bool noise_finite = false;     // ... and every Noise texture's scale and the Perlin gradients are such that its colour is finite wherever |p| < 1e30
+    bool noise_finite = false;     // ... and every Noise texture's scale and the Perlin gradients are such that its colour is finite wherever |p| < 1e4 (pt_args.h kLazyNoise*)
     bool has_chains = false;       // some entry sits below several Instance levels, or below Instances around its medium (scene graphs)
     bool is_graph = false;         // a scene graph that does not flatten: interpreted (pt_graph.h)
 };

@@ -547,14 +547,15 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                     path_odd = path_odd || !(__builtin_isfinite(c.x) && __builtin_isfinite(c.y) && __builtin_isfinite(c.z));
                     return c;
                 };
-                // the attenuation of a Lambertian / Isotropic scatter: the colour -- or, LAZY, the point of a Noise texture (WArgs::lazy_ok:
-                // the host checked that a Noise colour of a point below 1e30 is finite)
+                // the attenuation of a Lambertian / Isotropic scatter: the colour -- or, LAZY, the point of a Noise texture. Only where the
+                // colour is certainly finite (pt_args.h kLazyNoiseReach); a point further out is coloured here and now, and path_odd
+                // notices what comes out
                 bool lazy = false;
                 float lazy_scale = 0.0f;
                 auto surface = [&]() __attribute__((always_inline)) -> f3 {
                     if (LAZY && m.pad0 == 0.0f) {
                         const DTex leaf = texture_leaf(A.texs, m.tex, point);
-                        if (leaf.kind == PT_TEX_NOISE && __builtin_fabsf(point.x) < 1.0e30f && __builtin_fabsf(point.y) < 1.0e30f && __builtin_fabsf(point.z) < 1.0e30f) {
+                        if (leaf.kind == PT_TEX_NOISE && __builtin_fabsf(point.x) < kLazyNoiseReach && __builtin_fabsf(point.y) < kLazyNoiseReach && __builtin_fabsf(point.z) < kLazyNoiseReach) {
                             lazy = true, lazy_scale = leaf.scale;
                             return point;
                         }
