@@ -499,6 +499,29 @@ def main():
                      "note": "independent frames alternating over two scene handles and two HIP streams (the tail of one frame "
                              "overlaps the start of the next); each frame is bit-identical to the single-frame result"}
 
+    other_workloads = None
+    if not multi and not args.no_extras and args.preset == "random_spheres" and (W, H, S) == (1200, 800, 64) and not args.bvh:
+        # Extra, never `value`: the other kernels of the path at the headline's frame size (a BVH world on the list kernel, the
+        # general-world kernel on the reference's box / light presets), three frames of a never-seen view each after one warm-up.
+        other_workloads = {}
+        for name, preset, bvh in (("random_spheres -B", "random_spheres", True), ("random", "random", False), ("simple_light", "simple_light", False),
+                                  ("cornell", "cornell", False), ("cornell_smoke", "cornell_smoke", False), ("cornell_smoke -B", "cornell_smoke", True)):
+            ho = pthost.HostScene(preset, W, H, samples=S, use_bvh=bvh, device=local_rank)
+            so = ho.device_scene()
+            so.set_tuning(0, base_variant | 8192)
+            po = ptgpu.PtParams(W, H, S, depth, 0, 1 if bvh else 0)
+            bo = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+            ro = torch.zeros(1, dtype=torch.int64, device=dev)
+            so.update_device(po, ho.camera, 0, bo.data_ptr(), ro.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                bo.zero_()
+                so.update_device(po, ho.camera, 0, bo.data_ptr(), ro.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            elo = (time.perf_counter() - t0) / 3.0
+            other_workloads[name] = {"value": int(ro.item()) / 1e6 / elo, "unit": "Mrays/s", "ms_per_frame": elo * 1e3, "kernel": so.last_kernel_choice()["name"]}
+            del so, ho
     if rank == 0:
         grid, block, lds = scene.last_launch_info()
         tiles = multi and args.mode == "tiles"
@@ -545,6 +568,8 @@ def main():
             out["pipelined_frames"] = pipelined
         if progressive is not None:
             out["progressive_view"] = progressive
+        if other_workloads is not None:
+            out["other_workloads_same_frame_size"] = other_workloads
         if N == 1 and not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.preset, W, H, S, depth, args.bvh, args.cpu_secs)
         print(json.dumps(out))
