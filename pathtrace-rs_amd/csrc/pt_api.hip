@@ -39,6 +39,7 @@ const DevKnobs &dev_knobs() {
         if (const char *e = getenv("PTGPU_BLOCKS_PER_CU")) d.blocks_per_cu = (uint32_t)atoi(e);
         if (const char *e = getenv("PTGPU_VARIANT")) d.variant = (uint32_t)atoi(e);
         d.world_occ3 = getenv("PTGPU_WORLD_OCC3") != nullptr;
+        d.world_occ4 = getenv("PTGPU_WORLD_OCC4") != nullptr;
         d.debug = getenv("PTGPU_DEBUG") != nullptr;
         d.clamp_grid = getenv("PTGPU_CLAMP_GRID") != nullptr;
         d.timing = getenv("PTGPU_TIMING") != nullptr;

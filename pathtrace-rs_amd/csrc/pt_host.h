@@ -42,7 +42,7 @@ const char *last_error_message();
 // has none: every knob below then keeps its default).
 struct DevKnobs {
     int refill = -1, ready = -1, drain = -1, phase1_refill = -1, cull_axis = -1, cull_strips = -1;
-    bool world_occ3 = false, debug = false, clamp_grid = false, timing = false;
+    bool world_occ4 = false, world_occ3 = false, debug = false, clamp_grid = false, timing = false;
     int host_threads = -1;
     int coop_live = -1, coop_streak = -1, coop_period = -1, coop_est = -1;   // cooperative hand-over policy (pt_coop.h)
     uint32_t variant = 0, blocks_per_cu = 0;

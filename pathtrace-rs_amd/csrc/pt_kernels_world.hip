@@ -14,6 +14,8 @@ WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media, bool 
     if (chains)
         return bvh ? (hit_lds ? pt_world_kernel<true, true, 3, true, true> : pt_world_kernel<true, false, 3, true, true>)
                    : (hit_lds ? pt_world_kernel<false, true, 3, true, true> : pt_world_kernel<false, false, 3, true, true>);
+    if (occ == 5u)   // five waves per SIMD (96 VGPRs): pt_select.h picks it for worlds whose records sit in LDS
+        return bvh ? (media ? pt_world_kernel<true, true, 5, true> : pt_world_kernel<true, true, 5, false>) : (media ? pt_world_kernel<false, true, 5, true> : pt_world_kernel<false, true, 5, false>);
     // worlds whose records do not fit LDS share the MEDIA = true code
     if (occ == 4u)
         return bvh ? (hit_lds ? (media ? pt_world_kernel<true, true, 4, true> : pt_world_kernel<true, true, 4, false>) : pt_world_kernel<true, false, 4, true>)

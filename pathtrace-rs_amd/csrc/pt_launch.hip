@@ -304,7 +304,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
 
     // ---- which kernel, which geometry (pt_select.h) ----
     ptsel::Knobs knobs;
-    knobs.variant = s->variant, knobs.blocks_per_cu = s->blocks_per_cu, knobs.refill = dev_knobs().refill, knobs.world_occ3 = dev_knobs().world_occ3;
+    knobs.variant = s->variant, knobs.blocks_per_cu = s->blocks_per_cu, knobs.refill = dev_knobs().refill, knobs.world_occ3 = dev_knobs().world_occ3, knobs.world_occ4 = dev_knobs().world_occ4;
     const uint32_t local_rows = pt_shard_rows(params->height, shard_index, shard_count);
     const auto tree4_regs = [&] {
         return blocks_per_cu_by_registers(reinterpret_cast<const void *>(tree4_kernel_for_registers(s->tr.has_motion)), (uint32_t)kBlock);

@@ -97,7 +97,7 @@ struct KernelChoice {
 struct Knobs {                  // tuning word + the development overrides (-1 / 0: library default)
     uint32_t variant = 0, blocks_per_cu = 0;
     int refill = -1;
-    bool world_occ3 = false;
+    bool world_occ3 = false, world_occ4 = false;   // (development knobs: cap the general-world kernel's waves per SIMD)
 };
 
 inline bool shutter_inside(const SceneTraits &t, float time0, float time1) {
@@ -137,7 +137,9 @@ inline void select_world(const SceneTraits &t, const pt_params &p, uint32_t loca
     c.gstack = !c.stack_in_lds;
     // four waves per SIMD (128 VGPRs, no (u, v) in the hit record) for worlds without noise / image textures
     const bool occ4 = !t.has_noise && !t.has_image && !t.has_chains && k.blocks_per_cu == 0 && 4u * lds <= kLdsBudget && !k.world_occ3;
-    c.world_occ = occ4 ? 4u : 3u;
+    // ... and five (96 VGPRs, a handful of spills) where the LDS lets five workgroups share a CU: list worlds at depth 10 (cornell +7.5 %,
+    // cornell_smoke +9 %); a BVH world's traversal stack does not leave the room
+    c.world_occ = occ4 ? ((c.world_hit_lds && 5u * lds <= kLdsBudget && !k.world_occ4) ? 5u : 4u) : 3u;
     // worlds whose records do not fit LDS (more than ~600 hitables) share the MEDIA = true code
     c.world_media = t.has_media || !c.world_hit_lds || t.has_motion || t.has_chains;
     c.lds_bytes = lds;

@@ -342,8 +342,9 @@ namespace ptdev {
 // then reads them at LDS latency instead of waiting on the scalar cache for each entry (58 % of the wave-cycles of
 // cornell_smoke were such waits), and BVH mode gathers them per lane from LDS instead of L2.
 // OCC: waves per SIMD the kernel is compiled for. 4 (128 VGPRs, a few spills) pays for worlds without noise textures
-// whose LDS lets four workgroups share a CU (cornell +7 %, cornell_smoke +11 %); with Perlin noise inlined the spills
-// cost more than the fourth wave brings (simple_light -6 %), so those keep 2 (the compiler then uses ~160 VGPRs).
+// whose LDS lets four workgroups share a CU (cornell +7 %, cornell_smoke +11 %), 5 (96 VGPRs, 5-11 spilled) once more where it
+// lets five (list worlds at depth 10: cornell +7.5 %, cornell_smoke +9 %); with Perlin noise inlined the spills
+// cost more than the fourth wave brings (simple_light -6 %), so those keep 3 (the compiler then uses ~130 VGPRs).
 // MEDIA: some hitable is a ConstantMedium (own instantiations: worlds without media do not carry that path's registers).
 // CHAINS: some entry sits below more than one Instance level, or below Instances around its medium (scene graphs only).
 #ifdef PT_BBPROF   // tools/bbprof.py (BBPROF_UNIT=pt_kernels_world): the instrumented assembly keeps its counter registers above the compiler's
