@@ -223,14 +223,21 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     // per CU: as many levels as fit next to four of them, deeper ones in HBM/L2. 256-thread MFMA kernels: none (their LDS goes
     // to the fragments; 3 resident workgroups beat 1 with an LDS stack). Exact-scan kernels: all or nothing.
     uint32_t lds_levels = 0;
+    bool scan4 = false;
     if (wide) {
         lds_levels = 0;
     } else if (bvh && (v & kVarStackInHbm) == 0) {
         const uint32_t wg_regs = tree4 ? tree4_wg_by_regs : 4u;
         const uint32_t per_block = kLdsBudget / std::min(4u, std::max(1u, wg_regs));
         if (per_block > lds) lds_levels = std::min<uint32_t>(stack_levels, (per_block - lds) / (slots * blk * 4u));
-    } else if (!bvh && !mfma && (v & kVarStackInHbm) == 0 && lds + path_bytes <= kLdsPerBlockMax) {
-        lds_levels = stack_levels;
+    } else if (!bvh && !mfma && (v & kVarStackInHbm) == 0) {
+        // Exact-scan kernels (108 VGPRs: four waves per SIMD): FOUR workgroups per CU when all levels -- or all but the deepest two,
+        // which few paths reach and which then live in HBM/L2 -- fit beside four of them (smallpt +10 %, small +7 % over three);
+        // otherwise all levels or none, three workgroups
+        const uint32_t per4 = kLdsBudget / 4u, level_bytes = slots * blk * 4u;
+        const uint32_t fit4 = per4 > lds ? std::min<uint32_t>(stack_levels, (per4 - lds) / level_bytes) : 0u;
+        if (k.blocks_per_cu == 0 && fit4 + 2u >= stack_levels && fit4 != 0u) lds_levels = fit4, scan4 = true;
+        else if (lds + path_bytes <= kLdsPerBlockMax) lds_levels = stack_levels;
     }
     c.stack_in_lds = lds_levels * slots;
     lds += lds_levels * slots * blk * 4u;
@@ -249,7 +256,7 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     // persistent grid: CUs x resident workgroups
     uint32_t bpc = k.blocks_per_cu;
     c.bpc_forced = bpc != 0;
-    if (bpc == 0) bpc = wide ? 1u : (bvh ? 4u : 3u);
+    if (bpc == 0) bpc = wide ? 1u : ((bvh || scan4) ? 4u : 3u);
     const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
     if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
     c.bpc = std::min(bpc, 8u);
