@@ -178,6 +178,53 @@ __device__ __forceinline__ bool w_cuboid_t(f3 p0, f3 p1, const WRay &r, float t_
     t_out = closest;
     return found;
 }
+// A ConstantMedium asks its boundary twice (constant_medium.rs:39-43): (-MAX, MAX), then (t_first + 0.0001, MAX). For a Cuboid both
+// questions meet the same six planes: the plane parameters, the in-rectangle tests and the slabs of the AABB test (cuboid.rs:11-37,
+// rect.rs:73-190, aabb.rs:46-58) do not depend on the range -- they are formed ONCE here, and a question is then the range tests over
+// them, with the same comparisons in the same order as w_cuboid_t (ties between faces go to the later one there and here).
+struct WCuboidPlanes {
+    float t[6];      // plane parameter of face 0..5 (XY, XY', XZ, XZ', YZ, YZ'; ' = the face at p0)
+    uint32_t inb;    // bit f: the point at t[f] lies inside face f's rectangle
+    float s0[3], s1[3];   // per axis: sse_min / sse_max of the two slab parameters
+};
+template <int AXIS, bool FLIP>
+__device__ __forceinline__ void w_cuboid_plane(f3 p0, f3 p1, const WRay &r, WCuboidPlanes &P) {
+    float a0, a1, b0, b1, k, ok, rk, oa, da, ob, db;
+    w_cuboid_face_bounds<AXIS, FLIP>(p0, p1, a0, a1, b0, b1, k);
+    w_rect_axes((uint32_t)AXIS, r, ok, rk, oa, da, ob, db);
+    const float t = (k - ok) * rk;
+    const float a = oa + t * da, b = ob + t * db;
+    constexpr int f = 2 * AXIS + (FLIP ? 1 : 0);
+    P.t[f] = t;
+    P.inb |= (a < a0 || a > a1 || b < b0 || b > b1) ? 0u : (1u << f);
+}
+__device__ __forceinline__ void w_cuboid_slabs(f3 p0, f3 p1, const WRay &r, WCuboidPlanes &P) {
+    const float lx = (p0.x - r.o.x) * r.rcp.x, hx = (p1.x - r.o.x) * r.rcp.x, ly = (p0.y - r.o.y) * r.rcp.y, hy = (p1.y - r.o.y) * r.rcp.y;
+    const float lz = (p0.z - r.o.z) * r.rcp.z, hz = (p1.z - r.o.z) * r.rcp.z;
+    P.s0[0] = sse_min(lx, hx), P.s1[0] = sse_max(lx, hx), P.s0[1] = sse_min(ly, hy), P.s1[1] = sse_max(ly, hy), P.s0[2] = sse_min(lz, hz), P.s1[2] = sse_max(lz, hz);
+}
+__device__ __forceinline__ bool w_cuboid_box(const WCuboidPlanes &P, float t_min, float t_max) {   // w_aabb_hit over the slabs
+    const bool x = sse_min(P.s1[0], t_max) > sse_max(P.s0[0], t_min), y = sse_min(P.s1[1], t_max) > sse_max(P.s0[1], t_min), z = sse_min(P.s1[2], t_max) > sse_max(P.s0[2], t_min);
+    return x && y && z;
+}
+__device__ __forceinline__ void w_cuboid_faces(f3 p0, f3 p1, const WRay &r, WCuboidPlanes &P) {
+    P.inb = 0u;
+    w_cuboid_plane<0, false>(p0, p1, r, P), w_cuboid_plane<0, true>(p0, p1, r, P);
+    w_cuboid_plane<1, false>(p0, p1, r, P), w_cuboid_plane<1, true>(p0, p1, r, P);
+    w_cuboid_plane<2, false>(p0, p1, r, P), w_cuboid_plane<2, true>(p0, p1, r, P);
+}
+// the six faces of w_cuboid_t(p0, p1, r, t_min, t_max, ...) over the planes formed above (the caller has asked w_cuboid_box)
+__device__ __forceinline__ bool w_cuboid_ask(const WCuboidPlanes &P, float t_min, float t_max, float &t_out, uint32_t &face) {
+    bool found = false;
+    float closest = t_max;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const float t = P.t[f];
+        if (!(t < t_min || t > closest) && ((P.inb >> f) & 1u) != 0u) closest = t, face = (uint32_t)f, found = true;
+    }
+    t_out = closest;
+    return found;
+}
 __device__ __forceinline__ void w_cuboid_rec(f3 p0, f3 p1, uint32_t face, const WRay &r, float t, WHit &h, bool want_uv) {
     const uint32_t axis = face >> 1;
     const bool flip = (face & 1u) != 0u;
@@ -283,7 +330,9 @@ constexpr uint32_t kFaceMedium = 0xffu;   // `face` of a hit INSIDE a ConstantMe
 // One HitableList entry, first step: the accepted parameter. Returns the material index to shade with, or -1 for no hit.
 // A ConstantMedium asks its boundary twice (constant_medium.rs:39-43) -- two call sites of the shape code: a two-trip loop around
 // one call site carried its state around the back edge for EVERY entry of the list.
-template <bool MEDIA, bool CHAINS>
+// SHARE: a Cuboid that bounds a medium answers both questions from one set of plane parameters (list scans: cornell_smoke +3.5 %; the
+// per-lane walk of a BVH world keeps the two calls -- there the shared form measured 5 % slower).
+template <bool MEDIA, bool CHAINS, bool SHARE = false>
 __device__ __forceinline__ int w_hitable_t(const pt_hitable &H, const pt_affine *xf, const WRay &r_in, float t_min, float t_max, Rng &rng, float &t,
                                            uint32_t &face) {
     const bool medium = MEDIA && H.medium_material >= 0;   // MEDIA = false: the world has no ConstantMedium (its code, and the RNG's liveness across the scan, drop out)
@@ -294,13 +343,24 @@ __device__ __forceinline__ int w_hitable_t(const pt_hitable &H, const pt_affine 
     const WRay r = outer ? w_ray_into(xf, chain.first, chain.n_out, r_in) : r_in;
     face = 0u;
     const WRay local = w_local_ray<CHAINS>(xf, chain, r);   // (once for both questions of a medium)
-    const bool ok = w_shape_t(H, local, medium ? -kMaxT : t_min, medium ? kMaxT : t_max, t, face);
-    if (!medium) return ok ? (int)H.material : -1;
-    if (!ok) return -1;
-    const float t_first = t;
-    float t_second;
-    uint32_t face2 = 0u;
-    if (!w_shape_t(H, local, t_first + 0.0001f, kMaxT, t_second, face2)) return -1;   // constant_medium.rs:41
+    float t_first, t_second;
+    if (SHARE && medium && H.kind == PT_HIT_CUBOID) {   // both questions over one set of plane parameters (WCuboidPlanes)
+        const f3 p0 = mk3(H.p[0], H.p[1], H.p[2]), p1 = mk3(H.p[3], H.p[4], H.p[5]);
+        WCuboidPlanes P;
+        w_cuboid_slabs(p0, p1, local, P);
+        if (!w_cuboid_box(P, -kMaxT, kMaxT)) return -1;   // (most rays of a frame: the line misses the box, no plane is formed)
+        w_cuboid_faces(p0, p1, local, P);
+        uint32_t face2 = 0u;
+        if (!w_cuboid_ask(P, -kMaxT, kMaxT, t_first, face2)) return -1;
+        if (!w_cuboid_box(P, t_first + 0.0001f, kMaxT) || !w_cuboid_ask(P, t_first + 0.0001f, kMaxT, t_second, face2)) return -1;   // constant_medium.rs:41
+    } else {
+        const bool ok = w_shape_t(H, local, medium ? -kMaxT : t_min, medium ? kMaxT : t_max, t, face);
+        if (!medium) return ok ? (int)H.material : -1;
+        if (!ok) return -1;
+        t_first = t;
+        uint32_t face2 = 0u;
+        if (!w_shape_t(H, local, t_first + 0.0001f, kMaxT, t_second, face2)) return -1;   // constant_medium.rs:41
+    }
     // constant_medium.rs:44-76
     float t1 = t_first, t2 = t_second;
     if (t1 < t_min) t1 = t_min;
@@ -493,7 +553,7 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                 for (uint32_t k = 0; k < A.n_hit; ++k) {
                     float t;
                     uint32_t face;
-                    const int m = w_hitable_t<MEDIA, CHAINS>(hit[k], xf, ray, kMinT, closest, rng, t, face);
+                    const int m = w_hitable_t<MEDIA, CHAINS, true>(hit[k], xf, ray, kMinT, closest, rng, t, face);
                     if (m >= 0) {
                         best_k = k, best_face = face, best_t = t, best_mat = (uint32_t)m, found = true;
                         closest = t;
