@@ -4,14 +4,14 @@
 #include <cstdio>
 #include <hip/hip_runtime.h>
 extern "C" {
-__device__ __attribute__((used, visibility("default"))) unsigned long long pt_bbprof[32768];   // [0, 16384) executions of block i; [16384, 32768) lanes that were switched on, summed over them
+__device__ __attribute__((used, visibility("default"))) unsigned long long pt_bbprof[65536];   // [0, 32768) executions of block i; [32768, 65536) lanes that were switched on, summed over them
 }
 extern "C" __attribute__((visibility("default"), used)) inline int pt_bbprof_dump(const char *path) {
-    static unsigned long long host[32768];
+    static unsigned long long host[65536];
     if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(host, HIP_SYMBOL(pt_bbprof), sizeof host) != hipSuccess) return -1;
     FILE *f = fopen(path, "w");
     if (!f) return -2;
-    for (int i = 0; i < 32768; ++i)
+    for (int i = 0; i < 65536; ++i)
         if (host[i]) fprintf(f, "%d %llu\n", i, host[i]);
     fclose(f);
     return 0;

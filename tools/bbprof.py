@@ -56,7 +56,7 @@ def instrument(src_lines):
         # active lanes of this execution into the second half of the counter array. s_bcnt1 writes SCC, which may be live across
         # the block's entry (a compare in the block above): saved and restored. The wait keeps the data pair stable under the atomic.
         out.extend(["\ts_cselect_b32 s94, 1, 0", "\ts_bcnt1_i32_b64 s92, exec", "\ts_mov_b32 s93, 0",
-                    "\ts_atomic_add_x2 s[92:93], s[98:99], 0x%x" % (8 * (len(blocks) - 1) + 8 * 16384), "\ts_waitcnt lgkmcnt(0)", "\ts_cmp_lg_u32 s94, 0"])
+                    "\ts_atomic_add_x2 s[92:93], s[98:99], 0x%x" % (8 * (len(blocks) - 1) + 8 * 32768), "\ts_waitcnt lgkmcnt(0)", "\ts_cmp_lg_u32 s94, 0"])
 
     for l in src_lines:
         m = re.match(r'\s*\.file\s+(\d+)\s+"[^"]*"\s+"([^"]+)"', l)
@@ -113,7 +113,7 @@ def build():
     p_file = os.path.join(OUT, UNIT + "_bb.s")
     open(p_file, "w").write("\n".join(patched))
     json.dump(blocks, open(os.path.join(OUT, "bbprof_map.json"), "w"))
-    if len(blocks) > 16384: sys.exit("more blocks than counters")
+    if len(blocks) > 32768: sys.exit("more blocks than counters")
     sh([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", p_file, "-o", os.path.join(OUT, "dev.o")])
     sh([LLVM + "/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", os.path.join(OUT, "dev.out"), os.path.join(OUT, "dev.o")])
     sh([LLVM + "/clang-offload-bundler", "-type=o", "-bundle-align=4096", "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950",
@@ -185,7 +185,7 @@ def report(argv):
     for l in open(counts_file):
         a, b = l.split()
         if a == "rays": rays = int(b)
-        elif int(a) >= 16384: lanes_on[int(a) - 16384] = int(b)
+        elif int(a) >= 32768: lanes_on[int(a) - 32768] = int(b)
         else: counts[int(a)] = int(b)
     per_kernel = collections.defaultdict(lambda: collections.Counter())
     lines = collections.defaultdict(lambda: collections.Counter())
