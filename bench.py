@@ -528,7 +528,7 @@ def main():
         counters = committed_counters(args.preset, W, H, S, args.bvh)
         roof = roofline_block("pt_trace_kernel" if not hs.is_world else "pt_world_kernel", kms, float(rays_this_launch), n_spheres, args.bvh, counters)
         roof["pass_ms"] = pms
-        roof["note_pass"] = "kernel_ms = the frame kernel alone (what rocprofv3 reports; samples 2..S); pass_ms adds the measuring launch (first sample of every pixel) and the tile sort that precede it; traffic = the frame kernel's HBM bytes, which include reading back the 48 B per pixel (RNG stream + colour sum) the measuring launch parked"
+        roof["note_pass"] = "kernel_ms = the frame kernel alone (what rocprofv3 reports; samples 2..S); pass_ms adds the measuring launch (first sample of every other 8x8 tile) and the tile sort that precede it; traffic = the frame kernel's HBM bytes, which include reading back the 48 B per pixel (RNG stream + colour sum) the measuring launch parked"
         is_headline = args.preset == "random_spheres" and (W, H) == (1200, 800) and not args.bvh and ((not multi and S == 64) or (tiles and S == 256))
         out = {
             "metric": ("Mrays/sec, random_spheres 1200x800 %dspp" % S) if is_headline else "Mrays/sec, %s %dx%d %dspp" % (args.preset, W, H, S),
