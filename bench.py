@@ -551,7 +551,7 @@ def main():
                        "rccl": rccl_info,
                        "launched_as": launched_as,
                        "grid": grid, "block": block, "lds_bytes": lds,
-                       "work_order": "every timed step measures its own tile costs (launch 1: first sample of every pixel; launch 2: the "
+                       "work_order": "every timed step measures its own tile costs (launch 1: first sample of every other 8x8 tile; launch 2: the "
                                      "rest, expensive tiles first); the library's reuse of the previous frame's measured costs for a "
                                      "repeated view is switched off for `value` (pt_scene_set_tuning bit 8192) and reported as "
                                      "`progressive_view`"},
