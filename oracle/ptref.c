@@ -992,6 +992,7 @@ struct ora_scene {
     hitable_list list;      /* storage.rs:86 alloc_hitables */
     /* scene graphs (ora_scene_from_graph): the nested Hitables built over the leaves in `list` */
     instance *g_instances; constant_medium *g_media; hitable_list *g_lists; hitable *g_children; bvhnode *g_bvh;
+    const float *gb_minmax6; const int32_t *gb_lr2; uint32_t gb_n; size_t gb_used;   /* the BVHNode rows a graph is being built from (build time only) */
     int has_sky; v3 sky;    /* scene.rs:20 */
     camera cam;
     int use_bvh;
@@ -1621,7 +1622,6 @@ bad:
  * The product flattens the same graph where the list form can express it and interprets it otherwise (include/ptgpu.h pt_node);
  * this is what it must agree with. List worlds only. */
 #define GRAPH_POOL ((size_t)1 << 16)   /* entries per pool of ora_scene_from_graph */
-static const float *g_bvh_minmax6; static const int32_t *g_bvh_lr2; static uint32_t g_n_bvh; static size_t g_n_bvh_used;   /* (build-time only; the tests build scenes from one thread) */
 static int graph_build(ora_scene *sc, const uint32_t *nodes4, uint32_t n_nodes, const uint32_t *children, uint32_t n_children,
                        const float *transforms24, uint32_t n_transforms, const float *materials6, uint32_t n_materials, uint32_t n_textures,
                        uint32_t node, uint32_t depth, size_t *n_inst, size_t *n_med, size_t *n_lists, size_t *n_child, hitable *out) {
@@ -1675,17 +1675,17 @@ static int graph_build(ora_scene *sc, const uint32_t *nodes4, uint32_t n_nodes, 
         memset(out, 0, sizeof *out); out->kind = HIT_CONSTANT_MEDIUM; out->med = cm;
         return 1; }
     case 4: {
-        if (w[1] >= g_n_bvh || !g_bvh_minmax6 || !g_bvh_lr2) return 0;
-        const int32_t l = g_bvh_lr2[2 * w[1]], r = g_bvh_lr2[2 * w[1] + 1];
+        if (w[1] >= sc->gb_n || !sc->gb_minmax6 || !sc->gb_lr2) return 0;
+        const int32_t l = sc->gb_lr2[2 * w[1]], r = sc->gb_lr2[2 * w[1] + 1];
         if (l < 0 || r < 0) return 0;
         hitable lhs, rhs;
         if (!graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, (uint32_t)l, depth + 1, n_inst,
                          n_med, n_lists, n_child, &lhs) ||
             !graph_build(sc, nodes4, n_nodes, children, n_children, transforms24, n_transforms, materials6, n_materials, n_textures, (uint32_t)r, depth + 1, n_inst,
                          n_med, n_lists, n_child, &rhs)) return 0;
-        if (g_n_bvh_used >= pool) return 0;
-        bvhnode *bn = &sc->g_bvh[g_n_bvh_used++];
-        const float *m = g_bvh_minmax6 + 6 * w[1];
+        if (sc->gb_used >= pool) return 0;
+        bvhnode *bn = &sc->g_bvh[sc->gb_used++];
+        const float *m = sc->gb_minmax6 + 6 * w[1];
         bn->bb.min = V3(m[0], m[1], m[2]); bn->bb.max = V3(m[3], m[4], m[5]);
         bn->lhs = lhs; bn->rhs = rhs;
         *out = mk_node_hitable(bn);
@@ -1698,23 +1698,13 @@ ora_scene *ora_scene_from_graph_bvh(const uint32_t *records16, uint32_t n_hitabl
                                     const float *materials6, uint32_t n_materials, const float *textures7, uint32_t n_textures,
                                     const float *cam24, int has_sky, const float *sky3, const uint32_t *nodes4, uint32_t n_nodes,
                                     const uint32_t *children, uint32_t n_children, uint32_t root, const float *bvh_minmax6, const int32_t *bvh_lr2, uint32_t n_bvh) {
-    g_bvh_minmax6 = bvh_minmax6, g_bvh_lr2 = bvh_lr2, g_n_bvh = n_bvh, g_n_bvh_used = 0;
-    ora_scene *sc = ora_scene_from_graph(records16, n_hitables, transforms24, n_transforms, materials6, n_materials, textures7, n_textures, cam24, has_sky, sky3,
-                                         nodes4, n_nodes, children, n_children, root);
-    g_bvh_minmax6 = NULL, g_bvh_lr2 = NULL, g_n_bvh = 0;
-    return sc;
-}
-
-ora_scene *ora_scene_from_graph(const uint32_t *records16, uint32_t n_hitables, const float *transforms24, uint32_t n_transforms,
-                                const float *materials6, uint32_t n_materials, const float *textures7, uint32_t n_textures,
-                                const float *cam24, int has_sky, const float *sky3, const uint32_t *nodes4, uint32_t n_nodes,
-                                const uint32_t *children, uint32_t n_children, uint32_t root) {
     if (!nodes4 || !n_nodes || root >= n_nodes) return NULL;
     for (uint32_t i = 0; i < n_hitables; ++i)   /* leaves carry no wrappers: those are nodes */
         if ((int32_t)records16[16 * i + 3] >= 0 || (int32_t)records16[16 * i + 4] >= 0) return NULL;
     ora_scene *sc = ora_scene_from_world(records16, n_hitables, transforms24, n_transforms, materials6, n_materials, textures7, n_textures, cam24,
                                          has_sky, sky3, 0, NULL, NULL, 0);
     if (!sc) return NULL;
+    sc->gb_minmax6 = bvh_minmax6, sc->gb_lr2 = bvh_lr2, sc->gb_n = n_bvh, sc->gb_used = 0;
     /* a node can be reached along several paths (a DAG): size the pools for the expanded tree, bounded */
     const size_t cap = GRAPH_POOL;
     sc->g_instances = calloc(cap, sizeof(instance)); sc->g_media = calloc(cap, sizeof(constant_medium));
@@ -1729,7 +1719,16 @@ ora_scene *ora_scene_from_graph(const uint32_t *records16, uint32_t n_hitables, 
         return NULL;
     }
     sc->world = rooth;   /* scene.rs:19: the world is whatever Hitable the graph's root is */
+    sc->gb_minmax6 = NULL, sc->gb_lr2 = NULL, sc->gb_n = 0;   /* (the caller's arrays are not kept) */
     return sc;
+}
+
+ora_scene *ora_scene_from_graph(const uint32_t *records16, uint32_t n_hitables, const float *transforms24, uint32_t n_transforms,
+                                const float *materials6, uint32_t n_materials, const float *textures7, uint32_t n_textures,
+                                const float *cam24, int has_sky, const float *sky3, const uint32_t *nodes4, uint32_t n_nodes,
+                                const uint32_t *children, uint32_t n_children, uint32_t root) {
+    return ora_scene_from_graph_bvh(records16, n_hitables, transforms24, n_transforms, materials6, n_materials, textures7, n_textures, cam24, has_sky, sky3,
+                                    nodes4, n_nodes, children, n_children, root, NULL, NULL, 0);
 }
 
 void ora_scene_free(ora_scene *s) {
