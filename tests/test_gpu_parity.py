@@ -254,6 +254,25 @@ def test_work_order_from_the_previous_frame_never_changes_a_pixel(ptgpu, pthost,
         assert np.array_equal(runs["reuse"][0], runs[name][0]) and np.array_equal(runs["reuse"][1], runs[name][1])
 
 
+@pytest.mark.parametrize("W,H", [(520, 328), (519, 321), (1000, 264), (264, 1000)])   # 65 x 41, 65 x 41 (ragged edges), 125 x 33, 33 x 125 tiles: odd counts both ways
+def test_checkerboard_measuring_with_odd_tile_counts(ptgpu, pthost, W, H):
+    """The measuring launch of a new view traces one colour of a checkerboard of 8x8 tiles (include/ptgpu.h, tuning bit 262144 = every
+    tile); the list of the measured colour and the neighbour means are indexed by tile row and column. Same frame, same ray count as
+    measuring every tile and as no ordering at all, whatever the parity of the tile grid."""
+    S = 16
+    runs = {}
+    for name, variant in (("checker", 8192), ("all", 8192 | 262144), ("unordered", 32)):
+        hs = pthost.HostScene("random_spheres", W, H, samples=S, device=0)
+        sc = hs.device_scene()
+        sc.set_tuning(0, variant)
+        out = np.zeros((H, W, 3), np.float32)
+        rays = [sc.update(ptgpu.PtParams(W, H, S, 10, 0, 0), hs.camera, f, out) for f in range(2)]
+        assert sc.last_kernel_choice()["name"].startswith("mfma<")
+        runs[name] = (out, rays)
+    for name in ("all", "unordered"):
+        assert runs["checker"][1] == runs[name][1] and np.array_equal(runs["checker"][0], runs[name][0]), name
+
+
 @pytest.mark.parametrize("preset,bvh,W,H,S,frames,depth", [
     ("random_spheres", False, 96, 64, 48, 2, 10),     # 6 144 pixels for 262 144 lanes: nearly every pixel is finished by a worker
     ("random_spheres", True, 96, 64, 48, 1, 10),      # BVH world on the list kernel: the ancestor-AABB gate + DFS-rank ties inside the workers' scan
