@@ -1137,6 +1137,46 @@ def test_scene_graphs_that_do_not_flatten_are_interpreted(ptgpu, oracle, seed):
     assert np.array_equal(ref, out, equal_nan=True), _report(ref, out)
 
 
+def test_interpreted_graph_with_noise_textures_progressive_frames_and_shards(ptgpu, oracle):
+    """The interpreted walk next to the rest of the path: Noise textures on the graph's leaves (coloured where they are hit: the GRAPH
+    instantiation has no lazy form), progressive frames 0..2 blended like scene.rs:113-116, and the multi-GPU decomposition (rows
+    y % 3) of frame 0 stitched back together -- all equal to the oracle's literal recursion."""
+    W, H, S = 96, 66, 3
+    g = _random_graph_world(oracle, 931, W, H, n_top=5, max_depth=4, wild=True)
+    tex = g["textures"].copy()
+    tex[1] = [2, 0, 0, 0, -1, -1, 3.0]
+    tex[5] = [1, 0, 0, 0, 0, 1, 0]
+    g = dict(g, textures=tex)
+    osc = oracle.OracleScene.from_graph(g["hitables"], g["transforms"], g["materials"], g["textures"], g["camera"], W, H, g["nodes"], g["node_children"],
+                                        g["root_node"], sky=g["sky"], bvh_minmax=g["bvh_minmax"], bvh_children=g["bvh_children"])
+    ex = osc.export()
+    materials = [(int(r[0]), r[1:4], r[4], int(r[5])) for r in g["materials"]]
+    textures = [(int(r[0]), r[1:4], int(r[4]), int(r[5]), r[6]) for r in g["textures"]]
+    desc = ptgpu.WorldDesc(g["hitables"], g["transforms"], materials, textures, perlin=ex["perlin"], sky=g["sky"], nodes=g["nodes"], node_children=g["node_children"],
+                           root_node=g["root_node"], bvh_nodes=(g["bvh_minmax"], g["bvh_children"]) if len(g["bvh_minmax"]) else None)
+    sc = ptgpu.Scene(desc, 0)
+    p, cam = ptgpu.PtParams(W, H, S, 10, 0, 0), ptgpu.PtCamera.from_floats(g["camera"])
+    out, ref, total, ref_total = np.zeros((H, W, 3), np.float32), np.zeros((H, W, 3), np.float32), 0, 0
+    for frame in range(3):
+        total += sc.update(p, cam, frame, out)
+        ref, n = osc.update(S, max_depth=10, frame_num=frame, buffer=ref)   # (blends into the buffer as Scene::update does)
+        ref_total += n
+        if frame == 0:
+            frame0 = out.copy()
+    assert sc.last_kernel_choice()["world_graph"] == 1 and total == ref_total
+    np.testing.assert_allclose(out, ref, rtol=0, atol=NOISE_ATOL)
+    import torch
+    rc = torch.zeros(1, dtype=torch.int64, device="cuda")
+    stitched = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    for r in range(3):
+        shard = torch.zeros((ptgpu.shard_rows(H, r, 3), W, 3), dtype=torch.float32, device="cuda")
+        sc.update_shard_device(p, cam, 0, r, 3, shard.data_ptr(), rc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        stitched[r::3] = shard
+    sc.close()
+    assert np.array_equal(stitched.cpu().numpy(), frame0, equal_nan=True)
+
+
 def test_the_interpreted_graphs_of_the_test_above_cover_every_nesting(ptgpu, oracle):
     """(what the seeds above contain: a medium around a List, around another medium, around a BVHNode; a BVHNode under an Instance)"""
     seen = set()
