@@ -1305,6 +1305,19 @@ namespace ptdev {
 // BLK: threads per workgroup. 256 (three workgroups per CU) everywhere except the MFMA list kernels, which run ONE
 // 768-thread workgroup per CU when the scene allows: the sphere fragments are then staged once per CU instead of three
 // times, and the LDS that frees holds the per-lane attenuation stacks (no HBM traffic for them).
+//
+// MAP of the kernel body (search for the quoted banner):
+//   prologue      LDS carve, staging of tables / fragments / frame parameters, per-lane state
+//   main loop, one trip = one ray per live lane ("for (;;)"), its ONLY exit at the very end:
+//     "---- refill"                 finished pixels are written, free lanes claim pixels (batched), parked streams are reloaded
+//     "TAIL: once the list is dry"  a look into one other wave's mailbox (pt_coop.h), read at the end of the trip
+//     "---- camera.rs:56-68"        next sample's camera ray + the sphere draws a Metal scatter still owes, one shared rejection loop
+//     "---- hitable.rs:39-65"       closest hit: 4-wide tree (bvh4_run) | binary tree | MFMA prefilter + balanced exact tests | exact scan
+//     "---- scene.rs:49-71"         one level of ray_trace: material, scatter, attenuation push; on termination fold + sample count
+//     "Hand-over (pt_coop.h)"       a pixel between two samples goes to an idle worker
+//   epilogue      the wave retires or becomes a worker (coop_worker), ray count reduction, development counters
+// The stages share ~40 loop-carried registers per lane and are kept in one function body on purpose: every attempt to carry that state
+// through a struct or across call boundaries has cost registers in a kernel that lives at its 128-VGPR limit (NOTES.md).
 #ifdef PT_BBPROF   // tools/bbprof.py: the instrumented assembly keeps its counter registers above the compiler's
 #include "pt_bbprof.h"
 #define PT_BBPROF_ATTR __attribute__((amdgpu_num_sgpr(100)))
