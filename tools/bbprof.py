@@ -25,6 +25,8 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-I../include", "-Icsrc",
          "-I/opt/rocm/include", "-DPT_BBPROF"]
 UNIT = os.environ.get("BBPROF_UNIT", "pt_kernels_list")   # pt_kernels_list | pt_kernels_gate | pt_kernels_tree | pt_kernels_world
+if UNIT in ("pt_kernels_list", "pt_kernels_tree"):   # (as pathtrace-rs_amd/Makefile builds these two units)
+    FLAGS += ["-mllvm", "-amdgpu-use-amdgpu-trackers"]
 
 
 def sh(cmd, **kw):
