@@ -118,10 +118,11 @@ __device__ __forceinline__ bool w_rect_t(uint32_t axis, float a0, float a1, floa
     float ok, rk, oa, da, ob, db;
     w_rect_axes(axis, r, ok, rk, oa, da, ob, db);
     const float t = (k - ok) * rk;
-    if (t < t_min || t > t_max) return false;
     const float a = oa + t * da;
     const float b = ob + t * db;
-    if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+    // (one block, no branch between the range test and the rectangle test: the same comparisons, combined without short-circuit)
+    const bool miss = (t < t_min) | (t > t_max) | (a < a0) | (a > a1) | (b < b0) | (b > b1);
+    if (miss) return false;
     t_out = t;
     return true;
 }
