@@ -224,6 +224,12 @@ def report(argv):
             top = sorted(b["lines"].items(), key=lambda kv: -kv[1])[:5]
             print("   %5.2f%%  %-11s runs %.3g x (valu %d salu %d lds %d mfma %d)  %s" % (100.0 * dv / tot["valu"], b["label"], n, b["valu"], b["salu"], b["lds"], b["mfma"],
                                                                                     " ".join("%s(%d)" % (a.replace("pt_kernel.h", "k").replace("pt_device.h", "d").replace("__clang_hip_math.h", "m"), c) for a, c in top)))
+        print("   -- blocks by dynamic v_readlane / v_writelane / v_readfirstlane (SGPR spill traffic and wave-uniform reads)")
+        for dl, n, b in sorted(((r[1] * r[2].get("lanes", 0), r[1], r[2]) for r in rows[k]), key=lambda r: -r[0])[:25]:
+            if not dl: break
+            top = sorted(b["lines"].items(), key=lambda kv: -kv[1])[:4]
+            print("   %5.2f%%  %-11s runs %.3g x %d of valu %d  %s" % (100.0 * dl / max(tot["lanes"], 1), b["label"], n, b["lanes"], b["valu"],
+                                                                  " ".join("%s(%d)" % (a.replace("pt_kernel.h", "k").replace("pt_device.h", "d").replace("pt_coop.h", "c"), c) for a, c in top)))
         print("   -- source lines by dynamic VALU (innermost inlined location)")
         for ln, c in lines[k].most_common(60):
             print("   %5.2f%%  %s" % (100.0 * c / tot["valu"], ln))
