@@ -273,6 +273,34 @@ def test_checkerboard_measuring_with_odd_tile_counts(ptgpu, pthost, W, H):
         assert runs["checker"][1] == runs[name][1] and np.array_equal(runs["checker"][0], runs[name][0]), name
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_work_order_on_seeded_worlds_at_random_frame_sizes(ptgpu, oracle, seed):
+    """A slice of tools/order_soak.py: seeded sphere worlds (list and BVH, 40-700 spheres) at random frame sizes and sample counts
+    (>= 12: the two-launch path of scene.rs:73-121's frame) -- checkerboard measuring, every tile measured, natural order and the
+    hand-over switched off produce the same two progressive frames and ray counts."""
+    ob = oracle
+    rng = np.random.default_rng(seed)
+    W, H, S = int(rng.integers(200, 900)), int(rng.integers(150, 700)), int(rng.choice([12, 13, 16, 24, 40]))
+    n = int(rng.choice([40, 150, 400, 700]))
+    bvh = seed % 3 == 0
+    w = _random_sphere_world(ob, seed, n, W, H, float(rng.uniform(3, 12)), float(rng.uniform(0.2, 1.0)))
+    osc = ob.OracleScene.from_world(w["hitables"], w["transforms"], w["materials"], w["textures"], w["camera"], W, H, sky=w["sky"], use_bvh=bvh)
+    ex = osc.export()
+    frames, ordered = {}, 0
+    for variant in (8192, 8192 | 262144, 32, 8192 | 65536):
+        sc = ptgpu.Scene(ob.to_ptgpu_world_desc(ptgpu, ex), 0)
+        sc.set_tuning(0, variant)
+        out = np.zeros((H, W, 3), np.float32)
+        rays = [sc.update(ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0), ptgpu.PtCamera.from_floats(ex["camera"]), f, out) for f in range(2)]
+        ordered += int(bool(sc.last_kernel_choice()["ordered"]))
+        sc.close()
+        frames[variant] = (out, rays)
+    osc.close()
+    assert ordered == 3   # (tuning 32 is the natural order)
+    for v, (out, rays) in frames.items():
+        assert rays == frames[32][1] and np.array_equal(out, frames[32][0], equal_nan=True), v
+
+
 @pytest.mark.parametrize("preset,bvh,W,H,S,frames,depth", [
     ("random_spheres", False, 96, 64, 48, 2, 10),     # 6 144 pixels for 262 144 lanes: nearly every pixel is finished by a worker
     ("random_spheres", True, 96, 64, 48, 1, 10),      # BVH world on the list kernel: the ancestor-AABB gate + DFS-rank ties inside the workers' scan
