@@ -70,8 +70,17 @@ def cpu_baseline(preset, W, H, S, depth, use_bvh, target_secs=15.0):
     _, rays = sc.update(S, depth, 0, buffer=buf, nthreads=cores, pixels=px)
     dt = time.perf_counter() - t0
     value = rays / 1e6 / dt
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": value, "unit": "Mrays/s", "cores": cores, "kind": "port",
+        "cpu_model": model, "nproc": os.cpu_count(), "threads": cores,
         "one_thread": rate1, "speedup_over_one_thread": value / rate1 if rate1 > 0 else None,
         "sample": "%d of %d pixels (every %dth) of %s %dx%d %dspp depth %d, %d rays in %.1fs, "
                   "oracle/ptref.c -O3 -march=native -ffp-contract=off, %d pthreads (one thread alone: %.2f Mrays/s, "
@@ -361,18 +370,17 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0].item()), float(t[1].item()), float(t[2].item()), int(state["last"]["rays"].item())  # rays already summed over ranks
 
-    elapsed, kms, pms, rays_per_step = timed(args.mode, S, args.steps, args.warmup)
-    total_rays = rays_per_step * args.steps
-    value = total_rays / 1e6 / elapsed
-    ms_per_step = elapsed / args.steps * 1e3
-    rays_this_launch = int(sets[0]["rays"].item()) if not multi else rays_per_step / N   # tiles: ~1/N of the frame's rays per rank
-
-    if multi and os.environ.get("PT_BENCH_CHECK") == "1":
-        # self-check of the pipelined / sharded path: its last frame must equal this rank's own full render, bit for bit
-        for _ in range(3):
+    self_check = None
+    if multi and os.environ.get("PT_BENCH_CHECK", "1") != "0":
+        # Untimed, before the warm-up, on EVERY multi-rank run: the frame the sharded / pipelined path delivers on this rank must equal
+        # this rank's own unsharded render bit for bit, and the all-reduced ray count the unsharded frame's (scene.rs:90-93, 118-120).
+        # The first run on a multi-GPU node is thereby also the first evidence for pt_comm.hip on real RCCL with more than one rank;
+        # a mismatch on any rank ends the run with a non-zero exit code and no bench line.
+        for _ in range(len(sets) + 1):       # (every buffer set of the pipeline has carried a frame)
             step(args.mode, S)
         fence()
         got = state["frame"].clone()
+        got_rays = int(state["last"]["rays"].item())
         ref_full = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
         rc2 = torch.zeros(1, dtype=torch.int64, device=dev)
         if args.mode == "tiles":
@@ -384,9 +392,32 @@ def main():
             torch.cuda.synchronize()
             want = sharding.gather_progressive(dist, ref_full, torch.empty((N, H, W, 3), dtype=torch.float32, device=dev), rc2)
             torch.cuda.synchronize()
-        assert torch.equal(got, want) and int(rc2.item()) == int(state["last"]["rays"].item()), "sharded frame differs from the single-GPU frame"
+        same = bool(torch.equal(got, want)) and int(rc2.item()) == got_rays
+        flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not same:
+            diff = (got != want).any(dim=-1)
+            print("[bench check] rank %d: %s frame over %d rank(s) DIFFERS from this rank's own unsharded frame: %d pixels, rays %d vs %d"
+                  % (rank, args.mode, N, int(diff.sum().item()), got_rays, int(rc2.item())), file=sys.stderr)
+        if int(flag.item()) != 1:
+            if comm is not None:
+                comm.close()
+            dist.barrier()
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        self_check = {"sharded_equals_single": True, "ranks_seen": comm.world if comm is not None else N, "rays": got_rays,
+                      "rccl": rccl_info.get("version_code") if rccl_info else None,
+                      "note": "untimed, before the warm-up: the gathered frame on every rank == that rank's own unsharded render, bit for bit, "
+                              "and the all-reduced ray count == the unsharded frame's; a mismatch on any rank exits non-zero"}
         if rank == 0:
-            print("[bench check] %s frame over %d rank(s) == single-GPU frame, %d rays" % (args.mode, N, int(rc2.item())), file=sys.stderr)
+            print("[bench check] %s frame over %d rank(s) == single-GPU frame on every rank, %d rays" % (args.mode, N, got_rays), file=sys.stderr)
+        state["k"] = 0
+
+    elapsed, kms, pms, rays_per_step = timed(args.mode, S, args.steps, args.warmup)
+    total_rays = rays_per_step * args.steps
+    value = total_rays / 1e6 / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    rays_this_launch = int(sets[0]["rays"].item()) if not multi else rays_per_step / N   # tiles: ~1/N of the frame's rays per rank
 
     other = None
     if multi and not args.no_extras:   # the other decomposition, reported beside the main value
@@ -522,6 +553,40 @@ def main():
             elo = (time.perf_counter() - t0) / 3.0
             other_workloads[name] = {"value": int(ro.item()) / 1e6 / elo, "unit": "Mrays/s", "ms_per_frame": elo * 1e3, "kernel": so.last_kernel_choice()["name"]}
             del so, ho
+    baseline_configs = None
+    if not multi and not args.no_extras and args.preset == "random_spheres" and (W, H, S) == (1200, 800, 64) and not args.bvh:
+        # Extra, never `value`: the other BASELINE.json configurations on this one GPU, each at ITS frame size -- config 2 (aras
+        # 1280x720x16), config 4's frame (random_spheres 1200x800x256; the multi-GPU run shards it) and config 5 (perlin_spheres,
+        # 10 002 spheres, BVH, 1920x1080x128): one warm-up + three timed frames of a never-seen view each (bit 8192), the frame kernel's
+        # own time from HIP events, and the same counter-derived sub-block as the headline where a committed profile matches.
+        baseline_configs = {}
+        for name, preset, bw, bh, bs, bvh in (("config 2: aras 1280x720 16spp", "aras", 1280, 720, 16, False),
+                                              ("config 4 on one GPU: random_spheres 1200x800 256spp", "random_spheres", 1200, 800, 256, False),
+                                              ("config 5: perlin_spheres 1920x1080 128spp BVH", "perlin_spheres", 1920, 1080, 128, True)):
+            ho = pthost.HostScene(preset, bw, bh, samples=bs, use_bvh=bvh, device=local_rank)
+            so = ho.device_scene()
+            so.set_tuning(0, base_variant | 8192)
+            po = ptgpu.PtParams(bw, bh, bs, depth, 0, 1 if bvh else 0)
+            bo = torch.zeros((bh, bw, 3), dtype=torch.float32, device=dev)
+            ro = torch.zeros(1, dtype=torch.int64, device=dev)
+            so.update_device(po, ho.camera, 0, bo.data_ptr(), ro.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            nf, kms_o = 3, []
+            t0 = time.perf_counter()
+            for _ in range(nf):
+                bo.zero_()
+                so.update_device(po, ho.camera, 0, bo.data_ptr(), ro.data_ptr(), stream.cuda_stream)
+                kms_o.append(so.last_kernel_ms())     # (waits for the frame: these frames are timed one by one)
+            torch.cuda.synchronize()
+            elo = (time.perf_counter() - t0) / nf
+            rays_o = int(ro.item())
+            ent = {"value": rays_o / 1e6 / elo, "unit": "Mrays/s", "ms_per_frame": elo * 1e3, "frames": nf, "rays_per_frame": rays_o,
+                   "kernel": so.last_kernel_choice()["name"], "hitables": ho.world_desc.n_hitables}
+            cnt = committed_counters(preset, bw, bh, bs, bvh)
+            if cnt is not None:
+                ent["roofline"] = roofline_block("pt_trace_kernel", sum(kms_o) / nf, float(rays_o), ho.world_desc.n_hitables, bvh, cnt)
+            baseline_configs[name] = ent
+            del so, ho, bo
     if rank == 0:
         grid, block, lds = scene.last_launch_info()
         tiles = multi and args.mode == "tiles"
@@ -570,6 +635,11 @@ def main():
             out["progressive_view"] = progressive
         if other_workloads is not None:
             out["other_workloads_same_frame_size"] = other_workloads
+        if baseline_configs is not None:
+            out["baseline_configs"] = baseline_configs
+        if self_check is not None:
+            out["self_check"] = self_check
+            out["config"]["sharded_equals_single"] = True
         if N == 1 and not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.preset, W, H, S, depth, args.bvh, args.cpu_secs)
         print(json.dumps(out))

@@ -156,6 +156,7 @@ int comm_ensure(pt_comm *c, uint32_t width, uint32_t height, hipStream_t stream)
     c->slot_valid = false;
     HIP_TRY(hipMalloc((void **)&c->d_gather, need * sizeof(float)));
     HIP_TRY(hipMemsetAsync(c->d_gather, 0, need * sizeof(float), stream));   // ranks with one row less send a zero row
+    HIP_TRY(hipStreamSynchronize(stream));   // (once per growth: a later call may bring ANOTHER stream, which nothing would order behind this memset)
     c->gather_floats = need;
     return PT_OK;
 }
@@ -201,26 +202,36 @@ int comm_exchange(pt_comm *c, uint32_t width, uint32_t height, float *d_rgb_full
     return comm_unpack(c, width, height, d_rgb_full, root, stream);
 }
 
-// checks shared by the one-rank and the all-ranks forms of pt_render_sharded; prepares the rank's slot and enqueues its render
-int sharded_render_one(pt_scene *s, pt_comm *c, const pt_params *params, const pt_camera *cam, uint32_t frame_num, float *d_rgb_full_inout, uint64_t *d_ray_count,
-                       int root, hipStream_t stream) {
+// Argument checks of one rank of pt_render_sharded[_all], nothing enqueued: the all-ranks form runs them for EVERY rank before the
+// first render goes out (a rank failing in mid-loop would leave the ranks before it rendered for a frame that is never exchanged).
+// The blend reads the previous frame (scene.rs:114-116): this rank's rows. After an all-gather every rank's full buffer is
+// current, and they are packed out of it. A rank that does NOT receive the frame (root >= 0, another rank) has a stale
+// buffer; its gather slot still holds exactly the rows it rendered for the frame before, so those are kept instead.
+int sharded_check_one(const pt_scene *s, const pt_comm *c, const pt_params *params, uint32_t frame_num, const float *d_rgb_full_inout, const uint64_t *d_ray_count,
+                      int root, bool *keep_slot_out) {
     if (!s || !c || !d_ray_count) return fail(PT_ERR_INVALID_ARG, "NULL argument");
     if (s->device != c->device) return fail(PT_ERR_INVALID_ARG, "scene lives on device %d, communicator on %d", s->device, c->device);
     if (root >= (int)c->world) return fail(PT_ERR_INVALID_ARG, "root %d out of range (%u ranks)", root, c->world);
+    const bool receives = root < 0 || (uint32_t)root == c->rank;
+    if (receives && !d_rgb_full_inout) return fail(PT_ERR_INVALID_ARG, "d_rgb_full_inout is NULL on a rank that receives the frame");
+    const bool slot_is_previous = c->slot_valid && frame_num > 0 && c->slot_frame + 1u == frame_num && c->slot_w == params->width && c->slot_h == params->height;
+    const bool keep = slot_is_previous && !receives;
+    if (!keep && !d_rgb_full_inout) return fail(PT_ERR_INVALID_ARG, "d_rgb_full_inout is NULL and the communicator does not hold this rank's previous rows");
+    if (keep_slot_out) *keep_slot_out = keep;
+    return PT_OK;
+}
+
+// prepares the rank's slot and enqueues its render (shared by the one-rank and the all-ranks forms of pt_render_sharded)
+int sharded_render_one(pt_scene *s, pt_comm *c, const pt_params *params, const pt_camera *cam, uint32_t frame_num, float *d_rgb_full_inout, uint64_t *d_ray_count,
+                       int root, hipStream_t stream) {
+    bool keep_slot = false;
+    if (int rc = sharded_check_one(s, c, params, frame_num, d_rgb_full_inout, d_ray_count, root, &keep_slot)) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (int rc = comm_ensure(c, params->width, params->height, stream)) return rc;
     const uint32_t prow = (params->height + c->world - 1) / c->world;
     float *slot = c->d_gather + (size_t)c->rank * prow * params->width * 3u;
-    // The blend reads the previous frame (scene.rs:114-116): this rank's rows. After an all-gather every rank's full buffer is
-    // current, and they are packed out of it. A rank that does NOT receive the frame (root >= 0, another rank) has a stale
-    // buffer; its gather slot still holds exactly the rows it rendered for the frame before, so those are kept instead.
-    const bool receives = root < 0 || (uint32_t)root == c->rank;
-    if (receives && !d_rgb_full_inout) return fail(PT_ERR_INVALID_ARG, "d_rgb_full_inout is NULL on a rank that receives the frame");
-    const bool slot_is_previous = c->slot_valid && frame_num > 0 && c->slot_frame + 1u == frame_num && c->slot_w == params->width && c->slot_h == params->height;
-    if (!(slot_is_previous && !receives)) {
-        if (!d_rgb_full_inout) return fail(PT_ERR_INVALID_ARG, "d_rgb_full_inout is NULL and the communicator does not hold this rank's previous rows");
+    if (!keep_slot)
         if (int rc = pt_shard_pack(d_rgb_full_inout, slot, params->width, params->height, c->rank, c->world, stream)) return rc;
-    }
     c->slot_valid = false;
     if (int rc = launch(s, params, cam, frame_num, c->rank, c->world, slot, d_ray_count, stream)) return rc;
     c->slot_valid = true, c->slot_frame = frame_num, c->slot_w = params->width, c->slot_h = params->height;
@@ -405,9 +416,17 @@ extern "C" int pt_render_sharded_all(pt_scene *const *scenes, pt_comm *const *co
     if (params->width == 0 || params->height == 0 || params->samples == 0) return fail(PT_ERR_INVALID_ARG, "width/height/samples must be non-zero");
     if (root >= (int)n) return fail(PT_ERR_INVALID_ARG, "root %d out of range (%u ranks)", root, n);
     const auto stream_of = [&](uint32_t i) { return reinterpret_cast<hipStream_t>(hip_streams ? hip_streams[i] : nullptr); };
+    // every rank's arguments are checked before anything is enqueued for any of them
+    for (uint32_t i = 0; i < n; ++i)
+        if (int rc = sharded_check_one(scenes[i], comms[i], params, frame_num, d_rgb_full_inout[i], d_ray_counts[i], root, nullptr)) return rc;
     // every rank's pack + render first (nothing here waits for a peer), then ALL ranks' collectives inside one group, then the unpacks
     for (uint32_t i = 0; i < n; ++i)
-        if (int rc = sharded_render_one(scenes[i], comms[i], params, cam, frame_num, d_rgb_full_inout[i], d_ray_counts[i], root, stream_of(i))) return rc;
+        if (int rc = sharded_render_one(scenes[i], comms[i], params, cam, frame_num, d_rgb_full_inout[i], d_ray_counts[i], root, stream_of(i))) {
+            // (a launch failure in mid-loop: the ranks before this one rendered a frame that will not be exchanged -- their slots hold no
+            //  frame the next call may build on)
+            for (uint32_t j = 0; j < n; ++j) comms[j]->slot_valid = false;
+            return rc;
+        }
     if (int rc = comm_grouped(comms[0]->R, n, [&](uint32_t i) {
             (void)hipSetDevice(comms[i]->device);
             return comm_post(comms[i], params->width, params->height, d_ray_counts[i], root, stream_of(i));

@@ -383,6 +383,10 @@ __device__ __forceinline__ void coop_worker(const KArgs &A, const GateSrc &G, co
             nap = nap < 4u ? nap * 2u : 4u;
         }
         if (kind == 2u) return;
+        // The payload loads below must stay BEHIND the load that saw PIXEL. The hardware keeps them there (the writer drained its
+        // write-through payload stores before it stored the flag, and a wave's vector loads of one kind return in order); the compiler is
+        // told here: relaxed atomics to different addresses are otherwise only held back by the branch above, which it need not honour.
+        asm volatile("" ::: "memory");
         if (!loaded) coop_load_spheres(mine, sph, A.n_spheres), loaded = true;
         coop_trace_pixel<MOVING, GATED>(A, G, mot, s_par, mine, s_shade, pn, box, wave_rays);
     }

@@ -300,6 +300,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         return fail(PT_ERR_UNSUPPORTED, "sphere kernels take max_depth < 4096, samples < 2^20");
     if (shard_count == 0 || shard_index >= shard_count) return fail(PT_ERR_INVALID_ARG, "bad shard %u/%u", shard_index, shard_count);
     if (params->use_bvh && s->bvh_root < 0) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the scene was created without BVH nodes");
+    // (an interpreted scene graph's BVHNode rows are part of the graph, not a tree over the world: the same refusal as pt_debug_select's)
+    if (params->use_bvh && !s->tr.has_caller_bvh) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the description has no BVH nodes");
     HIP_TRY(hipSetDevice(s->device));
 
     // ---- which kernel, which geometry (pt_select.h) ----

@@ -1029,6 +1029,11 @@ void world_traits(const pt_world_desc *desc, const WorldAsSpheres &w, ptsel::Sce
     tr.atts_finite = true;
     for (uint32_t i = 0; i < desc->n_materials; ++i)
         for (int c = 0; c < 3; ++c) tr.atts_finite = tr.atts_finite && std::isfinite(desc->materials[i].albedo[c]);
+    // (pt_scene.hip folds a Lambertian / Isotropic material's Constant texture into its record, and the kernel's colour() returns that
+    //  colour without looking at it: an infinite Constant colour anywhere switches the shortcut off for the whole world as well)
+    for (uint32_t i = 0; i < desc->n_textures; ++i)
+        if (desc->textures[i].kind == PT_TEX_CONSTANT)
+            for (int c = 0; c < 3; ++c) tr.atts_finite = tr.atts_finite && std::isfinite(desc->textures[i].color[c]);
     // texture.rs:86-88: 0.5 (1 + sin(scale p.z + 10 turb(p))) is finite where its argument is (pt_args.h kLazyNoise*: bounds on the scale
     // and on the Perlin gradients here, on the point in the kernel)
     tr.noise_finite = tr.atts_finite && (!w.has_noise || desc->perlin != nullptr);

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Full-frame evidence for BASELINE config 5 (perlin_spheres, 10 002 spheres, BVH world, 1920x1080x128).
+
+The oracle walks the reference's own tree (bvh.rs:37-62: both children, original t_max; ~3 700 node visits per ray on
+this scene), so the whole frame costs ~19 core-hours. This script renders it in row blocks, keeps every block's ray
+count in a work directory (resumable: finished blocks are skipped), and writes
+    tests/golden/c5_perlin_spheres_1920x1080_128spp_fullframe_bvh.npz
+with the FULL frame's ray count (scene.rs:118-120), the ray count of every block of rows, and every 2 003rd pixel's colour.
+    nice -n 19 python tests/golden/make_c5_fullframe.py [--threads 8] [--work /tmp/c5_fullframe]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_binding as ob  # noqa: E402
+
+W, H, S, DEPTH, ROWS, STRIDE = 1920, 1080, 128, 10, 8, 2003
+NAME = "c5_perlin_spheres_1920x1080_128spp_fullframe_bvh"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--work", default="/tmp/c5_fullframe")
+    a = ap.parse_args()
+    os.makedirs(a.work, exist_ok=True)
+    sc = ob.OracleScene("perlin_spheres", W, H, use_bvh=True)
+    sampled = np.arange(0, W * H, STRIDE, dtype=np.uint32)
+    for b in range(H // ROWS):
+        out = os.path.join(a.work, "block_%03d.npz" % b)
+        if os.path.exists(out):
+            continue
+        pixels = np.arange(b * ROWS * W, (b + 1) * ROWS * W, dtype=np.uint32)
+        buf = np.zeros((H, W, 3), np.float32)
+        _, rays = sc.update(S, DEPTH, 0, buffer=buf, nthreads=a.threads, pixels=pixels)
+        mine = sampled[(sampled >= pixels[0]) & (sampled <= pixels[-1])]
+        np.savez(out + ".tmp.npz", rays=np.uint64(rays), pixels=mine, rgb=buf.reshape(-1, 3)[mine])
+        os.replace(out + ".tmp.npz", out)
+        print("block", b, "rays", rays, flush=True)
+    blocks = [np.load(os.path.join(a.work, "block_%03d.npz" % b)) for b in range(H // ROWS)]
+    block_rays = np.array([int(g["rays"]) for g in blocks], np.uint64)
+    pixels = np.concatenate([g["pixels"] for g in blocks]).astype(np.uint32)
+    rgb = np.concatenate([g["rgb"] for g in blocks]).astype(np.float32)
+    assert np.array_equal(pixels, sampled)
+    np.savez_compressed(os.path.join(HERE, NAME + ".npz"), preset="perlin_spheres", width=W, height=H, samples=S, depth=DEPTH,
+                        use_bvh=True, pixels=pixels, rgb=rgb, ray_count=np.uint64(block_rays.sum()), block_rows=ROWS,
+                        block_rays=block_rays)
+    print(NAME, "rays", int(block_rays.sum()), "sampled pixels", len(pixels), "mean", rgb.mean(axis=0))
+
+
+if __name__ == "__main__":
+    main()

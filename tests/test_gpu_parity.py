@@ -649,6 +649,23 @@ def test_communicators_from_a_device_list_and_side_by_side(ptgpu, pthost):
             sc.update_sharded(c, p, hs.camera, f, outs[id(c)].data_ptr(), rc.data_ptr(), root, stream)
             torch.cuda.synchronize()
             assert int(rc.item()) == int(rc_ref.item()) and torch.equal(outs[id(c)], ref), "frame %d root %d" % (f, root)
+    # the grouped forms (all ranks of a clique from one thread: ncclGroupStart, every rank's posts, ncclGroupEnd, unpacks on the ranks'
+    # streams) through the REAL library with the one rank a 1-GPU box has -- the mock behind tests/mock_rccl never blocks the host
+    full = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    ref.zero_()                                          # (it holds frames 0..2 blended: start over)
+    for f, root in ((0, -1), (1, 0), (2, -1)):
+        sc.update_device(p, hs.camera, f, ref.data_ptr(), rc_ref.data_ptr(), stream)
+        ptgpu.render_sharded_all([sc], [a], p, hs.camera, f, [full.data_ptr()], [rc.data_ptr()], root=root, streams=[stream])
+        torch.cuda.synchronize()
+        assert int(rc.item()) == int(rc_ref.item()) and torch.equal(full, ref), "render_sharded_all frame %d root %d" % (f, root)
+    shard = ref.clone()                                  # one rank owns every row: its compact shard IS the frame
+    full.zero_()
+    rc.fill_(12345)
+    ptgpu.gather_frame_all([a], W, H, [shard.data_ptr()], [full.data_ptr()], [rc.data_ptr()], root=0, streams=[stream])
+    torch.cuda.synchronize()
+    assert int(rc.item()) == 12345 and torch.equal(full, ref)
+    with pytest.raises(ptgpu.PtError):                   # a NULL frame on the receiving rank is refused BEFORE anything is enqueued
+        ptgpu.render_sharded_all([sc], [a], p, hs.camera, 3, [0], [rc.data_ptr()], root=0, streams=[stream])
     a.close()
     b.close()
     with pytest.raises(ptgpu.PtError):
@@ -1054,19 +1071,24 @@ def test_noise_colours_formed_at_the_end_of_a_path_equal_those_formed_at_the_hit
 
 
 @pytest.mark.parametrize("bvh", [False, True])
-def test_a_non_finite_colour_keeps_the_fold_of_a_dark_path(ptgpu, oracle, bvh):
+@pytest.mark.parametrize("where", ["albedo", "texture", "both"])
+def test_a_non_finite_colour_keeps_the_fold_of_a_dark_path(ptgpu, oracle, bvh, where):
     """scene.rs:62-64 multiplies a path that ended in black by each of its attenuations: zero for finite colours (the general-world
-    kernel then skips the loop), NaN as soon as one of them is infinite -- the kernel must notice (WArgs::atts_finite)."""
+    kernel then skips the loop), NaN as soon as one of them is infinite -- the kernel must notice (WArgs::atts_finite). The two places
+    an infinite colour can sit are exercised apart: a Metal's albedo (pt_material.albedo), and a Constant texture under a Lambertian,
+    which pt_scene_create folds into the material record where the kernel's colour() never looks at it again."""
     W, H, S = 96, 64, 4
     w = _random_world(oracle, 21, 14, (0, 2, 3, 4, 5), W, H, sky=(0.0, 0.0, 0.0))
     mats = w["materials"].copy()
-    mats[6, 1] = np.inf                       # the first Metal's red albedo
     tex = w["textures"].copy()
-    tex[2, 2] = np.inf                        # a Constant texture's green, under a Lambertian
+    if where in ("albedo", "both"):
+        mats[6, 1] = np.inf                   # the first Metal's red albedo
+    if where in ("texture", "both"):
+        tex[2, 2] = np.inf                    # a Constant texture's green, under a Lambertian
     w = dict(w, materials=mats, textures=tex)
     out, rays, ref, ref_rays = _render_world_both(ptgpu, oracle, w, W, H, S, bvh)
     assert rays == ref_rays
-    assert np.isnan(ref).any(), "the fixture no longer sends a dark path over the infinite colours"
+    assert np.isnan(ref).any(), "the fixture no longer sends a dark path over the infinite colour"
     assert np.array_equal(np.isnan(ref), np.isnan(out)) and np.array_equal(np.nan_to_num(ref, nan=-1.0), np.nan_to_num(out, nan=-1.0)), _report(ref, out)
 
 
@@ -1193,6 +1215,10 @@ def test_interpreted_graph_with_noise_textures_progressive_frames_and_shards(ptg
             frame0 = out.copy()
     assert sc.last_kernel_choice()["world_graph"] == 1 and total == ref_total
     np.testing.assert_allclose(out, ref, rtol=0, atol=NOISE_ATOL)
+    # `-B` over an interpreted graph is refused by the render call itself, not only by pt_debug_select (the graph's BVHNode rows are
+    # nodes of the graph, not a tree over the world) -- and the refusal leaves the scene usable
+    with pytest.raises(ptgpu.PtError, match="no BVH nodes"):
+        sc.update(ptgpu.PtParams(W, H, S, 10, 0, 1), cam, 0, np.zeros((H, W, 3), np.float32))
     import torch
     rc = torch.zeros(1, dtype=torch.int64, device="cuda")
     stitched = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
@@ -1725,11 +1751,13 @@ def test_device_pow5_vs_host_powf_mismatch_rate(ptgpu, oracle):
 
 def test_bench_sharded_path_self_check():
     """bench.py's N > 1 path (BASELINE config 4 through pt_comm_gather_frame, three buffer sets, exchange on a second stream)
-    on the one rank a 1-GPU box can form, at a reduced sample count: PT_BENCH_CHECK makes the script assert that the gathered
-    frame equals the rank's own full render bit for bit; the JSON line must say strong scaling and carry the roofline block."""
+    on the one rank a 1-GPU box can form, at a reduced sample count: every multi-rank run first checks, untimed, that the gathered
+    frame equals the rank's own full render bit for bit (and says so in its line; a mismatch exits non-zero); the JSON line must say
+    strong scaling and carry the roofline block."""
     import json
     import subprocess
-    env = dict(os.environ, PT_BENCH_FORCE_DIST="1", PT_BENCH_CHECK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env = dict(os.environ, PT_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env.pop("PT_BENCH_CHECK", None)   # (the check is on by default)
     for extra, spp in (([], "16"), (["--no-overlap"], "8")):   # (16 spp: the shard renders as two launches; 8: as one)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--samples", spp,
                               "--no-extras", "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True, timeout=600)
@@ -1738,6 +1766,8 @@ def test_bench_sharded_path_self_check():
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
         assert d["scaling"] == "strong" and d["unit"] == "Mrays/s" and d["value"] > 0 and "roofline" in d
+        assert d["self_check"]["sharded_equals_single"] is True and d["self_check"]["ranks_seen"] == 1 and d["self_check"]["rccl"] >= 21000
+        assert d["self_check"]["rays"] == d["config"]["rays_per_step"] and d["config"]["sharded_equals_single"] is True
         assert "split by rows" in d["config"]["workload"]
 
 
@@ -1760,4 +1790,10 @@ def test_bench_default_line_keeps_the_contract():
     for key in ("host_contract", "pipelined_frames", "progressive_view"):
         assert d[key]["value"] > 0 and d[key]["unit"] == "Mrays/s"
     assert d["host_contract"]["reused_buffer"]["value"] > 0 and d["host_contract"]["registered"]["value"] > 0 and "value_note" in d
+    # every BASELINE.json configuration that fits one GPU is in the driver-timed line, at its own frame size
+    bc = d["baseline_configs"]
+    assert len(bc) == 3 and all(v["value"] > 0 and v["frames"] >= 3 and v["unit"] == "Mrays/s" for v in bc.values())
+    assert bc["config 4 on one GPU: random_spheres 1200x800 256spp"]["rays_per_frame"] > 4 * 162000000
+    c5 = bc["config 5: perlin_spheres 1920x1080 128spp BVH"]
+    assert c5["hitables"] == 10002 and 0.0 < c5["roofline"]["frac"] <= 1.0
 

@@ -509,7 +509,7 @@ def test_scene_graph_nestings_the_list_form_cannot_hold_are_interpreted_and_malf
     assert time.time() - t0 < 20.0
 
 
-def test_committed_kernel_resource_table_shows_no_spill():
+def test_committed_kernel_resource_table_keeps_registers_and_spills_within_the_stated_bounds():
     """profiles/r04_kernel_resources.txt (`make -C pathtrace-rs_amd resources`: hipcc -Rpass-analysis=kernel-resource-usage on the
     four kernel translation units) is the evidence behind DESIGN.md's register claims: every one of the 43 pt_trace_kernel and 25
     pt_world_kernel instantiations is listed; none uses scratch or spills a VGPR EXCEPT the four 1024-thread frame kernels that carry
