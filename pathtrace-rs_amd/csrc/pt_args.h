@@ -197,6 +197,10 @@ __host__ __device__ constexpr uint32_t mfma_queue_bytes(uint32_t blk) { return (
 __host__ __device__ constexpr uint32_t scan_queue_bytes(uint32_t blk) { return ((uint32_t)(kQueueCap + 1) * blk * 2u + 15u) / 16u * 16u; }
 
 constexpr int kReadyMin = 56;  // shade as soon as this many lanes of the wave have a finished traversal
+#ifndef PT_SHARE_MIN
+#define PT_SHARE_MIN 4
+#endif
+constexpr int kShareMin = PT_SHARE_MIN;   // 4-wide tree with work sharing: lanes without traversal work before subtrees change hands
 
 #ifndef PT_LEAFQ
 #define PT_LEAFQ 8

@@ -1093,14 +1093,6 @@ __device__ __forceinline__ void bvh_run(const KArgs &A, uint32_t *s_stack, const
 // of the lanes' traversals. A lane's nearest hit so far (`best`, the culling limit) is refreshed from its key after
 // every drain.
 
-struct Trav4 {
-    uint32_t visits, leaves;   // VERIFY kernels: nodes fetched / exact sphere tests (SURVEY 8d counters)
-    int sp;                    // stack entries of this lane
-    int32_t cur;               // node to visit next (kNoChild4: pop)
-    uint32_t qn;               // queued leaf candidates
-    float limit;               // culling limit of the node tests: nearest accepted hit so far * 1.02 + 0.02 (refreshed after every drain)
-    bool active;
-};
 __device__ __forceinline__ float trav4_limit(float best) { return best < kMaxT ? (best * kCullRel + kCullAbs) : kMaxT; }
 
 // key of an accepted hit: smaller t wins; equal t goes to the lower list index (hitable_list.rs:48) or, in a BVH world,
@@ -1135,158 +1127,200 @@ __device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float tim
     }
 }
 
-template <bool MOVING, int BLK>
-__device__ __forceinline__ void drain4(const KArgs &A, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, f3 o, f3 d, f3 rcp, const DivA &av,
-                                       float time, Trav4 &st) {
-    const float a = av.a;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t incl = wave_inclusive_sum(st.qn);
-    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (total == 0u) return;
-    if (total > (uint32_t)kPairCap) {
-        // more pairs than the wave's list holds: every lane tests its own (rare: the queues drain at > 4 entries)
-        for (uint32_t j = 0; wave_any(j < st.qn); ++j)
-            if (j < st.qn) {
-                pair_test4<MOVING>(A, leafq[j * BLK + tid], time, o, d, rcp, av, &w_keys[lane]);
-            }
-    } else {
-        uint32_t pos = incl - st.qn;
-        for (uint32_t j = 0; j < st.qn; ++j) w_pairs[pos++] = ((uint32_t)lane << kPairLaneShift) | leafq[j * BLK + tid];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t base = 0; base < total; base += 64u) {
-            const bool valid = base + (uint32_t)lane < total;
-            const uint32_t e = valid ? w_pairs[base + lane] : 0u;
-            const uint32_t owner = e >> kPairLaneShift;
-            const uint32_t slot = e & ((1u << kPairLaneShift) - 1u);
-            const f3 po = mk3(lane_fetch(owner, o.x), lane_fetch(owner, o.y), lane_fetch(owner, o.z));
-            const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));
-            const DivA pav{lane_fetch(owner, a), lane_fetch(owner, av.y), av.fast};
-            const float ptime = MOVING ? lane_fetch(owner, time) : 0.0f;
-            // (a BVH world's gate test needs 1 / d of the owner's ray: three cross-lane fetches instead of three IEEE divisions per round)
-            const f3 prcp = A.gate ? mk3(lane_fetch(owner, rcp.x), lane_fetch(owner, rcp.y), lane_fetch(owner, rcp.z)) : rcp;
-            if (valid) pair_test4<MOVING>(A, slot, ptime, po, pd, prcp, pav, &w_keys[owner]);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    st.qn = 0;
-    st.limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[lane] >> 32)));   // (an empty key's t field is a NaN pattern: not < kMaxT)
-}
+// ---- the traversal loop: whole-wave iterations with work sharing (round 5) ------------------------------------------------------------
+// One call traces the rays of ALL lanes of the wave to their end. A lane whose own walk is finished does not wait: it takes a pending
+// subtree off the stack of a lane that has one to spare -- the entry at the BOTTOM of that stack: the shallowest, i.e. largest,
+// pending subtree -- and walks it for the owner's ray. The ray (origin, 1 / d, pad, culling limit) is fetched across lanes once per
+// hand-over, leaf candidates are queued under the OWNER's lane number and the exact tests reduce into the owner's key. The call
+// returns when NO lane has work left, so every ray of the wave is finished at the same point and nothing about "whose ray is
+// complete" has to be communicated; no traversal state survives a trip of the kernel's main loop. (Until round 4 a traversal was
+// resumable per lane and a wave left the loop as soon as 56 of its lanes were done, because a finished lane could only wait: 19 visit
+// rounds per wave-iteration for the 9.8 visits a ray needs, 41 of 64 lanes switched on in the block that is 45 % of the kernel --
+// profiles/r04_c5_bbprof_lanes.txt. Now: 13.7 rounds for 10.5 visits -- a helper's subtree is sometimes one the owner would have culled.)
+// Results cannot change: the winner is the (t, tie-break) minimum over every leaf whose boxes the ray enters, whatever the order and
+// whoever visits them; a helper culls with the limit it fetched (refreshed from the OWNER's key at each
+// drain), which is never tighter than what the owner's own walk would use at that moment... and never looser than "no limit".
+struct Steal4 {
+    uint32_t visits, leaves;
+};
 
 template <bool MOVING>
-__device__ __forceinline__ void bvh4_start(const KArgs &A, unsigned long long *w_keys, f3 o, f3 d, const DivA &av, float time, Trav4 &st) {
-    const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);  // ray.rs:14
-    float best = kMaxT;
-    int idx = -1;
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < A.n_bvh_large; ++j) {   // spheres kept out of the tree: tested for every ray
-        const int k = (int)A.bvh_large[j];
-        bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, rcp, av, best, idx, rank);
-    }
-    w_keys[threadIdx.x & 63] = idx < 0 ? ~0ull : key4_of(A, best, idx);
-    st.limit = trav4_limit(idx < 0 ? kMaxT : best);
-    st.sp = 0;
-    st.qn = 0;
-    st.cur = A.bvh_root >= 0 ? 0 : kNoChild4;
-    st.active = true;
+__device__ __forceinline__ void pair_test4_owner(const KArgs &A, uint32_t slot, float time, f3 o, f3 d, const DivA &av, unsigned long long *key) {
+    // (the gate of a BVH world needs ray.rs:14's 1 / d of the OWNER's ray; the owner's lane may be walking somebody else's subtree with
+    //  another ray's reciprocal in its registers, so it is formed here, from the fetched direction, in its short exact form)
+    const f3 rcp = A.gate ? mk3(recip_exact(d.x), recip_exact(d.y), recip_exact(d.z)) : mk3(0.f, 0.f, 0.f);
+    pair_test4<MOVING>(A, slot, time, o, d, rcp, av, key);
 }
 
 template <bool MOVING, bool COUNT, int BLK>
-__device__ __forceinline__ void bvh4_run(const KArgs &A, uint16_t *s_stack, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys,
-                                         f3 o, f3 d, const DivA &av, float time, bool have, Trav4 &st, unsigned long long *sec = nullptr) {
+__device__ __forceinline__ void bvh4_trace(const KArgs &A, uint16_t *s_stack, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys,
+                                           f3 o, f3 d, const DivA &av, float time, bool start, Steal4 &cnt, unsigned long long *sec = nullptr) {
     const int tid = threadIdx.x;
+    const uint32_t lane = (uint32_t)tid & 63u;
 #ifdef PT_SECTIONS
-    unsigned long long sub_last = __builtin_readcyclecounter();   // sec[5] node visits, sec[6] drains, sec[7] trips (count)
-#define PT_SUB4(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); sec[i] += now_ - sub_last; sub_last = now_; } while (0)
+    unsigned long long sub_last = __builtin_readcyclecounter();   // sec[5] node visits, sec[6] drains + hand-overs, sec[7] rounds (count)
+#define PT_SUBT(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); sec[i] += now_ - sub_last; sub_last = now_; } while (0)
 #else
     (void)sec;
-#define PT_SUB4(i) do { } while (0)
+#define PT_SUBT(i) do { } while (0)
 #endif
-    const f3 rcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    const float arx = __builtin_fabsf(rcp.x), ary = __builtin_fabsf(rcp.y), arz = __builtin_fabsf(rcp.z);
-    const float pad_ray = 1.0e-6f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z));
-    const bool neg_x = d.x < 0.0f, neg_y = d.y < 0.0f, neg_z = d.z < 0.0f;   // near plane of an axis = the upper one when the ray runs down it
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     const uint4 *base = reinterpret_cast<const uint4 *>(A.nodes4);
-    // 16-bit stack entries [entry][lane]: lanes 2j and 2j + 1 share an LDS bank, a 2-way conflict whenever their depths differ.
-    // Measured and kept: the conflict-free layout (two levels of a lane per dword) needs three more address instructions per
-    // push / pop, and cost 3.5 % of config 5 for the conflicts it removed.
-    const auto slot_of_entry = [&](int e) -> uint32_t { return (uint32_t)e * (uint32_t)BLK + (uint32_t)tid; };
-    for (;;) {
-        if (st.active) {
-            if (st.cur == kNoChild4) {
-                if (st.sp == 0) st.active = false;
-                else st.cur = (int32_t)s_stack[slot_of_entry(--st.sp)];
-            }
-            if (st.active) {
-                // (keeping the top levels of the tree in LDS was measured: no gain, and the flat loads that serve both kinds of
-                // lanes cost 3 %)
-                const uint4 *np = base + (size_t)(uint32_t)st.cur * 4u;
-                const uint4 qx = np[0], qy = np[1], qz = np[2], qm = np[3];   // (lo[4], hi[4]) f16 offsets per axis | origin, meta
-                if (COUNT) st.visits += 1u;
-                const uint32_t meta = qm.w;
-                const uint32_t cbase = meta & 0xffffu, n_inner = (meta >> 16) & 7u;
-                // node-level pad: k (|origin - o|^2 + |E|^2) + 1e-4 (+ rounding), k = 6e-6 / r_min and the constant term as powers of two
-                const float pk = __uint_as_float((__builtin_amdgcn_ubfe(meta, 22, 5) << 23) + (96u << 23));
-                const float p0 = __uint_as_float(((meta >> 27) << 23) + (113u << 23));
-                const float ex = __uint_as_float(qm.x) - o.x, ey = __uint_as_float(qm.y) - o.y, ez = __uint_as_float(qm.z) - o.z;
-                const float pad = __builtin_fmaf(pk, __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)), p0) + pad_ray;
-                // t = offset * rcp + ((origin - o) * rcp -+ pad |rcp|)
-                const float px = pad * arx, py = pad * ary, pz = pad * arz;
-                const float Bnx = __builtin_fmaf(ex, rcp.x, -px), Bny = __builtin_fmaf(ey, rcp.y, -py), Bnz = __builtin_fmaf(ez, rcp.z, -pz);
-                const float Bfx = __builtin_fmaf(ex, rcp.x, px), Bfy = __builtin_fmaf(ey, rcp.y, py), Bfz = __builtin_fmaf(ez, rcp.z, pz);
-                const float limit = st.limit;
-                // near / far plane pairs of each axis: children 0,1 in [0], 2,3 in [1]
-                const uint32_t nxw[2] = {neg_x ? qx.z : qx.x, neg_x ? qx.w : qx.y}, fxw[2] = {neg_x ? qx.x : qx.z, neg_x ? qx.y : qx.w};
-                const uint32_t nyw[2] = {neg_y ? qy.z : qy.x, neg_y ? qy.w : qy.y}, fyw[2] = {neg_y ? qy.x : qy.z, neg_y ? qy.y : qy.w};
-                const uint32_t nzw[2] = {neg_z ? qz.z : qz.x, neg_z ? qz.w : qz.y}, fzw[2] = {neg_z ? qz.x : qz.z, neg_z ? qz.y : qz.w};
-                // Inner children occupy the first slots and are consecutive nodes (first + slot), leaves follow, empty slots
-                // last (their planes can never be hit: lower offsets at the f16 maximum, upper ones zero). Everything below is branch-free: a slot's queue / stack entry is written unconditionally and only
-                // COUNTED when the child was hit.
-                uint32_t key[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const half2v hnx = __builtin_bit_cast(half2v, nxw[j >> 1]), hny = __builtin_bit_cast(half2v, nyw[j >> 1]), hnz = __builtin_bit_cast(half2v, nzw[j >> 1]);
-                    const half2v hfx = __builtin_bit_cast(half2v, fxw[j >> 1]), hfy = __builtin_bit_cast(half2v, fyw[j >> 1]), hfz = __builtin_bit_cast(half2v, fzw[j >> 1]);
-                    // NaNs (0 * inf) drop out of max3 / min3: that axis then imposes nothing, i.e. they count as a hit
-                    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf((float)hnx[j & 1], rcp.x, Bnx), __builtin_fmaf((float)hny[j & 1], rcp.y, Bny)),
-                                                                     __builtin_fmaf((float)hnz[j & 1], rcp.z, Bnz)), 0.0f);
-                    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf((float)hfx[j & 1], rcp.x, Bfx), __builtin_fmaf((float)hfy[j & 1], rcp.y, Bfy)),
-                                                     __builtin_fmaf((float)hfz[j & 1], rcp.z, Bfz));
-                    // hit = !(tf < tn) && !(tn > limit); tn is never NaN (max with 0), so the limit folds into the far side
-                    const bool miss = __builtin_fminf(tf, limit) < tn;
-                    const bool leaf = (uint32_t)j >= n_inner;
-                    leafq[st.qn * BLK + tid] = ((uint32_t)st.cur << 2) | (uint32_t)j;
-                    st.qn += (miss || !leaf) ? 0u : 1u;     // leaf child: one more candidate for the exact test
-                    if (COUNT) st.leaves += (miss || !leaf) ? 0u : 1u;
-                    key[j] = (miss || leaf) ? 0xffffffffu : ((__float_as_uint(tn) & ~3u) | (uint32_t)j);
-                }
-                // sort the inner children by entry distance (5 compare-exchanges), push far-to-near, continue with the nearest
-#define PT_CE(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
-                PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
-#undef PT_CE
-                // (16-bit stack entries: the 4-wide tree is only used while it has fewer than 65536 nodes)
-                s_stack[slot_of_entry(st.sp)] = (uint16_t)(cbase + (key[3] & 3u));
-                st.sp += key[3] != 0xffffffffu ? 1 : 0;
-                s_stack[slot_of_entry(st.sp)] = (uint16_t)(cbase + (key[2] & 3u));
-                st.sp += key[2] != 0xffffffffu ? 1 : 0;
-                s_stack[slot_of_entry(st.sp)] = (uint16_t)(cbase + (key[1] & 3u));
-                st.sp += key[1] != 0xffffffffu ? 1 : 0;
-                st.cur = key[0] != 0xffffffffu ? (int32_t)(cbase + (key[0] & 3u)) : kNoChild4;
-                if (st.cur == kNoChild4 && st.sp == 0) st.active = false;
-            }
+    const auto slot_of_entry = [&](int e, uint32_t column) -> uint32_t { return (uint32_t)e * (uint32_t)BLK + column; };
+    // the ray this lane TRAVERSES with (its own until it takes over part of another lane's walk)
+    f3 to = o, trcp = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);   // ray.rs:14
+    float tpad = 1.0e-6f * (__builtin_fabsf(o.x) + __builtin_fabsf(o.y) + __builtin_fabsf(o.z));
+    float limit = kMaxT;
+    uint32_t owner_tag = lane << kPairLaneShift;   // whose ray that is, as the pair list wants it
+    int sp = 0, sb = 0;                            // live stack entries of this lane: [sb, sp)
+    int32_t cur = kNoChild4;
+    uint32_t qn = 0;
+    if (start) {
+        float best = kMaxT;
+        int idx = -1;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < A.n_bvh_large; ++j) {   // spheres kept out of the tree: tested for every ray
+            const int k = (int)A.bvh_large[j];
+            bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, trcp, av, best, idx, rank);
         }
-        const unsigned long long act = wave_ballot(st.active);
-        const bool stop = act == 0ull || __popcll(wave_ballot(have && !st.active)) >= (int)A.ready_min;
-        PT_SUB4(5);
+        w_keys[lane] = idx < 0 ? ~0ull : key4_of(A, best, idx);
+        limit = trav4_limit(idx < 0 ? kMaxT : best);
+        cur = A.bvh_root >= 0 ? 0 : kNoChild4;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    for (;;) {
+        if (cur == kNoChild4 && sp > sb) cur = (int32_t)s_stack[slot_of_entry(--sp, (uint32_t)tid)];
+        if (cur != kNoChild4) {
+            const uint4 *np = base + (size_t)(uint32_t)cur * 4u;
+            const uint4 qx = np[0], qy = np[1], qz = np[2], qm = np[3];   // (lo[4], hi[4]) f16 offsets per axis | origin, meta
+            if (COUNT) cnt.visits += 1u;
+            const bool neg_x = trcp.x < 0.0f, neg_y = trcp.y < 0.0f, neg_z = trcp.z < 0.0f;   // near plane of an axis = the upper one when the ray runs down it
+            const uint32_t meta = qm.w;
+            const uint32_t cbase = meta & 0xffffu, n_inner = (meta >> 16) & 7u;
+            const float pk = __uint_as_float((__builtin_amdgcn_ubfe(meta, 22, 5) << 23) + (96u << 23));
+            const float p0 = __uint_as_float(((meta >> 27) << 23) + (113u << 23));
+            const float ex = __uint_as_float(qm.x) - to.x, ey = __uint_as_float(qm.y) - to.y, ez = __uint_as_float(qm.z) - to.z;
+            const float pad = __builtin_fmaf(pk, __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex)), p0) + tpad;
+            const float px = pad * __builtin_fabsf(trcp.x), py = pad * __builtin_fabsf(trcp.y), pz = pad * __builtin_fabsf(trcp.z);
+            const float Bnx = __builtin_fmaf(ex, trcp.x, -px), Bny = __builtin_fmaf(ey, trcp.y, -py), Bnz = __builtin_fmaf(ez, trcp.z, -pz);
+            const float Bfx = __builtin_fmaf(ex, trcp.x, px), Bfy = __builtin_fmaf(ey, trcp.y, py), Bfz = __builtin_fmaf(ez, trcp.z, pz);
+            const uint32_t nxw[2] = {neg_x ? qx.z : qx.x, neg_x ? qx.w : qx.y}, fxw[2] = {neg_x ? qx.x : qx.z, neg_x ? qx.y : qx.w};
+            const uint32_t nyw[2] = {neg_y ? qy.z : qy.x, neg_y ? qy.w : qy.y}, fyw[2] = {neg_y ? qy.x : qy.z, neg_y ? qy.y : qy.w};
+            const uint32_t nzw[2] = {neg_z ? qz.z : qz.x, neg_z ? qz.w : qz.y}, fzw[2] = {neg_z ? qz.x : qz.z, neg_z ? qz.y : qz.w};
+            uint32_t key[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const half2v hnx = __builtin_bit_cast(half2v, nxw[j >> 1]), hny = __builtin_bit_cast(half2v, nyw[j >> 1]), hnz = __builtin_bit_cast(half2v, nzw[j >> 1]);
+                const half2v hfx = __builtin_bit_cast(half2v, fxw[j >> 1]), hfy = __builtin_bit_cast(half2v, fyw[j >> 1]), hfz = __builtin_bit_cast(half2v, fzw[j >> 1]);
+                const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf((float)hnx[j & 1], trcp.x, Bnx), __builtin_fmaf((float)hny[j & 1], trcp.y, Bny)),
+                                                                 __builtin_fmaf((float)hnz[j & 1], trcp.z, Bnz)), 0.0f);
+                const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaf((float)hfx[j & 1], trcp.x, Bfx), __builtin_fmaf((float)hfy[j & 1], trcp.y, Bfy)),
+                                                 __builtin_fmaf((float)hfz[j & 1], trcp.z, Bfz));
+                const bool miss = __builtin_fminf(tf, limit) < tn;
+                const bool leaf = (uint32_t)j >= n_inner;
+                leafq[qn * BLK + tid] = owner_tag | ((uint32_t)cur << 2) | (uint32_t)j;
+                qn += (miss || !leaf) ? 0u : 1u;
+                if (COUNT) cnt.leaves += (miss || !leaf) ? 0u : 1u;
+                key[j] = (miss || leaf) ? 0xffffffffu : ((__float_as_uint(tn) & ~3u) | (uint32_t)j);
+            }
+#define PT_CE(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+            PT_CE(0, 1) PT_CE(2, 3) PT_CE(0, 2) PT_CE(1, 3) PT_CE(1, 2)
+#undef PT_CE
+            s_stack[slot_of_entry(sp, (uint32_t)tid)] = (uint16_t)(cbase + (key[3] & 3u));
+            sp += key[3] != 0xffffffffu ? 1 : 0;
+            s_stack[slot_of_entry(sp, (uint32_t)tid)] = (uint16_t)(cbase + (key[2] & 3u));
+            sp += key[2] != 0xffffffffu ? 1 : 0;
+            s_stack[slot_of_entry(sp, (uint32_t)tid)] = (uint16_t)(cbase + (key[1] & 3u));
+            sp += key[1] != 0xffffffffu ? 1 : 0;
+            cur = key[0] != 0xffffffffu ? (int32_t)(cbase + (key[0] & 3u)) : kNoChild4;
+        }
+        const bool work = cur != kNoChild4 || sp > sb;
+        const unsigned long long wm = wave_ballot(work);
+        const bool stop = wm == 0ull;
+        PT_SUBT(5);
 #ifdef PT_SECTIONS
         sec[7] += 1ull;
 #endif
-        if (stop || wave_any(st.qn > A.drain_at)) drain4<MOVING, BLK>(A, leafq, w_pairs, w_keys, o, d, rcp, av, time, st);
-        PT_SUB4(6);
+        if (stop || wave_any(qn > A.drain_at)) {
+            // exact tests of the queued leaf candidates, one (owner ray, leaf slot) pair per lane and round, reduced into the owner's key
+            // with ds_min_u64 (the entries carry their owner); afterwards every lane refreshes its culling limit from ITS owner's key
+            const uint32_t incl = wave_inclusive_sum(qn);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (total != 0u) {
+                const float a = av.a;
+                if (total > (uint32_t)kPairCap) {
+                    // more pairs than the wave's list holds (rare): every lane walks its own queue, the owners' rays still come across lanes
+                    for (uint32_t j = 0; wave_any(j < qn); ++j) {
+                        const bool valid = j < qn;
+                        const uint32_t e = valid ? leafq[j * BLK + tid] : owner_tag;
+                        const uint32_t ow = e >> kPairLaneShift;
+                        const f3 po = mk3(lane_fetch(ow, o.x), lane_fetch(ow, o.y), lane_fetch(ow, o.z));
+                        const f3 pd = mk3(lane_fetch(ow, d.x), lane_fetch(ow, d.y), lane_fetch(ow, d.z));
+                        const DivA pav{lane_fetch(ow, a), lane_fetch(ow, av.y), av.fast};
+                        const float ptime = MOVING ? lane_fetch(ow, time) : 0.0f;
+                        if (valid) pair_test4_owner<MOVING>(A, e & ((1u << kPairLaneShift) - 1u), ptime, po, pd, pav, &w_keys[ow]);
+                    }
+                } else {
+                    uint32_t pos = incl - qn;
+                    for (uint32_t j = 0; j < qn; ++j) w_pairs[pos++] = leafq[j * BLK + tid];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t b0 = 0; b0 < total; b0 += 64u) {
+                        const bool valid = b0 + lane < total;
+                        const uint32_t e = valid ? w_pairs[b0 + lane] : owner_tag;
+                        const uint32_t ow = e >> kPairLaneShift;
+                        const f3 po = mk3(lane_fetch(ow, o.x), lane_fetch(ow, o.y), lane_fetch(ow, o.z));
+                        const f3 pd = mk3(lane_fetch(ow, d.x), lane_fetch(ow, d.y), lane_fetch(ow, d.z));
+                        const DivA pav{lane_fetch(ow, a), lane_fetch(ow, av.y), av.fast};
+                        const float ptime = MOVING ? lane_fetch(ow, time) : 0.0f;
+                        if (valid) pair_test4_owner<MOVING>(A, e & ((1u << kPairLaneShift) - 1u), ptime, po, pd, pav, &w_keys[ow]);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                qn = 0;
+                limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[owner_tag >> kPairLaneShift] >> 32)));   // (an empty key's t field is a NaN pattern: not < kMaxT)
+            }
+        }
         if (stop) break;
+        // ---- hand-over: lanes without work take the bottom entry of the stacks of lanes that can spare one
+        const unsigned long long im = ~wm;
+        if ((uint32_t)__popcll(im) >= A.ready_min) {
+#ifndef PT_SHARE_DEPTH
+#define PT_SHARE_DEPTH 1
+#endif
+            const bool offer = sp - sb >= PT_SHARE_DEPTH && (cur != kNoChild4 || sp - sb >= 2);
+            const unsigned long long om = wave_ballot(offer);
+            if (om != 0ull) {
+                const uint32_t n_pairs = min((uint32_t)__popcll(om), (uint32_t)__popcll(im));
+                const uint32_t ro = __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u));
+                const uint32_t ri = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+                const bool give = offer && ro < n_pairs, take = !work && ri < n_pairs;
+                if (give) {
+                    w_pairs[ro] = lane | ((uint32_t)sb << 8);
+                    sb += 1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t g = take ? w_pairs[ri] : lane;
+                const uint32_t from = g & 63u;
+                // (every lane fetches -- a lane that takes nothing fetches its own values)
+                const f3 fo = mk3(lane_fetch(from, to.x), lane_fetch(from, to.y), lane_fetch(from, to.z));
+                const f3 fr = mk3(lane_fetch(from, trcp.x), lane_fetch(from, trcp.y), lane_fetch(from, trcp.z));
+                const float fpad = lane_fetch(from, tpad), flim = lane_fetch(from, limit);
+                const uint32_t ftag = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)owner_tag);
+                if (take) {
+                    cur = (int32_t)s_stack[slot_of_entry((int)(g >> 8), ((uint32_t)tid & ~63u) | from)];
+                    to = fo, trcp = fr, tpad = fpad, limit = flim, owner_tag = ftag;
+                    sp = 0, sb = 0;
+                }
+                __builtin_amdgcn_wave_barrier();   // (the scratch words are the pair list again from here on)
+            }
+        }
+        PT_SUBT(6);
     }
+#undef PT_SUBT
 }
 
 }  // namespace ptdev
@@ -1312,7 +1346,7 @@ namespace ptdev {
 //     "---- refill"                 finished pixels are written, free lanes claim pixels (batched), parked streams are reloaded
 //     "TAIL: once the list is dry"  a look into one other wave's mailbox (pt_coop.h), read at the end of the trip
 //     "---- camera.rs:56-68"        next sample's camera ray + the sphere draws a Metal scatter still owes, one shared rejection loop
-//     "---- hitable.rs:39-65"       closest hit: 4-wide tree (bvh4_run) | binary tree | MFMA prefilter + balanced exact tests | exact scan
+//     "---- hitable.rs:39-65"       closest hit: 4-wide tree (bvh4_trace) | binary tree | MFMA prefilter + balanced exact tests | exact scan
 //     "---- scene.rs:49-71"         one level of ray_trace: material, scatter, attenuation push; on termination fold + sample count
 //     "Hand-over (pt_coop.h)"       a pixel between two samples goes to an idle worker
 //   epilogue      the wave retires or becomes a worker (coop_worker), ray count reduction, development counters
@@ -1463,7 +1497,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     float metal_fuzz = 0.0f;
     uint32_t pix_rays = 0;
     BvhTrav trav{0u, 0u, 0, kMaxT, -1, 0u, false};
-    Trav4 trav4{0u, 0u, 0, kNoChild4, 0u, kMaxT, false};
+    Steal4 steal4{0u, 0u};
     // per-lane bookkeeping, packed (every register counts: the 4-waves-per-SIMD kernels are compiled for 128 VGPRs):
     //   pxy = pixel column | local row << 16 (launch() keeps width and height below 65536)
     //   sd  = bounce depth (12 bits) | sample number << 12 (launch(): max_depth <= 4095, samples < 2^20)
@@ -1676,17 +1710,15 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         float t_hit;
         int idx;
         if (TREE4) {
-            if (have && trav_new) {
-                bvh4_start<MOVING>(A, w_keys, o, d, av, rtime, trav4);
-                trav_new = false;
-            }
-            bvh4_run<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint16_t *>(s_bvh), reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, ro, rd, av, rtime, have, trav4
+            // (every ray of the wave is finished when this returns: no traversal state is carried into the next trip)
+            bvh4_trace<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint16_t *>(s_bvh), reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, ro, rd, av, rtime, have, steal4
 #ifdef PT_SECTIONS
-                                          , sec_t
+                                            , sec_t
 #endif
-                                          );
+                                            );
+            trav_new = false;
             idx = -1, t_hit = kMaxT;
-            if (have && !trav4.active) {   // (lanes without a finished ray hold a stale or never-written key)
+            if (have) {   // (lanes without a ray hold a stale or never-written key)
                 const unsigned long long key = w_keys[lane];
                 const uint32_t low = (uint32_t)key;
                 // BVH world: the key carries the leaf's DFS rank; shading reads the rank-ordered copy of the records, so
@@ -1720,7 +1752,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 
         PT_SEC(2);
         // ---- scene.rs:49-71 one level of ray_trace (BVH mode: only lanes whose traversal has finished)
-        const bool shading = have && !(BVH && (TREE4 ? trav4.active : trav.active));
+        const bool shading = have && !(BVH && !TREE4 && trav.active);
         wave_rays += (unsigned long long)__popcll(wave_ballot(shading));   // scene.rs:57 `ray_count += 1` for every lane shaded below
         // 4-wide tree kernels: Texture::Noise of the lanes that will scatter off a noise-textured Lambertian, evaluated for the
         // whole wave at once (wave_balanced_turb): the shading below is divergent, and a third of its lanes (sky misses) idle
@@ -1884,11 +1916,21 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         if (k >= 3) V = mk3(0.0f + qc3.x * V.x, 0.0f + qc3.y * V.y, 0.0f + qc3.z * V.z);
                     }
                 }
-                for (int k = PAL ? 0 : (int)PT_DEPTH - 1; k >= 1; --k) {
-                    if (PAL) {
-                    } else if (WST) {
-                        const f3 c = word_colour(__float_as_uint(path_ld((uint32_t)(k - 1))));
-                        V = mk3(0.0f + c.x * V.x, 0.0f + c.y * V.y, 0.0f + c.z * V.z);
+                if (WST) {
+                    // three levels per trip, as above: the words, then the colours behind them, are fetched together (a level per trip ran
+                    // 8 trips per wave-iteration on config 5, four lanes switched on, each trip one dependent LDS round trip)
+                    for (int k = (int)PT_DEPTH - 1; k >= 1; k -= 3) {
+                        const uint32_t wa = __float_as_uint(path_ld((uint32_t)(k - 1)));
+                        const uint32_t wb = __float_as_uint(path_ld((uint32_t)(k >= 2 ? k - 2 : 0)));
+                        const uint32_t wc = __float_as_uint(path_ld((uint32_t)(k >= 3 ? k - 3 : 0)));
+                        const f3 ca = word_colour(wa), cb = word_colour(wb), cc = word_colour(wc);
+                        V = mk3(0.0f + ca.x * V.x, 0.0f + ca.y * V.y, 0.0f + ca.z * V.z);
+                        if (k >= 2) V = mk3(0.0f + cb.x * V.x, 0.0f + cb.y * V.y, 0.0f + cb.z * V.z);
+                        if (k >= 3) V = mk3(0.0f + cc.x * V.x, 0.0f + cc.y * V.y, 0.0f + cc.z * V.z);
+                    }
+                }
+                for (int k = (PAL || WST) ? 0 : (int)PT_DEPTH - 1; k >= 1; --k) {
+                    if (PAL || WST) {
                     } else {
                         V.x = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 0u) * V.x;
                         V.y = 0.0f + path_ld((uint32_t)(k - 1) * 3u + 1u) * V.y;
@@ -1974,8 +2016,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 #endif
     }
     if (BVH && VERIFY) {   // traversal counters (accumulate over the lane's whole life: never reset per ray)
-        atomicAdd(&A.debug[8], (unsigned long long)(TREE4 ? trav4.visits : trav.visits));
-        atomicAdd(&A.debug[9], (unsigned long long)(TREE4 ? trav4.leaves : trav.leaves) + (lane == 0 ? wave_rays * A.n_bvh_large : 0ull));
+        atomicAdd(&A.debug[8], (unsigned long long)(TREE4 ? steal4.visits : trav.visits));
+        atomicAdd(&A.debug[9], (unsigned long long)(TREE4 ? steal4.leaves : trav.leaves) + (lane == 0 ? wave_rays * A.n_bvh_large : 0ull));
     }
     // scene.rs:118 ray_count: wave reduce, one atomic per wave
     if (lane == 0) atomicAdd(A.ray_count, wave_rays);

@@ -383,7 +383,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.gamma = s->gamma;
     A.verify = (c.verify ? 1u : 0u) | ((s->variant & ptsel::kVarNoStack) ? 2u : 0u);
     A.debug = s->d_debug;
-    A.ready_min = dev_knobs().ready >= 0 ? (uint32_t)dev_knobs().ready : (uint32_t)kReadyMin;
+    A.ready_min = dev_knobs().ready >= 0 ? (uint32_t)dev_knobs().ready : (uint32_t)((tree4) ? kShareMin : kReadyMin);   // (4-wide tree: lanes without work before subtrees change hands)
     A.drain_at = dev_knobs().drain >= 0 ? std::min<uint32_t>((uint32_t)dev_knobs().drain, (uint32_t)(kLeafQ - 4)) : (uint32_t)(kLeafQ - 4);
     A.wnodes = s->d_wnodes;
     A.n_nodes = s->tr.bin_nodes;

@@ -914,7 +914,7 @@ struct Flattener {
         if (outer.size() > 15 || inner.size() > 15)
             return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u sits below %zu Instance levels on one side of a medium; at most 15 are supported", leaf_node,
                         std::max(outer.size(), inner.size()));
-        if (out->hit.size() >= (1u << 22)) return fail(PT_ERR_UNSUPPORTED, "scene graph: flattening yields more than 2^22 list entries (an Instance around a HitableList is distributed over its children)");
+        if (out->hit.size() >= (1u << 20)) return fail(PT_ERR_UNSUPPORTED, "scene graph: flattening yields more than 2^20 list entries (an Instance around a HitableList is distributed over its children)");
         h.transform = encode_chain(outer, inner);
         if (out->xf.size() >= (1u << 20)) return fail(PT_ERR_UNSUPPORTED, "scene graph: flattening needs more than 2^20 transform slots");
         h.medium_material = medium_material;
@@ -927,7 +927,7 @@ struct Flattener {
         if (on_path(n)) return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u contains itself (a cycle)", n);
         if (path.size() > 256) return fail(PT_ERR_UNSUPPORTED, "scene graph: deeper than 256 levels at node %u", n);
         // shared children are expanded once per path: a DAG of nested lists can cost exponential time on caller-supplied input
-        if (++visits > (1ull << 24)) return fail(PT_ERR_UNSUPPORTED, "scene graph: flattening visits more than 2^24 nodes (shared children are expanded per path)");
+        if (++visits > (1ull << 22)) return fail(PT_ERR_UNSUPPORTED, "scene graph: flattening visits more than 2^22 nodes (shared children are expanded per path)");
         const pt_node &N = d->nodes[n];
         path.push_back(n);
         int r = PT_OK;
@@ -975,6 +975,7 @@ int flatten_world_graph(const pt_world_desc *desc, FlatWorld &out, const pt_worl
     if (!desc->nodes || (desc->n_node_children && !desc->node_children)) return fail(PT_ERR_INVALID_ARG, "scene graph: nodes / node_children is NULL");
     if (desc->n_hitables && !desc->hitables) return fail(PT_ERR_INVALID_ARG, "hitables is NULL");
     if (desc->n_transforms && !desc->transforms) return fail(PT_ERR_INVALID_ARG, "transforms is NULL");
+    if (desc->n_materials && !desc->materials) return fail(PT_ERR_INVALID_ARG, "materials is NULL");   // (a ConstantMedium node looks its phase function up during the walk: found by tools/fuzz_desc.cpp)
     if (desc->root_node >= desc->n_nodes) return fail(PT_ERR_INVALID_ARG, "scene graph: root node %u out of range", desc->root_node);
     Flattener F{desc, &out, {}, {}};
     // a nesting the list form cannot express: the graph is validated and handed on as it is, to be interpreted (pt_graph.h)

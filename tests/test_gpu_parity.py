@@ -1217,7 +1217,7 @@ def test_interpreted_graph_with_noise_textures_progressive_frames_and_shards(ptg
     np.testing.assert_allclose(out, ref, rtol=0, atol=NOISE_ATOL)
     # `-B` over an interpreted graph is refused by the render call itself, not only by pt_debug_select (the graph's BVHNode rows are
     # nodes of the graph, not a tree over the world) -- and the refusal leaves the scene usable
-    with pytest.raises(ptgpu.PtError, match="no BVH nodes"):
+    with pytest.raises(ptgpu.PtError, match="use_bvh requested"):
         sc.update(ptgpu.PtParams(W, H, S, 10, 0, 1), cam, 0, np.zeros((H, W, 3), np.float32))
     import torch
     rc = torch.zeros(1, dtype=torch.int64, device="cuda")

@@ -505,7 +505,7 @@ def test_scene_graph_nestings_the_list_form_cannot_hold_are_interpreted_and_malf
     t0 = time.time()
     with pytest.raises(ptgpu.PtError) as e:
         select(nodes, children, depth)
-    assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and ("2^24" in str(e.value) or "2^22" in str(e.value)), str(e.value)
+    assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and ("2^22" in str(e.value) or "2^20" in str(e.value)), str(e.value)
     assert time.time() - t0 < 20.0
 
 

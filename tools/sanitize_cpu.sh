@@ -33,3 +33,21 @@ print("sanitize_cpu: clean")
 PY
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so)" \
     ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 python "$OUT/run.py"
+
+# ---- the LIBRARY's host side: every translation unit of libptgpu.so compiled host-only (kernels become launch stubs that are never
+# called) with ASan + UBSan, linked with tools/fuzz_desc.cpp, and fed seeded malformed descriptions through pt_debug_select -- the
+# validators, the scene-graph flattener, the tree restatements and the kernel selection, none of which touch a device.
+#   FUZZ_CASES (default 100000), FUZZ_SEED (default 1)
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+SANFLAGS="--offload-host-only -O1 -g -std=c++17 -ffp-contract=off -fPIC -Iinclude -Ipathtrace-rs_amd/csrc -I/opt/rocm/include -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer"
+objs=""
+for u in pt_api pt_prep pt_scene pt_launch pt_render pt_comm pt_query pt_build pt_kernels_list pt_kernels_gate pt_kernels_tree pt_kernels_world; do
+    if [ ! -f "$OUT/$u.o" ] || [ -n "$(find pathtrace-rs_amd/csrc include -newer "$OUT/$u.o" -type f | head -1)" ]; then
+        $HIPCC $SANFLAGS -c pathtrace-rs_amd/csrc/$u.hip -o "$OUT/$u.o" &
+    fi
+    objs="$objs $OUT/$u.o"
+done
+wait
+$HIPCC $SANFLAGS -c tools/fuzz_desc.cpp -x hip -o "$OUT/fuzz_desc.o" 2>/dev/null || $HIPCC $SANFLAGS -x hip -c tools/fuzz_desc.cpp -o "$OUT/fuzz_desc.o"
+$HIPCC --offload-host-only -fsanitize=address,undefined $objs "$OUT/fuzz_desc.o" -o "$OUT/fuzz_desc" -ldl -lpthread
+ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=print_stacktrace=1 "$OUT/fuzz_desc" ${FUZZ_CASES:-100000} ${FUZZ_SEED:-1}
