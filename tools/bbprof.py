@@ -27,6 +27,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
 UNIT = os.environ.get("BBPROF_UNIT", "pt_kernels_list")   # pt_kernels_list | pt_kernels_gate | pt_kernels_tree | pt_kernels_world
 if UNIT in ("pt_kernels_list", "pt_kernels_tree"):   # (as pathtrace-rs_amd/Makefile builds these two units)
     FLAGS += ["-mllvm", "-amdgpu-use-amdgpu-trackers"]
+# BBPROF_DEFS="-DPT_SECTIONS": the kernel then reads the cycle counter (s_memtime) at its section boundaries, in source order; the
+# instrumenter numbers every instruction by how many of those reads precede it in the assembly, and `report` adds up instructions
+# per SECTION -- to be set beside the cycle shares a -DPT_SECTIONS library prints (cold blocks the compiler moved to the end of the
+# function land in the last section: they are cold)
+FLAGS += os.environ.get("BBPROF_DEFS", "").split()
 
 
 def sh(cmd, **kw):
@@ -49,10 +54,12 @@ def instrument(src_lines):
     """One counter per basic block of every pt_trace_kernel instance; returns (patched lines, map)."""
     files, out, blocks = {}, [], []
     kernel, cur, loc = None, None, None
+    marks = 0   # cycle-counter reads seen so far in this kernel (section boundaries of a -DPT_SECTIONS build)
 
     def open_block(name):
         nonlocal cur
-        cur = {"kernel": kernel, "label": name, "valu": 0, "salu": 0, "lds": 0, "mfma": 0, "vmem": 0, "other": 0, "trans": 0, "lanes": 0, "movs": 0, "lines": collections.Counter()}
+        cur = {"kernel": kernel, "label": name, "valu": 0, "salu": 0, "lds": 0, "mfma": 0, "vmem": 0, "other": 0, "trans": 0, "lanes": 0, "movs": 0, "lines": collections.Counter(),
+               "sec_valu": collections.Counter(), "sec_all": collections.Counter()}
         blocks.append(cur)
         out.append("\ts_atomic_add_x2 s[96:97], s[98:99], 0x%x" % (8 * (len(blocks) - 1)))
         # active lanes of this execution into the second half of the counter array. s_bcnt1 writes SCC, which may be live across
@@ -66,6 +73,7 @@ def instrument(src_lines):
         m = re.match(r"^(_ZN5ptdev\d+pt_(?:trace|world)_kernel\w+):", l)
         if m:
             kernel = m.group(1)
+            marks = 0
             out.append(l)
             out += ["\ts_mov_b64 s[96:97], 1", "\ts_getpc_b64 s[98:99]", "\ts_add_u32 s98, s98, pt_bbprof@gotpcrel32@lo+4", "\ts_addc_u32 s99, s99, pt_bbprof@gotpcrel32@hi+12",
                     "\ts_load_dwordx2 s[98:99], s[98:99], 0x0", "\ts_waitcnt lgkmcnt(0)"]
@@ -95,6 +103,9 @@ def instrument(src_lines):
                 op = m.group(1)
                 k = classify(op)
                 cur[k] += 1
+                if op == "s_memtime": marks += 1
+                cur["sec_all"][str(marks)] += 1
+                if k == "valu": cur["sec_valu"][str(marks)] += 1
                 if k == "valu":
                     if re.match(r"v_(rcp|sqrt|rsq|div_|exp|log|sin|cos)", op): cur["trans"] += 1
                     if re.match(r"v_(readlane|writelane|readfirstlane)", op): cur["lanes"] += 1   # SGPR spill traffic and wave-uniform reads
@@ -103,7 +114,7 @@ def instrument(src_lines):
         elif ".amdhsa_next_free_sgpr" in l and blocks and ("pt_trace_kernel" in (blocks[-1]["kernel"] or "") or "pt_world_kernel" in (blocks[-1]["kernel"] or "")):
             l = "\t\t.amdhsa_next_free_sgpr 100"   # the descriptor follows the function body
         out.append(l)
-    for b in blocks: b["lines"] = dict(b["lines"])
+    for b in blocks: b["lines"], b["sec_valu"], b["sec_all"] = dict(b["lines"]), dict(b["sec_valu"]), dict(b["sec_all"])
     return out, blocks
 
 
@@ -180,6 +191,42 @@ def remap():
     json.dump(blocks, open(os.path.join(OUT, "bbprof_map.json"), "w"))
 
 
+def section_of_line_table():
+    """Which section of the MFMA list kernel's main loop a source line belongs to, where that is unambiguous: the kernel body's own lines
+    (between its PT_SEC markers) and the functions only one section calls. Lines of shared helpers (pt_device.h: RNG, square roots,
+    normalisation ...) are attributed per BASIC BLOCK, by the majority of the block's unambiguous lines."""
+    src = open(os.path.join(PKG, "csrc", "pt_kernel.h")).read().split("\n")
+    def find(text, start=0):
+        for i in range(start, len(src)):
+            if text in src[i]: return i + 1
+        raise KeyError(text)
+    feat0 = find("__device__ __forceinline__ RayFeat make_ray_features")
+    feat1 = find("// Candidate queue without atomics")
+    clip0 = find("struct TileClip {")
+    mf0 = find("__device__ __forceinline__ int intersect_list_mfma")
+    drain0, drain1 = find("auto drain = [&]() {", mf0), find("    // the always-tested spheres first", mf0)
+    sub6 = find("PT_SUB(6);", mf0)
+    mf1 = find("// bvh.rs:37-62 over the CALLER's tree", mf0)
+    refill0 = find("// ---- refill:")
+    sec0, sec1, sec2, sec3 = find("PT_SEC(0);", refill0), find("PT_SEC(1);", refill0), find("PT_SEC(2);", refill0), find("PT_SEC(3);", refill0)
+    fold0 = find("if (terminal) {", sec2)
+    end = find("#undef PT_DEPTH", sec3)
+    table = []   # (file, first line, last line, section)
+    table += [("pt_kernel.h", refill0, sec0, "refill"), ("pt_kernel.h", sec0 + 1, sec1, "camera + rejection loop"), ("pt_kernel.h", sec1 + 1, sec2, "tiles: always-tested spheres, masks, MFMA loop"),
+              ("pt_kernel.h", sec2 + 1, fold0 - 1, "shade"), ("pt_kernel.h", fold0, sec3, "fold + sample end"), ("pt_kernel.h", sec3 + 1, end, "hand-over + worker (pt_coop.h)"),
+              ("pt_kernel.h", feat0, feat1 - 1, "ray features"), ("pt_kernel.h", clip0, mf0 - 1, "tiles: always-tested spheres, masks, MFMA loop"),
+              ("pt_kernel.h", mf0, drain0 - 1, "tiles: always-tested spheres, masks, MFMA loop"), ("pt_kernel.h", drain0, drain1 - 1, "phase 2: balanced exact tests"),
+              ("pt_kernel.h", drain1, sub6, "tiles: always-tested spheres, masks, MFMA loop"), ("pt_kernel.h", sub6 + 1, mf1 - 1, "phase 2: balanced exact tests"),
+              ("pt_coop.h", 1, 100000, "hand-over + worker (pt_coop.h)")]
+    def lookup(loc):
+        f, _, ln = loc.rpartition(":")
+        f, ln = os.path.basename(f), int(ln)
+        for tf, a, b, sec in table:
+            if f == tf and a <= ln <= b: return sec
+        return None
+    return lookup
+
+
 def report(argv):
     counts_file = argv[0] if argv else os.path.join(ROOT, "gpurun_out", "bbprof_counts.txt")
     blocks = json.load(open(os.path.join(OUT, "bbprof_map.json")))
@@ -198,6 +245,10 @@ def report(argv):
         k = b["kernel"]
         for c in ("valu", "salu", "lds", "mfma", "vmem", "trans", "lanes", "movs"): per_kernel[k][c] += n * b.get(c, 0)
         per_kernel[k]["blocks"] += n
+        for sidx, c in b.get("sec_valu", {}).items():
+            per_kernel[k]["sec_valu_" + sidx] += n * c
+            per_kernel[k]["sec_lane_on_" + sidx] += lanes_on.get(i, 64 * n) * c
+        for sidx, c in b.get("sec_all", {}).items(): per_kernel[k]["sec_all_" + sidx] += n * c
         if b["label"] == "entry": per_kernel[k]["waves"] += n
         for ln, c in b["lines"].items(): lines[k][ln] += n * c
         on = lanes_on.get(i, 64 * n)
@@ -219,6 +270,39 @@ def report(argv):
                 print("   %5.2f%%  %-11s lanes on %4.1f  valu share %5.2f%%  runs %.3g x valu %d  %s" % (
                     100.0 * (64 * n - on) * b["valu"] / max(masked_total, 1), b["label"], on / max(n, 1), 100.0 * dv / tot["valu"], n, b["valu"],
                     " ".join("%s(%d)" % (a.replace("pt_kernel.h", "k").replace("pt_device.h", "d").replace("pt_coop.h", "c").replace("__clang_hip_math.h", "m"), c) for a, c in top)))
+        if UNIT == "pt_kernels_list" and "pt_trace_kernel" in k:
+            # sections by SOURCE: a block belongs to the section most of its unambiguous lines belong to
+            lookup = section_of_line_table()
+            secs_all = [key for key in tot if key.startswith("sec_valu_")]
+            by_sec, on_sec, all_sec = collections.Counter(), collections.Counter(), collections.Counter()
+            for dv, n, b, on in rows[k]:
+                votes = collections.Counter()
+                for loc, c in b["lines"].items():
+                    sec = lookup(loc)
+                    if sec: votes[sec] += c
+                if votes:
+                    sec = votes.most_common(1)[0][0]
+                else:
+                    # only shared helpers (pt_device.h: RNG steps, square roots, sines ...): where the block LIES in the assembly, by the
+                    # cycle-counter reads of a -DPT_SECTIONS build that precede it (BBPROF_DEFS; hot helper blocks stay in line)
+                    marks = b.get("sec_valu", {})
+                    idx = int(max(marks.items(), key=lambda kv: kv[1])[0]) if marks else -1
+                    sec = {1: "refill", 2: "camera + rejection loop", 3: "ray features", 4: "ray features", 5: "tiles: always-tested spheres, masks, MFMA loop",
+                           6: "phase 2: balanced exact tests", 7: "shade", 8: "shade", 9: "hand-over + worker (pt_coop.h)", 10: "hand-over + worker (pt_coop.h)"}.get(idx, "(unattributed)") if len(secs_all) > 1 else "(shared helpers only: unattributed)"
+                by_sec[sec] += dv
+                on_sec[sec] += on * b["valu"]
+                all_sec[sec] += n * (b["valu"] + b["salu"] + b["lds"] + b["mfma"] + b["vmem"])
+            alli = sum(all_sec.values())
+            print("   -- instructions by section of the main loop (a basic block counts for the section most of its own source lines lie in)")
+            for sec, v in by_sec.most_common():
+                print("   %-50s valu %5.2f%%  lanes on %4.1f  all instructions %5.2f%%" % (sec, 100.0 * v / tot["valu"], on_sec[sec] / max(v, 1), 100.0 * all_sec[sec] / max(alli, 1)))
+        secs = sorted((int(key[len("sec_valu_"):]) for key in tot if key.startswith("sec_valu_")))
+        if len(secs) > 1:
+            print("   -- instructions by SECTION (index = cycle-counter reads that precede the instruction in the assembly): share of VALU, lanes on, share of all instructions")
+            alli = sum(v for key, v in tot.items() if key.startswith("sec_all_"))
+            for sidx in secs:
+                v = tot["sec_valu_%d" % sidx]
+                print("   section %2d  valu %5.2f%%  lanes on %4.1f  all instructions %5.2f%%" % (sidx, 100.0 * v / tot["valu"], tot["sec_lane_on_%d" % sidx] / max(v, 1), 100.0 * tot["sec_all_%d" % sidx] / max(alli, 1)))
         print("   -- blocks by dynamic VALU")
         for dv, n, b, _on in sorted(rows[k], key=lambda r: -r[0])[:45]:
             top = sorted(b["lines"].items(), key=lambda kv: -kv[1])[:5]
