@@ -365,31 +365,20 @@ int pt_scene_debug_tree(pt_scene *scene, void *nodes_out, size_t capacity_bytes)
  * binary tree). Tests check that every packed box contains the 128-byte node's box. */
 int pt_scene_debug_tree_packed(pt_scene *scene, void *nodes_out, size_t capacity_bytes, uint32_t *usable_out);
 
-/* Tuning knobs (0 = library default): workgroups resident per CU for the persistent grid, and a
- * kernel-variant bit mask (DESIGN.md "kernel variants"): 1 = scan table from HBM/L2 instead of LDS,
- * 2 = attenuation stack in HBM (MFMA kernels: 3 x 256 threads per CU instead of 1 x 768),
- * 4 = disable the MFMA prefilter (exact VALU scan), 8 = verify mode,
- * 32 = no heavy-first tile ordering, 64 = never walk the internal tree in list mode (forces the scan),
- * 128 = trace Sphere + MovingSphere worlds with the general kernel instead of the MOVING sphere kernels,
- * 256 = use_bvh worlds always walk the internal tree (default: the MFMA list kernel + ancestor gate when it fits),
- * 1024 = the MFMA kernels run every sphere tile for every wave (no tile culling),
- * 2048 = the tree kernels walk the binary internal tree (host-built) instead of the 4-wide one,
- * 8192 = every frame measures its own work order. Default: a frame of the SAME view as the scene's last one (equal pt_params,
- *        pt_camera and shard) is ordered by the rays each tile took in that last frame, measured by the frame kernel itself;
- *        a frame of a new view (from 12 samples on) runs as two launches, the first tracing the first sample of every pixel for
- *        real while it counts the rays per tile. The order of the work never changes a pixel or the ray count.
- * 65536 = no cooperative hand-over. Default on the wide (one workgroup per CU) MFMA list kernels: once the work list is dry, a wave
- *        that has run out of pixels finishes pixels handed over by waves that still have some, all 64 lanes on each ray
- *        (csrc/pt_coop.h; scene.rs:96-111 makes a pixel one serial chain, and this shortens the chain). A pixel's RNG stream
- *        travels with it: who traces a pixel never changes it.
- * 262144 = the measuring launch of a new view traces every tile. Default on the MFMA list kernels: it traces one colour of a checkerboard
- *        of 8x8 tiles; a tile of the other colour takes the mean of its measured neighbours as its cost and starts at its first sample
- *        in the second launch (measuring launch + order of config 3: 0.30 -> 0.23 ms).
- * 131072 = general-world kernel: the colour of a Noise texture (texture.rs:86-88) is evaluated where the surface is hit, by every lane
- *        for itself. Default for worlds with Noise textures: a Lambertian / Isotropic scatter keeps the hit POINT, and the colour is formed
- *        only when the path ends on something that is not black, by the whole wave for all such lanes (csrc/pt_world.h LAZY). A path
- *        that ends in black multiplies each of its (finite) attenuations by zero (scene.rs:62-64): 0 + a * 0 = 0, the same bits.
- * (Bits 4096, 16384 and 32768 of earlier versions were A/B switches of settled questions and are ignored.) */
+/* Tuning (0 = library default for both arguments): workgroups resident per CU for the persistent grid, and a word of flags.
+ * Two flags are meant for integrators:
+ *   PT_TUNE_MEASURE_EVERY_FRAME  every frame measures its own work order. Default: a frame of the SAME view as the scene's last one (equal
+ *        pt_params, pt_camera and shard) is ordered by the rays each 8x8 tile took in that last frame, measured by the frame kernel itself;
+ *        a frame of a new view (from 12 samples on) runs as two launches, the first tracing the first sample of its pixels for real while it
+ *        counts the rays per tile. Set it when consecutive frames are unrelated although their parameters are equal (a benchmark of
+ *        "one frame of an unseen view"); the order of the work never changes a pixel or the ray count.
+ *   PT_TUNE_NO_HANDOVER  no cooperative hand-over. Default on the wide (one workgroup per CU) list kernels: once the work list is dry, a wave
+ *        that has run out of pixels finishes pixels handed over by waves that still have some, all 64 lanes on each ray (scene.rs:96-111
+ *        makes a pixel one serial chain, and this shortens it). A pixel's RNG stream travels with it: who traces a pixel never changes it.
+ * Every other bit is a development switch (A/B measurements, parity tests of the kernel variants -- all variants render identical frames);
+ * they are listed in pathtrace-rs_amd/csrc/pt_devknobs.h and may change between versions. */
+#define PT_TUNE_MEASURE_EVERY_FRAME 8192u
+#define PT_TUNE_NO_HANDOVER 65536u
 int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
 
 /* Which kernel a frame runs on, and with what geometry (csrc/pt_select.h; DESIGN.md "kernel selection"). family: 0 general-world
@@ -401,9 +390,9 @@ typedef struct pt_kernel_choice {
     uint32_t stack_in_lds, global_stack, n_tiles;     /* attenuation-stack slots in LDS, some levels in HBM, MFMA tiles */
     uint32_t world_hit_lds, world_occ, world_media;   /* general-world kernel: <BVH = ref_bvh, HIT_LDS, OCC, MEDIA> */
     uint32_t refill_min;
-    uint32_t coop;                                    /* wide MFMA list kernels: waves that run out of work finish pixels handed over by busy ones, 64 lanes per ray (tuning bit 65536 switches it off) */
+    uint32_t coop;                                    /* wide MFMA list kernels: waves that run out of work finish pixels handed over by busy ones, 64 lanes per ray (PT_TUNE_NO_HANDOVER switches it off) */
     uint32_t world_graph;                             /* general-world kernel: the world is a scene graph that does not flatten and is interpreted (csrc/pt_graph.h) */
-    uint32_t world_lazy;                              /* general-world kernel, worlds with Noise textures: a scatter's Noise colour is formed when its path ends lit, by the whole wave (tuning bit 131072 switches it off) */
+    uint32_t world_lazy;                              /* general-world kernel, worlds with Noise textures: a scatter's Noise colour is formed when its path ends lit, by the whole wave (a development switch turns it off: csrc/pt_devknobs.h kVarWorldEager) */
     char name[96];
 } pt_kernel_choice;
 /* The choice the scene's most recent render made. */
@@ -415,12 +404,17 @@ int pt_debug_select(const pt_scene_desc *sphere_desc, const pt_world_desc *world
                     const pt_camera *camera, uint32_t shard_count, uint32_t blocks_per_cu, uint32_t variant,
                     pt_kernel_choice *out);
 
-/* Verify-mode counters of the MFMA prefilter (variant bit 8): out4 = { exact-positive pairs the
+/* The kernel instantiations that choice launches, as the symbols of their host-side launch stubs (frame kernel; measuring kernel, or ""
+ * when the work is not ordered by one): for the thread's last successful pt_debug_select. Tests hold the union over many descriptions
+ * against the stubs the shared object defines, so that no instantiation is carried that nothing selects. */
+int pt_debug_last_kernel_symbols(char *frame_out, char *measure_out, size_t capacity);
+
+/* Verify-mode counters of the MFMA prefilter (verify mode: csrc/pt_devknobs.h kVarVerify = 8): out4 = { exact-positive pairs the
  * prefilter failed to flag (must be 0), queued candidates, queue-overflow fallbacks, exact-positive
  * pairs }. Synchronises the device. */
 int pt_scene_debug_counters(pt_scene *scene, uint64_t out4[4], int reset);
 
-/* Traversal counters of the tree kernels in verify mode (variant bit 8 with use_bvh, or a list world large enough
+/* Traversal counters of the tree kernels in verify mode (verify mode, kVarVerify = 8, with use_bvh, or a list world large enough
  * to walk the internal tree): out2 = { nodes of the internal tree fetched, spheres tested exactly } summed over
  * all rays since the last reset (reported next to the oracle's counts for the caller's tree). */
 int pt_scene_traversal_counters(pt_scene *scene, uint64_t out2[2], int reset);

@@ -1,5 +1,7 @@
 // pt_api.hip -- the small entry points of the C ABI: errors, identification, tuning, timing and debug getters, the device
 // self-test probes, and pt_debug_select (kernel selection for a description, no GPU needed).
+#include <dlfcn.h>
+
 #include "pt_device.h"
 #include "pt_host.h"
 #include "pt_world.h"   // logf_ref (the probe of constant_medium.rs:60's ln)
@@ -145,6 +147,8 @@ extern "C" int pt_last_launch_info(pt_scene *s, uint32_t *grid_out, uint32_t *bl
 }
 
 namespace {
+thread_local ptsel::KernelChoice g_debug_choice;
+thread_local bool g_debug_choice_valid = false;
 void fill_choice(const ptsel::KernelChoice &c, pt_kernel_choice *out) {
     memset(out, 0, sizeof *out);
     out->family = (uint32_t)c.family;
@@ -227,6 +231,33 @@ extern "C" int pt_debug_select(const pt_scene_desc *sphere_desc, const pt_world_
         ptsel::select_kernel(tr, *params, camera->time0, camera->time1, local_rows, knobs, 4u, c);
     }
     fill_choice(c, out);
+    g_debug_choice = c, g_debug_choice_valid = true;
+    return PT_OK;
+}
+
+// Which instantiations the choice of this thread's last successful pt_debug_select launches: the symbols of the host-side launch stubs of
+// the frame kernel and (sphere kernels whose work is ordered by a measuring launch) of the measuring kernel, "" when there is none.
+// tests/test_host_cpu.py holds the union over many descriptions against the stubs the shared object defines: an instantiation
+// nothing selects is dead weight in a library whose build time and size are its kernels.
+extern "C" int pt_debug_last_kernel_symbols(char *frame_out, char *measure_out, size_t capacity) {
+    if (!frame_out || !measure_out || capacity == 0) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    if (!g_debug_choice_valid) return fail(PT_ERR_INVALID_ARG, "no successful pt_debug_select on this thread yet");
+    const ptsel::KernelChoice &c = g_debug_choice;
+    const void *frame = nullptr, *measure = nullptr;
+    if (c.family == ptsel::Family::World) {
+        frame = reinterpret_cast<const void *>(world_kernel_for(c));
+    } else {
+        SphereKernel f = nullptr, m = nullptr;
+        sphere_kernels_for(c, &f, &m);
+        frame = reinterpret_cast<const void *>(f);
+        if (c.order == ptsel::Order::Measured) measure = reinterpret_cast<const void *>(m);
+    }
+    const auto name_of = [&](const void *fn, char *out) {
+        Dl_info info{};
+        out[0] = 0;
+        if (fn && dladdr(fn, &info) && info.dli_sname) snprintf(out, capacity, "%s", info.dli_sname);
+    };
+    name_of(frame, frame_out), name_of(measure, measure_out);
     return PT_OK;
 }
 

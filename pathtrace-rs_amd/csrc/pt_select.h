@@ -9,6 +9,7 @@
 #include <cstdint>
 
 #include "pt_args.h"
+#include "pt_devknobs.h"
 
 namespace ptsel {
 
@@ -23,24 +24,7 @@ constexpr uint32_t kLdsPerBlockMax = 96u * 1024u;  // exact-scan kernels: leave 
 constexpr uint32_t kListTreeMin = 768u;            // = 24 MFMA tiles: beyond that the fragments no longer fit beside the rest; list worlds walk the tree
 constexpr uint32_t kMaxMfmaTiles = 24u;
 
-// Tuning word (pt_scene_set_tuning): the bits that select code paths. All variants render identical frames.
-enum : uint32_t {
-    kVarScanFromHbm = 1u,        // scan table / tree nodes from HBM/L2 instead of LDS
-    kVarStackInHbm = 2u,         // attenuation stack in HBM (MFMA kernels: 3 x 256 threads per CU)
-    kVarExactScan = 4u,          // exact VALU scan instead of the MFMA prefilter
-    kVarVerify = 8u,             // verify mode: audits prefilter + culling / counts tree work
-    kVarNoStack = 16u,           // (timing experiment)
-    kVarNaturalOrder = 32u,      // no heavy-first work order
-    kVarNoListTree = 64u,        // list worlds never walk the internal tree
-    kVarGeneralMoving = 128u,    // Sphere + MovingSphere worlds on the general kernel
-    kVarBvhOnTree = 256u,        // use_bvh worlds always walk the internal tree
-    kVarNoCulling = 1024u,       // MFMA kernels run every tile
-    kVarBinaryTree = 2048u,      // tree kernels walk the binary tree
-    kVarMeasureEveryFrame = 8192u,   // no reuse of the previous frame's measured tile costs
-    kVarMeasureAllTiles = 262144u,   // MFMA list kernels: the measuring launch of a new view traces EVERY tile (default: one colour of a checkerboard)
-    kVarWorldEager = 131072u,    // general-world kernel: Noise colours where the surface is hit, every lane its own (no LAZY instantiation)
-    kVarNoCoop = 65536u,         // wide list kernels: no hand-over of pixels to idle waves (pt_coop.h)
-};
+// (the bits of the tuning word that select code paths: pt_devknobs.h)
 
 // Facts about a scene that kernel selection may look at. Filled by pt_scene_create*; never changes afterwards
 // (bin_* : the binary internal tree is built the first time a launch needs it).

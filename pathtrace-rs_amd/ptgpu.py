@@ -122,7 +122,7 @@ EXPORTS = [
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
     "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree", "pt_scene_debug_tree_packed",
-    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters", "pt_render_sharded_all", "pt_comm_gather_frame_all", "pt_closest_hit",
+    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_debug_last_kernel_symbols", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters", "pt_render_sharded_all", "pt_comm_gather_frame_all", "pt_closest_hit",
 ]
 COMM_ID_BYTES = 128
 

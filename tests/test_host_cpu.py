@@ -540,3 +540,28 @@ def test_committed_kernel_resource_table_keeps_registers_and_spills_within_the_s
         if name.startswith("pt_trace_kernel<") and flags[-1] == "1024":
             assert vgprs <= 128 and occ == 4, (name, vgprs, occ)
     assert workers == 4
+
+
+def test_fuzzed_descriptions_are_accepted_or_refused_by_name_and_reach_every_instantiation(tmp_path):
+    """A slice of tools/fuzz_desc.cpp against the shipped library (no device needed: pt_debug_select): 60 000 seeded descriptions -- sphere
+    scenes, general worlds, scene graphs, over the thresholds kernel selection looks at -- three quarters of them with out-of-range / wrapped
+    indices, cycles, NULL arrays, NaN radii, DAG blow-ups; every one must come back PT_OK or PT_ERR_INVALID_ARG / PT_ERR_UNSUPPORTED with a
+    message. (tools/sanitize_cpu.sh runs the same program, 10^5 + descriptions, on an ASan + UBSan build of the library's host side:
+    profiles/r05_sanitize.txt.) And the accepted ones, between them, select EVERY kernel instantiation the shared object carries
+    (pt_debug_last_kernel_symbols against `nm`): the library's build time and size are its 68 kernels, none may be dead weight."""
+    exe = str(tmp_path / "fuzz_desc")
+    build = os.path.join(ROOT, "pathtrace-rs_amd", "_build")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "fuzz_desc.cpp"), "-o", exe,
+                           "-L" + build, "-lptgpu", "-Wl,-rpath," + build])
+    out = subprocess.run([exe, "60000", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "every one accepted or refused by name" in out.stdout
+    counts = {int(m.group(1)): int(m.group(2)) for m in re.finditer(r"code (\d+) \([A-Z_]+\): (\d+)", out.stdout)}
+    assert set(counts) <= {0, 1, 4} and sum(counts.values()) == 60000 and counts[0] > 10000 and counts[1] > 10000 and counts.get(4, 0) > 500, counts
+    reached = set(re.findall(r"symbol (\S+) \d+", out.stdout))
+    nm = subprocess.run(["nm", "-D", "--defined-only", os.path.join(build, "libptgpu.so")], capture_output=True, text=True, check=True).stdout
+    # (a kernel's host-side handle is `ns::name<...>`, its launch stub `ns::__device_stub__name<...>`: one of each per instantiation)
+    carried = set(re.findall(r"\b(_ZN5ptdev15pt_(?:trace|world)_kernelI\S+)", nm))
+    stubs = set(re.findall(r"\b_ZN5ptdev30__device_stub__(pt_(?:trace|world)_kernelI\S+)", nm))
+    assert len(carried) == len(stubs) == 68, (len(carried), len(stubs))
+    assert reached == carried, "never selected: %s; selected but not carried: %s" % (sorted(carried - reached), sorted(reached - carried))

@@ -140,8 +140,9 @@ void sphere_case(Rng &r, Case &c) {
 
 void world_case(Rng &r, Case &c, bool graph) {
     tables(r, c, true);
-    const uint32_t n = r.chance(5) ? 0u : 1u + r.below(40);
-    const uint32_t nx = r.below(5);
+    const bool spheres_only = !graph && r.chance(25);          // Sphere + MovingSphere worlds run on the sphere kernels' MOVING instantiations
+    const uint32_t n = r.chance(5) ? 0u : (r.chance(8) ? 500u + r.below(1500) : (spheres_only && r.chance(60) ? 33u + r.below(600) : 1u + r.below(40)));
+    const uint32_t nx = spheres_only ? 0u : r.below(5);
     for (uint32_t i = 0; i < nx; ++i) {
         pt_affine a{};
         for (int q = 0; q < 12; ++q) a.m[q] = (q % 4 == q / 3 || q == 0 || q == 4 || q == 8) ? 1.0f : r.uni(-0.3f, 0.3f), a.inv[q] = a.m[q];
@@ -149,20 +150,21 @@ void world_case(Rng &r, Case &c, bool graph) {
     }
     for (uint32_t i = 0; i < n; ++i) {
         pt_hitable h{};
-        h.kind = r.below(6);
+        h.kind = spheres_only ? r.below(2) : r.below(6);
         h.material = r.below((uint32_t)c.materials.size());
         for (uint32_t tries = 0; tries < 8 && c.materials[h.material].kind == PT_MAT_ISOTROPIC; ++tries) h.material = r.below((uint32_t)c.materials.size());   // (a phase function is no surface)
         h.flip_normals = r.below(2);
         h.transform = (!graph && nx && r.chance(30)) ? (int32_t)r.below(nx) : -1;
         h.medium_material = -1;
-        if (!graph && r.chance(15)) {
+        if (!graph && !spheres_only && r.chance(15)) {
             for (uint32_t m = 0; m < c.materials.size(); ++m)
                 if (c.materials[m].kind == PT_MAT_ISOTROPIC) h.medium_material = (int32_t)m;
             h.density = r.uni(0.01f, 0.5f);
         }
         for (int q = 0; q < 10; ++q) h.p[q] = r.uni(-3.0f, 3.0f);
+        if (spheres_only) h.p[0] = r.uni(-8, 8), h.p[1] = r.uni(0, 2), h.p[2] = r.uni(-8, 8);
         if (h.kind == PT_HIT_SPHERE) h.p[3] = r.uni(0.1f, 1.0f);
-        if (h.kind == PT_HIT_MOVING_SPHERE) h.p[6] = r.uni(0.1f, 1.0f), h.p[7] = 0.0f, h.p[8] = 1.0f;
+        if (h.kind == PT_HIT_MOVING_SPHERE) h.p[3] = 0.0f, h.p[4] = r.uni(0.0f, 0.5f), h.p[5] = 0.0f, h.p[6] = r.uni(0.1f, 1.0f), h.p[7] = 0.0f, h.p[8] = 1.0f;
         c.hitables.push_back(h);
     }
     if (graph && n) {
@@ -191,11 +193,37 @@ void world_case(Rng &r, Case &c, bool graph) {
             }
         }
         // the root: a list over a few of the nodes
-        const uint32_t cnt = 1 + r.below(5);
+        const uint32_t cnt = r.chance(10) ? 400u + r.below(1200) : 1 + r.below(5);   // (now and then more list entries than the LDS holds records)
         pt_node root{PT_NODE_LIST, (uint32_t)c.children.size(), cnt, 0.0f};
-        for (uint32_t j = 0; j < cnt; ++j) c.children.push_back(r.below((uint32_t)c.nodes.size()));
+        const bool with_bvh = r.chance(30);   // a BVH over the root list: its leaves index the list's children, each of which must flatten to ONE entry
+        std::vector<uint32_t> kids;
+        for (uint32_t j = 0; j < cnt; ++j) {
+            if (!with_bvh) {
+                kids.push_back(r.below((uint32_t)c.nodes.size()));
+                continue;
+            }
+            uint32_t node = r.below(n);                                     // a leaf shape ...
+            for (uint32_t lv = r.below(3); lv > 0 && nx; --lv) {            // ... below up to two Instance levels
+                c.nodes.push_back(pt_node{PT_NODE_INSTANCE, r.below(nx), node, 0.0f});
+                node = (uint32_t)c.nodes.size() - 1u;
+            }
+            kids.push_back(node);
+        }
+        root.a = (uint32_t)c.children.size();
+        for (uint32_t k : kids) c.children.push_back(k);
         c.nodes.push_back(root);
         c.root_node = (uint32_t)c.nodes.size() - 1u;
+        if (with_bvh) {
+            const int32_t top = build_bvh(r, c, 0, cnt);
+            if (top < 0) {
+                pt_bvh_node b{{-1, -1, -1}, {1, 1, 1}, ~0, ~0};
+                c.bvh.push_back(b);
+                c.bvh_root = 0;
+            } else {
+                c.bvh_root = top;
+            }
+            c.params.use_bvh = r.chance(70);
+        }
     } else if (n && r.chance(50)) {
         const int32_t root = build_bvh(r, c, 0, n);
         if (root < 0) {
@@ -288,7 +316,7 @@ int main(int argc, char **argv) {
     const uint64_t seed0 = argc > 2 ? strtoull(argv[2], nullptr, 10) : 1ull;
     signal(SIGALRM, on_alarm);
     std::map<int, uint64_t> by_code;
-    std::map<std::string, uint64_t> by_message, by_kernel;
+    std::map<std::string, uint64_t> by_message, by_kernel, symbols;
     uint64_t mutated = 0;
     for (uint64_t i = 0; i < cases; ++i) {
         g_case = seed0 + i;
@@ -301,6 +329,18 @@ int main(int argc, char **argv) {
         else world_case(r, c, graph);
         for (int q = 0; q < 3; ++q) c.cam.origin[q] = r.uni(-5, 5), c.cam.horizontal[q] = r.uni(-1, 1), c.cam.vertical[q] = r.uni(-1, 1), c.cam.lower_left_corner[q] = r.uni(-1, 1);
         c.cam.time1 = 1.0f;
+        // the coordinates kernel selection looks at, spread over their thresholds (valid values: these are not mutations)
+        if (r.chance(60)) {
+            static const uint32_t depths[] = {1, 3, 10, 26, 27, 40, 41, 64, 65, 200}, spps[] = {1, 4, 11, 12, 16, 64, 256};
+            static const uint32_t sizes[][2] = {{8, 8}, {64, 48}, {200, 100}, {1200, 100}, {1200, 800}, {2400, 1600}};
+            static const uint32_t bits[] = {1, 2, 4, 8, 32, 64, 128, 256, 1024, 2048, 8192, 65536, 131072, 262144};
+            c.params.max_depth = depths[r.below(10)], c.params.samples = spps[r.below(7)];
+            const uint32_t sz = r.below(6);
+            c.params.width = sizes[sz][0], c.params.height = sizes[sz][1];
+            if (r.chance(40)) c.variant = bits[r.below(14)] | (r.chance(30) ? bits[r.below(14)] : 0u);
+            if (r.chance(15)) c.shard_count = 2u + r.below(7);
+            if (r.chance(10)) c.blocks = 1u + r.below(5);
+        }
         c.has_sky = r.below(2);
         const uint32_t n_mut = r.chance(25) ? 0u : 1u + r.below(3);
         for (uint32_t m = 0; m < n_mut; ++m) mutate(r, c, world);
@@ -355,6 +395,11 @@ int main(int argc, char **argv) {
         const char *msg = pt_last_error();
         if (rc == PT_OK) {
             if (po) by_kernel[std::string(out.name)] += 1;
+            char fs[256], ms[256];
+            if (pt_debug_last_kernel_symbols(fs, ms, sizeof fs) == PT_OK) {
+                if (fs[0]) symbols[fs] += 1;
+                if (ms[0]) symbols[ms] += 1;
+            }
         } else if (rc == PT_ERR_INVALID_ARG || rc == PT_ERR_UNSUPPORTED) {
             if (!msg || !msg[0]) {
                 fprintf(stderr, "fuzz_desc: case %llu refused with code %d and NO message\n", (unsigned long long)g_case, rc);
@@ -375,6 +420,8 @@ int main(int argc, char **argv) {
     for (const auto &kv : by_code) printf("  code %d (%s): %llu\n", kv.first, kv.first == 0 ? "PT_OK" : (kv.first == 1 ? "PT_ERR_INVALID_ARG" : "PT_ERR_UNSUPPORTED"), (unsigned long long)kv.second);
     printf("  kernels chosen for the accepted ones:\n");
     for (const auto &kv : by_kernel) printf("    %-40s %llu\n", kv.first.c_str(), (unsigned long long)kv.second);
+    printf("  kernel instantiations the accepted ones launch (launch-stub symbols): %zu\n", symbols.size());
+    for (const auto &kv : symbols) printf("    symbol %s %llu\n", kv.first.c_str(), (unsigned long long)kv.second);
     printf("  refusals by message (digits masked):\n");
     for (const auto &kv : by_message) printf("    %8llu  %s\n", (unsigned long long)kv.second, kv.first.c_str());
     return 0;
