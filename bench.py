@@ -230,8 +230,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path is HIP-only (no CPU fallback)")
+    # Test hooks (tests/test_gpu_parity.py drives THIS script's N > 1 path with two processes on a one-GPU box): every rank on device 0, the
+    # launcher's process group over gloo (real RCCL refuses two ranks on one device), the C ABI's RCCL pinned to the cross-process
+    # test double through PTGPU_RCCL_LIBRARY. None of it is set in a real run.
+    if os.environ.get("PT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("PT_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")   # where the few scalars the ranks reduce among themselves live
     dist = None
     force_dist = os.environ.get("PT_BENCH_FORCE_DIST") == "1"   # exercise the sharded path with one rank (testing)
     if world > 1 or force_dist:
@@ -241,7 +248,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     multi = N > 1 or dist is not None
     S = args.samples if args.samples > 0 else (256 if (multi and args.mode == "tiles") else 64)
 
@@ -365,7 +375,7 @@ def main():
         if overlap:
             kms_list.append(scene.last_kernel_ms())
             pms_list.append(scene.last_pass_ms())
-        t = torch.tensor([el, sum(kms_list) / max(1, len(kms_list)), sum(pms_list) / max(1, len(pms_list))], dtype=torch.float64, device=dev)
+        t = torch.tensor([el, sum(kms_list) / max(1, len(kms_list)), sum(pms_list) / max(1, len(pms_list))], dtype=torch.float64, device=red_dev)
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t[0].item()), float(t[1].item()), float(t[2].item()), int(state["last"]["rays"].item())  # rays already summed over ranks
@@ -393,7 +403,7 @@ def main():
             want = sharding.gather_progressive(dist, ref_full, torch.empty((N, H, W, 3), dtype=torch.float32, device=dev), rc2)
             torch.cuda.synchronize()
         same = bool(torch.equal(got, want)) and int(rc2.item()) == got_rays
-        flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+        flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=red_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if not same:
             diff = (got != want).any(dim=-1)

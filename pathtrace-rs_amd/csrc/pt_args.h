@@ -78,7 +78,7 @@ struct DCamera {  // camera.rs:8-19
 //   [14] tile culling's second axis: cull_u0_2, cull_inv_cell_2, cull_axis2 (u32 bits), -
 constexpr uint32_t kLdsParamBytes = 15u * 16u;
 
-// Bit of a ray's 32-bit tile mask (pt_kernel.h, intersect_list_mfma) that fragment row `row` of a tile ends up in. A lane of
+// Bit of a ray's 32-bit tile mask (pt_prefilter.h, intersect_list_mfma) that fragment row `row` of a tile ends up in. A lane of
 // v_mfma_f32_32x32x16_f16 holds rows (r & 3) + 8 (r >> 2) + 4 * (lane >> 5) in accumulator registers r = 0..15; the kernel shifts
 // the signs in so that register r lands at bit 15 - r, the low half of the wave supplying bits 0..15 and the high half 16..31.
 // tile_sphere is stored in this BIT order, so a candidate bit indexes it directly.

@@ -186,7 +186,7 @@ __global__ void pack_kernel(const DNode4 *nodes, uint32_t n_nodes, const float4 
     packed[i] = q;
     for (uint32_t j = 0; j < 4u; ++j) {
         // A slot without a leaf must never produce a hit: its planes cannot be met while the node-level pad stays below half
-        // the f16 range, but a ray starting ~10^4 units away pads every box by more than that (pt_kernel.h bvh4_trace), and the
+        // the f16 range, but a ray starting ~10^4 units away pads every box by more than that (pt_tree.h bvh4_trace), and the
         // exact test then runs on this record. A NaN centre makes the reference discriminant NaN, which is not > 0.
         const float qnan = __uint_as_float(0x7fc00000u);
         float4 r0 = make_float4(qnan, qnan, qnan, 0.f), r1 = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r1, r3 = r1;

@@ -3,8 +3,8 @@
 // ncclAllReduce of the ray count (scene.rs:118-120). xGMI is point-to-point and the message is small (11.5 MB at 1200x800),
 // so one collective, no ring tuning.
 //
-// RCCL is resolved at RUN time, when the first pt_comm_* function is called: the library already loaded into the process
-// wins (a PyTorch process has its own librccl.so, and two RCCL builds behind one soname must not meet), else the system's.
+// RCCL is resolved at RUN time, when the first pt_comm_* function is called: PTGPU_RCCL_LIBRARY if set, else the library already
+// loaded into the process (a PyTorch process has its own librccl.so, and two RCCL builds behind one soname must not meet), else the system's.
 // The render entry points therefore work on machines without RCCL, and libptgpu.so has no link-time dependency on it.
 #include "pt_host.h"
 
@@ -57,16 +57,23 @@ const Rccl *rccl() {
                 return 0;
             },
             loaded);
-        if (loaded[0]) R.handle = dlopen(loaded, RTLD_NOW | RTLD_NOLOAD);
+        // 0. an explicit choice: PTGPU_RCCL_LIBRARY=/path/to/librccl.so pins the RCCL build this library talks to, whatever else the process
+        //    has loaded (a deployment with several ROCm installations; the tests' cross-process double, tests/mock_rccl/mock_rccl_xproc.hip)
+        const char *pinned = getenv("PTGPU_RCCL_LIBRARY");
+        if (pinned && pinned[0]) {
+            R.handle = dlopen(pinned, RTLD_NOW | RTLD_LOCAL);
+            if (!R.handle) loaded[0] = 0;   // (fall through to the error below: a pinned library that cannot be loaded is not replaced silently)
+        }
+        if (!R.handle && !(pinned && pinned[0]) && loaded[0]) R.handle = dlopen(loaded, RTLD_NOW | RTLD_NOLOAD);
         const char *rocm = getenv("ROCM_PATH");
         char full[2][320];
         snprintf(full[0], sizeof full[0], "%s/lib/librccl.so.1", rocm ? rocm : "/opt/rocm");
         snprintf(full[1], sizeof full[1], "/opt/rocm/lib/librccl.so.1");
         const char *later[] = {"librccl.so.1", full[0], full[1]};
         for (const char *n : later)   // 2. the loader's search path, then the ROCm installation
-            if (!R.handle) R.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (!R.handle && !(pinned && pinned[0])) R.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (!R.handle) {
-            snprintf(why, sizeof why, "RCCL is not available (dlopen librccl.so.1: %s)", dlerror());
+            snprintf(why, sizeof why, "RCCL is not available (dlopen %s: %s)", (pinned && pinned[0]) ? pinned : "librccl.so.1", dlerror());
         } else {
             bool all = true;
 #define PT_RCCL_SYM(field, sym) all = ((R.field = reinterpret_cast<decltype(R.field)>(dlsym(R.handle, sym))) != nullptr) && all

@@ -6,7 +6,7 @@
 // what the end of a frame, the heaviest pixel, and every shard of a multi-GPU frame wait for. Here the 64 lanes of a wave work on
 // ONE ray: each lane tests ceil(n / 64) spheres with the reference's exact arithmetic (sphere.rs:29-66), the winner is the
 // lexicographic minimum of (t, list index) -- or (t, DFS rank) behind the ancestor-AABB gate in a BVH world -- over the wave, which
-// is what hitable_list.rs:40-56 / bvh.rs:37-62 return (pt_kernel.h "order-independent closest hit"), and everything else (camera,
+// is what hitable_list.rs:40-56 / bvh.rs:37-62 return (pt_prefilter.h, DESIGN.md 4.2 "order-independent closest hit"), and everything else (camera,
 // scatter, RNG) is computed redundantly by all lanes on wave-uniform data: a few hundred dependent instructions per ray instead of
 // 2 200. Per ray that is ~15x the work of the per-lane kernel, so it only ever runs on waves that would otherwise idle.
 //

@@ -364,7 +364,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.cull_axis2 = s->cull_axis2, A.cull_u0_2 = s->cull_u0_2, A.cull_inv_cell_2 = s->cull_inv_cell_2;
     memcpy(A.clip_min, s->clip_min, 12), memcpy(A.clip_max, s->clip_max, 12);
     if (A.cull_axis < 3u) {
-        // Per-RAY reach of the reference's f32 discriminant error (pt_kernel.h lane_tile_mask): the kernel pads the clip box and
+        // Per-RAY reach of the reference's f32 discriminant error (pt_prefilter.h lane_tile_mask): the kernel pads the clip box and
         // the segment's extent along the sort axis by sqrt(r_min^2 + kappa (2 |o - c0|^2 + 2 Rs^2 + r_max^2)) - r_min for the
         // ray at hand, so nothing here depends on where the camera is. The constants are rounded up.
         const double kappa = 4.0 * 1.3e-6;

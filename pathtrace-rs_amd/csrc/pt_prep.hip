@@ -138,7 +138,7 @@ bool prepare_mfma(const pt_scene_desc *desc, const MotionIn *motion, double t_lo
     out.n_tiles = (uint32_t)((small.size() + 31) / 32);
     // ---- tile culling: give the tiles a spatial meaning -------------------------------------------------------
     // Spheres of ordinary size are sorted along one axis, so a tile of 32 consecutive ones covers a short interval of
-    // that axis and a wave can skip the tiles no ray of it comes near (pt_kernel.h lane_tile_mask). Oversized spheres
+    // that axis and a wave can skip the tiles no ray of it comes near (pt_prefilter.h lane_tile_mask). Oversized spheres
     // go last; a tile holding any of them is always run. The axis is the one on which the tiles come out narrowest.
     // The order of the prefiltered spheres never affects the image (closest hit by (t, index)).
     if (out.n_tiles >= 4 && out.n_tiles <= 32) {

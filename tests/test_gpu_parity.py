@@ -1771,6 +1771,35 @@ def test_bench_sharded_path_self_check():
         assert "split by rows" in d["config"]["workload"]
 
 
+@pytest.mark.parametrize("ranks,extra", [(2, []), (3, ["--no-overlap"])])
+def test_bench_multi_rank_path_on_one_gpu_behind_the_cross_process_test_double(ranks, extra):
+    """bench.py's OWN N > 1 code path with N processes, started exactly as the driver starts them (python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N): rank 0's unique id travels over the launcher's process
+    group, every rank creates its pt_comm, renders its rows of BASELINE config 4's frame (at a reduced sample count), the shards are
+    exchanged through pt_comm_gather_frame (on a second stream) or pt_render_sharded -- and the script's self-check, which runs before the
+    warm-up on every multi-rank run, finds the gathered frame on EVERY rank equal to that rank's own unsharded render and the reduced ray
+    count equal to the frame's. One GPU only, so: all ranks on device 0, the launcher's group over gloo, and the C ABI's RCCL pinned
+    (PTGPU_RCCL_LIBRARY) to tests/mock_rccl/mock_rccl_xproc.hip, which moves the data through shared memory. Real RCCL stays out of it."""
+    import json
+    import subprocess
+    src, lib = os.path.join(MOCK_RCCL, "mock_rccl_xproc.hip"), os.path.join(MOCK_RCCL, "_build", "librccl_xproc.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-shared", "-fPIC", "-I/opt/rocm/include", src, "-o", lib, "-lrt"])
+    env = dict(os.environ, PT_BENCH_ONE_DEVICE="1", PT_BENCH_BACKEND="gloo", PTGPU_RCCL_LIBRARY=lib)
+    env.pop("PT_BENCH_CHECK", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(29540 + ranks),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--samples", "16", "--no-extras", "--no-cpu-baseline"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "[bench check] tiles frame over %d rank(s) == single-GPU frame on every rank" % ranks in out.stderr
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == ranks and d["scaling"] == "strong" and d["value"] > 0
+    assert d["self_check"]["sharded_equals_single"] is True and d["self_check"]["ranks_seen"] == ranks and d["self_check"]["rccl"] == 29901
+    assert d["config"]["ranks_seen"] == ranks and "mock_rccl" in d["config"]["rccl"]["library"]
+    assert d["self_check"]["rays"] == d["config"]["rays_per_step"]
+
+
 def test_bench_default_line_keeps_the_contract():
     """The one JSON line of `python bench.py` (N = 1): BASELINE's metric on BASELINE's workload, every fraction of the roofline
     block <= 1, the extras present and self-consistent (bench.py asserts that each extra reproduces the headline frame)."""

@@ -510,14 +510,14 @@ def test_scene_graph_nestings_the_list_form_cannot_hold_are_interpreted_and_malf
 
 
 def test_committed_kernel_resource_table_keeps_registers_and_spills_within_the_stated_bounds():
-    """profiles/r04_kernel_resources.txt (`make -C pathtrace-rs_amd resources`: hipcc -Rpass-analysis=kernel-resource-usage on the
+    """profiles/r05_kernel_resources.txt (`make -C pathtrace-rs_amd resources`: hipcc -Rpass-analysis=kernel-resource-usage on the
     four kernel translation units) is the evidence behind DESIGN.md's register claims: every one of the 43 pt_trace_kernel and 25
     pt_world_kernel instantiations is listed; none uses scratch or spills a VGPR EXCEPT the four 1024-thread frame kernels that carry
     the cooperative worker (csrc/pt_coop.h: it saves its sphere registers around a handed-over pixel: <= 160 B, <= 24 VGPRs) and the
     general-world kernel that INTERPRETS a scene graph (csrc/pt_graph.h: the walk is an out-of-line call, <= 128 B of call frame) and its
     four instantiations for five waves per SIMD (96 VGPRs, <= 16 spilled), and
     all 1024-thread prefilter kernels (one workgroup per CU, four waves per SIMD) stay within the 128 registers that occupancy allows."""
-    rows = [l for l in open(os.path.join(ROOT, "profiles", "r04_kernel_resources.txt")).read().splitlines()[1:] if l.strip()]
+    rows = [l for l in open(os.path.join(ROOT, "profiles", "r05_kernel_resources.txt")).read().splitlines()[1:] if l.strip()]
     parsed = []
     for l in rows:
         name, rest = l[:100].strip(), l[100:].split()

@@ -195,29 +195,27 @@ def section_of_line_table():
     """Which section of the MFMA list kernel's main loop a source line belongs to, where that is unambiguous: the kernel body's own lines
     (between its PT_SEC markers) and the functions only one section calls. Lines of shared helpers (pt_device.h: RNG, square roots,
     normalisation ...) are attributed per BASIC BLOCK, by the majority of the block's unambiguous lines."""
-    src = open(os.path.join(PKG, "csrc", "pt_kernel.h")).read().split("\n")
-    def find(text, start=0):
-        for i in range(start, len(src)):
-            if text in src[i]: return i + 1
+    srcs = {f: open(os.path.join(PKG, "csrc", f)).read().split("\n") for f in ("pt_kernel.h", "pt_prefilter.h")}
+    def find(f, text, start=0):
+        for i in range(start, len(srcs[f])):
+            if text in srcs[f][i]: return i + 1
         raise KeyError(text)
-    feat0 = find("__device__ __forceinline__ RayFeat make_ray_features")
-    feat1 = find("// Candidate queue without atomics")
-    clip0 = find("struct TileClip {")
-    mf0 = find("__device__ __forceinline__ int intersect_list_mfma")
-    drain0, drain1 = find("auto drain = [&]() {", mf0), find("    // the always-tested spheres first", mf0)
-    sub6 = find("PT_SUB(6);", mf0)
-    mf1 = find("// bvh.rs:37-62 over the CALLER's tree", mf0)
-    refill0 = find("// ---- refill:")
-    sec0, sec1, sec2, sec3 = find("PT_SEC(0);", refill0), find("PT_SEC(1);", refill0), find("PT_SEC(2);", refill0), find("PT_SEC(3);", refill0)
-    fold0 = find("if (terminal) {", sec2)
-    end = find("#undef PT_DEPTH", sec3)
-    table = []   # (file, first line, last line, section)
-    table += [("pt_kernel.h", refill0, sec0, "refill"), ("pt_kernel.h", sec0 + 1, sec1, "camera + rejection loop"), ("pt_kernel.h", sec1 + 1, sec2, "tiles: always-tested spheres, masks, MFMA loop"),
-              ("pt_kernel.h", sec2 + 1, fold0 - 1, "shade"), ("pt_kernel.h", fold0, sec3, "fold + sample end"), ("pt_kernel.h", sec3 + 1, end, "hand-over + worker (pt_coop.h)"),
-              ("pt_kernel.h", feat0, feat1 - 1, "ray features"), ("pt_kernel.h", clip0, mf0 - 1, "tiles: always-tested spheres, masks, MFMA loop"),
-              ("pt_kernel.h", mf0, drain0 - 1, "tiles: always-tested spheres, masks, MFMA loop"), ("pt_kernel.h", drain0, drain1 - 1, "phase 2: balanced exact tests"),
-              ("pt_kernel.h", drain1, sub6, "tiles: always-tested spheres, masks, MFMA loop"), ("pt_kernel.h", sub6 + 1, mf1 - 1, "phase 2: balanced exact tests"),
-              ("pt_coop.h", 1, 100000, "hand-over + worker (pt_coop.h)")]
+    K, P = "pt_kernel.h", "pt_prefilter.h"
+    feat0 = find(P, "__device__ __forceinline__ RayFeat make_ray_features")
+    feat1 = find(P, "// Candidate queue without atomics")
+    clip0 = find(P, "struct TileClip {")
+    mf0 = find(P, "__device__ __forceinline__ int intersect_list_mfma")
+    drain0, drain1 = find(P, "auto drain = [&]() {", mf0), find(P, "    // the always-tested spheres first", mf0)
+    sub6 = find(P, "PT_SUB(6);", mf0)
+    refill0 = find(K, "// ---- refill:")
+    sec0, sec1, sec2, sec3 = find(K, "PT_SEC(0);", refill0), find(K, "PT_SEC(1);", refill0), find(K, "PT_SEC(2);", refill0), find(K, "PT_SEC(3);", refill0)
+    fold0 = find(K, "if (terminal) {", sec2)
+    end = find(K, "#undef PT_DEPTH", sec3)
+    tiles, phase2 = "tiles: always-tested spheres, masks, MFMA loop", "phase 2: balanced exact tests"
+    table = [(K, refill0, sec0, "refill"), (K, sec0 + 1, sec1, "camera + rejection loop"), (K, sec1 + 1, sec2, tiles), (K, sec2 + 1, fold0 - 1, "shade"),
+             (K, fold0, sec3, "fold + sample end"), (K, sec3 + 1, end, "hand-over + worker (pt_coop.h)"),
+             (P, feat0, feat1 - 1, "ray features"), (P, clip0, mf0 - 1, tiles), (P, mf0, drain0 - 1, tiles), (P, drain0, drain1 - 1, phase2), (P, drain1, sub6, tiles),
+             (P, sub6 + 1, len(srcs[P]), phase2), ("pt_coop.h", 1, 100000, "hand-over + worker (pt_coop.h)")]
     def lookup(loc):
         f, _, ln = loc.rpartition(":")
         f, ln = os.path.basename(f), int(ln)
