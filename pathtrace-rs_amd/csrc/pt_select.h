@@ -212,7 +212,7 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
         lds_levels = 0;
     } else if (bvh && (v & kVarStackInHbm) == 0) {
         const uint32_t wg_regs = tree4 ? tree4_wg_by_regs : 4u;
-        const uint32_t per_block = kLdsBudget / std::min(4u, std::max(1u, wg_regs));
+        const uint32_t per_block = kLdsBudget / std::min(tree4 ? (uint32_t)PT_TREE4_WAVES : 4u, std::max(1u, wg_regs));
         if (per_block > lds) lds_levels = std::min<uint32_t>(stack_levels, (per_block - lds) / (slots * blk * 4u));
     } else if (!bvh && !mfma && (v & kVarStackInHbm) == 0) {
         // Exact-scan kernels (108 VGPRs: four waves per SIMD): FOUR workgroups per CU when all levels -- or all but the deepest two,
@@ -240,7 +240,7 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     // persistent grid: CUs x resident workgroups
     uint32_t bpc = k.blocks_per_cu;
     c.bpc_forced = bpc != 0;
-    if (bpc == 0) bpc = wide ? 1u : ((bvh || scan4) ? 4u : 3u);
+    if (bpc == 0) bpc = wide ? 1u : (tree4 ? (uint32_t)PT_TREE4_WAVES : ((bvh || scan4) ? 4u : 3u));
     const uint32_t lds_limit = lds ? (kLdsBudget / lds) : 8u;
     if (bpc > lds_limit) bpc = lds_limit ? lds_limit : 1u;
     c.bpc = std::min(bpc, 8u);

@@ -17,9 +17,16 @@ namespace ptdev {
 // inside has t >= entry distance (up to rounding, covered by the slack), and the
 // subtree's AABB test itself is the reference's, evaluated with the reference's arithmetic. Equal-t
 // ties are resolved by the precomputed DFS rank of the leaf instead of by visiting order.
-// relative / absolute slack of the distance cull (DESIGN.md "BVH culling slack")
-constexpr float kCullRel = 1.02f;
-constexpr float kCullAbs = 0.02f;
+// Relative / absolute slack of the distance cull. The entry distance of a (padded) box is a GEOMETRIC lower bound of every hit inside it;
+// what the slack has to cover is how far the reference's f32 ROOT (sphere.rs:40: (-b - sqrt(disc)) / a) can fall below the true parameter:
+// ~1e-6 of t for origins far from the sphere (cancellation in -b - sqrt), nothing near it. 5e-4 relative + 5e-4 absolute is two orders
+// above that. (Rounds 1-4 used 2 % + 0.02: at t = 20 every box entered within 0.4 units behind the nearest hit was still visited.)
+#ifndef PT_CULL_REL
+#define PT_CULL_REL 1.0005f
+#define PT_CULL_ABS 5.0e-4f
+#endif
+constexpr float kCullRel = PT_CULL_REL;
+constexpr float kCullAbs = PT_CULL_ABS;
 
 // One leaf of the reference tree: hitable.rs:47 passes the ORIGINAL t_max to the sphere, and the sphere only
 // counts if every ancestor AABB passed aabb.rs:46-58. Ancestor boxes nest (each is the union of its
