@@ -5,7 +5,8 @@ The oracle walks the reference's own tree (bvh.rs:37-62: both children, original
 this scene), so the whole frame costs ~19 core-hours. This script renders it in row blocks, keeps every block's ray
 count in a work directory (resumable: finished blocks are skipped), and writes
     tests/golden/c5_perlin_spheres_1920x1080_128spp_fullframe_bvh.npz
-with the FULL frame's ray count (scene.rs:118-120), the ray count of every block of rows, and every 2 003rd pixel's colour.
+with the FULL frame's ray count (`frame_ray_count`, scene.rs:118-120), the ray count of every block of eight rows, and every 2 003rd pixel's
+colour (+ `ray_count`, the rays of those pixels alone, as in the other fixtures).
     nice -n 19 python tests/golden/make_c5_fullframe.py [--threads 8] [--work /tmp/c5_fullframe]
 """
 import argparse
@@ -46,10 +47,14 @@ def main():
     pixels = np.concatenate([g["pixels"] for g in blocks]).astype(np.uint32)
     rgb = np.concatenate([g["rgb"] for g in blocks]).astype(np.float32)
     assert np.array_equal(pixels, sampled)
+    # (`ray_count` means in every fixture "the rays of the recorded pixels": rendered once more on their own, which also checks the blocks' colours)
+    buf = np.zeros((H, W, 3), np.float32)
+    _, sampled_rays = sc.update(S, DEPTH, 0, buffer=buf, nthreads=a.threads, pixels=sampled)
+    assert np.array_equal(buf.reshape(-1, 3)[sampled], rgb)
     np.savez_compressed(os.path.join(HERE, NAME + ".npz"), preset="perlin_spheres", width=W, height=H, samples=S, depth=DEPTH,
-                        use_bvh=True, pixels=pixels, rgb=rgb, ray_count=np.uint64(block_rays.sum()), block_rows=ROWS,
-                        block_rays=block_rays)
-    print(NAME, "rays", int(block_rays.sum()), "sampled pixels", len(pixels), "mean", rgb.mean(axis=0))
+                        use_bvh=True, pixels=pixels, rgb=rgb, ray_count=np.uint64(sampled_rays), frame_ray_count=np.uint64(block_rays.sum()),
+                        block_rows=ROWS, block_rays=block_rays)
+    print(NAME, "frame rays", int(block_rays.sum()), "sampled pixels", len(pixels), "their rays", sampled_rays, "mean", rgb.mean(axis=0))
 
 
 if __name__ == "__main__":

@@ -369,6 +369,8 @@ def test_golden_fixture(ptgpu, pthost, path, mode):
         assert np.array_equal(got, g["rgb"]), _report(g["rgb"], got)
     if len(g["pixels"]) == W * H:
         assert rays == int(g["ray_count"])
+    if "frame_ray_count" in g.files and mode == "as_recorded":   # the oracle rendered the WHOLE frame for this count (tests/golden/make_c5_fullframe.py: ~19 core-hours for config 5)
+        assert rays == int(g["frame_ray_count"]), "frame ray count %d vs the oracle's %d" % (rays, int(g["frame_ray_count"]))
 
 
 # ---- full BASELINE sizes: sampled pixels + size-independent properties ----------------------------
