@@ -50,6 +50,10 @@
 namespace ptdev {
 
 enum : uint32_t { kCtlWork = 0, kCtlDone = 1, kCtlStarted = 6 };
+#ifndef PT_COOP_PRIO
+#define PT_COOP_PRIO 1
+#endif
+constexpr int kCoopBusyPrio = PT_COOP_PRIO;   // s_setprio of a wave of the wide frame kernels while it is in its main loop (workers: 0)
 constexpr uint32_t kBoxIdle = 1u, kBoxClaimed = 2u, kBoxPixel = 3u;
 
 __device__ __forceinline__ uint32_t ctl_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -355,6 +359,10 @@ __device__ __forceinline__ void coop_worker(const KArgs &A, const GateSrc &G, co
     const uint64_t stamp = (uint64_t)A.tail_gen << 2;
     CoopSpheres mine;
     bool loaded = false;
+    // A worker spends ~15x the instructions per ray of a per-lane wave: it is meant to use issue slots nobody else wants. The SIMD's
+    // arbiter serves the higher priority first: waves still in their main loops run at priority kCoopBusyPrio, workers at 0
+    // (config 3 +0.8 %, 256 spp +0.7 ... 1.6 %, the eighth of config 4 10.86 -> 10.64 ms; priority 3 measured the same: tools/shard_ab.sh).
+    if (kCoopBusyPrio != 0) __builtin_amdgcn_s_setprio(0);
     for (;;) {
         uint32_t kind = 0u;
         if (lane == 0u) {
@@ -380,7 +388,10 @@ __device__ __forceinline__ void coop_worker(const KArgs &A, const GateSrc &G, co
             // with 1 024-cycle naps they were 8 % of ALL VALU instructions of a config-3 frame, each with one lane switched on:
             // tools/bbprof.py, profiles/r04_bbprof_lanes.txt)
             for (uint32_t i = 0; i < nap; ++i) __builtin_amdgcn_s_sleep(64);
-            nap = nap < 4u ? nap * 2u : 4u;
+#ifndef PT_COOP_NAP
+#define PT_COOP_NAP 4u
+#endif
+            nap = nap < PT_COOP_NAP ? nap * 2u : PT_COOP_NAP;
         }
         if (kind == 2u) return;
         // The payload loads below must stay BEHIND the load that saw PIXEL. The hardware keeps them there (the writer drained its
