@@ -654,34 +654,6 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             }
         }
         PT_SEC(3);
-#ifdef PT_COOP_MULTI
-        if (TAIL && tail_polled) {
-            // Hand-over (pt_coop.h), several pixels per iteration: every lane has looked into a mailbox of its own; the lanes at a sample
-            // boundary take, in lane order, the idle workers those looks found (their numbers travel through 64 words of the idle pair
-            // list) and park their pixels there -- RNG stream, colour sum, counters: a pixel's whole state between two samples.
-            const bool idle_l = (uint32_t)tail_probe == ((A.tail_gen << 2) | kBoxIdle) && (uint32_t)(tail_probe >> 32) == (A.tail_gen >> 30);
-            const unsigned long long im = wave_ballot(idle_l);
-            tail_streak = im != 0ull ? tail_streak + 1u : 0u;
-            const uint32_t live = (uint32_t)__popcll(wave_ballot(have));
-            if (im != 0ull && (live <= A.tail_live_max || tail_streak >= A.tail_streak)) {
-                const uint32_t done_s = sd >> 12;
-                const float est = (float)pix_rays * (float)(__float_as_uint(s_par[12].w) - done_s) * __builtin_amdgcn_rcpf((float)done_s);   // rays per sample so far x samples left
-                const bool cand = have && need_cam && est >= A.tail_min_est;   // between two samples (NaN before the first one: not >=)
-                const unsigned long long cm = wave_ballot(cand);
-                if (cm != 0ull) {
-                    if (idle_l) w_pairs[__builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u))] = tail_target;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(cm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cm, 0u));
-                    if (cand && r < (uint32_t)__popcll(im)) {
-                        if (coop_hand_over(A, w_pairs[r], rng, col, pxy, done_s, pix_rays)) have = false;   // (not `finished`: nothing is written, the lane simply holds no pixel any more)
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-#else
         if (TAIL && tail_polled) {
             // Hand-over (pt_coop.h): the list is dry and the probed wave is an idle worker -- the lane at a sample boundary with the
             // most estimated work left parks its pixel (RNG stream, colour sum, counters: the pixel's whole state between two samples)
@@ -701,7 +673,6 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 }
             }
         }
-#endif
         // The loop's only exit, at its very end. (A wave whose refill brought no pixel -- beyond the frame's edge, or the list ran dry --
         // used to skip the body with `continue` / leave with `break` from here up there. The compiler's structurizer turns such an edge
         // into a flag tested after the body, which keeps every loop-carried register's start-of-iteration value alive THROUGH the body:
