@@ -134,7 +134,14 @@ enum {
     PT_HIT_RECT_XY = 2,       /* rect.rs:6-31            p = a0 a1 b0 b1 k: the two in-plane ranges in the variant's */
     PT_HIT_RECT_XZ = 3,       /*                          own order (XY: x,y  XZ: x,z  YZ: y,z) and the plane offset */
     PT_HIT_RECT_YZ = 4,
-    PT_HIT_CUBOID = 5         /* cuboid.rs:4-23          p = p0(3) p1(3); faces derived as Cuboid::new does */
+    PT_HIT_CUBOID = 5,        /* cuboid.rs:4-23          p = p0(3) p1(3); faces derived as Cuboid::new does */
+    PT_HIT_MEDIUM_GROUP = 6   /* constant_medium.rs:11-15 whose BOUNDARY is a HitableList: this entry is the medium (medium_material, density, and in
+                               * `transform` the Instances AROUND it: outer levels only), and the next N entries -- N = the bits of p[0] read as a u32,
+                               * >= 1 -- are the list's children in order: shapes (kinds 0..5) under their own Instance levels (`transform`: inner
+                               * levels only), medium_material = -1. The children are NOT list entries of their own: the scan asks them twice, as the
+                               * medium's boundary (constant_medium.rs:39-43 over hitable_list.rs:40-56), and skips them; BVH leaves may index the
+                               * group's first entry only. `material` of the group entry is ignored. Written by the scene-graph flattener for a
+                               * ConstantMedium node around a List node; accepted in a hand-written list as well. */
 };
 typedef struct pt_hitable {
     uint32_t kind;
@@ -170,8 +177,9 @@ typedef struct pt_image {
  *   - Instance around a HitableList: Instance::ray_hit (instance.rs:32-47) builds the same local ray for every child
  *     and t is shared between the two spaces, so Instance(List(a, b)) = List(Instance(a), Instance(b));
  *   - any depth of Instance around a shape, and around or inside a ConstantMedium (transform chains, see pt_hitable).
- * Not expressible in the list form: a ConstantMedium whose boundary is a HitableList or another ConstantMedium
- * (constant_medium.rs:32-43 asks its boundary twice, and a medium in there draws from the pixel's RNG both times), and a
+ * A ConstantMedium whose boundary is a HitableList of shapes (each under any number of Instances) becomes a PT_HIT_MEDIUM_GROUP entry
+ * followed by its children. Not expressible in the list form: a ConstantMedium whose boundary holds another ConstantMedium or a List
+ * inside a List (constant_medium.rs:32-43 asks its boundary twice, and a medium in there draws from the pixel's RNG both times), and a
  * BVHNode below the root (PT_NODE_BVH: bvh.rs:37-62 as a Hitable anywhere, hitable.rs:12-21). A graph with either is not
  * flattened but INTERPRETED on the device (csrc/pt_graph.h: Hitable::ray_hit as the reference recurses, one stack of frames
  * per lane; correct for every nesting, several times slower than the list form; at most 24 nested ray_hit calls;

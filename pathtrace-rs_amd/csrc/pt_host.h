@@ -246,6 +246,7 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &out);
 struct FlatWorld {
     std::vector<pt_hitable> hit;
     std::vector<pt_affine> xf;
+    std::vector<pt_bvh_node> bvh;   // the caller's BVH with its leaves re-indexed (root-list child -> first list entry of that child)
     pt_world_desc flat{};
     bool interpreted = false;   // the graph does not flatten (pt_graph.h): `flat` is the caller's description, nodes and all
 };

@@ -717,9 +717,41 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
     for (uint32_t i = 0; i < desc->n_textures; ++i) W.has_image = W.has_image || desc->textures[i].kind == PT_TEX_IMAGE;
     W.all_spheres = true, W.sphere_like = true, W.has_media = false;
     W.is_graph = desc->n_nodes != 0;   // (a graph that flattens arrives here without nodes: flatten_world_graph)
+    std::vector<uint8_t> member(desc->n_hitables, 0);   // 1: a child of a PT_HIT_MEDIUM_GROUP (asked through its group only)
+    uint32_t members_left = 0;
     for (uint32_t i = 0; i < desc->n_hitables; ++i) {
         const pt_hitable &h = desc->hitables[i];
+        if (h.kind == PT_HIT_MEDIUM_GROUP) {   // a ConstantMedium around a HitableList: this entry + the next p[0] entries (include/ptgpu.h)
+            uint32_t n_members;
+            memcpy(&n_members, &h.p[0], 4);
+            if (members_left) return fail(PT_ERR_INVALID_ARG, "hitable %u: a medium group inside a medium group", i);
+            if (n_members == 0 || (uint64_t)i + n_members > (uint64_t)desc->n_hitables - 1ull)
+                return fail(PT_ERR_INVALID_ARG, "hitable %u: a medium group of %u entries does not fit the list", i, n_members);
+            if (h.medium_material < 0 || (uint32_t)h.medium_material >= desc->n_materials || desc->materials[h.medium_material].kind != PT_MAT_ISOTROPIC)
+                return fail(PT_ERR_INVALID_ARG, "hitable %u: medium_material must index an Isotropic material", i);
+            if (h.transform >= 0) {   // outer levels only
+                const uint32_t u = (uint32_t)h.transform;
+                if ((u >> 28) != 0u || ((u >> 20) & 15u) != 0u || ((u >> 24) & 15u) == 0u || (uint64_t)(u & 0xfffffu) + ((u >> 24) & 15u) > desc->n_transforms)
+                    return fail(PT_ERR_INVALID_ARG, "hitable %u: transform index / chain out of range", i);
+            }
+            W.has_media = W.has_chains = true;
+            W.all_spheres = W.sphere_like = false;
+            members_left = n_members;
+            continue;
+        }
         if (h.kind > PT_HIT_CUBOID) return fail(PT_ERR_INVALID_ARG, "hitable %u: unknown kind %u", i, h.kind);
+        if (members_left) {   // a child of the group above: a shape under Instance levels of its own
+            members_left -= 1;
+            member[i] = 1;
+            if (h.medium_material >= 0) return fail(PT_ERR_INVALID_ARG, "hitable %u: a medium inside a medium group", i);
+            if (h.transform >= 0) {
+                const uint32_t u = (uint32_t)h.transform, ext = u >> 20;
+                const uint64_t last = ext ? (uint64_t)(u & 0xfffffu) + ((u >> 20) & 15u) : (uint64_t)u + 1u;
+                if (last > desc->n_transforms || (ext && ((u >> 24) != 0u || ((u >> 20) & 15u) == 0u)))
+                    return fail(PT_ERR_INVALID_ARG, "hitable %u: transform index / chain out of range", i);
+            }
+            continue;   // (its material is never looked at: a hit inside the group is the medium's)
+        }
         if (h.material >= desc->n_materials) return fail(PT_ERR_INVALID_ARG, "hitable %u: material index out of range", i);
         if (desc->materials[h.material].kind == PT_MAT_ISOTROPIC)
             return fail(PT_ERR_INVALID_ARG, "hitable %u: Isotropic is only valid as a medium's phase function", i);
@@ -749,6 +781,9 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
         if (!desc->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "bvh_nodes is NULL");
         W.ref_depth = bvh_depth_checked(desc->bvh_nodes, desc->n_bvh_nodes, desc->n_hitables, desc->bvh_root);
         if (W.ref_depth == 0) return fail(PT_ERR_INVALID_ARG, "malformed BVH (bad child index or cycle)");
+        for (uint32_t i = 0; i < desc->n_bvh_nodes; ++i)   // (the children of a medium group are reached through their group only)
+            for (const int32_t c : {desc->bvh_nodes[i].lhs, desc->bvh_nodes[i].rhs})
+                if (c < 0 && member[(uint32_t)~c]) return fail(PT_ERR_INVALID_ARG, "BVH node %u: leaf %d is a child of a medium group", i, ~c);
     }
     if (!(W.sphere_like && desc->n_hitables)) {
         W.sphere_like = false;
@@ -891,11 +926,11 @@ struct Flattener {
         for (uint32_t guard = 0; guard <= d->n_nodes; ++guard) {
             if (n >= d->n_nodes) return fail(PT_ERR_INVALID_ARG, "scene graph: node index %u out of range", n);
             const pt_node &N = d->nodes[n];
-            if (N.kind == PT_NODE_HITABLE) {
+            if (N.kind == PT_NODE_HITABLE || N.kind == PT_NODE_LIST) {   // (a List: the caller emits a medium group, emit_group)
                 *leaf = n;
                 return PT_OK;
             }
-            if (N.kind == PT_NODE_LIST || N.kind == PT_NODE_MEDIUM || N.kind == PT_NODE_BVH) needs_interpreter = true;
+            if (N.kind == PT_NODE_MEDIUM || N.kind == PT_NODE_BVH) needs_interpreter = true;
             if (N.kind != PT_NODE_INSTANCE)
                 return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u is a ConstantMedium whose boundary contains %s (node %u); only Instance levels around one shape can bound a medium",
                             medium_node, node_kind_name(N.kind), n);
@@ -904,6 +939,63 @@ struct Flattener {
             n = N.b;
         }
         return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u is a ConstantMedium whose boundary never reaches a shape (a cycle of Instances)", medium_node);
+    }
+    // A ConstantMedium whose boundary is Instance* (HitableList of Instance* (shape)): one PT_HIT_MEDIUM_GROUP entry (the medium and the
+    // Instances around it) + one entry per child, each under `between` (the Instances between the medium and the list) followed by its own.
+    // Returns PT_ERR_UNSUPPORTED with needs_interpreter set when a child is anything else (a list, a medium, a BVHNode) or a chain is too long.
+    int emit_group(uint32_t medium_node, uint32_t list_node, const std::vector<uint32_t> &outer, const std::vector<uint32_t> &between, int32_t medium_material, float density) {
+        const pt_node &L = d->nodes[list_node];
+        if ((uint64_t)L.a + L.b > d->n_node_children) return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: children [%u, %u) exceed node_children", list_node, L.a, L.a + L.b);
+        if (L.b == 0) {   // an empty boundary never answers: the medium is never hit (constant_medium.rs:39-40) -- nothing to emit
+            return PT_OK;
+        }
+        if (outer.size() > 15 || between.size() > 15) {
+            needs_interpreter = true;
+            return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u sits below %zu Instance levels on one side of a medium; at most 15 are supported", medium_node, outer.size());
+        }
+        struct Child { uint32_t leaf; std::vector<uint32_t> chain; };
+        std::vector<Child> kids;
+        for (uint32_t j = 0; j < L.b; ++j) {
+            uint32_t n = d->node_children[L.a + j];
+            Child c{0u, between};
+            for (uint32_t guard = 0;; ++guard) {
+                if (n >= d->n_nodes) return fail(PT_ERR_INVALID_ARG, "scene graph: node index %u out of range (child of node %u)", n, list_node);
+                const pt_node &N = d->nodes[n];
+                if (N.kind == PT_NODE_HITABLE) break;
+                if (N.kind != PT_NODE_INSTANCE || guard > d->n_nodes || c.chain.size() >= 15) {
+                    needs_interpreter = true;   // (a List, a medium or a BVHNode inside the boundary, a cycle, or more than 15 levels: the interpreter's case -- or its refusal)
+                    return fail(PT_ERR_UNSUPPORTED, "scene graph: node %u is a ConstantMedium whose boundary list (node %u) holds %s (node %u)", medium_node, list_node,
+                                node_kind_name(N.kind), n);
+                }
+                if (N.a >= d->n_transforms) return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: transform index %u out of range", n, N.a);
+                c.chain.push_back(N.a);
+                n = N.b;
+            }
+            c.leaf = n;
+            kids.push_back(std::move(c));
+        }
+        if (out->hit.size() + kids.size() + 1 >= (1u << 20)) return fail(PT_ERR_UNSUPPORTED, "scene graph: flattening yields more than 2^20 list entries (an Instance around a HitableList is distributed over its children)");
+        pt_hitable g{};
+        g.kind = PT_HIT_MEDIUM_GROUP;
+        g.material = 0;
+        g.transform = encode_chain(outer, {});
+        g.medium_material = medium_material;
+        g.density = density;
+        const uint32_t n_members = (uint32_t)kids.size();
+        memcpy(&g.p[0], &n_members, 4);
+        out->hit.push_back(g);
+        for (const Child &c : kids) {
+            const pt_node &Lf = d->nodes[c.leaf];
+            if (Lf.a >= d->n_hitables) return fail(PT_ERR_INVALID_ARG, "scene graph: node %u: hitable index %u out of range", c.leaf, Lf.a);
+            pt_hitable h = d->hitables[Lf.a];
+            if (h.transform >= 0 || h.medium_material >= 0)
+                return fail(PT_ERR_INVALID_ARG, "scene graph: hitable %u carries its own transform / medium; in a graph these are Instance / ConstantMedium nodes", Lf.a);
+            h.transform = encode_chain({}, c.chain);
+            h.medium_material = -1;
+            if (out->xf.size() >= (1u << 20)) return fail(PT_ERR_UNSUPPORTED, "scene graph: flattening needs more than 2^20 transform slots");
+            out->hit.push_back(h);
+        }
+        return PT_OK;
     }
     int emit(uint32_t leaf_node, const std::vector<uint32_t> &outer, const std::vector<uint32_t> &inner, int32_t medium_material, float density) {
         const pt_node &L = d->nodes[leaf_node];
@@ -954,7 +1046,8 @@ struct Flattener {
                 r = fail(PT_ERR_INVALID_ARG, "scene graph: node %u: a ConstantMedium's material %u must index an Isotropic material", n, N.a);
                 break;
             }
-            if ((r = boundary(n, N.b, inner, &leaf)) == PT_OK) r = emit(leaf, chain, inner, (int32_t)N.a, N.density);
+            if ((r = boundary(n, N.b, inner, &leaf)) == PT_OK)
+                r = d->nodes[leaf].kind == PT_NODE_LIST ? emit_group(n, leaf, chain, inner, (int32_t)N.a, N.density) : emit(leaf, chain, inner, (int32_t)N.a, N.density);
             break;
         }
         case PT_NODE_BVH:
@@ -1007,10 +1100,25 @@ int flatten_world_graph(const pt_world_desc *desc, FlatWorld &out, const pt_worl
     out.flat.n_hitables = (uint32_t)out.hit.size(), out.flat.hitables = out.hit.data();
     out.flat.n_transforms = (uint32_t)out.xf.size(), out.flat.transforms = out.xf.data();
     if (desc->n_bvh_nodes) {
-        for (size_t c = 0; c + 1 < first_of_child.size(); ++c)
-            if (first_of_child[c + 1] - first_of_child[c] != 1u)
-                return fail(PT_ERR_UNSUPPORTED, "scene graph: BVH leaves index the root list's children, and child %zu flattens to %u list entries instead of one", c,
-                            first_of_child[c + 1] - first_of_child[c]);
+        if (!desc->bvh_nodes) return fail(PT_ERR_INVALID_ARG, "bvh_nodes is NULL");
+        // BVH leaves index the root list's CHILDREN; each must be one list entry -- or one medium group, whose first entry then stands for it
+        const size_t n_children = first_of_child.size() - 1;
+        for (size_t c = 0; c < n_children; ++c) {
+            const uint32_t span = first_of_child[c + 1] - first_of_child[c];
+            uint32_t members = 0;
+            if (span >= 2u && out.hit[first_of_child[c]].kind == PT_HIT_MEDIUM_GROUP) memcpy(&members, &out.hit[first_of_child[c]].p[0], 4);
+            if (span != 1u && span != members + 1u)
+                return fail(PT_ERR_UNSUPPORTED, "scene graph: BVH leaves index the root list's children, and child %zu flattens to %u list entries instead of one", c, span);
+        }
+        out.bvh.assign(desc->bvh_nodes, desc->bvh_nodes + desc->n_bvh_nodes);
+        for (pt_bvh_node &nd : out.bvh)
+            for (int32_t *c : {&nd.lhs, &nd.rhs})
+                if (*c < 0) {
+                    const uint32_t child = (uint32_t)~*c;
+                    if (child >= n_children) return fail(PT_ERR_INVALID_ARG, "malformed BVH (bad child index or cycle)");
+                    *c = ~(int32_t)first_of_child[child];
+                }
+        out.flat.bvh_nodes = out.bvh.data();
     }
     *use = &out.flat;
     return PT_OK;

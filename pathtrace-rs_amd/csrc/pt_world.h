@@ -378,6 +378,50 @@ __device__ __forceinline__ int w_hitable_t(const pt_hitable &H, const pt_affine 
     }
     return -1;
 }
+// A ConstantMedium whose BOUNDARY is a HitableList (include/ptgpu.h PT_HIT_MEDIUM_GROUP): the header entry `G[0]` carries the medium
+// (phase-function material, density, the Instances AROUND it), the `n` entries behind it are the list's children -- shapes under their own
+// Instance levels, no list entries of their own. constant_medium.rs:39-43 asks the boundary twice, and the boundary answers as
+// hitable_list.rs:40-56 does: children in order, each with t_max = the closest parameter so far. Then constant_medium.rs:44-76 as above.
+// (CHAINS kernels only: worlds with such an entry are selected onto them.)
+__device__ __forceinline__ bool w_group_ask(const pt_hitable *G, uint32_t n, const pt_affine *xf, const WRay &r, float t_min, float t_max, float &t_out) {
+    bool any = false;
+    float closest = t_max;
+    for (uint32_t j = 1; j <= n; ++j) {
+        const pt_hitable &C = G[j];
+        const WChain c = w_chain(C.transform);
+        const WRay local = c.n_in != 0u ? w_ray_into(xf, c.first + c.n_out, c.n_in, r) : r;
+        float t;
+        uint32_t face;
+        if (w_shape_t(C, local, t_min, closest, t, face)) closest = t, any = true;
+    }
+    t_out = closest;
+    return any;
+}
+__device__ __forceinline__ int w_group_t(const pt_hitable *G, uint32_t n, const pt_affine *xf, const WRay &r_in, float t_min, float t_max, Rng &rng, float &t, uint32_t &face) {
+    const pt_hitable &H = G[0];
+    const WChain chain = w_chain(H.transform);
+    const WRay r = chain.n_out != 0u ? w_ray_into(xf, chain.first, chain.n_out, r_in) : r_in;
+    face = 0u;
+    float t_first, t_second;
+    if (!w_group_ask(G, n, xf, r, -kMaxT, kMaxT, t_first)) return -1;
+    if (!w_group_ask(G, n, xf, r, t_first + 0.0001f, kMaxT, t_second)) return -1;   // constant_medium.rs:41
+    float t1 = t_first, t2 = t_second;   // constant_medium.rs:44-76
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return -1;
+    if (t1 < 0.0f) t1 = 0.0f;
+    const float ray_length = length3(r.d);
+    const float distance_inside_boundary = (t2 - t1) * ray_length;
+    const float hit_distance = -(1.0f / H.density) * logf_ref(rng_f32(rng));
+    if (hit_distance < distance_inside_boundary) {
+        t = t1 + hit_distance / ray_length;
+        face = kFaceMedium;
+        return H.medium_material;
+    }
+    return -1;
+}
+__device__ __forceinline__ uint32_t w_group_size(const pt_hitable &H) { return __float_as_uint(H.p[0]); }
+
 // ... second step, for the entry whose hit won: its record at parameter t
 template <bool MEDIA, bool CHAINS>
 __device__ __forceinline__ void w_hitable_rec(const pt_hitable &H, const pt_affine *xf, const WRay &r_in, float t, uint32_t face, WHit &h, bool want_uv) {
@@ -554,11 +598,19 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                 for (uint32_t k = 0; k < A.n_hit; ++k) {
                     float t;
                     uint32_t face;
-                    const int m = w_hitable_t<MEDIA, CHAINS, true>(hit[k], xf, ray, kMinT, closest, rng, t, face);
+                    int m;
+                    uint32_t members = 0u;
+                    if (MEDIA && CHAINS && hit[k].kind == (uint32_t)PT_HIT_MEDIUM_GROUP) {   // (wave-uniform: a medium around a list, its children behind it)
+                        members = w_group_size(hit[k]);
+                        m = w_group_t(hit + k, members, xf, ray, kMinT, closest, rng, t, face);
+                    } else {
+                        m = w_hitable_t<MEDIA, CHAINS, true>(hit[k], xf, ray, kMinT, closest, rng, t, face);
+                    }
                     if (m >= 0) {
                         best_k = k, best_face = face, best_t = t, best_mat = (uint32_t)m, found = true;
                         closest = t;
                     }
+                    k += members;
                 }
             } else {  // bvh.rs:37-62, iterative: lhs subtree, then rhs, both with the original t_max
                 int sp = 0;
@@ -568,7 +620,9 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
                     if (ref < 0) {
                         float t;
                         uint32_t face;
-                        const int m = w_hitable_t<MEDIA, CHAINS>(hit[~ref], xf, ray, kMinT, kMaxT, rng, t, face);
+                        const bool group = MEDIA && CHAINS && hit[~ref].kind == (uint32_t)PT_HIT_MEDIUM_GROUP;
+                        const int m = group ? w_group_t(hit + ~ref, w_group_size(hit[~ref]), xf, ray, kMinT, kMaxT, rng, t, face)
+                                            : w_hitable_t<MEDIA, CHAINS>(hit[~ref], xf, ray, kMinT, kMaxT, rng, t, face);
                         if (m >= 0) {
                             // bvh.rs:48-53: lhs only when lhs.t < rhs.t -> an equal t goes to the later leaf
                             if (!found || !(best_t < t)) best_k = (uint32_t)~ref, best_face = face, best_t = t, best_mat = (uint32_t)m;

@@ -1175,6 +1175,83 @@ def _render_graph_both(ptgpu, oracle, g, W, H, S, depth=10, frame=0):
     return out, rays, ref, ref_rays, choice
 
 
+@pytest.mark.parametrize("bvh", [False, True])
+def test_a_medium_around_a_list_of_shapes_flattens_to_a_group(ptgpu, oracle, bvh):
+    """constant_medium.rs:32-43 with a HitableList as the boundary: the medium asks the list twice ((-MAX, MAX), then (t + 0.0001, MAX)), and the
+    list answers as hitable_list.rs:40-56 does, children in order with the closest parameter so far as t_max. Since round 5 such a medium is a
+    list entry of the general-world kernel (PT_HIT_MEDIUM_GROUP: the medium + its children behind it) instead of a reason to interpret the whole
+    graph: shapes of every kind under Instances of their own, Instances between the medium and the list, Instances around the medium, two
+    groups side by side; as a list world and -- the groups being single leaves of the caller's tree -- as a BVH world. Bit for bit."""
+    W, H, S = 96, 64, 4
+    g = _random_graph_world(oracle, 977, W, H, n_top=4, max_depth=2, wild=False)     # (for its 40 leaf shapes, transforms and tables)
+    mats = [list(r) for r in g["materials"]]
+    mats.append([4, 0, 0, 0, 0, 0])
+    iso = len(mats) - 1
+    rng = np.random.default_rng(5)
+    xfs = []
+    for _ in range(2):    # glam Affine3A (x_axis, y_axis, z_axis, translation) and its inverse, as Instance::new stores them (instance.rs:16-22)
+        m = np.linalg.qr(rng.normal(size=(3, 3)))[0] * rng.uniform(0.8, 1.25, 3)
+        t = rng.uniform(-0.7, 0.7, 3)
+        m32, t32 = m.astype(np.float32), t.astype(np.float32)
+        inv = np.linalg.inv(m32.astype(np.float64))
+        xfs.append(np.concatenate([m32.T.reshape(-1), t32, inv.astype(np.float32).T.reshape(-1), (-(inv @ t32.astype(np.float64))).astype(np.float32)]))
+    g = dict(g, transforms=np.array(xfs, np.float32).reshape(-1, 24))
+    n_xf = 2
+    nodes, children = [], []
+
+    def add(kind, a, b, density=0.0):
+        nodes.append([kind, a, b, int(np.float32(density).view(np.uint32))])
+        return len(nodes) - 1
+
+    def lst(kids):
+        first = len(children)
+        children.extend(kids)
+        return add(1, first, len(kids))
+
+    leaf = [add(0, i, 0) for i in range(12)]
+    inner_a = lst([leaf[0], add(2, 0, leaf[1]), add(2, 1, add(2, 0, leaf[2])), leaf[3]])       # shapes, Instance(shape), Instance(Instance(shape))
+    group_a = add(2, 1 % n_xf, add(3, iso, add(2, 0, inner_a), 0.45))                        # Instance(Medium(Instance(List)))
+    group_b = add(3, iso, lst([leaf[4], leaf[5]]), 0.2)                                      # Medium(List(a, b)), no Instances
+    tops = [leaf[6], group_a, leaf[7], group_b, add(2, 0, leaf[8])]
+    if not bvh:
+        root = lst(tops)
+        gg = dict(g, materials=np.array(mats, np.float32), nodes=np.array(nodes, np.uint32), node_children=np.array(children, np.uint32), root_node=root,
+                  bvh_minmax=np.zeros((0, 6), np.float32), bvh_children=np.zeros((0, 2), np.int32))
+        out, rays, ref, ref_rays, choice = _render_graph_both(ptgpu, oracle, gg, W, H, S, depth=10)
+    else:
+        # the caller's tree over the five children of the root list: ((0 1) (2 (3 4))), boxes generous (both sides take them as given)
+        box = [-60, -60, -60, 60, 60, 60]
+        root_list = lst(tops)
+        # oracle: the same tree as BVHNode NODES of the graph (rows hold node indices), rooted at the top node
+        o_nodes, o_children = [list(r) for r in nodes], list(children)
+        rows = []
+
+        def bnode(l, r):
+            rows.append([l, r])
+            o_nodes.append([4, len(rows) - 1, 0, 0])
+            return len(o_nodes) - 1
+
+        top = bnode(bnode(tops[0], tops[1]), bnode(tops[2], bnode(tops[3], tops[4])))
+        osc = oracle.OracleScene.from_graph(g["hitables"], g["transforms"], np.array(mats, np.float32), g["textures"], g["camera"], W, H, np.array(o_nodes, np.uint32),
+                                            np.array(o_children, np.uint32), top, sky=g["sky"], bvh_minmax=np.array([box] * len(rows), np.float32),
+                                            bvh_children=np.array(rows, np.int32))
+        ref, ref_rays = osc.update(S, max_depth=10, frame_num=0)
+        # product: the root LIST + bvh_nodes whose leaves index its children, rendered with use_bvh
+        p_rows = [[~0, ~1], [~3, ~4], [~2, 1], [0, 2]]     # node 3 is the root
+        materials = [(int(r[0]), r[1:4], r[4], int(r[5])) for r in np.array(mats, np.float32)]
+        textures = [(int(r[0]), r[1:4], int(r[4]), int(r[5]), r[6]) for r in g["textures"]]
+        desc = ptgpu.WorldDesc(g["hitables"], g["transforms"], materials, textures, sky=g["sky"], nodes=np.array(nodes, np.uint32), node_children=np.array(children, np.uint32),
+                               root_node=root_list, bvh_nodes=(np.array([box] * 4, np.float32), np.array(p_rows, np.int32)), bvh_root=3)
+        sc = ptgpu.Scene(desc, 0)
+        out = np.zeros((H, W, 3), np.float32)
+        rays = sc.update(ptgpu.PtParams(W, H, S, 10, 0, 1), ptgpu.PtCamera.from_floats(g["camera"]), 0, out)
+        choice = sc.last_kernel_choice()
+        sc.close()
+    assert choice["world_graph"] == 0 and "chains" in choice["name"] and choice["ref_bvh"] == (1 if bvh else 0), choice
+    assert rays == ref_rays, "ray_count %d vs oracle %d; %s" % (rays, ref_rays, _report(ref, out))
+    assert np.array_equal(ref, out, equal_nan=True), _report(ref, out)
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_scene_graphs_that_do_not_flatten_are_interpreted(ptgpu, oracle, seed):
     """A ConstantMedium whose boundary is a HitableList or another medium (constant_medium.rs:32-43 asks the boundary twice; a medium

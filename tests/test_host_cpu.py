@@ -447,11 +447,16 @@ def test_scene_graph_nestings_the_list_form_cannot_hold_are_interpreted_and_malf
     assert ok["name"].startswith("world<")
     # a List of plain spheres inside a List is still a sphere world (exact scan: three spheres)
     assert select([[0, 0, 0, 0], [0, 1, 0, 0], [0, 2, 0, 0], [1, 0, 2, 0], [1, 2, 2, 0]], [0, 1, 3, 2], 4)["name"] == "scan-lds<blk=256>"
-    # what the list form cannot express is INTERPRETED (csrc/pt_graph.h): a ConstantMedium around a HitableList, around another medium,
-    # a BVHNode below the root (its row of bvh_nodes holds the box and two NODE indices)
+    # a ConstantMedium around a HitableList of shapes flattens to a medium GROUP (PT_HIT_MEDIUM_GROUP + its children; round 5) and runs on the
+    # general kernel's `chains` instantiation ...
     med_list = ([[0, 0, 0, 0], [0, 1, 0, 0], [1, 0, 2, 0], [3, 1, 2, dens], [1, 2, 1, 0]], [0, 1, 3], 4)
+    d = select(*med_list)
+    assert d["world_graph"] == 0 and d["name"] == "world<bvh=0,hit_lds=1,occ=3,media=1,chains>", d
+    # ... what the list form still cannot express is INTERPRETED (csrc/pt_graph.h): a medium around another medium, a medium around a List
+    # that holds a List or a medium, a BVHNode below the root (its row of bvh_nodes holds the box and two NODE indices)
     med_med = ([[0, 0, 0, 0], [3, 1, 0, dens], [3, 1, 1, dens], [1, 0, 1, 0]], [2], 3)
-    for nodes, children, root in (med_list, med_med):
+    med_list_list = ([[0, 0, 0, 0], [0, 1, 0, 0], [1, 0, 2, 0], [1, 2, 1, 0], [3, 1, 3, dens], [1, 3, 1, 0]], [0, 1, 2, 4], 5)   # List(Medium(List(List(a, b))))
+    for nodes, children, root in (med_med, med_list_list):
         d = select(nodes, children, root)
         assert d["world_graph"] == 1 and d["name"] == "world<bvh=0,hit_lds=0,occ=3,media=1,graph>" and d["world_lazy"] == 0, d
     box = (np.array([[-1, -1, -1, 5, 1, 1]], np.float32), np.array([[0, 1]], np.int32))
@@ -473,8 +478,11 @@ def test_scene_graph_nestings_the_list_form_cannot_hold_are_interpreted_and_malf
     with pytest.raises(ptgpu.PtError) as e:                  # BVHNode row out of range
         select_bvh([[0, 0, 0, 0], [4, 3, 0, 0], [1, 0, 1, 0]], [1], 2, box)
     assert e.value.code == ptgpu.PT_ERR_INVALID_ARG and "BVHNode row" in str(e.value)
-    # the interpreted walk keeps one frame per nested ray_hit call: 24. List(Instance^k(Medium(List(a, b)))) needs k + 4
+    # the interpreted walk keeps one frame per nested ray_hit call: 24. List(Instance^k(Medium(List(a, b)))) needs k + 4 -- and flattens to a
+    # group while the k Instance levels around the medium fit a chain (15)
     deep = lambda k: ([[0, 0, 0, 0], [0, 1, 0, 0], [1, 0, 2, 0], [3, 1, 2, dens]] + [[2, 0, 3 + i, 0] for i in range(k)] + [[1, 2, 1, 0]], [0, 1, 3 + k], 4 + k)
+    assert select(*deep(15))["world_graph"] == 0
+    assert select(*deep(16))["world_graph"] == 1
     assert select(*deep(20))["world_graph"] == 1
     with pytest.raises(ptgpu.PtError) as e:
         select(*deep(21))

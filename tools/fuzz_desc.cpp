@@ -266,7 +266,19 @@ void mutate(Rng &r, Case &c, bool world) {
     case 19: c.shard_count = r.chance(50) ? 0u : (r.chance(50) ? 65537u : bad); break;
     case 20: c.null_mask |= 1u << r.below(12); break;
     case 21: c.variant = r.next(); c.blocks = r.chance(50) ? r.below(64) : bad; break;
-    case 22: if (!c.hitables.empty()) pick(r, c.hitables).kind = r.chance(50) ? 6u : bad; break;
+    case 22: if (!c.hitables.empty()) {   // an unknown kind -- or a medium group (PT_HIT_MEDIUM_GROUP) with a plausible / wild member count
+        pt_hitable &h = pick(r, c.hitables);
+        if (r.chance(40)) { h.kind = r.chance(50) ? 7u : bad; break; }
+        h.kind = PT_HIT_MEDIUM_GROUP;
+        const uint32_t left = (uint32_t)(c.hitables.data() + c.hitables.size() - &h) - 1u;
+        const uint32_t n = r.chance(60) ? (left ? 1u + r.below(left) : 0u) : (r.chance(50) ? left + 1u + r.below(3) : bad);
+        memcpy(&h.p[0], &n, 4);
+        h.density = r.uni(0.05f, 0.5f);
+        h.transform = -1;
+        for (uint32_t m = 0; m < c.materials.size(); ++m)
+            if (c.materials[m].kind == PT_MAT_ISOTROPIC && r.chance(80)) h.medium_material = (int32_t)m;
+        break;
+    }
     case 23: if (!c.hitables.empty()) pick(r, c.hitables).material = r.chance(50) ? (uint32_t)c.materials.size() : bad; break;
     case 24: if (!c.hitables.empty()) pick(r, c.hitables).transform = r.chance(30) ? (int32_t)c.transforms.size() : (int32_t)(r.below(4) | (r.below(16) << 20) | (r.below(16) << 24) | (r.chance(20) ? 0x80000000u : 0u)); break;
     case 25: if (!c.hitables.empty()) { pt_hitable &h = pick(r, c.hitables); h.medium_material = r.chance(30) ? (int32_t)c.materials.size() : (r.chance(50) ? (int32_t)r.below((uint32_t)c.materials.size()) : (int32_t)bad); h.density = bf; } break;
