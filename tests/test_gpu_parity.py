@@ -1869,7 +1869,14 @@ def test_bench_multi_rank_path_on_one_gpu_behind_the_cross_process_test_double(r
     env.pop("PT_BENCH_CHECK", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(29540 + ranks),
            os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--samples", "16", "--no-extras", "--no-cpu-baseline"] + extra
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    try:
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    finally:
+        for f in glob.glob("/dev/shm/mock_rccl_*"):    # (the last rank to leave unlinks the segment; a run that died half-way cannot)
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     assert "[bench check] tiles frame over %d rank(s) == single-GPU frame on every rank" % ranks in out.stderr
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
