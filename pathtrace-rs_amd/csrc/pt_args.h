@@ -110,6 +110,13 @@ struct KArgs {
     const float4 *gate_chain;    // ancestors whose test is not implied by the box below them (inverted boxes only)
     const uint32_t *bvh_large;   // spheres kept out of the internal tree (huge radius): tested for every ray
     uint32_t n_bvh_large;
+    // uniform cell grid (pt_grid.h; pt_host.h GridPlan): non-NULL grid_cells selects it in the 4-wide tree kernels
+    const uint4 *grid_cells;     // [n_records][5]: four spheres (cx, cy, cz, radius) + (index x 4 | link in the last word)
+    const uint32_t *grid_large;  // spheres outside the grid: tested for every ray
+    uint32_t n_grid_large, grid_records;
+    uint32_t grid_n[3];
+    float grid_min[3], grid_h, grid_inv_h;
+    float grid_centre[3], grid_half_diag, grid_d_build, grid_infl, grid_rmax2;
     uint32_t n_spheres;
     uint32_t n_spheres_pad;      // multiple of kScanUnroll; padding entries can never be hit
     // MFMA discriminant prefilter (list mode, see "MFMA prefilter" below); n_tiles == 0 disables it

@@ -30,6 +30,7 @@ enum : uint32_t {
     kVarMeasureAllTiles = 262144u,   // MFMA list kernels: the measuring launch of a new view traces EVERY tile. Default: one colour of a checkerboard of
                                      // 8x8 tiles; a tile of the other colour takes the mean of its measured neighbours as its cost and starts at its
                                      // first sample in the second launch (measuring launch + order of config 3: 0.30 -> 0.23 ms)
+    kVarNoGrid = 524288u,        // tree kernels always walk the 4-wide tree (default: the uniform cell grid of pt_grid.h when the scene has one)
     // (4096, 16384 and 32768 were A/B switches of questions settled in rounds 2-3 and are ignored)
 };
 

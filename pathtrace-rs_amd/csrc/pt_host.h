@@ -65,6 +65,11 @@ int upload(T **dst, const void *src, size_t count) {
 
 }  // namespace pthostside
 
+struct pthostside_grid_geom {   // the scalars of a GridPlan the launch copies into KArgs
+    uint32_t n[3], n_records, n_large;
+    float gmin[3], h, centre[3], half_diag, d_build, infl, rmax2;
+};
+
 // ---- the scene handle ------------------------------------------------------------------------------------------------
 struct pt_scene {
     int device = 0;
@@ -88,6 +93,9 @@ struct pt_scene {
     ptdev::DNode4 *d_nodes4 = nullptr;               // 4-wide internal tree (default of the tree kernels), built on the device
     ptdev::DNode4Q *d_nodes4q = nullptr;             // ... as the packed 64-byte nodes the kernels read (pt_tree4.h), and the leaves' slot records
     float4 *d_slotrec = nullptr;
+    uint4 *d_grid_cells = nullptr;                   // uniform cell grid (GridPlan below; tr.grid_ok)
+    uint32_t *d_grid_large = nullptr;
+    pthostside_grid_geom grid_geom{};
     float tree_build_ms = 0.f;                       // device time of that build (HIP events)
     bool tree_on_device = false;
     std::vector<pt_sphere> h_spheres;                // kept for the lazily built binary tree
@@ -208,6 +216,25 @@ struct Tree4Host {
 };
 Tree4Host tree4_build_host(std::vector<TreeItem> items);
 
+// Uniform cell grid over the small spheres of a big scene (csrc/pt_grid.h): what the tree kernels walk instead of the 4-wide tree when the
+// spheres are many, of similar size and spread evenly enough. Results never depend on it. One RECORD is five 16-byte words: up to four
+// spheres (cx, cy, cz, radius as KArgs::spheres holds them; an empty slot holds a sphere nothing hits) and their list indices; the first
+// n[0] n[1] n[2] records are the cells (x fastest), a cell with more than four spheres continues in a record behind them (three spheres
+// + link 0x80000000 | record). A sphere is registered in every cell its box -- padded by how far the reference's f32 discriminant can
+// inflate it for a ray whose origin lies within `d_build` of it (pt_tree4.h: 0.65e-6 (|o - c|^2 + r^2) / r; 1e-6 here) plus h / 1000 for the
+// walk's own rounding -- overlaps. Rays from farther away walk 27 parallel lines (pt_grid.h), so `d_build` is a cost knob, not a limit.
+struct GridPlan {
+    bool ok = false;
+    uint32_t n[3] = {1, 1, 1}, n_records = 0;
+    float gmin[3] = {0, 0, 0}, h = 0.f;
+    float centre[3] = {0, 0, 0}, half_diag = 0.f, d_build = 0.f;
+    float infl = 0.f, rmax2 = 0.f;     // inflation of the thinnest sphere for a ray from distance D: infl * (D^2 + rmax2)
+    std::vector<uint4> cells;          // 5 per record
+    std::vector<uint32_t> large;       // spheres outside the grid: tested for every ray
+    double items_per_cell = 0.0, records_per_cell = 0.0;
+};
+bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi, const std::vector<float4> &sph, GridPlan &out);
+
 // Everything pt_scene_create derives from a sphere scene's description BEFORE anything touches the device: the flattened
 // device layouts and the traits kernel selection looks at. pt_debug_select runs exactly this, so the selection table can be
 // enumerated on a machine without a GPU.
@@ -222,6 +249,7 @@ struct SpherePlan {
     std::vector<TreeItem> titems;
     bool has_prep = false;
     MfmaPrep prep;
+    GridPlan grid;
 };
 // validation + analysis of a sphere scene (no HIP call); `motion` optional (n_spheres entries)
 int plan_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, SpherePlan &plan);

@@ -11,6 +11,7 @@
 //   pt_prefilter.h  list worlds on the wide kernels: MFMA prefilter (64 rays x 32 spheres x K = 32 per tile), tile culling, balanced
 //                   exact phase 2; the ancestor-AABB gate / DFS-rank rule that makes the same kernel serve BVH worlds
 //   pt_tree.h       the internal trees: binary (variant), and the 4-wide packed tree with whole-wave work-sharing traversal
+//   pt_grid.h       the uniform cell grid (3D-DDA) the tree kernels walk instead when the scene has one
 //   pt_texture.h    Texture::value, Perlin noise, wave-balanced turbulence
 //   pt_coop.h       the wave-cooperative mode (one pixel per wave) behind the hand-over of the wide kernels
 // DESIGN.md section 4 has the derivations and the error budget.
@@ -24,6 +25,7 @@
 #include "pt_sphere.h"
 #include "pt_prefilter.h"   // (also: cross-lane helpers, gates and accept rules the tree kernels share)
 #include "pt_tree.h"
+#include "pt_grid.h"    // the uniform cell grid the tree kernels walk when the scene has one
 #include "pt_coop.h"   // the wave-cooperative mode of the wide list kernels (one pixel per wave), built from the pieces above
 namespace ptdev {
 
@@ -36,6 +38,7 @@ namespace ptdev {
 // every exact sphere test / normal uses the centre at that time; prefilter fragments and internal-tree boxes
 // were built over the motion's whole sweep.
 // GATE: a BVH world on the MFMA list kernel (ancestor-AABB gate + DFS-rank ties at hit acceptance).
+// GRID: the 4-wide tree kernels' flavour that walks the scene's uniform cell grid (pt_grid.h) instead of the tree.
 // BLK: threads per workgroup. 256 (three workgroups per CU) everywhere except the MFMA list kernels, which run ONE
 // 768-thread workgroup per CU when the scene allows: the sphere fragments are then staged once per CU instead of three
 // times, and the LDS that frees holds the per-lane attenuation stacks (no HBM traffic for them).
@@ -58,9 +61,10 @@ namespace ptdev {
 #else
 #define PT_BBPROF_ATTR
 #endif
-template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false, bool GATE = false, int BLK = kBlock>
+template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false, bool GATE = false, int BLK = kBlock, bool GRID = false>
 __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4_WAVES : PT_MINWAVES) : 1) PT_BBPROF_ATTR void pt_trace_kernel(const KArgs A) {
     static_assert(BLK == kBlock || (MFMA && !BVH), "only the MFMA list kernels take another workgroup size");
+    static_assert(!GRID || (BVH && SPH_LDS), "the uniform cell grid (pt_grid.h) is a traversal structure of the 4-wide tree kernels");
     constexpr bool TREE4 = BVH && SPH_LDS;   // tree kernels: SPH_LDS selects the 4-wide tree (false: the binary one, variant bit 2048)
     // Wide (one workgroup per CU) MFMA kernels: every attenuation a path can pick up is one of a finite PALETTE -- a sphere's
     // constant / metal albedo, one of its two checker colours, or white (dielectric) -- so the per-lane attenuation stack
@@ -412,7 +416,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         int idx;
         if (TREE4) {
             // (every ray of the wave is finished when this returns: no traversal state is carried into the next trip)
-            bvh4_trace<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint16_t *>(s_bvh), reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, ro, rd, av, rtime, have, steal4
+            if (GRID) grid_trace<MOVING, VERIFY>(A, w_keys, ro, rd, av, rtime, have, steal4);
+            else bvh4_trace<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint16_t *>(s_bvh), reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, ro, rd, av, rtime, have, steal4
 #ifdef PT_SECTIONS
                                             , sec_t
 #endif

@@ -9,7 +9,7 @@ namespace pthostside {
 void mfma_list_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *frame, SphereKernel *measure);   // GATE = false (pt_kernels_list.hip)
 void mfma_gate_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *frame, SphereKernel *measure);   // GATE = true  (pt_kernels_gate.hip)
 // tree kernels pt_trace_kernel<true, TREE4, false, VERIFY, PILOT, MOVING> and the exact-scan kernels (pt_kernels_tree.hip)
-void tree_kernels(bool tree4, bool moving, bool verify, SphereKernel *frame, SphereKernel *measure);
+void tree_kernels(bool tree4, bool moving, bool verify, bool grid, SphereKernel *frame, SphereKernel *measure);
 void scan_kernels(bool sph_lds, SphereKernel *frame, SphereKernel *measure);
 // pt_world_kernel<BVH, HIT_LDS, OCC, MEDIA, CHAINS> (pt_kernels_world.hip)
 WorldKernel world_kernel(bool bvh, bool hit_lds, uint32_t occ, bool media, bool chains, bool lazy, bool graph);

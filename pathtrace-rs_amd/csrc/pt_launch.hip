@@ -269,8 +269,8 @@ WorldKernel world_kernel_for(const ptsel::KernelChoice &c) { return world_kernel
 
 void sphere_kernels_for(const ptsel::KernelChoice &c, SphereKernel *frame, SphereKernel *measure) {
     switch (c.family) {
-    case ptsel::Family::Tree4: tree_kernels(true, c.moving, c.verify, frame, measure); break;
-    case ptsel::Family::TreeBinary: tree_kernels(false, c.moving, c.verify, frame, measure); break;
+    case ptsel::Family::Tree4: tree_kernels(true, c.moving, c.verify, c.grid, frame, measure); break;
+    case ptsel::Family::TreeBinary: tree_kernels(false, c.moving, c.verify, false, frame, measure); break;
     case ptsel::Family::Mfma:
         if (c.gate) mfma_gate_kernels(c.moving, c.block, c.verify, frame, measure);
         else mfma_list_kernels(c.moving, c.block, c.verify, frame, measure);
@@ -285,7 +285,7 @@ const char *kernel_name(const ptsel::KernelChoice &c, char *buf, size_t cap) {
     if (c.family == ptsel::Family::World)
         snprintf(buf, cap, "world<bvh=%d,hit_lds=%d,occ=%u,media=%d%s>", (int)c.ref_bvh, (int)c.world_hit_lds, c.world_occ, (int)c.world_media, c.world_graph ? ",graph" : (c.world_chains ? ",chains" : (c.world_lazy ? ",lazy" : "")));
     else
-        snprintf(buf, cap, "%s<blk=%u%s%s%s>", fam[(uint32_t)c.family], c.block, c.moving ? ",moving" : "", c.gate ? ",gate" : "", c.verify ? ",verify" : "");
+        snprintf(buf, cap, "%s<blk=%u%s%s%s>", c.grid ? "grid" : fam[(uint32_t)c.family], c.block, c.moving ? ",moving" : "", c.gate ? ",gate" : "", c.verify ? ",verify" : "");
     return buf;
 }
 
@@ -342,6 +342,12 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.bvh_large = s->d_bvh_large;
     A.n_bvh_large = s->n_bvh_large;
     A.nodes4 = s->d_nodes4q;
+    if (c.grid) {
+        const pthostside_grid_geom &q = s->grid_geom;
+        A.grid_cells = s->d_grid_cells, A.grid_large = s->d_grid_large, A.n_grid_large = q.n_large, A.grid_records = q.n_records;
+        for (int k = 0; k < 3; ++k) A.grid_n[k] = q.n[k], A.grid_min[k] = q.gmin[k], A.grid_centre[k] = q.centre[k];
+        A.grid_h = q.h, A.grid_inv_h = 1.0f / q.h, A.grid_half_diag = q.half_diag, A.grid_d_build = q.d_build, A.grid_infl = q.infl, A.grid_rmax2 = q.rmax2;
+    }
     A.slotrec = s->d_slotrec;
     A.rank_sphere = s->d_rank_sphere;
     A.shade_rank = s->d_shade_rank;
@@ -484,6 +490,21 @@ void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, h
             for (int i = 0; i < 18; ++i) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double)c[24 + i] / (double)(c[2] ? c[2] : 1));
             fprintf(stderr, "\n");
         }
+    }
+#endif
+#ifdef PT_GRID_ROUNDS
+    if (A.grid_cells && (A.verify & 1u)) {   // record visits per ray, wave-level rounds per call of grid_trace
+        (void)hipStreamSynchronize(stream);
+        unsigned long long c[64];
+        (void)hipMemcpy(c, s->d_debug + 24, sizeof c, hipMemcpyDeviceToHost);
+        (void)hipMemset(s->d_debug + 24, 0, sizeof c);
+        double nr = 0, nc = 0;
+        for (int i = 0; i < 32; ++i) nr += (double)c[i], nc += (double)c[32 + i];
+        fprintf(stderr, "[ptgpu grid] visits per ray:");
+        for (int i = 0; i < 32; ++i) fprintf(stderr, " %d:%.2f%%", i, 100.0 * (double)c[i] / (nr > 0 ? nr : 1));
+        fprintf(stderr, "\n[ptgpu grid] rounds per call:");
+        for (int i = 0; i < 32; ++i) fprintf(stderr, " %d:%.2f%%", i, 100.0 * (double)c[32 + i] / (nc > 0 ? nc : 1));
+        fprintf(stderr, "\n");
     }
 #endif
 #ifdef PT_COOPSEC

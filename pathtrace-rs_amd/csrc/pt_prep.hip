@@ -389,6 +389,169 @@ std::vector<AccelItem> accel_items(const pt_scene_desc *desc, const MotionIn *mo
     return items;
 }
 
+// ---- uniform cell grid (pt_host.h GridPlan; walked by csrc/pt_grid.h) ------------------------------------------------------------------
+// Eligibility and geometry are decided here, from the description alone: at least kGridMinItems spheres of similar size (those wider
+// than 2.5 median radii are tested for every ray instead, at most kGridMaxLarge of them), a cell size and alignment picked from a
+// small set by the estimated work per unit of ray length (records met per cell / h), bounded tables.
+namespace {
+constexpr uint32_t kGridMinItems = 1024u, kGridMaxLarge = 16u, kGridMaxCells = 1u << 20, kGridMaxRecords = 1u << 21;
+constexpr uint32_t kGridNone = 0x7fffffffu, kGridLink = 0x80000000u;
+
+struct GridGeom {
+    uint32_t n[3];
+    double gmin[3], h;
+};
+// records a cell with `items` spheres takes: four in the last one, three in every one before it
+inline uint32_t grid_records_of(uint32_t items) { return items <= 4u ? 1u : 1u + (items - 4u + 2u) / 3u; }
+inline void grid_cell_range(const GridGeom &g, const double lo[3], const double hi[3], uint32_t a[3], uint32_t b[3]) {
+    for (int k = 0; k < 3; ++k) {
+        const double fa = std::floor((lo[k] - g.gmin[k]) / g.h), fb = std::floor((hi[k] - g.gmin[k]) / g.h);
+        a[k] = (uint32_t)std::min<double>(std::max(fa, 0.0), (double)g.n[k] - 1.0);
+        b[k] = (uint32_t)std::min<double>(std::max(fb, 0.0), (double)g.n[k] - 1.0);
+    }
+}
+}  // namespace
+
+bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi, const std::vector<float4> &sph, GridPlan &G) {
+    G = GridPlan{};
+    std::vector<uint32_t> large;
+    std::vector<AccelItem> items = accel_items(desc, motion, t_lo, t_hi, large);
+    if (items.size() < kGridMinItems) return false;
+    std::vector<float> radii;
+    for (const AccelItem &it : items) radii.push_back(it.r);
+    std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+    const double r_med = radii[radii.size() / 2];
+    {   // the few wide ones leave the grid
+        std::vector<AccelItem> keep;
+        for (const AccelItem &it : items) {
+            double w = 0.0;
+            for (int k = 0; k < 3; ++k) w = std::max(w, 0.5 * ((double)it.mx[k] - (double)it.mn[k]));
+            if (w > 2.5 * r_med) large.push_back(it.sphere);
+            else keep.push_back(it);
+        }
+        items.swap(keep);
+    }
+    if (large.size() > kGridMaxLarge || items.size() < kGridMinItems) return false;
+    std::sort(large.begin(), large.end());
+    double bmin[3] = {1e300, 1e300, 1e300}, bmax[3] = {-1e300, -1e300, -1e300}, r_min = 1e300, r_max = 0.0;
+    for (const AccelItem &it : items) {
+        for (int k = 0; k < 3; ++k) bmin[k] = std::min(bmin[k], (double)it.mn[k]), bmax[k] = std::max(bmax[k], (double)it.mx[k]);
+        r_min = std::min(r_min, (double)it.r), r_max = std::max(r_max, (double)it.r);
+    }
+    double hd2 = 0.0;
+    for (int k = 0; k < 3; ++k) hd2 += 0.25 * (bmax[k] - bmin[k]) * (bmax[k] - bmin[k]);
+    const double half_diag = std::sqrt(hd2);
+    // rays from within three half-diagonals of the grid's centre walk one line (a camera framing the spheres is at about two)
+    const double d_build = 3.0 * half_diag, infl = 1.0e-6;
+    const auto inflate = [&](double r) { return infl * (d_build * d_build + r * r) / r; };
+    const double w_med = 2.0 * (r_med + inflate(r_med));
+    if (!(inflate(r_min) <= 0.5 * r_med) || !std::isfinite(half_diag) || !(half_diag > 0.0)) return false;   // too little precision left at that distance: the tree pads per ray
+    // padded boxes (the walk's own rounding is covered by h / 1000 more, added per candidate geometry below)
+    std::vector<double> lo(3 * items.size()), hi(3 * items.size());
+    for (size_t i = 0; i < items.size(); ++i) {
+        const double d = inflate(items[i].r);
+        for (int k = 0; k < 3; ++k) lo[3 * i + k] = (double)items[i].mn[k] - d, hi[3 * i + k] = (double)items[i].mx[k] + d;
+    }
+    // candidates: cell sizes around the padded median width, four alignments per axis that has more than one cell
+    GridGeom best{};
+    double best_cost = 1e300;
+    std::vector<uint32_t> count;
+    static const double kSizes[] = {0.625, 0.75, 0.875, 1.0, 1.25, 1.5, 2.0, 3.0};
+    for (double sz : kSizes) {
+        const double h = sz * w_med;
+        for (int align = 0; align < 64; ++align) {
+            GridGeom g{};
+            g.h = h;
+            bool skip = false;
+            uint64_t cells = 1;
+            for (int k = 0; k < 3; ++k) {
+                const double ext = (bmax[k] - bmin[k]) + 2.0 * inflate(r_min) + 4.0e-3 * h;
+                const int sh = (align >> (2 * k)) & 3;
+                const bool single = ext <= 1.5 * h;
+                if (single && sh != 0) skip = true;   // (alignment means nothing along an axis with one cell)
+                const double start = bmin[k] - inflate(r_min) - 2.0e-3 * h - (single ? 0.0 : 0.25 * sh * h);
+                g.gmin[k] = start;
+                g.n[k] = single ? 1u : (uint32_t)std::ceil((bmax[k] + inflate(r_min) + 2.0e-3 * h - start) / h);
+                if (g.n[k] == 0u || g.n[k] > 1023u) skip = true;
+                cells *= g.n[k];
+            }
+            if (skip || cells > kGridMaxCells) continue;
+            count.assign((size_t)cells, 0u);
+            for (size_t i = 0; i < items.size(); ++i) {
+                double l[3], u[3];
+                for (int k = 0; k < 3; ++k) l[k] = lo[3 * i + k] - 1.0e-3 * h, u[k] = hi[3 * i + k] + 1.0e-3 * h;
+                uint32_t a[3], b[3];
+                grid_cell_range(g, l, u, a, b);
+                for (uint32_t z = a[2]; z <= b[2]; ++z)
+                    for (uint32_t y = a[1]; y <= b[1]; ++y)
+                        for (uint32_t x = a[0]; x <= b[0]; ++x) count[((size_t)z * g.n[1] + y) * g.n[0] + x] += 1u;
+            }
+            uint64_t records = 0;
+            for (uint32_t c : count) records += grid_records_of(c);
+            if (records > kGridMaxRecords) continue;
+            const double cost = ((double)records / (double)cells + 0.35) / h;   // (+ the walk's own step per cell)
+            if (cost < best_cost) best_cost = cost, best = g;
+        }
+    }
+    if (!(best_cost < 1e300)) return false;
+    const GridGeom &g = best;
+    const size_t cells = (size_t)g.n[0] * g.n[1] * g.n[2];
+    std::vector<std::vector<uint32_t>> lists(cells);
+    size_t regs = 0;
+    for (size_t i = 0; i < items.size(); ++i) {
+        double l[3], u[3];
+        for (int k = 0; k < 3; ++k) l[k] = lo[3 * i + k] - 1.0e-3 * g.h, u[k] = hi[3 * i + k] + 1.0e-3 * g.h;
+        uint32_t a[3], b[3];
+        grid_cell_range(g, l, u, a, b);
+        for (uint32_t z = a[2]; z <= b[2]; ++z)
+            for (uint32_t y = a[1]; y <= b[1]; ++y)
+                for (uint32_t x = a[0]; x <= b[0]; ++x) lists[((size_t)z * g.n[1] + y) * g.n[0] + x].push_back(items[i].sphere), ++regs;
+    }
+    union FU { float f; uint32_t u; };
+    const auto bits = [](float f) { FU q; q.f = f; return q.u; };
+    const uint4 never = make_uint4(bits(3.0e38f), bits(3.0e38f), bits(3.0e38f), 0u);
+    std::vector<uint4> rec(5 * cells);
+    for (size_t c = 0; c < cells; ++c) {
+        std::vector<uint32_t> &L = lists[c];
+        std::sort(L.begin(), L.end());
+        size_t at = c, done = 0;
+        for (;;) {
+            const size_t left = L.size() - done, take = left <= 4 ? left : 3;
+            uint32_t ids[4] = {kGridNone, kGridNone, kGridNone, kGridNone};
+            for (size_t j = 0; j < 4; ++j) rec[5 * at + j] = never;
+            for (size_t j = 0; j < take; ++j) {
+                const float4 q = sph[L[done + j]];
+                rec[5 * at + j] = make_uint4(bits(q.x), bits(q.y), bits(q.z), bits(q.w));
+                ids[j] = L[done + j];
+            }
+            done += take;
+            if (done == L.size()) {
+                rec[5 * at + 4] = make_uint4(ids[0], ids[1], ids[2], ids[3]);
+                break;
+            }
+            const size_t next = rec.size() / 5;
+            rec[5 * at + 4] = make_uint4(ids[0], ids[1], ids[2], kGridLink | (uint32_t)next);
+            rec.resize(rec.size() + 5);
+            at = next;
+        }
+    }
+    G.ok = true;
+    for (int k = 0; k < 3; ++k) G.n[k] = g.n[k], G.gmin[k] = (float)g.gmin[k], G.centre[k] = (float)(0.5 * (bmin[k] + bmax[k]));
+    G.h = (float)g.h;
+    // (the kernel works with these f32 values; the registration above used the doubles they were rounded from -- h / 1000 covers the difference)
+    G.half_diag = (float)(half_diag * 1.0001), G.d_build = (float)(d_build * 0.999);
+    G.infl = (float)(infl / r_min * 1.0001), G.rmax2 = (float)(r_max * r_max * 1.0001);
+    G.n_records = (uint32_t)(rec.size() / 5);
+    G.cells.swap(rec);
+    G.large.swap(large);
+    G.items_per_cell = (double)regs / (double)cells, G.records_per_cell = (double)G.n_records / (double)cells;
+#ifdef PT_GRID_ROUNDS
+    fprintf(stderr, "[ptgpu grid plan] %u x %u x %u cells of %.4f (median padded width %.4f), %zu spheres + %zu large, %.2f spheres and %.2f records per cell, d_build %.1f half_diag %.1f\n", G.n[0], G.n[1], G.n[2],
+            g.h, w_med, items.size(), G.large.size(), G.items_per_cell, G.records_per_cell, d_build, half_diag);
+#endif
+    return true;
+}
+
 AccelBuild build_accel(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi) {
     AccelBuild out;
     std::vector<AccelItem> items = accel_items(desc, motion, t_lo, t_hi, out.large);
@@ -661,6 +824,7 @@ int plan_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, SphereP
             memcpy(P.titems[i].c, items[i].c, 12), memcpy(P.titems[i].mn, items[i].mn, 12), memcpy(P.titems[i].mx, items[i].mx, 12);
         }
     }
+    tr.grid_ok = plan_cell_grid(desc, motion, t_lo, t_hi, P.sph, P.grid);
     P.pvec.assign(256, make_float4(0, 0, 0, 0));
     P.pperm.assign(768, 0);
     if (desc->perlin) {

@@ -41,6 +41,7 @@ struct SceneTraits {
     float time_lo = 0.f, time_hi = 0.f;
     uint32_t n_nodes4 = 0, depth4 = 0;   // the 4-wide internal tree
     bool tree4_packed = false;
+    bool grid_ok = false;          // the scene has a uniform cell grid (pt_host.h GridPlan): the tree kernels walk it instead of the tree
     uint32_t bin_nodes = 0, bin_depth = 0;   // the binary internal tree once built (0: not yet)
     // ---- general worlds
     uint32_t n_hitables = 0, n_world_xf = 0, ref_bvh_depth = 0;
@@ -75,6 +76,7 @@ struct KernelChoice {
     // values the kernels' LDS carve is driven by (copied into KArgs / WArgs)
     uint32_t sph_bytes = 0, n_tiles = 0, stack_in_lds = 0, nodes_in_lds = 0, bvh_stack_entries = 0, cull_off = 0;
     uint32_t refill_min = 4;
+    bool grid = false;          // Tree4 family: the traversal structure is the uniform cell grid (pt_grid.h), not the 4-wide tree
     bool coop = false;          // wide list kernels: idle waves finish pixels handed over by busy ones, 64 lanes per ray (pt_coop.h)
 };
 
@@ -231,6 +233,7 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     c.block = blk;
     c.family = bvh ? (tree4 ? Family::Tree4 : Family::TreeBinary) : (mfma ? Family::Mfma : (sph_lds ? Family::ScanLds : Family::ScanHbm));
     c.gate = mfma && ref_bvh;
+    c.grid = tree4 && t.grid_ok && (v & kVarNoGrid) == 0;
     // cooperative hand-over: the wide frame kernels; a path's attenuations live one level per lane there (depth <= 64), a lane's spheres in 8 register sets (<= 512 spheres)
     c.coop = wide && !c.verify && p.max_depth <= 64u && t.n_spheres <= 512u && (v & kVarNoCoop) == 0;
     // refills are batched: 4 waiting lanes for long pixels, 8 when pixels are short (< 32 spp); 16-wave workgroups batch harder

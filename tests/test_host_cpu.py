@@ -334,8 +334,8 @@ SELECTION_TABLE = {
     ("aras", True): ("mfma<blk=1024,gate>", 67248, 1, 0),
     ("random_spheres", False): ("mfma<blk=1024>", 130480, 1, 0),                # BASELINE config 3 / 4: the headline kernel
     ("random_spheres", True): ("mfma<blk=1024,gate>", 148048, 1, 0),
-    ("perlin_spheres", False): ("tree4<blk=256>", 38384, 4, 9),                 # BASELINE config 5 as a list world: walks the tree
-    ("perlin_spheres", True): ("tree4<blk=256>", 38384, 4, 9),                  # BASELINE config 5
+    ("perlin_spheres", False): ("grid<blk=256>", 38384, 4, 9),                  # BASELINE config 5 as a list world: walks the uniform cell grid (pt_grid.h)
+    ("perlin_spheres", True): ("grid<blk=256>", 38384, 4, 9),                   # BASELINE config 5
     ("two_perlin_spheres", False): ("scan-lds<blk=256>", 40560, 4, 24),          # eight of its nine stack levels in LDS, the deepest in HBM: four workgroups fit
     ("two_perlin_spheres", True): ("tree4<blk=256>", 29168, 4, 9),
     ("random", False): ("mfma<blk=1024,moving>", 146096, 1, 0),                 # Sphere + MovingSphere world on the fast kernels
@@ -405,7 +405,7 @@ def test_kernel_selection_follows_the_tuning_word_and_the_frame(ptgpu, pthost):
 
 def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
     """Sphere clouds of the sizes the fuzzers draw (tests/test_gpu_parity.py _random_scene): below 32 spheres the exact scan,
-    up to 768 the MFMA prefilter, beyond that the internal tree -- and use_bvh without BVH nodes is refused."""
+    up to 768 the MFMA prefilter, beyond that the internal tree or, from 1 024 similar spheres, the cell grid -- and use_bvh without BVH nodes is refused."""
     rng = np.random.default_rng(5)
 
     def cloud(n):
@@ -418,7 +418,9 @@ def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
     p = ptgpu.PtParams(640, 480, 16, 10, 0, 0)
     names = {n: ptgpu.debug_select(cloud(n), p, cam)["name"] for n in (12, 40, 300, 768, 800, 2500)}
     assert {n: names[n] for n in (12, 40, 300, 800, 2500)} == {12: "scan-lds<blk=256>", 40: "mfma<blk=1024>", 300: "mfma<blk=1024>",
-                                                               800: "tree4<blk=256>", 2500: "tree4<blk=256>"}, names
+                                                               800: "tree4<blk=256>", 2500: "grid<blk=256>"}, names
+    # (1 024 similar spheres and more, evenly spread: the uniform cell grid of csrc/pt_grid.h; a development switch keeps the tree)
+    assert ptgpu.debug_select(cloud(2500), p, cam, variant=524288)["name"] == "tree4<blk=256>"
     assert names[768].startswith("mfma<")          # 24 tiles: the last size whose fragments fit beside the rest
     # the hand-over's workers keep a lane's spheres in eight register sets: up to 512 spheres
     assert ptgpu.debug_select(cloud(512), p, cam)["coop"] == 1 and ptgpu.debug_select(cloud(513), p, cam)["coop"] == 0
@@ -556,7 +558,7 @@ def test_fuzzed_descriptions_are_accepted_or_refused_by_name_and_reach_every_ins
     indices, cycles, NULL arrays, NaN radii, DAG blow-ups; every one must come back PT_OK or PT_ERR_INVALID_ARG / PT_ERR_UNSUPPORTED with a
     message. (tools/sanitize_cpu.sh runs the same program, 10^5 + descriptions, on an ASan + UBSan build of the library's host side:
     profiles/r05_sanitize.txt.) And the accepted ones, between them, select EVERY kernel instantiation the shared object carries
-    (pt_debug_last_kernel_symbols against `nm`): the library's build time and size are its 68 kernels, none may be dead weight."""
+    (pt_debug_last_kernel_symbols against `nm`): the library's build time and size are its 74 kernels, none may be dead weight."""
     exe = str(tmp_path / "fuzz_desc")
     build = os.path.join(ROOT, "pathtrace-rs_amd", "_build")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "fuzz_desc.cpp"), "-o", exe,
@@ -571,5 +573,5 @@ def test_fuzzed_descriptions_are_accepted_or_refused_by_name_and_reach_every_ins
     # (a kernel's host-side handle is `ns::name<...>`, its launch stub `ns::__device_stub__name<...>`: one of each per instantiation)
     carried = set(re.findall(r"\b(_ZN5ptdev15pt_(?:trace|world)_kernelI\S+)", nm))
     stubs = set(re.findall(r"\b_ZN5ptdev30__device_stub__(pt_(?:trace|world)_kernelI\S+)", nm))
-    assert len(carried) == len(stubs) == 68, (len(carried), len(stubs))
+    assert len(carried) == len(stubs) == 74, (len(carried), len(stubs))
     assert reached == carried, "never selected: %s; selected but not carried: %s" % (sorted(carried - reached), sorted(reached - carried))

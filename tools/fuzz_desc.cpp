@@ -141,7 +141,7 @@ void sphere_case(Rng &r, Case &c) {
 void world_case(Rng &r, Case &c, bool graph) {
     tables(r, c, true);
     const bool spheres_only = !graph && r.chance(25);          // Sphere + MovingSphere worlds run on the sphere kernels' MOVING instantiations
-    const uint32_t n = r.chance(5) ? 0u : (r.chance(8) ? 500u + r.below(1500) : (spheres_only && r.chance(60) ? 33u + r.below(600) : 1u + r.below(40)));
+    const uint32_t n = r.chance(5) ? 0u : (r.chance(spheres_only ? 25 : 8) ? 500u + r.below(1500) : (spheres_only && r.chance(60) ? 33u + r.below(600) : 1u + r.below(40)));
     const uint32_t nx = spheres_only ? 0u : r.below(5);
     for (uint32_t i = 0; i < nx; ++i) {
         pt_affine a{};
