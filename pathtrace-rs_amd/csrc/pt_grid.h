@@ -1,12 +1,21 @@
-// pt_grid.h -- closest hit over a UNIFORM CELL GRID: what the 4-wide tree kernels walk instead of the tree when the scene has one
-// (pt_host.h GridPlan: many spheres of similar size, spread evenly enough; KArgs::grid_cells != nullptr).
+// pt_grid.h -- closest hit over a UNIFORM CELL GRID: what the GRID flavour of the 4-wide tree kernels walks instead of the tree
+// (pt_host.h GridPlan: at least 1 024 spheres of similar size, spread evenly enough).
 //
 // Why. A visit of the 4-wide tree tests FOUR BOXES (146 VALU instructions) and a ray of BASELINE config 5 -- 10 000 spheres of radius 0.2
 // on a 100 x 100 lattice -- needs 10.4 of them plus 3.4 exact sphere tests. A cell of the grid holds the spheres themselves: a visit is
-// one 80-byte record (five 16-byte loads: up to four spheres and their list indices), four reference discriminants (sphere.rs:33-37,
-// the reference's own operation order: the filter is EXACT, a sphere with a discriminant <= 0 does nothing in the reference either) and
-// one step of a 3D-DDA; the few spheres with a positive discriminant go through sphere.rs:38-64 and the accept rule right there, so the
-// lane's nearest hit -- its walk's limit -- is exact after every cell.
+// one 80-byte record (five 16-byte loads: up to four spheres and their list indices), four reference discriminants (sphere.rs:33-37 in
+// the reference's own operation order: the filter is EXACT, a sphere whose discriminant is not positive does nothing in the reference
+// either) and one step of a 3D-DDA: 2.3 records and 2.5 positive discriminants per ray on that scene.
+//
+// Structure of a call (one per trip of the kernel's main loop, all rays of the wave to their end, like bvh4_trace):
+//   walk rounds   every lane with cells left visits one record; spheres with a positive discriminant are QUEUED (owner lane | sphere), and
+//                 an ESTIMATE of their hit parameter (hardware square root and reciprocal) tightens the lane's walk limit;
+//   drain         when no lane can go on (or a queue fills): the queued pairs are tested exactly by the whole wave (drain_pairs4:
+//                 sphere.rs:38-64, the ancestor gate of a BVH world, ds_min_u64 into the owner's (t, tie-break) key -- the records are the
+//                 per-sphere slot records of GridPlan::rec) and every lane's limit becomes the EXACT one of its key. A lane whose
+//                 estimate was too optimistic (the gate refused the hit, a root within a hair of t_min) simply walks on.
+// The estimate therefore decides nothing: a lane is finished only when the entry parameter of its next cell lies beyond
+// trav4_limit(exact key) or outside the grid.
 //
 // What makes it the same closest hit. The winner is the (t, tie-break) minimum over every sphere whose reference test accepts the ray
 // (DESIGN.md 4.2 / 4.4), so the structure only has to PRESENT every such sphere before the walk ends:
@@ -18,7 +27,8 @@
 //   * a ray from FARTHER away (|o - centre| + half diagonal > grid_d_build: the reference's discriminant is coarser than the registration
 //     assumed) walks 27 parallel lines, its own and those displaced by -+ its own inflation bound per axis: a point within that bound of
 //     a registered box lies, per axis, in the cell of one of the three displaced points (the bound is below the cell size; beyond that the
-//     ray looks at every record). Rare by construction: a camera framing the spheres sits at two half diagonals.
+//     ray looks at every record). Rare by construction (a camera framing the spheres sits at two half diagonals): grid_far_rays, one
+//     lane per ray, exact tests on the spot.
 // Large spheres (KArgs::grid_large) are tested for every ray first, as the tree kernels do with theirs.
 #pragma once
 
@@ -26,159 +36,258 @@ namespace ptdev {
 
 constexpr uint32_t kGridLinkBit = 0x80000000u;
 
-template <bool MOVING, bool COUNT>
-__device__ __forceinline__ void grid_trace(const KArgs &A, unsigned long long *w_keys, f3 o, f3 d, const DivA &av, float time, bool start, Steal4 &cnt) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const float a = av.a;
-    float best = kMaxT;
-    int idx = -1;
-    uint32_t rank = 0;
-    const f3 rcp = mk3(recip_exact(d.x), recip_exact(d.y), recip_exact(d.z));   // ray.rs:14 (read by the gates of a BVH world)
-    if (start) {
-        for (uint32_t j = 0; j < A.n_grid_large; ++j) {
-            const int k = (int)A.grid_large[j];
-            bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, rcp, av, best, idx, rank);   // (`rank` is only used among these)
-        }
-    }
-    float limit = trav4_limit(idx < 0 ? kMaxT : best);
-#ifdef PT_GRID_ROUNDS
-    if (COUNT && lane == 0u) cnt.leaves += 1u;
-#endif
+// The DDA of one lane: the line (origin + t direction, the origin possibly displaced: far rays), the cell it is in, the parameters at
+// which it crosses the next cell boundary per axis.
+struct GridWalk {
+    float ox, oy, oz, rx, ry, rz;   // line origin; 1 / direction (0 along an axis the line does not move along)
+    float tnx, tny, tnz;            // parameter of the next boundary crossing per axis (+inf along such an axis)
+    float tcur, t_out;              // entry parameter of the current cell; where the line leaves the grid's box
+    int ix, iy, iz;
+    bool alive;
+};
 
-    // one record: the reference's discriminant of its (up to) four spheres, then sphere.rs:38-64 + the accept rule for the positive ones.
-    // Returns the record's last word (a list index or a link).
-#ifdef PT_GRID_ROUNDS
-    uint32_t dbg_visits = 0u, dbg_rounds = 0u;
-#endif
+__device__ __forceinline__ void grid_walk_start(const KArgs &A, GridWalk &w, f3 o, f3 d, f3 rcp, bool active) {
+    const float h = A.grid_h, inv_h = A.grid_inv_h;
+    const int nx = (int)A.grid_n[0], ny = (int)A.grid_n[1], nz = (int)A.grid_n[2];
+    const float kInf = __builtin_inff();
+    const bool par_x = __builtin_fabsf(d.x) < 1.0e-30f, par_y = __builtin_fabsf(d.y) < 1.0e-30f, par_z = __builtin_fabsf(d.z) < 1.0e-30f;
+    w.ox = o.x, w.oy = o.y, w.oz = o.z;
+    w.rx = par_x ? 0.0f : rcp.x, w.ry = par_y ? 0.0f : rcp.y, w.rz = par_z ? 0.0f : rcp.z;
+    // clip against the grid's box
+    const float lox = A.grid_min[0], loy = A.grid_min[1], loz = A.grid_min[2];
+    const float hix = lox + (float)nx * h, hiy = loy + (float)ny * h, hiz = loz + (float)nz * h;
+    const float ax0 = (lox - o.x) * w.rx, ax1 = (hix - o.x) * w.rx, ay0 = (loy - o.y) * w.ry, ay1 = (hiy - o.y) * w.ry, az0 = (loz - o.z) * w.rz, az1 = (hiz - o.z) * w.rz;
+    const bool in_x = o.x >= lox && o.x <= hix, in_y = o.y >= loy && o.y <= hiy, in_z = o.z >= loz && o.z <= hiz;
+    const float nrx = par_x ? (in_x ? -kInf : kInf) : __builtin_fminf(ax0, ax1), frx = par_x ? (in_x ? kInf : -kInf) : __builtin_fmaxf(ax0, ax1);
+    const float nry = par_y ? (in_y ? -kInf : kInf) : __builtin_fminf(ay0, ay1), fry = par_y ? (in_y ? kInf : -kInf) : __builtin_fmaxf(ay0, ay1);
+    const float nrz = par_z ? (in_z ? -kInf : kInf) : __builtin_fminf(az0, az1), frz = par_z ? (in_z ? kInf : -kInf) : __builtin_fmaxf(az0, az1);
+    const float t_in = __builtin_fmaxf(__builtin_fmaxf(nrx, nry), __builtin_fmaxf(nrz, 0.0f));
+    w.t_out = __builtin_fminf(__builtin_fminf(frx, fry), frz);
+    w.alive = active && t_in <= w.t_out;
+    const float px = o.x + d.x * t_in, py = o.y + d.y * t_in, pz = o.z + d.z * t_in;
+    w.ix = min(max((int)__builtin_floorf((px - lox) * inv_h), 0), nx - 1);
+    w.iy = min(max((int)__builtin_floorf((py - loy) * inv_h), 0), ny - 1);
+    w.iz = min(max((int)__builtin_floorf((pz - loz) * inv_h), 0), nz - 1);
+    w.tnx = par_x ? kInf : ((lox + (float)(w.ix + (d.x >= 0.0f ? 1 : 0)) * h) - o.x) * w.rx;
+    w.tny = par_y ? kInf : ((loy + (float)(w.iy + (d.y >= 0.0f ? 1 : 0)) * h) - o.y) * w.ry;
+    w.tnz = par_z ? kInf : ((loz + (float)(w.iz + (d.z >= 0.0f ? 1 : 0)) * h) - o.z) * w.rz;
+    w.tcur = t_in;
+}
+__device__ __forceinline__ uint32_t grid_walk_cell(const KArgs &A, const GridWalk &w) { return (uint32_t)((w.iz * (int)A.grid_n[1] + w.iy) * (int)A.grid_n[0] + w.ix); }
+// one step: into the neighbour across the nearest boundary (the boundary of the NEW cell is formed from its integer number)
+__device__ __forceinline__ void grid_walk_step(const KArgs &A, GridWalk &w, f3 d) {
+    const float h = A.grid_h;
+    w.tcur = __builtin_fminf(__builtin_fminf(w.tnx, w.tny), w.tnz);
+    if (w.tnx <= w.tny && w.tnx <= w.tnz) {
+        w.ix += d.x >= 0.0f ? 1 : -1;
+        w.alive = (uint32_t)w.ix < A.grid_n[0];
+        w.tnx = ((A.grid_min[0] + (float)(w.ix + (d.x >= 0.0f ? 1 : 0)) * h) - w.ox) * w.rx;
+    } else if (w.tny <= w.tnz) {
+        w.iy += d.y >= 0.0f ? 1 : -1;
+        w.alive = (uint32_t)w.iy < A.grid_n[1];
+        w.tny = ((A.grid_min[1] + (float)(w.iy + (d.y >= 0.0f ? 1 : 0)) * h) - w.oy) * w.ry;
+    } else {
+        w.iz += d.z >= 0.0f ? 1 : -1;
+        w.alive = (uint32_t)w.iz < A.grid_n[2];
+        w.tnz = ((A.grid_min[2] + (float)(w.iz + (d.z >= 0.0f ? 1 : 0)) * h) - w.oz) * w.rz;
+    }
+}
+
+// Rays from beyond grid_d_build (see the head of the file), one lane per ray: 27 displaced lines -- or every record -- with the exact test
+// of each positive discriminant on the spot; the result is reduced into w_keys[lane] like any other candidate's.
+template <bool MOVING, bool COUNT>
+__device__ __forceinline__ void grid_far_rays(const KArgs &A, unsigned long long *w_keys, f3 o, f3 d, f3 rcp, const DivA &av, float time, bool far, float delta, Steal4 &cnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long key = far ? w_keys[lane] : ~0ull;
+    float limit = trav4_limit(__uint_as_float((uint32_t)(key >> 32)));
+    const float a = av.a;
     const auto visit = [&](uint32_t rec) -> uint32_t {
-#ifdef PT_GRID_ROUNDS
-        dbg_visits += 1u;
-#endif
         const uint4 *cp = A.grid_cells + (size_t)rec * 5u;
-        uint4 q0 = cp[0], q1 = cp[1], q2 = cp[2], q3 = cp[3], m = cp[4];
-        // (all five loads in flight at once: left alone, the scheduler issues them one by one, each behind the arithmetic of the one before --
-        //  four round trips to the L2 per record instead of one -- to save the sixteen registers this takes)
-        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w),
-                     "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w), "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));
-#ifndef PT_GRID_ROUNDS
-        if (COUNT) cnt.visits += 1u;
-#endif
-        float bj[4], dj[4];
-        uint32_t pos = 0u;
-        const uint4 qs[4] = {q0, q1, q2, q3};
+        const uint4 q0 = cp[0], q1 = cp[1], q2 = cp[2], q3 = cp[3], m = cp[4];
+        const uint4 qs[4] = {make_uint4(q0.x, q0.z, q1.x, q1.z), make_uint4(q0.y, q0.w, q1.y, q1.w), make_uint4(q2.x, q2.z, q3.x, q3.z), make_uint4(q2.y, q2.w, q3.y, q3.w)};
         const uint32_t ks[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
+        if (COUNT) cnt.visits += 1u;
         for (int j = 0; j < 4; ++j) {
+            if (!(ks[j] < A.n_spheres)) continue;
             float4 c = make_float4(__uint_as_float(qs[j].x), __uint_as_float(qs[j].y), __uint_as_float(qs[j].z), __uint_as_float(qs[j].w));
-            if (MOVING) c = sphere_at<MOVING>(A, (int)(ks[j] < A.n_spheres ? ks[j] : 0u), c, time);
+            c = sphere_at<MOVING>(A, (int)ks[j], c, time);
             const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
             const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
             const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
             const float disc = b * b - a * cc;
-            bj[j] = b, dj[j] = disc;
-            pos |= (disc > 0.0f && ks[j] < A.n_spheres) ? (1u << j) : 0u;
-        }
-        while (wave_any(pos != 0u)) {
-            if (pos != 0u) {
-                const uint32_t j = (uint32_t)__builtin_ctz(pos);
-                pos &= pos - 1u;
-                const float b = j == 0u ? bj[0] : (j == 1u ? bj[1] : (j == 2u ? bj[2] : bj[3]));
-                const float disc = j == 0u ? dj[0] : (j == 1u ? dj[1] : (j == 2u ? dj[2] : dj[3]));
-                const uint32_t k = j == 0u ? ks[0] : (j == 1u ? ks[1] : (j == 2u ? ks[2] : ks[3]));
-#ifndef PT_GRID_ROUNDS
-                if (COUNT) cnt.leaves += 1u;
-#endif
-                const float t = sphere_hit_t(av, b, disc, true);
-                if (t < kMaxT) {
-                    // equal t: the DFS-last leaf in a BVH world (bvh.rs:47-53), the lower list index in a list world (hitable_list.rs:48). The
-                    // ranks are only fetched for such a tie (a dependent load per candidate otherwise) and once for the winner at the end.
-                    bool better = idx < 0 || t < best;
-                    if (!better && t == best && (int)k != idx) better = A.gate ? (A.leaf_rank[k] > A.leaf_rank[idx]) : ((int)k < idx);
-                    if (better && (!A.gate || gate_pass(A, (int)k, o, rcp))) best = t, idx = (int)k;
-                }
+            if (!(disc > 0.0f)) continue;
+            if (COUNT) cnt.leaves += 1u;
+            const float t = sphere_hit_t(DivA{av.a, av.y, false}, b, disc, true);
+            if (t < kMaxT) {
+                const unsigned long long kk = key4_of(A, t, (int)ks[j]);
+                if (kk < key && (!A.gate || gate_pass(A, (int)ks[j], o, rcp))) key = kk;
             }
         }
-        limit = trav4_limit(idx < 0 ? kMaxT : best);
+        limit = trav4_limit(__uint_as_float((uint32_t)(key >> 32)));
         return m.w;
     };
-
-    // ---- how many lines this ray walks
-    const float gx = o.x - A.grid_centre[0], gy = o.y - A.grid_centre[1], gz = o.z - A.grid_centre[2];
-    const float dist = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz) * 1.001f + A.grid_half_diag;
-    const bool far = start && !(dist <= A.grid_d_build);
-    const float delta = far ? A.grid_infl * (dist * dist + A.grid_rmax2) * 1.001f : 0.0f;
     const bool full = far && !(delta <= A.grid_h);   // (also a NaN origin)
-    const uint32_t my_lines = !start || full ? 0u : (far ? 27u : 1u);
-    const uint32_t n_lines = wave_any(my_lines > 1u) ? 27u : 1u;
-    const float h = A.grid_h, inv_h = A.grid_inv_h;
-    const int nx = (int)A.grid_n[0], ny = (int)A.grid_n[1], nz = (int)A.grid_n[2];
-    const bool par_x = __builtin_fabsf(d.x) < 1.0e-30f, par_y = __builtin_fabsf(d.y) < 1.0e-30f, par_z = __builtin_fabsf(d.z) < 1.0e-30f;
-    const float rx = par_x ? 0.0f : rcp.x, ry = par_y ? 0.0f : rcp.y, rz = par_z ? 0.0f : rcp.z;
-    const int sx = d.x >= 0.0f ? 1 : -1, sy = d.y >= 0.0f ? 1 : -1, sz = d.z >= 0.0f ? 1 : -1;
-    const float kInf = __builtin_inff();
-    for (uint32_t line = 0; line < n_lines; ++line) {
-        const uint32_t l3 = (line + 13u) % 27u;
-        const float ox = o.x + delta * (float)((int)(l3 % 3u) - 1), oy = o.y + delta * (float)((int)((l3 / 3u) % 3u) - 1), oz = o.z + delta * (float)((int)(l3 / 9u) - 1);
-        // clip against the grid's box
-        const float lox = A.grid_min[0], loy = A.grid_min[1], loz = A.grid_min[2];
-        const float hix = lox + (float)nx * h, hiy = loy + (float)ny * h, hiz = loz + (float)nz * h;
-        const float ax0 = (lox - ox) * rx, ax1 = (hix - ox) * rx, ay0 = (loy - oy) * ry, ay1 = (hiy - oy) * ry, az0 = (loz - oz) * rz, az1 = (hiz - oz) * rz;
-        const bool in_x = ox >= lox && ox <= hix, in_y = oy >= loy && oy <= hiy, in_z = oz >= loz && oz <= hiz;
-        const float nrx = par_x ? (in_x ? -kInf : kInf) : __builtin_fminf(ax0, ax1), frx = par_x ? (in_x ? kInf : -kInf) : __builtin_fmaxf(ax0, ax1);
-        const float nry = par_y ? (in_y ? -kInf : kInf) : __builtin_fminf(ay0, ay1), fry = par_y ? (in_y ? kInf : -kInf) : __builtin_fmaxf(ay0, ay1);
-        const float nrz = par_z ? (in_z ? -kInf : kInf) : __builtin_fminf(az0, az1), frz = par_z ? (in_z ? kInf : -kInf) : __builtin_fmaxf(az0, az1);
-        const float t_in = __builtin_fmaxf(__builtin_fmaxf(nrx, nry), __builtin_fmaxf(nrz, 0.0f));
-        const float t_out = __builtin_fminf(__builtin_fminf(frx, fry), frz);
-        bool alive = line < my_lines && t_in <= t_out;
-        const float px = ox + d.x * t_in, py = oy + d.y * t_in, pz = oz + d.z * t_in;
-        int ix = min(max((int)__builtin_floorf((px - lox) * inv_h), 0), nx - 1);
-        int iy = min(max((int)__builtin_floorf((py - loy) * inv_h), 0), ny - 1);
-        int iz = min(max((int)__builtin_floorf((pz - loz) * inv_h), 0), nz - 1);
-        float tnx = par_x ? kInf : ((lox + (float)(ix + (sx > 0 ? 1 : 0)) * h) - ox) * rx;
-        float tny = par_y ? kInf : ((loy + (float)(iy + (sy > 0 ? 1 : 0)) * h) - oy) * ry;
-        float tnz = par_z ? kInf : ((loz + (float)(iz + (sz > 0 ? 1 : 0)) * h) - oz) * rz;
-        float tcur = t_in;
-        uint32_t rec = alive ? (uint32_t)((iz * ny + iy) * nx + ix) : 0u;
-        for (;;) {
-            const bool go = alive && tcur <= __builtin_fminf(t_out, limit);
-            if (!wave_any(go)) break;
-#ifdef PT_GRID_ROUNDS   // development aid: wave-level rounds instead of record visits, calls instead of positive discriminants
-            if (COUNT && lane == 0u) cnt.visits += 1u;
-            dbg_rounds += 1u;
-#endif
-            if (go) {
-                const uint32_t last = visit(rec);
-                if (last & kGridLinkBit) {
-                    rec = last & ~kGridLinkBit;   // the cell continues in another record
-                } else {
-                    tcur = __builtin_fminf(__builtin_fminf(tnx, tny), tnz);
-                    if (tnx <= tny && tnx <= tnz) {
-                        ix += sx;
-                        alive = (uint32_t)ix < (uint32_t)nx;
-                        tnx = ((lox + (float)(ix + (sx > 0 ? 1 : 0)) * h) - ox) * rx;
-                    } else if (tny <= tnz) {
-                        iy += sy;
-                        alive = (uint32_t)iy < (uint32_t)ny;
-                        tny = ((loy + (float)(iy + (sy > 0 ? 1 : 0)) * h) - oy) * ry;
+    if (wave_any(far && !full)) {
+        for (uint32_t line = 0; line < 27u; ++line) {
+            GridWalk w;
+            grid_walk_start(A, w, mk3(o.x + delta * (float)((int)(line % 3u) - 1), o.y + delta * (float)((int)((line / 3u) % 3u) - 1), o.z + delta * (float)((int)(line / 9u) - 1)), d, rcp, far && !full);
+            uint32_t rec = grid_walk_cell(A, w);
+            for (;;) {
+                const bool go = w.alive && w.tcur <= __builtin_fminf(w.t_out, limit);
+                if (!wave_any(go)) break;
+                if (go) {
+                    const uint32_t last = visit(rec);
+                    if (last & kGridLinkBit) {
+                        rec = last & ~kGridLinkBit;
                     } else {
-                        iz += sz;
-                        alive = (uint32_t)iz < (uint32_t)nz;
-                        tnz = ((loz + (float)(iz + (sz > 0 ? 1 : 0)) * h) - oz) * rz;
+                        grid_walk_step(A, w, d);
+                        rec = grid_walk_cell(A, w);
                     }
-                    rec = (uint32_t)((iz * ny + iy) * nx + ix);
                 }
             }
         }
     }
-    if (__builtin_expect(wave_any(full), 0)) {   // a ray from so far away that the reference's discriminant is coarser than a cell: every record
+    if (wave_any(full)) {
         for (uint32_t r = 0; r < A.grid_records; ++r)
             if (full) (void)visit(r);
     }
+    if (far) w_keys[lane] = key;
+}
+
+template <bool MOVING, bool COUNT, int BLK>
+__device__ __forceinline__ void grid_trace(const KArgs &A, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, f3 o, f3 d, const DivA &av, float time, bool start, Steal4 &cnt,
+                                           unsigned long long *sec = nullptr) {
+    const int tid = threadIdx.x;
+    const uint32_t lane = (uint32_t)tid & 63u;
+#ifdef PT_SECTIONS
+    unsigned long long sub_last = __builtin_readcyclecounter();   // sec[5] walk rounds, sec[6] drains, sec[7] rounds (count)
+#define PT_SUBT(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); sec[i] += now_ - sub_last; sub_last = now_; } while (0)
+#else
+    (void)sec;
+#define PT_SUBT(i) do { } while (0)
+#endif
+    const uint32_t owner_tag = lane << kPairLaneShift;
+    const float a = av.a;
+    const f3 rcp = mk3(recip_exact(d.x), recip_exact(d.y), recip_exact(d.z));   // ray.rs:14 (the gates of a BVH world read it; the walk where it is finite)
+    float limit = kMaxT;
+    if (start) {
+        float best = kMaxT;
+        int idx = -1;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < A.n_grid_large; ++j) {
+            const int k = (int)A.grid_large[j];
+            bvh_leaf(A, k, sphere_at<MOVING>(A, k, A.spheres[k], time), o, d, rcp, av, best, idx, rank);
+        }
+        w_keys[lane] = idx < 0 ? ~0ull : key4_of(A, best, idx);
+        limit = trav4_limit(idx < 0 ? kMaxT : best);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    // ---- does this ray walk one line?
+    const float gx = o.x - A.grid_centre[0], gy = o.y - A.grid_centre[1], gz = o.z - A.grid_centre[2];
+    const float dist = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz) * 1.001f + A.grid_half_diag;
+    const bool far = start && !(dist <= A.grid_d_build);
+    GridWalk w;
+    grid_walk_start(A, w, o, d, rcp, start && !far);
+    uint32_t rec = grid_walk_cell(A, w);
+    const float ia = __builtin_amdgcn_rcpf(a);
+    uint32_t qn = 0;
+#ifdef PT_GRID_ROUNDS
+    uint32_t dbg_visits = 0u, dbg_rounds = 0u;
+    if (COUNT && lane == 0u) cnt.leaves += 1u;
+#endif
+    for (;;) {
+        bool go = w.alive && w.tcur <= __builtin_fminf(w.t_out, limit);
+        if (!wave_any(go) || wave_any(qn > A.drain_at)) {
+            PT_SUBT(5);
+            // exact tests of everything queued; the limit becomes the exact one of the lane's key (an empty key's t field is a NaN pattern: not < kMaxT)
+            if (drain_pairs4<MOVING, BLK>(A, leafq, w_pairs, w_keys, qn, o, d, av, time, owner_tag)) limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[lane] >> 32)));
+            go = w.alive && w.tcur <= __builtin_fminf(w.t_out, limit);
+            PT_SUBT(6);
+            if (!wave_any(go)) break;
+        }
+#ifdef PT_SECTIONS
+        sec[7] += 1ull;
+#endif
+#ifdef PT_GRID_ROUNDS   // development aid: wave-level rounds instead of record visits, calls instead of positive discriminants
+        if (COUNT && lane == 0u) cnt.visits += 1u;
+        dbg_rounds += 1u;
+#endif
+        if (go) {
+            const uint4 *cp = A.grid_cells + (size_t)rec * 5u;
+            uint4 q0 = cp[0], q1 = cp[1], q2 = cp[2], q3 = cp[3], m = cp[4];
+            // (all five loads in flight at once: left alone, the scheduler issues them one by one, each behind the arithmetic of the one
+            //  before -- four round trips to the L2 per record instead of one -- to save the sixteen registers this takes)
+            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w),
+                         "+v"(q3.x), "+v"(q3.y), "+v"(q3.z), "+v"(q3.w), "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));
+#ifdef PT_GRID_ROUNDS
+            dbg_visits += 1u;
+#else
+            if (COUNT) cnt.visits += 1u;
+#endif
+            // the reference's discriminants (sphere.rs:33-37, its operation order), two spheres per packed instruction
+            typedef float v2f __attribute__((ext_vector_type(2)));
+            const uint32_t ks[4] = {m.x, m.y, m.z, m.w};
+            const uint4 qp[2][2] = {{q0, q1}, {q2, q3}};
+            float nb_min = __builtin_inff(), d_sel = -1.0f;   // the positive candidate whose closest approach comes first: the one the estimate is formed for
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                v2f X = {__uint_as_float(qp[pr][0].x), __uint_as_float(qp[pr][0].y)}, Y = {__uint_as_float(qp[pr][0].z), __uint_as_float(qp[pr][0].w)};
+                v2f Z = {__uint_as_float(qp[pr][1].x), __uint_as_float(qp[pr][1].y)}, Rr = {__uint_as_float(qp[pr][1].z), __uint_as_float(qp[pr][1].w)};
+                if (MOVING) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const uint32_t k = ks[2 * pr + e];
+                        const float4 c = sphere_at<MOVING>(A, (int)(k < A.n_spheres ? k : 0u), make_float4(X[e], Y[e], Z[e], Rr[e]), time);
+                        X[e] = c.x, Y[e] = c.y, Z[e] = c.z;
+                    }
+                }
+                const v2f ocx = o.x - X, ocy = o.y - Y, ocz = o.z - Z;
+                const v2f b = (ocx * d.x + ocy * d.y) + ocz * d.z;
+                const v2f cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - Rr * Rr;
+                const v2f disc = b * b - a * cc;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const uint32_t k = ks[2 * pr + e];
+                    // a sphere the ray is leaving through its surface (every scattered ray's own): its far root (-b + sqrt(disc)) / a lies
+                    // below 2.5e-4 when -cc < 5e-4 b, four times under t_min -- the reference rejects both roots (sphere.rs:41,52), whatever the
+                    // last bits of its quotient (for |b| < 100 the two differ by less than 1e-4): not queued
+                    const bool leaving = b[e] > 0.0f && b[e] < 100.0f && -cc[e] < 5.0e-4f * b[e];
+                    const bool pos = disc[e] > 0.0f && k < A.n_spheres && !leaving;   // (an empty slot, or the link, is no list index)
+                    leafq[qn * BLK + tid] = owner_tag | k;
+                    qn += pos ? 1u : 0u;
+#ifndef PT_GRID_ROUNDS
+                    if (COUNT) cnt.leaves += pos ? 1u : 0u;
+#endif
+                    const bool nearer = pos && -b[e] < nb_min;
+                    nb_min = nearer ? -b[e] : nb_min, d_sel = nearer ? disc[e] : d_sel;
+                }
+            }
+            // where that candidate would be hit, roughly: the walk pauses beyond it until the drain has the exact answer
+            float tq = __builtin_inff();
+            {
+                const float sq = __builtin_amdgcn_sqrtf(d_sel);
+                const float t1 = (nb_min - sq) * ia, t2 = (nb_min + sq) * ia;
+                tq = t1 > 2.0e-3f ? t1 : (t2 > 2.0e-3f ? t2 : tq);   // (no candidate: d_sel = -1, the root is NaN and nothing compares true)
+            }
+            limit = __builtin_fminf(limit, tq * 1.001f + 1.0e-3f);
+            if (m.w & kGridLinkBit) {
+                rec = m.w & ~kGridLinkBit;   // the cell continues in another record
+            } else {
+                grid_walk_step(A, w, d);
+                rec = grid_walk_cell(A, w);
+            }
+        }
+    }
+    PT_SUBT(5);
+#undef PT_SUBT
 #ifdef PT_GRID_ROUNDS   // histograms: record visits per ray [24..55], rounds per call [56..87]
     if (COUNT && start) atomicAdd(&A.debug[24u + min(dbg_visits, 31u)], 1ull);
     if (COUNT && lane == 0u) atomicAdd(&A.debug[56u + min(dbg_rounds, 31u)], 1ull);
 #endif
-    if (start) w_keys[lane] = idx < 0 ? ~0ull : key4_of(A, best, idx);
+    if (__builtin_expect(wave_any(far), 0)) {
+        const float delta = far ? A.grid_infl * (dist * dist + A.grid_rmax2) * 1.001f : 0.0f;
+        grid_far_rays<MOVING, COUNT>(A, w_keys, o, d, rcp, av, time, far, delta, cnt);
+    }
 }
 
 }  // namespace ptdev

@@ -95,6 +95,7 @@ struct pt_scene {
     float4 *d_slotrec = nullptr;
     uint4 *d_grid_cells = nullptr;                   // uniform cell grid (GridPlan below; tr.grid_ok)
     uint32_t *d_grid_large = nullptr;
+    float4 *d_grid_rec = nullptr;
     pthostside_grid_geom grid_geom{};
     float tree_build_ms = 0.f;                       // device time of that build (HIP events)
     bool tree_on_device = false;
@@ -218,7 +219,8 @@ Tree4Host tree4_build_host(std::vector<TreeItem> items);
 
 // Uniform cell grid over the small spheres of a big scene (csrc/pt_grid.h): what the tree kernels walk instead of the 4-wide tree when the
 // spheres are many, of similar size and spread evenly enough. Results never depend on it. One RECORD is five 16-byte words: up to four
-// spheres (cx, cy, cz, radius as KArgs::spheres holds them; an empty slot holds a sphere nothing hits) and their list indices; the first
+// spheres (cx, cy, cz, radius as KArgs::spheres holds them; an empty slot holds a sphere nothing hits; spheres 0 | 1 and 2 | 3 are stored
+// side by side, component by component: (x0 x1 y0 y1) (z0 z1 r0 r1) (x2 x3 y2 y3) (z2 z3 r2 r3)) and their list indices; the first
 // n[0] n[1] n[2] records are the cells (x fastest), a cell with more than four spheres continues in a record behind them (three spheres
 // + link 0x80000000 | record). A sphere is registered in every cell its box -- padded by how far the reference's f32 discriminant can
 // inflate it for a ray whose origin lies within `d_build` of it (pt_tree4.h: 0.65e-6 (|o - c|^2 + r^2) / r; 1e-6 here) plus h / 1000 for the
@@ -230,6 +232,7 @@ struct GridPlan {
     float centre[3] = {0, 0, 0}, half_diag = 0.f, d_build = 0.f;
     float infl = 0.f, rmax2 = 0.f;     // inflation of the thinnest sphere for a ray from distance D: infl * (D^2 + rmax2)
     std::vector<uint4> cells;          // 5 per record
+    std::vector<float4> rec;           // per SPHERE, the slot record of an exact test (KArgs::slotrec layout: sphere | gate min | gate max | rank bits, index bits): filled by plan_sphere_scene
     std::vector<uint32_t> large;       // spheres outside the grid: tested for every ray
     double items_per_cell = 0.0, records_per_cell = 0.0;
 };

@@ -348,7 +348,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         for (int k = 0; k < 3; ++k) A.grid_n[k] = q.n[k], A.grid_min[k] = q.gmin[k], A.grid_centre[k] = q.centre[k];
         A.grid_h = q.h, A.grid_inv_h = 1.0f / q.h, A.grid_half_diag = q.half_diag, A.grid_d_build = q.d_build, A.grid_infl = q.infl, A.grid_rmax2 = q.rmax2;
     }
-    A.slotrec = s->d_slotrec;
+    A.slotrec = c.grid ? s->d_grid_rec : s->d_slotrec;   // (grid: the exact tests' records are per sphere, not per leaf slot of the tree)
     A.rank_sphere = s->d_rank_sphere;
     A.shade_rank = s->d_shade_rank;
     A.leaf_rank = s->d_leaf_rank;

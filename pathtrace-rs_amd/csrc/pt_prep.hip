@@ -509,7 +509,7 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
     }
     union FU { float f; uint32_t u; };
     const auto bits = [](float f) { FU q; q.f = f; return q.u; };
-    const uint4 never = make_uint4(bits(3.0e38f), bits(3.0e38f), bits(3.0e38f), 0u);
+    const float4 never = make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f);
     std::vector<uint4> rec(5 * cells);
     for (size_t c = 0; c < cells; ++c) {
         std::vector<uint32_t> &L = lists[c];
@@ -518,11 +518,13 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
         for (;;) {
             const size_t left = L.size() - done, take = left <= 4 ? left : 3;
             uint32_t ids[4] = {kGridNone, kGridNone, kGridNone, kGridNone};
-            for (size_t j = 0; j < 4; ++j) rec[5 * at + j] = never;
-            for (size_t j = 0; j < take; ++j) {
-                const float4 q = sph[L[done + j]];
-                rec[5 * at + j] = make_uint4(bits(q.x), bits(q.y), bits(q.z), bits(q.w));
-                ids[j] = L[done + j];
+            float4 four[4] = {never, never, never, never};
+            for (size_t j = 0; j < take; ++j) four[j] = sph[L[done + j]], ids[j] = L[done + j];
+            // spheres 0 | 1 and 2 | 3 side by side, component by component: a 16-byte load fills two operand PAIRS of the packed f32 instructions
+            for (size_t pr = 0; pr < 2; ++pr) {
+                const float4 u = four[2 * pr], v = four[2 * pr + 1];
+                rec[5 * at + 2 * pr] = make_uint4(bits(u.x), bits(v.x), bits(u.y), bits(v.y));
+                rec[5 * at + 2 * pr + 1] = make_uint4(bits(u.z), bits(v.z), bits(u.w), bits(v.w));
             }
             done += take;
             if (done == L.size()) {
@@ -825,6 +827,14 @@ int plan_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, SphereP
         }
     }
     tr.grid_ok = plan_cell_grid(desc, motion, t_lo, t_hi, P.sph, P.grid);
+    if (tr.grid_ok) {   // what drain_pairs4 reads for a queued sphere: ONE 64-byte fetch per exact test, as the tree's leaf slots
+        P.grid.rec.resize(4 * (size_t)desc->n_spheres);
+        for (uint32_t i = 0; i < desc->n_spheres; ++i) {
+            union { uint32_t u; float f; } rk{P.leaf_rank[i]}, ix{i};
+            P.grid.rec[4 * (size_t)i] = P.sph[i], P.grid.rec[4 * (size_t)i + 1] = P.gate[2 * (size_t)i], P.grid.rec[4 * (size_t)i + 2] = P.gate[2 * (size_t)i + 1];
+            P.grid.rec[4 * (size_t)i + 3] = make_float4(rk.f, ix.f, 0.f, 0.f);
+        }
+    }
     P.pvec.assign(256, make_float4(0, 0, 0, 0));
     P.pperm.assign(768, 0);
     if (desc->perlin) {

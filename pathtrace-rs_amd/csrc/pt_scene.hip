@@ -93,7 +93,9 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
     if (P.has_motion && (rc = upload(&s->d_motion, P.mot.data(), P.mot.size()))) return bail(rc);
     if (P.grid.ok) {   // uniform cell grid (csrc/pt_grid.h): tr.grid_ok was set by the plan
         const GridPlan &g = P.grid;
-        if ((rc = upload(&s->d_grid_cells, g.cells.data(), g.cells.size())) || (rc = upload(&s->d_grid_large, g.large.data(), g.large.size()))) return bail(rc);
+        if ((rc = upload(&s->d_grid_cells, g.cells.data(), g.cells.size())) || (rc = upload(&s->d_grid_large, g.large.data(), g.large.size())) ||
+            (rc = upload(&s->d_grid_rec, g.rec.data(), g.rec.size())))
+            return bail(rc);
         pthostside_grid_geom &q = s->grid_geom;
         for (int k = 0; k < 3; ++k) q.n[k] = g.n[k], q.gmin[k] = g.gmin[k], q.centre[k] = g.centre[k];
         q.n_records = g.n_records, q.n_large = (uint32_t)g.large.size();
@@ -253,7 +255,7 @@ extern "C" void pt_scene_destroy(pt_scene *s) {
                          s->d_shade, s->d_sphere_mat, s->d_mats, s->d_texs, s->d_perlin_vec, s->d_perlin_perm, s->d_gate, s->d_gate_chain, s->d_bvh_large,
                          s->d_wnodes, s->d_nodes4, s->d_nodes4q, s->d_slotrec, s->d_rank_sphere, s->d_leafrec, s->d_shade_rank, s->d_leaf_rank, s->d_afrag,
                          s->d_tile_sphere, s->d_cull_tab, s->d_large, s->d_debug, s->d_tile_buf, s->d_px_state, s->d_work_counter, s->d_ray_count,
-                         s->d_frame, s->d_gstack, s->d_wave_end, s->d_tail_box, s->d_gnodes, s->d_gchildren, s->d_gframes, s->d_grid_cells, s->d_grid_large};
+                         s->d_frame, s->d_gstack, s->d_wave_end, s->d_tail_box, s->d_gnodes, s->d_gchildren, s->d_gframes, s->d_grid_cells, s->d_grid_large, s->d_grid_rec};
     for (void *p : dev) (void)hipFree(p);
     (void)hipHostFree(s->h_stage);
     if (s->ev_start) (void)hipEventDestroy(s->ev_start);

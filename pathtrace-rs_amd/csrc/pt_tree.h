@@ -218,6 +218,53 @@ __device__ __forceinline__ void pair_test4_owner(const KArgs &A, uint32_t slot, 
     pair_test4<MOVING>(A, slot, time, o, d, rcp, av, key);
 }
 
+// Exact tests of the leaf candidates the lanes of a wave have queued (`leafq`, `qn` per lane; an entry = owner lane << kPairLaneShift | slot
+// record): expanded into ONE list of (owner ray, slot) pairs per wave, every lane takes one pair per round whoever's ray it belongs to,
+// and the test reduces into the owner's (t, tie-break) key with ds_min_u64. The owners' rays are fetched across lanes from (o, d, av,
+// time): the registers every lane holds for ITS OWN ray. Returns false when nothing was queued; empties the queues.
+template <bool MOVING, int BLK>
+__device__ __forceinline__ bool drain_pairs4(const KArgs &A, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, uint32_t &qn, f3 o, f3 d, const DivA &av, float time,
+                                             uint32_t owner_tag) {
+    const int tid = threadIdx.x;
+    const uint32_t lane = (uint32_t)tid & 63u;
+    const uint32_t incl = wave_inclusive_sum(qn);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (total == 0u) return false;
+    const float a = av.a;
+    if (total > (uint32_t)kPairCap) {
+        // more pairs than the wave's list holds (rare): every lane walks its own queue, the owners' rays still come across lanes
+        for (uint32_t j = 0; wave_any(j < qn); ++j) {
+            const bool valid = j < qn;
+            const uint32_t e = valid ? leafq[j * BLK + tid] : owner_tag;
+            const uint32_t ow = e >> kPairLaneShift;
+            const f3 po = mk3(lane_fetch(ow, o.x), lane_fetch(ow, o.y), lane_fetch(ow, o.z));
+            const f3 pd = mk3(lane_fetch(ow, d.x), lane_fetch(ow, d.y), lane_fetch(ow, d.z));
+            const DivA pav{lane_fetch(ow, a), lane_fetch(ow, av.y), av.fast};
+            const float ptime = MOVING ? lane_fetch(ow, time) : 0.0f;
+            if (valid) pair_test4_owner<MOVING>(A, e & ((1u << kPairLaneShift) - 1u), ptime, po, pd, pav, &w_keys[ow]);
+        }
+    } else {
+        uint32_t pos = incl - qn;
+        for (uint32_t j = 0; j < qn; ++j) w_pairs[pos++] = leafq[j * BLK + tid];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t b0 = 0; b0 < total; b0 += 64u) {
+            const bool valid = b0 + lane < total;
+            const uint32_t e = valid ? w_pairs[b0 + lane] : owner_tag;
+            const uint32_t ow = e >> kPairLaneShift;
+            const f3 po = mk3(lane_fetch(ow, o.x), lane_fetch(ow, o.y), lane_fetch(ow, o.z));
+            const f3 pd = mk3(lane_fetch(ow, d.x), lane_fetch(ow, d.y), lane_fetch(ow, d.z));
+            const DivA pav{lane_fetch(ow, a), lane_fetch(ow, av.y), av.fast};
+            const float ptime = MOVING ? lane_fetch(ow, time) : 0.0f;
+            if (valid) pair_test4_owner<MOVING>(A, e & ((1u << kPairLaneShift) - 1u), ptime, po, pd, pav, &w_keys[ow]);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    qn = 0;
+    return true;
+}
+
 template <bool MOVING, bool COUNT, int BLK>
 __device__ __forceinline__ void bvh4_trace(const KArgs &A, uint16_t *s_stack, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys,
                                            f3 o, f3 d, const DivA &av, float time, bool start, Steal4 &cnt, unsigned long long *sec = nullptr) {
@@ -308,43 +355,8 @@ __device__ __forceinline__ void bvh4_trace(const KArgs &A, uint16_t *s_stack, ui
         sec[7] += 1ull;
 #endif
         if (stop || wave_any(qn > A.drain_at)) {
-            // exact tests of the queued leaf candidates, one (owner ray, leaf slot) pair per lane and round, reduced into the owner's key
-            // with ds_min_u64 (the entries carry their owner); afterwards every lane refreshes its culling limit from ITS owner's key
-            const uint32_t incl = wave_inclusive_sum(qn);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (total != 0u) {
-                const float a = av.a;
-                if (total > (uint32_t)kPairCap) {
-                    // more pairs than the wave's list holds (rare): every lane walks its own queue, the owners' rays still come across lanes
-                    for (uint32_t j = 0; wave_any(j < qn); ++j) {
-                        const bool valid = j < qn;
-                        const uint32_t e = valid ? leafq[j * BLK + tid] : owner_tag;
-                        const uint32_t ow = e >> kPairLaneShift;
-                        const f3 po = mk3(lane_fetch(ow, o.x), lane_fetch(ow, o.y), lane_fetch(ow, o.z));
-                        const f3 pd = mk3(lane_fetch(ow, d.x), lane_fetch(ow, d.y), lane_fetch(ow, d.z));
-                        const DivA pav{lane_fetch(ow, a), lane_fetch(ow, av.y), av.fast};
-                        const float ptime = MOVING ? lane_fetch(ow, time) : 0.0f;
-                        if (valid) pair_test4_owner<MOVING>(A, e & ((1u << kPairLaneShift) - 1u), ptime, po, pd, pav, &w_keys[ow]);
-                    }
-                } else {
-                    uint32_t pos = incl - qn;
-                    for (uint32_t j = 0; j < qn; ++j) w_pairs[pos++] = leafq[j * BLK + tid];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    for (uint32_t b0 = 0; b0 < total; b0 += 64u) {
-                        const bool valid = b0 + lane < total;
-                        const uint32_t e = valid ? w_pairs[b0 + lane] : owner_tag;
-                        const uint32_t ow = e >> kPairLaneShift;
-                        const f3 po = mk3(lane_fetch(ow, o.x), lane_fetch(ow, o.y), lane_fetch(ow, o.z));
-                        const f3 pd = mk3(lane_fetch(ow, d.x), lane_fetch(ow, d.y), lane_fetch(ow, d.z));
-                        const DivA pav{lane_fetch(ow, a), lane_fetch(ow, av.y), av.fast};
-                        const float ptime = MOVING ? lane_fetch(ow, time) : 0.0f;
-                        if (valid) pair_test4_owner<MOVING>(A, e & ((1u << kPairLaneShift) - 1u), ptime, po, pd, pav, &w_keys[ow]);
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                qn = 0;
+            // exact tests of the queued leaf candidates (drain_pairs4); afterwards every lane refreshes its culling limit from ITS owner's key
+            if (drain_pairs4<MOVING, BLK>(A, leafq, w_pairs, w_keys, qn, o, d, av, time, owner_tag)) {
                 limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[owner_tag >> kPairLaneShift] >> 32)));   // (an empty key's t field is a NaN pattern: not < kMaxT)
             }
         }

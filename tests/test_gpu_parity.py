@@ -1432,7 +1432,7 @@ def _far_origin_world(oracle, seed, n, W, H, spread, rmax, kind, scale, moving=F
     return dict(w, hitables=np.concatenate([rec, more]), camera=cam)
 
 
-def _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, depth=10):
+def _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, depth=10, more_variants=(), default_kernel=None):
     """Default kernel, no tile culling (1024), exact VALU scan (4 | 64) and -- list worlds the prefilter takes -- verify mode
     (8: dropped positives and culled winners must be 0), every one against the ORACLE."""
     osc = oracle.OracleScene.from_world(w["hitables"], w["transforms"], w["materials"], w["textures"], w["camera"], W, H, sky=w["sky"], use_bvh=bvh)
@@ -1441,12 +1441,14 @@ def _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, dep
     sc = ptgpu.Scene(oracle.to_ptgpu_world_desc(ptgpu, ex), 0)
     p, cam = ptgpu.PtParams(W, H, S, depth, 0, 1 if bvh else 0), ptgpu.PtCamera.from_floats(ex["camera"])
     bad = []
-    for variant in (0, 1024, 4 | 64) + ((256,) if bvh else (8,)):
+    for variant in (0, 1024, 4 | 64) + ((256,) if bvh else (8,)) + tuple(more_variants):
         sc.set_tuning(0, variant)
         if variant == 8:
             sc.debug_counters(reset=True)
         out = np.zeros((H, W, 3), np.float32)
         rays = sc.update(p, cam, 0, out)
+        if variant == 0 and default_kernel is not None and not sc.last_kernel_choice()["name"].startswith(default_kernel):
+            bad.append("default kernel is %s, expected %s..." % (sc.last_kernel_choice()["name"], default_kernel))
         if rays != ref_rays or not np.array_equal(ref, out, equal_nan=True):
             bad.append("variant %d: rays %d vs %d, %s" % (variant, rays, ref_rays, _report(ref, out)))
         if variant == 8:
@@ -1478,6 +1480,30 @@ def test_far_ray_origins_with_moving_spheres(ptgpu, oracle, scale, bvh):
     W, H, S = 96, 64, 3
     w = _far_origin_world(oracle, 41, 200, W, H, 4.0, 0.7, "enclosing", scale, moving=True)
     bad = _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh)
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("kind,scale", [("enclosing", 1.0e2), ("enclosing", 2.0e3), ("enclosing", 3.0e5), ("offcentre", 3.0e2), ("ground", 1.0e4), ("mirrors", 1.0e3)])
+@pytest.mark.parametrize("bvh", [False, True])
+def test_cell_grid_walk_equals_the_oracle_from_near_far_and_beyond(ptgpu, oracle, kind, scale, bvh):
+    """Worlds of 1 500 small spheres -- the size from which a scene gets a uniform cell grid (csrc/pt_grid.h) -- with bounce origins inside
+    the cloud, a few half diagonals away (the 27 displaced lines of grid_far_rays) and so far away that the reference's f32
+    discriminant is coarser than a cell (every record): the default kernel must BE the grid walk, and it, the 4-wide tree (524288), the
+    exact scan and verify mode's counting twin (8 | 256) all equal the ORACLE bit for bit, list and BVH semantics."""
+    W, H, S = 112, 80, 3
+    w = _far_origin_world(oracle, 57, 1500, W, H, 9.0, 0.3, kind, scale)
+    bad = _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, depth=25 if kind == "offcentre" else 10, more_variants=(524288, 8 | 256), default_kernel="grid<")
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("scale", [3.0e2, 3.0e5])
+@pytest.mark.parametrize("bvh", [False, True])
+def test_cell_grid_walk_with_moving_spheres(ptgpu, oracle, scale, bvh):
+    """The MOVING flavour: 1 300 Sphere + MovingSphere entries (cells hold a moving sphere wherever its sweep reaches; the discriminants
+    use the centre at the ray's time), near and far bounce origins, against the oracle and the tree."""
+    W, H, S = 96, 64, 3
+    w = _far_origin_world(oracle, 43, 1300, W, H, 4.0, 0.7, "enclosing", scale, moving=True)
+    bad = _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, more_variants=(524288,), default_kernel="grid<")
     assert not bad, bad
 
 
