@@ -112,11 +112,12 @@ struct KArgs {
     uint32_t n_bvh_large;
     // uniform cell grid (pt_grid.h; pt_host.h GridPlan): non-NULL grid_cells selects it in the 4-wide tree kernels
     const uint4 *grid_cells;     // [n_records][5]: four spheres (cx, cy, cz, radius) + (index x 4 | link in the last word)
+    const float4 *grid_rec;      // per SPHERE, the 64-byte record of an exact test (slotrec's layout)
     const uint32_t *grid_large;  // spheres outside the grid: tested for every ray
-    uint32_t n_grid_large, grid_records;
+    uint32_t n_grid_large;
     uint32_t grid_n[3];
     float grid_min[3], grid_h, grid_inv_h;
-    float grid_centre[3], grid_half_diag, grid_d_build, grid_infl, grid_rmax2;
+    float grid_centre[3], grid_half_diag, grid_d_build;   // a ray whose origin is farther than d_build - half_diag from the centre walks the tree instead
     uint32_t n_spheres;
     uint32_t n_spheres_pad;      // multiple of kScanUnroll; padding entries can never be hit
     // MFMA discriminant prefilter (list mode, see "MFMA prefilter" below); n_tiles == 0 disables it

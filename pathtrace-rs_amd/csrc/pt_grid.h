@@ -25,10 +25,9 @@
 //   * the walk visits every cell the line passes through from its entry into the grid's box to the first cell whose entry parameter lies
 //     beyond best * 1.0005 + 5e-4 (the tree's culling slack: the reference's root can fall below the true parameter);
 //   * a ray from FARTHER away (|o - centre| + half diagonal > grid_d_build: the reference's discriminant is coarser than the registration
-//     assumed) walks 27 parallel lines, its own and those displaced by -+ its own inflation bound per axis: a point within that bound of
-//     a registered box lies, per axis, in the cell of one of the three displaced points (the bound is below the cell size; beyond that the
-//     ray looks at every record). Rare by construction (a camera framing the spheres sits at two half diagonals): grid_far_rays, one
-//     lane per ray, exact tests on the spot.
+//     assumed) does not walk the grid at all: it walks the scene's 4-wide tree, whose boxes are padded for the ray at hand (bvh4_trace,
+//     called for such lanes at the end; the other lanes of the wave help). How often that happens is a property of the scene (bounce
+//     origins on a huge ground far from the spheres): d_build is a cost knob, not a limit.
 // Large spheres (KArgs::grid_large) are tested for every ray first, as the tree kernels do with theirs.
 #pragma once
 
@@ -36,7 +35,7 @@ namespace ptdev {
 
 constexpr uint32_t kGridLinkBit = 0x80000000u;
 
-// The DDA of one lane: the line (origin + t direction, the origin possibly displaced: far rays), the cell it is in, the parameters at
+// The DDA of one lane: the line (origin + t direction), the cell it is in, the parameters at
 // which it crosses the next cell boundary per axis.
 struct GridWalk {
     float ox, oy, oz, rx, ry, rz;   // line origin; 1 / direction (0 along an axis the line does not move along)
@@ -93,69 +92,8 @@ __device__ __forceinline__ void grid_walk_step(const KArgs &A, GridWalk &w, f3 d
     }
 }
 
-// Rays from beyond grid_d_build (see the head of the file), one lane per ray: 27 displaced lines -- or every record -- with the exact test
-// of each positive discriminant on the spot; the result is reduced into w_keys[lane] like any other candidate's.
-template <bool MOVING, bool COUNT>
-__device__ __forceinline__ void grid_far_rays(const KArgs &A, unsigned long long *w_keys, f3 o, f3 d, f3 rcp, const DivA &av, float time, bool far, float delta, Steal4 &cnt) {
-    const uint32_t lane = threadIdx.x & 63u;
-    unsigned long long key = far ? w_keys[lane] : ~0ull;
-    float limit = trav4_limit(__uint_as_float((uint32_t)(key >> 32)));
-    const float a = av.a;
-    const auto visit = [&](uint32_t rec) -> uint32_t {
-        const uint4 *cp = A.grid_cells + (size_t)rec * 5u;
-        const uint4 q0 = cp[0], q1 = cp[1], q2 = cp[2], q3 = cp[3], m = cp[4];
-        const uint4 qs[4] = {make_uint4(q0.x, q0.z, q1.x, q1.z), make_uint4(q0.y, q0.w, q1.y, q1.w), make_uint4(q2.x, q2.z, q3.x, q3.z), make_uint4(q2.y, q2.w, q3.y, q3.w)};
-        const uint32_t ks[4] = {m.x, m.y, m.z, m.w};
-        if (COUNT) cnt.visits += 1u;
-        for (int j = 0; j < 4; ++j) {
-            if (!(ks[j] < A.n_spheres)) continue;
-            float4 c = make_float4(__uint_as_float(qs[j].x), __uint_as_float(qs[j].y), __uint_as_float(qs[j].z), __uint_as_float(qs[j].w));
-            c = sphere_at<MOVING>(A, (int)ks[j], c, time);
-            const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
-            const float b = (ocx * d.x + ocy * d.y) + ocz * d.z;
-            const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w * c.w;
-            const float disc = b * b - a * cc;
-            if (!(disc > 0.0f)) continue;
-            if (COUNT) cnt.leaves += 1u;
-            const float t = sphere_hit_t(DivA{av.a, av.y, false}, b, disc, true);
-            if (t < kMaxT) {
-                const unsigned long long kk = key4_of(A, t, (int)ks[j]);
-                if (kk < key && (!A.gate || gate_pass(A, (int)ks[j], o, rcp))) key = kk;
-            }
-        }
-        limit = trav4_limit(__uint_as_float((uint32_t)(key >> 32)));
-        return m.w;
-    };
-    const bool full = far && !(delta <= A.grid_h);   // (also a NaN origin)
-    if (wave_any(far && !full)) {
-        for (uint32_t line = 0; line < 27u; ++line) {
-            GridWalk w;
-            grid_walk_start(A, w, mk3(o.x + delta * (float)((int)(line % 3u) - 1), o.y + delta * (float)((int)((line / 3u) % 3u) - 1), o.z + delta * (float)((int)(line / 9u) - 1)), d, rcp, far && !full);
-            uint32_t rec = grid_walk_cell(A, w);
-            for (;;) {
-                const bool go = w.alive && w.tcur <= __builtin_fminf(w.t_out, limit);
-                if (!wave_any(go)) break;
-                if (go) {
-                    const uint32_t last = visit(rec);
-                    if (last & kGridLinkBit) {
-                        rec = last & ~kGridLinkBit;
-                    } else {
-                        grid_walk_step(A, w, d);
-                        rec = grid_walk_cell(A, w);
-                    }
-                }
-            }
-        }
-    }
-    if (wave_any(full)) {
-        for (uint32_t r = 0; r < A.grid_records; ++r)
-            if (full) (void)visit(r);
-    }
-    if (far) w_keys[lane] = key;
-}
-
 template <bool MOVING, bool COUNT, int BLK>
-__device__ __forceinline__ void grid_trace(const KArgs &A, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, f3 o, f3 d, const DivA &av, float time, bool start, Steal4 &cnt,
+__device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, f3 o, f3 d, const DivA &av, float time, bool start, Steal4 &cnt,
                                            unsigned long long *sec = nullptr) {
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
@@ -169,8 +107,12 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint32_t *leafq, uint
     const uint32_t owner_tag = lane << kPairLaneShift;
     const float a = av.a;
     const f3 rcp = mk3(recip_exact(d.x), recip_exact(d.y), recip_exact(d.z));   // ray.rs:14 (the gates of a BVH world read it; the walk where it is finite)
+    // ---- is this ray the grid's? (origin within d_build of every sphere: what the registration was padded for)
+    const float gx = o.x - A.grid_centre[0], gy = o.y - A.grid_centre[1], gz = o.z - A.grid_centre[2];
+    const float dist = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz) * 1.001f + A.grid_half_diag;
+    const bool far = start && !(dist <= A.grid_d_build);   // (also a NaN origin)
     float limit = kMaxT;
-    if (start) {
+    if (start && !far) {
         float best = kMaxT;
         int idx = -1;
         uint32_t rank = 0;
@@ -182,10 +124,6 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint32_t *leafq, uint
         limit = trav4_limit(idx < 0 ? kMaxT : best);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    // ---- does this ray walk one line?
-    const float gx = o.x - A.grid_centre[0], gy = o.y - A.grid_centre[1], gz = o.z - A.grid_centre[2];
-    const float dist = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz) * 1.001f + A.grid_half_diag;
-    const bool far = start && !(dist <= A.grid_d_build);
     GridWalk w;
     grid_walk_start(A, w, o, d, rcp, start && !far);
     uint32_t rec = grid_walk_cell(A, w);
@@ -200,7 +138,7 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint32_t *leafq, uint
         if (!wave_any(go) || wave_any(qn > A.drain_at)) {
             PT_SUBT(5);
             // exact tests of everything queued; the limit becomes the exact one of the lane's key (an empty key's t field is a NaN pattern: not < kMaxT)
-            if (drain_pairs4<MOVING, BLK>(A, leafq, w_pairs, w_keys, qn, o, d, av, time, owner_tag)) limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[lane] >> 32)));
+            if (drain_pairs4<MOVING, BLK>(A, A.grid_rec, leafq, w_pairs, w_keys, qn, o, d, av, time, owner_tag)) limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[lane] >> 32)));
             go = w.alive && w.tcur <= __builtin_fminf(w.t_out, limit);
             PT_SUBT(6);
             if (!wave_any(go)) break;
@@ -284,10 +222,8 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint32_t *leafq, uint
     if (COUNT && start) atomicAdd(&A.debug[24u + min(dbg_visits, 31u)], 1ull);
     if (COUNT && lane == 0u) atomicAdd(&A.debug[56u + min(dbg_rounds, 31u)], 1ull);
 #endif
-    if (__builtin_expect(wave_any(far), 0)) {
-        const float delta = far ? A.grid_infl * (dist * dist + A.grid_rmax2) * 1.001f : 0.0f;
-        grid_far_rays<MOVING, COUNT>(A, w_keys, o, d, rcp, av, time, far, delta, cnt);
-    }
+    // rays from beyond d_build: the 4-wide tree, whose boxes are padded for the ray at hand (lanes without such a ray help: bvh4_trace shares work)
+    if (__builtin_expect(wave_any(far), 0)) bvh4_trace<MOVING, COUNT, BLK>(A, s_stack, leafq, w_pairs, w_keys, o, d, av, time, far, cnt);
 }
 
 }  // namespace ptdev

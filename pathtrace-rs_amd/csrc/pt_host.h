@@ -67,7 +67,7 @@ int upload(T **dst, const void *src, size_t count) {
 
 struct pthostside_grid_geom {   // the scalars of a GridPlan the launch copies into KArgs
     uint32_t n[3], n_records, n_large;
-    float gmin[3], h, centre[3], half_diag, d_build, infl, rmax2;
+    float gmin[3], h, centre[3], half_diag, d_build;
 };
 
 // ---- the scene handle ------------------------------------------------------------------------------------------------
@@ -224,17 +224,16 @@ Tree4Host tree4_build_host(std::vector<TreeItem> items);
 // n[0] n[1] n[2] records are the cells (x fastest), a cell with more than four spheres continues in a record behind them (three spheres
 // + link 0x80000000 | record). A sphere is registered in every cell its box -- padded by how far the reference's f32 discriminant can
 // inflate it for a ray whose origin lies within `d_build` of it (pt_tree4.h: 0.65e-6 (|o - c|^2 + r^2) / r; 1e-6 here) plus h / 1000 for the
-// walk's own rounding -- overlaps. Rays from farther away walk 27 parallel lines (pt_grid.h), so `d_build` is a cost knob, not a limit.
+// walk's own rounding -- overlaps. Rays from farther away walk the 4-wide tree instead (pt_grid.h), so `d_build` is a cost knob, not a limit.
 struct GridPlan {
     bool ok = false;
     uint32_t n[3] = {1, 1, 1}, n_records = 0;
     float gmin[3] = {0, 0, 0}, h = 0.f;
     float centre[3] = {0, 0, 0}, half_diag = 0.f, d_build = 0.f;
-    float infl = 0.f, rmax2 = 0.f;     // inflation of the thinnest sphere for a ray from distance D: infl * (D^2 + rmax2)
     std::vector<uint4> cells;          // 5 per record
     std::vector<float4> rec;           // per SPHERE, the slot record of an exact test (KArgs::slotrec layout: sphere | gate min | gate max | rank bits, index bits): filled by plan_sphere_scene
     std::vector<uint32_t> large;       // spheres outside the grid: tested for every ray
-    double items_per_cell = 0.0, records_per_cell = 0.0;
+    double items_per_cell = 0.0, records_per_cell = 0.0, occupied = 0.0;   // (statistics of the plan; occupied: share of the cells that hold a sphere)
 };
 bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_lo, double t_hi, const std::vector<float4> &sph, GridPlan &out);
 

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         int idx;
         if (TREE4) {
             // (every ray of the wave is finished when this returns: no traversal state is carried into the next trip)
-            if (GRID) grid_trace<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, ro, rd, av, rtime, have, steal4
+            if (GRID) grid_trace<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint16_t *>(s_bvh), reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, ro, rd, av, rtime, have, steal4
 #ifdef PT_SECTIONS
                                                          , sec_t
 #endif

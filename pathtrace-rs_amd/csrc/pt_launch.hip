@@ -344,11 +344,11 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.nodes4 = s->d_nodes4q;
     if (c.grid) {
         const pthostside_grid_geom &q = s->grid_geom;
-        A.grid_cells = s->d_grid_cells, A.grid_large = s->d_grid_large, A.n_grid_large = q.n_large, A.grid_records = q.n_records;
+        A.grid_cells = s->d_grid_cells, A.grid_rec = s->d_grid_rec, A.grid_large = s->d_grid_large, A.n_grid_large = q.n_large;
         for (int k = 0; k < 3; ++k) A.grid_n[k] = q.n[k], A.grid_min[k] = q.gmin[k], A.grid_centre[k] = q.centre[k];
-        A.grid_h = q.h, A.grid_inv_h = 1.0f / q.h, A.grid_half_diag = q.half_diag, A.grid_d_build = q.d_build, A.grid_infl = q.infl, A.grid_rmax2 = q.rmax2;
+        A.grid_h = q.h, A.grid_inv_h = 1.0f / q.h, A.grid_half_diag = q.half_diag, A.grid_d_build = q.d_build;
     }
-    A.slotrec = c.grid ? s->d_grid_rec : s->d_slotrec;   // (grid: the exact tests' records are per sphere, not per leaf slot of the tree)
+    A.slotrec = s->d_slotrec;
     A.rank_sphere = s->d_rank_sphere;
     A.shade_rank = s->d_shade_rank;
     A.leaf_rank = s->d_leaf_rank;

@@ -542,14 +542,23 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
     G.h = (float)g.h;
     // (the kernel works with these f32 values; the registration above used the doubles they were rounded from -- h / 1000 covers the difference)
     G.half_diag = (float)(half_diag * 1.0001), G.d_build = (float)(d_build * 0.999);
-    G.infl = (float)(infl / r_min * 1.0001), G.rmax2 = (float)(r_max * r_max * 1.0001);
     G.n_records = (uint32_t)(rec.size() / 5);
     G.cells.swap(rec);
     G.large.swap(large);
     G.items_per_cell = (double)regs / (double)cells, G.records_per_cell = (double)G.n_records / (double)cells;
+    size_t occupied = 0;
+    for (const std::vector<uint32_t> &L : lists) occupied += L.empty() ? 0u : 1u;
+    G.occupied = (double)occupied / (double)cells;
+    // Where the walk pays (tools/grid_ab.py, grid against the 4-wide tree on one MI355X): an even, DENSE field of spheres -- config 5's single layer
+    // (4.1 spheres per cell, every cell occupied) 1.39x, 10 000 equal spheres filling a cube (5.5 per cell, 88 % occupied) 1.08x -- and not a
+    // loose cloud (1.1 ... 2.7 per cell, 64 ... 82 % occupied: 0.69 ... 0.91x; the tree skips empty space, the walk steps through it).
+    if (G.occupied < 0.9 || G.items_per_cell < 3.5) {
+        G = GridPlan{};
+        return false;
+    }
 #ifdef PT_GRID_ROUNDS
-    fprintf(stderr, "[ptgpu grid plan] %u x %u x %u cells of %.4f (median padded width %.4f), %zu spheres + %zu large, %.2f spheres and %.2f records per cell, d_build %.1f half_diag %.1f\n", G.n[0], G.n[1], G.n[2],
-            g.h, w_med, items.size(), G.large.size(), G.items_per_cell, G.records_per_cell, d_build, half_diag);
+    fprintf(stderr, "[ptgpu grid plan] %u x %u x %u cells of %.4f (median padded width %.4f), %zu spheres + %zu large, %.2f spheres and %.2f records per cell, %.0f %% of the cells occupied, d_build %.1f half_diag %.1f\n", G.n[0], G.n[1], G.n[2],
+            g.h, w_med, items.size(), G.large.size(), G.items_per_cell, G.records_per_cell, 100.0 * G.occupied, d_build, half_diag);
 #endif
     return true;
 }

@@ -172,10 +172,10 @@ __device__ __forceinline__ unsigned long long key4_of(const KArgs &A, float t, i
 // then the ancestor-AABB gate of a BVH world). The slot record holds the sphere together with its gate box, rank and
 // index: the accept rule needs no dependent loads.
 template <bool MOVING>
-__device__ __forceinline__ void pair_test4(const KArgs &A, uint32_t e, float time, f3 o, f3 d, f3 rcp, const DivA &av, unsigned long long *key) {
+__device__ __forceinline__ void pair_test4(const KArgs &A, const float4 *recs, uint32_t e, float time, f3 o, f3 d, f3 rcp, const DivA &av, unsigned long long *key) {
     const float a = av.a;
     const bool gated = A.gate != nullptr;
-    const float4 *R = A.slotrec + 4 * (size_t)e;
+    const float4 *R = recs + 4 * (size_t)e;
     float4 c = R[0], g0 = make_float4(0, 0, 0, 0), g1 = g0;
     const float4 g2 = R[3];
     if (gated) g0 = R[1], g1 = R[2];
@@ -211,19 +211,20 @@ struct Steal4 {
 };
 
 template <bool MOVING>
-__device__ __forceinline__ void pair_test4_owner(const KArgs &A, uint32_t slot, float time, f3 o, f3 d, const DivA &av, unsigned long long *key) {
+__device__ __forceinline__ void pair_test4_owner(const KArgs &A, const float4 *recs, uint32_t slot, float time, f3 o, f3 d, const DivA &av, unsigned long long *key) {
     // (the gate of a BVH world needs ray.rs:14's 1 / d of the OWNER's ray; the owner's lane may be walking somebody else's subtree with
     //  another ray's reciprocal in its registers, so it is formed here, from the fetched direction, in its short exact form)
     const f3 rcp = A.gate ? mk3(recip_exact(d.x), recip_exact(d.y), recip_exact(d.z)) : mk3(0.f, 0.f, 0.f);
-    pair_test4<MOVING>(A, slot, time, o, d, rcp, av, key);
+    pair_test4<MOVING>(A, recs, slot, time, o, d, rcp, av, key);
 }
 
 // Exact tests of the leaf candidates the lanes of a wave have queued (`leafq`, `qn` per lane; an entry = owner lane << kPairLaneShift | slot
 // record): expanded into ONE list of (owner ray, slot) pairs per wave, every lane takes one pair per round whoever's ray it belongs to,
 // and the test reduces into the owner's (t, tie-break) key with ds_min_u64. The owners' rays are fetched across lanes from (o, d, av,
-// time): the registers every lane holds for ITS OWN ray. Returns false when nothing was queued; empties the queues.
+// time): the registers every lane holds for ITS OWN ray. `recs`: the 64-byte records the entries index (the tree's leaf slots, or the cell
+// grid's per-sphere records). Returns false when nothing was queued; empties the queues.
 template <bool MOVING, int BLK>
-__device__ __forceinline__ bool drain_pairs4(const KArgs &A, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, uint32_t &qn, f3 o, f3 d, const DivA &av, float time,
+__device__ __forceinline__ bool drain_pairs4(const KArgs &A, const float4 *recs, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, uint32_t &qn, f3 o, f3 d, const DivA &av, float time,
                                              uint32_t owner_tag) {
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
@@ -241,7 +242,7 @@ __device__ __forceinline__ bool drain_pairs4(const KArgs &A, uint32_t *leafq, ui
             const f3 pd = mk3(lane_fetch(ow, d.x), lane_fetch(ow, d.y), lane_fetch(ow, d.z));
             const DivA pav{lane_fetch(ow, a), lane_fetch(ow, av.y), av.fast};
             const float ptime = MOVING ? lane_fetch(ow, time) : 0.0f;
-            if (valid) pair_test4_owner<MOVING>(A, e & ((1u << kPairLaneShift) - 1u), ptime, po, pd, pav, &w_keys[ow]);
+            if (valid) pair_test4_owner<MOVING>(A, recs, e & ((1u << kPairLaneShift) - 1u), ptime, po, pd, pav, &w_keys[ow]);
         }
     } else {
         uint32_t pos = incl - qn;
@@ -256,7 +257,7 @@ __device__ __forceinline__ bool drain_pairs4(const KArgs &A, uint32_t *leafq, ui
             const f3 pd = mk3(lane_fetch(ow, d.x), lane_fetch(ow, d.y), lane_fetch(ow, d.z));
             const DivA pav{lane_fetch(ow, a), lane_fetch(ow, av.y), av.fast};
             const float ptime = MOVING ? lane_fetch(ow, time) : 0.0f;
-            if (valid) pair_test4_owner<MOVING>(A, e & ((1u << kPairLaneShift) - 1u), ptime, po, pd, pav, &w_keys[ow]);
+            if (valid) pair_test4_owner<MOVING>(A, recs, e & ((1u << kPairLaneShift) - 1u), ptime, po, pd, pav, &w_keys[ow]);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -356,7 +357,7 @@ __device__ __forceinline__ void bvh4_trace(const KArgs &A, uint16_t *s_stack, ui
 #endif
         if (stop || wave_any(qn > A.drain_at)) {
             // exact tests of the queued leaf candidates (drain_pairs4); afterwards every lane refreshes its culling limit from ITS owner's key
-            if (drain_pairs4<MOVING, BLK>(A, leafq, w_pairs, w_keys, qn, o, d, av, time, owner_tag)) {
+            if (drain_pairs4<MOVING, BLK>(A, A.slotrec, leafq, w_pairs, w_keys, qn, o, d, av, time, owner_tag)) {
                 limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[owner_tag >> kPairLaneShift] >> 32)));   // (an empty key's t field is a NaN pattern: not < kMaxT)
             }
         }

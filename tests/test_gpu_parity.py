@@ -1483,15 +1483,36 @@ def test_far_ray_origins_with_moving_spheres(ptgpu, oracle, scale, bvh):
     assert not bad, bad
 
 
+def _as_dense_field(w, n, seed, pitch=0.5, radius=0.2):
+    """Turns the first n entries (Sphere / MovingSphere rows) of a world from _far_origin_world into an even, dense field: a jittered
+    side x side lattice of equal spheres in the plane y = radius, centred on the origin -- BASELINE config 5's layout, the kind of scene
+    that gets a uniform cell grid (csrc/pt_grid.h; looser clouds keep the tree)."""
+    rng = np.random.default_rng(seed)
+    side = int(np.sqrt(n))
+    assert side * side == n
+    rec = w["hitables"]
+    p = rec[:n, 6:16].view(np.float32)
+    i = np.arange(n)
+    p[:, 0] = pitch * ((i % side) - side / 2) + rng.uniform(0, 0.3, n).astype(np.float32)
+    p[:, 1] = radius
+    p[:, 2] = pitch * ((i // side) - side / 2) + rng.uniform(0, 0.3, n).astype(np.float32)
+    moving = rec[:n, 0] == 1
+    p[~moving, 3] = radius
+    p[moving, 3:6] *= 0.1                      # (centre_delta: the sweeps stay within a cell or two)
+    p[moving, 6] = radius
+    return w
+
+
 @pytest.mark.parametrize("kind,scale", [("enclosing", 1.0e2), ("enclosing", 2.0e3), ("enclosing", 3.0e5), ("offcentre", 3.0e2), ("ground", 1.0e4), ("mirrors", 1.0e3)])
 @pytest.mark.parametrize("bvh", [False, True])
 def test_cell_grid_walk_equals_the_oracle_from_near_far_and_beyond(ptgpu, oracle, kind, scale, bvh):
-    """Worlds of 1 500 small spheres -- the size from which a scene gets a uniform cell grid (csrc/pt_grid.h) -- with bounce origins inside
-    the cloud, a few half diagonals away (the 27 displaced lines of grid_far_rays) and so far away that the reference's f32
-    discriminant is coarser than a cell (every record): the default kernel must BE the grid walk, and it, the 4-wide tree (524288), the
-    exact scan and verify mode's counting twin (8 | 256) all equal the ORACLE bit for bit, list and BVH semantics."""
+    """A dense field of 1 600 equal spheres -- the kind of scene that gets a uniform cell grid (csrc/pt_grid.h) -- with bounce origins inside
+    the field, and so far away (off a concave mirror of radius 100 ... 300 000 around it, a huge ground, two distant mirrors) that the
+    reference's f32 discriminant is coarser than the grid's registration: those rays walk the tree inside the grid kernel. The default
+    kernel must BE the grid walk, and it, the 4-wide tree (524288), the exact scan and verify mode's counting twin (8 | 256) all equal the
+    ORACLE bit for bit, list and BVH semantics."""
     W, H, S = 112, 80, 3
-    w = _far_origin_world(oracle, 57, 1500, W, H, 9.0, 0.3, kind, scale)
+    w = _as_dense_field(_far_origin_world(oracle, 57, 1600, W, H, 9.0, 0.3, kind, scale), 1600, 57)
     bad = _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, depth=25 if kind == "offcentre" else 10, more_variants=(524288, 8 | 256), default_kernel="grid<")
     assert not bad, bad
 
@@ -1499,10 +1520,10 @@ def test_cell_grid_walk_equals_the_oracle_from_near_far_and_beyond(ptgpu, oracle
 @pytest.mark.parametrize("scale", [3.0e2, 3.0e5])
 @pytest.mark.parametrize("bvh", [False, True])
 def test_cell_grid_walk_with_moving_spheres(ptgpu, oracle, scale, bvh):
-    """The MOVING flavour: 1 300 Sphere + MovingSphere entries (cells hold a moving sphere wherever its sweep reaches; the discriminants
-    use the centre at the ray's time), near and far bounce origins, against the oracle and the tree."""
+    """The MOVING flavour: a dense field of 1 296 Sphere + MovingSphere entries (cells hold a moving sphere wherever its sweep reaches; the
+    discriminants use the centre at the ray's time), near and far bounce origins, against the oracle and the tree."""
     W, H, S = 96, 64, 3
-    w = _far_origin_world(oracle, 43, 1300, W, H, 4.0, 0.7, "enclosing", scale, moving=True)
+    w = _as_dense_field(_far_origin_world(oracle, 43, 1296, W, H, 4.0, 0.7, "enclosing", scale, moving=True), 1296, 43)
     bad = _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, more_variants=(524288,), default_kernel="grid<")
     assert not bad, bad
 

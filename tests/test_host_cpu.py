@@ -405,7 +405,7 @@ def test_kernel_selection_follows_the_tuning_word_and_the_frame(ptgpu, pthost):
 
 def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
     """Sphere clouds of the sizes the fuzzers draw (tests/test_gpu_parity.py _random_scene): below 32 spheres the exact scan,
-    up to 768 the MFMA prefilter, beyond that the internal tree or, from 1 024 similar spheres, the cell grid -- and use_bvh without BVH nodes is refused."""
+    up to 768 the MFMA prefilter, beyond that the internal tree or, for an even dense field of similar spheres, the cell grid -- and use_bvh without BVH nodes is refused."""
     rng = np.random.default_rng(5)
 
     def cloud(n):
@@ -418,9 +418,13 @@ def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
     p = ptgpu.PtParams(640, 480, 16, 10, 0, 0)
     names = {n: ptgpu.debug_select(cloud(n), p, cam)["name"] for n in (12, 40, 300, 768, 800, 2500)}
     assert {n: names[n] for n in (12, 40, 300, 800, 2500)} == {12: "scan-lds<blk=256>", 40: "mfma<blk=1024>", 300: "mfma<blk=1024>",
-                                                               800: "tree4<blk=256>", 2500: "grid<blk=256>"}, names
-    # (1 024 similar spheres and more, evenly spread: the uniform cell grid of csrc/pt_grid.h; a development switch keeps the tree)
-    assert ptgpu.debug_select(cloud(2500), p, cam, variant=524288)["name"] == "tree4<blk=256>"
+                                                               800: "tree4<blk=256>", 2500: "tree4<blk=256>"}, names
+    # an even, dense field of 1 024 or more similar spheres (here a jittered 40 x 40 lattice, like BASELINE config 5's 100 x 100): the
+    # uniform cell grid of csrc/pt_grid.h; a development switch keeps the tree
+    ij = np.stack(np.meshgrid(np.arange(40), np.arange(40)), -1).reshape(-1, 2)
+    lattice = np.concatenate([0.5 * ij[:, :1] + rng.uniform(0, 0.3, (1600, 1)), np.full((1600, 1), 0.2), 0.5 * ij[:, 1:] + rng.uniform(0, 0.3, (1600, 1)), np.full((1600, 1), 0.2)], axis=1).astype(np.float32)
+    field = ptgpu.SceneDesc(lattice, np.zeros(1600, np.uint32), [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0)], [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)])
+    assert ptgpu.debug_select(field, p, cam)["name"] == "grid<blk=256>" and ptgpu.debug_select(field, p, cam, variant=524288)["name"] == "tree4<blk=256>"
     assert names[768].startswith("mfma<")          # 24 tiles: the last size whose fragments fit beside the rest
     # the hand-over's workers keep a lane's spheres in eight register sets: up to 512 spheres
     assert ptgpu.debug_select(cloud(512), p, cam)["coop"] == 1 and ptgpu.debug_select(cloud(513), p, cam)["coop"] == 0

@@ -119,8 +119,12 @@ int32_t build_bvh(Rng &r, Case &c, uint32_t lo, uint32_t hi) {
 
 void sphere_case(Rng &r, Case &c) {
     tables(r, c, false);
-    const uint32_t n = r.chance(5) ? 0u : (r.chance(10) ? 700u + r.below(400) : 1u + r.below(60));
+    const bool field = r.chance(4);   // an even, dense field of equal spheres (a jittered lattice like BASELINE config 5's): the cell grid's territory
+    const uint32_t side = 33u + r.below(10);
+    const uint32_t n = field ? side * side : (r.chance(5) ? 0u : (r.chance(10) ? 700u + r.below(400) : 1u + r.below(60)));
     for (uint32_t i = 0; i < n; ++i) {
+        if (field) c.spheres.push_back(pt_sphere{0.5f * (float)(i % side) + r.uni(0.0f, 0.3f), 0.2f, 0.5f * (float)(i / side) + r.uni(0.0f, 0.3f), 0.2f});
+        else
         c.spheres.push_back(pt_sphere{r.uni(-8, 8), r.uni(0, 2), r.uni(-8, 8), r.chance(5) ? -r.uni(0.1f, 0.6f) : r.uni(0.1f, 0.6f)});
         uint32_t m = r.below((uint32_t)c.materials.size());
         c.sphere_mat.push_back(m);
@@ -141,7 +145,9 @@ void sphere_case(Rng &r, Case &c) {
 void world_case(Rng &r, Case &c, bool graph) {
     tables(r, c, true);
     const bool spheres_only = !graph && r.chance(25);          // Sphere + MovingSphere worlds run on the sphere kernels' MOVING instantiations
-    const uint32_t n = r.chance(5) ? 0u : (r.chance(spheres_only ? 25 : 8) ? 500u + r.below(1500) : (spheres_only && r.chance(60) ? 33u + r.below(600) : 1u + r.below(40)));
+    const bool field = spheres_only && r.chance(15);   // (as in sphere_case: a dense lattice, here with a few MovingSphere entries)
+    const uint32_t side = 33u + r.below(10);
+    const uint32_t n = field ? side * side : r.chance(5) ? 0u : (r.chance(spheres_only ? 25 : 8) ? 500u + r.below(1500) : (spheres_only && r.chance(60) ? 33u + r.below(600) : 1u + r.below(40)));
     const uint32_t nx = spheres_only ? 0u : r.below(5);
     for (uint32_t i = 0; i < nx; ++i) {
         pt_affine a{};
@@ -165,6 +171,12 @@ void world_case(Rng &r, Case &c, bool graph) {
         if (spheres_only) h.p[0] = r.uni(-8, 8), h.p[1] = r.uni(0, 2), h.p[2] = r.uni(-8, 8);
         if (h.kind == PT_HIT_SPHERE) h.p[3] = r.uni(0.1f, 1.0f);
         if (h.kind == PT_HIT_MOVING_SPHERE) h.p[3] = 0.0f, h.p[4] = r.uni(0.0f, 0.5f), h.p[5] = 0.0f, h.p[6] = r.uni(0.1f, 1.0f), h.p[7] = 0.0f, h.p[8] = 1.0f;
+        if (field) {
+            h.kind = r.chance(3) ? PT_HIT_MOVING_SPHERE : PT_HIT_SPHERE;
+            h.p[0] = 0.5f * (float)(i % side) + r.uni(0.0f, 0.3f), h.p[1] = 0.2f, h.p[2] = 0.5f * (float)(i / side) + r.uni(0.0f, 0.3f);
+            if (h.kind == PT_HIT_SPHERE) h.p[3] = 0.2f;
+            else h.p[3] = 0.0f, h.p[4] = r.uni(0.0f, 0.1f), h.p[5] = 0.0f, h.p[6] = 0.2f, h.p[7] = 0.0f, h.p[8] = 1.0f;
+        }
         c.hitables.push_back(h);
     }
     if (graph && n) {
