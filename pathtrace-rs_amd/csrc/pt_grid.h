@@ -73,23 +73,25 @@ __device__ __forceinline__ void grid_walk_start(const KArgs &A, GridWalk &w, f3 
     w.tcur = t_in;
 }
 __device__ __forceinline__ uint32_t grid_walk_cell(const KArgs &A, const GridWalk &w) { return (uint32_t)((w.iz * (int)A.grid_n[1] + w.iy) * (int)A.grid_n[0] + w.ix); }
-// one step: into the neighbour across the nearest boundary (the boundary of the NEW cell is formed from its integer number)
+// one step: into the neighbour across the nearest boundary (the boundary of the NEW cell is formed from its integer number). Straight-line
+// code on purpose: the walk issues a record's loads and takes this step in their shadow.
 __device__ __forceinline__ void grid_walk_step(const KArgs &A, GridWalk &w, f3 d) {
-    const float h = A.grid_h;
-    w.tcur = __builtin_fminf(__builtin_fminf(w.tnx, w.tny), w.tnz);
-    if (w.tnx <= w.tny && w.tnx <= w.tnz) {
-        w.ix += d.x >= 0.0f ? 1 : -1;
-        w.alive = (uint32_t)w.ix < A.grid_n[0];
-        w.tnx = ((A.grid_min[0] + (float)(w.ix + (d.x >= 0.0f ? 1 : 0)) * h) - w.ox) * w.rx;
-    } else if (w.tny <= w.tnz) {
-        w.iy += d.y >= 0.0f ? 1 : -1;
-        w.alive = (uint32_t)w.iy < A.grid_n[1];
-        w.tny = ((A.grid_min[1] + (float)(w.iy + (d.y >= 0.0f ? 1 : 0)) * h) - w.oy) * w.ry;
-    } else {
-        w.iz += d.z >= 0.0f ? 1 : -1;
-        w.alive = (uint32_t)w.iz < A.grid_n[2];
-        w.tnz = ((A.grid_min[2] + (float)(w.iz + (d.z >= 0.0f ? 1 : 0)) * h) - w.oz) * w.rz;
-    }
+    // (every field through a local copy: selects between the FIELDS of `w` become selects between their addresses, and the walk ends up in scratch)
+    const float tnx = w.tnx, tny = w.tny, tnz = w.tnz, ox = w.ox, oy = w.oy, oz = w.oz, rx = w.rx, ry = w.ry, rz = w.rz;
+    const int ix = w.ix, iy = w.iy, iz = w.iz;
+    const uint32_t gnx = A.grid_n[0], gny = A.grid_n[1], gnz = A.grid_n[2];
+    const float lox = A.grid_min[0], loy = A.grid_min[1], loz = A.grid_min[2];
+    const bool step_x = tnx <= tny && tnx <= tnz, step_y = !step_x && tny <= tnz;
+    const bool up = (step_x ? d.x : (step_y ? d.y : d.z)) >= 0.0f;
+    const int i_new = (step_x ? ix : (step_y ? iy : iz)) + (up ? 1 : -1);
+    const uint32_t n_axis = step_x ? gnx : (step_y ? gny : gnz);
+    const float lo_axis = step_x ? lox : (step_y ? loy : loz);
+    const float o_axis = step_x ? ox : (step_y ? oy : oz), r_axis = step_x ? rx : (step_y ? ry : rz);
+    const float tn_new = ((lo_axis + (float)(i_new + (up ? 1 : 0)) * A.grid_h) - o_axis) * r_axis;
+    w.tcur = __builtin_fminf(__builtin_fminf(tnx, tny), tnz);
+    w.alive = (uint32_t)i_new < n_axis;
+    w.ix = step_x ? i_new : ix, w.iy = step_y ? i_new : iy, w.iz = (step_x || step_y) ? iz : i_new;
+    w.tnx = step_x ? tn_new : tnx, w.tny = step_y ? tn_new : tny, w.tnz = (step_x || step_y) ? tnz : tn_new;
 }
 
 template <bool MOVING, bool COUNT, int BLK>
@@ -133,13 +135,14 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
     uint32_t dbg_visits = 0u, dbg_rounds = 0u;
     if (COUNT && lane == 0u) cnt.leaves += 1u;
 #endif
+    bool cont = false;   // `rec` continues the cell the lane is already in (its walk has stepped on: such a record is visited whatever the limit says)
     for (;;) {
-        bool go = w.alive && w.tcur <= __builtin_fminf(w.t_out, limit);
+        bool go = cont || (w.alive && w.tcur <= __builtin_fminf(w.t_out, limit));
         if (!wave_any(go) || wave_any(qn > A.drain_at)) {
             PT_SUBT(5);
             // exact tests of everything queued; the limit becomes the exact one of the lane's key (an empty key's t field is a NaN pattern: not < kMaxT)
             if (drain_pairs4<MOVING, BLK>(A, A.grid_rec, leafq, w_pairs, w_keys, qn, o, d, av, time, owner_tag)) limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[lane] >> 32)));
-            go = w.alive && w.tcur <= __builtin_fminf(w.t_out, limit);
+            go = cont || (w.alive && w.tcur <= __builtin_fminf(w.t_out, limit));
             PT_SUBT(6);
             if (!wave_any(go)) break;
         }
@@ -153,6 +156,8 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
         if (go) {
             const uint4 *cp = A.grid_cells + (size_t)rec * 5u;
             uint4 q0 = cp[0], q1 = cp[1], q2 = cp[2], q3 = cp[3], m = cp[4];
+            // the step into the next cell does not depend on what the record holds: taken here, in the shadow of the loads
+            if (!cont) grid_walk_step(A, w, d);
             // (all five loads in flight at once: left alone, the scheduler issues them one by one, each behind the arithmetic of the one
             //  before -- four round trips to the L2 per record instead of one -- to save the sixteen registers this takes)
             asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w),
@@ -208,12 +213,8 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
                 tq = t1 > 2.0e-3f ? t1 : (t2 > 2.0e-3f ? t2 : tq);   // (no candidate: d_sel = -1, the root is NaN and nothing compares true)
             }
             limit = __builtin_fminf(limit, tq * 1.001f + 1.0e-3f);
-            if (m.w & kGridLinkBit) {
-                rec = m.w & ~kGridLinkBit;   // the cell continues in another record
-            } else {
-                grid_walk_step(A, w, d);
-                rec = grid_walk_cell(A, w);
-            }
+            cont = (m.w & kGridLinkBit) != 0u;   // the cell continues in another record
+            rec = cont ? (m.w & ~kGridLinkBit) : grid_walk_cell(A, w);
         }
     }
     PT_SUBT(5);
