@@ -402,6 +402,18 @@ struct GridGeom {
     double gmin[3], h;
 };
 // records a cell with `items` spheres takes: four in the last one, three in every one before it
+// does the ball (c, R) reach into cell (x, y, z)? (plain spheres are registered by their padded BALL, not its box: the corner cells of
+// the box drop out -- a ray the reference's test accepts passes through the ball, hence through a cell the ball reaches into)
+inline bool grid_ball_in_cell(const GridGeom &g, const double c[3], double R, uint32_t x, uint32_t y, uint32_t z) {
+    const uint32_t i[3] = {x, y, z};
+    double d2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        const double lo = g.gmin[k] + g.h * (double)i[k], hi = lo + g.h;
+        const double d = c[k] < lo ? lo - c[k] : (c[k] > hi ? c[k] - hi : 0.0);
+        d2 += d * d;
+    }
+    return d2 <= R * R;
+}
 inline uint32_t grid_records_of(uint32_t items) { return items <= 4u ? 1u : 1u + (items - 4u + 2u) / 3u; }
 inline void grid_cell_range(const GridGeom &g, const double lo[3], const double hi[3], uint32_t a[3], uint32_t b[3]) {
     for (int k = 0; k < 3; ++k) {
@@ -447,10 +459,13 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
     const double w_med = 2.0 * (r_med + inflate(r_med));
     if (!(inflate(r_min) <= 0.5 * r_med) || !std::isfinite(half_diag) || !(half_diag > 0.0)) return false;   // too little precision left at that distance: the tree pads per ray
     // padded boxes (the walk's own rounding is covered by h / 1000 more, added per candidate geometry below)
-    std::vector<double> lo(3 * items.size()), hi(3 * items.size());
+    std::vector<double> lo(3 * items.size()), hi(3 * items.size()), ctr(3 * items.size()), rad(items.size());
+    std::vector<char> ball(items.size());   // a plain sphere (its box is the ball's): registered by the ball; a moving one by the box of its sweep
     for (size_t i = 0; i < items.size(); ++i) {
         const double d = inflate(items[i].r);
-        for (int k = 0; k < 3; ++k) lo[3 * i + k] = (double)items[i].mn[k] - d, hi[3 * i + k] = (double)items[i].mx[k] + d;
+        ball[i] = !(motion && motion[items[i].sphere].moving);
+        rad[i] = (double)items[i].r + d;
+        for (int k = 0; k < 3; ++k) lo[3 * i + k] = (double)items[i].mn[k] - d, hi[3 * i + k] = (double)items[i].mx[k] + d, ctr[3 * i + k] = (double)items[i].c[k];
     }
     // candidates: cell sizes around the padded median width, four alignments per axis that has more than one cell
     GridGeom best{};
@@ -484,7 +499,8 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
                 grid_cell_range(g, l, u, a, b);
                 for (uint32_t z = a[2]; z <= b[2]; ++z)
                     for (uint32_t y = a[1]; y <= b[1]; ++y)
-                        for (uint32_t x = a[0]; x <= b[0]; ++x) count[((size_t)z * g.n[1] + y) * g.n[0] + x] += 1u;
+                        for (uint32_t x = a[0]; x <= b[0]; ++x)
+                            if (!ball[i] || grid_ball_in_cell(g, &ctr[3 * i], rad[i] + 1.0e-3 * h, x, y, z)) count[((size_t)z * g.n[1] + y) * g.n[0] + x] += 1u;
             }
             uint64_t records = 0;
             for (uint32_t c : count) records += grid_records_of(c);
@@ -505,7 +521,8 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
         grid_cell_range(g, l, u, a, b);
         for (uint32_t z = a[2]; z <= b[2]; ++z)
             for (uint32_t y = a[1]; y <= b[1]; ++y)
-                for (uint32_t x = a[0]; x <= b[0]; ++x) lists[((size_t)z * g.n[1] + y) * g.n[0] + x].push_back(items[i].sphere), ++regs;
+                for (uint32_t x = a[0]; x <= b[0]; ++x)
+                    if (!ball[i] || grid_ball_in_cell(g, &ctr[3 * i], rad[i] + 1.0e-3 * g.h, x, y, z)) lists[((size_t)z * g.n[1] + y) * g.n[0] + x].push_back(items[i].sphere), ++regs;
     }
     union FU { float f; uint32_t u; };
     const auto bits = [](float f) { FU q; q.f = f; return q.u; };
