@@ -390,7 +390,8 @@ int pt_scene_debug_tree_packed(pt_scene *scene, void *nodes_out, size_t capacity
 int pt_scene_set_tuning(pt_scene *scene, uint32_t blocks_per_cu, uint32_t variant);
 
 /* Which kernel a frame runs on, and with what geometry (csrc/pt_select.h; DESIGN.md "kernel selection"). family: 0 general-world
- * kernel, 1 binary-tree kernel, 2 4-wide tree kernel, 3 MFMA list kernel, 4 exact scan from LDS, 5 exact scan from HBM/L2. */
+ * kernel, 1 binary-tree kernel, 2 4-wide tree kernel (`name` starts with "grid<" when it walks the scene's uniform cell grid instead of the tree:
+ * csrc/pt_grid.h), 3 MFMA list kernel, 4 exact scan from LDS, 5 exact scan from HBM/L2. */
 typedef struct pt_kernel_choice {
     uint32_t family, block, lds_bytes, blocks_per_cu; /* threads per workgroup, dynamic LDS per workgroup, resident workgroups per CU (before the register clamp) */
     uint32_t moving, gate, verify, ref_bvh;           /* MOVING / GATE / VERIFY instantiation; BVHNode::ray_hit semantics */
