@@ -116,7 +116,7 @@ struct KArgs {
     const uint32_t *grid_large;  // spheres outside the grid: tested for every ray
     uint32_t n_grid_large;
     uint32_t grid_n[3];
-    float grid_min[3], grid_h, grid_inv_h;
+    float grid_min[3], grid_h[3], grid_inv_h[3];   // (cells are cubes, except along an axis with ONE cell: that one spans the spheres' whole extent)
     float grid_centre[3], grid_half_diag, grid_d_build;   // a ray whose origin is farther than d_build - half_diag from the centre walks the tree instead
     uint32_t n_spheres;
     uint32_t n_spheres_pad;      // multiple of kScanUnroll; padding entries can never be hit

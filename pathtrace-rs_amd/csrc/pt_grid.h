@@ -46,7 +46,7 @@ struct GridWalk {
 };
 
 __device__ __forceinline__ void grid_walk_start(const KArgs &A, GridWalk &w, f3 o, f3 d, f3 rcp, bool active) {
-    const float h = A.grid_h, inv_h = A.grid_inv_h;
+    const float hx = A.grid_h[0], hy = A.grid_h[1], hz = A.grid_h[2];
     const int nx = (int)A.grid_n[0], ny = (int)A.grid_n[1], nz = (int)A.grid_n[2];
     const float kInf = __builtin_inff();
     const bool par_x = __builtin_fabsf(d.x) < 1.0e-30f, par_y = __builtin_fabsf(d.y) < 1.0e-30f, par_z = __builtin_fabsf(d.z) < 1.0e-30f;
@@ -54,7 +54,7 @@ __device__ __forceinline__ void grid_walk_start(const KArgs &A, GridWalk &w, f3 
     w.rx = par_x ? 0.0f : rcp.x, w.ry = par_y ? 0.0f : rcp.y, w.rz = par_z ? 0.0f : rcp.z;
     // clip against the grid's box
     const float lox = A.grid_min[0], loy = A.grid_min[1], loz = A.grid_min[2];
-    const float hix = lox + (float)nx * h, hiy = loy + (float)ny * h, hiz = loz + (float)nz * h;
+    const float hix = lox + (float)nx * hx, hiy = loy + (float)ny * hy, hiz = loz + (float)nz * hz;
     const float ax0 = (lox - o.x) * w.rx, ax1 = (hix - o.x) * w.rx, ay0 = (loy - o.y) * w.ry, ay1 = (hiy - o.y) * w.ry, az0 = (loz - o.z) * w.rz, az1 = (hiz - o.z) * w.rz;
     const bool in_x = o.x >= lox && o.x <= hix, in_y = o.y >= loy && o.y <= hiy, in_z = o.z >= loz && o.z <= hiz;
     const float nrx = par_x ? (in_x ? -kInf : kInf) : __builtin_fminf(ax0, ax1), frx = par_x ? (in_x ? kInf : -kInf) : __builtin_fmaxf(ax0, ax1);
@@ -64,12 +64,12 @@ __device__ __forceinline__ void grid_walk_start(const KArgs &A, GridWalk &w, f3 
     w.t_out = __builtin_fminf(__builtin_fminf(frx, fry), frz);
     w.alive = active && t_in <= w.t_out;
     const float px = o.x + d.x * t_in, py = o.y + d.y * t_in, pz = o.z + d.z * t_in;
-    w.ix = min(max((int)__builtin_floorf((px - lox) * inv_h), 0), nx - 1);
-    w.iy = min(max((int)__builtin_floorf((py - loy) * inv_h), 0), ny - 1);
-    w.iz = min(max((int)__builtin_floorf((pz - loz) * inv_h), 0), nz - 1);
-    w.tnx = par_x ? kInf : ((lox + (float)(w.ix + (d.x >= 0.0f ? 1 : 0)) * h) - o.x) * w.rx;
-    w.tny = par_y ? kInf : ((loy + (float)(w.iy + (d.y >= 0.0f ? 1 : 0)) * h) - o.y) * w.ry;
-    w.tnz = par_z ? kInf : ((loz + (float)(w.iz + (d.z >= 0.0f ? 1 : 0)) * h) - o.z) * w.rz;
+    w.ix = min(max((int)__builtin_floorf((px - lox) * A.grid_inv_h[0]), 0), nx - 1);
+    w.iy = min(max((int)__builtin_floorf((py - loy) * A.grid_inv_h[1]), 0), ny - 1);
+    w.iz = min(max((int)__builtin_floorf((pz - loz) * A.grid_inv_h[2]), 0), nz - 1);
+    w.tnx = par_x ? kInf : ((lox + (float)(w.ix + (d.x >= 0.0f ? 1 : 0)) * hx) - o.x) * w.rx;
+    w.tny = par_y ? kInf : ((loy + (float)(w.iy + (d.y >= 0.0f ? 1 : 0)) * hy) - o.y) * w.ry;
+    w.tnz = par_z ? kInf : ((loz + (float)(w.iz + (d.z >= 0.0f ? 1 : 0)) * hz) - o.z) * w.rz;
     w.tcur = t_in;
 }
 __device__ __forceinline__ uint32_t grid_walk_cell(const KArgs &A, const GridWalk &w) { return (uint32_t)((w.iz * (int)A.grid_n[1] + w.iy) * (int)A.grid_n[0] + w.ix); }
@@ -85,9 +85,9 @@ __device__ __forceinline__ void grid_walk_step(const KArgs &A, GridWalk &w, f3 d
     const bool up = (step_x ? d.x : (step_y ? d.y : d.z)) >= 0.0f;
     const int i_new = (step_x ? ix : (step_y ? iy : iz)) + (up ? 1 : -1);
     const uint32_t n_axis = step_x ? gnx : (step_y ? gny : gnz);
-    const float lo_axis = step_x ? lox : (step_y ? loy : loz);
+    const float lo_axis = step_x ? lox : (step_y ? loy : loz), h_axis = step_x ? A.grid_h[0] : (step_y ? A.grid_h[1] : A.grid_h[2]);
     const float o_axis = step_x ? ox : (step_y ? oy : oz), r_axis = step_x ? rx : (step_y ? ry : rz);
-    const float tn_new = ((lo_axis + (float)(i_new + (up ? 1 : 0)) * A.grid_h) - o_axis) * r_axis;
+    const float tn_new = ((lo_axis + (float)(i_new + (up ? 1 : 0)) * h_axis) - o_axis) * r_axis;
     w.tcur = __builtin_fminf(__builtin_fminf(tnx, tny), tnz);
     w.alive = (uint32_t)i_new < n_axis;
     w.ix = step_x ? i_new : ix, w.iy = step_y ? i_new : iy, w.iz = (step_x || step_y) ? iz : i_new;

@@ -67,7 +67,7 @@ int upload(T **dst, const void *src, size_t count) {
 
 struct pthostside_grid_geom {   // the scalars of a GridPlan the launch copies into KArgs
     uint32_t n[3], n_records, n_large;
-    float gmin[3], h, centre[3], half_diag, d_build;
+    float gmin[3], h, ha[3], centre[3], half_diag, d_build;
 };
 
 // ---- the scene handle ------------------------------------------------------------------------------------------------
@@ -228,7 +228,7 @@ Tree4Host tree4_build_host(std::vector<TreeItem> items);
 struct GridPlan {
     bool ok = false;
     uint32_t n[3] = {1, 1, 1}, n_records = 0;
-    float gmin[3] = {0, 0, 0}, h = 0.f;
+    float gmin[3] = {0, 0, 0}, h = 0.f, ha[3] = {0, 0, 0};   // h: the cubic cell; ha: per axis (an axis with ONE cell spans the whole extent, up to 1.5 h)
     float centre[3] = {0, 0, 0}, half_diag = 0.f, d_build = 0.f;
     std::vector<uint4> cells;          // 5 per record
     std::vector<float4> rec;           // per SPHERE, the slot record of an exact test (KArgs::slotrec layout: sphere | gate min | gate max | rank bits, index bits): filled by plan_sphere_scene

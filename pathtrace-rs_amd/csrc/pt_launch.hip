@@ -346,7 +346,8 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         const pthostside_grid_geom &q = s->grid_geom;
         A.grid_cells = s->d_grid_cells, A.grid_rec = s->d_grid_rec, A.grid_large = s->d_grid_large, A.n_grid_large = q.n_large;
         for (int k = 0; k < 3; ++k) A.grid_n[k] = q.n[k], A.grid_min[k] = q.gmin[k], A.grid_centre[k] = q.centre[k];
-        A.grid_h = q.h, A.grid_inv_h = 1.0f / q.h, A.grid_half_diag = q.half_diag, A.grid_d_build = q.d_build;
+        for (int k = 0; k < 3; ++k) A.grid_h[k] = q.ha[k], A.grid_inv_h[k] = 1.0f / q.ha[k];
+        A.grid_half_diag = q.half_diag, A.grid_d_build = q.d_build;
     }
     A.slotrec = s->d_slotrec;
     A.rank_sphere = s->d_rank_sphere;

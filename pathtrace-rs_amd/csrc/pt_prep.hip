@@ -399,7 +399,7 @@ constexpr uint32_t kGridNone = 0x7fffffffu, kGridLink = 0x80000000u;
 
 struct GridGeom {
     uint32_t n[3];
-    double gmin[3], h;
+    double gmin[3], h, ha[3];   // h: the cubic cell; ha[k]: the cell's size along axis k (h, or the whole extent along an axis with ONE cell)
 };
 // records a cell with `items` spheres takes: four in the last one, three in every one before it
 // does the ball (c, R) reach into cell (x, y, z)? (plain spheres are registered by their padded BALL, not its box: the corner cells of
@@ -408,7 +408,7 @@ inline bool grid_ball_in_cell(const GridGeom &g, const double c[3], double R, ui
     const uint32_t i[3] = {x, y, z};
     double d2 = 0.0;
     for (int k = 0; k < 3; ++k) {
-        const double lo = g.gmin[k] + g.h * (double)i[k], hi = lo + g.h;
+        const double lo = g.gmin[k] + g.ha[k] * (double)i[k], hi = lo + g.ha[k];
         const double d = c[k] < lo ? lo - c[k] : (c[k] > hi ? c[k] - hi : 0.0);
         d2 += d * d;
     }
@@ -417,7 +417,7 @@ inline bool grid_ball_in_cell(const GridGeom &g, const double c[3], double R, ui
 inline uint32_t grid_records_of(uint32_t items) { return items <= 4u ? 1u : 1u + (items - 4u + 2u) / 3u; }
 inline void grid_cell_range(const GridGeom &g, const double lo[3], const double hi[3], uint32_t a[3], uint32_t b[3]) {
     for (int k = 0; k < 3; ++k) {
-        const double fa = std::floor((lo[k] - g.gmin[k]) / g.h), fb = std::floor((hi[k] - g.gmin[k]) / g.h);
+        const double fa = std::floor((lo[k] - g.gmin[k]) / g.ha[k]), fb = std::floor((hi[k] - g.gmin[k]) / g.ha[k]);
         a[k] = (uint32_t)std::min<double>(std::max(fa, 0.0), (double)g.n[k] - 1.0);
         b[k] = (uint32_t)std::min<double>(std::max(fb, 0.0), (double)g.n[k] - 1.0);
     }
@@ -487,6 +487,7 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
                 const double start = bmin[k] - inflate(r_min) - 2.0e-3 * h - (single ? 0.0 : 0.25 * sh * h);
                 g.gmin[k] = start;
                 g.n[k] = single ? 1u : (uint32_t)std::ceil((bmax[k] + inflate(r_min) + 2.0e-3 * h - start) / h);
+                g.ha[k] = single ? ext : h;   // (one cell along this axis: it spans the spheres' whole extent, up to 1.5 h)
                 if (g.n[k] == 0u || g.n[k] > 1023u) skip = true;
                 cells *= g.n[k];
             }
@@ -557,6 +558,7 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
     G.ok = true;
     for (int k = 0; k < 3; ++k) G.n[k] = g.n[k], G.gmin[k] = (float)g.gmin[k], G.centre[k] = (float)(0.5 * (bmin[k] + bmax[k]));
     G.h = (float)g.h;
+    for (int k = 0; k < 3; ++k) G.ha[k] = (float)g.ha[k];
     // (the kernel works with these f32 values; the registration above used the doubles they were rounded from -- h / 1000 covers the difference)
     G.half_diag = (float)(half_diag * 1.0001), G.d_build = (float)(d_build * 0.999);
     G.n_records = (uint32_t)(rec.size() / 5);

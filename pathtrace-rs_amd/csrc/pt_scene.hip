@@ -100,6 +100,7 @@ int create_sphere_scene(const pt_scene_desc *desc, const MotionIn *motion, int d
         for (int k = 0; k < 3; ++k) q.n[k] = g.n[k], q.gmin[k] = g.gmin[k], q.centre[k] = g.centre[k];
         q.n_records = g.n_records, q.n_large = (uint32_t)g.large.size();
         q.h = g.h, q.half_diag = g.half_diag, q.d_build = g.d_build;
+        for (int k = 0; k < 3; ++k) q.ha[k] = g.ha[k];
     }
     // the caller's tree as given: only pt_closest_hit(PT_QUERY_BVH) walks it (the frame kernels use the gates and ranks derived from it)
     if (desc->n_bvh_nodes && (rc = upload(&s->d_ref_nodes, desc->bvh_nodes, desc->n_bvh_nodes))) return bail(rc);

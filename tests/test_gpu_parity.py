@@ -1528,6 +1528,20 @@ def test_cell_grid_walk_with_moving_spheres(ptgpu, oracle, scale, bvh):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("first,count", [(40, 10), (285, 6), (5000, 60)])
+def test_cell_grid_soak_slice(ptgpu, first, count):
+    """A slice of tools/grid_soak.py: seeded dense sphere fields (one layer, several, a packed cube, a long strip; radii within a band; a ground,
+    big and degenerate spheres beside them; cameras inside, near, far, very far; every third one a BVH world) -- the default kernel, the grid
+    walk for most of them, against the exact scan, every pixel and the ray count. Seeds 45 and 288 are the two that caught a real defect (a
+    single cell along the thin axis of a layer thicker than the cell: the grid's box cut the spheres' tops off)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("grid_soak", os.path.join(ROOT, "tools", "grid_soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    grids, bad = mod.run(first, count)
+    assert bad == 0 and grids >= count // 3, (grids, bad)
+
+
 @pytest.mark.parametrize("first", [90000, 90040])
 def test_fuzz_slice_of_far_origin_worlds(ptgpu, oracle, first):
     """40 seeded worlds per slice of the far-origin kind (tools/fuzz_worlds.py kind 3): cloud size, spread, radius range,
