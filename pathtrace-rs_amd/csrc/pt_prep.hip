@@ -418,8 +418,9 @@ inline uint32_t grid_records_of(uint32_t items) { return items <= 4u ? 1u : 1u +
 inline void grid_cell_range(const GridGeom &g, const double lo[3], const double hi[3], uint32_t a[3], uint32_t b[3]) {
     for (int k = 0; k < 3; ++k) {
         const double fa = std::floor((lo[k] - g.gmin[k]) / g.ha[k]), fb = std::floor((hi[k] - g.gmin[k]) / g.ha[k]);
-        a[k] = (uint32_t)std::min<double>(std::max(fa, 0.0), (double)g.n[k] - 1.0);
-        b[k] = (uint32_t)std::min<double>(std::max(fb, 0.0), (double)g.n[k] - 1.0);
+        const double top = (double)g.n[k] - 1.0;   // (comparisons written so that a NaN lands on a valid cell: nothing non-finite gets this far, but a cast of one is undefined)
+        a[k] = fa > 0.0 ? (fa < top ? (uint32_t)fa : g.n[k] - 1u) : 0u;
+        b[k] = fb > 0.0 ? (fb < top ? (uint32_t)fb : g.n[k] - 1u) : 0u;
     }
 }
 }  // namespace
@@ -444,6 +445,9 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
         items.swap(keep);
     }
     if (large.size() > kGridMaxLarge || items.size() < kGridMinItems) return false;
+    for (const AccelItem &it : items)   // (a MovingSphere's swept box can overflow f32: such a scene keeps the tree)
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(it.mn[k]) || !std::isfinite(it.mx[k]) || !std::isfinite(it.c[k]) || !(it.mn[k] <= it.mx[k])) return false;
     std::sort(large.begin(), large.end());
     double bmin[3] = {1e300, 1e300, 1e300}, bmax[3] = {-1e300, -1e300, -1e300}, r_min = 1e300, r_max = 0.0;
     for (const AccelItem &it : items) {
@@ -470,6 +474,7 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
     // candidates: cell sizes around the padded median width, four alignments per axis that has more than one cell
     GridGeom best{};
     double best_cost = 1e300;
+    const size_t stride = (items.size() + 19999) / 20000;
     std::vector<uint32_t> count;
     static const double kSizes[] = {0.625, 0.75, 0.875, 1.0, 1.25, 1.5, 2.0, 3.0};
     for (double sz : kSizes) {
@@ -493,7 +498,7 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
             }
             if (skip || cells > kGridMaxCells) continue;
             count.assign((size_t)cells, 0u);
-            for (size_t i = 0; i < items.size(); ++i) {
+            for (size_t i = 0; i < items.size(); i += stride) {   // (big scenes: the candidates are compared on every stride-th sphere)
                 double l[3], u[3];
                 for (int k = 0; k < 3; ++k) l[k] = lo[3 * i + k] - 1.0e-3 * h, u[k] = hi[3 * i + k] + 1.0e-3 * h;
                 uint32_t a[3], b[3];
@@ -504,7 +509,7 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
                             if (!ball[i] || grid_ball_in_cell(g, &ctr[3 * i], rad[i] + 1.0e-3 * h, x, y, z)) count[((size_t)z * g.n[1] + y) * g.n[0] + x] += 1u;
             }
             uint64_t records = 0;
-            for (uint32_t c : count) records += grid_records_of(c);
+            for (uint32_t c : count) records += grid_records_of((uint32_t)std::min<uint64_t>((uint64_t)c * stride, 0xffffffffull));
             if (records > kGridMaxRecords) continue;
             const double cost = ((double)records / (double)cells + 0.35) / h;   // (+ the walk's own step per cell)
             if (cost < best_cost) best_cost = cost, best = g;
@@ -555,6 +560,7 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
             at = next;
         }
     }
+    if (rec.size() / 5 > kGridMaxRecords) return false;   // (the candidates of a big scene were only estimated)
     G.ok = true;
     for (int k = 0; k < 3; ++k) G.n[k] = g.n[k], G.gmin[k] = (float)g.gmin[k], G.centre[k] = (float)(0.5 * (bmin[k] + bmax[k]));
     G.h = (float)g.h;
