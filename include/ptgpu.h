@@ -413,6 +413,14 @@ int pt_debug_select(const pt_scene_desc *sphere_desc, const pt_world_desc *world
                     const pt_camera *camera, uint32_t shard_count, uint32_t blocks_per_cu, uint32_t variant,
                     pt_kernel_choice *out);
 
+/* The uniform cell grid pt_scene_create would plan for a sphere scene (csrc/pt_grid.h; host only, no device): the structure the tree kernels'
+ * "grid<...>" flavour walks. info16 = { cells x, y, z, records, large spheres, 0, 0, 0 | as f32 bits: box min x, y, z, cell size x, y, z, centre-to-origin
+ * distance the registration is padded for (d_build), half diagonal of the field }. records5x4 (may be NULL): up to `capacity_records` records of
+ * five 16-byte words -- spheres 0 | 1 and 2 | 3 interleaved component by component, then four list indices (0x7fffffff: empty; in the last word
+ * 0x80000000 | record: the cell continues there). large (may be NULL): up to 16 list indices. Returns PT_ERR_UNSUPPORTED (with the plan's
+ * reason in pt_last_error) when the scene gets no grid. tests/test_host_cpu.py checks the registration against the spheres themselves. */
+int pt_debug_cell_grid(const pt_scene_desc *sphere_desc, uint32_t info16[16], uint32_t *records5x4, size_t capacity_records, uint32_t *large16);
+
 /* The kernel instantiations that choice launches, as the symbols of their host-side launch stubs (frame kernel; measuring kernel, or ""
  * when the work is not ordered by one): for the thread's last successful pt_debug_select. Tests hold the union over many descriptions
  * against the stubs the shared object defines, so that no instantiation is carried that nothing selects. */

@@ -235,6 +235,28 @@ extern "C" int pt_debug_select(const pt_scene_desc *sphere_desc, const pt_world_
     return PT_OK;
 }
 
+// The cell grid a sphere scene would get (include/ptgpu.h): plan_sphere_scene's GridPlan, copied out for the tests.
+extern "C" int pt_debug_cell_grid(const pt_scene_desc *sphere_desc, uint32_t info16[16], uint32_t *records5x4, size_t capacity_records, uint32_t *large16) {
+    if (!sphere_desc || !info16) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    SpherePlan P;
+    if (int rc = plan_sphere_scene(sphere_desc, nullptr, P)) return rc;
+    const GridPlan &g = P.grid;
+    if (!g.ok) return fail(PT_ERR_UNSUPPORTED, "this scene gets no cell grid (fewer than 1 024 similar spheres, or not an even dense field): it walks the tree");
+    union { float f; uint32_t u; } q;
+    memset(info16, 0, 16 * sizeof(uint32_t));
+    for (int k = 0; k < 3; ++k) {
+        info16[k] = g.n[k];
+        q.f = g.gmin[k], info16[8 + k] = q.u;
+        q.f = g.ha[k], info16[11 + k] = q.u;
+    }
+    info16[3] = g.n_records, info16[4] = (uint32_t)g.large.size();
+    q.f = g.d_build, info16[14] = q.u;
+    q.f = g.half_diag, info16[15] = q.u;
+    if (records5x4) memcpy(records5x4, g.cells.data(), std::min<size_t>(capacity_records, g.n_records) * 5 * sizeof(uint4));
+    if (large16) memcpy(large16, g.large.data(), std::min<size_t>(16, g.large.size()) * sizeof(uint32_t));
+    return PT_OK;
+}
+
 // Which instantiations the choice of this thread's last successful pt_debug_select launches: the symbols of the host-side launch stubs of
 // the frame kernel and (sphere kernels whose work is ordered by a measuring launch) of the measuring kernel, "" when there is none.
 // tests/test_host_cpu.py holds the union over many descriptions against the stubs the shared object defines: an instantiation

@@ -122,7 +122,7 @@ EXPORTS = [
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
     "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree", "pt_scene_debug_tree_packed",
-    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_debug_last_kernel_symbols", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters", "pt_render_sharded_all", "pt_comm_gather_frame_all", "pt_closest_hit",
+    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_debug_last_kernel_symbols", "pt_debug_cell_grid", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters", "pt_render_sharded_all", "pt_comm_gather_frame_all", "pt_closest_hit",
 ]
 COMM_ID_BYTES = 128
 
@@ -186,6 +186,7 @@ def lib():
         L.pt_last_kernel_choice.argtypes = [vp, C.POINTER(PtKernelChoice)]
         L.pt_debug_select.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(PtWorldDesc), C.POINTER(PtParams), C.POINTER(PtCamera), C.c_uint32, C.c_uint32,
                                       C.c_uint32, C.POINTER(PtKernelChoice)]
+        L.pt_debug_cell_grid.argtypes = [C.POINTER(PtSceneDesc), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32)]
         L.pt_comm_runtime.argtypes = [C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.pt_last_host_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pt_last_error.restype = C.c_char_p
@@ -443,6 +444,22 @@ def debug_select(desc, params, camera, shard_count=1, blocks_per_cu=0, variant=0
         rc = lib().pt_debug_select(C.byref(d), None, C.byref(params), C.byref(camera), shard_count, blocks_per_cu, variant, C.byref(c))
     _check(rc)
     return c.as_dict()
+
+
+def debug_cell_grid(desc):
+    """pt_debug_cell_grid: the uniform cell grid a sphere scene would get (host only) as a dict -- cells per axis `n`, box corner `gmin`, cell
+    sizes `h`, `d_build`, `half_diag`, the records (n_records x 5 x 4 uint32) and the list indices of the spheres outside the grid. Raises
+    PtError(PT_ERR_UNSUPPORTED) for a scene that walks the tree."""
+    info = (C.c_uint32 * 16)()
+    d = desc.struct()
+    _check(lib().pt_debug_cell_grid(C.byref(d), info, None, 0, None))
+    iu = np.frombuffer(info, np.uint32).copy()
+    fl = iu.view(np.float32)
+    rec = np.zeros((int(iu[3]), 5, 4), np.uint32)
+    large = np.zeros(16, np.uint32)
+    _check(lib().pt_debug_cell_grid(C.byref(d), info, rec.ctypes.data_as(C.POINTER(C.c_uint32)), rec.shape[0], large.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return {"n": iu[:3].astype(int), "gmin": fl[8:11].astype(np.float64), "h": fl[11:14].astype(np.float64), "d_build": float(fl[14]), "half_diag": float(fl[15]),
+            "records": rec, "large": large[:int(iu[4])].astype(int)}
 
 
 def comm_runtime():

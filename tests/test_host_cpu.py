@@ -523,6 +523,92 @@ def test_scene_graph_nestings_the_list_form_cannot_hold_are_interpreted_and_malf
     assert time.time() - t0 < 20.0
 
 
+def _cell_members(rec, first):
+    """List indices in the chain of records that starts at cell record `first` (csrc/pt_grid.h layout), and the spheres stored beside them."""
+    ids, sph, at, hops = [], [], first, 0
+    while True:
+        r = rec[at]
+        pairs = r[:4].view(np.float32)   # (x0 x1 y0 y1) (z0 z1 r0 r1) (x2 x3 y2 y3) (z2 z3 r2 r3)
+        four = [(pairs[0, 0], pairs[0, 2], pairs[1, 0], pairs[1, 2]), (pairs[0, 1], pairs[0, 3], pairs[1, 1], pairs[1, 3]),
+                (pairs[2, 0], pairs[2, 2], pairs[3, 0], pairs[3, 2]), (pairs[2, 1], pairs[2, 3], pairs[3, 1], pairs[3, 3])]
+        link = int(r[4, 3]) if r[4, 3] & 0x80000000 else None
+        for j in range(4):
+            k = int(r[4, j])
+            if j == 3 and link is not None:
+                continue
+            if k != 0x7fffffff:
+                ids.append(k), sph.append(four[j])
+        if link is None:
+            return ids, sph
+        at, hops = link & 0x7fffffff, hops + 1
+        assert hops < 64 and at >= 0
+
+
+@pytest.mark.parametrize("layout", ["config5", "layers", "strip"])
+def test_cell_grid_plan_registers_every_sphere_wherever_its_padded_ball_reaches(ptgpu, pthost, layout):
+    """The uniform cell grid of csrc/pt_grid.h as pt_scene_create plans it (pt_debug_cell_grid: host only), checked against the spheres
+    themselves: every sphere is either in the `large` list or inside the grid's box and registered in EVERY cell that its ball -- padded by
+    the inflation the reference's f32 discriminant can reach at d_build (1e-6 (d^2 + r^2) / r) -- reaches into; each cell's chain of records
+    ends, holds every index once, and stores the sphere's own four floats beside it. The walk's exactness rests on exactly this (and on
+    the DDA visiting the cells a line passes through, which the GPU tests pin against the exact scan)."""
+    rng = np.random.default_rng(3)
+    if layout == "config5":
+        hs = pthost.HostScene("perlin_spheres", 64, 36, samples=1, use_bvh=True, device=None)
+        ex = hs.export()
+        sph = ex["hitables"][:, 6:10].view(np.float32).copy()
+        desc = ptgpu.SceneDesc(sph, np.zeros(len(sph), np.uint32), [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0)], [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)])
+    else:
+        side, layers = (40, 3) if layout == "layers" else (0, 1)
+        if layout == "layers":
+            ijk = np.stack(np.meshgrid(np.arange(side), np.arange(layers), np.arange(side)), -1).reshape(-1, 3).astype(np.float64)
+        else:
+            ijk = np.stack(np.meshgrid(np.arange(150), np.arange(1), np.arange(10)), -1).reshape(-1, 3).astype(np.float64)
+        c = 0.7 * ijk + rng.uniform(0, 0.2, ijk.shape) * [1, 0.5, 1]
+        sph = np.concatenate([c, rng.uniform(0.22, 0.3, (len(c), 1))], 1).astype(np.float32)
+        sph = np.concatenate([sph, np.array([[0, -1000.5, 0, 1000.0], [3, 4, 3, 2.5]], np.float32)])   # a ground and a big sphere: outside the grid
+        desc = ptgpu.SceneDesc(sph, np.zeros(len(sph), np.uint32), [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0)], [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)])
+    g = ptgpu.debug_cell_grid(desc)
+    n, gmin, h, rec = g["n"], g["gmin"], g["h"], g["records"]
+    n_cells = int(n[0] * n[1] * n[2])
+    assert len(rec) >= n_cells and (n >= 1).all() and (h > 0).all()
+    members = {}
+    for cell in range(n_cells):
+        ids, stored = _cell_members(rec, cell)
+        assert len(set(ids)) == len(ids), cell
+        for k, four in zip(ids, stored):
+            assert 0 <= k < len(sph) and np.array_equal(np.asarray(four, np.float32), sph[k]), (cell, k)
+        members[cell] = set(ids)
+    large = set(int(k) for k in g["large"])
+    in_grid = set().union(*members.values())
+    assert in_grid | large == set(range(len(sph))) and not (in_grid & large)
+    if layout != "config5":
+        assert large == {len(sph) - 2, len(sph) - 1}
+    else:
+        assert large == {0, 1}          # the ground (r = 1000) and the r = 2 sphere of presets.rs:299-312
+    hi = gmin + n * h
+    pad = 1e-6 * (g["d_build"] ** 2 + sph[:, 3].astype(np.float64) ** 2) / np.abs(sph[:, 3].astype(np.float64))
+    checked = 0
+    for k in sorted(in_grid):
+        c, R = sph[k, :3].astype(np.float64), abs(float(sph[k, 3])) + pad[k]
+        assert (c - R >= gmin - 1e-9).all() and (c + R <= hi + 1e-9).all(), k        # the padded ball lies inside the grid's box
+        lo_i = np.clip(np.floor((c - R - gmin) / h).astype(int), 0, n - 1)
+        hi_i = np.clip(np.floor((c + R - gmin) / h).astype(int), 0, n - 1)
+        for z in range(lo_i[2], hi_i[2] + 1):
+            for y in range(lo_i[1], hi_i[1] + 1):
+                for x in range(lo_i[0], hi_i[0] + 1):
+                    cl, ch = gmin + np.array([x, y, z]) * h, gmin + (np.array([x, y, z]) + 1) * h
+                    d2 = (np.maximum(0.0, np.maximum(cl - c, c - ch)) ** 2).sum()
+                    if d2 <= R * R:
+                        assert k in members[(z * n[1] + y) * n[0] + x], (k, x, y, z)
+                        checked += 1
+    assert checked >= len(in_grid)
+    # a loose cloud gets no grid, and says so
+    cloud = np.concatenate([rng.uniform(-20, 20, (3000, 3)), rng.uniform(0.05, 0.4, (3000, 1))], 1).astype(np.float32)
+    with pytest.raises(ptgpu.PtError) as e:
+        ptgpu.debug_cell_grid(ptgpu.SceneDesc(cloud, np.zeros(3000, np.uint32), [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0)], [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)]))
+    assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and "no cell grid" in str(e.value)
+
+
 def test_committed_kernel_resource_table_keeps_registers_and_spills_within_the_stated_bounds():
     """profiles/r05_kernel_resources.txt (`make -C pathtrace-rs_amd resources`: hipcc -Rpass-analysis=kernel-resource-usage on the
     four kernel translation units) is the evidence behind DESIGN.md's register claims: every one of the 49 pt_trace_kernel and 25
