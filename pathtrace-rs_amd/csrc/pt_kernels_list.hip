@@ -11,13 +11,28 @@ namespace ptdev {
 // pass: the same kernel at 1 sample per pixel with throw-away seeds (random_seed path), writing nothing but
 // the rays spent per 8x8 tile (~1.5 % of the frame's work). The order only decides WHEN a pixel is rendered,
 // never its value.
+// `checker_tiles_x` != 0: only the tiles of one colour of a checkerboard were measured (tcol + trow even); a tile of the other colour takes
+// the mean of its measured neighbours as its cost (formed here on the fly: nobody else reads the costs of a new view).
+// The kernel also zeroes the frame's work counter block (`work_counter`, 16 words): it is the last thing enqueued before the frame kernel.
+__device__ __forceinline__ uint32_t ordered_cost(const uint32_t *cost, uint32_t t, uint32_t tiles_x, uint32_t tiles_y) {
+    if (tiles_x == 0u) return cost[t];
+    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+    if (((tx + ty) & 1u) == 0u) return cost[t];
+    uint32_t sum = 0, n = 0;   // (its four neighbours are all of the measured colour)
+    if (tx > 0u) sum += cost[t - 1u], n += 1u;
+    if (tx + 1u < tiles_x) sum += cost[t + 1u], n += 1u;
+    if (ty > 0u) sum += cost[t - tiles_x], n += 1u;
+    if (ty + 1u < tiles_y) sum += cost[t + tiles_x], n += 1u;
+    return n ? sum / n : 0u;
+}
 __global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile_cost, uint32_t cost_scale,
-                                     uint32_t *tile_order) {
+                                     uint32_t *tile_order, uint32_t checker_tiles_x, uint32_t checker_tiles_y, uint32_t *work_counter) {
     __shared__ uint32_t count[64], cursor[64];
     if (threadIdx.x < 64) count[threadIdx.x] = 0;
+    if (work_counter && threadIdx.x < 16) work_counter[threadIdx.x] = 0u;
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
-        const uint32_t b = tile_cost[t] / cost_scale;
+        const uint32_t b = ordered_cost(tile_cost, t, checker_tiles_x, checker_tiles_y) / cost_scale;
         atomicAdd(&count[b < 63u ? b : 63u], 1u);
     }
     __syncthreads();
@@ -30,48 +45,41 @@ __global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
-        const uint32_t b = tile_cost[t] / cost_scale;
+        const uint32_t b = ordered_cost(tile_cost, t, checker_tiles_x, checker_tiles_y) / cost_scale;
         tile_order[atomicAdd(&cursor[b < 63u ? b : 63u], 1u)] = t;
+    }
+}
+
+// Everything a new view's measuring launch needs zeroed or listed, in ONE launch (they were four fills and a kernel, each behind the other on
+// the stream): the work counter block, the ray count, the tile costs, and -- `list` != nullptr -- the tiles of the measured colour.
+__global__ void pt_frame_reset_kernel(uint32_t *work_counter, unsigned long long *ray_count, uint32_t *cost, uint32_t n_cost, uint32_t *list, uint32_t tiles_x,
+                                      uint32_t tiles_y) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < 16u) work_counter[t] = 0u;
+    if (t == 0u) *ray_count = 0ull;
+    if (t < n_cost) cost[t] = 0u;
+    if (list && t < tiles_x * tiles_y) {
+        const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+        // two rows hold tiles_x measured tiles: ceil(tiles_x / 2) in the even row, the rest in the odd one
+        if (((tx + ty) & 1u) == 0u) list[(ty >> 1) * tiles_x + ((ty & 1u) ? (tiles_x + 1u) / 2u : 0u) + (tx >> 1)] = t;
     }
 }
 
 // ---- measuring every OTHER tile -----------------------------------------------------------------
 // The measuring launch of a new view traces one sample of the tiles of one colour of a checkerboard (tcol + trow even); a tile of the
-// other colour takes the mean of its measured neighbours as its cost and is traced from its first sample by the frame kernel
-// (KArgs::checker). Config 3: measuring launch + order 0.30 -> 0.23 ms, frame 6.75 -> 6.70 ms; 16 spp 2.23 -> 2.15 ms. (One tile of every
-// 2 x 2 block was measured too: 7.1 ms -- the order gets too coarse. tools/checker_ab.sh)
-__global__ void pt_checker_list_kernel(uint32_t tiles_x, uint32_t tiles_y, uint32_t *list) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= tiles_x * tiles_y) return;
-    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
-    if (((tx + ty) & 1u) != 0u) return;
-    // two rows hold tiles_x measured tiles: ceil(tiles_x / 2) in the even row, the rest in the odd one
-    list[(ty >> 1) * tiles_x + ((ty & 1u) ? (tiles_x + 1u) / 2u : 0u) + (tx >> 1)] = t;
-}
-__global__ void pt_checker_fill_kernel(uint32_t tiles_x, uint32_t tiles_y, uint32_t *cost) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= tiles_x * tiles_y) return;
-    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
-    if (((tx + ty) & 1u) == 0u) return;
-    uint32_t sum = 0, n = 0;   // (its four neighbours are all of the measured colour, and nobody writes those)
-    if (tx > 0u) sum += cost[t - 1u], n += 1u;
-    if (tx + 1u < tiles_x) sum += cost[t + 1u], n += 1u;
-    if (ty > 0u) sum += cost[t - tiles_x], n += 1u;
-    if (ty + 1u < tiles_y) sum += cost[t + tiles_x], n += 1u;
-    cost[t] = n ? sum / n : 0u;
-}
+// other colour takes the mean of its measured neighbours as its cost (ordered_cost above) and is traced from its first sample by the frame
+// kernel (KArgs::checker). Config 3: measuring launch + order 0.30 -> 0.23 ms, frame 6.75 -> 6.70 ms; 16 spp 2.23 -> 2.15 ms. (One tile of
+// every 2 x 2 block was measured too: 7.1 ms -- the order gets too coarse. tools/checker_ab.sh)
 
 }  // namespace ptdev
 
 namespace pthostside {
 
-void launch_checker_list(uint32_t tiles_x, uint32_t tiles_y, uint32_t *list, hipStream_t stream) {
-    hipLaunchKernelGGL(pt_checker_list_kernel, dim3((tiles_x * tiles_y + 255u) / 256u), dim3(256), 0, stream, tiles_x, tiles_y, list);
+void launch_frame_reset(uint32_t *work_counter, unsigned long long *ray_count, uint32_t *cost, uint32_t n_cost, uint32_t *list, uint32_t tiles_x, uint32_t tiles_y,
+                        hipStream_t stream) {
+    const uint32_t n = std::max(std::max(n_cost, 16u), list ? tiles_x * tiles_y : 0u);
+    hipLaunchKernelGGL(pt_frame_reset_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, work_counter, ray_count, cost, n_cost, list, tiles_x, tiles_y);
 }
-void launch_checker_fill(uint32_t tiles_x, uint32_t tiles_y, uint32_t *cost, hipStream_t stream) {
-    hipLaunchKernelGGL(pt_checker_fill_kernel, dim3((tiles_x * tiles_y + 255u) / 256u), dim3(256), 0, stream, tiles_x, tiles_y, cost);
-}
-
 
 void mfma_list_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *frame, SphereKernel *measure) {
     // [moving][256 frame, 256 measure, verify, 768 frame, 768 measure, 1024 frame, 1024 measure]
@@ -90,8 +98,9 @@ void mfma_list_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *fra
     *measure = verify ? nullptr : t[w + 1];
 }
 
-void launch_tile_order(uint32_t n_work_tiles, const uint32_t *tile_cost, uint32_t cost_scale, uint32_t *tile_order, hipStream_t stream) {
-    hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, tile_cost, cost_scale, tile_order);
+void launch_tile_order(uint32_t n_work_tiles, const uint32_t *tile_cost, uint32_t cost_scale, uint32_t *tile_order, uint32_t checker_tiles_x, uint32_t checker_tiles_y,
+                       uint32_t *work_counter, hipStream_t stream) {
+    hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, tile_cost, cost_scale, tile_order, checker_tiles_x, checker_tiles_y, work_counter);
 }
 
 }  // namespace pthostside

@@ -150,6 +150,9 @@ int ensure_gstack(pt_scene *s, size_t need_floats) {
 // on any of this, never its value. `A` is the frame kernel's argument block (updated in place), `measure` launches phase 1.
 inline void set_checker(KArgs &A, bool on) { A.checker = on ? 1u : 0u; }
 inline void set_checker(WArgs &, bool) {}   // (the general-world kernel measures every tile)
+// The caller has NOT zeroed the work counter block and the ray count: a new view's reset kernel does it together with the tile costs and the
+// list of measured tiles (one launch where there were four fills and a kernel), a repeated view's two fills here; the order kernel zeroes the
+// work counter again for the frame kernel.
 template <typename Args, typename LaunchMeasure>
 int order_work(pt_scene *s, Args &A, const pt_params *params, const pt_camera *cam, uint32_t shard_index, uint32_t shard_count, hipStream_t stream,
                uint32_t measure_refill, LaunchMeasure measure, bool checker = false) {
@@ -162,29 +165,28 @@ int order_work(pt_scene *s, Args &A, const pt_params *params, const pt_camera *c
     uint32_t measured_scale = params->samples * (params->max_depth + 1u);
     if (reuse) {
         // the last frame of this view measured every tile: order by that (64 buckets over samples x (depth + 1) x 64 pixels)
-        launch_tile_order(n_work_tiles, measured, s->hint_scale, order, stream);
+        HIP_TRY(hipMemsetAsync(A.ray_count, 0, sizeof(uint64_t), stream));
+        launch_tile_order(n_work_tiles, measured, s->hint_scale, order, 0u, 0u, s->d_work_counter, stream);
     } else {
         if (int rc = ensure_px_state(s, (size_t)A.width * A.local_rows)) return rc;
-        HIP_TRY(hipMemsetAsync(cost, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
         Args A1 = A;
         A1.samples = 1, A1.phase = 1, A1.px_state = s->d_px_state, A1.tile_cost = cost;
         const uint32_t tiles_y = n_work_tiles / A.tiles_x;
-        if (checker) {   // every other tile (pt_kernels_list.hip): the list of the measured colour lives where the frame's order will be written
-            launch_checker_list(A.tiles_x, tiles_y, order, stream);
+        // (checker: every other tile -- pt_kernels_list.hip; the list of the measured colour lives where the frame's order will be written)
+        launch_frame_reset(s->d_work_counter, A.ray_count, cost, n_work_tiles, checker ? order : nullptr, A.tiles_x, tiles_y, stream);
+        if (checker) {
             A1.tile_order = order;
             A1.n_items = ((tiles_y >> 1) * A.tiles_x + ((tiles_y & 1u) ? (A.tiles_x + 1u) / 2u : 0u)) * kTilePix;
         }
         // one sample per pixel: refills dominate, batch them hard (`measure_refill` lanes must be waiting: the caller's choice)
         A1.refill_min = dev_knobs().phase1_refill > 0 ? (uint32_t)dev_knobs().phase1_refill : measure_refill;
         measure(A1);
-        if (checker) launch_checker_fill(A.tiles_x, tiles_y, cost, stream);
-        launch_tile_order(n_work_tiles, cost, params->max_depth + 1u, order, stream);
+        launch_tile_order(n_work_tiles, cost, params->max_depth + 1u, order, checker ? A.tiles_x : 0u, tiles_y, s->d_work_counter, stream);
         A.samples = params->samples - 1u, A.phase = 2, A.px_state = s->d_px_state;
         set_checker(A, checker);
         measured_scale = A.samples * (params->max_depth + 1u);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
     A.tile_order = order;
     if ((s->variant & ptsel::kVarMeasureEveryFrame) == 0) {   // this frame measures the tiles for the next one (after the order kernel has read the old values)
         HIP_TRY(hipMemsetAsync(measured, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
@@ -215,8 +217,10 @@ int launch_world(pt_scene *s, const ptsel::KernelChoice &c, const pt_params *par
     W.bvh_stack_entries = c.bvh_stack_entries;
     W.stack_in_lds = c.stack_in_lds;
     fill_frame_args(W, s, params, cam, frame_num, shard_index, shard_count, d_rgb, d_ray_count, c);
-    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
-    HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
+    if (c.order != ptsel::Order::Measured || W.n_items == 0) {   // (an ordered frame: order_work zeroes both, with what else the view needs)
+        HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
+        HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
+    }
     if (W.n_items == 0) {
         s->ev_valid = false;
         return PT_OK;
@@ -356,8 +360,13 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.n_spheres = s->tr.n_spheres;
     A.n_spheres_pad = ptsel::scan_pad(s->tr.n_spheres);
     fill_frame_args(A, s, params, cam, frame_num, shard_index, shard_count, d_rgb, d_ray_count, c);
-    HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
-    HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
+    SphereKernel kern = nullptr, measure_kern = nullptr;
+    sphere_kernels_for(c, &kern, &measure_kern);
+    const bool ordered = c.order == ptsel::Order::Measured && measure_kern != nullptr;
+    if (!ordered || A.n_items == 0) {   // (an ordered frame: order_work zeroes both, with what else the view needs)
+        HIP_TRY(hipMemsetAsync(s->d_work_counter, 0, 64, stream));
+        HIP_TRY(hipMemsetAsync(d_ray_count, 0, sizeof(uint64_t), stream));
+    }
     if (A.n_items == 0) {
         s->ev_valid = false;
         return PT_OK;
@@ -403,8 +412,6 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.tile_cost = nullptr;
     (void)bvh;
 
-    SphereKernel kern = nullptr, measure_kern = nullptr;
-    sphere_kernels_for(c, &kern, &measure_kern);
     const uint32_t blk = c.block, lds = c.lds_bytes;
     // ---- persistent grid: CUs x resident workgroups ----
     uint32_t bpc = c.bpc;
@@ -444,7 +451,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     HIP_TRY(hipEventRecord(s->ev_pass, stream));
     A.wave_end = s->d_wave_end;
     if (s->d_wave_end) (void)hipMemsetAsync(s->d_wave_end, 0, 65535 * 8, stream), (void)hipMemsetAsync(s->d_wave_end + 65535, 0xff, 8, stream), (void)hipMemsetAsync(s->d_debug + 91, 0, 8, stream);
-    if (c.order == ptsel::Order::Measured && measure_kern) {
+    if (ordered) {
         // The measuring launch of the prefilter kernels refills ALL lanes of a wave at once: the wave then always holds one whole
         // 8x8 tile, and the rays of one sample differ little in length (measuring launch + order kernel on config 3: 0.44 ms at 16
         // waiting lanes, 0.35 at 48, 0.31 at 60, 0.28 at 64; tools/sweep_phase1.sh). Tree traversals differ a lot: 48 stays better there.
