@@ -291,7 +291,7 @@ void sphere_kernels_for(const ptsel::KernelChoice &c, SphereKernel *frame, Spher
 WorldKernel world_kernel_for(const ptsel::KernelChoice &c);
 SphereKernel tree4_kernel_for_registers(bool moving);   // the symbol whose register count decides how many tree workgroups fit a CU
 const char *kernel_name(const ptsel::KernelChoice &c, char *buf, size_t cap);
-void launch_tile_order(uint32_t n_work_tiles, const uint32_t *tile_cost, uint32_t cost_scale, uint32_t *tile_order, uint32_t checker_tiles_x, uint32_t checker_tiles_y,
+void launch_tile_order(uint32_t n_work_tiles, uint32_t *tile_cost, uint32_t cost_scale, uint32_t *tile_order, uint32_t checker_tiles_x, uint32_t checker_tiles_y,
                        uint32_t *work_counter, hipStream_t stream);
 void launch_frame_reset(uint32_t *work_counter, unsigned long long *ray_count, uint32_t *cost, uint32_t n_cost, uint32_t *list, uint32_t tiles_x, uint32_t tiles_y,
                         hipStream_t stream);

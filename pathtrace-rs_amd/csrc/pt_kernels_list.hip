@@ -25,14 +25,17 @@ __device__ __forceinline__ uint32_t ordered_cost(const uint32_t *cost, uint32_t 
     if (ty + 1u < tiles_y) sum += cost[t + tiles_x], n += 1u;
     return n ? sum / n : 0u;
 }
-__global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile_cost, uint32_t cost_scale,
+__global__ void pt_tile_order_kernel(uint32_t n_work_tiles, uint32_t *tile_cost, uint32_t cost_scale,
                                      uint32_t *tile_order, uint32_t checker_tiles_x, uint32_t checker_tiles_y, uint32_t *work_counter) {
     __shared__ uint32_t count[64], cursor[64];
     if (threadIdx.x < 64) count[threadIdx.x] = 0;
     if (work_counter && threadIdx.x < 16) work_counter[threadIdx.x] = 0u;
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
-        const uint32_t b = ordered_cost(tile_cost, t, checker_tiles_x, checker_tiles_y) / cost_scale;
+        // (an unmeasured tile's cost is written back for the second pass: its neighbours are measured tiles, which nobody writes)
+        const uint32_t c = ordered_cost(tile_cost, t, checker_tiles_x, checker_tiles_y);
+        if (checker_tiles_x != 0u) tile_cost[t] = c;
+        const uint32_t b = c / cost_scale;
         atomicAdd(&count[b < 63u ? b : 63u], 1u);
     }
     __syncthreads();
@@ -45,7 +48,7 @@ __global__ void pt_tile_order_kernel(uint32_t n_work_tiles, const uint32_t *tile
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
-        const uint32_t b = ordered_cost(tile_cost, t, checker_tiles_x, checker_tiles_y) / cost_scale;
+        const uint32_t b = tile_cost[t] / cost_scale;
         tile_order[atomicAdd(&cursor[b < 63u ? b : 63u], 1u)] = t;
     }
 }
@@ -98,7 +101,7 @@ void mfma_list_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *fra
     *measure = verify ? nullptr : t[w + 1];
 }
 
-void launch_tile_order(uint32_t n_work_tiles, const uint32_t *tile_cost, uint32_t cost_scale, uint32_t *tile_order, uint32_t checker_tiles_x, uint32_t checker_tiles_y,
+void launch_tile_order(uint32_t n_work_tiles, uint32_t *tile_cost, uint32_t cost_scale, uint32_t *tile_order, uint32_t checker_tiles_x, uint32_t checker_tiles_y,
                        uint32_t *work_counter, hipStream_t stream) {
     hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(1024), 0, stream, n_work_tiles, tile_cost, cost_scale, tile_order, checker_tiles_x, checker_tiles_y, work_counter);
 }
