@@ -1,11 +1,11 @@
 // pt_grid.h -- closest hit over a UNIFORM CELL GRID: what the GRID flavour of the 4-wide tree kernels walks instead of the tree
-// (pt_host.h GridPlan: at least 1 024 spheres of similar size, spread evenly enough).
+// (pt_host.h GridPlan: at least 1 024 spheres of similar size in an even, dense field -- looser clouds keep the tree, which skips empty space).
 //
 // Why. A visit of the 4-wide tree tests FOUR BOXES (146 VALU instructions) and a ray of BASELINE config 5 -- 10 000 spheres of radius 0.2
 // on a 100 x 100 lattice -- needs 10.4 of them plus 3.4 exact sphere tests. A cell of the grid holds the spheres themselves: a visit is
 // one 80-byte record (five 16-byte loads: up to four spheres and their list indices), four reference discriminants (sphere.rs:33-37 in
 // the reference's own operation order: the filter is EXACT, a sphere whose discriminant is not positive does nothing in the reference
-// either) and one step of a 3D-DDA: 2.3 records and 2.5 positive discriminants per ray on that scene.
+// either) and one step of a 3D-DDA: 2.3 records and 1.9 queued spheres per ray on that scene (8.8 -> 12.5 Grays/s).
 //
 // Structure of a call (one per trip of the kernel's main loop, all rays of the wave to their end, like bvh4_trace):
 //   walk rounds   every lane with cells left visits one record; spheres with a positive discriminant are QUEUED (owner lane | sphere), and
@@ -19,8 +19,8 @@
 //
 // What makes it the same closest hit. The winner is the (t, tie-break) minimum over every sphere whose reference test accepts the ray
 // (DESIGN.md 4.2 / 4.4), so the structure only has to PRESENT every such sphere before the walk ends:
-//   * a sphere is registered in every cell its box overlaps, the box padded by how far the reference's f32 discriminant can inflate the
-//     sphere for a ray whose origin lies within KArgs::grid_d_build of it (pt_tree4.h: 0.65e-6 (|o - c|^2 + r^2) / r; the plan uses 1e-6)
+//   * a sphere is registered in every cell its BALL reaches into (a MovingSphere: the box of its sweep), padded by how far the reference's
+//     f32 discriminant can inflate the sphere for a ray whose origin lies within KArgs::grid_d_build of it (pt_tree4.h: 0.65e-6 (|o - c|^2 + r^2) / r; the plan uses 1e-6)
 //     and by h / 1000 for the walk's own rounding (cell boundaries are recomputed from integer cell numbers, never accumulated);
 //   * the walk visits every cell the line passes through from its entry into the grid's box to the first cell whose entry parameter lies
 //     beyond best * 1.0005 + 5e-4 (the tree's culling slack: the reference's root can fall below the true parameter);
