@@ -402,6 +402,7 @@ typedef struct pt_kernel_choice {
     uint32_t coop;                                    /* wide MFMA list kernels: waves that run out of work finish pixels handed over by busy ones, 64 lanes per ray (PT_TUNE_NO_HANDOVER switches it off) */
     uint32_t world_graph;                             /* general-world kernel: the world is a scene graph that does not flatten and is interpreted (csrc/pt_graph.h) */
     uint32_t world_lazy;                              /* general-world kernel, worlds with Noise textures: a scatter's Noise colour is formed when its path ends lit, by the whole wave (a development switch turns it off: csrc/pt_devknobs.h kVarWorldEager) */
+    uint32_t pool_slots;                              /* 1024-thread MFMA list kernels: entries of each wave's pool of ready-to-start pixels in LDS (0: lanes wait for batched refills; `name` carries ",pool" otherwise) */
     char name[96];
 } pt_kernel_choice;
 /* The choice the scene's most recent render made. */

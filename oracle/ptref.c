@@ -1806,6 +1806,7 @@ static uint64_t render_pixel(const ora_scene *s, uint32_t width, uint32_t height
 typedef struct {
     const ora_scene *s; uint32_t width, height, samples, max_depth, frame_num;
     float *buffer; const uint32_t *pixels; uint64_t begin, end;
+    uint32_t *pixel_rays; /* optional: rays of job pixel k (the per-pixel summand of scene.rs:118) */
     atomic_ullong next; atomic_ullong ray_count;
 } job;
 
@@ -1819,8 +1820,10 @@ static void *worker(void *arg) {
         uint64_t e = b + JOB_CHUNK; if (e > j->end) e = j->end;
         for (uint64_t k = b; k < e; ++k) {
             uint64_t i = j->pixels ? j->pixels[k] : k;
-            local += render_pixel(j->s, j->width, j->height, j->samples, j->max_depth, j->frame_num, i,
-                                  j->buffer + 3 * i);
+            uint64_t rays = render_pixel(j->s, j->width, j->height, j->samples, j->max_depth, j->frame_num, i,
+                                         j->buffer + 3 * i);
+            if (j->pixel_rays) j->pixel_rays[k - j->begin] = (uint32_t)rays;
+            local += rays;
         }
     }
     atomic_fetch_add(&j->ray_count, local); /* scene.rs:118 */
@@ -1862,6 +1865,17 @@ uint64_t ora_scene_update_pixels(const ora_scene *s, uint32_t width, uint32_t he
     job j; memset(&j, 0, sizeof j);
     j.s = s; j.width = width; j.height = height; j.samples = samples; j.max_depth = max_depth;
     j.frame_num = frame_num; j.buffer = buffer; j.pixels = pixels; j.begin = 0; j.end = n_pixels;
+    atomic_store(&j.next, 0);
+    return run_job(&j, nthreads);
+}
+
+uint64_t ora_scene_update_pixels_counted(const ora_scene *s, uint32_t width, uint32_t height, uint32_t samples,
+                                         uint32_t max_depth, uint32_t frame_num, float *buffer,
+                                         const uint32_t *pixels, uint64_t n_pixels, uint32_t *pixel_rays, int nthreads) {
+    job j; memset(&j, 0, sizeof j);
+    j.s = s; j.width = width; j.height = height; j.samples = samples; j.max_depth = max_depth;
+    j.frame_num = frame_num; j.buffer = buffer; j.pixels = pixels; j.begin = 0; j.end = n_pixels;
+    j.pixel_rays = pixel_rays;
     atomic_store(&j.next, 0);
     return run_job(&j, nthreads);
 }

@@ -86,6 +86,16 @@ uint64_t ora_scene_update_pixels(const ora_scene *s, uint32_t width,
                                  float *buffer, const uint32_t *pixels,
                                  uint64_t n_pixels, int nthreads);
 
+/* Same, and pixel_rays[k] receives the rays traced for pixels[k] (the
+ * per-pixel summand of scene.rs:118's ray_count; test fixtures keep them
+ * per 8x8 tile). pixel_rays may be NULL. */
+uint64_t ora_scene_update_pixels_counted(const ora_scene *s, uint32_t width,
+                                         uint32_t height, uint32_t samples,
+                                         uint32_t max_depth, uint32_t frame_num,
+                                         float *buffer, const uint32_t *pixels,
+                                         uint64_t n_pixels, uint32_t *pixel_rays,
+                                         int nthreads);
+
 /* ---- flat export of the built scene (for cross-checks / feeding the
  *      product through its C ABI in tests) -------------------------------- */
 uint32_t ora_scene_num_spheres(const ora_scene *s);

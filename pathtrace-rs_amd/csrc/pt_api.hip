@@ -37,6 +37,8 @@ const DevKnobs &dev_knobs() {
         if (const char *e = getenv("PTGPU_COOP_STREAK")) d.coop_streak = atoi(e);
         if (const char *e = getenv("PTGPU_COOP_PERIOD")) d.coop_period = atoi(e);
         if (const char *e = getenv("PTGPU_COOP_EST")) d.coop_est = atoi(e);
+        if (const char *e = getenv("PTGPU_POOL")) d.pool = std::max(0, atoi(e));
+        if (const char *e = getenv("PTGPU_POOL_TAIL")) d.pool_tail = std::max(0, atoi(e));
         if (const char *e = getenv("PTGPU_HOST_THREADS")) d.host_threads = std::max(0, atoi(e));
         if (const char *e = getenv("PTGPU_BLOCKS_PER_CU")) d.blocks_per_cu = (uint32_t)atoi(e);
         if (const char *e = getenv("PTGPU_VARIANT")) d.variant = (uint32_t)atoi(e);
@@ -161,6 +163,7 @@ void fill_choice(const ptsel::KernelChoice &c, pt_kernel_choice *out) {
     out->coop = c.coop ? 1u : 0u;
     out->world_lazy = c.world_lazy ? 1u : 0u;
     out->world_graph = c.world_graph ? 1u : 0u;
+    out->pool_slots = c.pool_slots;
     kernel_name(c, out->name, sizeof out->name);
 }
 }  // namespace

@@ -31,6 +31,7 @@ enum : uint32_t {
                                      // 8x8 tiles; a tile of the other colour takes the mean of its measured neighbours as its cost and starts at its
                                      // first sample in the second launch (measuring launch + order of config 3: 0.30 -> 0.23 ms)
     kVarNoGrid = 524288u,        // tree kernels always walk the 4-wide tree (default: the uniform cell grid of pt_grid.h when the scene has one)
+    kVarNoPool = 1048576u,       // wide list frame kernels: no per-wave pool of ready pixels in LDS; freed lanes wait for a batched refill (rounds 2-5)
     // (4096, 16384 and 32768 were A/B switches of questions settled in rounds 2-3 and are ignored)
 };
 
@@ -39,6 +40,7 @@ enum : uint32_t {
 // Environment knobs, read ONLY by builds made with `make DEFS=-DPT_DEVKNOBS` (pt_api.hip dev_knobs(); the shipped library reads one
 // variable, PTGPU_HOST_BUILD, the hook with which the parity tests compare the two tree builders):
 //   PTGPU_REFILL / PTGPU_PHASE1_REFILL   lanes that must want a pixel before the wave refills (frame / measuring launch)
+//   PTGPU_POOL / PTGPU_POOL_TAIL         wide list kernels: entries of a wave's pixel pool (0: off) / items before the list's end from which claims stop filling it
 //   PTGPU_READY                          4-wide tree: lanes without traversal work before subtrees change hands (kShareMin)
 //   PTGPU_DRAIN                          4-wide tree: queued leaf candidates of one lane that trigger the wave's drain
 //   PTGPU_COOP_LIVE / _STREAK / _PERIOD / _EST / PTGPU_COOP_DBG     hand-over policy of the wide list kernels (pt_coop.h)

@@ -39,6 +39,7 @@ namespace ptdev {
 // were built over the motion's whole sweep.
 // GATE: a BVH world on the MFMA list kernel (ancestor-AABB gate + DFS-rank ties at hit acceptance).
 // GRID: the 4-wide tree kernels' flavour that walks the scene's uniform cell grid (pt_grid.h) instead of the tree.
+// NOPOOL: a 1024-thread frame kernel without the per-wave pixel pools (see POOL below).
 // BLK: threads per workgroup. 256 (three workgroups per CU) everywhere except the MFMA list kernels, which run ONE
 // 768-thread workgroup per CU when the scene allows: the sphere fragments are then staged once per CU instead of three
 // times, and the LDS that frees holds the per-lane attenuation stacks (no HBM traffic for them).
@@ -61,7 +62,7 @@ namespace ptdev {
 #else
 #define PT_BBPROF_ATTR
 #endif
-template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false, bool GATE = false, int BLK = kBlock, bool GRID = false>
+template <bool BVH, bool SPH_LDS, bool MFMA, bool VERIFY, bool PILOT, bool MOVING = false, bool GATE = false, int BLK = kBlock, bool GRID = false, bool NOPOOL = false>
 __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4_WAVES : PT_MINWAVES) : 1) PT_BBPROF_ATTR void pt_trace_kernel(const KArgs A) {
     static_assert(BLK == kBlock || (MFMA && !BVH), "only the MFMA list kernels take another workgroup size");
     static_assert(!GRID || (BVH && SPH_LDS), "the uniform cell grid (pt_grid.h) is a traversal structure of the 4-wide tree kernels");
@@ -74,6 +75,14 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     constexpr bool PAL = (BLK != kBlock);
     // The wide frame kernels hand pixels over to waves that have run out of work (pt_coop.h); A.tail_cap == 0 switches it off.
     constexpr bool TAIL = PAL && !PILOT && !VERIFY;
+    // The wide frame kernels keep a per-wave POOL of ready-to-start pixels in LDS (A.pool_slots entries of 48 bytes: RNG stream, colour sum,
+    // coordinates): a lane that finishes a pixel takes the next one from it in the same trip, and the global round trips of a claim (work
+    // counter -> tile order -> parked stream) are paid once per pool_slots pixels by the whole wave instead of making freed lanes wait for
+    // a batch ("---- refill" below; A.pool_slots == 0: the batched refill of the other kernels).
+    // (the 1024-thread frame kernels; NOPOOL = true keeps round 5's batched refill for scenes whose LDS has no room for pools and for the tuning bit
+    //  kVarNoPool. 768-thread kernels -- three waves per SIMD at up to 149 registers -- measured 1.6 % slower with pools: they keep the batch.)
+    constexpr bool POOL = TAIL && BLK == 1024 && !NOPOOL;
+    static_assert(!NOPOOL || (TAIL && BLK == 1024), "NOPOOL only distinguishes the 1024-thread frame kernels");
     // 4-wide tree kernels: ONE 32-bit word per attenuation-stack level -- the grey value of a Noise texture as its float bits
     // (texture.rs:86-89 yields (v, v, v)), or a palette code like PAL's for everything else: 0xFFE00000 | even-checker bit << 20 |
     // record index (0xFFFFF = white). No arithmetic produces such a NaN pattern (canonical NaNs are 0x7FC00000 / 0xFFC00000).
@@ -230,6 +239,13 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     };
     float rtime = 0.f;  // ray.time (only MOVING kernels read it)
     bool first_claim = true;   // (wave-uniform: every lane of a wave takes part in its first fetch)
+    // POOL, one wave-uniform word: bits 0-6 the pool's first live entry, 7-13 how many are live, 14-20 items left of the wave's 64 static first
+    // ones, 21 the work list has nothing more for this wave, 22 the list is about to end (claims take what is wanted and no more)
+    uint32_t pool_st = (POOL && A.first_static != 0u) ? (64u << 14) : 0u;
+    if (POOL && A.pool_tail >= A.n_items) pool_st |= 1u << 22;
+#define PT_POOL_LEFT ((pool_st >> 7) & 127u)
+#define PT_POOL_DRY ((pool_st >> 21) & 1u)
+#define PT_POOL_EXACT ((pool_st >> 22) & 1u)
     bool tail_dry = TAIL && A.tail_dry0 != 0u;     // TAIL, wave-uniform: the work list has run dry (from then on pixels may be handed over)
     uint32_t tail_it = 0, tail_streak = 0, tail_rand = (blockIdx.x * (BLK / 64) + wave_id) * 2654435761u + 12345u;   // (wave-uniform)
 #ifdef PT_DEVKNOBS
@@ -245,94 +261,180 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 #endif
 
     for (;;) {
-        // ---- refill: one wave-aggregated atomic for all lanes that need a pixel. The refill code (a global atomic
-        // round trip and four SplitMix64 steps of 64-bit multiplies) runs for the whole wave whenever ANY lane needs
-        // it, so lanes wait until A.refill_min of them do (or nobody has work left): fewer, fuller refills.
+        // ---- refill: lanes without a pixel get one
         const unsigned long long want = wave_ballot(!have && !exhausted);
-        const bool refill_now = __popcll(want) >= (int)A.refill_min || wave_ballot(have) == 0ull;
-        if (!have && !exhausted && refill_now) {
-            if (finished) {
-                // scene.rs:113-116
-                finished = false;
-                const float4 pf = s_par[10];   // inv_ns, mix_prev, mix_new
-                if (PILOT && A.phase == 1u) {   // to be continued: park the stream and the sum
-                    uint4 *st = A.px_state + 3u * (size_t)((pxy >> 16) * A.width + (pxy & 0xffffu));
-                    st[0] = make_uint4((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
-                    st[1] = make_uint4((uint32_t)rng.s2, (uint32_t)(rng.s2 >> 32), (uint32_t)rng.s3, (uint32_t)(rng.s3 >> 32));
-                    st[2] = make_uint4(__float_as_uint(col.x), __float_as_uint(col.y), __float_as_uint(col.z), 0u);
-                }
-                col = scale3(col, pf.x);
-                if (!PILOT) {
-                    float *out = A.rgb + ((pxy >> 16) * A.width + (pxy & 0xffffu)) * 3u;
-                    // (prev_zero: pt_render found the host buffer all +0.0f and did not upload it -- same products, same sums)
-                    const bool pz = pf.w != 0.0f;   // (KArgs::prev_zero, through the LDS parameter block like its neighbours)
-                    const float p0 = pz ? 0.0f : out[0], p1 = pz ? 0.0f : out[1], p2 = pz ? 0.0f : out[2];
-                    out[0] = p0 * pf.y + col.x * pf.z;
-                    out[1] = p1 * pf.y + col.y * pf.z;
-                    out[2] = p2 * pf.y + col.z * pf.z;
-                }
-                // (frame kernels: the NEXT frame's work order; the pixel's work tile is recomputed from its coordinates)
-                if (PILOT || A.tile_cost) atomicAdd(&A.tile_cost[((pxy >> 16) >> kTileLog2) * A.tiles_x + ((pxy & 0xffffu) >> kTileLog2)], pix_rays);
+        // scene.rs:113-116: a finished pixel is averaged, blended into the frame and its rays are booked on its work tile
+        auto write_finished_pixel = [&]() {
+            finished = false;
+            const float4 pf = s_par[10];   // inv_ns, mix_prev, mix_new
+            if (PILOT && A.phase == 1u) {   // to be continued: park the stream and the sum
+                uint4 *st = A.px_state + 3u * (size_t)((pxy >> 16) * A.width + (pxy & 0xffffu));
+                st[0] = make_uint4((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
+                st[1] = make_uint4((uint32_t)rng.s2, (uint32_t)(rng.s2 >> 32), (uint32_t)rng.s3, (uint32_t)(rng.s3 >> 32));
+                st[2] = make_uint4(__float_as_uint(col.x), __float_as_uint(col.y), __float_as_uint(col.z), 0u);
             }
-            const unsigned long long m = wave_ballot(1);
-            const int leader = __ffsll((long long)m) - 1;
-            uint32_t base = 0;
-            if (A.first_static != 0u && first_claim) {
-                // A SIMD's arbiter serves its OLDEST wave first: the first waves of a 16-wave workgroup advance up to twice as fast
-                // as the last ones ("The end of a frame"). The head of the heavy-first list -- the pixels whose
-                // serial sample chains decide when the frame ends -- therefore goes to them: a wave's first 64 items are fixed by
-                // its age class (wave >> 2) instead of by the race for the counter, which starts behind these items.
-                const uint32_t wv = wave_id, cls = wv >> 2, idx = blockIdx.x * 4u + (wv & 3u);
-                base = (cls * gridDim.x * 4u + idx) * 64u;
-            } else {
-                if (lane == leader) base = atomicAdd(A.work_counter, (uint32_t)__popcll(m));
-                base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader) + A.first_static;
+            col = scale3(col, pf.x);
+            if (!PILOT) {
+                float *out = A.rgb + ((pxy >> 16) * A.width + (pxy & 0xffffu)) * 3u;
+                // (prev_zero: pt_render found the host buffer all +0.0f and did not upload it -- same products, same sums)
+                const bool pz = pf.w != 0.0f;   // (KArgs::prev_zero, through the LDS parameter block like its neighbours)
+                const float p0 = pz ? 0.0f : out[0], p1 = pz ? 0.0f : out[1], p2 = pz ? 0.0f : out[2];
+                out[0] = p0 * pf.y + col.x * pf.z;
+                out[1] = p1 * pf.y + col.y * pf.z;
+                out[2] = p2 * pf.y + col.z * pf.z;
             }
-            first_claim = false;
-            const uint32_t item = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // lanes of m below this one
-            if (item >= A.n_items) {
-                exhausted = true;
-#ifdef PT_WAVE_DETAIL
-                if (A.wave_end && dbg_exh_iter == 0) dbg_exh_iter = dbg_iters, dbg_last_refill = wall_clock64();
-#endif
+            // (frame kernels: the NEXT frame's work order; the pixel's work tile is recomputed from its coordinates)
+            if (PILOT || A.tile_cost) atomicAdd(&A.tile_cost[((pxy >> 16) >> kTileLog2) * A.tiles_x + ((pxy & 0xffffu) >> kTileLog2)], pix_rays);
+        };
+        // the sample number a pixel starts this launch with. Phase 2 of a frame whose measuring launch traced every OTHER tile (KArgs::checker):
+        // a pixel of an unmeasured tile starts here, one sample behind the others -- its sample number starts at -1 (20 bits), so that it too
+        // is done when the number reaches s_par[12].w = samples - 1
+        auto tile_parked = [&](uint32_t tcol, uint32_t trow) -> bool { return !PILOT && A.phase == 2u && (A.checker == 0u || ((tcol + trow) & 1u) == 0u); };
+        auto start_sd = [&](bool parked) -> uint32_t { return (!PILOT && A.phase == 2u && !parked) ? 0xfffff000u : 0u; };
+        // work item -> the pixel and the state it starts with (false: the item lies beyond the frame's edge)
+        auto start_item = [&](uint32_t item, uint32_t &pxy_o, bool &parked_o, Rng &rng_o, f3 &col_o) -> bool {
+            const uint32_t in = item & (kTilePix - 1u);
+            const uint32_t tile = A.tile_order ? A.tile_order[item >> (2u * kTileLog2)] : (item >> (2u * kTileLog2));
+            // tile / tiles_x by the host's magic (a u32 division costs ~25 instructions and a hoisted reciprocal register):
+            // umulhi underestimates the quotient by at most one for any tile < 2^32
+            uint32_t trow = __umulhi(tile, A.tiles_x_magic), tcol = tile - trow * A.tiles_x;
+            if (tcol >= A.tiles_x) trow += 1u, tcol -= A.tiles_x;
+            const uint32_t x = tcol * kTileSide + (in & (kTileSide - 1u));
+            const uint32_t ly = trow * kTileSide + (in >> kTileLog2);
+            if (!(x < A.width && ly < A.local_rows)) return false;
+            pxy_o = x | (ly << 16);
+            const uint32_t px = x, py = ly * A.shard_count + A.shard_index;
+            parked_o = tile_parked(tcol, trow);
+            if (parked_o) {   // continue the stream and the sum phase 1 parked
+                const uint4 *st = A.px_state + 3u * (size_t)(ly * A.width + x);
+                const uint4 a = st[0], b = st[1], c = st[2];
+                rng_o.s0 = (uint64_t)a.x | ((uint64_t)a.y << 32), rng_o.s1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
+                rng_o.s2 = (uint64_t)b.x | ((uint64_t)b.y << 32), rng_o.s3 = (uint64_t)b.z | ((uint64_t)b.w << 32);
+                col_o = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
             } else {
-                const uint32_t in = item & (kTilePix - 1u);
-                const uint32_t tile = A.tile_order ? A.tile_order[item >> (2u * kTileLog2)] : (item >> (2u * kTileLog2));
-                pix_rays = 0;
-                // tile / tiles_x by the host's magic (a u32 division costs ~25 instructions and a hoisted reciprocal register):
-                // umulhi underestimates the quotient by at most one for any tile < 2^32
-                uint32_t trow = __umulhi(tile, A.tiles_x_magic), tcol = tile - trow * A.tiles_x;
-                if (tcol >= A.tiles_x) trow += 1u, tcol -= A.tiles_x;
-                const uint32_t x = tcol * kTileSide + (in & (kTileSide - 1u));
-                const uint32_t ly = trow * kTileSide + (in >> kTileLog2);
-                if (x < A.width && ly < A.local_rows) {
-                    have = true;
-                    pxy = x | (ly << 16);
-#ifdef PT_WAVE_DETAIL
-                    if (dbg_first_pxy == 0xffffffffu) dbg_first_pxy = pxy;
-#endif
-                    const uint32_t px = x, py = ly * A.shard_count + A.shard_index;
-                    need_cam = true;
-                    // phase 2 of a frame whose measuring launch traced every OTHER tile (KArgs::checker): a pixel of an unmeasured tile
-                    // starts here, one sample behind the others -- its sample number starts at -1 (20 bits), so that it too is done
-                    // when the number reaches s_par[12].w = samples - 1
-                    const bool parked = !PILOT && A.phase == 2u && (A.checker == 0u || ((tcol + trow) & 1u) == 0u);
-                    sd = (!PILOT && A.phase == 2u && !parked) ? 0xfffff000u : 0u;
-                    if (parked) {   // continue the stream and the sum phase 1 parked
-                        const uint4 *st = A.px_state + 3u * (size_t)(ly * A.width + x);
-                        const uint4 a = st[0], b = st[1], c = st[2];
+                col_o = mk3(0.f, 0.f, 0.f);
+                // scene.rs:96-102
+                uint64_t seed = ((uint64_t)px * 1973ull + (uint64_t)py * 9277ull + (uint64_t)A.frame_num * 26699ull) | 1ull;
+                if (A.random_seed) {
+                    uint64_t h = A.seed_base ^ (seed * 0x9e3779b97f4a7c15ULL);
+                    seed = splitmix64_next(h);
+                }
+                rng_seed_from_u64(rng_o, seed);
+            }
+            return true;
+        };
+        if (POOL) {
+            // Wide frame kernels: freed lanes do not wait for a batch. The wave keeps a POOL of ready-to-start pixels in LDS (A.pool_slots entries of
+            // 48 bytes per wave: RNG stream, colour sum, coordinates); a lane that finishes takes the next entry in the same trip, and the global
+            // round trips of a claim (work counter -> tile order -> parked stream) are paid once per pool_slots pixels, by all lanes together. Near
+            // the list's end (A.pool_tail items before it) claims take what is wanted and no more, batched by A.refill_min like the other kernels'.
+            if (want != 0ull) {   // (wave-uniform)
+                if (!have && finished) write_finished_pixel();
+                uint32_t wv_here = wave_id;
+                asm volatile("" : "+s"(wv_here));   // (the pool's address is formed here: hoisted out of the loop it is one more live scalar)
+                uint4 *const w_pool = reinterpret_cast<uint4 *>(smem + A.pool_off) + wv_here * (A.pool_slots * 3u);
+                const uint32_t wn = (uint32_t)__popcll(want);
+                if (PT_POOL_LEFT == 0u && !PT_POOL_DRY && (!PT_POOL_EXACT || wn >= A.refill_min || wave_ballot(have) == 0ull)) {
+                    // ---- claim: the whole wave fetches up to pool_slots work items and parks their start states in its pool
+                    uint32_t n = A.pool_slots, base;
+                    const uint32_t static_left = (pool_st >> 14) & 127u;
+                    if (static_left != 0u) {
+                        // A SIMD's arbiter serves its OLDEST wave first: the first waves of a 16-wave workgroup advance up to twice as fast
+                        // as the last ones ("The end of a frame"). The head of the heavy-first list -- the pixels whose
+                        // serial sample chains decide when the frame ends -- therefore goes to them: a wave's first 64 items are fixed by
+                        // its age class (wave >> 2) instead of by the race for the counter, which starts behind these items.
+                        const uint32_t cls = wv_here >> 2, idx = blockIdx.x * 4u + (wv_here & 3u);
+                        n = n < static_left ? n : static_left;
+                        base = (cls * gridDim.x * 4u + idx) * 64u + (64u - static_left);
+                        pool_st -= n << 14;
+                    } else {
+                        if (PT_POOL_EXACT) n = n < wn ? n : wn;   // (a pixel parked here is one an idle lane elsewhere cannot take)
+                        uint32_t b = 0;
+                        if (lane == 0) b = atomicAdd(A.work_counter, n);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b) + A.first_static;
+                    }
+                    if (base + n + A.pool_tail >= A.n_items) pool_st |= 1u << 22;
+                    if (base + n >= A.n_items) pool_st |= 1u << 21;
+                    const uint32_t item = base + (uint32_t)lane;
+                    uint32_t q = 0;
+                    bool parked_q = false;
+                    Rng r{0, 0, 0, 0};
+                    f3 c = mk3(0.f, 0.f, 0.f);
+                    const bool ok = (uint32_t)lane < n && item < A.n_items && start_item(item, q, parked_q, r, c);
+                    const unsigned long long m = wave_ballot(ok);
+                    if (ok) {
+                        uint4 *e = w_pool + 3u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        e[0] = make_uint4((uint32_t)r.s0, (uint32_t)(r.s0 >> 32), (uint32_t)r.s1, (uint32_t)(r.s1 >> 32));
+                        e[1] = make_uint4((uint32_t)r.s2, (uint32_t)(r.s2 >> 32), (uint32_t)r.s3, (uint32_t)(r.s3 >> 32));
+                        e[2] = make_uint4(__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), q);
+                    }
+                    pool_st = (pool_st & ~0x3fffu) | ((uint32_t)__popcll(m) << 7);   // first entry 0, that many live
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // ---- serve: waiting lanes take the pool's next entries, in order (a lane the pool cannot serve waits for the next claim)
+                const uint32_t pool_head = pool_st & 127u, pool_left = PT_POOL_LEFT;
+                if (!have && !exhausted) {
+                    const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
+                    if (rk < pool_left) {
+                        const uint4 *e = w_pool + 3u * (pool_head + rk);
+                        const uint4 a = e[0], b = e[1], c = e[2];
                         rng.s0 = (uint64_t)a.x | ((uint64_t)a.y << 32), rng.s1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
                         rng.s2 = (uint64_t)b.x | ((uint64_t)b.y << 32), rng.s3 = (uint64_t)b.z | ((uint64_t)b.w << 32);
                         col = mk3(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z));
-                    } else {
-                        col = mk3(0.f, 0.f, 0.f);
-                        // scene.rs:96-102
-                        uint64_t seed = ((uint64_t)px * 1973ull + (uint64_t)py * 9277ull + (uint64_t)A.frame_num * 26699ull) | 1ull;
-                        if (A.random_seed) {
-                            uint64_t h = A.seed_base ^ (seed * 0x9e3779b97f4a7c15ULL);
-                            seed = splitmix64_next(h);
-                        }
-                        rng_seed_from_u64(rng, seed);
+                        pxy = c.w;
+                        sd = start_sd(tile_parked((pxy & 0xffffu) >> kTileLog2, (pxy >> 16) >> kTileLog2));
+                        pix_rays = 0;
+                        have = true;
+                        need_cam = true;
+#ifdef PT_WAVE_DETAIL
+                        if (dbg_first_pxy == 0xffffffffu) dbg_first_pxy = pxy;
+#endif
+                    } else if (PT_POOL_DRY) {
+                        exhausted = true;
+#ifdef PT_WAVE_DETAIL
+                        if (A.wave_end && dbg_exh_iter == 0) dbg_exh_iter = dbg_iters, dbg_last_refill = wall_clock64();
+#endif
+                    }
+                }
+                const uint32_t took = wn < pool_left ? wn : pool_left;
+                pool_st += took - (took << 7);   // head += took, left -= took
+            }
+        } else {
+            // ---- the other kernels: one wave-aggregated atomic for all lanes that need a pixel. The refill code (a global atomic
+            // round trip and four SplitMix64 steps of 64-bit multiplies) runs for the whole wave whenever ANY lane needs
+            // it, so lanes wait until A.refill_min of them do (or nobody has work left): fewer, fuller refills.
+            const bool refill_now = __popcll(want) >= (int)A.refill_min || wave_ballot(have) == 0ull;
+            if (!have && !exhausted && refill_now) {
+                if (finished) write_finished_pixel();
+                const unsigned long long m = wave_ballot(1);
+                const int leader = __ffsll((long long)m) - 1;
+                uint32_t base = 0;
+                if (A.first_static != 0u && first_claim) {
+                    // (the waves' first 64 items by age class: see the pool's claim above)
+                    const uint32_t wv = wave_id, cls = wv >> 2, idx = blockIdx.x * 4u + (wv & 3u);
+                    base = (cls * gridDim.x * 4u + idx) * 64u;
+                } else {
+                    if (lane == leader) base = atomicAdd(A.work_counter, (uint32_t)__popcll(m));
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader) + A.first_static;
+                }
+                first_claim = false;
+                const uint32_t item = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // lanes of m below this one
+                if (item >= A.n_items) {
+                    exhausted = true;
+#ifdef PT_WAVE_DETAIL
+                    if (A.wave_end && dbg_exh_iter == 0) dbg_exh_iter = dbg_iters, dbg_last_refill = wall_clock64();
+#endif
+                } else {
+                    pix_rays = 0;
+                    bool parked = false;
+                    if (start_item(item, pxy, parked, rng, col)) {
+                        have = true;
+#ifdef PT_WAVE_DETAIL
+                        if (dbg_first_pxy == 0xffffffffu) dbg_first_pxy = pxy;
+#endif
+                        need_cam = true;
+                        sd = start_sd(parked);
                     }
                 }
             }
@@ -343,7 +445,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         uint32_t tail_target = 0;
         bool tail_polled = false;   // (wave-uniform)
         if (TAIL && A.tail_cap != 0u) {
-            tail_dry = tail_dry || wave_any(exhausted);
+            tail_dry = tail_dry || (POOL && PT_POOL_DRY) || wave_any(exhausted);
             tail_polled = tail_dry && PT_COOP_DBG(2u) && ((tail_it & A.tail_period_mask) == 0u || (uint32_t)__popcll(wave_ballot(have)) <= A.tail_live_max);
             if (tail_polled) {
                 tail_rand = tail_rand * 1664525u + 1013904223u;
@@ -405,6 +507,18 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         }
 
         PT_SEC(1);
+#ifdef PT_CULLSTATS
+        {   // development aid: who holds a ray this trip -- debug[96] trips, [97] lanes with a ray, [98] lanes waiting for the batched refill, [99] lanes with no work left
+            const unsigned long long hv = wave_ballot(have), wt = wave_ballot(!have && !exhausted), ex = wave_ballot(!have && exhausted);
+            if (lane == 0) {
+                atomicAdd(&A.debug[96], 1ull);
+                atomicAdd(&A.debug[97], (unsigned long long)__popcll(hv));
+                atomicAdd(&A.debug[98], (unsigned long long)__popcll(wt));
+                atomicAdd(&A.debug[99], (unsigned long long)__popcll(ex));
+                atomicAdd(&A.debug[104 + (__popcll(hv) >> 3)], 1ull);   // histogram of live lanes per trip, in eighths of a wave ([112]: all 64)
+            }
+        }
+#endif
         // ---- hitable.rs:39-65: closest hit (inactive lanes carry a null ray)
         const f3 ro = have ? o : mk3(0.f, 0.f, 0.f);
         const f3 rd = have ? d : mk3(0.f, 0.f, 0.f);
@@ -732,6 +846,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     // scene.rs:118 ray_count: wave reduce, one atomic per wave
     if (lane == 0) atomicAdd(A.ray_count, wave_rays);
 #undef PT_DEPTH
+#undef PT_POOL_LEFT
+#undef PT_POOL_DRY
+#undef PT_POOL_EXACT
 }
 
 }  // namespace ptdev

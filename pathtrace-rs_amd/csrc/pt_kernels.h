@@ -5,9 +5,9 @@
 
 namespace pthostside {
 
-// MFMA list kernels: pt_trace_kernel<false, true, true, VERIFY, PILOT, MOVING, GATE, BLK>; blk in {256, 768, 1024}
-void mfma_list_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *frame, SphereKernel *measure);   // GATE = false (pt_kernels_list.hip)
-void mfma_gate_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *frame, SphereKernel *measure);   // GATE = true  (pt_kernels_gate.hip)
+// MFMA list kernels: pt_trace_kernel<false, true, true, VERIFY, PILOT, MOVING, GATE, BLK>; blk in {256, 768, 1024}; pool: the 1024-thread frame kernel with per-wave pixel pools
+void mfma_list_kernels(bool moving, uint32_t blk, bool verify, bool pool, SphereKernel *frame, SphereKernel *measure);   // GATE = false (pt_kernels_list.hip)
+void mfma_gate_kernels(bool moving, uint32_t blk, bool verify, bool pool, SphereKernel *frame, SphereKernel *measure);   // GATE = true  (pt_kernels_gate.hip)
 // tree kernels pt_trace_kernel<true, TREE4, false, VERIFY, PILOT, MOVING> and the exact-scan kernels (pt_kernels_tree.hip)
 void tree_kernels(bool tree4, bool moving, bool verify, bool grid, SphereKernel *frame, SphereKernel *measure);
 void scan_kernels(bool sph_lds, SphereKernel *frame, SphereKernel *measure);

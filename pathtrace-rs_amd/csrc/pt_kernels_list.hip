@@ -84,20 +84,22 @@ void launch_frame_reset(uint32_t *work_counter, unsigned long long *ray_count, u
     hipLaunchKernelGGL(pt_frame_reset_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, work_counter, ray_count, cost, n_cost, list, tiles_x, tiles_y);
 }
 
-void mfma_list_kernels(bool moving, uint32_t blk, bool verify, SphereKernel *frame, SphereKernel *measure) {
+void mfma_list_kernels(bool moving, uint32_t blk, bool verify, bool pool, SphereKernel *frame, SphereKernel *measure) {
     // [moving][256 frame, 256 measure, verify, 768 frame, 768 measure, 1024 frame, 1024 measure]
-    static const SphereKernel table[2][7] = {
+    static const SphereKernel table[2][8] = {
         {pt_trace_kernel<false, true, true, false, false, false, false>, pt_trace_kernel<false, true, true, false, true, false, false>,
          pt_trace_kernel<false, true, true, true, false, false, false>,
          pt_trace_kernel<false, true, true, false, false, false, false, 768>, pt_trace_kernel<false, true, true, false, true, false, false, 768>,
-         pt_trace_kernel<false, true, true, false, false, false, false, 1024>, pt_trace_kernel<false, true, true, false, true, false, false, 1024>},
+         pt_trace_kernel<false, true, true, false, false, false, false, 1024>, pt_trace_kernel<false, true, true, false, true, false, false, 1024>,
+         pt_trace_kernel<false, true, true, false, false, false, false, 1024, false, true>},
         {pt_trace_kernel<false, true, true, false, false, true, false>, pt_trace_kernel<false, true, true, false, true, true, false>,
          pt_trace_kernel<false, true, true, true, false, true, false>,
          pt_trace_kernel<false, true, true, false, false, true, false, 768>, pt_trace_kernel<false, true, true, false, true, true, false, 768>,
-         pt_trace_kernel<false, true, true, false, false, true, false, 1024>, pt_trace_kernel<false, true, true, false, true, true, false, 1024>}};
+         pt_trace_kernel<false, true, true, false, false, true, false, 1024>, pt_trace_kernel<false, true, true, false, true, true, false, 1024>,
+         pt_trace_kernel<false, true, true, false, false, true, false, 1024, false, true>}};
     const SphereKernel *t = table[moving ? 1 : 0];
     const int w = blk == 1024u ? 5 : (blk == 768u ? 3 : 0);
-    *frame = verify ? t[2] : t[w];
+    *frame = verify ? t[2] : ((blk == 1024u && !pool) ? t[7] : t[w]);   // ([7]: the 1024-thread frame kernel without pixel pools)
     *measure = verify ? nullptr : t[w + 1];
 }
 

@@ -276,8 +276,8 @@ void sphere_kernels_for(const ptsel::KernelChoice &c, SphereKernel *frame, Spher
     case ptsel::Family::Tree4: tree_kernels(true, c.moving, c.verify, c.grid, frame, measure); break;
     case ptsel::Family::TreeBinary: tree_kernels(false, c.moving, c.verify, false, frame, measure); break;
     case ptsel::Family::Mfma:
-        if (c.gate) mfma_gate_kernels(c.moving, c.block, c.verify, frame, measure);
-        else mfma_list_kernels(c.moving, c.block, c.verify, frame, measure);
+        if (c.gate) mfma_gate_kernels(c.moving, c.block, c.verify, c.pool_slots != 0u, frame, measure);
+        else mfma_list_kernels(c.moving, c.block, c.verify, c.pool_slots != 0u, frame, measure);
         break;
     case ptsel::Family::ScanLds: scan_kernels(true, frame, measure); break;
     default: scan_kernels(false, frame, measure); break;
@@ -289,7 +289,7 @@ const char *kernel_name(const ptsel::KernelChoice &c, char *buf, size_t cap) {
     if (c.family == ptsel::Family::World)
         snprintf(buf, cap, "world<bvh=%d,hit_lds=%d,occ=%u,media=%d%s>", (int)c.ref_bvh, (int)c.world_hit_lds, c.world_occ, (int)c.world_media, c.world_graph ? ",graph" : (c.world_chains ? ",chains" : (c.world_lazy ? ",lazy" : "")));
     else
-        snprintf(buf, cap, "%s<blk=%u%s%s%s>", c.grid ? "grid" : fam[(uint32_t)c.family], c.block, c.moving ? ",moving" : "", c.gate ? ",gate" : "", c.verify ? ",verify" : "");
+        snprintf(buf, cap, "%s<blk=%u%s%s%s>", c.grid ? "grid" : fam[(uint32_t)c.family], c.block, c.moving ? ",moving" : "", c.gate ? ",gate" : "", c.verify ? ",verify" : (c.pool_slots ? ",pool" : ""));
     return buf;
 }
 
@@ -310,7 +310,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
 
     // ---- which kernel, which geometry (pt_select.h) ----
     ptsel::Knobs knobs;
-    knobs.variant = s->variant, knobs.blocks_per_cu = s->blocks_per_cu, knobs.refill = dev_knobs().refill, knobs.world_occ3 = dev_knobs().world_occ3, knobs.world_occ4 = dev_knobs().world_occ4;
+    knobs.variant = s->variant, knobs.blocks_per_cu = s->blocks_per_cu, knobs.refill = dev_knobs().refill, knobs.pool = dev_knobs().pool, knobs.world_occ3 = dev_knobs().world_occ3, knobs.world_occ4 = dev_knobs().world_occ4;
     const uint32_t local_rows = pt_shard_rows(params->height, shard_index, shard_count);
     const auto tree4_regs = [&] {
         return blocks_per_cu_by_registers(reinterpret_cast<const void *>(tree4_kernel_for_registers(s->tr.has_motion)), (uint32_t)kBlock);
@@ -408,6 +408,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.nodes_in_lds = c.nodes_in_lds;
     A.stack_in_lds = c.stack_in_lds;
     A.lds_sphere_bytes = c.sph_bytes;
+    A.pool_slots = c.pool_slots, A.pool_off = c.pool_off;
     A.tile_order = nullptr;
     A.tile_cost = nullptr;
     (void)bvh;
@@ -441,6 +442,12 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         A.tail_period_mask = dev_knobs().coop_period >= 0 ? (uint32_t)dev_knobs().coop_period : 0u;
         A.tail_min_est = dev_knobs().coop_est >= 0 ? (float)dev_knobs().coop_est : 24.0f;
     }
+    // (pixel pools of the wide frame kernels: from eight items per wave before the list's end, claims take what is wanted and no more; measured
+    //  flat between 2 and 12 per wave on config 3, tools/pool_ab.sh)
+    A.pool_tail = dev_knobs().pool_tail >= 0 ? (uint32_t)dev_knobs().pool_tail : grid * (blk / 64u) * 8u;
+    // (pixel pools of the wide frame kernels: from eight items per wave before the list's end, claims take what is wanted and no more; measured
+    //  flat between 2 and 12 per wave on config 3, tools/pool_ab.sh)
+    A.pool_tail = dev_knobs().pool_tail >= 0 ? (uint32_t)dev_knobs().pool_tail : grid * (blk / 64u) * 8u;
     if (c.gstack) {
         if (int rc = ensure_gstack(s, (size_t)grid * params->max_depth * 3ull * blk)) return rc;
         A.gstack = s->d_gstack;
@@ -496,6 +503,16 @@ void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, h
             for (int i = 0; i < 18; ++i) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double)c[4 + i] / (double)c[0]);
             fprintf(stderr, "\n  lane histogram:");
             for (int i = 0; i < 18; ++i) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double)c[24 + i] / (double)(c[2] ? c[2] : 1));
+            fprintf(stderr, "\n");
+        }
+        unsigned long long l[24];
+        (void)hipMemcpy(l, s->d_debug + 96, sizeof l, hipMemcpyDeviceToHost);
+        (void)hipMemset(s->d_debug + 96, 0, sizeof l);
+        if (l[0]) {
+            const double n = (double)l[0];
+            fprintf(stderr, "[ptgpu lanes] trips %llu: lanes with a ray %.2f, waiting for the batched refill %.2f, out of work %.2f; tile-quarters asked per trip %.2f (of 4 x tiles), tile-halves %.2f\n  live lanes per trip (eighths):",
+                    l[0], l[1] / n, l[2] / n, l[3] / n, l[4] / n, l[5] / n);
+            for (int i = 0; i < 9; ++i) fprintf(stderr, " %d+:%.1f%%", 8 * i, 100.0 * (double)l[8 + i] / n);
             fprintf(stderr, "\n");
         }
     }

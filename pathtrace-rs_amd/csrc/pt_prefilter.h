@@ -502,6 +502,19 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
 #ifdef PT_CULLSTATS
         // development aid: debug[24] wave-iterations, [25] tiles run, [26] active lanes, [27] tiles the lanes asked for,
         // [28 + min(n, 17)] histogram of tiles run per wave-iteration, [48 + min(n, 17)] of tiles asked for per lane
+        {   // the union per quarter / half of the wave (what v_mfma_f32_16x16x32 tiles with per-16-ray masks could skip): debug[100] / [101]
+            uint32_t v = mine;
+            v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
+            v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
+            v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);
+            v |= (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true);
+            const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), q1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                           q2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), q3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+            if (lane == 0) {
+                atomicAdd(&A.debug[100], (unsigned long long)(__popc(q0) + __popc(q1) + __popc(q2) + __popc(q3)));
+                atomicAdd(&A.debug[101], (unsigned long long)(__popc(q0 | q1) + __popc(q2 | q3)));
+            }
+        }
         if (lane == 0) {
             atomicAdd(&A.debug[24], 1ull);
             atomicAdd(&A.debug[25], (unsigned long long)__popc(rem));

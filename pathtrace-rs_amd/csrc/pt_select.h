@@ -16,6 +16,7 @@ namespace ptsel {
 using namespace ptdev;
 
 constexpr uint32_t kLdsBudget = 160u * 1024u;      // LDS per CU on gfx950
+constexpr uint32_t kPoolSlots = 32u, kPoolSlotsMin = 8u;   // wide kernels: entries of a wave's pixel pool (pt_kernel.h POOL), and the fewest a wide kernel is chosen with
 constexpr uint32_t kTwoLaunchMinSamples = 12u;     // frames of a new view with at least this many samples measure their tiles with their own
                                                    // first sample (random_spheres 1200x800: -11 % at 8 spp, +2 % at 12, +8 % at 16, +5 % at 64)
 constexpr uint32_t kMinOrderedTiles = 256u;        // below this many work tiles the order is not worth its launches
@@ -76,13 +77,14 @@ struct KernelChoice {
     // values the kernels' LDS carve is driven by (copied into KArgs / WArgs)
     uint32_t sph_bytes = 0, n_tiles = 0, stack_in_lds = 0, nodes_in_lds = 0, bvh_stack_entries = 0, cull_off = 0;
     uint32_t refill_min = 4;
+    uint32_t pool_slots = 0, pool_off = 0;   // wide frame kernels: entries of each wave's pixel pool, byte offset of the pools in the LDS carve
     bool grid = false;          // Tree4 family: the traversal structure is the uniform cell grid (pt_grid.h), not the 4-wide tree
     bool coop = false;          // wide list kernels: idle waves finish pixels handed over by busy ones, 64 lanes per ray (pt_coop.h)
 };
 
 struct Knobs {                  // tuning word + the development overrides (-1 / 0: library default)
     uint32_t variant = 0, blocks_per_cu = 0;
-    int refill = -1;
+    int refill = -1, pool = -1;
     bool world_occ3 = false, world_occ4 = false;   // (development knobs: cap the general-world kernel's waves per SIMD)
 };
 
@@ -229,6 +231,18 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     lds += lds_levels * slots * blk * 4u;
     if (wide) lds += (uint32_t)wide_extra(blk);
     c.gstack = !wide && lds_levels < stack_levels;
+    // 1024-thread frame kernels: a pool of ready-to-start pixels per wave (48 bytes an entry; pt_kernel.h POOL) where the LDS left over holds at
+    // least kPoolSlotsMin entries per wave; otherwise (and for the 768-thread kernels, and under kVarNoPool) the kernel that batches its refills.
+    // A power of two, so that a claim is whole rows of one 8x8 work tile: 12, 20 or 43 entries measured 2-4 % SLOWER than 8, 16 or 32.
+    if (blk == 1024u && !c.verify && (v & kVarNoPool) == 0 && k.pool != 0) {
+        const uint32_t waves = blk / 64u, room = kLdsBudget > lds ? (kLdsBudget - lds) / (48u * waves) : 0u;
+        uint32_t slots = std::min<uint32_t>(std::min<uint32_t>(k.pool > 0 ? (uint32_t)k.pool : kPoolSlots, 64u), room);
+        if (k.pool <= 0) while (slots & (slots - 1u)) slots &= slots - 1u;
+        if (slots >= kPoolSlotsMin || (k.pool > 0 && slots > 0u)) {
+            c.pool_slots = slots, c.pool_off = lds;
+            lds += slots * 48u * waves;
+        }
+    }
     c.lds_bytes = lds;
     c.block = blk;
     c.family = bvh ? (tree4 ? Family::Tree4 : Family::TreeBinary) : (mfma ? Family::Mfma : (sph_lds ? Family::ScanLds : Family::ScanHbm));
@@ -239,6 +253,8 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     // refills are batched: 4 waiting lanes for long pixels, 8 when pixels are short (< 32 spp); 16-wave workgroups batch harder
     c.refill_min = p.samples < 32u ? 8u : 4u;
     if (blk == 1024u && p.samples >= 32u) c.refill_min = 12u;
+    // (kernels with pixel pools batch only near the list's end, where 4 measured best)
+    if (c.pool_slots != 0u) c.refill_min = 4u;
     if (k.refill >= 0) c.refill_min = (uint32_t)k.refill;
     // persistent grid: CUs x resident workgroups
     uint32_t bpc = k.blocks_per_cu;

@@ -9,7 +9,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libptgpu.so")
+# PTGPU_BUILD_DIR (development): a build directory other than the shipped _build -- `make -C pathtrace-rs_amd B=_build_dev DEFS=...` puts a
+# complete set (libptgpu.so + libpthost.so + CLI, linked to each other by $ORIGIN) there, so A/B runs never overwrite the product.
+_BUILD = os.environ.get("PTGPU_BUILD_DIR") or "_build"
+LIB_PATH = os.path.join(_BUILD if os.path.isabs(_BUILD) else os.path.join(_HERE, _BUILD), "libptgpu.so")
 
 PT_OK = 0
 PT_ERR_INVALID_ARG = 1
@@ -104,7 +107,7 @@ class PtWorldDesc(C.Structure):
 class PtKernelChoice(C.Structure):
     """pt_kernel_choice: which kernel a frame runs on (include/ptgpu.h)."""
     _fields_ = [(n, C.c_uint32) for n in ("family", "block", "lds_bytes", "blocks_per_cu", "moving", "gate", "verify", "ref_bvh", "ordered",
-                                          "stack_in_lds", "global_stack", "n_tiles", "world_hit_lds", "world_occ", "world_media", "refill_min", "coop", "world_graph", "world_lazy")] + \
+                                          "stack_in_lds", "global_stack", "n_tiles", "world_hit_lds", "world_occ", "world_media", "refill_min", "coop", "world_graph", "world_lazy", "pool_slots")] + \
                [("name", C.c_char * 96)]
 
     def as_dict(self):

@@ -7,7 +7,10 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_build", "libpthost.so")
+# PTGPU_BUILD_DIR (development): a build directory other than the shipped _build -- `make -C pathtrace-rs_amd B=_build_dev DEFS=...` puts a
+# complete set (libptgpu.so + libpthost.so + CLI, linked to each other by $ORIGIN) there, so A/B runs never overwrite the product.
+_BUILD = os.environ.get("PTGPU_BUILD_DIR") or "_build"
+LIB_PATH = os.path.join(_BUILD if os.path.isabs(_BUILD) else os.path.join(_HERE, _BUILD), "libpthost.so")
 
 if __package__:
     from . import ptgpu  # noqa: F401

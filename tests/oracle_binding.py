@@ -53,6 +53,8 @@ def _bind(L):
     L.ora_scene_update_range.argtypes = [vp, u32, u32, u32, u32, u32, vp, u64, u64, C.c_int]
     L.ora_scene_update_pixels.restype = u64
     L.ora_scene_update_pixels.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp, u64, C.c_int]
+    L.ora_scene_update_pixels_counted.restype = u64
+    L.ora_scene_update_pixels_counted.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp, u64, vp, C.c_int]
     for n in ("num_spheres", "num_materials", "num_textures", "num_bvh_nodes", "num_hitables", "num_transforms"):
         f = getattr(L, "ora_scene_" + n)
         f.restype, f.argtypes = u32, [vp]
@@ -180,12 +182,18 @@ class OracleScene:
             pass
 
     # Scene::update
-    def update(self, samples, max_depth=10, frame_num=0, buffer=None, nthreads=0, pix_range=None, pixels=None):
+    def update(self, samples, max_depth=10, frame_num=0, buffer=None, nthreads=0, pix_range=None, pixels=None, pixel_rays=None):
+        """pixel_rays (with pixels): a uint32 array that receives the rays traced for each listed pixel."""
         W, H = self.width, self.height
         if buffer is None:
             buffer = np.zeros((H, W, 3), dtype=np.float32)
         assert buffer.dtype == np.float32 and buffer.flags["C_CONTIGUOUS"] and buffer.size == W * H * 3
-        if pixels is not None:
+        if pixel_rays is not None:
+            px = np.ascontiguousarray(pixels, dtype=np.uint32)
+            assert pixel_rays.dtype == np.uint32 and pixel_rays.flags["C_CONTIGUOUS"] and pixel_rays.size == len(px)
+            rc = self.L.ora_scene_update_pixels_counted(self.h, W, H, samples, max_depth, frame_num, buffer.ctypes.data,
+                                                        px.ctypes.data, len(px), pixel_rays.ctypes.data, nthreads)
+        elif pixels is not None:
             px = np.ascontiguousarray(pixels, dtype=np.uint32)
             rc = self.L.ora_scene_update_pixels(self.h, W, H, samples, max_depth, frame_num, buffer.ctypes.data,
                                                 px.ctypes.data, len(px), nthreads)

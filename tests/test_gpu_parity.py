@@ -80,9 +80,38 @@ def test_scan_variants_agree(ptgpu, oracle):
     osc, a, ra = _gpu_render(ptgpu, oracle, "random_spheres", 96, 64, 4, False, variant=0)
     ref, ref_rays = osc.update(4)
     assert ra == ref_rays and np.array_equal(a, ref)
-    for variant in (2, 4, 5, 6, 32, 1024):
+    for variant in (2, 4, 5, 6, 32, 1024, 1048576):
         _, b, rb = _gpu_render(ptgpu, oracle, "random_spheres", 96, 64, 4, False, variant=variant)
         assert rb == ref_rays and np.array_equal(b, ref), "variant %d: %s" % (variant, _report(ref, b))
+
+
+@pytest.mark.parametrize("preset,W,H,S,bvh,depth", [
+    ("random_spheres", 203, 117, 5, False, 10),   # ragged frame: claims straddle the frame's edge; 32 pool entries per wave
+    ("random_spheres", 203, 117, 20, False, 20),  # two launches (measuring launch + ordered frame kernel), 16 entries
+    ("random_spheres", 333, 250, 12, True, 14),   # BVH world (gates in LDS), 8 entries
+    ("aras", 640, 360, 16, False, 10),
+    ("random", 320, 200, 12, False, 10),          # MovingSphere world
+])
+def test_pixel_pools_change_when_a_pixel_starts_never_its_value(ptgpu, pthost, oracle, preset, W, H, S, bvh, depth):
+    """The 1024-thread frame kernels keep a pool of ready-to-start pixels per wave in LDS (csrc/pt_kernel.h POOL): a freed lane takes the next
+    entry at once instead of waiting for a batched refill. The same frame with the pools (default), with the batched refill of rounds 2-5
+    (development bit 1048576), with and without the cooperative hand-over, measuring every frame, and on the exact scan / general kernel: one
+    set of bits, the oracle's."""
+    ref, ref_rays = oracle.OracleScene(preset, W, H, use_bvh=bvh).update(S, depth)
+    hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=bvh, device=0)
+    sc = hs.device_scene()
+    p = ptgpu.PtParams(W, H, S, depth, 0, 1 if bvh else 0)
+    for variant in (0, 1048576, 65536, 1048576 | 65536, 8192, 128 if preset == "random" else 4):
+        sc.set_tuning(0, variant)
+        out = np.zeros((H, W, 3), np.float32)
+        rays = sc.update(p, hs.camera, 0, out)
+        assert rays == ref_rays and np.array_equal(out, ref), "variant %d: %s" % (variant, _report(ref, out))
+        ch = sc.last_kernel_choice()
+        if variant in (0, 65536, 8192):   # (the pools were really on: the kernel's name says so)
+            assert ch["name"].endswith(",pool>") and ch["pool_slots"] == {10: 32, 20: 16, 14: 8}[depth] // (2 if preset == "random" else 1), ch
+        else:
+            assert ch["pool_slots"] == 0 and "pool" not in ch["name"], ch
+    sc.set_tuning(0, 0)
 
 
 @pytest.mark.parametrize("preset,W,H,S", [("random_spheres", 1200, 800, 2), ("aras", 640, 360, 8)])

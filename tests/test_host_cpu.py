@@ -330,16 +330,16 @@ def _select(ptgpu, pthost, preset, W, H, S, bvh, depth=10, variant=0, shards=1, 
 SELECTION_TABLE = {
     ("small", False): ("scan-lds<blk=256>", 38768, 4, 27),                      # 5 spheres: too few for the prefilter; four workgroups of 38 KB per CU
     ("small", True): ("tree4<blk=256>", 24304, 4, 9),
-    ("aras", False): ("mfma<blk=1024>", 65584, 1, 0),                           # BASELINE config 2
-    ("aras", True): ("mfma<blk=1024,gate>", 67248, 1, 0),
-    ("random_spheres", False): ("mfma<blk=1024>", 130480, 1, 0),                # BASELINE config 3 / 4: the headline kernel
-    ("random_spheres", True): ("mfma<blk=1024,gate>", 148048, 1, 0),
+    ("aras", False): ("mfma<blk=1024,pool>", 90160, 1, 0),                      # BASELINE config 2 (",pool": 32 ready-to-start pixels per wave in LDS, 24 KB)
+    ("aras", True): ("mfma<blk=1024,gate,pool>", 91824, 1, 0),
+    ("random_spheres", False): ("mfma<blk=1024,pool>", 155056, 1, 0),           # BASELINE config 3 / 4: the headline kernel
+    ("random_spheres", True): ("mfma<blk=1024,gate,pool>", 160336, 1, 0),       # (16 entries per wave: what the LDS left over holds)
     ("perlin_spheres", False): ("grid<blk=256>", 38384, 4, 9),                  # BASELINE config 5 as a list world: walks the uniform cell grid (pt_grid.h)
     ("perlin_spheres", True): ("grid<blk=256>", 38384, 4, 9),                   # BASELINE config 5
     ("two_perlin_spheres", False): ("scan-lds<blk=256>", 40560, 4, 24),          # eight of its nine stack levels in LDS, the deepest in HBM: four workgroups fit
     ("two_perlin_spheres", True): ("tree4<blk=256>", 29168, 4, 9),
-    ("random", False): ("mfma<blk=1024,moving>", 146096, 1, 0),                 # Sphere + MovingSphere world on the fast kernels
-    ("random", True): ("mfma<blk=1024,moving,gate>", 163664, 1, 0),
+    ("random", False): ("mfma<blk=1024,moving,pool>", 158384, 1, 0),            # Sphere + MovingSphere world on the fast kernels
+    ("random", True): ("mfma<blk=1024,moving,gate>", 163664, 1, 0),             # (176 bytes of LDS left: no pools, the batched refill)
     ("simple_light", False): ("world<bvh=0,hit_lds=1,occ=3,media=0,lazy>", 49152, 3, 1),   # noise texture: the 3-wave build with (u, v); Noise colours when a lit path ends (4-word stack levels)
     ("simple_light", True): ("world<bvh=1,hit_lds=1,occ=3,media=0,lazy>", 53248, 3, 1),
     ("cornell", False): ("world<bvh=0,hit_lds=1,occ=5,media=0>", 31424, 5, 1),      # five workgroups of 31 KB share a CU (96 VGPRs)
@@ -377,10 +377,13 @@ def test_kernel_selection_follows_the_tuning_word_and_the_frame(ptgpu, pthost):
     assert sel(bvh=True, variant=256)["name"] == "tree4<blk=256>"                                # BVH worlds on the internal tree
     assert sel(bvh=True, variant=256 | 2048)["name"] == "tree-binary<blk=256>"                   # ... the binary one
     assert sel(variant=32)["ordered"] == 0                                                       # natural order
-    assert sel(S=8)["ordered"] == 0 and sel(S=8)["refill_min"] == 8                              # below 12 spp: one launch, natural order
+    assert sel(S=8)["ordered"] == 0 and sel(S=8)["refill_min"] == 4                              # below 12 spp: one launch, natural order
+    assert sel(S=8, variant=1048576)["refill_min"] == 8 and sel(variant=1048576)["refill_min"] == 12   # without pixel pools: batched refills, harder on 16-wave workgroups
+    assert sel()["pool_slots"] == 32 and sel(variant=1048576)["pool_slots"] == 0 and sel(variant=1048576)["name"] == "mfma<blk=1024>" and sel(depth=27)["pool_slots"] == 0
     assert sel(S=12)["ordered"] == 1
     assert sel(W=64, H=48)["ordered"] == 0                                                       # 48 work tiles: not worth two launches
-    assert sel(S=256, shards=8)["name"] == "mfma<blk=1024>" and sel(S=256, shards=8)["ordered"] == 1    # one shard of BASELINE config 4
+    assert sel(S=256, shards=8)["name"] == "mfma<blk=1024,pool>" and sel(S=256, shards=8)["ordered"] == 1    # one shard of BASELINE config 4
+    assert sel(depth=20)["pool_slots"] == 16 and sel(depth=22)["name"] == "mfma<blk=1024,pool>" and sel(depth=22)["pool_slots"] == 8   # deeper palette stacks leave less LDS for the pixel pools ...
     assert sel(depth=26)["name"] == "mfma<blk=1024>" and sel(depth=27)["name"] == "mfma<blk=768>"   # 26 palette levels: 16 waves no longer fit the LDS
     assert sel(depth=40)["name"] == "mfma<blk=768>"
     assert sel(depth=41)["name"] == "mfma<blk=256>" and sel(depth=41)["global_stack"] == 1       # ... nor 12: float stacks in HBM
@@ -390,7 +393,7 @@ def test_kernel_selection_follows_the_tuning_word_and_the_frame(ptgpu, pthost):
     assert lazy["world_lazy"] == 1 and eager["world_lazy"] == 0 and eager["name"] == "world<bvh=0,hit_lds=1,occ=3,media=0>" and eager["lds_bytes"] < lazy["lds_bytes"]
     assert deep["world_lazy"] == 0                                                               # one stack level per bit of a 64-bit word
     assert sel(preset="cornell_smoke")["world_lazy"] == 0                                        # no Noise texture
-    assert sel()["coop"] == 1 and sel(variant=65536)["coop"] == 0 and sel(variant=65536)["name"] == "mfma<blk=1024>"   # no hand-over to idle waves: same kernel
+    assert sel()["coop"] == 1 and sel(variant=65536)["coop"] == 0 and sel(variant=65536)["name"] == "mfma<blk=1024,pool>"   # no hand-over to idle waves: same kernel
     assert sel(depth=40)["coop"] == 1 and sel(depth=41)["coop"] == 0 and sel(variant=8)["coop"] == 0 and sel(variant=2)["coop"] == 0
     # a camera shutter outside the interval the moving spheres are defined on leaves the MOVING kernels (their sweeps do not cover it)
     hs = pthost.HostScene("random", 1200, 800, samples=64, device=None)
@@ -417,7 +420,7 @@ def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
     cam = ptgpu.PtCamera.from_floats(np.zeros(24, np.float32))
     p = ptgpu.PtParams(640, 480, 16, 10, 0, 0)
     names = {n: ptgpu.debug_select(cloud(n), p, cam)["name"] for n in (12, 40, 300, 768, 800, 2500)}
-    assert {n: names[n] for n in (12, 40, 300, 800, 2500)} == {12: "scan-lds<blk=256>", 40: "mfma<blk=1024>", 300: "mfma<blk=1024>",
+    assert {n: names[n] for n in (12, 40, 300, 800, 2500)} == {12: "scan-lds<blk=256>", 40: "mfma<blk=1024,pool>", 300: "mfma<blk=1024,pool>",
                                                                800: "tree4<blk=256>", 2500: "tree4<blk=256>"}, names
     # an even, dense field of 1 024 or more similar spheres (here a jittered 40 x 40 lattice, like BASELINE config 5's 100 x 100): the
     # uniform cell grid of csrc/pt_grid.h; a development switch keeps the tree
@@ -651,7 +654,7 @@ def test_fuzzed_descriptions_are_accepted_or_refused_by_name_and_reach_every_ins
     indices, cycles, NULL arrays, NaN radii, DAG blow-ups; every one must come back PT_OK or PT_ERR_INVALID_ARG / PT_ERR_UNSUPPORTED with a
     message. (tools/sanitize_cpu.sh runs the same program, 10^5 + descriptions, on an ASan + UBSan build of the library's host side:
     profiles/r05_sanitize.txt.) And the accepted ones, between them, select EVERY kernel instantiation the shared object carries
-    (pt_debug_last_kernel_symbols against `nm`): the library's build time and size are its 74 kernels, none may be dead weight."""
+    (pt_debug_last_kernel_symbols against `nm`): the library's build time and size are its 78 kernels, none may be dead weight."""
     exe = str(tmp_path / "fuzz_desc")
     build = os.path.join(ROOT, "pathtrace-rs_amd", "_build")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "fuzz_desc.cpp"), "-o", exe,
@@ -666,5 +669,5 @@ def test_fuzzed_descriptions_are_accepted_or_refused_by_name_and_reach_every_ins
     # (a kernel's host-side handle is `ns::name<...>`, its launch stub `ns::__device_stub__name<...>`: one of each per instantiation)
     carried = set(re.findall(r"\b(_ZN5ptdev15pt_(?:trace|world)_kernelI\S+)", nm))
     stubs = set(re.findall(r"\b_ZN5ptdev30__device_stub__(pt_(?:trace|world)_kernelI\S+)", nm))
-    assert len(carried) == len(stubs) == 74, (len(carried), len(stubs))
+    assert len(carried) == len(stubs) == 78, (len(carried), len(stubs))
     assert reached == carried, "never selected: %s; selected but not carried: %s" % (sorted(carried - reached), sorted(reached - carried))

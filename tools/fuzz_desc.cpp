@@ -357,11 +357,11 @@ int main(int argc, char **argv) {
         if (r.chance(60)) {
             static const uint32_t depths[] = {1, 3, 10, 26, 27, 40, 41, 64, 65, 200}, spps[] = {1, 4, 11, 12, 16, 64, 256};
             static const uint32_t sizes[][2] = {{8, 8}, {64, 48}, {200, 100}, {1200, 100}, {1200, 800}, {2400, 1600}};
-            static const uint32_t bits[] = {1, 2, 4, 8, 32, 64, 128, 256, 1024, 2048, 8192, 65536, 131072, 262144};
+            static const uint32_t bits[] = {1, 2, 4, 8, 32, 64, 128, 256, 1024, 2048, 8192, 65536, 131072, 262144, 524288, 1048576};
             c.params.max_depth = depths[r.below(10)], c.params.samples = spps[r.below(7)];
             const uint32_t sz = r.below(6);
             c.params.width = sizes[sz][0], c.params.height = sizes[sz][1];
-            if (r.chance(40)) c.variant = bits[r.below(14)] | (r.chance(30) ? bits[r.below(14)] : 0u);
+            if (r.chance(40)) c.variant = bits[r.below(16)] | (r.chance(30) ? bits[r.below(16)] : 0u);
             if (r.chance(15)) c.shard_count = 2u + r.below(7);
             if (r.chance(10)) c.blocks = 1u + r.below(5);
         }
