@@ -193,8 +193,9 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
                     const uint32_t k = ks[2 * pr + e];
                     // a sphere the ray is leaving through its surface (every scattered ray's own): its far root (-b + sqrt(disc)) / a lies
                     // below 2.5e-4 when -cc < 5e-4 b, four times under t_min -- the reference rejects both roots (sphere.rs:41,52), whatever the
-                    // last bits of its quotient (for |b| < 100 the two differ by less than 1e-4): not queued
-                    const bool leaving = b[e] > 0.0f && b[e] < 100.0f && -cc[e] < 5.0e-4f * b[e];
+                    // last bits of its quotient: the computed root is off by ~ eps b / a, under 1e-5 while b < 100 a (the bound is relative to a:
+                    // the C ABI takes rays of any direction length, and with a << 1 a bound on b alone would let that error reach t_min): not queued
+                    const bool leaving = b[e] > 0.0f && b[e] < 100.0f * a && -cc[e] < 5.0e-4f * b[e];
                     const bool pos = disc[e] > 0.0f && k < A.n_spheres && !leaving;   // (an empty slot, or the link, is no list index)
                     leafq[qn * BLK + tid] = owner_tag | k;
                     qn += pos ? 1u : 0u;

@@ -32,9 +32,10 @@ __global__ void pt_tile_order_kernel(uint32_t n_work_tiles, uint32_t *tile_cost,
     if (work_counter && threadIdx.x < 16) work_counter[threadIdx.x] = 0u;
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < n_work_tiles; t += blockDim.x) {
-        // (an unmeasured tile's cost is written back for the second pass: its neighbours are measured tiles, which nobody writes)
+        // (an unmeasured tile's cost is written back for the second pass: its neighbours are measured tiles, which nobody writes -- a measured
+        //  tile's own word is left alone, so no thread reads a word another one stores to)
         const uint32_t c = ordered_cost(tile_cost, t, checker_tiles_x, checker_tiles_y);
-        if (checker_tiles_x != 0u) tile_cost[t] = c;
+        if (checker_tiles_x != 0u && (((t / checker_tiles_x) + (t % checker_tiles_x)) & 1u) != 0u) tile_cost[t] = c;
         const uint32_t b = c / cost_scale;
         atomicAdd(&count[b < 63u ? b : 63u], 1u);
     }

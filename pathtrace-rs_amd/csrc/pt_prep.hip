@@ -517,6 +517,14 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
     }
     if (!(best_cost < 1e300)) return false;
     const GridGeom &g = best;
+    // The walk forms cell boundaries, entry points and the grid's corner in f32 AT the grid's coordinates; the registrations are padded by
+    // h / 1000 for that rounding. Far from the origin an ulp outgrows the pad (r = 0.2 spheres around x = 20 000: ulp 2e-3, pad 6e-4): such a
+    // field keeps the tree, whose boxes are padded per ray. (2^-22 |x| = two ulps at |x|; a quarter of the pad is the budget.)
+    {
+        double far = 0.0, h_min = g.h;
+        for (int k = 0; k < 3; ++k) far = std::max(far, std::max(std::fabs(g.gmin[k]), std::fabs(g.gmin[k] + g.n[k] * g.ha[k]))), h_min = std::min(h_min, g.ha[k]);
+        if (far * (1.0 / 4194304.0) > 0.25e-3 * h_min) return false;
+    }
     const size_t cells = (size_t)g.n[0] * g.n[1] * g.n[2];
     std::vector<std::vector<uint32_t>> lists(cells);
     size_t regs = 0;
@@ -933,6 +941,10 @@ int analyze_world(const pt_world_desc *desc, WorldAsSpheres &W) {
             uint32_t n_members;
             memcpy(&n_members, &h.p[0], 4);
             if (members_left) return fail(PT_ERR_INVALID_ARG, "hitable %u: a medium group inside a medium group", i);
+            // (a group's members are asked through the group only, so their materials are never validated -- which holds for a LIST, the
+            //  flattener's own output. A scene graph's Hitable nodes can point at any entry, a member included: the interpreted walk would
+            //  then shade with the member's unchecked material index. Graphs say "a medium around a list" with nodes, never with groups.)
+            if (W.is_graph) return fail(PT_ERR_INVALID_ARG, "hitable %u: PT_HIT_MEDIUM_GROUP entries cannot be combined with scene-graph nodes (n_nodes = %u)", i, desc->n_nodes);
             if (n_members == 0 || (uint64_t)i + n_members > (uint64_t)desc->n_hitables - 1ull)
                 return fail(PT_ERR_INVALID_ARG, "hitable %u: a medium group of %u entries does not fit the list", i, n_members);
             if (h.medium_material < 0 || (uint32_t)h.medium_material >= desc->n_materials || desc->materials[h.medium_material].kind != PT_MAT_ISOTROPIC)

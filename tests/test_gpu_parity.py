@@ -1546,6 +1546,25 @@ def test_cell_grid_walk_equals_the_oracle_from_near_far_and_beyond(ptgpu, oracle
     assert not bad, bad
 
 
+@pytest.mark.parametrize("offset,kernel", [((150.0, -40.0, 90.0), "grid<"), ((-260.0, 3.0, 310.0), "grid<"), ((2.0e3, 0.0, -1.0e3), "tree4<"), ((1.0e4, 5.0e3, 3.0e4), "tree4<"), ((1.0e5, 0.0, 0.0), "tree4<")])
+@pytest.mark.parametrize("bvh", [False, True])
+def test_dense_fields_away_from_the_origin(ptgpu, oracle, offset, kernel, bvh):
+    """The whole scene -- field, mirror, camera -- translated away from the origin (round 5's advisor finding: every grid test sat on it). The walk
+    forms its cell boundaries in f32 at the grid's coordinates, and the registrations are padded by h / 1000 for that rounding: within a few
+    hundred cell sizes of the origin the field keeps its grid and the walk equals the oracle; farther out, where an ulp outgrows the pad, the
+    planner hands the field to the tree (whose boxes are padded per ray) -- which equals the oracle as well."""
+    W, H, S = 96, 64, 3
+    w = _as_dense_field(_far_origin_world(oracle, 61, 1600, W, H, 9.0, 0.3, "enclosing", 1.0e2), 1600, 61)
+    off = np.array(offset, np.float32)
+    w["hitables"][:, 6:9] = (w["hitables"][:, 6:9].view(np.float32) + off).view(np.uint32)
+    cam = np.array(w["camera"], np.float32)
+    cam[0:3] += off          # origin
+    cam[3:6] += off          # lower_left_corner (camera.rs:8-19: both are points)
+    w["camera"] = cam
+    bad = _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, more_variants=(524288,), default_kernel=kernel)
+    assert not bad, bad
+
+
 @pytest.mark.parametrize("seed,scale", [(43, 3.0e2), (43, 3.0e5), (44, 1.0e2), (45, 3.0e3), (46, 3.0e2), (47, 1.0e4)])
 @pytest.mark.parametrize("bvh", [False, True])
 def test_cell_grid_walk_with_moving_spheres(ptgpu, oracle, seed, scale, bvh):

@@ -428,6 +428,13 @@ def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
     lattice = np.concatenate([0.5 * ij[:, :1] + rng.uniform(0, 0.3, (1600, 1)), np.full((1600, 1), 0.2), 0.5 * ij[:, 1:] + rng.uniform(0, 0.3, (1600, 1)), np.full((1600, 1), 0.2)], axis=1).astype(np.float32)
     field = ptgpu.SceneDesc(lattice, np.zeros(1600, np.uint32), [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0)], [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)])
     assert ptgpu.debug_select(field, p, cam)["name"] == "grid<blk=256>" and ptgpu.debug_select(field, p, cam, variant=524288)["name"] == "tree4<blk=256>"
+    # ... and so does the same field far from the origin: the walk forms cell boundaries in f32 at the grid's coordinates, and from a few
+    # hundred cell sizes out an ulp there outgrows the h / 1000 the registrations are padded by (round 5's advisor finding)
+    def shifted(dx):
+        far = lattice.copy()
+        far[:, 0] += np.float32(dx)
+        return ptgpu.debug_select(ptgpu.SceneDesc(far, np.zeros(1600, np.uint32), [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0)], [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)]), p, cam)["name"]
+    assert shifted(100.0) == "grid<blk=256>" and shifted(1.0e3) == "tree4<blk=256>" and shifted(-1.0e5) == "tree4<blk=256>"
     assert names[768].startswith("mfma<")          # 24 tiles: the last size whose fragments fit beside the rest
     # the hand-over's workers keep a lane's spheres in eight register sets: up to 512 spheres
     assert ptgpu.debug_select(cloud(512), p, cam)["coop"] == 1 and ptgpu.debug_select(cloud(513), p, cam)["coop"] == 0
@@ -487,6 +494,20 @@ def test_scene_graph_nestings_the_list_form_cannot_hold_are_interpreted_and_malf
     with pytest.raises(ptgpu.PtError) as e:                  # BVHNode row out of range
         select_bvh([[0, 0, 0, 0], [4, 3, 0, 0], [1, 0, 1, 0]], [1], 2, box)
     assert e.value.code == ptgpu.PT_ERR_INVALID_ARG and "BVHNode row" in str(e.value)
+    # a PT_HIT_MEDIUM_GROUP entry beside scene-graph nodes is refused (round 5's advisor finding): a group's members are reached through
+    # the group only and their materials are not validated, but an interpreted graph's Hitable node may point at a member directly -- here
+    # [group header of one member, a sphere with material 999999, a sphere] under List(Hitable(1), Medium(List(List(Hitable(2))))), which
+    # used to be accepted as world<...,graph> and would have shaded with mats[999999]
+    grp = rec.copy()
+    grp[0, 0], grp[0, 4], grp[0, 6] = 6, 1, 1     # kind = PT_HIT_MEDIUM_GROUP, medium_material = the Isotropic, p[0] = one member (as a u32)
+    grp[0, 5] = dens
+    grp[1, 1] = 999999
+    with pytest.raises(ptgpu.PtError) as e:
+        ptgpu.debug_select(ptgpu.WorldDesc(grp, eye, mats, tex, nodes=np.array([[0, 1, 0, 0], [0, 2, 0, 0], [1, 0, 1, 0], [1, 1, 1, 0], [3, 1, 3, dens], [1, 2, 2, 0]], np.uint32),
+                                           node_children=[1, 2, 0, 4], root_node=5), p, cam)
+    assert e.value.code == ptgpu.PT_ERR_INVALID_ARG and "PT_HIT_MEDIUM_GROUP" in str(e.value) and "scene-graph nodes" in str(e.value), str(e.value)
+    # (the same hitables as a plain list are fine: the member is asked through its group and its material never read)
+    assert ptgpu.debug_select(ptgpu.WorldDesc(grp, eye, mats, tex), p, cam)["name"] == "world<bvh=0,hit_lds=1,occ=3,media=1,chains>"
     # the interpreted walk keeps one frame per nested ray_hit call: 24. List(Instance^k(Medium(List(a, b)))) needs k + 4 -- and flattens to a
     # group while the k Instance levels around the medium fit a chain (15)
     deep = lambda k: ([[0, 0, 0, 0], [0, 1, 0, 0], [1, 0, 2, 0], [3, 1, 2, dens]] + [[2, 0, 3 + i, 0] for i in range(k)] + [[1, 2, 1, 0]], [0, 1, 3 + k], 4 + k)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Development aid: measuring launch over every tile (tuning bit 262144) vs one colour of a checkerboard (default), on the library in _build_dev.
-cp pathtrace-rs_amd/_build/libptgpu.so /tmp/cur.so
-cp pathtrace-rs_amd/_build_dev/libptgpu.so pathtrace-rs_amd/_build/libptgpu.so
+export PTGPU_BUILD_DIR=_build
+export PTGPU_BUILD_DIR=_build_dev
 out=gpurun_out/checker_ab.log
 : > $out
 for rep in 1 2 3; do
@@ -11,5 +11,5 @@ for args in "--steps 20 --warmup 3" "--bvh --steps 10 --warmup 2" "--preset rand
   done
 done; done
 timeout 900 python -m pytest tests -m gpu -x -q -k "full_frames or exact_parity or handover or work_order or progressive or shard" 2>&1 | tail -4 >> $out
-cp /tmp/cur.so pathtrace-rs_amd/_build/libptgpu.so
+export PTGPU_BUILD_DIR=_build
 cat $out

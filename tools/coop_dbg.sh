@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development aid: what each part of the cooperative mode costs when NOTHING is handed over (PTGPU_COOP_DBG: 1 no workers, 2 no probes, 4 no counting)
-cp pathtrace-rs_amd/_build_dev/libptgpu.so pathtrace-rs_amd/_build/libptgpu.so
+export PTGPU_BUILD_DIR=_build_dev
 out=gpurun_out/coop_dbg.log
 : > $out
 export PTGPU_COOP_LIVE=0 PTGPU_COOP_STREAK=100000

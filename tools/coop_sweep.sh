@@ -1,7 +1,7 @@
 #!/bin/bash
 # Development aid: hand-over policy sweep on a -DPT_DEVKNOBS library (make B=_build_dev DEFS=-DPT_DEVKNOBS), copied over the shipped one ON THE BOX.
 # COOP_CFGS: "live:streak:period_mask:min_est" ...
-cp pathtrace-rs_amd/_build_dev/libptgpu.so pathtrace-rs_amd/_build/libptgpu.so
+export PTGPU_BUILD_DIR=_build_dev
 out=gpurun_out/coop_sweep.log
 : > $out
 for args in "--steps 20 --warmup 3" "--width 1200 --height 100 --samples 256 --steps 4 --warmup 1" "--width 1200 --height 200 --samples 256 --steps 4 --warmup 1"; do

@@ -1,5 +1,5 @@
 #!/bin/bash
-cp pathtrace-rs_amd/_build_dev/libptgpu.so pathtrace-rs_amd/_build/libptgpu.so
+export PTGPU_BUILD_DIR=_build_dev
 out=gpurun_out/coop_timeline.log
 : > $out
 for a in "--shards 8" "--shards 4" "--shards 1 --samples 64"; do

@@ -7,9 +7,9 @@ timeout 200 python tools/bq.py --no-extras --preset perlin_spheres --width 1920 
 timeout 200 python tools/bq.py --no-extras --preset smallpt --bvh --steps 4 --warmup 1
 timeout 120 python tools/tree_stats.py 2>&1 | tail -3
 if [ -f pathtrace-rs_amd/_build_dev/libptgpu.so ]; then
-  cp pathtrace-rs_amd/_build/libptgpu.so /tmp/cur.so
-  cp pathtrace-rs_amd/_build_dev/libptgpu.so pathtrace-rs_amd/_build/libptgpu.so
+  export PTGPU_BUILD_DIR=_build
+  export PTGPU_BUILD_DIR=_build_dev
   echo "dev build (nodes = wave rounds, sphere tests = calls, both per RAY: rounds per call = ratio):"
   timeout 120 python tools/tree_stats.py perlin_spheres 960 540 8 1 2>&1 | tail -2
-  cp /tmp/cur.so pathtrace-rs_amd/_build/libptgpu.so
+  export PTGPU_BUILD_DIR=_build
 fi
