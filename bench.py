@@ -40,6 +40,37 @@ def _load(name, rel):
     return mod
 
 
+def cpu_quota_cores():
+    """CPU time this container may use, in cores, and where that was read: cgroup v2 cpu.max / v1 cfs quota, capped by the effective
+    cpuset. (None, reason) when nothing limits it. sched_getaffinity alone says 256 on a box that pays for 8."""
+    def read(path):
+        try:
+            return open(path).read().strip()
+        except OSError:
+            return None
+    quota, src = None, "no cgroup CPU quota found"
+    v2 = read("/sys/fs/cgroup/cpu.max")
+    if v2:
+        q, _, per = v2.partition(" ")
+        if q != "max" and per:
+            quota, src = float(q) / float(per), "/sys/fs/cgroup/cpu.max = " + v2
+        else:
+            src = "/sys/fs/cgroup/cpu.max = " + v2
+    else:
+        q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+        if q and per and int(q) > 0:
+            quota, src = int(q) / int(per), "cpu.cfs_quota_us / cpu.cfs_period_us = %s / %s" % (q, per)
+    cs = read("/sys/fs/cgroup/cpuset.cpus.effective") or read("/sys/fs/cgroup/cpuset/cpuset.effective_cpus")
+    if cs:
+        n = 0
+        for part in cs.split(","):
+            a, _, b = part.partition("-")
+            n += (int(b) - int(a) + 1) if b else 1
+        if n and (quota is None or n < quota):
+            quota, src = float(n), "cpuset.cpus.effective = " + cs
+    return quota, src
+
+
 def cpu_baseline(preset, W, H, S, depth, use_bvh, target_secs=15.0):
     """Time the oracle (C restatement of the reference's rayon/AoS path; kind = "port") on all host
     cores, on a bounded strided pixel sample of the SAME workload. Checker only: never the product."""
@@ -48,6 +79,8 @@ def cpu_baseline(preset, W, H, S, depth, use_bvh, target_secs=15.0):
     import oracle_binding as ob
     L = ob.lib(ob.build_native())
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota, quota_src = cpu_quota_cores()
+    quota_threads = max(1, min(cores, int(-(-quota // 1)))) if quota else None   # min(affinity, ceil(quota))
     sc = ob.OracleScene(preset, W, H, use_bvh=use_bvh, library=L)
     buf = np.zeros((H, W, 3), np.float32)
     total = W * H
@@ -70,6 +103,13 @@ def cpu_baseline(preset, W, H, S, depth, use_bvh, target_secs=15.0):
     _, rays = sc.update(S, depth, 0, buffer=buf, nthreads=cores, pixels=px)
     dt = time.perf_counter() - t0
     value = rays / 1e6 / dt
+    # the same sample with as many threads as the container's CPU quota pays for: when that figure equals the all-threads one, "N cores'
+    # worth" is the box's limit, not the oracle's scaling (offline.rs:27-41 is the timer both mirror)
+    at_quota = None
+    if quota_threads is not None and quota_threads != cores:
+        t0 = time.perf_counter()
+        _, rays_q = sc.update(S, depth, 0, buffer=buf, nthreads=quota_threads, pixels=px)
+        at_quota = rays_q / 1e6 / (time.perf_counter() - t0)
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -82,6 +122,8 @@ def cpu_baseline(preset, W, H, S, depth, use_bvh, target_secs=15.0):
         "value": value, "unit": "Mrays/s", "cores": cores, "kind": "port",
         "cpu_model": model, "nproc": os.cpu_count(), "threads": cores,
         "one_thread": rate1, "speedup_over_one_thread": value / rate1 if rate1 > 0 else None,
+        "cpu_quota_cores": quota, "cpu_quota_source": quota_src, "quota_threads": quota_threads, "value_at_quota_threads": at_quota,
+        "speedup_at_quota_threads": (at_quota / rate1 if (at_quota and rate1 > 0) else None),
         "sample": "%d of %d pixels (every %dth) of %s %dx%d %dspp depth %d, %d rays in %.1fs, "
                   "oracle/ptref.c -O3 -march=native -ffp-contract=off, %d pthreads (one thread alone: %.2f Mrays/s, "
                   "so the %d threads delivered %.1f cores' worth)"
@@ -117,6 +159,7 @@ def committed_counters(preset, W, H, S, use_bvh):
                 if k in prof:
                     per_launch[k] = prof[k]
             per_launch["kernel_avg_ms_rocprof"] = prof.get("kernel_avg_ms")
+            per_launch["build"] = line.get("build")   # pt_version() of the library the counters were taken on (None: a profile from before round 6)
             best = ({k: v / rays for k, v in per_launch.items() if isinstance(v, (int, float))}, per_launch, os.path.basename(f))
             break
         except Exception:
@@ -124,9 +167,10 @@ def committed_counters(preset, W, H, S, use_bvh):
     return best
 
 
-def roofline_block(kernel_name, kms, rays_launch, n_hitables, use_bvh, counters):
+def roofline_block(kernel_name, kms, rays_launch, n_hitables, use_bvh, counters, build=None):
     """Counter-derived fractions of the resources the frame kernel uses. Nothing here is an "effective" figure:
-    SURVEY 8(d)'s scan-equivalent rate is kept apart under `algorithmic_equiv`."""
+    SURVEY 8(d)'s scan-equivalent rate is kept apart under `algorithmic_equiv`. `build`: pt_version() of the library being timed; counters
+    taken on any other build are STALE: the block says so and carries no `frac` (the figures move to *_stale_counters keys)."""
     ksec = kms * 1e-3
     out = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_TLANEOPS, "peak_measured": VALU_PEAK_MEASURED,
            "unit": "T lane-ops/s", "frac": None, "traffic": None, "kernel": kernel_name, "kernel_ms": kms}
@@ -174,6 +218,14 @@ def roofline_block(kernel_name, kms, rays_launch, n_hitables, use_bvh, counters)
         if "SQ_INSTS_SALU" in per_ray:
             out["salu_per_valu"] = per_ray["SQ_INSTS_SALU"] / max(per_ray.get("SQ_INSTS_VALU", 0.0), 1e-30)
         out["counters_from"] = "profiles/" + fname + " (rocprofv3 --pmc passes of this workload, scaled per ray to this launch)"
+        out["counters_build"] = per_launch.get("build")
+        out["stale_counters"] = bool(build) and per_launch.get("build") != build
+        if out["stale_counters"]:
+            for k in ("frac", "frac_of_measured_peak", "frac_of_simple_op_rate", "frac_at_measured_clock", "frac_useful", "achieved", "achieved_useful"):
+                if k in out:
+                    out[k + "_stale_counters"], out[k] = out[k], None
+            out["note_stale"] = ("the committed counters were taken on build %r, this run times %r: the fractions above are withheld (kept under "
+                                 "*_stale_counters for orientation); retake with tools/profile_all.sh" % (per_launch.get("build"), build))
     else:
         out["note_counters"] = "no committed rocprofv3 counters for this workload (profiles/r*_pmc_traffic.json): fractions unavailable"
     # the reference's scan reads 16 B x N spheres per ray (list) -- what the kernel would have to stream if
@@ -594,14 +646,15 @@ def main():
                    "kernel": so.last_kernel_choice()["name"], "hitables": ho.world_desc.n_hitables}
             cnt = committed_counters(preset, bw, bh, bs, bvh)
             if cnt is not None:
-                ent["roofline"] = roofline_block("pt_trace_kernel", sum(kms_o) / nf, float(rays_o), ho.world_desc.n_hitables, bvh, cnt)
+                ent["roofline"] = roofline_block("pt_trace_kernel", sum(kms_o) / nf, float(rays_o), ho.world_desc.n_hitables, bvh, cnt, build=ptgpu.lib().pt_version().decode())
             baseline_configs[name] = ent
             del so, ho, bo
     if rank == 0:
         grid, block, lds = scene.last_launch_info()
         tiles = multi and args.mode == "tiles"
         counters = committed_counters(args.preset, W, H, S, args.bvh)
-        roof = roofline_block("pt_trace_kernel" if not hs.is_world else "pt_world_kernel", kms, float(rays_this_launch), n_spheres, args.bvh, counters)
+        build = ptgpu.lib().pt_version().decode()
+        roof = roofline_block("pt_trace_kernel" if not hs.is_world else "pt_world_kernel", kms, float(rays_this_launch), n_spheres, args.bvh, counters, build=build)
         roof["pass_ms"] = pms
         roof["note_pass"] = "kernel_ms = the frame kernel alone (what rocprofv3 reports; samples 2..S); pass_ms adds the measuring launch (first sample of every other 8x8 tile) and the tile sort that precede it; traffic = the frame kernel's HBM bytes, which include reading back the 48 B per pixel (RNG stream + colour sum) the measuring launch parked"
         is_headline = args.preset == "random_spheres" and (W, H) == (1200, 800) and not args.bvh and ((not multi and S == 64) or (tiles and S == 256))
@@ -611,6 +664,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if tiles else "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
+            "build": build,   # pt_version(): the source hash of the library that was timed (profiles record the same string)
             "config": {"workload": "preset %s (%d hitables) %dx%d %dspp depth %d %s, seed 0, %s"
                                    % (args.preset, n_spheres, W, H, S, depth, "BVH" if args.bvh else "list",
                                       "frame 0" if not multi else ("frame 0 split by rows over %d GPUs (BASELINE config 4)" % N if tiles

@@ -480,7 +480,9 @@ int pt_selftest_probe(int device, uint32_t probe, const float *in, float *out, s
 /* Thread-local message describing the last error returned on this thread. */
 const char *pt_last_error(void);
 
-/* Library / kernel identification string, e.g. "ptgpu 0.1 gfx950". */
+/* Library / kernel identification string: "ptgpu <version> gfx950 src <12 hex digits>[ defs <build defines>]". The hex digits are a hash
+ * of the library's device and host sources as built (csrc, this header, the Makefile and its DEFS): bench.py writes the string into its line
+ * and every committed profile records it, so a number can be tied to the build it was measured on. */
 const char *pt_version(void);
 
 #ifdef __cplusplus

@@ -56,7 +56,15 @@ const DevKnobs &dev_knobs() {
 }  // namespace pthostside
 
 extern "C" const char *pt_last_error(void) { return last_error_message(); }
-extern "C" const char *pt_version(void) { return "ptgpu 0.3 gfx950"; }
+// "ptgpu <version> gfx950 src <hash>[ defs <DEFS>]": the hash covers csrc/*.h, csrc/*.hip, include/ptgpu.h, the Makefile and its DEFS
+// (pathtrace-rs_amd/Makefile SRC_HASH) -- what bench.py and the committed profiles use to tell which build a number belongs to.
+#ifndef PT_SOURCE_HASH
+#define PT_SOURCE_HASH "unknown"
+#endif
+#ifndef PT_BUILD_DEFS
+#define PT_BUILD_DEFS ""
+#endif
+extern "C" const char *pt_version(void) { return sizeof(PT_BUILD_DEFS) > 1 ? "ptgpu 0.4 gfx950 src " PT_SOURCE_HASH " defs " PT_BUILD_DEFS : "ptgpu 0.4 gfx950 src " PT_SOURCE_HASH; }
 
 extern "C" int pt_device_count(int *count_out) {
     if (!count_out) return fail(PT_ERR_INVALID_ARG, "count_out is NULL");

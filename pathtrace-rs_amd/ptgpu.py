@@ -138,6 +138,51 @@ class PtError(RuntimeError):
         self.code = code
 
 
+def hip_runtimes_mapped():
+    """Paths of the libamdhip64 copies mapped into this process (Linux: /proc/self/maps), in the order they appear."""
+    seen = []
+    try:
+        for line in open("/proc/self/maps"):
+            path = line.rsplit(None, 1)[-1] if "/" in line else ""
+            if os.path.basename(path).startswith("libamdhip64") and os.path.realpath(path) not in [os.path.realpath(q) for q in seen]:
+                seen.append(path)
+    except OSError:
+        pass
+    return seen
+
+
+def _hip_runtime_conflict(paths, torch_initialised):
+    """None when the HIP runtimes mapped into the process can work together, else the message to raise. PyTorch's wheel carries its own
+    libamdhip64 and libptgpu.so links the system's: both work in one process only if torch's runtime initialises the GPU FIRST -- the other
+    way round torch later reports "No HIP GPUs are available", far from the cause."""
+    if len(paths) < 2 or torch_initialised:
+        return None
+    return ("two HIP runtimes are mapped into this process (%s) and torch.cuda has not been initialised yet: libptgpu.so would initialise "
+            "the GPU through the system's libamdhip64 first, after which torch's own copy reports \"No HIP GPUs are available\". "
+            "`import torch; torch.cuda.init()` BEFORE the first ptgpu call (bench.py and tests/conftest.py do), or set "
+            "PTGPU_ALLOW_SECOND_HIP=1 if this process never touches torch.cuda." % ", ".join(paths))
+
+
+def check_hip_runtimes():
+    """Raises RuntimeError for the one load order of two HIP runtimes that cannot work (see _hip_runtime_conflict); called by lib()."""
+    import sys
+    if os.environ.get("PTGPU_ALLOW_SECOND_HIP") == "1":
+        return
+    torch = sys.modules.get("torch")
+    if torch is None:
+        return   # (only a process that imported torch has its copy mapped; a torch imported LATER cannot be seen from here)
+    try:
+        initialised = bool(torch.cuda.is_initialized())
+        gpus = int(torch.cuda.device_count())   # (counting devices does not initialise the GPU)
+    except Exception:
+        return
+    if gpus == 0:
+        return   # no GPU in this machine: neither runtime will initialise anything (the CPU test runs)
+    msg = _hip_runtime_conflict(hip_runtimes_mapped(), initialised)
+    if msg:
+        raise RuntimeError(msg)
+
+
 def lib():
     """Load libptgpu.so; raises (never falls back) when it is missing."""
     global _lib
@@ -146,6 +191,7 @@ def lib():
             raise FileNotFoundError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
+        check_hip_runtimes()   # (after the load: the system's libamdhip64 is mapped now, nothing has touched the GPU through it yet)
         vp = C.c_void_p
         L.pt_device_count.argtypes = [C.POINTER(C.c_int)]
         L.pt_scene_create.argtypes = [C.POINTER(PtSceneDesc), C.c_int, C.POINTER(vp)]

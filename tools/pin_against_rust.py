@@ -63,7 +63,7 @@ def png_rgb8(path):
 
 
 def main():
-    ap = argparse.ArgumentParser()
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("checkout", help="path of a bitshifter/pathtrace-rs checkout")
     ap.add_argument("--only", default=None, help="run the cases of one preset")
     ap.add_argument("--no-build", action="store_true", help="use target/release/pathtrace-rs as it is")
