@@ -160,9 +160,9 @@ struct KArgs {
     uint4 *px_state;
     uint32_t first_static;       // 0, or the number of items handed out statically as the waves' first fetches (grid x 1024)
     uint32_t refill_min;         // lanes that must be waiting before a wave fetches new pixels (4; 8 below 32 spp)
-    // wide frame kernels: per-wave pool of ready-to-start pixels in LDS (pt_kernel.h POOL): entries per wave (0: batched refill instead), byte
-    // offset of the pools in the dynamic LDS, and how many items before the list's end claims stop filling the pool
-    uint32_t pool_slots, pool_off, pool_tail;
+    // 1024-thread frame kernels: per-wave pool of ready-to-start pixels in LDS (pt_kernel.h POOL): entries per wave, byte offset of the pools in
+    // the dynamic LDS, the fair share (items left per wave of the grid) below which claims stop filling the pool, floor(2^32 / waves of the grid)
+    uint32_t pool_slots, pool_off, pool_tail, pool_waves_magic;
     uint32_t ready_min;          // 4-wide tree: lanes with a finished traversal before the wave leaves the traversal loop to shade
     uint32_t drain_at;           // 4-wide tree: a lane holding more than this many leaf candidates triggers the wave's drain
     uint64_t seed_base;

@@ -40,7 +40,7 @@ enum : uint32_t {
 // Environment knobs, read ONLY by builds made with `make DEFS=-DPT_DEVKNOBS` (pt_api.hip dev_knobs(); the shipped library reads one
 // variable, PTGPU_HOST_BUILD, the hook with which the parity tests compare the two tree builders):
 //   PTGPU_REFILL / PTGPU_PHASE1_REFILL   lanes that must want a pixel before the wave refills (frame / measuring launch)
-//   PTGPU_POOL / PTGPU_POOL_TAIL         wide list kernels: entries of a wave's pixel pool (0: off) / items before the list's end from which claims stop filling it
+//   PTGPU_POOL / PTGPU_POOL_TAIL         wide list kernels: entries of a wave's pixel pool (0: off) / fair share of the list (items left per wave) below which claims stop filling it
 //   PTGPU_READY                          4-wide tree: lanes without traversal work before subtrees change hands (kShareMin)
 //   PTGPU_DRAIN                          4-wide tree: queued leaf candidates of one lane that trigger the wave's drain
 //   PTGPU_COOP_LIVE / _STREAK / _PERIOD / _EST / PTGPU_COOP_DBG     hand-over policy of the wide list kernels (pt_coop.h)

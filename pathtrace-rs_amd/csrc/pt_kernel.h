@@ -240,12 +240,19 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     float rtime = 0.f;  // ray.time (only MOVING kernels read it)
     bool first_claim = true;   // (wave-uniform: every lane of a wave takes part in its first fetch)
     // POOL, one wave-uniform word: bits 0-6 the pool's first live entry, 7-13 how many are live, 14-20 items left of the wave's 64 static first
-    // ones, 21 the work list has nothing more for this wave, 22 the list is about to end (claims take what is wanted and no more)
+    // ones, 21 the work list has nothing more for this wave, 22-31 the wave's FAIR SHARE of what the list still held at its last claim
+    // (items left / waves of the grid, capped at 1023): a claim parks at most half of it, so the pools never hold more than half of what is
+    // left -- an item parked here is one an idle lane elsewhere cannot take -- and the claims shrink with the list until they take what is
+    // wanted and no more (a frame of two pixels per lane kept 60 % of its dynamic items parked under a fixed claim size: +5 % frame time)
     uint32_t pool_st = (POOL && A.first_static != 0u) ? (64u << 14) : 0u;
-    if (POOL && A.pool_tail >= A.n_items) pool_st |= 1u << 22;
+    if (POOL) {
+        const uint32_t share0 = __umulhi(A.n_items - A.first_static, A.pool_waves_magic);
+        pool_st |= (share0 < 1023u ? share0 : 1023u) << 22;
+    }
 #define PT_POOL_LEFT ((pool_st >> 7) & 127u)
 #define PT_POOL_DRY ((pool_st >> 21) & 1u)
-#define PT_POOL_EXACT ((pool_st >> 22) & 1u)
+#define PT_POOL_SHARE (pool_st >> 22)
+#define PT_POOL_EXACT (PT_POOL_SHARE < A.pool_tail)
     bool tail_dry = TAIL && A.tail_dry0 != 0u;     // TAIL, wave-uniform: the work list has run dry (from then on pixels may be handed over)
     uint32_t tail_it = 0, tail_streak = 0, tail_rand = (blockIdx.x * (BLK / 64) + wave_id) * 2654435761u + 12345u;   // (wave-uniform)
 #ifdef PT_DEVKNOBS
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             // Wide frame kernels: freed lanes do not wait for a batch. The wave keeps a POOL of ready-to-start pixels in LDS (A.pool_slots entries of
             // 48 bytes per wave: RNG stream, colour sum, coordinates); a lane that finishes takes the next entry in the same trip, and the global
             // round trips of a claim (work counter -> tile order -> parked stream) are paid once per pool_slots pixels, by all lanes together. Near
-            // the list's end (A.pool_tail items before it) claims take what is wanted and no more, batched by A.refill_min like the other kernels'.
+            // the list's end (the wave's fair share of it below A.pool_tail items) claims take what is wanted and no more, batched by A.refill_min like the other kernels'.
             if (want != 0ull) {   // (wave-uniform)
                 if (!have && finished) write_finished_pixel();
                 uint32_t wv_here = wave_id;
@@ -348,13 +355,20 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         base = (cls * gridDim.x * 4u + idx) * 64u + (64u - static_left);
                         pool_st -= n << 14;
                     } else {
-                        if (PT_POOL_EXACT) n = n < wn ? n : wn;   // (a pixel parked here is one an idle lane elsewhere cannot take)
+                        // half the fair share, as a power of two (a claim is then whole rows of one 8x8 work tile), but never less than is wanted now
+                        const uint32_t half = PT_POOL_SHARE >> 1;
+                        const uint32_t fill = (PT_POOL_EXACT || half == 0u) ? 0u : (0x80000000u >> __builtin_clz(half));
+                        const uint32_t want_now = fill > wn ? fill : wn;
+                        n = n < want_now ? n : want_now;
                         uint32_t b = 0;
                         if (lane == 0) b = atomicAdd(A.work_counter, n);
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b) + A.first_static;
                     }
-                    if (base + n + A.pool_tail >= A.n_items) pool_st |= 1u << 22;
                     if (base + n >= A.n_items) pool_st |= 1u << 21;
+                    if (static_left == 0u) {   // what the list holds now, per wave of the grid
+                        const uint32_t share = __umulhi(base + n < A.n_items ? A.n_items - (base + n) : 0u, A.pool_waves_magic);
+                        pool_st = (pool_st & 0x3fffffu) | ((share < 1023u ? share : 1023u) << 22);
+                    }
                     const uint32_t item = base + (uint32_t)lane;
                     uint32_t q = 0;
                     bool parked_q = false;
@@ -849,6 +863,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 #undef PT_POOL_LEFT
 #undef PT_POOL_DRY
 #undef PT_POOL_EXACT
+#undef PT_POOL_SHARE
 }
 
 }  // namespace ptdev

@@ -442,12 +442,14 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
         A.tail_period_mask = dev_knobs().coop_period >= 0 ? (uint32_t)dev_knobs().coop_period : 0u;
         A.tail_min_est = dev_knobs().coop_est >= 0 ? (float)dev_knobs().coop_est : 24.0f;
     }
-    // (pixel pools of the wide frame kernels: from eight items per wave before the list's end, claims take what is wanted and no more; measured
-    //  flat between 2 and 12 per wave on config 3, tools/pool_ab.sh)
-    A.pool_tail = dev_knobs().pool_tail >= 0 ? (uint32_t)dev_knobs().pool_tail : grid * (blk / 64u) * 8u;
-    // (pixel pools of the wide frame kernels: from eight items per wave before the list's end, claims take what is wanted and no more; measured
-    //  flat between 2 and 12 per wave on config 3, tools/pool_ab.sh)
-    A.pool_tail = dev_knobs().pool_tail >= 0 ? (uint32_t)dev_knobs().pool_tail : grid * (blk / 64u) * 8u;
+    // (pixel pools of the 1024-thread frame kernels: a claim parks at most half of the wave's fair share of what the list still holds; below a
+    //  share of 4 items claims take what is wanted and no more -- tools/pool_ab.sh)
+    A.pool_tail = dev_knobs().pool_tail >= 0 ? (uint32_t)dev_knobs().pool_tail : 4u;
+    A.pool_waves_magic = (uint32_t)(0x100000000ull / std::max<uint64_t>(2u, (uint64_t)grid * (blk / 64u)));
+    // (pixel pools of the 1024-thread frame kernels: a claim parks at most half of the wave's fair share of what the list still holds; below a
+    //  share of 4 items claims take what is wanted and no more -- tools/pool_ab.sh)
+    A.pool_tail = dev_knobs().pool_tail >= 0 ? (uint32_t)dev_knobs().pool_tail : 4u;
+    A.pool_waves_magic = (uint32_t)(0x100000000ull / std::max<uint64_t>(2u, (uint64_t)grid * (blk / 64u)));
     if (c.gstack) {
         if (int rc = ensure_gstack(s, (size_t)grid * params->max_depth * 3ull * blk)) return rc;
         A.gstack = s->d_gstack;

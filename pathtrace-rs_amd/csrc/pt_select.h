@@ -234,7 +234,10 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     // 1024-thread frame kernels: a pool of ready-to-start pixels per wave (48 bytes an entry; pt_kernel.h POOL) where the LDS left over holds at
     // least kPoolSlotsMin entries per wave; otherwise (and for the 768-thread kernels, and under kVarNoPool) the kernel that batches its refills.
     // A power of two, so that a claim is whole rows of one 8x8 work tile: 12, 20 or 43 entries measured 2-4 % SLOWER than 8, 16 or 32.
-    if (blk == 1024u && !c.verify && (v & kVarNoPool) == 0 && k.pool != 0) {
+    // ... and only frames with more than two pixels per lane of an MI355X (256 CUs x 1024): below that nearly every pixel is handed out by the
+    // waves' static first claims and the kernel without the pool code is the faster one by 1-2 % (the shards of a multi-GPU frame)
+    const uint64_t frame_items = (uint64_t)work_tiles(p.width, local_rows) * kTilePix;
+    if (blk == 1024u && !c.verify && (v & kVarNoPool) == 0 && k.pool != 0 && (frame_items > 2ull * 256ull * 1024ull || k.pool > 0)) {
         const uint32_t waves = blk / 64u, room = kLdsBudget > lds ? (kLdsBudget - lds) / (48u * waves) : 0u;
         uint32_t slots = std::min<uint32_t>(std::min<uint32_t>(k.pool > 0 ? (uint32_t)k.pool : kPoolSlots, 64u), room);
         if (k.pool <= 0) while (slots & (slots - 1u)) slots &= slots - 1u;
@@ -253,8 +256,7 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     // refills are batched: 4 waiting lanes for long pixels, 8 when pixels are short (< 32 spp); 16-wave workgroups batch harder
     c.refill_min = p.samples < 32u ? 8u : 4u;
     if (blk == 1024u && p.samples >= 32u) c.refill_min = 12u;
-    // (kernels with pixel pools batch only near the list's end, where 4 measured best)
-    if (c.pool_slots != 0u) c.refill_min = 4u;
+    // (kernels with pixel pools batch the same way once the list is nearly empty -- or from the start, when a frame has about a pixel per lane)
     if (k.refill >= 0) c.refill_min = (uint32_t)k.refill;
     // persistent grid: CUs x resident workgroups
     uint32_t bpc = k.blocks_per_cu;

@@ -85,12 +85,12 @@ def test_scan_variants_agree(ptgpu, oracle):
         assert rb == ref_rays and np.array_equal(b, ref), "variant %d: %s" % (variant, _report(ref, b))
 
 
-@pytest.mark.parametrize("preset,W,H,S,bvh,depth", [
-    ("random_spheres", 203, 117, 5, False, 10),   # ragged frame: claims straddle the frame's edge; 32 pool entries per wave
-    ("random_spheres", 203, 117, 20, False, 20),  # two launches (measuring launch + ordered frame kernel), 16 entries
-    ("random_spheres", 333, 250, 12, True, 14),   # BVH world (gates in LDS), 8 entries
-    ("aras", 640, 360, 16, False, 10),
-    ("random", 320, 200, 12, False, 10),          # MovingSphere world
+@pytest.mark.parametrize("preset,W,H,S,bvh,depth", [   # (frames of more than two pixels per lane of the GPU: smaller ones run the kernel without pools)
+    ("random_spheres", 1203, 797, 3, False, 10),   # ragged frame: claims straddle the frame's edge; 32 pool entries per wave; one launch
+    ("random_spheres", 1200, 800, 12, False, 20),  # two launches (measuring launch + ordered frame kernel), 16 entries
+    ("random_spheres", 1100, 900, 4, True, 14),    # BVH world (gates in LDS), 8 entries
+    ("aras", 1280, 720, 16, False, 10),            # BASELINE config 2
+    ("random", 1200, 800, 3, False, 10),           # MovingSphere world
 ])
 def test_pixel_pools_change_when_a_pixel_starts_never_its_value(ptgpu, pthost, oracle, preset, W, H, S, bvh, depth):
     """The 1024-thread frame kernels keep a pool of ready-to-start pixels per wave in LDS (csrc/pt_kernel.h POOL): a freed lane takes the next

@@ -408,12 +408,13 @@ def test_kernel_selection_follows_the_tuning_word_and_the_frame(ptgpu, pthost):
     assert sel(bvh=True, variant=256)["name"] == "tree4<blk=256>"                                # BVH worlds on the internal tree
     assert sel(bvh=True, variant=256 | 2048)["name"] == "tree-binary<blk=256>"                   # ... the binary one
     assert sel(variant=32)["ordered"] == 0                                                       # natural order
-    assert sel(S=8)["ordered"] == 0 and sel(S=8)["refill_min"] == 4                              # below 12 spp: one launch, natural order
-    assert sel(S=8, variant=1048576)["refill_min"] == 8 and sel(variant=1048576)["refill_min"] == 12   # without pixel pools: batched refills, harder on 16-wave workgroups
+    assert sel(S=8)["ordered"] == 0 and sel(S=8)["refill_min"] == 8                              # below 12 spp: one launch, natural order
+    assert sel()["refill_min"] == 12 and sel(variant=1048576)["refill_min"] == 12               # batched refills (with pixel pools: only near the list's end), harder on 16-wave workgroups
     assert sel()["pool_slots"] == 32 and sel(variant=1048576)["pool_slots"] == 0 and sel(variant=1048576)["name"] == "mfma<blk=1024>" and sel(depth=27)["pool_slots"] == 0
     assert sel(S=12)["ordered"] == 1
     assert sel(W=64, H=48)["ordered"] == 0                                                       # 48 work tiles: not worth two launches
-    assert sel(S=256, shards=8)["name"] == "mfma<blk=1024,pool>" and sel(S=256, shards=8)["ordered"] == 1    # one shard of BASELINE config 4
+    assert sel(S=256, shards=8)["name"] == "mfma<blk=1024>" and sel(S=256, shards=8)["ordered"] == 1    # one shard of BASELINE config 4 (under two pixels per lane: no pixel pools)
+    assert sel(S=256, shards=2)["pool_slots"] == 0 and sel(W=1280, H=720, S=16)["pool_slots"] == 32
     assert sel(depth=20)["pool_slots"] == 16 and sel(depth=22)["name"] == "mfma<blk=1024,pool>" and sel(depth=22)["pool_slots"] == 8   # deeper palette stacks leave less LDS for the pixel pools ...
     assert sel(depth=26)["name"] == "mfma<blk=1024>" and sel(depth=27)["name"] == "mfma<blk=768>"   # 26 palette levels: 16 waves no longer fit the LDS
     assert sel(depth=40)["name"] == "mfma<blk=768>"
@@ -451,7 +452,7 @@ def test_kernel_selection_for_world_classes_of_the_fuzzers(ptgpu):
     cam = ptgpu.PtCamera.from_floats(np.zeros(24, np.float32))
     p = ptgpu.PtParams(640, 480, 16, 10, 0, 0)
     names = {n: ptgpu.debug_select(cloud(n), p, cam)["name"] for n in (12, 40, 300, 768, 800, 2500)}
-    assert {n: names[n] for n in (12, 40, 300, 800, 2500)} == {12: "scan-lds<blk=256>", 40: "mfma<blk=1024,pool>", 300: "mfma<blk=1024,pool>",
+    assert {n: names[n] for n in (12, 40, 300, 800, 2500)} == {12: "scan-lds<blk=256>", 40: "mfma<blk=1024>", 300: "mfma<blk=1024>",
                                                                800: "tree4<blk=256>", 2500: "tree4<blk=256>"}, names
     # an even, dense field of 1 024 or more similar spheres (here a jittered 40 x 40 lattice, like BASELINE config 5's 100 x 100): the
     # uniform cell grid of csrc/pt_grid.h; a development switch keeps the tree

@@ -12,7 +12,7 @@ export PTGPU_BUILD_DIR=_build_dev
 for rep in 1 2; do
   echo "batched refill (tuning bit 1048576)"; PTGPU_VARIANT=1048576 run
   for n in 8 16 32; do echo "pool of $n"; PTGPU_POOL=$n run; done
-  for t in 0 8192 32768 65536; do echo "pool of 32, exact claims from $t items before the end"; PTGPU_POOL_TAIL=$t run; done
+  for t in 0 2 4 16 64; do echo "pool of 32, exact claims below a fair share of $t items per wave"; PTGPU_POOL_TAIL=$t run; done
   echo "aras 16 spp: batched / pool"; PTGPU_VARIANT=1048576 run --preset aras --width 1280 --height 720 --samples 16; run --preset aras --width 1280 --height 720 --samples 16
   echo "256 spp: batched / pool"; PTGPU_VARIANT=1048576 run --samples 256 --steps 4; run --samples 256 --steps 4
 done

@@ -40,7 +40,7 @@ def main():
     buf = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
     base = None
     for N in [int(x) for x in args.counts.split(",")]:
-        worst, total_rays, times = 0.0, 0, []
+        worst, total_rays, times, shard_rays = 0.0, 0, [], []
         for r in range(N):
             best = 1e30
             for _ in range(args.reps):
@@ -50,11 +50,15 @@ def main():
                 best = min(best, sc.last_pass_ms())
             times.append(best)
             total_rays += int(rc.item())
+            shard_rays.append(int(rc.item()))
             worst = max(worst, best)
         if base is None:
             base = worst * N
         print("N=%d  slowest shard %.2f ms (shards: %s)  -> %.0f Mrays/s, %.2fx of ideal vs N=%d"
               % (N, worst, " ".join("%.2f" % t for t in times), total_rays / 1e3 / worst, base / N / worst, int(args.counts.split(",")[0])))
+        if N > 1:   # (are the slow shards the ones with more rays? rows dealt y % N give every shard the same rays to within a fraction of a percent)
+            mean = sum(shard_rays) / N
+            print("      rays per shard relative to their mean: %s; time max / min %.3f" % (" ".join("%+.2f%%" % (100.0 * (r / mean - 1.0)) for r in shard_rays), max(times) / min(times)))
 
 
 if __name__ == "__main__":
