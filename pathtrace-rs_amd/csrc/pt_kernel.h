@@ -239,6 +239,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     };
     float rtime = 0.f;  // ray.time (only MOVING kernels read it)
     bool first_claim = true;   // (wave-uniform: every lane of a wave takes part in its first fetch)
+#ifdef PT_CAMSKIP
+    bool cam_skipped = false;   // (wave-uniform)
+#endif
     // POOL, one wave-uniform word: bits 0-6 the pool's first live entry, 7-13 how many are live, 14-20 items left of the wave's 64 static first
     // ones, 21 the work list has nothing more for this wave, 22-31 the wave's FAIR SHARE of what the list still held at its last claim
     // (items left / waves of the grid, capped at 1023): a claim parks at most half of it, so the pools never hold more than half of what is
@@ -482,7 +485,15 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         // both loops become ONE whose trips cost the maximum instead of the sum. Same arithmetic per role: x = 2a - 1 etc.,
         // (x x + y y) + z z with z = 0 in the plane, which is the reference's (x x + y y) + 0.
         const bool cam_role = have && need_cam, met_role = have && pend_metal;
+#ifdef PT_CAMSKIP
+        // (timing experiment, round 5's verdict item 8 -- NOTES.md "camera stage every other trip": when fewer than PT_CAMSKIP lanes need the stage it
+        //  is skipped for ONE trip: those lanes idle through the trip -- they hold no finished ray -- and the stage's ~360 instructions are issued less often)
+        const bool cam_run = (uint32_t)__popcll(wave_ballot(cam_role || met_role)) >= (uint32_t)(PT_CAMSKIP) || cam_skipped;
+        cam_skipped = !cam_run && wave_any(cam_role || met_role);
+        if ((cam_role || met_role) && cam_run) {
+#else
         if (cam_role || met_role) {
+#endif
             const float4 c0 = s_par[4], c1 = s_par[5], c2 = s_par[6], c3 = s_par[7], c4 = s_par[8], c5 = s_par[9], pn2 = s_par[3];
             const f3 cam_origin = mk3(c0.x, c0.y, c0.z), cam_llc = mk3(c0.w, c1.x, c1.y), cam_horizontal = mk3(c1.z, c1.w, c2.x),
                      cam_vertical = mk3(c2.y, c2.z, c2.w), cam_u = mk3(c3.x, c3.y, c3.z), cam_v = mk3(c3.w, c4.x, c4.y);
@@ -534,6 +545,10 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         }
 #endif
         // ---- hitable.rs:39-65: closest hit (inactive lanes carry a null ray)
+#ifdef PT_CAMSKIP
+        const bool sat_out = have && (need_cam || pend_metal);   // (lanes whose camera stage was put off sit this trip out; restored below)
+        have = have && !sat_out;
+#endif
         const f3 ro = have ? o : mk3(0.f, 0.f, 0.f);
         const f3 rd = have ? d : mk3(0.f, 0.f, 0.f);
         const float a = dot3(rd, rd);  // sphere.rs:34
@@ -791,6 +806,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             }
         }
         PT_SEC(3);
+#ifdef PT_CAMSKIP
+        have = have || sat_out;
+#endif
         if (TAIL && tail_polled) {
             // Hand-over (pt_coop.h): the list is dry and the probed wave is an idle worker -- the lane at a sample boundary with the
             // most estimated work left parks its pixel (RNG stream, colour sum, counters: the pixel's whole state between two samples)

@@ -1,15 +1,11 @@
-run() { python bench.py --steps 12 --warmup 3 --no-cpu-baseline --no-extras --no-pipeline "$@" 2>/dev/null | python -c "
+run() { python bench.py --steps 16 --warmup 3 --no-cpu-baseline --no-extras --no-pipeline "$@" 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('   %.1f Mrays/s  %.3f ms/step  kernel %.3f ms  lds %d block %d' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['config']['lds_bytes'], d['config']['block']))"; }
-for rep in 1 2; do
-for b in _build_r5 _build_dev; do
+print('   %.1f Mrays/s  %.3f ms/step  kernel %.3f ms rays %d' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['config']['rays_per_step']))"; }
+for rep in 1 2 3; do
+for b in _build _build_cs4 _build_cs8 _build_cs16; do
 export PTGPU_BUILD_DIR=$b
 echo "$b c3"; run
-echo "$b aras"; run --preset aras --width 1280 --height 720 --samples 16
-done
-done
-for b in _build_r5 _build_dev; do
-export PTGPU_BUILD_DIR=$b
-echo $b; python tools/shard_times.py --counts 2,4,8 --reps 4 2>&1 | grep -v amdgpu.ids
-done
+done; done
+export PTGPU_BUILD_DIR=_build_cs8
+python -m pytest tests -m gpu -x -q -k "full_frames or exact_parity" 2>&1 | tail -2
