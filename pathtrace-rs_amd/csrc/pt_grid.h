@@ -225,7 +225,8 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
     if (COUNT && lane == 0u) atomicAdd(&A.debug[56u + min(dbg_rounds, 31u)], 1ull);
 #endif
     // rays from beyond d_build: the 4-wide tree, whose boxes are padded for the ray at hand (lanes without such a ray help: bvh4_trace shares work)
-    if (__builtin_expect(wave_any(far), 0)) bvh4_trace<MOVING, COUNT, BLK>(A, s_stack, leafq, w_pairs, w_keys, o, d, av, time, far, cnt);
+    // (-DPT_SECTIONS builds: the tree walk's cycles land in the same section slots -- a null `sec` here faulted such builds on config 5)
+    if (__builtin_expect(wave_any(far), 0)) bvh4_trace<MOVING, COUNT, BLK>(A, s_stack, leafq, w_pairs, w_keys, o, d, av, time, far, cnt, sec);
 }
 
 }  // namespace ptdev
