@@ -441,6 +441,13 @@ int pt_scene_traversal_counters(pt_scene *scene, uint64_t out2[2], int reset);
  * reset. Synchronises the device. */
 int pt_scene_coop_counters(pt_scene *scene, uint64_t out2[2], int reset);
 
+/* Rays per 8x8 WORK TILE of the handle's last frame -- the per-pixel summands of scene.rs:118's ray_count added up per tile, which the
+ * kernels count anyway to order the next frame's work (tile t = (t / tiles_x, t % tiles_x), tile row 0 = the frame's bottom rows; a shard's
+ * tiles cover its compact rows). rays_out may be NULL to ask for the sizes. PT_ERR_UNSUPPORTED when the last frame ran as one launch
+ * (fewer than 12 samples, small frames) or under PT_TUNE_MEASURE_EVERY_FRAME: nothing was counted then. Synchronises the device.
+ * Tests compare these counts tile by tile between kernels and with the oracle's full-frame fixture of BASELINE config 5. */
+int pt_scene_debug_tile_rays(pt_scene *scene, uint32_t *rays_out, uint32_t capacity, uint32_t *n_tiles_out, uint32_t *tiles_x_out);
+
 /* Closest-hit QUERIES on explicit rays, asynchronous on `hip_stream` -- the unit of the reference's own #[bench] functions (one
  * `ray_hit` on the centre ray of a preset: bench.rs:8-26, hitable_list.rs:68-75, spheres_soa.rs:464-485, bvh.rs:361-379) and the home of
  * SpheresSoA (collision/spheres_soa.rs:12-392), which only those benches call. Sphere / MovingSphere worlds. Not on the render

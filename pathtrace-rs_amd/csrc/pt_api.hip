@@ -460,6 +460,29 @@ extern "C" int pt_scene_coop_counters(pt_scene *s, uint64_t out2[2], int reset) 
     return PT_OK;
 }
 
+extern "C" int pt_scene_debug_tile_rays(pt_scene *s, uint32_t *rays_out, uint32_t capacity, uint32_t *n_tiles_out, uint32_t *tiles_x_out) {
+    if (!s || !n_tiles_out || !tiles_x_out) return fail(PT_ERR_INVALID_ARG, "NULL argument");
+    const auto &ti = s->tile_rays_info;
+    if (ti.n_tiles == 0 || !ti.frame_counted || !s->d_tile_buf)
+        return fail(PT_ERR_UNSUPPORTED, "the handle's last frame did not count rays per work tile (a frame in one launch, or PT_TUNE_MEASURE_EVERY_FRAME)");
+    *n_tiles_out = ti.n_tiles, *tiles_x_out = ti.tiles_x;
+    if (!rays_out) return PT_OK;
+    if (capacity < ti.n_tiles) return fail(PT_ERR_INVALID_ARG, "capacity %u below the frame's %u work tiles", capacity, ti.n_tiles);
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());
+    // d_tile_buf = [8 scratch words | costs of the measuring launch | order | rays the frame kernel counted]
+    std::vector<uint32_t> cost(ti.n_tiles), counted(ti.n_tiles);
+    HIP_TRY(hipMemcpy(cost.data(), s->d_tile_buf + 8, (size_t)ti.n_tiles * 4u, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(counted.data(), s->d_tile_buf + 8 + 2 * s->d_tile_cap, (size_t)ti.n_tiles * 4u, hipMemcpyDeviceToHost));
+    for (uint32_t t = 0; t < ti.n_tiles; ++t) {
+        const uint32_t ty = t / ti.tiles_x, tx = t - ty * ti.tiles_x;
+        // (a checkerboard's odd tiles start at their first sample in the frame kernel: their cost word holds their neighbours' mean, not rays)
+        const bool first_here = ti.first_sample_in_cost && (!ti.checker || ((tx + ty) & 1u) == 0u);
+        rays_out[t] = counted[t] + (first_here ? cost[t] : 0u);
+    }
+    return PT_OK;
+}
+
 extern "C" int pt_scene_debug_counters(pt_scene *s, uint64_t out4[4], int reset) {
     if (!s || !out4) return fail(PT_ERR_INVALID_ARG, "NULL argument");
     HIP_TRY(hipSetDevice(s->device));

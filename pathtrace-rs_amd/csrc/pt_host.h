@@ -156,6 +156,9 @@ struct pt_scene {
         uint32_t shard_index, shard_count, variant, n_tiles;
     } hint_key{};
     bool hint_valid = false;
+    // what the last frame's launches left in d_tile_buf, for pt_scene_debug_tile_rays: tiles, tiles per row, whether a measuring launch counted the
+    // first sample (of every tile / of the even tiles of a checkerboard) into the cost words, whether the frame kernel counted into the measured words
+    struct { uint32_t n_tiles = 0, tiles_x = 0; bool first_sample_in_cost = false, checker = false, frame_counted = false; } tile_rays_info;
     uint32_t hint_scale = 1;                         // bucket width of the measured costs
     uint64_t seed_base = 0x243f6a8885a308d3ull;
     uint32_t blocks_per_cu = 0, variant = 0;         // pt_scene_set_tuning

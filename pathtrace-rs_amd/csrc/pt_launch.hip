@@ -188,6 +188,9 @@ int order_work(pt_scene *s, Args &A, const pt_params *params, const pt_camera *c
     }
     HIP_TRY(hipGetLastError());
     A.tile_order = order;
+    s->tile_rays_info.n_tiles = n_work_tiles, s->tile_rays_info.tiles_x = A.tiles_x;
+    s->tile_rays_info.first_sample_in_cost = !reuse, s->tile_rays_info.checker = !reuse && checker;
+    s->tile_rays_info.frame_counted = (s->variant & ptsel::kVarMeasureEveryFrame) == 0;
     if ((s->variant & ptsel::kVarMeasureEveryFrame) == 0) {   // this frame measures the tiles for the next one (after the order kernel has read the old values)
         HIP_TRY(hipMemsetAsync(measured, 0, (size_t)n_work_tiles * sizeof(uint32_t), stream));
         A.tile_cost = measured;

@@ -125,7 +125,7 @@ EXPORTS = [
     "pt_last_launch_info", "pt_scene_set_tuning", "pt_last_error", "pt_version", "pt_selftest_probe", "pt_scene_debug_counters", "pt_scene_traversal_counters",
     "pt_last_pass_ms", "pt_comm_unique_id", "pt_comm_create", "pt_comm_create_all", "pt_comm_destroy", "pt_comm_rank", "pt_comm_gather_frame",
     "pt_render_sharded", "pt_shard_pack", "pt_shard_unpack_all", "pt_scene_build_info", "pt_scene_debug_tree", "pt_scene_debug_tree_packed",
-    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_debug_last_kernel_symbols", "pt_debug_cell_grid", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters", "pt_render_sharded_all", "pt_comm_gather_frame_all", "pt_closest_hit",
+    "pt_buffer_register", "pt_buffer_unregister", "pt_last_kernel_choice", "pt_debug_select", "pt_debug_last_kernel_symbols", "pt_debug_cell_grid", "pt_comm_runtime", "pt_last_host_ms", "pt_scene_coop_counters", "pt_scene_debug_tile_rays", "pt_render_sharded_all", "pt_comm_gather_frame_all", "pt_closest_hit",
 ]
 COMM_ID_BYTES = 128
 
@@ -213,6 +213,7 @@ def lib():
         L.pt_scene_debug_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.pt_scene_traversal_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
         L.pt_scene_coop_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
+        L.pt_scene_debug_tile_rays.argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.pt_closest_hit.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_float, C.c_float, vp, vp]
         L.pt_last_pass_ms.argtypes = [vp, C.POINTER(C.c_float)]
         L.pt_comm_unique_id.argtypes = [vp]
@@ -418,6 +419,14 @@ class Scene:
         out = (C.c_uint64 * 2)()
         _check(lib().pt_scene_coop_counters(self._h, out, 1 if reset else 0))
         return dict(pixels=out[0], rays=out[1])
+
+    def tile_rays(self):
+        """pt_scene_debug_tile_rays: rays per 8x8 work tile of the last frame as a (tile rows, tiles per row) uint32 array, row 0 = bottom."""
+        n, tx = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().pt_scene_debug_tile_rays(self._h, None, 0, C.byref(n), C.byref(tx)))
+        out = np.zeros(n.value, np.uint32)
+        _check(lib().pt_scene_debug_tile_rays(self._h, out.ctypes.data, n.value, C.byref(n), C.byref(tx)))
+        return out.reshape(-1, tx.value)
 
     def closest_hit(self, mode, n_rays, d_rays7_ptr, d_hits8_ptr, t_min=0.001, t_max=3.4028234663852886e38, stream=0):
         """pt_closest_hit: the reference's closest-hit query (QUERY_* mode) for n_rays explicit rays on the device."""

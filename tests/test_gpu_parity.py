@@ -115,6 +115,17 @@ def test_pixel_pools_change_when_a_pixel_starts_never_its_value(ptgpu, pthost, o
     sc.set_tuning(0, 0)
 
 
+def test_pixel_pool_soak_slice(ptgpu):
+    """A slice of tools/pool_soak.py: seeded sphere clouds at frames of more than two pixels per lane (ragged edges, one launch and two, 32 / 16 / 8
+    pool entries, progressive frames): the pooled kernel, the batched refill, pools without hand-over and the exact scan render the same floats and
+    the same ray count. (Round 6's soak: seeds 1000..4999, 3 203 worlds on pooled kernels, 0 mismatches.)"""
+    spec = importlib.util.spec_from_file_location("pool_soak", os.path.join(ROOT, "tools", "pool_soak.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pooled, bad = mod.run(7000, 30, verbose=False)
+    assert bad == 0 and pooled >= 15, (pooled, bad)
+
+
 @pytest.mark.parametrize("preset,W,H,S", [("random_spheres", 1200, 800, 2), ("aras", 640, 360, 8)])
 def test_mfma_prefilter_never_drops_a_positive_discriminant(ptgpu, pthost, preset, W, H, S):
     """Verify mode (variant 8): for EVERY ray of the frame, every sphere whose reference discriminant
@@ -391,7 +402,8 @@ def test_golden_fixture(ptgpu, pthost, path, mode):
         bvh = not bvh                    # list and BVH worlds give the same image (closest hit either way)
     hs = pthost.HostScene(preset, W, H, samples=S, use_bvh=bvh, device=0)   # scene built by the C++ host
     out = np.zeros((H, W, 3), np.float32)
-    rays = hs.device_scene().update(ptgpu.PtParams(W, H, S, int(g["depth"]), 0, 1 if bvh else 0), hs.camera, 0, out)
+    sc = hs.device_scene()
+    rays = sc.update(ptgpu.PtParams(W, H, S, int(g["depth"]), 0, 1 if bvh else 0), hs.camera, 0, out)
     got = out.reshape(-1, 3)[g["pixels"]]
     if "perlin" in preset or preset == "simple_light":
         np.testing.assert_allclose(got, g["rgb"], rtol=0, atol=NOISE_ATOL)
@@ -401,6 +413,39 @@ def test_golden_fixture(ptgpu, pthost, path, mode):
         assert rays == int(g["ray_count"])
     if "frame_ray_count" in g.files and mode == "as_recorded":   # the oracle rendered the WHOLE frame for this count (tests/golden/make_c5_fullframe.py: ~19 core-hours for config 5)
         assert rays == int(g["frame_ray_count"]), "frame ray count %d vs the oracle's %d" % (rays, int(g["frame_ray_count"]))
+    if "tile_rays" in g.files:   # ... and kept the rays of every 8x8 tile: the kernel that renders config 5 (the cell grid) against the oracle, tile by tile
+        mine = sc.tile_rays()
+        assert mine.shape == g["tile_rays"].shape and int(mine.sum(dtype=np.uint64)) == rays
+        wrong = np.argwhere(mine != g["tile_rays"])
+        assert len(wrong) == 0, "%d of %d tiles differ in their ray count, first (row %d, column %d): %d vs the oracle's %d" % (
+            len(wrong), mine.size, wrong[0][0], wrong[0][1], mine[tuple(wrong[0])], g["tile_rays"][tuple(wrong[0])])
+
+
+def test_config5_full_frame_cell_grid_equals_the_tree_kernel_tile_by_tile(ptgpu, pthost):
+    """BASELINE config 5 at full size (1920 x 1080 x 128, 10 002 spheres, BVH world) on the kernel that renders it -- the uniform cell grid of
+    csrc/pt_grid.h -- and on the 4-wide tree kernel (development bit 524288): the same ray count in every one of the 32 400 8x8 tiles, the
+    frame's 733 152 639 rays, and EVERY pixel equal bit for bit (both kernels evaluate Texture::Noise with the same wave-balanced sums; only
+    the oracle comparison needs the sinf tolerance, test_golden_fixture). List world as well: a third and fourth render of the same frame."""
+    W, H, S = 1920, 1080, 128
+    frames = {}
+    for bvh in (True, False):
+        hs = pthost.HostScene("perlin_spheres", W, H, samples=S, use_bvh=bvh, device=0)
+        sc = hs.device_scene()
+        for variant in (0, 524288):
+            sc.set_tuning(0, variant)
+            out = np.zeros((H, W, 3), np.float32)
+            rays = sc.update(ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0), hs.camera, 0, out)
+            name = sc.last_kernel_choice()["name"]
+            assert name.startswith("grid<" if variant == 0 else "tree4<"), name
+            frames[(bvh, variant)] = (rays, out, sc.tile_rays())
+    assert frames[(True, 0)][0] == 733152639
+    for bvh in (True, False):   # (a BVH world's ancestor-AABB gates refuse a handful of grazing hits a list world accepts -- bvh.rs:37-62: 8 rays of this frame)
+        ref_rays, ref, ref_tiles = frames[(bvh, 0)]
+        rays, out, tiles = frames[(bvh, 524288)]
+        assert ref_tiles.shape == (135, 240) and int(ref_tiles.sum(dtype=np.uint64)) == ref_rays
+        assert rays == ref_rays and np.array_equal(tiles, ref_tiles), (bvh, rays, ref_rays, int((tiles != ref_tiles).sum()))
+        assert np.array_equal(out, ref), "bvh %r: %s" % (bvh, _report(ref, out))
+    assert 0 < abs(frames[(False, 0)][0] - frames[(True, 0)][0]) < 100
 
 
 # ---- full BASELINE sizes: sampled pixels + size-independent properties ----------------------------

@@ -303,6 +303,35 @@ def test_oracle_reproduces_golden(oracle, path):
     assert np.array_equal(buf.reshape(-1, 3)[g["pixels"]], g["rgb"])
 
 
+def test_config5_full_frame_fixture_is_consistent_and_the_oracle_reproduces_slices_of_it(oracle):
+    """tests/golden/c5_..._fullframe_bvh.npz is the ORACLE's render of BASELINE config 5's whole frame (tests/golden/make_c5_fullframe.py: 1920 x 1080
+    x 128 through the reference's own both-children tree walk, ~19 core-hours): the frame's ray count, the rays of every 8 x 8 tile and every
+    251st pixel's colour. Here: the fixture adds up, and the oracle of THIS checkout reproduces two whole tiles' ray counts and a dozen of the
+    recorded colours bit for bit (a change to oracle/ptref.c that moves config 5 fails here in seconds, not after another 19 core-hours)."""
+    g = np.load(os.path.join(GOLDEN, "c5_perlin_spheres_1920x1080_128spp_fullframe_bvh.npz"))
+    W, H, S, T = int(g["width"]), int(g["height"]), int(g["samples"]), int(g["tile"])
+    assert (W, H, S, T, bool(g["use_bvh"])) == (1920, 1080, 128, 8, True)
+    tiles = g["tile_rays"]
+    assert tiles.shape == (H // T, W // T) and tiles.dtype == np.uint32
+    assert int(tiles.sum(dtype=np.uint64)) == int(g["frame_ray_count"]) == 733152639
+    assert np.array_equal(tiles.sum(axis=1, dtype=np.uint64), g["block_rays"])          # a block of eight rows is a row of tiles
+    assert tiles.min() >= T * T * S and tiles.max() <= T * T * S * 11                    # 1 .. max_depth + 1 rays per sample
+    px = g["pixels"]
+    assert len(px) == (W * H + 250) // 251 and np.array_equal(px, np.arange(0, W * H, 251, dtype=np.uint32)) and g["rgb"].shape == (len(px), 3)
+    sc = oracle.OracleScene("perlin_spheres", W, H, use_bvh=True)
+    # two tiles: a cheap one in the sky and the frame's most expensive one
+    for ty, tx in (np.unravel_index(int(tiles.argmin()), tiles.shape), np.unravel_index(int(tiles.argmax()), tiles.shape)):
+        pix = np.array([(ty * T + dy) * W + tx * T + dx for dy in range(T) for dx in range(T)], np.uint32)
+        per = np.zeros(len(pix), np.uint32)
+        _, rays = sc.update(S, int(g["depth"]), 0, buffer=np.zeros((H, W, 3), np.float32), pixels=pix, pixel_rays=per)
+        assert rays == int(per.sum()) == int(tiles[ty, tx]), (ty, tx, rays, int(tiles[ty, tx]))
+    some = px[:: max(1, len(px) // 12)][:12]
+    buf = np.zeros((H, W, 3), np.float32)
+    sc.update(S, int(g["depth"]), 0, buffer=buf, pixels=some)
+    want = g["rgb"][np.searchsorted(px, some)]
+    assert np.array_equal(buf.reshape(-1, 3)[some], want)
+
+
 # ---- general worlds (SURVEY 8f rank 3): known answers for the other Hitable arms ------------------
 def _hitable_hit(oracle, sc, index, o, d, time=0.0, tmin=0.001, tmax=3.4028234663852886e38, seed=7):
     import ctypes
