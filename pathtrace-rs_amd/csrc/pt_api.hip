@@ -37,6 +37,8 @@ const DevKnobs &dev_knobs() {
         if (const char *e = getenv("PTGPU_COOP_STREAK")) d.coop_streak = atoi(e);
         if (const char *e = getenv("PTGPU_COOP_PERIOD")) d.coop_period = atoi(e);
         if (const char *e = getenv("PTGPU_COOP_EST")) d.coop_est = atoi(e);
+        if (const char *e = getenv("PTGPU_PARK_MAX")) d.park_max = std::max(0, atoi(e));
+        if (const char *e = getenv("PTGPU_PARK_AFTER")) d.park_after = std::max(0, atoi(e));
         if (const char *e = getenv("PTGPU_POOL")) d.pool = std::max(0, atoi(e));
         if (const char *e = getenv("PTGPU_POOL_TAIL")) d.pool_tail = std::max(0, atoi(e));
         if (const char *e = getenv("PTGPU_HOST_THREADS")) d.host_threads = std::max(0, atoi(e));

@@ -163,6 +163,7 @@ struct KArgs {
     // 1024-thread frame kernels: per-wave pool of ready-to-start pixels in LDS (pt_kernel.h POOL): entries per wave, byte offset of the pools in
     // the dynamic LDS, the fair share (items left per wave of the grid) below which claims stop filling the pool, floor(2^32 / waves of the grid)
     uint32_t pool_slots, pool_off, pool_tail, pool_waves_magic;
+    uint32_t grid_park_max, grid_park_after;   // cell-grid kernels: at most this many lanes still walking park their walk (0: never), after this many rounds of a call (pt_grid.h)
     uint32_t ready_min;          // 4-wide tree: lanes with a finished traversal before the wave leaves the traversal loop to shade
     uint32_t drain_at;           // 4-wide tree: a lane holding more than this many leaf candidates triggers the wave's drain
     uint64_t seed_base;
@@ -219,6 +220,9 @@ constexpr int kShareMin = PT_SHARE_MIN;   // 4-wide tree with work sharing: lane
 constexpr int kLeafQ = PT_LEAFQ;   // per-lane candidate slots; drained when a lane holds more than kLeafQ - 4
 constexpr uint32_t kPairLaneShift = 26u;   // pair = owner lane << 26 | leaf slot (node * 4 + slot; the tree has < 65536 nodes)
 __host__ __device__ constexpr uint32_t tree4_queue_bytes(uint32_t blk) { return (uint32_t)kLeafQ * blk * 4u + (blk / 64u) * kWavePairBytes; }
+// cell-grid kernels (pt_grid.h): the last few lanes of a wave still walking PARK their walk (8 words) here and finish it in the wave's next call
+constexpr uint32_t kGridParkMax = 8u, kGridParkWords = 8u;
+__host__ __device__ constexpr uint32_t grid_park_bytes(uint32_t blk) { return (blk / 64u) * kGridParkMax * kGridParkWords * 4u; }
 
 // ---- binary internal tree node (variant bit 2048 / trees beyond the 4-wide format) ----
 struct DWideNode {  // 64 B

@@ -32,6 +32,8 @@ enum : uint32_t {
                                      // first sample in the second launch (measuring launch + order of config 3: 0.30 -> 0.23 ms)
     kVarNoGrid = 524288u,        // tree kernels always walk the 4-wide tree (default: the uniform cell grid of pt_grid.h when the scene has one)
     kVarNoPool = 1048576u,       // wide list frame kernels: no per-wave pool of ready pixels in LDS; freed lanes wait for a batched refill (rounds 2-5)
+    kVarNoPark = 2097152u,       // cell-grid kernels: every call walks all its rays to their end (default: the last few lanes still walking park their walk
+                                 // in LDS and finish it in the wave's next call, pt_grid.h)
     // (4096, 16384 and 32768 were A/B switches of questions settled in rounds 2-3 and are ignored)
 };
 
@@ -41,6 +43,7 @@ enum : uint32_t {
 // variable, PTGPU_HOST_BUILD, the hook with which the parity tests compare the two tree builders):
 //   PTGPU_REFILL / PTGPU_PHASE1_REFILL   lanes that must want a pixel before the wave refills (frame / measuring launch)
 //   PTGPU_POOL / PTGPU_POOL_TAIL         wide list kernels: entries of a wave's pixel pool (0: off) / fair share of the list (items left per wave) below which claims stop filling it
+//   PTGPU_PARK_MAX / PTGPU_PARK_AFTER    cell-grid kernels: lanes still walking that park their walk (0: never) / rounds of a call before they may
 //   PTGPU_READY                          4-wide tree: lanes without traversal work before subtrees change hands (kShareMin)
 //   PTGPU_DRAIN                          4-wide tree: queued leaf candidates of one lane that trigger the wave's drain
 //   PTGPU_COOP_LIVE / _STREAK / _PERIOD / _EST / PTGPU_COOP_DBG     hand-over policy of the wide list kernels (pt_coop.h)

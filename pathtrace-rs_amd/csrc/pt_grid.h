@@ -95,8 +95,8 @@ __device__ __forceinline__ void grid_walk_step(const KArgs &A, GridWalk &w, f3 d
 }
 
 template <bool MOVING, bool COUNT, int BLK>
-__device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, f3 o, f3 d, const DivA &av, float time, bool start, Steal4 &cnt,
-                                           unsigned long long *sec = nullptr) {
+__device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, uint32_t *w_park, unsigned long long &parked,
+                                           f3 o, f3 d, const DivA &av, float time, bool start, Steal4 &cnt, unsigned long long *sec = nullptr) {
     const int tid = threadIdx.x;
     const uint32_t lane = (uint32_t)tid & 63u;
 #ifdef PT_SECTIONS
@@ -112,9 +112,17 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
     // ---- is this ray the grid's? (origin within d_build of every sphere: what the registration was padded for)
     const float gx = o.x - A.grid_centre[0], gy = o.y - A.grid_centre[1], gz = o.z - A.grid_centre[2];
     const float dist = __builtin_sqrtf((gx * gx + gy * gy) + gz * gz) * 1.001f + A.grid_half_diag;
-    const bool far = start && !(dist <= A.grid_d_build);   // (also a NaN origin)
+    // PARKED walks (round 6). The rounds of a call thin out -- 37, 27, 16, 9, 5, 3, 2 ... lanes walking in rounds 0, 1, 2, ... on config 5 -- and a
+    // round costs the wave the same ~160 instructions and one L2 round trip whether 37 lanes walk or one: a third of all rounds ran for the
+    // last four stragglers. When at most A.grid_park_max lanes are still walking (after A.grid_park_after rounds, in a wave that has other
+    // work), they PARK: eight words of walk state go to the wave's LDS slots, the call ends with its drain, the lanes sit out this trip's shading
+    // (pt_kernel.h: `grid_parked`) and RESUME in the next call, whose early rounds run anyway. Nothing about the result changes: a resumed walk
+    // visits the cells it would have visited, its key (w_keys, LDS) and its ray (the lane's registers) are untouched in between.
+    const bool resume = start && ((parked >> lane) & 1ull) != 0ull;
+    const bool fresh = start && !resume;
+    const bool far = fresh && !(dist <= A.grid_d_build);   // (also a NaN origin)
     float limit = kMaxT;
-    if (start && !far) {
+    if (fresh && !far) {
         float best = kMaxT;
         int idx = -1;
         uint32_t rank = 0;
@@ -129,20 +137,80 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
     GridWalk w;
     grid_walk_start(A, w, o, d, rcp, start && !far);
     uint32_t rec = grid_walk_cell(A, w);
+    bool cont = false;   // `rec` continues the cell the lane is already in (its walk has stepped on: such a record is visited whatever the limit says)
+    if (parked != 0ull) {   // (wave-uniform) somebody resumes
+        if (resume) {
+            const uint32_t *q = w_park + kGridParkWords * __builtin_amdgcn_mbcnt_hi((uint32_t)(parked >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)parked, 0u));
+            const uint4 qa = *reinterpret_cast<const uint4 *>(q), qb = *reinterpret_cast<const uint4 *>(q + 4);
+            w.tnx = __uint_as_float(qa.x), w.tny = __uint_as_float(qa.y), w.tnz = __uint_as_float(qa.z), w.tcur = __uint_as_float(qa.w);
+            w.t_out = __uint_as_float(qb.x);
+            w.ix = (int)(qb.y & 1023u), w.iy = (int)((qb.y >> 10) & 1023u), w.iz = (int)((qb.y >> 20) & 1023u);
+            w.alive = (qb.y >> 30) != 0u;
+            cont = (qb.z & kGridLinkBit) != 0u;
+            rec = qb.z & ~kGridLinkBit;
+            // (the drain that ended the last call may have found this ray a hit: the exact limit of its key; an empty key's t field is a NaN pattern: not < kMaxT)
+            limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[lane] >> 32)));
+        }
+        parked = 0ull;
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t n_started = (uint32_t)__popcll(wave_ballot(start));
+    uint32_t rounds_done = 0u;   // (wave-uniform)
     const float ia = __builtin_amdgcn_rcpf(a);
     uint32_t qn = 0;
 #ifdef PT_GRID_ROUNDS
     uint32_t dbg_visits = 0u, dbg_rounds = 0u;
     if (COUNT && lane == 0u) cnt.leaves += 1u;
 #endif
-    bool cont = false;   // `rec` continues the cell the lane is already in (its walk has stepped on: such a record is visited whatever the limit says)
+#ifdef PT_ROUNDCAP   // (timing experiment, WRONG images: walks cut after PT_ROUNDCAP rounds -- what the rounds beyond would be worth if they cost nothing)
+    uint32_t cap_rounds = 0;
+#endif
     for (;;) {
         bool go = cont || (w.alive && w.tcur <= __builtin_fminf(w.t_out, limit));
+#ifdef PT_ROUNDCAP
+        if (cap_rounds++ >= (uint32_t)(PT_ROUNDCAP)) go = false, cont = false, w.alive = false;
+#endif
+        {   // park the last few walkers? First the drain -- every limit becomes exact, a lane whose estimate was too optimistic walks on --, then whoever still has
+            // cells left parks, if the wave's slots hold them all (otherwise the call simply goes on)
+            const uint32_t n_go = (uint32_t)__popcll(wave_ballot(go));
+            if (n_go != 0u && n_go <= A.grid_park_max && rounds_done >= A.grid_park_after && n_started >= 4u * kGridParkMax) {
+                PT_SUBT(5);
+                if (drain_pairs4<MOVING, BLK>(A, A.grid_rec, leafq, w_pairs, w_keys, qn, o, d, av, time, owner_tag)) limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[lane] >> 32)));
+                go = cont || (w.alive && w.tcur <= __builtin_fminf(w.t_out, limit));
+                PT_SUBT(6);
+                const unsigned long long gm = wave_ballot(go);
+                if (gm == 0ull) break;
+                if ((uint32_t)__popcll(gm) <= kGridParkMax) {
+                    if (go) {
+                        uint32_t *q = w_park + kGridParkWords * __builtin_amdgcn_mbcnt_hi((uint32_t)(gm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gm, 0u));
+                        *reinterpret_cast<uint4 *>(q) = make_uint4(__float_as_uint(w.tnx), __float_as_uint(w.tny), __float_as_uint(w.tnz), __float_as_uint(w.tcur));
+                        *reinterpret_cast<uint4 *>(q + 4) = make_uint4(__float_as_uint(w.t_out), ((uint32_t)w.ix & 1023u) | (((uint32_t)w.iy & 1023u) << 10) | (((uint32_t)w.iz & 1023u) << 20) | (w.alive ? 1u << 30 : 0u),   // (a walk that has left the grid holds -1 or n somewhere: masked, and never read again)
+                                                                       rec | (cont ? kGridLinkBit : 0u), 0u);
+                    }
+                    parked = gm;
+                    break;
+                }
+            }
+        }
+        rounds_done += 1u;
         if (!wave_any(go) || wave_any(qn > A.drain_at)) {
             PT_SUBT(5);
             // exact tests of everything queued; the limit becomes the exact one of the lane's key (an empty key's t field is a NaN pattern: not < kMaxT)
+#ifdef PT_GRID_ROUNDS
+            const bool forced = wave_any(go);   // (a full queue forced this drain: lanes were still walking)
+            const uint32_t queued_now = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_sum(qn), 63);
+#endif
             if (drain_pairs4<MOVING, BLK>(A, A.grid_rec, leafq, w_pairs, w_keys, qn, o, d, av, time, owner_tag)) limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[lane] >> 32)));
             go = cont || (w.alive && w.tcur <= __builtin_fminf(w.t_out, limit));
+#ifdef PT_GRID_ROUNDS
+            const unsigned long long dbg_on = wave_ballot(go);
+            if (COUNT && lane == 0u && queued_now != 0u) {   // [92] drains with pairs, [93] of them forced by a full queue, [94] pairs drained, [95] lanes that walk on after a drain
+                atomicAdd(&A.debug[92], 1ull);
+                atomicAdd(&A.debug[93], forced ? 1ull : 0ull);
+                atomicAdd(&A.debug[94], (unsigned long long)queued_now);
+                atomicAdd(&A.debug[95], (unsigned long long)__popcll(dbg_on));
+            }
+#endif
             PT_SUBT(6);
             if (!wave_any(go)) break;
         }
@@ -151,6 +219,12 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
 #endif
 #ifdef PT_GRID_ROUNDS   // development aid: wave-level rounds instead of record visits, calls instead of positive discriminants
         if (COUNT && lane == 0u) cnt.visits += 1u;
+        const unsigned long long dbg_gm = wave_ballot(go);
+        if (COUNT && lane == 0u) {   // lanes walking in round r of a call ([96 + r], r < 15; later rounds in [111]) and how many calls reach it ([112 + r]); drains in [92..95]
+            const uint32_t r = dbg_rounds < 15u ? dbg_rounds : 15u;
+            atomicAdd(&A.debug[96u + r], (unsigned long long)__popcll(dbg_gm));
+            atomicAdd(&A.debug[112u + r], 1ull);
+        }
         dbg_rounds += 1u;
 #endif
         if (go) {

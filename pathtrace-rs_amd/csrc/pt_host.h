@@ -45,6 +45,7 @@ struct DevKnobs {
     bool world_occ4 = false, world_occ3 = false, debug = false, clamp_grid = false, timing = false;
     int host_threads = -1;
     int coop_live = -1, coop_streak = -1, coop_period = -1, coop_est = -1;   // cooperative hand-over policy (pt_coop.h)
+    int park_max = -1, park_after = -1;   // cell-grid kernels: lanes that may park their walk / rounds before they may (pt_grid.h)
     int pool = -1, pool_tail = -1;   // wide list kernels: pixel pool entries per wave / its end-of-list threshold (pt_kernel.h POOL)
     uint32_t variant = 0, blocks_per_cu = 0;
 };

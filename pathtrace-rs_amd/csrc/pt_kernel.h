@@ -107,6 +107,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     uint32_t *w_pairs = reinterpret_cast<uint32_t *>(p + (TREE4 ? kLeafQ : kEntCap) * BLK * 4 + (threadIdx.x >> 6) * kWavePairBytes);
     unsigned long long *w_keys = reinterpret_cast<unsigned long long *>(w_pairs + kPairCap);
     p += BVH ? (TREE4 ? tree4_queue_bytes(BLK) : 0u) : (MFMA ? mfma_queue_bytes(BLK) : scan_queue_bytes(BLK));
+    uint32_t *w_park = reinterpret_cast<uint32_t *>(p) + (threadIdx.x >> 6) * (kGridParkMax * kGridParkWords);   // GRID: this wave's parked walks (pt_grid.h)
+    p += GRID ? grid_park_bytes(BLK) : 0u;
     uint4 *s_afrag = reinterpret_cast<uint4 *>(p);        // MFMA: [n_tiles][2][64] x 16 B
     p += MFMA ? A.n_tiles * 2048u : 0u;
     uint16_t *s_tile_sphere = reinterpret_cast<uint16_t *>(p);
@@ -212,6 +214,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     uint32_t pix_rays = 0;
     BvhTrav trav{0u, 0u, 0, kMaxT, -1, 0u, false};
     Steal4 steal4{0u, 0u};
+    unsigned long long grid_parked = 0ull;   // GRID, wave-uniform: lanes whose walk is parked in w_park (pt_grid.h), to be resumed by the next call
     // per-lane bookkeeping, packed (every register counts: the 4-waves-per-SIMD kernels are compiled for 128 VGPRs):
     //   pxy = pixel column | local row << 16 (launch() keeps width and height below 65536)
     //   sd  = bounce depth (12 bits) | sample number << 12 (launch(): max_depth <= 4095, samples < 2^20)
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         int idx;
         if (TREE4) {
             // (every ray of the wave is finished when this returns: no traversal state is carried into the next trip)
-            if (GRID) grid_trace<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint16_t *>(s_bvh), reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, ro, rd, av, rtime, have, steal4
+            if (GRID) grid_trace<MOVING, VERIFY, BLK>(A, reinterpret_cast<uint16_t *>(s_bvh), reinterpret_cast<uint32_t *>(s_queue), w_pairs, w_keys, w_park, grid_parked, ro, rd, av, rtime, have, steal4
 #ifdef PT_SECTIONS
                                                          , sec_t
 #endif
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                                             );
             trav_new = false;
             idx = -1, t_hit = kMaxT;
-            if (have) {   // (lanes without a ray hold a stale or never-written key)
+            if (have && !(GRID && ((grid_parked >> lane) & 1ull))) {   // (lanes without a ray hold a stale or never-written key; a parked walk has no result yet)
                 const unsigned long long key = w_keys[lane];
                 const uint32_t low = (uint32_t)key;
                 // BVH world: the key carries the leaf's DFS rank; shading reads the rank-ordered copy of the records, so
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
 
         PT_SEC(2);
         // ---- scene.rs:49-71 one level of ray_trace (BVH mode: only lanes whose traversal has finished)
-        const bool shading = have && !(BVH && !TREE4 && trav.active);
+        const bool shading = have && !(BVH && !TREE4 && trav.active) && !(GRID && ((grid_parked >> lane) & 1ull));   // (GRID: a lane whose walk was parked finishes its ray in the next trip)
         wave_rays += (unsigned long long)__popcll(wave_ballot(shading));   // scene.rs:57 `ray_count += 1` for every lane shaded below
         // 4-wide tree kernels: Texture::Noise of the lanes that will scatter off a noise-textured Lambertian, evaluated for the
         // whole wave at once (wave_balanced_turb): the shading below is divergent, and a third of its lanes (sky misses) idle

@@ -402,6 +402,9 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.gamma = s->gamma;
     A.verify = (c.verify ? 1u : 0u) | ((s->variant & ptsel::kVarNoStack) ? 2u : 0u);
     A.debug = s->d_debug;
+    // (cell-grid kernels: the last four lanes of a wave still walking after three rounds park their walk and finish it in the next call -- tools/park_ab.sh)
+    A.grid_park_max = (s->variant & ptsel::kVarNoPark) ? 0u : (dev_knobs().park_max >= 0 ? std::min<uint32_t>((uint32_t)dev_knobs().park_max, kGridParkMax) : 4u);
+    A.grid_park_after = dev_knobs().park_after >= 0 ? (uint32_t)dev_knobs().park_after : 3u;
     A.ready_min = dev_knobs().ready >= 0 ? (uint32_t)dev_knobs().ready : (uint32_t)((tree4) ? kShareMin : kReadyMin);   // (4-wide tree: lanes without work before subtrees change hands)
     A.drain_at = dev_knobs().drain >= 0 ? std::min<uint32_t>((uint32_t)dev_knobs().drain, (uint32_t)(kLeafQ - 4)) : (uint32_t)(kLeafQ - 4);
     A.wnodes = s->d_wnodes;
@@ -534,6 +537,14 @@ void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, h
         for (int i = 0; i < 32; ++i) fprintf(stderr, " %d:%.2f%%", i, 100.0 * (double)c[i] / (nr > 0 ? nr : 1));
         fprintf(stderr, "\n[ptgpu grid] rounds per call:");
         for (int i = 0; i < 32; ++i) fprintf(stderr, " %d:%.2f%%", i, 100.0 * (double)c[32 + i] / (nc > 0 ? nc : 1));
+        fprintf(stderr, "\n");
+        unsigned long long e[48] = {0};
+        (void)hipMemcpy(e + 12, s->d_debug + 92, 36 * sizeof(unsigned long long), hipMemcpyDeviceToHost);   // e[12..15] drains, e[16..31] lanes per round, e[32..47] calls per round
+        (void)hipMemset(s->d_debug + 92, 0, 36 * sizeof(unsigned long long));
+        e[0] = e[12], e[1] = e[13], e[2] = e[14], e[3] = e[15];
+        fprintf(stderr, "[ptgpu grid] calls %.3g; drains with pairs per call %.2f (%.1f %% forced by a full queue), %.1f pairs per drain, %.1f lanes walk on after a drain\n  lanes walking in round r (share of calls that reach it):",
+                nc, (double)e[0] / (nc > 0 ? nc : 1), 100.0 * (double)e[1] / (double)(e[0] ? e[0] : 1), (double)e[2] / (double)(e[0] ? e[0] : 1), (double)e[3] / (double)(e[0] ? e[0] : 1));
+        for (int r = 0; r < 16; ++r) fprintf(stderr, " %d:%.1f(%.0f%%)", r, (double)e[16 + r] / (double)(e[32 + r] ? e[32 + r] : 1), 100.0 * (double)e[32 + r] / (nc > 0 ? nc : 1));
         fprintf(stderr, "\n");
     }
 #endif

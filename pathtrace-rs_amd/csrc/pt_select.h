@@ -184,6 +184,8 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     c.bvh_stack_entries = tree4 ? (3u * (t.depth4 ? t.depth4 - 1u : 0u) + 3u) : (t.bin_depth + 2u);
     if (bvh) lds += c.bvh_stack_entries * (uint32_t)kBlock * (tree4 ? 2u : 4u);
     if (tree4) lds += tree4_queue_bytes((uint32_t)kBlock);
+    const bool grid = tree4 && t.grid_ok && (v & kVarNoGrid) == 0;
+    if (grid) lds += grid_park_bytes((uint32_t)kBlock);
     // binary-tree nodes go to LDS only while FOUR workgroups still fit on the CU (with two levels of attenuation stack each)
     c.nodes_in_lds = (bvh && !tree4 && (v & kVarScanFromHbm) == 0 && lds + t.bin_nodes * 64u + 2u * 3u * (uint32_t)kBlock * 4u <= kLdsBudget / 4u) ? 1u : 0u;
     if (c.nodes_in_lds) lds += t.bin_nodes * 64u;
@@ -250,7 +252,7 @@ inline void select_spheres(const SceneTraits &t, const pt_params &p, float time0
     c.block = blk;
     c.family = bvh ? (tree4 ? Family::Tree4 : Family::TreeBinary) : (mfma ? Family::Mfma : (sph_lds ? Family::ScanLds : Family::ScanHbm));
     c.gate = mfma && ref_bvh;
-    c.grid = tree4 && t.grid_ok && (v & kVarNoGrid) == 0;
+    c.grid = grid;
     // cooperative hand-over: the wide frame kernels; a path's attenuations live one level per lane there (depth <= 64), a lane's spheres in 8 register sets (<= 512 spheres)
     c.coop = wide && !c.verify && p.max_depth <= 64u && t.n_spheres <= 512u && (v & kVarNoCoop) == 0;
     // refills are batched: 4 waiting lanes for long pixels, 8 when pixels are short (< 32 spp); 16-wave workgroups batch harder

@@ -405,7 +405,12 @@ def test_golden_fixture(ptgpu, pthost, path, mode):
     sc = hs.device_scene()
     rays = sc.update(ptgpu.PtParams(W, H, S, int(g["depth"]), 0, 1 if bvh else 0), hs.camera, 0, out)
     got = out.reshape(-1, 3)[g["pixels"]]
-    if "perlin" in preset or preset == "simple_light":
+    if "frame_ray_count" in g.files and mode == "other_world":
+        # config 5's whole frame as a LIST world against the BVH world's fixture: the ancestor-AABB gates of bvh.rs:37-62 refuse a handful of
+        # grazing hits a list accepts (8 rays of the frame's 733 152 639) -- with 8 262 pixels sampled, one of those paths is among them
+        off = (np.abs(got - g["rgb"]) > NOISE_ATOL).any(axis=1)
+        assert off.sum() <= 3 and 0 < abs(rays - int(g["frame_ray_count"])) < 100, (int(off.sum()), rays)
+    elif "perlin" in preset or preset == "simple_light":
         np.testing.assert_allclose(got, g["rgb"], rtol=0, atol=NOISE_ATOL)
     else:
         assert np.array_equal(got, g["rgb"]), _report(g["rgb"], got)
@@ -413,7 +418,7 @@ def test_golden_fixture(ptgpu, pthost, path, mode):
         assert rays == int(g["ray_count"])
     if "frame_ray_count" in g.files and mode == "as_recorded":   # the oracle rendered the WHOLE frame for this count (tests/golden/make_c5_fullframe.py: ~19 core-hours for config 5)
         assert rays == int(g["frame_ray_count"]), "frame ray count %d vs the oracle's %d" % (rays, int(g["frame_ray_count"]))
-    if "tile_rays" in g.files:   # ... and kept the rays of every 8x8 tile: the kernel that renders config 5 (the cell grid) against the oracle, tile by tile
+    if "tile_rays" in g.files and mode == "as_recorded":   # ... and kept the rays of every 8x8 tile: the kernel that renders config 5 (the cell grid) against the oracle, tile by tile
         mine = sc.tile_rays()
         assert mine.shape == g["tile_rays"].shape and int(mine.sum(dtype=np.uint64)) == rays
         wrong = np.argwhere(mine != g["tile_rays"])
