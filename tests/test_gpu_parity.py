@@ -428,7 +428,8 @@ def test_golden_fixture(ptgpu, pthost, path, mode):
 
 def test_config5_full_frame_cell_grid_equals_the_tree_kernel_tile_by_tile(ptgpu, pthost):
     """BASELINE config 5 at full size (1920 x 1080 x 128, 10 002 spheres, BVH world) on the kernel that renders it -- the uniform cell grid of
-    csrc/pt_grid.h -- and on the 4-wide tree kernel (development bit 524288): the same ray count in every one of the 32 400 8x8 tiles, the
+    csrc/pt_grid.h, whose stragglers park their walks between calls (round 6) --, on the same kernel with every call walked to its end (2097152)
+    and on the 4-wide tree kernel (development bit 524288): the same ray count in every one of the 32 400 8x8 tiles, the
     frame's 733 152 639 rays, and EVERY pixel equal bit for bit (both kernels evaluate Texture::Noise with the same wave-balanced sums; only
     the oracle comparison needs the sinf tolerance, test_golden_fixture). List world as well: a third and fourth render of the same frame."""
     W, H, S = 1920, 1080, 128
@@ -436,20 +437,21 @@ def test_config5_full_frame_cell_grid_equals_the_tree_kernel_tile_by_tile(ptgpu,
     for bvh in (True, False):
         hs = pthost.HostScene("perlin_spheres", W, H, samples=S, use_bvh=bvh, device=0)
         sc = hs.device_scene()
-        for variant in (0, 524288):
+        for variant in (0, 524288, 2097152):   # the grid walk with parked walks (default), the tree, the grid walk with every call walked to its end
             sc.set_tuning(0, variant)
             out = np.zeros((H, W, 3), np.float32)
             rays = sc.update(ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0), hs.camera, 0, out)
             name = sc.last_kernel_choice()["name"]
-            assert name.startswith("grid<" if variant == 0 else "tree4<"), name
+            assert name.startswith("tree4<" if variant == 524288 else "grid<"), name
             frames[(bvh, variant)] = (rays, out, sc.tile_rays())
     assert frames[(True, 0)][0] == 733152639
     for bvh in (True, False):   # (a BVH world's ancestor-AABB gates refuse a handful of grazing hits a list world accepts -- bvh.rs:37-62: 8 rays of this frame)
         ref_rays, ref, ref_tiles = frames[(bvh, 0)]
-        rays, out, tiles = frames[(bvh, 524288)]
         assert ref_tiles.shape == (135, 240) and int(ref_tiles.sum(dtype=np.uint64)) == ref_rays
-        assert rays == ref_rays and np.array_equal(tiles, ref_tiles), (bvh, rays, ref_rays, int((tiles != ref_tiles).sum()))
-        assert np.array_equal(out, ref), "bvh %r: %s" % (bvh, _report(ref, out))
+        for variant in (524288, 2097152):
+            rays, out, tiles = frames[(bvh, variant)]
+            assert rays == ref_rays and np.array_equal(tiles, ref_tiles), (bvh, variant, rays, ref_rays, int((tiles != ref_tiles).sum()))
+            assert np.array_equal(out, ref), "bvh %r variant %d: %s" % (bvh, variant, _report(ref, out))
     assert 0 < abs(frames[(False, 0)][0] - frames[(True, 0)][0]) < 100
 
 
@@ -1593,7 +1595,7 @@ def test_cell_grid_walk_equals_the_oracle_from_near_far_and_beyond(ptgpu, oracle
     ORACLE bit for bit, list and BVH semantics."""
     W, H, S = 112, 80, 3
     w = _as_dense_field(_far_origin_world(oracle, 57, 1600, W, H, 9.0, 0.3, kind, scale), 1600, 57)
-    bad = _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, depth=25 if kind == "offcentre" else 10, more_variants=(524288, 8 | 256), default_kernel="grid<")
+    bad = _check_all_list_paths_against_the_oracle(ptgpu, oracle, w, W, H, S, bvh, depth=25 if kind == "offcentre" else 10, more_variants=(524288, 8 | 256, 2097152), default_kernel="grid<")   # (2097152: no parked walks)
     assert not bad, bad
 
 
