@@ -173,7 +173,7 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
         {   // park the last few walkers? First the drain -- every limit becomes exact, a lane whose estimate was too optimistic walks on --, then whoever still has
             // cells left parks, if the wave's slots hold them all (otherwise the call simply goes on)
             const uint32_t n_go = (uint32_t)__popcll(wave_ballot(go));
-            if (n_go != 0u && n_go <= A.grid_park_max && rounds_done >= A.grid_park_after && n_started >= 4u * kGridParkMax) {
+            if (n_go != 0u && n_go <= A.grid_park_max && rounds_done >= A.grid_park_after && n_started >= 32u) {
                 PT_SUBT(5);
                 if (drain_pairs4<MOVING, BLK>(A, A.grid_rec, leafq, w_pairs, w_keys, qn, o, d, av, time, owner_tag)) limit = trav4_limit(__uint_as_float((uint32_t)(w_keys[lane] >> 32)));
                 go = cont || (w.alive && w.tcur <= __builtin_fminf(w.t_out, limit));

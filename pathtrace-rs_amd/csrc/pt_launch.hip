@@ -402,9 +402,10 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     A.gamma = s->gamma;
     A.verify = (c.verify ? 1u : 0u) | ((s->variant & ptsel::kVarNoStack) ? 2u : 0u);
     A.debug = s->d_debug;
-    // (cell-grid kernels: the last four lanes of a wave still walking after three rounds park their walk and finish it in the next call -- tools/park_ab.sh)
-    A.grid_park_max = (s->variant & ptsel::kVarNoPark) ? 0u : (dev_knobs().park_max >= 0 ? std::min<uint32_t>((uint32_t)dev_knobs().park_max, kGridParkMax) : 4u);
-    A.grid_park_after = dev_knobs().park_after >= 0 ? (uint32_t)dev_knobs().park_after : 3u;
+    // (cell-grid kernels: the last six lanes of a wave still walking after two rounds park their walk and finish it in the next call. tools/park_ab.sh,
+    //  config 5 kernel time: off 59.6 ms; 3 / 4 / 5 / 6 / 8 / 12 / 16 lanes 55.9 / 55.5 / 55.4 / 55.2 / 55.4 / 55.9 / 56.7; after 1 / 2 / 3 rounds within 0.3 ms)
+    A.grid_park_max = (s->variant & ptsel::kVarNoPark) ? 0u : (dev_knobs().park_max >= 0 ? std::min<uint32_t>((uint32_t)dev_knobs().park_max, kGridParkMax) : 6u);
+    A.grid_park_after = dev_knobs().park_after >= 0 ? (uint32_t)dev_knobs().park_after : 2u;
     A.ready_min = dev_knobs().ready >= 0 ? (uint32_t)dev_knobs().ready : (uint32_t)((tree4) ? kShareMin : kReadyMin);   // (4-wide tree: lanes without work before subtrees change hands)
     A.drain_at = dev_knobs().drain >= 0 ? std::min<uint32_t>((uint32_t)dev_knobs().drain, (uint32_t)(kLeafQ - 4)) : (uint32_t)(kLeafQ - 4);
     A.wnodes = s->d_wnodes;

@@ -365,8 +365,8 @@ SELECTION_TABLE = {
     ("aras", True): ("mfma<blk=1024,gate,pool>", 91824, 1, 0),
     ("random_spheres", False): ("mfma<blk=1024,pool>", 155056, 1, 0),           # BASELINE config 3 / 4: the headline kernel
     ("random_spheres", True): ("mfma<blk=1024,gate,pool>", 160336, 1, 0),       # (16 entries per wave: what the LDS left over holds)
-    ("perlin_spheres", False): ("grid<blk=256>", 38384, 4, 9),                  # BASELINE config 5 as a list world: walks the uniform cell grid (pt_grid.h)
-    ("perlin_spheres", True): ("grid<blk=256>", 38384, 4, 9),                   # BASELINE config 5
+    ("perlin_spheres", False): ("grid<blk=256>", 39408, 4, 9),                  # BASELINE config 5 as a list world: walks the uniform cell grid (pt_grid.h; 1 KB of it: the slots of parked walks)
+    ("perlin_spheres", True): ("grid<blk=256>", 39408, 4, 9),                   # BASELINE config 5
     ("two_perlin_spheres", False): ("scan-lds<blk=256>", 40560, 4, 24),          # eight of its nine stack levels in LDS, the deepest in HBM: four workgroups fit
     ("two_perlin_spheres", True): ("tree4<blk=256>", 29168, 4, 9),
     ("random", False): ("mfma<blk=1024,moving,pool>", 158384, 1, 0),            # Sphere + MovingSphere world on the fast kernels

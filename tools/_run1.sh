@@ -1,17 +1,4 @@
-export PTGPU_BUILD_DIR=_build_dev
-for env in "PTGPU_PARK_MAX=0" "PTGPU_PARK_MAX=4" "PTGPU_PARK_MAX=4 PTGPU_PARK_AFTER=100"; do
-echo "== $env"
-env $env timeout 60 python - <<PY 2>&1 | tail -4
-import sys, importlib.util, numpy as np
-sys.path.insert(0,'tests')
-from conftest import load_ptgpu
-ptgpu = load_ptgpu()
-spec = importlib.util.spec_from_file_location("pthost", "pathtrace-rs_amd/pthost.py"); pthost = importlib.util.module_from_spec(spec); spec.loader.exec_module(pthost)
-for (W,H,S) in ((96,54,2),(200,120,2),(320,200,16)):
-    hs = pthost.HostScene("perlin_spheres", W, H, samples=S, use_bvh=True, device=0)
-    sc = hs.device_scene()
-    out = np.zeros((H,W,3), np.float32)
-    rays = sc.update(ptgpu.PtParams(W,H,S,10,0,1), hs.camera, 0, out)
-    print(W,H,S,rays, sc.last_kernel_choice()["name"], sc.last_kernel_choice()["lds_bytes"], flush=True)
-PY
-done
+export PTGPU_BUILD_DIR=_build_sec
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --preset perlin_spheres --bvh --width 1920 --height 1080 --samples 128 2>&1 | grep -v "^{" | tail -1
+export PTGPU_BUILD_DIR=_build_gr
+timeout 120 python tools/tree_stats.py perlin_spheres 960 540 8 1 2>&1 | grep -v binary | tail -5 | cut -c1-900
