@@ -666,25 +666,25 @@ def test_cell_grid_plan_registers_every_sphere_wherever_its_padded_ball_reaches(
 
 
 def test_committed_kernel_resource_table_keeps_registers_and_spills_within_the_stated_bounds():
-    """profiles/r05_kernel_resources.txt (`make -C pathtrace-rs_amd resources`: hipcc -Rpass-analysis=kernel-resource-usage on the
-    four kernel translation units) is the evidence behind DESIGN.md's register claims: every one of the 49 pt_trace_kernel and 25
-    pt_world_kernel instantiations is listed; none uses scratch or spills a VGPR EXCEPT the four 1024-thread frame kernels that carry
-    the cooperative worker (csrc/pt_coop.h: it saves its sphere registers around a handed-over pixel: <= 160 B, <= 24 VGPRs) and the
+    """profiles/r06_kernel_resources.txt (`make -C pathtrace-rs_amd resources`: hipcc -Rpass-analysis=kernel-resource-usage on the
+    four kernel translation units) is the evidence behind DESIGN.md's register claims: every one of the 53 pt_trace_kernel and 25
+    pt_world_kernel instantiations is listed; none uses scratch or spills a VGPR EXCEPT the eight 1024-thread frame kernels (with and without
+    pixel pools) that carry the cooperative worker (csrc/pt_coop.h: it saves its sphere registers around a handed-over pixel: <= 160 B, <= 24 VGPRs) and the
     general-world kernel that INTERPRETS a scene graph (csrc/pt_graph.h: the walk is an out-of-line call, <= 128 B of call frame) and its
     four instantiations for five waves per SIMD (96 VGPRs, <= 16 spilled), and the MOVING flavours of the cell-grid kernels (csrc/pt_grid.h:
-    128 VGPRs, <= 4 spilled), and
+    128 VGPRs, <= 8 spilled), and
     all 1024-thread prefilter kernels (one workgroup per CU, four waves per SIMD) stay within the 128 registers that occupancy allows."""
-    rows = [l for l in open(os.path.join(ROOT, "profiles", "r05_kernel_resources.txt")).read().splitlines()[1:] if l.strip()]
+    rows = [l for l in open(os.path.join(ROOT, "profiles", "r06_kernel_resources.txt")).read().splitlines()[1:] if l.strip()]
     parsed = []
     for l in rows:
         name, rest = l[:100].strip(), l[100:].split()
         vgprs, scratch, _sgpr_spills, vgpr_spills, occ = (int(x) for x in rest)
         parsed.append((name, vgprs, scratch, vgpr_spills, occ))
-    assert sum(n.startswith("pt_trace_kernel<") for n, *_ in parsed) == 49 and sum(n.startswith("pt_world_kernel<") for n, *_ in parsed) == 25
+    assert sum(n.startswith("pt_trace_kernel<") for n, *_ in parsed) == 53 and sum(n.startswith("pt_world_kernel<") for n, *_ in parsed) == 25
     workers = 0
     for name, vgprs, scratch, vgpr_spills, occ in parsed:
         flags = [f.strip() for f in name[name.index("<") + 1:name.index(">")].split(",")] if "<" in name else [""] * 8
-        wide_frame = name.startswith("pt_trace_kernel<") and flags[7] == "1024" and flags[3] == "false" and flags[4] == "false"   # (<BVH, SPH_LDS, MFMA, VERIFY, PILOT, MOVING, GATE, BLK, GRID>)
+        wide_frame = name.startswith("pt_trace_kernel<") and flags[7] == "1024" and flags[3] == "false" and flags[4] == "false"   # (<BVH, SPH_LDS, MFMA, VERIFY, PILOT, MOVING, GATE, BLK, GRID, NOPOOL>)
         if wide_frame:
             workers += 1
             assert scratch <= 160 and vgpr_spills <= 24, (name, scratch, vgpr_spills)
@@ -693,12 +693,12 @@ def test_committed_kernel_resource_table_keeps_registers_and_spills_within_the_s
         elif name.startswith("pt_world_kernel<") and flags[2] == "5":   # five waves per SIMD: 96 VGPRs and a handful spilled (worth +7-9 %)
             assert vgprs <= 96 and occ == 5 and scratch <= 64 and vgpr_spills <= 16, (name, vgprs, scratch, vgpr_spills)
         elif name.startswith("pt_trace_kernel<") and flags[8] == "true" and flags[5] == "true":   # GRID + MOVING
-            assert vgprs <= 128 and occ == 4 and scratch <= 32 and vgpr_spills <= 4, (name, vgprs, scratch, vgpr_spills)
+            assert vgprs <= 128 and occ == 4 and scratch <= 32 and vgpr_spills <= 8, (name, vgprs, scratch, vgpr_spills)
         else:
             assert scratch == 0 and vgpr_spills == 0, (name, scratch, vgpr_spills)
         if name.startswith("pt_trace_kernel<") and flags[7] == "1024":
             assert vgprs <= 128 and occ == 4, (name, vgprs, occ)
-    assert workers == 4
+    assert workers == 8
 
 
 def test_fuzzed_descriptions_are_accepted_or_refused_by_name_and_reach_every_instantiation(tmp_path):
