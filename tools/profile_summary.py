@@ -143,6 +143,7 @@ if pmc_m:
 bl = os.path.join(src, "bench_line.json")
 if os.path.exists(bl) and os.path.getsize(bl):
     out["bench_line_under_profiler"] = json.load(open(bl))
+    out["build"] = out["bench_line_under_profiler"].get("build")   # pt_version() of the library these counters were taken on: bench.py marks them stale for any other build
     lines.append("")
     lines.append("# bench.py line under the profiler: value %.1f %s, kernel_ms %.3f" % (
         out["bench_line_under_profiler"]["value"], out["bench_line_under_profiler"]["unit"],
