@@ -118,16 +118,25 @@ def cpu_baseline(preset, W, H, S, depth, use_bvh, target_secs=15.0):
                 break
     except OSError:
         pass
+    # the figure to quote is the better of the two legs: with 256 threads on a 16-core quota the kernel throttles the process and the
+    # all-threads leg delivers HALF of what 16 threads do (9.7 vs 20.2 Mrays/s on the pool's EPYC 9575F boxes)
+    all_threads = value
+    used = cores
+    if at_quota is not None and at_quota > value:
+        value, used = at_quota, quota_threads
     return {
-        "value": value, "unit": "Mrays/s", "cores": cores, "kind": "port",
-        "cpu_model": model, "nproc": os.cpu_count(), "threads": cores,
+        "value": value, "unit": "Mrays/s", "cores": used, "kind": "port",
+        "cpu_model": model, "nproc": os.cpu_count(), "threads": used,
+        "value_all_threads": all_threads, "all_threads": cores,
         "one_thread": rate1, "speedup_over_one_thread": value / rate1 if rate1 > 0 else None,
         "cpu_quota_cores": quota, "cpu_quota_source": quota_src, "quota_threads": quota_threads, "value_at_quota_threads": at_quota,
         "speedup_at_quota_threads": (at_quota / rate1 if (at_quota and rate1 > 0) else None),
         "sample": "%d of %d pixels (every %dth) of %s %dx%d %dspp depth %d, %d rays in %.1fs, "
-                  "oracle/ptref.c -O3 -march=native -ffp-contract=off, %d pthreads (one thread alone: %.2f Mrays/s, "
-                  "so the %d threads delivered %.1f cores' worth)"
-                  % (len(px), total, stride, preset, W, H, S, depth, rays, dt, cores, rate1, cores, value / max(rate1, 1e-9)),
+                  "oracle/ptref.c -O3 -march=native -ffp-contract=off, %d pthreads: %.2f Mrays/s (one thread alone: %.2f Mrays/s, "
+                  "so the %d threads delivered %.1f cores' worth)%s"
+                  % (len(px), total, stride, preset, W, H, S, depth, rays, dt, cores, all_threads, rate1, cores, all_threads / max(rate1, 1e-9),
+                     ("; the same sample with %d threads, what the container's CPU quota (%s) pays for: %.2f Mrays/s = %.1f cores' worth -- `value`"
+                      % (quota_threads, quota_src, at_quota, at_quota / max(rate1, 1e-9))) if (at_quota is not None and at_quota > all_threads) else ""),
     }
 
 
