@@ -514,7 +514,7 @@ void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, h
             for (int i = 0; i < 18; ++i) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double)c[24 + i] / (double)(c[2] ? c[2] : 1));
             fprintf(stderr, "\n");
         }
-        unsigned long long l[24];
+        unsigned long long l[32];
         (void)hipMemcpy(l, s->d_debug + 96, sizeof l, hipMemcpyDeviceToHost);
         (void)hipMemset(s->d_debug + 96, 0, sizeof l);
         if (l[0]) {
@@ -522,6 +522,9 @@ void report_dev_aids(pt_scene *s, const KArgs &A, uint32_t grid, uint32_t blk, h
             fprintf(stderr, "[ptgpu lanes] trips %llu: lanes with a ray %.2f, waiting for the batched refill %.2f, out of work %.2f; tile-quarters asked per trip %.2f (of 4 x tiles), tile-halves %.2f\n  live lanes per trip (eighths):",
                     l[0], l[1] / n, l[2] / n, l[3] / n, l[4] / n, l[5] / n);
             for (int i = 0; i < 9; ++i) fprintf(stderr, " %d+:%.1f%%", 8 * i, 100.0 * (double)l[8 + i] / n);
+            static const char *pop[8] = {"1", "2", "3", "4", "5-8", "9-16", "17-32", "33-64"};
+            fprintf(stderr, "\n  tiles run per trip by the number of lanes that asked for them:");
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " %s:%.2f", pop[i], (double)l[17 + i] / n);
             fprintf(stderr, "\n");
         }
     }

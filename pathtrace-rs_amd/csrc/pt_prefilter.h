@@ -515,6 +515,16 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                 atomicAdd(&A.debug[101], (unsigned long long)(__popc(q0 | q1) + __popc(q2 | q3)));
             }
         }
+        {   // how many lanes ask for each tile the wave runs: debug[113 + bucket], buckets 1, 2, 3, 4, 5-8, 9-16, 17-32, 33-64 lanes
+            uint32_t tb = rem;
+            while (tb != 0u) {
+                const uint32_t T = (uint32_t)__builtin_ctz(tb);
+                tb &= tb - 1u;
+                const uint32_t n = (uint32_t)__popcll(wave_ballot(active && ((mine >> T) & 1u) != 0u));
+                const uint32_t bucket = n <= 4u ? (n ? n - 1u : 0u) : (n <= 8u ? 4u : (n <= 16u ? 5u : (n <= 32u ? 6u : 7u)));
+                if (lane == 0) atomicAdd(&A.debug[113u + bucket], 1ull);
+            }
+        }
         if (lane == 0) {
             atomicAdd(&A.debug[24], 1ull);
             atomicAdd(&A.debug[25], (unsigned long long)__popc(rem));

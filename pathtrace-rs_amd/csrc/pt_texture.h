@@ -21,10 +21,19 @@ struct PerlinLds {
                              // compiled for 128 VGPRs spill with it, the general-world kernel gains 10 % from it)
 };
 
+// `small`: every lane's coordinates are known to lie below 2^31 in magnitude (wave-uniform; perlin_small_range on the base point covers all seven
+// octaves). Rust's saturating `f32 as usize` (perlin.rs:96-98) is then just "negative -> 0, else the exact integer": the two comparisons against
+// 2^31 and 2^64 of floor_as_usize_low8 fall away -- 3 instead of 8 instructions per axis, 15 of an octave's ~150.
+__device__ __forceinline__ bool perlin_small_range(f3 p) {
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(p.x), __builtin_fabsf(p.y)), __builtin_fabsf(p.z)) < 16777216.0f;   // 2^24: x 2^6 for the last octave (a NaN fails)
+}
+template <bool SMALL = false>
 __device__ __forceinline__ float perlin_noise(const PerlinLds &pn, f3 p) {
     const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
-    const uint32_t i = floor_as_usize_low8(fx), j = floor_as_usize_low8(fy), k = floor_as_usize_low8(fz);
+    const uint32_t i = SMALL ? ((uint32_t)__builtin_fmaxf(fx, 0.0f) & 255u) : floor_as_usize_low8(fx);
+    const uint32_t j = SMALL ? ((uint32_t)__builtin_fmaxf(fy, 0.0f) & 255u) : floor_as_usize_low8(fy);
+    const uint32_t k = SMALL ? ((uint32_t)__builtin_fmaxf(fz, 0.0f) & 255u) : floor_as_usize_low8(fz);
     const float uu = u * u * (3.0f - 2.0f * u);
     const float vv = v * v * (3.0f - 2.0f * v);
     const float ww = w * w * (3.0f - 2.0f * w);
@@ -73,16 +82,24 @@ __device__ __forceinline__ float perlin_noise(const PerlinLds &pn, f3 p) {
 }
 
 // perlin.rs:76-87
-__device__ __forceinline__ float perlin_turb(const PerlinLds &pn, f3 p) {
+template <bool SMALL>
+__device__ __forceinline__ float perlin_turb_octaves(const PerlinLds &pn, f3 p) {
     float accum = 0.0f;
     f3 temp_p = p;
     float weight = 1.0f;
     for (int d = 0; d < 7; ++d) {
-        accum += weight * perlin_noise(pn, temp_p);
+        accum += weight * perlin_noise<SMALL>(pn, temp_p);
         weight *= 0.5f;
         temp_p = scale3(temp_p, 2.0f);
     }
     return fabsf(accum);
+}
+// FAST = false: the caller keeps one copy of the octave (the general-world kernel: two copies cost it 1.7 % on simple_light; the sphere kernels gain 2-4 %)
+template <bool FAST = true>
+__device__ __forceinline__ float perlin_turb(const PerlinLds &pn, f3 p) {
+    // (one wave-uniform test for all lanes that are here; the lanes of a divergent caller vote among themselves)
+    if (!FAST || __builtin_expect(wave_any(!perlin_small_range(p)), 0)) return perlin_turb_octaves<false>(pn, p);
+    return perlin_turb_octaves<true>(pn, p);
 }
 
 // perlin.rs:76-87 for the lanes of a wave that need it, BALANCED over the wave: the seven octaves of a point are independent
@@ -94,12 +111,12 @@ __device__ __forceinline__ float perlin_turb(const PerlinLds &pn, f3 p) {
 #ifndef PT_BALANCE_MAX
 #define PT_BALANCE_MAX 4
 #endif
-template <int MAX_ROUNDS = PT_BALANCE_MAX>
+template <int MAX_ROUNDS = PT_BALANCE_MAX, bool FAST = true>
 __device__ __forceinline__ float wave_balanced_turb(const PerlinLds &pn, uint32_t *scratch, bool need, f3 p) {
     const unsigned long long mask = wave_ballot(need);
     const uint32_t n = (uint32_t)__popcll(mask);
     if (n == 0u) return 0.0f;
-    if (7u * n > (uint32_t)MAX_ROUNDS * 64u) return need ? perlin_turb(pn, p) : 0.0f;   // (measured on config 5: balancing pays up to four rounds -- 8.03 Grays/s against 7.73 without, 7.97 when always on)
+    if (7u * n > (uint32_t)MAX_ROUNDS * 64u) return need ? perlin_turb<FAST>(pn, p) : 0.0f;   // (measured on config 5: balancing pays up to four rounds -- 8.03 Grays/s against 7.73 without, 7.97 when always on)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     float *sp = reinterpret_cast<float *>(scratch);
@@ -109,13 +126,15 @@ __device__ __forceinline__ float wave_balanced_turb(const PerlinLds &pn, uint32_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float accum = 0.0f;
     const uint32_t tasks = 7u * n;
+    const bool small = FAST && !wave_any(need && !perlin_small_range(p));   // (wave-uniform: every point of this call, hence every task)
     for (uint32_t base = 0; base < tasks; base += 64u) {
         const uint32_t t = base + lane;
         float val = 0.0f;
         if (t < tasks) {
             const uint32_t k = t / 7u, oct = t - 7u * k;
             const float sc = (float)(1u << oct);          // temp_p after `oct` doublings (perlin.rs:83)
-            val = perlin_noise(pn, mk3(sp[3u * k] * sc, sp[3u * k + 1u] * sc, sp[3u * k + 2u] * sc));
+            const f3 q = mk3(sp[3u * k] * sc, sp[3u * k + 1u] * sc, sp[3u * k + 2u] * sc);
+            val = small ? perlin_noise<true>(pn, q) : perlin_noise<false>(pn, q);
         }
         // octave j of the owner with rank r is task 7 r + j: computed in round (7 r + j) / 64 by lane (7 r + j) % 64
         float weight = 1.0f;
@@ -187,7 +206,7 @@ __device__ __forceinline__ f3 texture_leaf_value(const DTex &t, float turb, f3 p
 __device__ __forceinline__ f3 texture_value(const DTex *texs, const PerlinLds &pn, int32_t tex, f3 p, float u = 0.0f, float v = 0.0f,
                                          DImages images = DImages{nullptr, nullptr}) {
     const DTex t = texture_leaf(texs, tex, p);
-    return texture_leaf_value(t, t.kind == PT_TEX_NOISE ? perlin_turb(pn, p) : 0.0f, p, u, v, images);
+    return texture_leaf_value(t, t.kind == PT_TEX_NOISE ? perlin_turb<false>(pn, p) : 0.0f, p, u, v, images);
 }
 
 }  // namespace ptdev

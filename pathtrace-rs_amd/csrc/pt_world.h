@@ -749,7 +749,7 @@ __global__ __launch_bounds__(kBlock, OCC) PT_WBBPROF_ATTR void pt_world_kernel(c
             while (wave_any(pend)) {
                 const uint32_t k = pend ? 63u - (uint32_t)__builtin_clzll(lazy_mask) : 0u;
                 const f3 q = pend ? mk3(path[(k * PS + 0) * kBlock], path[(k * PS + 1) * kBlock], path[(k * PS + 2) * kBlock]) : mk3(0.f, 0.f, 0.f);
-                const float turb = wave_balanced_turb<PT_WORLD_TURB_ROUNDS>(pn, s_turb, pend, q);
+                const float turb = wave_balanced_turb<PT_WORLD_TURB_ROUNDS, false>(pn, s_turb, pend, q);
                 if (pend) {
                     DTex leaf{};
                     leaf.kind = PT_TEX_NOISE, leaf.scale = path[(k * PS + 3) * kBlock];

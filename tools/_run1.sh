@@ -1,4 +1,8 @@
-export PTGPU_BUILD_DIR=_build_sec
-python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --preset perlin_spheres --bvh --width 1920 --height 1080 --samples 128 2>&1 | grep -v "^{" | tail -1
-export PTGPU_BUILD_DIR=_build_gr
-timeout 120 python tools/tree_stats.py perlin_spheres 960 540 8 1 2>&1 | grep -v binary | tail -5 | cut -c1-900
+run() { python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-pipeline "$@" 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('   %.1f Mrays/s  %.3f ms/step  kernel %.3f ms' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms']))"; }
+for rep in 1 2 3; do for b in _build_prev _build; do export PTGPU_BUILD_DIR=$b; echo "$b c5"; run --preset perlin_spheres --bvh --width 1920 --height 1080 --samples 128; done; done
+for b in _build_prev _build; do export PTGPU_BUILD_DIR=$b; echo "$b two_perlin"; run --preset two_perlin_spheres; echo "$b simple_light"; run --preset simple_light; done
+unset PTGPU_BUILD_DIR
+timeout 600 python -m pytest tests -m gpu -x -q -k "noise or golden or perlin or world_presets or config5" 2>&1 | tail -2
