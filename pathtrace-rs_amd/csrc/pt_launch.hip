@@ -310,6 +310,7 @@ int launch(pt_scene *s, const pt_params *params, const pt_camera *cam, uint32_t 
     // (an interpreted scene graph's BVHNode rows are part of the graph, not a tree over the world: the same refusal as pt_debug_select's)
     if (params->use_bvh && !s->tr.has_caller_bvh) return fail(PT_ERR_UNSUPPORTED, "use_bvh requested but the description has no BVH nodes");
     HIP_TRY(hipSetDevice(s->device));
+    s->tile_rays_info.n_tiles = 0;   // (pt_scene_debug_tile_rays answers for THIS frame only: order_work fills it in when the frame counts rays per tile)
 
     // ---- which kernel, which geometry (pt_select.h) ----
     ptsel::Knobs knobs;

@@ -426,6 +426,21 @@ def test_golden_fixture(ptgpu, pthost, path, mode):
             len(wrong), mine.size, wrong[0][0], wrong[0][1], mine[tuple(wrong[0])], g["tile_rays"][tuple(wrong[0])])
 
 
+def test_tile_ray_counts_belong_to_the_last_frame_only(ptgpu, pthost):
+    """pt_scene_debug_tile_rays: the counts of a two-launch frame add up to its ray count; a frame that runs as one launch (4 samples) counts nothing,
+    and the call then refuses instead of handing back the previous frame's numbers."""
+    hs = pthost.HostScene("random_spheres", 320, 200, samples=16, device=0)
+    sc = hs.device_scene()
+    out = np.zeros((200, 320, 3), np.float32)
+    rays = sc.update(ptgpu.PtParams(320, 200, 16, 10, 0, 0), hs.camera, 0, out)
+    tiles = sc.tile_rays()
+    assert tiles.shape == (25, 40) and int(tiles.sum(dtype=np.uint64)) == rays and tiles.min() >= 64 * 16
+    sc.update(ptgpu.PtParams(320, 200, 4, 10, 0, 0), hs.camera, 0, out)
+    with pytest.raises(ptgpu.PtError) as e:
+        sc.tile_rays()
+    assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED
+
+
 def test_config5_full_frame_cell_grid_equals_the_tree_kernel_tile_by_tile(ptgpu, pthost):
     """BASELINE config 5 at full size (1920 x 1080 x 128, 10 002 spheres, BVH world) on the kernel that renders it -- the uniform cell grid of
     csrc/pt_grid.h, whose stragglers park their walks between calls (round 6) --, on the same kernel with every call walked to its end (2097152)
