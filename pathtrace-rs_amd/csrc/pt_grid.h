@@ -94,6 +94,24 @@ __device__ __forceinline__ void grid_walk_step(const KArgs &A, GridWalk &w, f3 d
     w.tnx = step_x ? tn_new : tnx, w.tny = step_y ? tn_new : tny, w.tnz = (step_x || step_y) ? tnz : tn_new;
 }
 
+// the same step in a grid that is ONE cell thick along y (a layer of spheres, BASELINE config 5: 99 x 1 x 99): the line leaves such a cell through
+// its top or bottom only by leaving the grid -- t_out knows -- so y never steps (grid_trace sets tny = +inf) and every three-way select is a two-way one
+__device__ __forceinline__ void grid_walk_step_xz(const KArgs &A, GridWalk &w, f3 d) {
+    const float tnx = w.tnx, tnz = w.tnz, ox = w.ox, oz = w.oz, rx = w.rx, rz = w.rz;
+    const int ix = w.ix, iz = w.iz;
+    const bool step_x = tnx <= tnz;
+    const bool up = (step_x ? d.x : d.z) >= 0.0f;
+    const int i_new = (step_x ? ix : iz) + (up ? 1 : -1);
+    const uint32_t n_axis = step_x ? A.grid_n[0] : A.grid_n[2];
+    const float lo_axis = step_x ? A.grid_min[0] : A.grid_min[2], h_axis = step_x ? A.grid_h[0] : A.grid_h[2];
+    const float o_axis = step_x ? ox : oz, r_axis = step_x ? rx : rz;
+    const float tn_new = ((lo_axis + (float)(i_new + (up ? 1 : 0)) * h_axis) - o_axis) * r_axis;
+    w.tcur = __builtin_fminf(tnx, tnz);
+    w.alive = (uint32_t)i_new < n_axis;
+    w.ix = step_x ? i_new : ix, w.iz = step_x ? iz : i_new;
+    w.tnx = step_x ? tn_new : tnx, w.tnz = step_x ? tnz : tn_new;
+}
+
 template <bool MOVING, bool COUNT, int BLK>
 __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, uint32_t *leafq, uint32_t *w_pairs, unsigned long long *w_keys, uint32_t *w_park, unsigned long long &parked,
                                            f3 o, f3 d, const DivA &av, float time, bool start, Steal4 &cnt, unsigned long long *sec = nullptr) {
@@ -136,6 +154,8 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     GridWalk w;
     grid_walk_start(A, w, o, d, rcp, start && !far);
+    const bool layer = A.grid_n[1] == 1u;   // (wave-uniform) one cell along y: the walk steps in x and z only
+    if (layer) w.tny = __builtin_inff();
     uint32_t rec = grid_walk_cell(A, w);
     bool cont = false;   // `rec` continues the cell the lane is already in (its walk has stepped on: such a record is visited whatever the limit says)
     if (parked != 0ull) {   // (wave-uniform) somebody resumes
@@ -231,7 +251,10 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
             const uint4 *cp = A.grid_cells + (size_t)rec * 5u;
             uint4 q0 = cp[0], q1 = cp[1], q2 = cp[2], q3 = cp[3], m = cp[4];
             // the step into the next cell does not depend on what the record holds: taken here, in the shadow of the loads
-            if (!cont) grid_walk_step(A, w, d);
+            if (!cont) {
+                if (layer) grid_walk_step_xz(A, w, d);
+                else grid_walk_step(A, w, d);
+            }
             // (all five loads in flight at once: left alone, the scheduler issues them one by one, each behind the arithmetic of the one
             //  before -- four round trips to the L2 per record instead of one -- to save the sixteen registers this takes)
             asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q0.w), "+v"(q1.x), "+v"(q1.y), "+v"(q1.z), "+v"(q1.w), "+v"(q2.x), "+v"(q2.y), "+v"(q2.z), "+v"(q2.w),
@@ -270,7 +293,10 @@ __device__ __forceinline__ void grid_trace(const KArgs &A, uint16_t *s_stack, ui
                     // last bits of its quotient: the computed root is off by ~ eps b / a, under 1e-5 while b < 100 a (the bound is relative to a:
                     // the C ABI takes rays of any direction length, and with a << 1 a bound on b alone would let that error reach t_min): not queued
                     const bool leaving = b[e] > 0.0f && b[e] < 100.0f * a && -cc[e] < 5.0e-4f * b[e];
-                    const bool pos = disc[e] > 0.0f && k < A.n_spheres && !leaving;   // (an empty slot, or the link, is no list index)
+                    // (an empty slot of a record -- its index word is kGridNone or the link -- holds the sphere (3e38, 3e38, 3e38; 0): oc.oc overflows to +inf for
+                    //  any finite origin, so its discriminant is b b - a inf = -inf or NaN, never > 0: no test of the index word is needed. MOVING
+                    //  records go through sphere_at, which wants a valid index: they keep the test.)
+                    const bool pos = disc[e] > 0.0f && (!MOVING || k < A.n_spheres) && !leaving;
                     leafq[qn * BLK + tid] = owner_tag | k;
                     qn += pos ? 1u : 0u;
 #ifndef PT_GRID_ROUNDS
