@@ -277,24 +277,26 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
     for (;;) {
         // ---- refill: lanes without a pixel get one
         // (this section reads its arguments -- frame buffer, parked streams, work order, counters, frame geometry: two dozen scalars it needs once per
-        //  pixel -- through `R`, the kernel's argument block behind an opaque pointer: loaded where they are used instead of being kept in scalar
-        //  registers across the whole loop, which left the hot loops reading spilled scalars back with v_readlane)
+        //  pixel -- through RF(field): in the frame kernels the kernel's argument block behind an OPAQUE pointer to the kernarg segment, so that they are
+        //  loaded where they are used instead of being kept in scalar registers across the whole loop, which left the hot loops reading spilled scalars
+        //  back with v_readlane (headline kernel: 77 -> 35 spilled SGPRs, +2 %). The measuring and verify twins read the plain block.)
+        constexpr bool kOpaqueArgs = !PILOT && !VERIFY;
         const KArgsK Rp = [] { KArgsK q = (KArgsK)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(q)); return q; }();
-        const auto &R = *Rp;
+#define RF(field) (kOpaqueArgs ? Rp->field : A.field)
         const unsigned long long want = wave_ballot(!have && !exhausted);
         // scene.rs:113-116: a finished pixel is averaged, blended into the frame and its rays are booked on its work tile
         auto write_finished_pixel = [&]() {
             finished = false;
             const float4 pf = s_par[10];   // inv_ns, mix_prev, mix_new
-            if (PILOT && R.phase == 1u) {   // to be continued: park the stream and the sum
-                uint4 *st = R.px_state + 3u * (size_t)((pxy >> 16) * R.width + (pxy & 0xffffu));
+            if (PILOT && RF(phase) == 1u) {   // to be continued: park the stream and the sum
+                uint4 *st = RF(px_state) + 3u * (size_t)((pxy >> 16) * RF(width) + (pxy & 0xffffu));
                 st[0] = make_uint4((uint32_t)rng.s0, (uint32_t)(rng.s0 >> 32), (uint32_t)rng.s1, (uint32_t)(rng.s1 >> 32));
                 st[1] = make_uint4((uint32_t)rng.s2, (uint32_t)(rng.s2 >> 32), (uint32_t)rng.s3, (uint32_t)(rng.s3 >> 32));
                 st[2] = make_uint4(__float_as_uint(col.x), __float_as_uint(col.y), __float_as_uint(col.z), 0u);
             }
             col = scale3(col, pf.x);
             if (!PILOT) {
-                float *out = R.rgb + ((pxy >> 16) * R.width + (pxy & 0xffffu)) * 3u;
+                float *out = RF(rgb) + ((pxy >> 16) * RF(width) + (pxy & 0xffffu)) * 3u;
                 // (prev_zero: pt_render found the host buffer all +0.0f and did not upload it -- same products, same sums)
                 const bool pz = pf.w != 0.0f;   // (KArgs::prev_zero, through the LDS parameter block like its neighbours)
                 const float p0 = pz ? 0.0f : out[0], p1 = pz ? 0.0f : out[1], p2 = pz ? 0.0f : out[2];
@@ -303,29 +305,29 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 out[2] = p2 * pf.y + col.z * pf.z;
             }
             // (frame kernels: the NEXT frame's work order; the pixel's work tile is recomputed from its coordinates)
-            if (PILOT || R.tile_cost) atomicAdd(&R.tile_cost[((pxy >> 16) >> kTileLog2) * R.tiles_x + ((pxy & 0xffffu) >> kTileLog2)], pix_rays);
+            if (PILOT || RF(tile_cost)) atomicAdd(&RF(tile_cost)[((pxy >> 16) >> kTileLog2) * RF(tiles_x) + ((pxy & 0xffffu) >> kTileLog2)], pix_rays);
         };
         // the sample number a pixel starts this launch with. Phase 2 of a frame whose measuring launch traced every OTHER tile (KArgs::checker):
         // a pixel of an unmeasured tile starts here, one sample behind the others -- its sample number starts at -1 (20 bits), so that it too
         // is done when the number reaches s_par[12].w = samples - 1
-        auto tile_parked = [&](uint32_t tcol, uint32_t trow) -> bool { return !PILOT && R.phase == 2u && (R.checker == 0u || ((tcol + trow) & 1u) == 0u); };
-        auto start_sd = [&](bool parked) -> uint32_t { return (!PILOT && R.phase == 2u && !parked) ? 0xfffff000u : 0u; };
+        auto tile_parked = [&](uint32_t tcol, uint32_t trow) -> bool { return !PILOT && RF(phase) == 2u && (RF(checker) == 0u || ((tcol + trow) & 1u) == 0u); };
+        auto start_sd = [&](bool parked) -> uint32_t { return (!PILOT && RF(phase) == 2u && !parked) ? 0xfffff000u : 0u; };
         // work item -> the pixel and the state it starts with (false: the item lies beyond the frame's edge)
         auto start_item = [&](uint32_t item, uint32_t &pxy_o, bool &parked_o, Rng &rng_o, f3 &col_o) -> bool {
             const uint32_t in = item & (kTilePix - 1u);
-            const uint32_t tile = R.tile_order ? R.tile_order[item >> (2u * kTileLog2)] : (item >> (2u * kTileLog2));
+            const uint32_t tile = RF(tile_order) ? RF(tile_order)[item >> (2u * kTileLog2)] : (item >> (2u * kTileLog2));
             // tile / tiles_x by the host's magic (a u32 division costs ~25 instructions and a hoisted reciprocal register):
             // umulhi underestimates the quotient by at most one for any tile < 2^32
-            uint32_t trow = __umulhi(tile, R.tiles_x_magic), tcol = tile - trow * R.tiles_x;
-            if (tcol >= R.tiles_x) trow += 1u, tcol -= R.tiles_x;
+            uint32_t trow = __umulhi(tile, RF(tiles_x_magic)), tcol = tile - trow * RF(tiles_x);
+            if (tcol >= RF(tiles_x)) trow += 1u, tcol -= RF(tiles_x);
             const uint32_t x = tcol * kTileSide + (in & (kTileSide - 1u));
             const uint32_t ly = trow * kTileSide + (in >> kTileLog2);
-            if (!(x < R.width && ly < R.local_rows)) return false;
+            if (!(x < RF(width) && ly < RF(local_rows))) return false;
             pxy_o = x | (ly << 16);
-            const uint32_t px = x, py = ly * R.shard_count + R.shard_index;
+            const uint32_t px = x, py = ly * RF(shard_count) + RF(shard_index);
             parked_o = tile_parked(tcol, trow);
             if (parked_o) {   // continue the stream and the sum phase 1 parked
-                const uint4 *st = R.px_state + 3u * (size_t)(ly * R.width + x);
+                const uint4 *st = RF(px_state) + 3u * (size_t)(ly * RF(width) + x);
                 const uint4 a = st[0], b = st[1], c = st[2];
                 rng_o.s0 = (uint64_t)a.x | ((uint64_t)a.y << 32), rng_o.s1 = (uint64_t)a.z | ((uint64_t)a.w << 32);
                 rng_o.s2 = (uint64_t)b.x | ((uint64_t)b.y << 32), rng_o.s3 = (uint64_t)b.z | ((uint64_t)b.w << 32);
@@ -333,9 +335,9 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             } else {
                 col_o = mk3(0.f, 0.f, 0.f);
                 // scene.rs:96-102
-                uint64_t seed = ((uint64_t)px * 1973ull + (uint64_t)py * 9277ull + (uint64_t)R.frame_num * 26699ull) | 1ull;
-                if (R.random_seed) {
-                    uint64_t h = R.seed_base ^ (seed * 0x9e3779b97f4a7c15ULL);
+                uint64_t seed = ((uint64_t)px * 1973ull + (uint64_t)py * 9277ull + (uint64_t)RF(frame_num) * 26699ull) | 1ull;
+                if (RF(random_seed)) {
+                    uint64_t h = RF(seed_base) ^ (seed * 0x9e3779b97f4a7c15ULL);
                     seed = splitmix64_next(h);
                 }
                 rng_seed_from_u64(rng_o, seed);
@@ -343,19 +345,19 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             return true;
         };
         if (POOL) {
-            // Wide frame kernels: freed lanes do not wait for a batch. The wave keeps a POOL of ready-to-start pixels in LDS (R.pool_slots entries of
+            // Wide frame kernels: freed lanes do not wait for a batch. The wave keeps a POOL of ready-to-start pixels in LDS (RF(pool_slots) entries of
             // 48 bytes per wave: RNG stream, colour sum, coordinates); a lane that finishes takes the next entry in the same trip, and the global
             // round trips of a claim (work counter -> tile order -> parked stream) are paid once per pool_slots pixels, by all lanes together. Near
-            // the list's end (the wave's fair share of it below R.pool_tail items) claims take what is wanted and no more, batched by R.refill_min like the other kernels'.
+            // the list's end (the wave's fair share of it below RF(pool_tail) items) claims take what is wanted and no more, batched by RF(refill_min) like the other kernels'.
             if (want != 0ull) {   // (wave-uniform)
                 if (!have && finished) write_finished_pixel();
                 uint32_t wv_here = wave_id;
                 asm volatile("" : "+s"(wv_here));   // (the pool's address is formed here: hoisted out of the loop it is one more live scalar)
-                uint4 *const w_pool = reinterpret_cast<uint4 *>(smem + R.pool_off) + wv_here * (R.pool_slots * 3u);
+                uint4 *const w_pool = reinterpret_cast<uint4 *>(smem + RF(pool_off)) + wv_here * (RF(pool_slots) * 3u);
                 const uint32_t wn = (uint32_t)__popcll(want);
-                if (PT_POOL_LEFT == 0u && !PT_POOL_DRY && (!PT_POOL_EXACT || wn >= R.refill_min || wave_ballot(have) == 0ull)) {
+                if (PT_POOL_LEFT == 0u && !PT_POOL_DRY && (!PT_POOL_EXACT || wn >= RF(refill_min) || wave_ballot(have) == 0ull)) {
                     // ---- claim: the whole wave fetches up to pool_slots work items and parks their start states in its pool
-                    uint32_t n = R.pool_slots, base;
+                    uint32_t n = RF(pool_slots), base;
                     const uint32_t static_left = (pool_st >> 14) & 127u;
                     if (static_left != 0u) {
                         // A SIMD's arbiter serves its OLDEST wave first: the first waves of a 16-wave workgroup advance up to twice as fast
@@ -373,12 +375,12 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                         const uint32_t want_now = fill > wn ? fill : wn;
                         n = n < want_now ? n : want_now;
                         uint32_t b = 0;
-                        if (lane == 0) b = atomicAdd(R.work_counter, n);
-                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b) + R.first_static;
+                        if (lane == 0) b = atomicAdd(RF(work_counter), n);
+                        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)b) + RF(first_static);
                     }
-                    if (base + n >= R.n_items) pool_st |= 1u << 21;
+                    if (base + n >= RF(n_items)) pool_st |= 1u << 21;
                     if (static_left == 0u) {   // what the list holds now, per wave of the grid
-                        const uint32_t share = __umulhi(base + n < R.n_items ? R.n_items - (base + n) : 0u, R.pool_waves_magic);
+                        const uint32_t share = __umulhi(base + n < RF(n_items) ? RF(n_items) - (base + n) : 0u, RF(pool_waves_magic));
                         pool_st = (pool_st & 0x3fffffu) | ((share < 1023u ? share : 1023u) << 22);
                     }
                     const uint32_t item = base + (uint32_t)lane;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     bool parked_q = false;
                     Rng r{0, 0, 0, 0};
                     f3 c = mk3(0.f, 0.f, 0.f);
-                    const bool ok = (uint32_t)lane < n && item < R.n_items && start_item(item, q, parked_q, r, c);
+                    const bool ok = (uint32_t)lane < n && item < RF(n_items) && start_item(item, q, parked_q, r, c);
                     const unsigned long long m = wave_ballot(ok);
                     if (ok) {
                         uint4 *e = w_pool + 3u * __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                     } else if (PT_POOL_DRY) {
                         exhausted = true;
 #ifdef PT_WAVE_DETAIL
-                        if (R.wave_end && dbg_exh_iter == 0) dbg_exh_iter = dbg_iters, dbg_last_refill = wall_clock64();
+                        if (RF(wave_end) && dbg_exh_iter == 0) dbg_exh_iter = dbg_iters, dbg_last_refill = wall_clock64();
 #endif
                     }
                 }
@@ -429,27 +431,27 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         } else {
             // ---- the other kernels: one wave-aggregated atomic for all lanes that need a pixel. The refill code (a global atomic
             // round trip and four SplitMix64 steps of 64-bit multiplies) runs for the whole wave whenever ANY lane needs
-            // it, so lanes wait until R.refill_min of them do (or nobody has work left): fewer, fuller refills.
-            const bool refill_now = __popcll(want) >= (int)R.refill_min || wave_ballot(have) == 0ull;
+            // it, so lanes wait until RF(refill_min) of them do (or nobody has work left): fewer, fuller refills.
+            const bool refill_now = __popcll(want) >= (int)RF(refill_min) || wave_ballot(have) == 0ull;
             if (!have && !exhausted && refill_now) {
                 if (finished) write_finished_pixel();
                 const unsigned long long m = wave_ballot(1);
                 const int leader = __ffsll((long long)m) - 1;
                 uint32_t base = 0;
-                if (R.first_static != 0u && first_claim) {
+                if (RF(first_static) != 0u && first_claim) {
                     // (the waves' first 64 items by age class: see the pool's claim above)
                     const uint32_t wv = wave_id, cls = wv >> 2, idx = blockIdx.x * 4u + (wv & 3u);
                     base = (cls * gridDim.x * 4u + idx) * 64u;
                 } else {
-                    if (lane == leader) base = atomicAdd(R.work_counter, (uint32_t)__popcll(m));
-                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader) + R.first_static;
+                    if (lane == leader) base = atomicAdd(RF(work_counter), (uint32_t)__popcll(m));
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader) + RF(first_static);
                 }
                 first_claim = false;
                 const uint32_t item = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));   // lanes of m below this one
-                if (item >= R.n_items) {
+                if (item >= RF(n_items)) {
                     exhausted = true;
 #ifdef PT_WAVE_DETAIL
-                    if (R.wave_end && dbg_exh_iter == 0) dbg_exh_iter = dbg_iters, dbg_last_refill = wall_clock64();
+                    if (RF(wave_end) && dbg_exh_iter == 0) dbg_exh_iter = dbg_iters, dbg_last_refill = wall_clock64();
 #endif
                 } else {
                     pix_rays = 0;
@@ -465,6 +467,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
                 }
             }
         }
+#undef RF
         // TAIL: once the list is dry, every few iterations a look into ONE other wave's mailbox (pt_coop.h): a load of a line nobody
         // else polls, issued here and read at the end of the iteration, so its latency hides behind the iteration's work
         uint64_t tail_probe = 0;

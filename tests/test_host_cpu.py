@@ -671,7 +671,7 @@ def test_committed_kernel_resource_table_keeps_registers_and_spills_within_the_s
     pt_world_kernel instantiations is listed; none uses scratch or spills a VGPR EXCEPT the eight 1024-thread frame kernels (with and without
     pixel pools) that carry the cooperative worker (csrc/pt_coop.h: it saves its sphere registers around a handed-over pixel: <= 160 B, <= 24 VGPRs) and the
     general-world kernel that INTERPRETS a scene graph (csrc/pt_graph.h: the walk is an out-of-line call, <= 128 B of call frame) and its
-    four instantiations for five waves per SIMD (96 VGPRs, <= 16 spilled), and the MOVING flavours of the cell-grid kernels (csrc/pt_grid.h:
+    four instantiations for five waves per SIMD (96 VGPRs, <= 16 spilled), and the six cell-grid kernels (csrc/pt_grid.h:
     128 VGPRs, <= 8 spilled), and
     all 1024-thread prefilter kernels (one workgroup per CU, four waves per SIMD) stay within the 128 registers that occupancy allows."""
     rows = [l for l in open(os.path.join(ROOT, "profiles", "r06_kernel_resources.txt")).read().splitlines()[1:] if l.strip()]
@@ -692,7 +692,7 @@ def test_committed_kernel_resource_table_keeps_registers_and_spills_within_the_s
             assert scratch <= 128 and vgpr_spills == 0, (name, scratch, vgpr_spills)
         elif name.startswith("pt_world_kernel<") and flags[2] == "5":   # five waves per SIMD: 96 VGPRs and a handful spilled (worth +7-9 %)
             assert vgprs <= 96 and occ == 5 and scratch <= 64 and vgpr_spills <= 16, (name, vgprs, scratch, vgpr_spills)
-        elif name.startswith("pt_trace_kernel<") and flags[8] == "true" and flags[5] == "true":   # GRID + MOVING
+        elif name.startswith("pt_trace_kernel<") and flags[8] == "true":   # GRID (round 6: the Perlin range test and the parked walks cost the plain ones a few spills too)
             assert vgprs <= 128 and occ == 4 and scratch <= 32 and vgpr_spills <= 8, (name, vgprs, scratch, vgpr_spills)
         else:
             assert scratch == 0 and vgpr_spills == 0, (name, scratch, vgpr_spills)
