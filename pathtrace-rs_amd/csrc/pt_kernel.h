@@ -16,6 +16,9 @@
 //   pt_coop.h       the wave-cooperative mode (one pixel per wave) behind the hand-over of the wide kernels
 // DESIGN.md section 4 has the derivations and the error budget.
 #pragma once
+#ifndef PT_REJ_CAP
+#define PT_REJ_CAP 3   // tries of the shared rejection loop per trip before a lane puts the rest off to the next trip (0: until every lane is done; NOTES.md has 2, 3, 4 and 6 measured)
+#endif
 #include "pt_args.h"
 #include "pt_device.h"
 #include "pt_tree4.h"
@@ -512,17 +515,42 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             const float cam_time0 = c5.y, cam_time1 = c5.z, cam_lens_radius = c5.w;
             const uint32_t px = pxy & 0xffffu, py = (pxy >> 16) * A.shard_count + A.shard_index;
             float u = 0.f, v = 0.f;
+#if PT_REJ_CAP
+            // A lane that has not found its point after PT_REJ_CAP tries of the shared loop PUTS OFF the rest to the next trip (the loop ran ~4 trips per
+            // wave-trip for its last one or two lanes -- mostly Metal's ball in the cube, 48 % rejected): it keeps its role, sits this trip out, and a
+            // camera lane keeps its two jitter draws in its dead origin registers behind a marker no direction can be. The lane's draws keep their order.
+            constexpr uint32_t kRejMarker = 0x7fc0dea5u;
+            const bool cam_resumed = cam_role && __float_as_uint(d.z) == kRejMarker;
+            if (cam_role && cam_resumed) u = o.x, v = o.y;
+            if (cam_role && !cam_resumed) {
+#else
             if (cam_role) {   // scene.rs:107-108: the jitter draws come before the lens draws
+#endif
                 u = rng_plus(rng, (float)px) * pn2.z;
                 v = rng_plus(rng, (float)py) * pn2.w;
             }
             float sx, sy, sz;
+#if PT_REJ_CAP
+            bool inside_ball = false;
+            for (uint32_t tries = 0; tries < (uint32_t)(PT_REJ_CAP); ++tries) {
+                sx = rng_pm1(rng), sy = rng_pm1(rng);   // math.rs:8 / math.rs:17-21: 2 * draw - 1
+                sz = 0.0f;
+                if (met_role) sz = rng_pm1(rng);
+                inside_ball = ((sx * sx + sy * sy) + sz * sz) < 1.0f;
+                if (inside_ball) break;
+            }
+            if (!inside_ball) {
+                if (cam_role) o.x = u, o.y = v, d.z = __uint_as_float(kRejMarker);
+            } else {
+#else
             for (;;) {   // (a plain divergent loop: a lane leaves when its point is inside, the wave when its last lane has)
                 sx = rng_pm1(rng), sy = rng_pm1(rng);   // math.rs:8 / math.rs:17-21: 2 * draw - 1
                 sz = 0.0f;
                 if (met_role) sz = rng_pm1(rng);
                 if (((sx * sx + sy * sy) + sz * sz) < 1.0f) break;
             }
+            {
+#endif
             f3 vec;
             if (cam_role) {
                 const float rdx = cam_lens_radius * sx, rdy = cam_lens_radius * sy;
@@ -541,6 +569,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             }
             d = normalize3(vec);   // camera.rs:66 / material.rs:84, once for both roles
             pend_metal = false;
+            }
         }
 
         PT_SEC(1);
@@ -557,8 +586,8 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
         }
 #endif
         // ---- hitable.rs:39-65: closest hit (inactive lanes carry a null ray)
-#ifdef PT_CAMSKIP
-        const bool sat_out = have && (need_cam || pend_metal);   // (lanes whose camera stage was put off sit this trip out; restored below)
+#if defined(PT_CAMSKIP) || PT_REJ_CAP
+        const bool sat_out = have && (need_cam || pend_metal);   // (lanes whose camera ray / Metal sample was put off sit this trip out; restored below)
         have = have && !sat_out;
 #endif
         const f3 ro = have ? o : mk3(0.f, 0.f, 0.f);
@@ -818,7 +847,7 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             }
         }
         PT_SEC(3);
-#ifdef PT_CAMSKIP
+#if defined(PT_CAMSKIP) || PT_REJ_CAP
         have = have || sat_out;
 #endif
         if (TAIL && tail_polled) {
@@ -830,7 +859,11 @@ __global__ __launch_bounds__(BLK, (BLK == kBlock) ? ((BVH && SPH_LDS) ? PT_TREE4
             tail_streak = idle ? tail_streak + 1u : 0u;
             const uint32_t live = (uint32_t)__popcll(wave_ballot(have));
             if (idle && (live <= A.tail_live_max || tail_streak >= A.tail_streak)) {
+#if PT_REJ_CAP
+                const bool cand = have && need_cam && __float_as_uint(d.z) != 0x7fc0dea5u;   // between two samples (a lane that has put off its lens point is INSIDE one: its stream is past the jitter draws)
+#else
                 const bool cand = have && need_cam;   // between two samples
+#endif
                 const uint32_t done_s = sd >> 12;
                 const float est = (float)pix_rays * (float)(__float_as_uint(s_par[12].w) - done_s) * __builtin_amdgcn_rcpf((float)done_s);   // rays per sample so far x samples left
                 const uint32_t eb = (cand && est >= A.tail_min_est) ? __float_as_uint(est) : 0u;   // (NaN before the first sample: not >=)

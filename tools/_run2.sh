@@ -1,9 +1,8 @@
-run() { python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-extras --no-pipeline "$@" 2>/dev/null | python -c "
-import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('   %.1f Mrays/s  %.3f ms/step  kernel %.3f ms' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms']))"; }
-for rep in 1 2 3; do for b in _build_prev _build; do export PTGPU_BUILD_DIR=$b
-echo "$b c3"; run
-echo "$b aras"; run --preset aras --width 1280 --height 720 --samples 16
-echo "$b c4"; run --samples 256 --steps 4
-done; done
+bash tools/gpu_suite.sh
+timeout 600 python tools/fuzz_worlds.py 2100000 4000 all 2>&1 | tail -2
+timeout 300 python tools/fuzz_worlds.py 2200000 800 noise 2>&1 | tail -1
+timeout 300 python tools/fuzz_worlds.py 2300000 800 graphs 2>&1 | tail -1
+timeout 500 python tools/grid_soak.py 50000 2000 2>&1 | tail -1
+timeout 500 python tools/pool_soak.py 30000 1500 2>&1 | tail -1
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+python bench.py 2>/dev/null | tail -1
