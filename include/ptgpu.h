@@ -415,7 +415,7 @@ int pt_debug_select(const pt_scene_desc *sphere_desc, const pt_world_desc *world
                     pt_kernel_choice *out);
 
 /* The uniform cell grid pt_scene_create would plan for a sphere scene (csrc/pt_grid.h; host only, no device): the structure the tree kernels'
- * "grid<...>" flavour walks. info16 = { cells x, y, z, records, large spheres, 0, 0, 0 | as f32 bits: box min x, y, z, cell size x, y, z, centre-to-origin
+ * "grid<...>" flavour walks. info16 = { cells x, y, z, records, large spheres, as f32 bits: spheres registered per cell, fraction of the cells occupied, 0 | as f32 bits: box min x, y, z, cell size x, y, z, centre-to-origin
  * distance the registration is padded for (d_build), half diagonal of the field }. records5x4 (may be NULL): up to `capacity_records` records of
  * five 16-byte words -- spheres 0 | 1 and 2 | 3 interleaved component by component, then four list indices (0x7fffffff: empty; in the last word
  * 0x80000000 | record: the cell continues there). large (may be NULL): up to 16 list indices. Returns PT_ERR_UNSUPPORTED (with the plan's

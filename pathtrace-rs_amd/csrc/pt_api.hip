@@ -263,6 +263,8 @@ extern "C" int pt_debug_cell_grid(const pt_scene_desc *sphere_desc, uint32_t inf
         q.f = g.ha[k], info16[11 + k] = q.u;
     }
     info16[3] = g.n_records, info16[4] = (uint32_t)g.large.size();
+    q.f = (float)g.items_per_cell, info16[5] = q.u;
+    q.f = (float)g.occupied, info16[6] = q.u;
     q.f = g.d_build, info16[14] = q.u;
     q.f = g.half_diag, info16[15] = q.u;
     if (records5x4) memcpy(records5x4, g.cells.data(), std::min<size_t>(capacity_records, g.n_records) * 5 * sizeof(uint4));

@@ -1,5 +1,8 @@
 // pt_prefilter.h -- closest hit of a list world on the wide kernels: MFMA prefilter over lifted ray / sphere features, tile culling, balanced exact phase 2, and the accept rules of BVH worlds (4.3).
 #pragma once
+#ifndef PT_PAIR_SLOTS
+#define PT_PAIR_SLOTS 0   // 1: the wave's pair list holds (owner, tile slot); the sphere index is looked up when the pair is tested (NOTES.md)
+#endif
 #include "pt_sphere.h"
 
 namespace ptdev {
@@ -411,7 +414,11 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
                     while (mk != 0u) {
                         const uint32_t b = (uint32_t)__builtin_ctz(mk);
                         mk &= mk - 1u;
+#if PT_PAIR_SLOTS
+                        w_pairs[pos++] = ((uint32_t)lane << 16) | slot_of(T, b);   // (the sphere behind the slot is looked up by the lane that tests the pair: no dependent LDS read in this serial loop)
+#else
                         w_pairs[pos++] = ((uint32_t)lane << 16) | (uint32_t)s_tile_sphere[slot_of(T, b)];
+#endif
                     }
                 }
             }
@@ -421,9 +428,16 @@ __device__ __forceinline__ int intersect_list_mfma(const KArgs &A, const GateSrc
             __builtin_amdgcn_wave_barrier();
             // 3. one pair per lane and round, with the owner's ray fetched across lanes
             for (uint32_t base = 0; base < total; base += 64u) {
+#if PT_PAIR_SLOTS
+                const bool listed = base + (uint32_t)lane < total;
+                const uint32_t e = listed ? w_pairs[base + lane] : 0u;
+                const uint32_t owner = e >> 16;
+                const int k = listed ? (int)s_tile_sphere[e & 0xffffu] : 0xffff;
+#else
                 const uint32_t e = base + (uint32_t)lane < total ? w_pairs[base + lane] : 0xffffu;
                 const uint32_t owner = e >> 16;
                 const int k = (int)(e & 0xffffu);
+#endif
                 const bool valid = k != 0xffff;   // (beyond the list, or a padding row of a fragment)
                 const f3 po = mk3(lane_fetch(owner, o.x), lane_fetch(owner, o.y), lane_fetch(owner, o.z));
                 const f3 pd = mk3(lane_fetch(owner, d.x), lane_fetch(owner, d.y), lane_fetch(owner, d.z));

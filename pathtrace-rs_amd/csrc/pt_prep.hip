@@ -473,7 +473,7 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
     }
     // candidates: cell sizes around the padded median width, four alignments per axis that has more than one cell
     GridGeom best{};
-    double best_cost = 1e300;
+    double best_cost = 1e300, best_sz = 0.0;
     const size_t stride = (items.size() + 19999) / 20000;
     std::vector<uint32_t> count;
     static const double kSizes[] = {0.625, 0.75, 0.875, 1.0, 1.25, 1.5, 2.0, 3.0};
@@ -512,7 +512,7 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
             for (uint32_t c : count) records += grid_records_of((uint32_t)std::min<uint64_t>((uint64_t)c * stride, 0xffffffffull));
             if (records > kGridMaxRecords) continue;
             const double cost = ((double)records / (double)cells + 0.35) / h;   // (+ the walk's own step per cell)
-            if (cost < best_cost) best_cost = cost, best = g;
+            if (cost < best_cost) best_cost = cost, best = g, best_sz = sz;
         }
     }
     if (!(best_cost < 1e300)) return false;
@@ -582,10 +582,19 @@ bool plan_cell_grid(const pt_scene_desc *desc, const MotionIn *motion, double t_
     size_t occupied = 0;
     for (const std::vector<uint32_t> &L : lists) occupied += L.empty() ? 0u : 1u;
     G.occupied = (double)occupied / (double)cells;
-    // Where the walk pays (tools/grid_ab.py, grid against the 4-wide tree on one MI355X): an even, DENSE field of spheres -- config 5's single layer
-    // (4.1 spheres per cell, every cell occupied) 1.39x, 10 000 equal spheres filling a cube (5.5 per cell, 88 % occupied) 1.08x -- and not a
-    // loose cloud (1.1 ... 2.7 per cell, 64 ... 82 % occupied: 0.69 ... 0.91x; the tree skips empty space, the walk steps through it).
-    if (G.occupied < 0.9 || G.items_per_cell < 3.5) {
+    // Where the walk pays (tools/grid_ab.py, grid against the 4-wide tree on one MI355X, round 6's walk): an even, DENSE field of spheres whose cells are
+    // at most two median sphere widths wide -- config 5's single layer (4.1 spheres per cell, every cell occupied, cells of 1.25 widths) 1.5x; 10 000
+    // spheres filling a cube with 3.3 ... 5.3 per cell and 83 ... 89 % of the cells occupied 1.11 ... 1.39x -- and not a looser field, for which the cost
+    // estimate above picks cells of three widths (4.6 per cell, 89 % occupied: 0.89 ... 0.95x: most of a cell's spheres are far from the ray that
+    // crosses it), a thin layer (2.3 per cell, 81 %: 0.92x) or a loose cloud (1.1 ... 2.5 per cell, 63 ... 81 %: 0.70 ... 0.93x; the tree skips empty
+    // space, the walk steps through it). NOTES.md "Round 6 -- which fields get a cell grid" has the table.
+    double occ_min = 0.83, per_cell_min = 2.5, sz_max = 2.0;
+#ifdef PT_DEVKNOBS
+    if (const char *e = getenv("PTGPU_GRID_OCC")) occ_min = atof(e);       // development builds: tools/grid_ab.py sweeps the thresholds
+    if (const char *e = getenv("PTGPU_GRID_PER_CELL")) per_cell_min = atof(e);
+    if (const char *e = getenv("PTGPU_GRID_SZ")) sz_max = atof(e);
+#endif
+    if (G.occupied < occ_min || G.items_per_cell < per_cell_min || best_sz > sz_max) {
         G = GridPlan{};
         return false;
     }

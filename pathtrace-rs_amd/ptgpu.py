@@ -516,7 +516,7 @@ def debug_cell_grid(desc):
     rec = np.zeros((int(iu[3]), 5, 4), np.uint32)
     large = np.zeros(16, np.uint32)
     _check(lib().pt_debug_cell_grid(C.byref(d), info, rec.ctypes.data_as(C.POINTER(C.c_uint32)), rec.shape[0], large.ctypes.data_as(C.POINTER(C.c_uint32))))
-    return {"n": iu[:3].astype(int), "gmin": fl[8:11].astype(np.float64), "h": fl[11:14].astype(np.float64), "d_build": float(fl[14]), "half_diag": float(fl[15]),
+    return {"n": iu[:3].astype(int), "gmin": fl[8:11].astype(np.float64), "h": fl[11:14].astype(np.float64), "d_build": float(fl[14]), "half_diag": float(fl[15]), "items_per_cell": float(fl[5]), "occupied": float(fl[6]),
             "records": rec, "large": large[:int(iu[4])].astype(int)}
 
 

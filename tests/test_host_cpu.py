@@ -619,7 +619,7 @@ def test_cell_grid_plan_registers_every_sphere_wherever_its_padded_ball_reaches(
             ijk = np.stack(np.meshgrid(np.arange(side), np.arange(layers), np.arange(side)), -1).reshape(-1, 3).astype(np.float64)
         else:
             ijk = np.stack(np.meshgrid(np.arange(150), np.arange(1), np.arange(10)), -1).reshape(-1, 3).astype(np.float64)
-        c = 0.7 * ijk + rng.uniform(0, 0.2, ijk.shape) * [1, 0.5, 1]
+        c = (0.7 if layout == "layers" else 0.6) * ijk + rng.uniform(0, 0.2, ijk.shape) * [1, 0.5, 1]   # (the strip at 0.7 gets cells of three sphere widths: refused since round 6)
         sph = np.concatenate([c, rng.uniform(0.22, 0.3, (len(c), 1))], 1).astype(np.float32)
         sph = np.concatenate([sph, np.array([[0, -1000.5, 0, 1000.0], [3, 4, 3, 2.5]], np.float32)])   # a ground and a big sphere: outside the grid
         desc = ptgpu.SceneDesc(sph, np.zeros(len(sph), np.uint32), [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0)], [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)])
@@ -663,6 +663,24 @@ def test_cell_grid_plan_registers_every_sphere_wherever_its_padded_ball_reaches(
     with pytest.raises(ptgpu.PtError) as e:
         ptgpu.debug_cell_grid(ptgpu.SceneDesc(cloud, np.zeros(3000, np.uint32), [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0)], [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)]))
     assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED and "no cell grid" in str(e.value)
+
+
+def test_cell_grid_planner_admits_dense_random_fields_and_refuses_loose_ones(ptgpu):
+    """Which fields get a cell grid (csrc/pt_prep.hip plan_cell_grid; measured with tools/grid_ab.py, NOTES.md "Round 6 -- which fields get a cell
+    grid"): 10 000 spheres of r = 0.2 thrown into a cube of half-width 4 ... 8 (83 % + of the cells occupied, 3.3 ... 5.3 spheres per cell, cells of at
+    most two sphere widths: the walk is 1.1 ... 1.4x the tree) do; the same spheres in a cube of half-width 10 (the cost estimate picks cells of three
+    widths: 0.9x) or 20 (a loose cloud: 0.7x) keep the tree; so does a field of fewer than 1 024 spheres."""
+    def cube(n, half):
+        rng = np.random.default_rng(7)
+        sph = np.concatenate([rng.uniform(-half, half, (n, 3)), np.full((n, 1), 0.2)], 1).astype(np.float32)
+        return ptgpu.SceneDesc(sph, np.zeros(n, np.uint32), [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0)], [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0)])
+    for half in (4.0, 6.0, 8.0):
+        g = ptgpu.debug_cell_grid(cube(10000, half))
+        assert g["occupied"] >= 0.83 and g["items_per_cell"] >= 2.5 and g["h"][0] <= 2.0 * 2.0 * 0.2 * 1.1, (half, g["occupied"], g["items_per_cell"], g["h"])
+    for n, half in ((10000, 10.0), (10000, 20.0), (1000, 2.0)):
+        with pytest.raises(ptgpu.PtError) as e:
+            ptgpu.debug_cell_grid(cube(n, half))
+        assert e.value.code == ptgpu.PT_ERR_UNSUPPORTED
 
 
 def test_committed_kernel_resource_table_keeps_registers_and_spills_within_the_stated_bounds():

@@ -1,5 +1,5 @@
-"""Soak of the uniform cell grid (csrc/pt_grid.h) on the GPU box: seeded dense sphere fields -- jittered 2D lattices, layers, 3D packings, radii
-within a band, a ground and a few big spheres beside them, cameras inside, near, far and very far -- rendered by the default kernel (which must be
+"""Soak of the uniform cell grid (csrc/pt_grid.h) on the GPU box: seeded dense sphere fields -- jittered 2D lattices, layers, 3D packings, from seed
+100 000 on also RANDOM fields (filled cubes and thick layers: cells with no sphere, cells with a dozen), radii within a band, a ground and a few big spheres beside them, cameras inside, near, far and very far -- rendered by the default kernel (which must be
 the grid walk for most of them) and by the exact VALU scan (tuning 4 | 64: the reference's semantics), which must agree bit for bit in every pixel
 and in the ray count. Usage: python tools/grid_soak.py [first_seed] [count]"""
 import importlib
@@ -21,7 +21,15 @@ def field(seed):
     kind = int(rng.integers(0, 4))
     pitch = float(rng.uniform(0.3, 1.5))
     r0 = pitch * float(rng.uniform(0.32, 0.48))
-    if kind == 0:      # one layer, like BASELINE config 5
+    cloudy = seed >= 100000 and np.random.default_rng([seed, 1]).random() < 0.4   # (seeds below 100 000 keep the fields they always had)
+    if cloudy:         # round 6: RANDOM fields dense enough for the planner (83 % + of the cells occupied): a filled cube, or a layer a few spheres thick
+        n_c = int(rng.integers(1500, 7000))
+        if rng.random() < 0.6:
+            c = rng.uniform(-1, 1, (n_c, 3)) * r0 * n_c ** (1.0 / 3.0) * float(rng.uniform(0.85, 1.9))
+        else:
+            c = rng.uniform(-1, 1, (n_c, 3)) * r0 * n_c ** 0.5 * float(rng.uniform(0.65, 1.0))
+            c[:, 1] = rng.uniform(0.0, float(rng.uniform(1.0, 4.0)) * r0, n_c)
+    elif kind == 0:      # one layer, like BASELINE config 5
         side = int(rng.integers(33, 60))
         ij = np.stack(np.meshgrid(np.arange(side), np.arange(side)), -1).reshape(-1, 2)
         c = np.stack([pitch * ij[:, 0], np.full(len(ij), r0), pitch * ij[:, 1]], 1)
