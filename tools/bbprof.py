@@ -312,6 +312,12 @@ def report(argv):
             top = sorted(b["lines"].items(), key=lambda kv: -kv[1])[:4]
             print("   %5.2f%%  %-11s runs %.3g x %d of valu %d  %s" % (100.0 * dl / max(tot["lanes"], 1), b["label"], n, b["lanes"], b["valu"],
                                                                   " ".join("%s(%d)" % (a.replace("pt_kernel.h", "k").replace("pt_device.h", "d").replace("pt_coop.h", "c"), c) for a, c in top)))
+        print("   -- blocks by dynamic v_mov_b32 / v_accvgpr moves (register shuffling the allocator added)")
+        for dm, n, b in sorted(((r[1] * r[2].get("movs", 0), r[1], r[2]) for r in rows[k]), key=lambda r: -r[0])[:25]:
+            if not dm: break
+            top = sorted(b["lines"].items(), key=lambda kv: -kv[1])[:4]
+            print("   %5.2f%%  %-11s runs %.3g x %d of valu %d  %s" % (100.0 * dm / max(tot["movs"], 1), b["label"], n, b["movs"], b["valu"],
+                                                                  " ".join("%s(%d)" % (a.replace("pt_kernel.h", "k").replace("pt_device.h", "d").replace("pt_coop.h", "c"), c) for a, c in top)))
         print("   -- source lines by dynamic VALU (innermost inlined location)")
         for ln, c in lines[k].most_common(60):
             print("   %5.2f%%  %s" % (100.0 * c / tot["valu"], ln))
