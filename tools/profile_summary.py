@@ -40,15 +40,24 @@ def find(pattern):
 
 # bench frames under the profiler (steps + warm-up) -- the frame kernel is dispatched once per frame, or TWICE for general
 # worlds (their two launches of a new view share one symbol), plus pt_scene_prepare's throw-away frame before them
-n_frames = None
-_bl = os.path.join(src, "bench_line.json")
-if os.path.exists(_bl) and os.path.getsize(_bl):
-    _l = json.load(open(_bl))
-    n_frames = int(_l.get("steps", 0)) + int(_l.get("warmup", 0))
+def frames_of(name):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f):
+        l = json.load(open(f))
+        return int(l.get("steps", 0)) + int(l.get("warmup", 0)), int(l.get("steps", 0))
+    return None, None
 
 
-def bench_groups(items):
+n_frames_t, n_steps_t = frames_of("bench_line.json")          # the timing pass (--kernel-trace --stats)
+n_frames_p, _ = frames_of("bench_line_pmc.json")              # the counter passes (fewer frames: counters per launch do not depend on clocks)
+if n_frames_p is None:
+    n_frames_p = n_frames_t
+n_frames = n_frames_p
+
+
+def bench_groups(items, n_frames=None):
     """items: the frame kernel's dispatches in order. Returns them grouped per bench frame (prepare's dispatches dropped)."""
+    n_frames = n_frames or n_frames_p
     if not n_frames or len(items) < n_frames:
         return [[x] for x in items[1:]] if len(items) > 1 else [[x] for x in items]
     k = max(1, len(items) // (n_frames + 1)) if len(items) > n_frames else 1
@@ -59,7 +68,7 @@ def bench_groups(items):
 # 1. kernel stats
 ks = find("stats/**/*kernel_stats.csv")
 kt = find("stats/**/*kernel_trace.csv")
-lines.append("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
+lines.append("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps %s --warmup %s --no-cpu-baseline" % (n_steps_t, (n_frames_t or 0) - (n_steps_t or 0)))
 avg_ms = None
 if ks:
     for r in csv.DictReader(open(ks)):
@@ -74,10 +83,11 @@ if kt:
     if len(durs) > 1:
         # pt_scene_prepare's throw-away frame (part of Scene::new) comes first and is not a bench step; a bench frame of a
         # general world is two dispatches of this symbol (first sample of every pixel, then the rest): summed per frame
-        groups = bench_groups(durs)
-        avg_ms = sum(sum(g) for g in groups) / len(groups)
-        lines.append("frame kernel, average over the %d bench frames (%d dispatch(es) each; pt_scene_prepare excluded): %.3f ms" % (
-            len(groups), len(groups[0]), avg_ms))
+        groups = bench_groups(durs, n_frames_t)
+        timed = groups[-n_steps_t:] if n_steps_t and len(groups) >= n_steps_t else groups   # the frames bench.py times (its warm-up frames dropped)
+        avg_ms = sum(sum(g) for g in timed) / len(timed)
+        lines.append("frame kernel, average over the %d TIMED bench frames (%d dispatch(es) each; pt_scene_prepare's frame and the %d warm-up frames excluded): %.3f ms" % (
+            len(timed), len(timed[0]), len(groups) - len(timed), avg_ms))
     rows = [r for r in csv.DictReader(open(kt)) if is_frame_kernel(r["Kernel_Name"])]
     if rows:
         r = rows[-1]
