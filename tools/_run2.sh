@@ -1,10 +1,13 @@
-run() { python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras --no-pipeline "$@" 2>/dev/null | python -c "
-import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('   %.1f Mrays/s  %.3f ms/step  kernel %.3f ms rays %d' % (d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['config']['rays_per_step']))"; }
-for rep in 1 2; do for b in _build _build_b5 _build_b6; do export PTGPU_BUILD_DIR=$b
-echo "$b c5"; run --preset perlin_spheres --bvh --width 1920 --height 1080 --samples 128
-done; done
-for b in _build _build_b5 _build_b6; do export PTGPU_BUILD_DIR=$b
-echo "$b two_perlin"; run --preset two_perlin_spheres --steps 10
-done
+bash tools/gpu_suite.sh 2>&1 | tail -3
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
+python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_final.json
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_final.json'))
+r=d['roofline']
+print('value', d['value'], 'ms', d['ms_per_step'], 'build', d['build'])
+print('frac', r.get('frac'), 'frac_useful', r.get('frac_useful'), 'stale', r.get('stale_counters'), 'kernel_ms', r['kernel_ms'], 'traffic', r['traffic'])
+print('cpu', d['cpu_baseline']['value'], d['cpu_baseline']['cores'])
+for k,v in d['baseline_configs'].items(): print(k, v['value'], v['roofline'].get('frac'), v['roofline'].get('frac_useful'))
+for k,v in d['other_workloads_same_frame_size'].items(): print(k, v['value'])
+PY
