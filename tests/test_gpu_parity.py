@@ -470,6 +470,53 @@ def test_config5_full_frame_cell_grid_equals_the_tree_kernel_tile_by_tile(ptgpu,
     assert 0 < abs(frames[(False, 0)][0] - frames[(True, 0)][0]) < 100
 
 
+@pytest.mark.parametrize("half,rlo,rhi,bvh", [(5.0, 0.1, 0.3, False), (6.0, 0.2, 0.2, True)])
+def test_dense_random_cube_cell_grid_equals_the_tree_and_the_exact_scan(ptgpu, half, rlo, rhi, bvh):
+    """The class the planner of round 6 newly admits (csrc/pt_prep.hip plan_cell_grid; tools/grid_ab.py): 10 000 spheres THROWN into a cube -- 85-89 % of the
+    cells occupied, cells without a sphere beside chains of three records, Lambertian / Metal / Dielectric, a huge ground -- at 1200 x 800 x 16 on the grid
+    walk (default), the grid walk without parked walks (2097152) and the 4-wide tree (524288): the same frame bit for bit and the same ray count in every
+    8x8 tile; and at 240 x 160 x 4 against the exact scan (4 | 64: the reference's semantics; the BVH world: against the binary-tree kernel) as well. List world and a caller's BVH over it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("grid_ab", os.path.join(ROOT, "tools", "grid_ab.py"))
+    ab = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ab)
+    ptgpu = ab.ptgpu   # (the tool's own binding of the same library: its SceneDesc / PtCamera classes are the ones its builders return)
+    desc = ab.cloud(7, n=10000, half=half, rlo=rlo, rhi=rhi)
+    if bvh:
+        spec2 = importlib.util.spec_from_file_location("grid_soak", os.path.join(ROOT, "tools", "grid_soak.py"))
+        gs = importlib.util.module_from_spec(spec2)
+        spec2.loader.exec_module(gs)
+        nodes, root = gs.bvh_over(desc.spheres, np.random.default_rng(5))
+        tex = [(ptgpu.TEX_CONSTANT, (0.5, 0.5, 0.5), -1, -1, 0.0), (ptgpu.TEX_CONSTANT, (0.8, 0.3, 0.3), -1, -1, 0.0)]
+        mats = [(ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 0), (ptgpu.MAT_LAMBERTIAN, (0, 0, 0), 0.0, 1), (ptgpu.MAT_METAL, (0.8, 0.8, 0.8), 0.1, -1), (ptgpu.MAT_DIELECTRIC, (0, 0, 0), 1.5, -1)]
+        desc = ptgpu.SceneDesc(desc.spheres, desc.sphere_material, mats, tex, bvh_nodes=nodes, bvh_root=root)
+    sc = ptgpu.Scene(desc, 0)
+    other = (524288 | 2048) if bvh else (4 | 64)   # (a BVH world's flavour is always a tree kernel: its second reference is the BINARY tree without a grid)
+    for W, H, S, variants in ((1200, 800, 16, (0, 2097152, 524288)), (240, 160, 4, (0, 2097152, 524288, other))):
+        cam = ab.camera([1.6 * half, 0.8 * half + 1.0, 1.2 * half], 40.0, W / H)
+        p = ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0)
+        got = {}
+        for v in variants:
+            sc.set_tuning(0, v)
+            out = np.zeros((H, W, 3), np.float32)
+            rays = sc.update(p, cam, 0, out)
+            name = sc.last_kernel_choice()["name"]
+            assert name.startswith("grid<") == (v in (0, 2097152)), (v, name)
+            try:
+                tiles = sc.tile_rays()
+            except ptgpu.PtError:   # (a frame in one launch -- few samples, or the exact scan -- does not count rays per work tile)
+                tiles = None
+            got[v] = (rays, out, tiles)
+        ref_rays, ref, ref_tiles = got[0]
+        assert (ref_tiles is not None) == (S >= 12) and (ref_tiles is None or int(ref_tiles.sum(dtype=np.uint64)) == ref_rays)
+        for v in variants[1:]:
+            rays, out, tiles = got[v]
+            assert rays == ref_rays and np.array_equal(out, ref, equal_nan=True), (W, v, rays, ref_rays, _report(ref, out))
+            if tiles is not None and ref_tiles is not None:
+                assert np.array_equal(tiles, ref_tiles), (W, v, int((tiles != ref_tiles).sum()))
+    sc.close()
+
+
 # ---- full BASELINE sizes: sampled pixels + size-independent properties ----------------------------
 def test_config3_full_size_sampled_against_oracle(ptgpu, pthost, oracle):
     """random_spheres 1200x800 64 spp (the metric's configuration): every 811th pixel vs the oracle."""

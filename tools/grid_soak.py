@@ -1,6 +1,6 @@
 """Soak of the uniform cell grid (csrc/pt_grid.h) on the GPU box: seeded dense sphere fields -- jittered 2D lattices, layers, 3D packings, from seed
 100 000 on also RANDOM fields (filled cubes and thick layers: cells with no sphere, cells with a dozen), radii within a band, a ground and a few big spheres beside them, cameras inside, near, far and very far -- rendered by the default kernel (which must be
-the grid walk for most of them) and by the exact VALU scan (tuning 4 | 64: the reference's semantics), which must agree bit for bit in every pixel
+the grid walk for most of them) and by the exact VALU scan (tuning 4 | 64: the reference's semantics; BVH worlds: by the binary-tree kernel without a grid), which must agree bit for bit in every pixel
 and in the ray count. Usage: python tools/grid_soak.py [first_seed] [count]"""
 import importlib
 import os
@@ -107,9 +107,12 @@ def run(first, count):
             desc = ptgpu.SceneDesc(desc.spheres, desc.sphere_material, desc._materials, desc._textures, bvh_nodes=nodes, bvh_root=root)
         sc = ptgpu.Scene(desc, 0)
         p = ptgpu.PtParams(W, H, S, 10, 0, 1 if bvh else 0)
-        sc.set_tuning(0, 4 | 64)
+        # the reference side: a list world on the exact VALU scan; a BVH world (whose flavour is always a tree kernel: 4 | 64 would select the grid walk
+        # again) on the BINARY tree without a grid (524288 | 2048) -- another traversal, the same gates and DFS-rank ties
+        sc.set_tuning(0, (524288 | 2048) if bvh else (4 | 64))
         exact = np.zeros((H, W, 3), np.float32)
         rays_exact = sc.update(p, cam, 0, exact)
+        assert not sc.last_kernel_choice()["name"].startswith("grid<"), sc.last_kernel_choice()["name"]
         sc.set_tuning(0, 0)
         out = np.zeros((H, W, 3), np.float32)
         rays = sc.update(p, cam, 0, out)
