@@ -95,6 +95,9 @@ __device__ __forceinline__ bool coop_hand_over(const KArgs &A, uint32_t worker, 
 // The spheres one lane tests for every ray of every pixel its wave traces: lane l holds list entries l, l + 64, ... (the scan table's
 // (cx, cy, cz, r * r) rows; launch(): at most kCoopChunks * 64 = 512 spheres when this mode is on) -- loaded ONCE per worker, so a ray's scan reads no memory.
 constexpr int kCoopChunks = 8;
+#ifndef PT_COOP_SPH_LDS
+#define PT_COOP_SPH_LDS 0   // 1: a worker reads its spheres from the LDS table for every ray instead of holding them in 32 registers (NOTES.md)
+#endif
 struct CoopSpheres {
     float4 s[kCoopChunks];
 };
@@ -110,7 +113,7 @@ __device__ __forceinline__ void coop_load_spheres(CoopSpheres &mine, const float
 // scene.rs:105-116 for ONE pixel from sample `samples_done` on, all 64 lanes on each ray. Every value below is wave-uniform except
 // inside the scan; `s_shade`: the LDS shading records.
 template <bool MOVING, bool GATED>
-__device__ __forceinline__ void coop_trace_pixel(const KArgs &A, const GateSrc &G, const float4 *mot, const float4 *s_par, const CoopSpheres &mine, const float4 *s_shade,
+__device__ __forceinline__ void coop_trace_pixel(const KArgs &A, const GateSrc &G, const float4 *mot, const float4 *s_par, const CoopSpheres &mine, const float4 *sph, const float4 *s_shade,
                                                  const PerlinLds &pn, const uint64_t *box, unsigned long long &wave_rays) {
     const uint32_t lane = threadIdx.x & 63u;
     Rng rng;
@@ -181,7 +184,11 @@ __device__ __forceinline__ void coop_trace_pixel(const KArgs &A, const GateSrc &
             };
             auto disc_of = [&](int j, float &b) -> float {
                 const uint32_t k = 64u * (uint32_t)j + lane;
+#if PT_COOP_SPH_LDS
+                const float4 c = sphere_at_m<MOVING>(mot, (int)(k < n ? k : n - 1u), k < n ? sph[k] : make_float4(3.0e38f, 3.0e38f, 3.0e38f, 0.0f), rtime);   // (read from the LDS table per ray: 32 registers fewer)
+#else
                 const float4 c = sphere_at_m<MOVING>(mot, (int)(k < n ? k : n - 1u), mine.s[j], rtime);
+#endif
                 const float ocx = o.x - c.x, ocy = o.y - c.y, ocz = o.z - c.z;
                 b = (ocx * d.x + ocy * d.y) + ocz * d.z;
                 const float cc = ((ocx * ocx + ocy * ocy) + ocz * ocz) - c.w;
@@ -399,7 +406,7 @@ __device__ __forceinline__ void coop_worker(const KArgs &A, const GateSrc &G, co
         // told here: relaxed atomics to different addresses are otherwise only held back by the branch above, which it need not honour.
         asm volatile("" ::: "memory");
         if (!loaded) coop_load_spheres(mine, sph, A.n_spheres), loaded = true;
-        coop_trace_pixel<MOVING, GATED>(A, G, mot, s_par, mine, s_shade, pn, box, wave_rays);
+        coop_trace_pixel<MOVING, GATED>(A, G, mot, s_par, mine, sph, s_shade, pn, box, wave_rays);
     }
 }
 
